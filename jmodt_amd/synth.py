@@ -1,0 +1,90 @@
+"""Seeded synthetic KITTI-shaped inputs.  Shared by tests, golden generation,
+smoke() and bench.py so every consumer sees the same bytes for a given (seed, shape)."""
+import numpy as np
+
+
+def cloud(B, N, seed, dup_frac=0.0, quantize=None):
+    """uniform in the KITTI crop x[-40,40] y[-1,3] z[0,70.4] (config.py:34-36).
+    dup_frac: fraction of points overwritten by copies of other points (kitti_dataset.py:243-247
+    pads short clouds by re-sampling, so exact duplicates are normal input).
+    quantize: snap coordinates to multiples of `quantize` (power of two) so squared distances are
+    exact in float32 under any FMA contraction."""
+    rng = np.random.default_rng(seed)
+    lo = np.array([-40.0, -1.0, 0.0], dtype=np.float32)
+    hi = np.array([40.0, 3.0, 70.4], dtype=np.float32)
+    pts = (rng.random((B, N, 3), dtype=np.float32) * (hi - lo) + lo).astype(np.float32)
+    if quantize:
+        pts = (np.round(pts / quantize) * quantize).astype(np.float32)
+    if dup_frac > 0:
+        nd = int(N * dup_frac)
+        for b in range(B):
+            dst = rng.choice(N, nd, replace=False)
+            src = rng.integers(0, N, nd)
+            pts[b, dst] = pts[b, src]
+    return pts
+
+
+def dense_cloud(B, N, seed, extent=4.0):
+    """small-extent cloud so balls contain many points (exercises the >nsample truncation)."""
+    rng = np.random.default_rng(seed)
+    return (rng.random((B, N, 3), dtype=np.float32) * np.float32(extent)).astype(np.float32)
+
+
+def proposals(pts, M, seed):
+    """M boxes per frame centred on random cloud points: (h,w,l)=(1.526,1.629,3.883)*U(.9,1.1)
+    (config.py:38), ry~U(-pi,pi), y = box bottom."""
+    rng = np.random.default_rng(seed)
+    B, N, _ = pts.shape
+    boxes = np.zeros((B, M, 7), dtype=np.float32)
+    for b in range(B):
+        c = pts[b, rng.integers(0, N, M)]
+        hwl = np.array([1.526, 1.629, 3.883], dtype=np.float32) * rng.uniform(0.9, 1.1, (M, 3)).astype(np.float32)
+        boxes[b, :, 0] = c[:, 0]
+        boxes[b, :, 1] = c[:, 1] + hwl[:, 0] / 2
+        boxes[b, :, 2] = c[:, 2]
+        boxes[b, :, 3:6] = hwl
+        boxes[b, :, 6] = rng.uniform(-np.pi, np.pi, M).astype(np.float32)
+    return boxes
+
+
+def bev_boxes(n, seed, extent=40.0, jitter_clusters=True):
+    """n BEV boxes [x1,y1,x2,y2,ry] + distinct scores; clustered so NMS has work to do."""
+    rng = np.random.default_rng(seed)
+    nc = max(1, n // 12)
+    centres = rng.uniform(-extent, extent, (nc, 2)).astype(np.float32)
+    which = rng.integers(0, nc, n)
+    c = centres[which] + (rng.normal(0, 0.6, (n, 2)).astype(np.float32) if jitter_clusters else 0)
+    l = rng.uniform(3.4, 4.4, n).astype(np.float32)
+    w = rng.uniform(1.4, 1.9, n).astype(np.float32)
+    ry = rng.uniform(-np.pi, np.pi, n).astype(np.float32)
+    boxes = np.stack([c[:, 0] - l / 2, c[:, 1] - w / 2, c[:, 0] + l / 2, c[:, 1] + w / 2, ry], 1).astype(np.float32)
+    scores = rng.permutation(n).astype(np.float32) / np.float32(n)  # all distinct
+    return boxes, scores
+
+
+def pts_xy(pts, W=1280, H=384):
+    """project with a fixed KITTI-like pinhole and normalise to [-1,1] (kitti_dataset.py:254-255)"""
+    fu = fv = 721.5
+    cu, cv = 609.6, 172.9
+    z = np.maximum(pts[..., 2], 0.5)
+    u = fu * pts[..., 0] / z + cu
+    v = fv * pts[..., 1] / z + cv
+    xy = np.stack([u / (W - 1.0) * 2 - 1, v / (H - 1.0) * 2 - 1], -1)
+    return xy.astype(np.float32)
+
+
+def roi_features(P, C, seed):
+    rng = np.random.default_rng(seed)
+    return np.maximum(rng.normal(0, 1, (P, C)).astype(np.float32), 0)
+
+
+def mlp_weights(C, H1, H2, seed, scale=None):
+    """(W1,b1,W2,b2,w3,b3) xavier-normal like rcnn.py:116-134, non-zero biases to exercise them"""
+    rng = np.random.default_rng(seed)
+    W1 = rng.normal(0, np.sqrt(2.0 / (C + H1)), (H1, C)).astype(np.float32)
+    W2 = rng.normal(0, np.sqrt(2.0 / (H1 + H2)), (H2, H1)).astype(np.float32)
+    w3 = rng.normal(0, np.sqrt(2.0 / (H2 + 1)), (H2,)).astype(np.float32)
+    b1 = rng.normal(0, 0.05, H1).astype(np.float32)
+    b2 = rng.normal(0, 0.05, H2).astype(np.float32)
+    b3 = np.float32(rng.normal(0, 0.05))
+    return W1, b1, W2, b2, w3, b3

@@ -1,0 +1,715 @@
+/*
+ * jmodt_oracle.c — CPU restatement of the JMODT detection+association hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it (as the checker / reported CPU baseline).  The
+ * product path (jmodt_amd/) never imports, links or calls anything in oracle/.
+ *
+ * Every function restates the algorithm of one reference kernel and cites it
+ * (paths relative to /root/reference).  Pinning status:
+ *   - roipool3d / pts_in_boxes3d : checked against the reference's own CPU code compiled from
+ *     jmodt/ops/roipool3d/src/roipool3d.cpp (oracle/_ref, tests/test_oracle_vs_reference.py).
+ *   - affinity head, feature_gather, boxes3d_to_bev/enlarge_box3d, 3D-IoU torch math : checked
+ *     against the reference's importable Python / torch ops (tests/golden/make_golden.py).
+ *   - FPS, ball_query, group/gather, three_nn, three_interpolate, BEV overlap, NMS : the
+ *     reference has NO CPU code and NO tests for these ("parity unpinned" by the reference);
+ *     pinned here against independent brute-force numpy restatements + analytic cases.
+ *
+ * Floating-point conventions (build: gcc -O2 -ffp-contract=off):
+ *   - squared distance in FPS / ball_query / three_nn uses the contraction nvcc/clang apply to
+ *     `dx*dx + dy*dy + dz*dz` under their default -fmad / -ffp-contract=fast:
+ *         d = fmaf(dz, dz, fmaf(dx, dx, dy*dy))
+ *     written explicitly with fmaf so the result does not depend on compiler flags.
+ *   - three_interpolate: fmaf(w2,p2, fmaf(w0,p0, w1*p1)) (same rule).
+ *   - box geometry (roipool3d, iou3d): no contraction; sin/cos/atan2 through
+ *     include/jm_detmath.h (deterministic, within 1 ulp of libm).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/jm_detmath.h"
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * pointnet2 : sampling
+ * ---------------------------------------------------------------------------------------- */
+
+/* jmodt/ops/pointnet2/src/cuda_utils.h:10-14 (opt_n_threads) */
+ORC_API int orc_opt_n_threads(int work_size) {
+    const int pow_2 = (int)(log((double)work_size) / log(2.0));
+    int v = 1 << pow_2;
+    if (v > 1024) v = 1024;
+    if (v < 1) v = 1;
+    return v;
+}
+
+static inline float orc_sqdist(float x1, float y1, float z1, float x2, float y2, float z2) {
+    const float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+    return fmaf(dz, dz, fmaf(dx, dx, dy * dy));
+}
+
+/* Literal simulation of farthest_point_sampling_kernel<BS>
+ * (jmodt/ops/pointnet2/src/sampling_gpu.cu:93-209): BS "threads" with strided ownership
+ * k = tid, tid+BS, ..., strict `>` running best, then the BS/2..1 tree whose ties keep the
+ * lower slot (`__update`, :86-91).  temp must be pre-filled by the caller (1e10,
+ * pointnet2_utils.py:26) and is updated in place like the kernel does. */
+ORC_API void orc_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp, int* idxs) {
+    if (m <= 0) return;
+    const int bs = orc_opt_n_threads(n);
+#pragma omp parallel for schedule(static)
+    for (int bi = 0; bi < b; ++bi) {
+        const float* ds = dataset + (size_t)bi * n * 3;
+        float* tp = temp + (size_t)bi * n;
+        int* out = idxs + (size_t)bi * m;
+        float* dists = (float*)malloc(sizeof(float) * bs);
+        int* dists_i = (int*)malloc(sizeof(int) * bs);
+        int old = 0;
+        out[0] = old;
+        for (int j = 1; j < m; ++j) {
+            const float x1 = ds[old * 3 + 0], y1 = ds[old * 3 + 1], z1 = ds[old * 3 + 2];
+            for (int tid = 0; tid < bs; ++tid) {
+                int besti = 0;
+                float best = -1.f;
+                for (int k = tid; k < n; k += bs) {
+                    const float d = orc_sqdist(x1, y1, z1, ds[k * 3 + 0], ds[k * 3 + 1], ds[k * 3 + 2]);
+                    const float d2 = d < tp[k] ? d : tp[k]; /* CUDA min(d, temp[k]) */
+                    tp[k] = d2;
+                    besti = d2 > best ? k : besti;
+                    best = d2 > best ? d2 : best;
+                }
+                dists[tid] = best;
+                dists_i[tid] = besti;
+            }
+            for (int s = bs / 2; s >= 1; s >>= 1) {
+                for (int tid = 0; tid < s; ++tid) {
+                    const float v1 = dists[tid], v2 = dists[tid + s];
+                    const int i1 = dists_i[tid], i2 = dists_i[tid + s];
+                    dists[tid] = v1 > v2 ? v1 : v2; /* max(v1, v2) */
+                    dists_i[tid] = v2 > v1 ? i2 : i1;
+                }
+            }
+            old = dists_i[0];
+            out[j] = old;
+        }
+        free(dists);
+        free(dists_i);
+    }
+}
+
+/* gather_points_kernel_fast (sampling_gpu.cu:8-24): out[b,c,j] = points[b,c,idx[b,j]] */
+ORC_API void orc_gather_points(int b, int c, int n, int m, const float* points, const int* idx, float* out) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int bi = 0; bi < b; ++bi)
+        for (int ci = 0; ci < c; ++ci)
+            for (int j = 0; j < m; ++j)
+                out[((size_t)bi * c + ci) * m + j] = points[((size_t)bi * c + ci) * n + idx[(size_t)bi * m + j]];
+}
+
+/* gather_points_grad_kernel_fast (sampling_gpu.cu:46-63): scatter-add into pre-zeroed grad_points */
+ORC_API void orc_gather_points_grad(int b, int c, int n, int m, const float* grad_out, const int* idx,
+                                    float* grad_points) {
+    for (int bi = 0; bi < b; ++bi)
+        for (int ci = 0; ci < c; ++ci)
+            for (int j = 0; j < m; ++j)
+                grad_points[((size_t)bi * c + ci) * n + idx[(size_t)bi * m + j]] +=
+                    grad_out[((size_t)bi * c + ci) * m + j];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * pointnet2 : ball query / grouping
+ * ---------------------------------------------------------------------------------------- */
+
+/* ball_query_kernel_fast (ball_query_gpu.cu:9-45).  idx is (B,M,nsample), pre-zeroed by the
+ * caller (pointnet2_utils.py:218); slots of centres with no hit are left untouched. */
+ORC_API void orc_ball_query(int b, int n, int m, float radius, int nsample, const float* new_xyz,
+                            const float* xyz, int* idx) {
+    const float radius2 = radius * radius;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int bi = 0; bi < b; ++bi) {
+        for (int pi = 0; pi < m; ++pi) {
+            const float* c = new_xyz + ((size_t)bi * m + pi) * 3;
+            const float* p = xyz + (size_t)bi * n * 3;
+            int* o = idx + ((size_t)bi * m + pi) * nsample;
+            const float nx = c[0], ny = c[1], nz = c[2];
+            int cnt = 0;
+            for (int k = 0; k < n; ++k) {
+                /* (new_x - x)^2 + ... : sign differs from FPS but squares are identical */
+                const float dx = nx - p[k * 3 + 0], dy = ny - p[k * 3 + 1], dz = nz - p[k * 3 + 2];
+                const float d2 = fmaf(dz, dz, fmaf(dx, dx, dy * dy));
+                if (d2 < radius2) {
+                    if (cnt == 0)
+                        for (int l = 0; l < nsample; ++l) o[l] = k;
+                    o[cnt] = k;
+                    ++cnt;
+                    if (cnt >= nsample) break;
+                }
+            }
+        }
+    }
+}
+
+/* group_points_kernel_fast (group_points_gpu.cu:47-66): out[b,c,p,s] = points[b,c,idx[b,p,s]] */
+ORC_API void orc_group_points(int b, int c, int n, int npoints, int nsample, const float* points,
+                              const int* idx, float* out) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int bi = 0; bi < b; ++bi)
+        for (int ci = 0; ci < c; ++ci) {
+            const float* src = points + ((size_t)bi * c + ci) * n;
+            const int* ix = idx + (size_t)bi * npoints * nsample;
+            float* dst = out + ((size_t)bi * c + ci) * npoints * nsample;
+            for (int q = 0; q < npoints * nsample; ++q) dst[q] = src[ix[q]];
+        }
+}
+
+/* group_points_grad_kernel_fast (group_points_gpu.cu:8-25) */
+ORC_API void orc_group_points_grad(int b, int c, int n, int npoints, int nsample, const float* grad_out,
+                                   const int* idx, float* grad_points) {
+    for (int bi = 0; bi < b; ++bi)
+        for (int ci = 0; ci < c; ++ci) {
+            float* dst = grad_points + ((size_t)bi * c + ci) * n;
+            const int* ix = idx + (size_t)bi * npoints * nsample;
+            const float* src = grad_out + ((size_t)bi * c + ci) * npoints * nsample;
+            for (int q = 0; q < npoints * nsample; ++q) dst[ix[q]] += src[q];
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * pointnet2 : three_nn / three_interpolate
+ * ---------------------------------------------------------------------------------------- */
+
+/* three_nn_kernel_fast (interpolate_gpu.cu:9-52): double bests initialised 1e40, float d
+ * promoted for strict `<`; outputs cast back to float (1e40 -> +inf when m < 3). */
+ORC_API void orc_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2,
+                          int* idx) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int bi = 0; bi < b; ++bi)
+        for (int pi = 0; pi < n; ++pi) {
+            const float* u = unknown + ((size_t)bi * n + pi) * 3;
+            const float* kn = known + (size_t)bi * m * 3;
+            const float ux = u[0], uy = u[1], uz = u[2];
+            double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+            int besti1 = 0, besti2 = 0, besti3 = 0;
+            for (int k = 0; k < m; ++k) {
+                const float dx = ux - kn[k * 3 + 0], dy = uy - kn[k * 3 + 1], dz = uz - kn[k * 3 + 2];
+                const float d = fmaf(dz, dz, fmaf(dx, dx, dy * dy));
+                if (d < best1) {
+                    best3 = best2; besti3 = besti2;
+                    best2 = best1; besti2 = besti1;
+                    best1 = d; besti1 = k;
+                } else if (d < best2) {
+                    best3 = best2; besti3 = besti2;
+                    best2 = d; besti2 = k;
+                } else if (d < best3) {
+                    best3 = d; besti3 = k;
+                }
+            }
+            float* d2o = dist2 + ((size_t)bi * n + pi) * 3;
+            int* io = idx + ((size_t)bi * n + pi) * 3;
+            d2o[0] = (float)best1; d2o[1] = (float)best2; d2o[2] = (float)best3;
+            io[0] = besti1; io[1] = besti2; io[2] = besti3;
+        }
+}
+
+/* three_interpolate_kernel_fast (interpolate_gpu.cu:77-97) */
+ORC_API void orc_three_interpolate(int b, int c, int m, int n, const float* points, const int* idx,
+                                   const float* weight, float* out) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int bi = 0; bi < b; ++bi)
+        for (int ci = 0; ci < c; ++ci) {
+            const float* src = points + ((size_t)bi * c + ci) * m;
+            float* dst = out + ((size_t)bi * c + ci) * n;
+            for (int pi = 0; pi < n; ++pi) {
+                const int* ix = idx + ((size_t)bi * n + pi) * 3;
+                const float* w = weight + ((size_t)bi * n + pi) * 3;
+                dst[pi] = fmaf(w[2], src[ix[2]], fmaf(w[0], src[ix[0]], w[1] * src[ix[1]]));
+            }
+        }
+}
+
+/* three_interpolate_grad_kernel_fast (interpolate_gpu.cu:120-142) */
+ORC_API void orc_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out, const int* idx,
+                                        const float* weight, float* grad_points) {
+    for (int bi = 0; bi < b; ++bi)
+        for (int ci = 0; ci < c; ++ci) {
+            const float* g = grad_out + ((size_t)bi * c + ci) * n;
+            float* dst = grad_points + ((size_t)bi * c + ci) * m;
+            for (int pi = 0; pi < n; ++pi) {
+                const int* ix = idx + ((size_t)bi * n + pi) * 3;
+                const float* w = weight + ((size_t)bi * n + pi) * 3;
+                dst[ix[0]] += g[pi] * w[0];
+                dst[ix[1]] += g[pi] * w[1];
+                dst[ix[2]] += g[pi] * w[2];
+            }
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * roipool3d
+ * ---------------------------------------------------------------------------------------- */
+
+/* pt_in_box3d (roipool3d_kernel.cu:14-28) == pt_in_box3d_cpu (roipool3d.cpp:82-95).
+ * Mixed float/double arithmetic kept literally: `h / 2.0` etc. are double expressions. */
+static inline int orc_pt_in_box3d(float x, float y, float z, float cx, float bottom_y, float cz, float h,
+                                  float w, float l, float cosa, float sina) {
+    const float max_dis = 10.0f;
+    const float cy = (float)(bottom_y - h / 2.0);
+    if ((fabsf(x - cx) > max_dis) || (fabsf(y - cy) > h / 2.0) || (fabsf(z - cz) > max_dis)) return 0;
+    const float x_rot = (x - cx) * cosa + (z - cz) * (-sina);
+    const float z_rot = (x - cx) * sina + (z - cz) * cosa;
+    return (x_rot >= -l / 2.0) & (x_rot <= l / 2.0) & (z_rot >= -w / 2.0) & (z_rot <= w / 2.0);
+}
+
+/* roipool3dLauncher = assign_pts_to_box3d + get_pooled_idx + roipool3d_forward
+ * (roipool3d_kernel.cu:97-237).  boxes3d are the ALREADY ENLARGED boxes
+ * (roipool3d_utils.py:20).  pooled_features (B,M,S,3+C) and pooled_empty_flag (B,M) are
+ * pre-zeroed by the caller; rows of empty boxes are left untouched.  Also returns the
+ * compacted point indices in pts_idx (B,M,S) when non-NULL (internal temp of the reference,
+ * exposed for index-level parity checks). */
+ORC_API void orc_roipool3d(int B, int N, int M, int C, int S, const float* xyz, const float* boxes3d,
+                           const float* pts_feature, float* pooled_features, int* pooled_empty_flag,
+                           int* pts_idx_out) {
+#pragma omp parallel for collapse(2) schedule(dynamic, 4)
+    for (int bi = 0; bi < B; ++bi)
+        for (int mi = 0; mi < M; ++mi) {
+            const float* bx = boxes3d + ((size_t)bi * M + mi) * 7;
+            const float* p = xyz + (size_t)bi * N * 3;
+            float sina, cosa;
+            jm_sincosf(bx[6], &sina, &cosa);
+            int* idx = (int*)malloc(sizeof(int) * (S > 0 ? S : 1));
+            int cnt = 0;
+            for (int k = 0; k < N; ++k) {
+                if (orc_pt_in_box3d(p[k * 3], p[k * 3 + 1], p[k * 3 + 2], bx[0], bx[1], bx[2], bx[3], bx[4],
+                                    bx[5], cosa, sina)) {
+                    if (cnt < S) idx[cnt++] = k;
+                    else break;
+                }
+            }
+            if (cnt == 0) {
+                pooled_empty_flag[(size_t)bi * M + mi] = 1;
+                if (pts_idx_out)
+                    for (int s = 0; s < S; ++s) pts_idx_out[((size_t)bi * M + mi) * S + s] = -1;
+            } else {
+                for (int k = cnt; k < S; ++k) idx[k] = idx[k % cnt];
+                float* dst = pooled_features + ((size_t)bi * M + mi) * S * (3 + C);
+                for (int s = 0; s < S; ++s) {
+                    const int src = idx[s];
+                    float* row = dst + (size_t)s * (3 + C);
+                    row[0] = p[src * 3]; row[1] = p[src * 3 + 1]; row[2] = p[src * 3 + 2];
+                    memcpy(row + 3, pts_feature + ((size_t)bi * N + src) * C, sizeof(float) * C);
+                    if (pts_idx_out) pts_idx_out[((size_t)bi * M + mi) * S + s] = src;
+                }
+            }
+            free(idx);
+        }
+}
+
+/* pts_in_boxes3d_cpu (roipool3d.cpp:97-125): flags (M,N) int64 */
+ORC_API void orc_pts_in_boxes3d(int M, int N, const float* pts, const float* boxes3d, int64_t* flags) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < M; ++i) {
+        const float* bx = boxes3d + (size_t)i * 7;
+        float sina, cosa;
+        jm_sincosf(bx[6], &sina, &cosa);
+        for (int j = 0; j < N; ++j)
+            flags[(size_t)i * N + j] = orc_pt_in_box3d(pts[j * 3], pts[j * 3 + 1], pts[j * 3 + 2], bx[0], bx[1],
+                                                       bx[2], bx[3], bx[4], bx[5], cosa, sina);
+    }
+}
+
+/* roipool3d_cpu (roipool3d.cpp:127-195): un-batched, split xyz / feature outputs, int64 flag.
+ * Outputs pre-zeroed by the caller (roipool3d_utils.py:66-68). */
+ORC_API void orc_roipool3d_cpu(int N, int M, int C, int S, const float* pts, const float* boxes3d,
+                               const float* pts_feature, float* pooled_pts, float* pooled_features,
+                               int64_t* pooled_empty_flag) {
+    memset(pooled_empty_flag, 0, sizeof(int64_t) * M);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int i = 0; i < M; ++i) {
+        const float* bx = boxes3d + (size_t)i * 7;
+        float sina, cosa;
+        jm_sincosf(bx[6], &sina, &cosa);
+        int cnt = 0;
+        for (int j = 0; j < N; ++j) {
+            if (orc_pt_in_box3d(pts[j * 3], pts[j * 3 + 1], pts[j * 3 + 2], bx[0], bx[1], bx[2], bx[3], bx[4],
+                                bx[5], cosa, sina)) {
+                if (cnt < S) {
+                    memcpy(pooled_pts + ((size_t)i * S + cnt) * 3, pts + (size_t)j * 3, sizeof(float) * 3);
+                    memcpy(pooled_features + ((size_t)i * S + cnt) * C, pts_feature + (size_t)j * C,
+                           sizeof(float) * C);
+                    cnt++;
+                } else break;
+            }
+        }
+        if (cnt == 0) {
+            pooled_empty_flag[i] = 1;
+        } else if (cnt < S) {
+            for (int j = cnt; j < S; ++j) {
+                memcpy(pooled_pts + ((size_t)i * S + j) * 3, pooled_pts + ((size_t)i * S + (j % cnt)) * 3,
+                       sizeof(float) * 3);
+                memcpy(pooled_features + ((size_t)i * S + j) * C,
+                       pooled_features + ((size_t)i * S + (j % cnt)) * C, sizeof(float) * C);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * iou3d : rotated BEV overlap / IoU / NMS   (jmodt/ops/iou3d/src/iou3d_kernel.cu)
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct { float x, y; } OrcPt;
+
+static inline float orc_min(float a, float b) { return a < b ? a : b; }
+static inline float orc_max(float a, float b) { return a > b ? a : b; }
+
+/* cross(p1,p2,p0) iou3d_kernel.cu:38-40 */
+static inline float orc_cross3(OrcPt p1, OrcPt p2, OrcPt p0) {
+    return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+}
+/* cross(a,b) iou3d_kernel.cu:34-36 */
+static inline float orc_cross2(OrcPt a, OrcPt b) { return a.x * b.y - a.y * b.x; }
+
+/* check_rect_cross iou3d_kernel.cu:42-48 */
+static inline int orc_check_rect_cross(OrcPt p1, OrcPt p2, OrcPt q1, OrcPt q2) {
+    return orc_min(p1.x, p2.x) <= orc_max(q1.x, q2.x) && orc_min(q1.x, q2.x) <= orc_max(p1.x, p2.x) &&
+           orc_min(p1.y, p2.y) <= orc_max(q1.y, q2.y) && orc_min(q1.y, q2.y) <= orc_max(p1.y, p2.y);
+}
+
+/* check_in_box2d iou3d_kernel.cu:50-65; cos(-a)=cos a, sin(-a)=-sin a exactly */
+static inline int orc_check_in_box2d(const float* box, float box_cos, float box_sin, OrcPt p) {
+    const float MARGIN = 1e-5f;
+    const float center_x = (box[0] + box[2]) / 2;
+    const float center_y = (box[1] + box[3]) / 2;
+    const float angle_cos = box_cos, angle_sin = -box_sin;
+    const float rot_x = (p.x - center_x) * angle_cos + (p.y - center_y) * angle_sin + center_x;
+    const float rot_y = -(p.x - center_x) * angle_sin + (p.y - center_y) * angle_cos + center_y;
+    return (rot_x > box[0] - MARGIN && rot_x < box[2] + MARGIN && rot_y > box[1] - MARGIN &&
+            rot_y < box[3] + MARGIN);
+}
+
+/* intersection iou3d_kernel.cu:67-96 (EPS is the double literal 1e-8) */
+static inline int orc_intersection(OrcPt p1, OrcPt p0, OrcPt q1, OrcPt q0, OrcPt* ans) {
+    if (orc_check_rect_cross(p0, p1, q0, q1) == 0) return 0;
+    const float s1 = orc_cross3(q0, p1, p0);
+    const float s2 = orc_cross3(p1, q1, p0);
+    const float s3 = orc_cross3(p0, q1, q0);
+    const float s4 = orc_cross3(q1, p1, q0);
+    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
+    const float s5 = orc_cross3(q1, p1, p0);
+    if (fabs((double)(s5 - s1)) > 1e-8) {
+        ans->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+        ans->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+    } else {
+        const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+        const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+        const float D = a0 * b1 - a1 * b0;
+        ans->x = (b0 * c1 - b1 * c0) / D;
+        ans->y = (a1 * c0 - a0 * c1) / D;
+    }
+    return 1;
+}
+
+/* rotate_around_center iou3d_kernel.cu:98-102 */
+static inline OrcPt orc_rotate(OrcPt center, float c, float s, OrcPt p) {
+    OrcPt r;
+    r.x = (p.x - center.x) * c + (p.y - center.y) * s + center.x;
+    r.y = -(p.x - center.x) * s + (p.y - center.y) * c + center.y;
+    return r;
+}
+
+/* box_overlap iou3d_kernel.cu:108-212.  The reference sizes cross_points[16]; 24 slots here so a
+ * degenerate pair cannot write out of bounds (same results whenever the reference is defined). */
+static float orc_box_overlap(const float* box_a, const float* box_b) {
+    const float a_x1 = box_a[0], a_y1 = box_a[1], a_x2 = box_a[2], a_y2 = box_a[3], a_angle = box_a[4];
+    const float b_x1 = box_b[0], b_y1 = box_b[1], b_x2 = box_b[2], b_y2 = box_b[3], b_angle = box_b[4];
+    OrcPt center_a = {(a_x1 + a_x2) / 2, (a_y1 + a_y2) / 2};
+    OrcPt center_b = {(b_x1 + b_x2) / 2, (b_y1 + b_y2) / 2};
+    OrcPt ac[5] = {{a_x1, a_y1}, {a_x2, a_y1}, {a_x2, a_y2}, {a_x1, a_y2}, {0, 0}};
+    OrcPt bc[5] = {{b_x1, b_y1}, {b_x2, b_y1}, {b_x2, b_y2}, {b_x1, b_y2}, {0, 0}};
+    float a_cos, a_sin, b_cos, b_sin;
+    jm_sincosf(a_angle, &a_sin, &a_cos);
+    jm_sincosf(b_angle, &b_sin, &b_cos);
+    for (int k = 0; k < 4; k++) {
+        ac[k] = orc_rotate(center_a, a_cos, a_sin, ac[k]);
+        bc[k] = orc_rotate(center_b, b_cos, b_sin, bc[k]);
+    }
+    ac[4] = ac[0];
+    bc[4] = bc[0];
+
+    OrcPt cross_points[24];
+    OrcPt poly_center = {0, 0};
+    int cnt = 0;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            OrcPt ans;
+            if (orc_intersection(ac[i + 1], ac[i], bc[j + 1], bc[j], &ans)) {
+                cross_points[cnt] = ans;
+                poly_center.x = poly_center.x + ans.x;
+                poly_center.y = poly_center.y + ans.y;
+                cnt++;
+            }
+        }
+    for (int k = 0; k < 4; k++) {
+        if (orc_check_in_box2d(box_a, a_cos, a_sin, bc[k])) {
+            poly_center.x = poly_center.x + bc[k].x;
+            poly_center.y = poly_center.y + bc[k].y;
+            cross_points[cnt++] = bc[k];
+        }
+        if (orc_check_in_box2d(box_b, b_cos, b_sin, ac[k])) {
+            poly_center.x = poly_center.x + ac[k].x;
+            poly_center.y = poly_center.y + ac[k].y;
+            cross_points[cnt++] = ac[k];
+        }
+    }
+    if (cnt == 0) return 0.f; /* reference: 0/0 centre, empty loops, area 0 */
+    poly_center.x /= cnt;
+    poly_center.y /= cnt;
+
+    /* bubble sort by atan2 angle, point_cmp iou3d_kernel.cu:104-106,187-196 */
+    float ang[24];
+    for (int i = 0; i < cnt; i++)
+        ang[i] = jm_atan2f(cross_points[i].y - poly_center.y, cross_points[i].x - poly_center.x);
+    for (int j = 0; j < cnt - 1; j++)
+        for (int i = 0; i < cnt - j - 1; i++)
+            if (ang[i] > ang[i + 1]) {
+                OrcPt t = cross_points[i]; cross_points[i] = cross_points[i + 1]; cross_points[i + 1] = t;
+                float ta = ang[i]; ang[i] = ang[i + 1]; ang[i + 1] = ta;
+            }
+
+    float area = 0;
+    for (int k = 0; k < cnt - 1; k++) {
+        OrcPt u = {cross_points[k].x - cross_points[0].x, cross_points[k].y - cross_points[0].y};
+        OrcPt v = {cross_points[k + 1].x - cross_points[0].x, cross_points[k + 1].y - cross_points[0].y};
+        area += orc_cross2(u, v);
+    }
+    return (float)(fabs((double)area) / 2.0);
+}
+
+/* iou_bev iou3d_kernel.cu:214-221; fmaxf(., EPS) with EPS converted to float */
+static inline float orc_iou_bev(const float* a, const float* b) {
+    const float sa = (a[2] - a[0]) * (a[3] - a[1]);
+    const float sb = (b[2] - b[0]) * (b[3] - b[1]);
+    const float s_overlap = orc_box_overlap(a, b);
+    return s_overlap / fmaxf(sa + sb - s_overlap, (float)1e-8);
+}
+
+/* iou_normal iou3d_kernel.cu:295-303 */
+static inline float orc_iou_normal(const float* a, const float* b) {
+    const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+    const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+    const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+    const float interS = width * height;
+    const float Sa = (a[2] - a[0]) * (a[3] - a[1]);
+    const float Sb = (b[2] - b[0]) * (b[3] - b[1]);
+    return interS / fmaxf(Sa + Sb - interS, (float)1e-8);
+}
+
+/* boxes_overlap_kernel iou3d_kernel.cu:223-234 */
+ORC_API void orc_boxes_overlap_bev(int na, const float* boxes_a, int nb, const float* boxes_b, float* out) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) out[(size_t)i * nb + j] = orc_box_overlap(boxes_a + i * 5, boxes_b + j * 5);
+}
+
+/* boxes_iou_bev_kernel iou3d_kernel.cu:236-248 */
+ORC_API void orc_boxes_iou_bev(int na, const float* boxes_a, int nb, const float* boxes_b, float* out) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) out[(size_t)i * nb + j] = orc_iou_bev(boxes_a + i * 5, boxes_b + j * 5);
+}
+
+/* nms_kernel / nms_normal_kernel (iou3d_kernel.cu:250-348): 64x64-tile suppression bitmask,
+ * mask (N, ceil(N/64)) uint64; diagonal tile starts at column threadIdx.x + 1. */
+ORC_API void orc_nms_mask(int n, const float* boxes, float thresh, int normal, uint64_t* mask) {
+    const int col_blocks = (n + 63) / 64;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int i = 0; i < n; ++i) {
+        const int row_start = i / 64, tx = i % 64;
+        for (int cb = 0; cb < col_blocks; ++cb) {
+            const int col_size = (n - cb * 64) < 64 ? (n - cb * 64) : 64;
+            uint64_t t = 0;
+            const int start = (row_start == cb) ? tx + 1 : 0;
+            for (int j = start; j < col_size; ++j) {
+                const float* bj = boxes + (size_t)(cb * 64 + j) * 5;
+                const float v = normal ? orc_iou_normal(boxes + (size_t)i * 5, bj) : orc_iou_bev(boxes + (size_t)i * 5, bj);
+                if (v > thresh) t |= 1ULL << j;
+            }
+            mask[(size_t)i * col_blocks + cb] = t;
+        }
+    }
+}
+
+/* host greedy reduce of nms_gpu / nms_normal_gpu (iou3d.cpp:98-114, 150-161).
+ * boxes are already score-sorted (iou3d_utils.py:65-67).  Returns num_to_keep. */
+ORC_API int orc_nms(int n, const float* boxes, float thresh, int normal, int64_t* keep) {
+    const int col_blocks = (n + 63) / 64;
+    if (n <= 0) return 0;
+    uint64_t* mask = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n * col_blocks);
+    uint64_t* remv = (uint64_t*)calloc(col_blocks, sizeof(uint64_t));
+    orc_nms_mask(n, boxes, thresh, normal, mask);
+    int num_to_keep = 0;
+    for (int i = 0; i < n; i++) {
+        const int nblock = i / 64, inblock = i % 64;
+        if (!(remv[nblock] & (1ULL << inblock))) {
+            keep[num_to_keep++] = i;
+            const uint64_t* p = mask + (size_t)i * col_blocks;
+            for (int j = nblock; j < col_blocks; j++) remv[j] |= p[j];
+        }
+    }
+    free(mask);
+    free(remv);
+    return num_to_keep;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * LI-Fusion point -> image gather  (jmodt/detection/modeling/backbone.py:79-89)
+ *   F.grid_sample(feature_map, xy[B,1,N,2], mode='bilinear', padding_mode='zeros',
+ *                 align_corners=True)
+ * Third-party algorithm: PyTorch (reference env torch 1.9.0, README.md:34; torch 2.10 here)
+ * ATen/native/GridSampler.cpp grid_sampler_2d_cpu_kernel: unnormalise ix = (x+1)/2*(W-1),
+ * corner weights nw=(ix_se-ix)*(iy_se-iy) ..., taps outside the image contribute 0.
+ * feature_map (B,C,H,W) with arbitrary element strides (NCHW or channels-last).
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_feature_gather(int B, int C, int H, int W, int N, const float* fmap, int64_t sb, int64_t sc,
+                                int64_t sh, int64_t sw, const float* xy, float* out) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n) {
+            const float x = xy[((size_t)b * N + n) * 2 + 0], y = xy[((size_t)b * N + n) * 2 + 1];
+            const float ix = ((x + 1.f) / 2) * (W - 1);
+            const float iy = ((y + 1.f) / 2) * (H - 1);
+            const float fx = floorf(ix), fy = floorf(iy);
+            const float ix_nw = fx, iy_nw = fy, ix_ne = fx + 1, iy_ne = fy, ix_sw = fx, iy_sw = fy + 1,
+                        ix_se = fx + 1, iy_se = fy + 1;
+            const float nw = (ix_se - ix) * (iy_se - iy);
+            const float ne = (ix - ix_sw) * (iy_sw - iy);
+            const float sw_ = (ix_ne - ix) * (iy - iy_ne);
+            const float se = (ix - ix_nw) * (iy - iy_nw);
+            const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+            const int in_nw = (x0 >= 0 && x0 < W && y0 >= 0 && y0 < H);
+            const int in_ne = (x1 >= 0 && x1 < W && y0 >= 0 && y0 < H);
+            const int in_sw = (x0 >= 0 && x0 < W && y1 >= 0 && y1 < H);
+            const int in_se = (x1 >= 0 && x1 < W && y1 >= 0 && y1 < H);
+            for (int c = 0; c < C; ++c) {
+                const float* base = fmap + (size_t)b * sb + (size_t)c * sc;
+                float acc = 0.f;
+                if (in_nw) acc += base[(size_t)y0 * sh + (size_t)x0 * sw] * nw;
+                if (in_ne) acc += base[(size_t)y0 * sh + (size_t)x1 * sw] * ne;
+                if (in_sw) acc += base[(size_t)y1 * sh + (size_t)x0 * sw] * sw_;
+                if (in_se) acc += base[(size_t)y1 * sh + (size_t)x1 * sw] * se;
+                out[((size_t)b * C + c) * N + n] = acc;
+            }
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Pairwise link / start-end affinity  (jmodt/tracking/tracker.py:81-112;
+ * jmodt/detection/modeling/rcnn.py:91-111,239-258)
+ *   cor[i,j,:] = |p_i - d_j|;  S = link(cor);  A = (softmax(S,1) + softmax(S,0)) / 2
+ *   start_logit[j] = se(mean_i cor[i,j,:]);  end_logit[i] = se(mean_j cor[i,j,:])
+ * MLP = Conv1d(C,H1)+ReLU -> Conv1d(H1,H2)+ReLU -> Conv1d(H2,1)   (bias, no BN; k=1 convs
+ * are plain matrix-vector products).  Accumulation in double, rounded to float per layer
+ * output: an accuracy reference for the 1e-4 tolerance, not a bit pattern.
+ * ---------------------------------------------------------------------------------------- */
+static float orc_mlp3(const float* x, int C, int H1, int H2, const float* W1, const float* b1, const float* W2,
+                      const float* b2, const float* w3, float b3, float* h1, float* h2) {
+    for (int o = 0; o < H1; ++o) {
+        double acc = b1[o];
+        const float* w = W1 + (size_t)o * C;
+        for (int k = 0; k < C; ++k) acc += (double)w[k] * x[k];
+        h1[o] = acc > 0 ? (float)acc : 0.f;
+    }
+    for (int o = 0; o < H2; ++o) {
+        double acc = b2[o];
+        const float* w = W2 + (size_t)o * H1;
+        for (int k = 0; k < H1; ++k) acc += (double)w[k] * h1[k];
+        h2[o] = acc > 0 ? (float)acc : 0.f;
+    }
+    double acc = b3;
+    for (int k = 0; k < H2; ++k) acc += (double)w3[k] * h2[k];
+    return (float)acc;
+}
+
+/* raw link scores S (P,D) */
+ORC_API void orc_link_scores(int P, int D, int C, int H1, int H2, const float* pf, const float* df,
+                             const float* W1, const float* b1, const float* W2, const float* b2,
+                             const float* w3, float b3, float* S) {
+#pragma omp parallel
+    {
+        float* cor = (float*)malloc(sizeof(float) * C);
+        float* h1 = (float*)malloc(sizeof(float) * H1);
+        float* h2 = (float*)malloc(sizeof(float) * H2);
+#pragma omp for collapse(2) schedule(static)
+        for (int i = 0; i < P; ++i)
+            for (int j = 0; j < D; ++j) {
+                for (int k = 0; k < C; ++k) cor[k] = fabsf(pf[(size_t)i * C + k] - df[(size_t)j * C + k]);
+                S[(size_t)i * D + j] = orc_mlp3(cor, C, H1, H2, W1, b1, W2, b2, w3, b3, h1, h2);
+            }
+        free(cor); free(h1); free(h2);
+    }
+}
+
+/* A = (softmax(S, dim=1) + softmax(S, dim=0)) / 2   (tracker.py:87-89) */
+ORC_API void orc_dual_softmax(int P, int D, const float* S, float* A) {
+    double* rowmax = (double*)malloc(sizeof(double) * P);
+    double* rowsum = (double*)malloc(sizeof(double) * P);
+    double* colmax = (double*)malloc(sizeof(double) * D);
+    double* colsum = (double*)malloc(sizeof(double) * D);
+    for (int i = 0; i < P; ++i) { rowmax[i] = -INFINITY; rowsum[i] = 0; }
+    for (int j = 0; j < D; ++j) { colmax[j] = -INFINITY; colsum[j] = 0; }
+    for (int i = 0; i < P; ++i)
+        for (int j = 0; j < D; ++j) {
+            const double v = S[(size_t)i * D + j];
+            if (v > rowmax[i]) rowmax[i] = v;
+            if (v > colmax[j]) colmax[j] = v;
+        }
+    for (int i = 0; i < P; ++i)
+        for (int j = 0; j < D; ++j) {
+            const double v = S[(size_t)i * D + j];
+            rowsum[i] += exp(v - rowmax[i]);
+            colsum[j] += exp(v - colmax[j]);
+        }
+    for (int i = 0; i < P; ++i)
+        for (int j = 0; j < D; ++j) {
+            const double v = S[(size_t)i * D + j];
+            A[(size_t)i * D + j] = (float)((exp(v - rowmax[i]) / rowsum[i] + exp(v - colmax[j]) / colsum[j]) / 2);
+        }
+    free(rowmax); free(rowsum); free(colmax); free(colsum);
+}
+
+/* start/end logits (tracker.py:105-110 before the sigmoid and w_se scale; rcnn.py:254-257,
+ * 272-285).  start (D) uses the mean over the track axis, end (P) the mean over detections. */
+ORC_API void orc_start_end_logits(int P, int D, int C, int H1, int H2, const float* pf, const float* df,
+                                  const float* W1, const float* b1, const float* W2, const float* b2,
+                                  const float* w3, float b3, float* start, float* end) {
+    float* feat = (float*)malloc(sizeof(float) * C);
+    float* h1 = (float*)malloc(sizeof(float) * H1);
+    float* h2 = (float*)malloc(sizeof(float) * H2);
+    for (int j = 0; j < D; ++j) {
+        for (int k = 0; k < C; ++k) {
+            double acc = 0;
+            for (int i = 0; i < P; ++i) acc += fabsf(pf[(size_t)i * C + k] - df[(size_t)j * C + k]);
+            feat[k] = (float)(acc / P);
+        }
+        start[j] = orc_mlp3(feat, C, H1, H2, W1, b1, W2, b2, w3, b3, h1, h2);
+    }
+    for (int i = 0; i < P; ++i) {
+        for (int k = 0; k < C; ++k) {
+            double acc = 0;
+            for (int j = 0; j < D; ++j) acc += fabsf(pf[(size_t)i * C + k] - df[(size_t)j * C + k]);
+            feat[k] = (float)(acc / D);
+        }
+        end[i] = orc_mlp3(feat, C, H1, H2, W1, b1, W2, b2, w3, b3, h1, h2);
+    }
+    free(feat); free(h1); free(h2);
+}
+
+/* deterministic math passthroughs so tests can pin jm_detmath against libm */
+ORC_API void orc_detmath_sincos(int n, const float* a, float* s, float* c) {
+    for (int i = 0; i < n; ++i) jm_sincosf(a[i], &s[i], &c[i]);
+}
+ORC_API void orc_detmath_atan2(int n, const float* y, const float* x, float* r) {
+    for (int i = 0; i < n; ++i) r[i] = jm_atan2f(y[i], x[i]);
+}

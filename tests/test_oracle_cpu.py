@@ -1,0 +1,357 @@
+"""CPU tests (-m "not gpu"): pin the C oracle against independent numpy restatements,
+analytic cases, torch ops and — where /root/reference exists — the reference's own code."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from jmodt_amd import synth
+from tests import npref
+from tests.conftest import GOLDEN, REFERENCE, has_reference
+
+
+def ulp_diff(a, b):
+    a = np.asarray(a, np.float32).view(np.int32).astype(np.int64)
+    b = np.asarray(b, np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
+    b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
+    return np.abs(a - b)
+
+
+# ------------------------------------------------------------------ deterministic math
+def test_detmath_sincos_within_1ulp(oracle):
+    rng = np.random.default_rng(0)
+    a = np.concatenate([rng.uniform(-8, 8, 200000), rng.uniform(-1000, 1000, 50000),
+                        np.array([0.0, -0.0, np.pi, -np.pi, np.pi / 2, np.pi / 4, 1e-8, 3.0e4])]).astype(np.float32)
+    s, c = oracle.detmath_sincos(a)
+    rs = np.sin(a.astype(np.float64)).astype(np.float32)
+    rc = np.cos(a.astype(np.float64)).astype(np.float32)
+    assert ulp_diff(s, rs).max() <= 1
+    assert ulp_diff(c, rc).max() <= 1
+    # exact symmetry the box code relies on: cos(-a) == cos(a), sin(-a) == -sin(a)
+    s2, c2 = oracle.detmath_sincos(-a)
+    assert np.array_equal(c2, c) and np.array_equal(s2, -s)
+
+
+def test_detmath_atan2_within_1ulp(oracle):
+    rng = np.random.default_rng(1)
+    y = rng.normal(0, 3, 300000).astype(np.float32)
+    x = rng.normal(0, 3, 300000).astype(np.float32)
+    y[:8] = [0, 0, 1, -1, 0.0, -0.0, 1, -1]
+    x[:8] = [1, -1, 0, 0, 0.0, -1.0, 1, -1]
+    r = oracle.detmath_atan2(y, x)
+    ref = np.arctan2(y.astype(np.float64), x.astype(np.float64)).astype(np.float32)
+    assert ulp_diff(r, ref).max() <= 1
+    assert r[4] == 0 and r[5] == np.float32(-np.pi)
+
+
+# ------------------------------------------------------------------ FPS
+@pytest.mark.parametrize("B,N,m,kw", [
+    (2, 1024, 256, {}),
+    (2, 1000, 200, {}),                       # N not a power of two -> BS = 512
+    (1, 256, 64, dict(dup_frac=0.3)),         # exact duplicates -> ties
+    (2, 512, 128, dict(quantize=2.0 ** -3)),  # contraction-proof coordinates, many ties
+    (1, 4096, 512, dict(dup_frac=0.1)),
+])
+def test_fps_matches_closed_form_tie_rule(oracle, B, N, m, kw):
+    xyz = synth.cloud(B, N, seed=11, **kw)
+    got = oracle.furthest_point_sample(xyz, m)
+    want = npref.fps(xyz, m)
+    assert np.array_equal(got, want)
+
+
+def test_fps_all_equal_points(oracle):
+    xyz = np.ones((1, 128, 3), dtype=np.float32)
+    got = oracle.furthest_point_sample(xyz, 16)
+    # every distance ties at 0: winner = min (bitrev(k mod 128), k) = k=0 every time
+    assert np.array_equal(got, np.zeros((1, 16), np.int32))
+    assert oracle.opt_n_threads(1000) == 512 and oracle.opt_n_threads(16384) == 1024 and oracle.opt_n_threads(1) == 1
+
+
+# ------------------------------------------------------------------ ball query
+@pytest.mark.parametrize("radius,nsample,dense", [(0.1, 16, False), (0.5, 32, False), (4.0, 64, False),
+                                                  (0.5, 16, True), (1.0, 32, True)])
+def test_ball_query_vs_numpy(oracle, radius, nsample, dense):
+    xyz = synth.dense_cloud(2, 700, 5) if dense else synth.cloud(2, 900, 5, dup_frac=0.1)
+    new_xyz = xyz[:, ::7].copy()
+    got = oracle.ball_query(radius, nsample, xyz, new_xyz)
+    want = npref.ball_query(radius, nsample, xyz, new_xyz)
+    assert np.array_equal(got, want)
+
+
+def test_ball_query_edge_cases(oracle):
+    xyz = np.zeros((1, 8, 3), np.float32)
+    xyz[0, :, 0] = [0, 1, 2, 3, 4, 5, 6, 7]
+    centres = np.array([[[100, 0, 0], [0.0, 0, 0], [2.0, 0, 0], [3.5, 0, 0]]], np.float32)
+    idx = oracle.ball_query(1.0, 4, xyz, centres)
+    assert np.array_equal(idx[0, 0], [0, 0, 0, 0])        # no hit: caller's zero fill kept
+    assert np.array_equal(idx[0, 1], [0, 0, 0, 0])        # 1 hit (k=0); d==r is NOT a hit (strict <)
+    assert np.array_equal(idx[0, 2], [2, 2, 2, 2])        # points at distance exactly r excluded
+    assert np.array_equal(idx[0, 3], [3, 4, 3, 3])        # 2 hits, back-filled with the first
+    idx = oracle.ball_query(2.5, 3, xyz, centres[:, 2:3])
+    assert np.array_equal(idx[0, 0], [0, 1, 2])           # > nsample hits: first nsample in index order
+
+
+# ------------------------------------------------------------------ gather / group / 3nn / interpolate
+def test_gather_group_interp(oracle):
+    rng = np.random.default_rng(3)
+    B, C, N, M, S = 2, 5, 64, 16, 4
+    feats = rng.normal(size=(B, C, N)).astype(np.float32)
+    idx = rng.integers(0, N, (B, M)).astype(np.int32)
+    assert np.array_equal(oracle.gather_operation(feats, idx),
+                          np.take_along_axis(feats, idx[:, None, :].repeat(C, 1), 2))
+    gidx = rng.integers(0, N, (B, M, S)).astype(np.int32)
+    want = np.stack([feats[b][:, gidx[b]] for b in range(B)])
+    assert np.array_equal(oracle.grouping_operation(feats, gidx), want)
+    # grads = transpose of the gather: check by dot-product identity <G, gather(F)> == <scatter(G), F>
+    g = rng.normal(size=(B, C, M, S)).astype(np.float32)
+    gf = oracle.grouping_operation_grad(g, gidx, N)
+    assert np.allclose((g.astype(np.float64) * want).sum(), (gf.astype(np.float64) * feats).sum(), rtol=1e-5)
+    g2 = rng.normal(size=(B, C, M)).astype(np.float32)
+    gf2 = oracle.gather_operation_grad(g2, idx, N)
+    assert np.allclose((g2.astype(np.float64) * oracle.gather_operation(feats, idx)).sum(),
+                       (gf2.astype(np.float64) * feats).sum(), rtol=1e-5)
+
+
+def test_three_nn_and_interpolate(oracle):
+    unknown = synth.cloud(2, 300, 7, dup_frac=0.1)
+    known = unknown[:, ::4].copy()
+    d2, idx = oracle.three_nn(unknown, known)
+    rd2, ridx = npref.three_nn(unknown, known)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+    # m < 3: missing neighbours stay (inf, 0)
+    d2s, idxs = oracle.three_nn(unknown[:, :5], known[:, :2])
+    assert np.all(np.isinf(d2s[..., 2])) and np.all(idxs[..., 2] == 0)
+    rng = np.random.default_rng(2)
+    feats = rng.normal(size=(2, 6, known.shape[1])).astype(np.float32)
+    dist = np.sqrt(d2)
+    w = 1.0 / (dist + 1e-8)
+    w = (w / w.sum(2, keepdims=True)).astype(np.float32)
+    out = oracle.three_interpolate(feats, idx, w)
+    want = np.stack([(feats[b][:, idx[b]] * w[b][None]).sum(-1) for b in range(2)])
+    assert np.allclose(out, want, atol=1e-5)
+    g = rng.normal(size=out.shape).astype(np.float32)
+    gf = oracle.three_interpolate_grad(g, idx, w, known.shape[1])
+    assert np.allclose((g.astype(np.float64) * out).sum(), (gf.astype(np.float64) * feats).sum(), rtol=1e-4)
+
+
+# ------------------------------------------------------------------ roipool3d
+def _roipool_case(seed, N=2048, M=24, C=7):
+    pts = synth.dense_cloud(1, N, seed, extent=12.0)
+    pts[..., 1] = pts[..., 1] / 6.0  # y in [0,2]
+    boxes = synth.proposals(pts, M, seed + 1)
+    boxes[0, 0, 0:3] = [500, 0, 500]                # empty box
+    boxes[0, 1, 3:6] = [50, 50, 50]                 # huge box: |x-cx|>10 cut-off matters, >S points
+    boxes[0, 2, 3:6] = [0.2, 0.3, 0.3]              # tiny box: few points -> cyclic pad
+    feat = np.random.default_rng(seed).normal(size=(1, N, C)).astype(np.float32)
+    return pts, boxes, feat
+
+
+def test_roipool3d_semantics(oracle):
+    pts, boxes, feat = _roipool_case(21)
+    S = 64
+    eb = oracle.enlarge_box3d(boxes, 0.2)
+    pooled, empty, pidx = oracle.roipool3d(pts, feat, eb, S, return_idx=True)
+    flags = oracle.pts_in_boxes3d(pts[0], eb[0])
+    for m in range(boxes.shape[1]):
+        inside = np.nonzero(flags[m])[0]
+        if inside.size == 0:
+            assert empty[0, m] == 1 and not pooled[0, m].any()
+            continue
+        assert empty[0, m] == 0
+        sel = inside[:S]
+        want = sel[np.arange(S) % sel.size]
+        assert np.array_equal(pidx[0, m], want)
+        assert np.array_equal(pooled[0, m, :, :3], pts[0, want])
+        assert np.array_equal(pooled[0, m, :, 3:], feat[0, want])
+    assert empty[0, 0] == 1 and flags[1].sum() > S and 0 < flags[2].sum() < S
+
+
+def test_roipool3d_closed_faces_and_cutoff(oracle):
+    # axis-aligned box (ry=0): cos=1, sin=0 exactly -> points ON the faces are inside (closed)
+    box = np.array([[0, 1.0, 0, 2.0, 2.0, 4.0, 0.0]], np.float32)  # centre y = 0, h/2 = 1, l/2=2, w/2=1
+    pts = np.array([[2.0, 0, 0], [2.0000002, 0, 0], [0, 1.0, 0], [0, -1.0, 0], [0, 1.0000001, 0],
+                    [0, 0, 1.0], [0, 0, -1.0000001], [-2.0, 0, -1.0]], np.float32)
+    f = oracle.pts_in_boxes3d(pts, box)[0]
+    assert f.tolist() == [1, 0, 1, 1, 0, 1, 0, 1]
+    big = np.array([[0, 50.0, 0, 100.0, 100.0, 100.0, 0.3]], np.float32)
+    pts = np.array([[9.9, 0, 0], [10.1, 0, 0], [0, 0, -10.5], [0, 0, 9.99]], np.float32)
+    assert oracle.pts_in_boxes3d(pts, big)[0].tolist() == [1, 0, 0, 1]
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "roipool3d_ref.so")),
+                    reason="oracle/_ref not built (needs /root/reference)")
+def test_roipool3d_vs_compiled_reference(oracle):
+    """the reference's OWN roipool3d.cpp CPU functions, compiled from /root/reference"""
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref"))
+    import roipool3d_ref
+    for seed in (31, 32, 33):
+        pts, boxes, feat = _roipool_case(seed, N=4096, M=40, C=9)
+        eb = oracle.enlarge_box3d(boxes, 0.2)
+        S = 128
+        tp, tb, tf = torch.from_numpy(pts[0]), torch.from_numpy(eb[0]), torch.from_numpy(feat[0])
+        flag = torch.zeros((tb.shape[0], tp.shape[0]), dtype=torch.int64)
+        roipool3d_ref.pts_in_boxes3d_cpu(flag, tp, tb)
+        assert np.array_equal(flag.numpy(), oracle.pts_in_boxes3d(pts[0], eb[0]))
+        pp = torch.zeros((tb.shape[0], S, 3)); pf = torch.zeros((tb.shape[0], S, feat.shape[2]))
+        ef = torch.zeros((tb.shape[0],), dtype=torch.int64)
+        roipool3d_ref.roipool3d_cpu(tp, tb, tf, pp, pf, ef)
+        opp, opf, oef = oracle.roipool3d_cpu_layout(pts[0], eb[0], feat[0], S)
+        assert np.array_equal(pp.numpy(), opp) and np.array_equal(pf.numpy(), opf) and np.array_equal(ef.numpy(), oef)
+        pooled, empty = oracle.roipool3d(pts, feat, eb, S)
+        assert np.array_equal(pooled[0, :, :, :3], opp) and np.array_equal(pooled[0, :, :, 3:], opf)
+        assert np.array_equal(empty[0].astype(np.int64), oef)
+
+
+# ------------------------------------------------------------------ iou3d
+def test_overlap_analytic(oracle):
+    sq = np.array([[0, 0, 2, 2, 0.0]], np.float32)
+    assert oracle.boxes_iou_bev(sq, sq)[0, 0] == pytest.approx(1.0, abs=1e-6)
+    far = np.array([[10, 10, 12, 12, 0.3]], np.float32)
+    assert oracle.boxes_overlap_bev(sq, far)[0, 0] == 0.0
+    inner = np.array([[0.5, 0.5, 1.5, 1.5, 0.0]], np.float32)
+    assert oracle.boxes_overlap_bev(sq, inner)[0, 0] == pytest.approx(1.0, abs=1e-5)
+    rot = np.array([[0, 0, 2, 2, np.pi / 4]], np.float32)   # same square turned 45 deg: octagon
+    want = 8 * (np.sqrt(2) - 1)   # regular octagon: 2 a^2 (sqrt2 - 1) with a = 2
+    assert oracle.boxes_overlap_bev(sq, rot)[0, 0] == pytest.approx(want, rel=1e-5)
+    half = np.array([[1, 0, 3, 2, 0.0]], np.float32)
+    assert oracle.boxes_iou_bev(sq, half)[0, 0] == pytest.approx(2.0 / 6.0, rel=1e-5)
+
+
+def test_overlap_vs_float64_clipping(oracle):
+    a, _ = synth.bev_boxes(60, 41, extent=6.0)
+    b, _ = synth.bev_boxes(50, 42, extent=6.0)
+    got = oracle.boxes_overlap_bev(a, b)
+    want = npref.overlap_bev(a, b)
+    assert (want > 0.1).sum() > 50
+    assert np.abs(got - want).max() < 2e-4
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]); area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    iou = want / np.maximum(area_a[:, None] + area_b[None] - want, 1e-8)
+    assert np.abs(oracle.boxes_iou_bev(a, b) - iou).max() < 1e-4
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 500, 1000])
+@pytest.mark.parametrize("thresh", [0.1, 0.8, 0.85])
+def test_nms_normal_vs_textbook(oracle, n, thresh):
+    boxes, scores = synth.bev_boxes(n, 100 + n)
+    order = np.argsort(-scores, kind="stable")
+    iou = npref.iou_normal_matrix(boxes[order])
+    want = order[npref.greedy_nms(iou, np.float32(thresh))]
+    got = oracle.nms(boxes, scores, thresh, normal=True)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n,thresh", [(100, 0.1), (400, 0.5), (64, 0.8)])
+def test_nms_rotated_vs_textbook(oracle, n, thresh):
+    boxes, scores = synth.bev_boxes(n, 7 + n)
+    order = np.argsort(-scores, kind="stable")
+    bs = boxes[order]
+    iou = oracle.boxes_iou_bev(bs, bs)
+    want = order[npref.greedy_nms(iou, np.float32(thresh))]
+    assert np.array_equal(oracle.nms(boxes, scores, thresh, normal=False), want)
+    # the bit mask itself: bit j of mask[i, j//64] == (iou[i,j] > thr) for j > i
+    mask = oracle.nms_mask(bs, thresh, normal=False)
+    for i in range(0, n, 17):
+        for j in range(i + 1, n):
+            assert bool((int(mask[i, j // 64]) >> (j % 64)) & 1) == bool(iou[i, j] > np.float32(thresh))
+
+
+def test_nms_empty(oracle):
+    assert oracle.nms_sorted(np.zeros((0, 5), np.float32), 0.5, True).size == 0
+
+
+def test_boxes_iou3d_vs_torch_restatement(oracle):
+    import torch
+    pts = synth.dense_cloud(1, 256, 3, extent=10.0)
+    a = synth.proposals(pts, 30, 4)[0]
+    b = synth.proposals(pts, 20, 5)[0]
+    got = oracle.boxes_iou3d(a, b)
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    ov = torch.from_numpy(oracle.boxes_overlap_bev(oracle.boxes3d_to_bev(a), oracle.boxes3d_to_bev(b)))
+    # iou3d_utils.py:36-52 restated with torch on CPU
+    hmin = torch.max((ta[:, 1] - ta[:, 3]).view(-1, 1), (tb[:, 1] - tb[:, 3]).view(1, -1))
+    hmax = torch.min(ta[:, 1].view(-1, 1), tb[:, 1].view(1, -1))
+    o3 = ov * torch.clamp(hmax - hmin, min=0)
+    va = (ta[:, 3] * ta[:, 4] * ta[:, 5]).view(-1, 1); vb = (tb[:, 3] * tb[:, 4] * tb[:, 5]).view(1, -1)
+    want = (o3 / torch.clamp(va + vb - o3, min=1e-7)).numpy()
+    assert np.allclose(got, want, atol=1e-6) and (want > 0.05).sum() > 5
+    for i in range(5):
+        assert oracle.boxes_iou3d(a[i:i + 1], a[i:i + 1])[0, 0] == pytest.approx(1.0, abs=1e-5)
+
+
+@pytest.mark.skipif(not has_reference(), reason="needs /root/reference")
+def test_bev_and_enlarge_vs_reference_kitti_utils(oracle):
+    import torch
+    sys.path.insert(0, REFERENCE)
+    from jmodt.utils import kitti_utils  # the reference's own module (imports fine on CPU)
+    pts = synth.dense_cloud(1, 128, 9, extent=30.0)
+    b = synth.proposals(pts, 50, 10)[0]
+    assert np.array_equal(kitti_utils.boxes3d_to_bev_torch(torch.from_numpy(b)).numpy(), oracle.boxes3d_to_bev(b))
+    assert np.array_equal(kitti_utils.enlarge_box3d(b, 0.2), oracle.enlarge_box3d(b, 0.2))
+    assert np.array_equal(kitti_utils.enlarge_box3d(torch.from_numpy(b), 0.2).numpy(), oracle.enlarge_box3d(b, 0.2))
+
+
+# ------------------------------------------------------------------ LI-Fusion gather
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_feature_gather_vs_torch_grid_sample(oracle, channels_last):
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(5)
+    B, C, H, W, N = 2, 6, 24, 80, 500
+    fm = torch.from_numpy(rng.normal(size=(B, C, H, W)).astype(np.float32))
+    if channels_last:
+        fm = fm.contiguous(memory_format=torch.channels_last)
+    xy = rng.uniform(-1.15, 1.15, (B, N, 2)).astype(np.float32)
+    xy[0, 0] = [-1, -1]; xy[0, 1] = [1, 1]; xy[0, 2] = [1.0, -1.0]; xy[0, 3] = [0, 0]
+    xy[0, 4] = [2 * 5 / (W - 1) - 1, 2 * 7 / (H - 1) - 1]        # exact pixel centre (5,7)
+    xy[0, 5] = [1.5, 0.2]                                          # outside -> zeros
+    want = F.grid_sample(fm, torch.from_numpy(xy).unsqueeze(1), align_corners=True).squeeze(2).numpy()
+    got = oracle.feature_gather(fm.numpy() if not channels_last else
+                                np.lib.stride_tricks.as_strided(fm.permute(0, 2, 3, 1).numpy().reshape(-1),
+                                                                (B, C, H, W), (H * W * C * 4, 4, W * C * 4, C * 4)), xy)
+    assert np.abs(got - want).max() < 1e-5
+    assert np.all(got[0, :, 5] == 0)
+    assert np.allclose(got[0, :, 4], fm[0, :, 7, 5].numpy(), atol=1e-5)
+
+
+# ------------------------------------------------------------------ affinity
+def _torch_affinity(pf, df, link_layer, se_layer):
+    """tracker.py:81-112 restated literally with torch ops"""
+    import torch
+    P, D = pf.shape[0], df.shape[0]
+    cor = torch.abs(pf.unsqueeze(1).repeat(1, D, 1) - df.unsqueeze(0).repeat(P, 1, 1))
+    s = link_layer(cor.view(P * D, -1, 1)).view(P, D)
+    A = (torch.softmax(s, dim=1) + torch.softmax(s, dim=0)) / 2
+    start = se_layer(cor.mean(dim=0).unsqueeze(-1)).flatten()
+    end = se_layer(cor.mean(dim=1).unsqueeze(-1)).flatten()
+    return s, A, start, end
+
+
+def _torch_head(C, H1, H2, w):
+    import torch
+    import torch.nn as nn
+    W1, b1, W2, b2, w3, b3 = w
+    head = nn.Sequential(nn.Conv1d(C, H1, 1), nn.ReLU(), nn.Dropout(0.0), nn.Conv1d(H1, H2, 1), nn.ReLU(),
+                         nn.Conv1d(H2, 1, 1))
+    with torch.no_grad():
+        head[0].weight.copy_(torch.from_numpy(W1)[..., None]); head[0].bias.copy_(torch.from_numpy(b1))
+        head[3].weight.copy_(torch.from_numpy(W2)[..., None]); head[3].bias.copy_(torch.from_numpy(b2))
+        head[5].weight.copy_(torch.from_numpy(w3)[None, :, None]); head[5].bias.fill_(float(b3))
+    return head.eval()
+
+
+@pytest.mark.parametrize("P,D,C", [(7, 5, 64), (1, 1, 32), (16, 16, 512)])
+def test_affinity_vs_torch(oracle, P, D, C):
+    import torch
+    lw = synth.mlp_weights(C, C, C, 1)
+    sw = synth.mlp_weights(C, C, C, 2)
+    pf, df = synth.roi_features(P, C, 3), synth.roi_features(D, C, 4)
+    with torch.no_grad():
+        s, A, st, en = _torch_affinity(torch.from_numpy(pf), torch.from_numpy(df), _torch_head(C, C, C, lw),
+                                       _torch_head(C, C, C, sw))
+    assert np.abs(oracle.link_scores(pf, df, lw) - s.numpy()).max() < 1e-4
+    gA, gs, ge = oracle.affinity(pf, df, lw, sw)
+    assert np.abs(gA - A.numpy()).max() < 1e-5
+    assert np.abs(gs - st.numpy()).max() < 1e-4 and np.abs(ge - en.numpy()).max() < 1e-4
