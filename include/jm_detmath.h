@@ -19,7 +19,7 @@
 #define JM_DETMATH_H
 
 #if defined(__HIPCC__) || defined(__HIP_DEVICE_COMPILE__)
-#define JM_HD __host__ __device__ __forceinline__
+#define JM_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define JM_HD static inline
 #endif

@@ -1,0 +1,170 @@
+/*
+ * jmodt_hip.h — C ABI of libjmodt_hip.so: the MI355X (gfx950) implementation of JMODT's
+ * detection + association hot path.  Plain pointers and sizes only (no torch types).
+ *
+ * Every entry point replaces one function of the reference's three pybind extension modules
+ * (file:line cited per function, paths relative to the reference repo) or one of the two
+ * pure-PyTorch pieces named by the north star (LI-Fusion gather, affinity head).
+ *
+ * Conventions
+ *   - All tensor arguments are DEVICE pointers to contiguous float32 / int32 / int64 data
+ *     unless the name ends in _cpu (host pointers; the reference's CPU entry points).
+ *   - The caller owns every buffer, including scratch (`ws`); nothing is allocated or freed
+ *     and no host synchronisation happens inside a call (the reference cudaMalloc/cudaMemcpy's
+ *     inside nms_gpu and roipool3d: iou3d.cpp:87-95, roipool3d_kernel.cu:214-232).
+ *   - `stream` is a hipStream_t (NULL = the legacy default stream, which is what the reference
+ *     launches on).  Calls are re-entrant; the library keeps no global mutable state except a
+ *     thread-local error string.
+ *   - Return value: 0 on success, a JM_E* code otherwise (the reference returns a meaningless 1
+ *     and exit()s the process on kernel failure: ball_query_gpu.cu:62-66, iou3d.cpp:13-21).
+ *     jm_last_error() describes the most recent failure on the calling thread.
+ */
+#ifndef JMODT_HIP_H
+#define JMODT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
+
+#define JM_OK 0
+#define JM_EINVAL 1   /* bad argument (negative size, NULL pointer, unsupported shape) */
+#define JM_ELAUNCH 2  /* hipGetLastError() after a launch */
+#define JM_EWORKSPACE 3 /* workspace too small */
+
+typedef void* jm_stream_t; /* hipStream_t */
+
+int jm_version(void);
+const char* jm_last_error(void);
+
+/* ------------------------------------------------------------------ pointnet2_cuda -------- */
+
+/* farthest_point_sampling_wrapper (pointnet2/src/sampling.cpp:36-46, sampling_gpu.cu:93-253).
+ * xyz (B,N,3); temp (B,N) pre-filled by the caller (1e10) and updated in place; idx (B,M) i32.
+ * Bit-exact with the reference's block-tree arg-max tie order. */
+int jm_furthest_point_sampling(int b, int n, int m, const float* xyz, float* temp, int* idx, jm_stream_t stream);
+
+/* gather_points_wrapper / gather_points_grad_wrapper (sampling.cpp:11-33, sampling_gpu.cu:8-83).
+ * points (B,C,N), idx (B,M) -> out (B,C,M);  grad_points (B,C,N) pre-zeroed, accumulated. */
+int jm_gather_points(int b, int c, int n, int npoints, const float* points, const int* idx, float* out,
+                     jm_stream_t stream);
+int jm_gather_points_grad(int b, int c, int n, int npoints, const float* grad_out, const int* idx,
+                          float* grad_points, jm_stream_t stream);
+
+/* ball_query_wrapper (ball_query.cpp:14-25, ball_query_gpu.cu:9-67).  new_xyz (B,M,3),
+ * xyz (B,N,3) -> idx (B,M,nsample) i32, pre-zeroed by the caller; centres without a hit are
+ * left untouched.  First `nsample` hits in ascending point index, back-filled with the first. */
+int jm_ball_query(int b, int n, int m, float radius, int nsample, const float* new_xyz, const float* xyz,
+                  int* idx, jm_stream_t stream);
+/* MI355X-native extension: both MSG radii of one SA level in a single pass over xyz
+ * (pointnet2_modules.py:46-47 calls ball_query once per radius on the same centres). */
+int jm_ball_query_dual(int b, int n, int m, float radius0, int nsample0, float radius1, int nsample1,
+                       const float* new_xyz, const float* xyz, int* idx0, int* idx1, jm_stream_t stream);
+
+/* group_points_wrapper / group_points_grad_wrapper (group_points.cpp:11-36,
+ * group_points_gpu.cu:8-86).  points (B,C,N), idx (B,P,S) -> out (B,C,P,S). */
+int jm_group_points(int b, int c, int n, int npoints, int nsample, const float* points, const int* idx,
+                    float* out, jm_stream_t stream);
+int jm_group_points_grad(int b, int c, int n, int npoints, int nsample, const float* grad_out, const int* idx,
+                         float* grad_points, jm_stream_t stream);
+
+/* three_nn_wrapper (interpolate.cpp:14-23, interpolate_gpu.cu:9-74).  unknown (B,N,3),
+ * known (B,M,3) -> dist2 (B,N,3) SQUARED distances, idx (B,N,3) i32. */
+int jm_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2, int* idx,
+                jm_stream_t stream);
+
+/* three_interpolate_wrapper / _grad_wrapper (interpolate.cpp:26-54, interpolate_gpu.cu:77-161).
+ * points (B,C,M), idx/weight (B,N,3) -> out (B,C,N);  grad_points (B,C,M) pre-zeroed. */
+int jm_three_interpolate(int b, int c, int m, int n, const float* points, const int* idx, const float* weight,
+                         float* out, jm_stream_t stream);
+int jm_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out, const int* idx,
+                              const float* weight, float* grad_points, jm_stream_t stream);
+
+/* ------------------------------------------------------------------ roipool3d_cuda -------- */
+
+/* forward / forward_slow (roipool3d/src/roipool3d.cpp:16-79, roipool3d_kernel.cu:31-237).
+ * xyz (B,N,3), boxes3d (B,M,7) ALREADY ENLARGED, pts_feature (B,N,C) ->
+ * pooled_features (B,M,S,3+C), pooled_empty_flag (B,M) i32.
+ * zero_empty = 0: reference contract — both outputs pre-zeroed by the caller, rows of empty
+ *                 boxes are not written.
+ * zero_empty = 1: the kernel writes zeros for empty boxes and 0/1 into every flag, so the
+ *                 caller may pass uninitialised buffers (saves one full pass over the output). */
+int jm_roipool3d_forward(int batch_size, int pts_num, int boxes_num, int feature_in_len, int sampled_pts_num,
+                         const float* xyz, const float* boxes3d, const float* pts_feature,
+                         float* pooled_features, int* pooled_empty_flag, int zero_empty, jm_stream_t stream);
+
+/* pts_in_boxes3d_cpu / roipool3d_cpu (roipool3d.cpp:97-195): HOST pointers, synchronous. */
+int jm_pts_in_boxes3d_cpu(int boxes_num, int pts_num, const float* pts, const float* boxes3d, int64_t* pts_flag);
+int jm_roipool3d_cpu(int pts_num, int boxes_num, int feature_len, int sampled_pts_num, const float* pts,
+                     const float* boxes3d, const float* pts_feature, float* pooled_pts, float* pooled_features,
+                     int64_t* pooled_empty_flag);
+
+/* ------------------------------------------------------------------ iou3d_cuda ------------ */
+
+/* boxes_overlap_bev_gpu / boxes_iou_bev_gpu (iou3d/src/iou3d.cpp:31-71,
+ * iou3d_kernel.cu:108-248,354-371).  boxes (N,5) [x1,y1,x2,y2,ry] -> (Na,Nb). */
+int jm_boxes_overlap_bev(int num_a, const float* boxes_a, int num_b, const float* boxes_b, float* ans_overlap,
+                         jm_stream_t stream);
+int jm_boxes_iou_bev(int num_a, const float* boxes_a, int num_b, const float* boxes_b, float* ans_iou,
+                     jm_stream_t stream);
+
+/* nms_gpu / nms_normal_gpu (iou3d.cpp:73-166, iou3d_kernel.cu:250-348,374-387).
+ * boxes (N,5) score-sorted.  The suppression bit-mask AND the greedy reduce both run on the
+ * device: keep (N) int64 and num_keep (1) int32 are DEVICE buffers; ws holds the mask
+ * (jm_nms_workspace_bytes(N)).  normal = 1 selects the axis-aligned IoU (nms_normal_gpu). */
+size_t jm_nms_workspace_bytes(int boxes_num);
+int jm_nms(int boxes_num, const float* boxes, float nms_overlap_thresh, int normal, int64_t* keep,
+           int* num_keep, void* ws, size_t ws_bytes, jm_stream_t stream);
+/* mask only (N, ceil(N/64)) uint64; tiles with col_block < row_block are never consumed by the
+ * reduce (iou3d.cpp:108) and are left unwritten. */
+int jm_nms_mask(int boxes_num, const float* boxes, float nms_overlap_thresh, int normal,
+                unsigned long long* mask, jm_stream_t stream);
+
+/* ------------------------------------------------------------------ LI-Fusion gather ------ */
+
+/* feature_gather (jmodt/detection/modeling/backbone.py:79-89) =
+ * F.grid_sample(map, xy[B,1,N,2], bilinear, zeros padding, align_corners=True).
+ * fmap (B,C,H,W) with ELEMENT strides (sb,sc,sh,sw) — NCHW or channels-last, no copy;
+ * xy (B,N,2) in [-1,1] -> out (B,C,N). */
+int jm_feature_gather(int b, int c, int h, int w, int n, const float* fmap, int64_t sb, int64_t sc, int64_t sh,
+                      int64_t sw, const float* xy, float* out, jm_stream_t stream);
+/* gradient w.r.t. the feature map (pre-zeroed, same strides), accumulated with atomics */
+int jm_feature_gather_grad(int b, int c, int h, int w, int n, const float* grad_out, const float* xy,
+                           float* grad_fmap, int64_t sb, int64_t sc, int64_t sh, int64_t sw, jm_stream_t stream);
+
+/* ------------------------------------------------------------------ affinity head --------- */
+
+/* link_layer / se_layer MLP (jmodt/detection/modeling/rcnn.py:91-111):
+ *   Conv1d(C,H1)+ReLU -> Conv1d(H1,H2)+ReLU -> Conv1d(H2,1), bias, kernel size 1.
+ * W1 (H1,C), b1 (H1), W2 (H2,H1), b2 (H2), w3 (H2), b3 (1): all device pointers. */
+typedef struct {
+    int c, h1, h2;
+    const float *w1, *b1, *w2, *b2, *w3, *b3;
+} jm_mlp3_t;
+
+/* Inference-time pairwise affinity (jmodt/tracking/tracker.py:81-112; training form
+ * rcnn.py:239-258).  pred_feat (P,C), det_feat (D,C) ->
+ *   link_raw (P,D)  raw link scores S              (may be NULL)
+ *   link     (P,D)  (softmax(S,dim=1)+softmax(S,dim=0))/2
+ *   start    (D)    se(mean_i |p_i-d_j|)  raw logit (tracker applies w_se*sigmoid)
+ *   end      (P)    se(mean_j |p_i-d_j|)  raw logit
+ * The (P*D,C) pair tensor is never materialised.  fp32 MFMA, exact-f32 products. */
+size_t jm_affinity_workspace_bytes(int p, int d, const jm_mlp3_t* link, const jm_mlp3_t* se);
+int jm_affinity_forward(int p, int d, const float* pred_feat, const float* det_feat, const jm_mlp3_t* link,
+                        const jm_mlp3_t* se, float* link_raw, float* link_out, float* start, float* end, void* ws,
+                        size_t ws_bytes, jm_stream_t stream);
+
+/* The same MLP on plain rows x (M,C) -> y (M): used for the start/end features and exposed for
+ * callers that hold a materialised feature matrix (rcnn.py:272-285). */
+size_t jm_mlp3_workspace_bytes(int m, const jm_mlp3_t* mlp);
+int jm_mlp3_forward(int m, const float* x, const jm_mlp3_t* mlp, float* y, void* ws, size_t ws_bytes,
+                    jm_stream_t stream);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* JMODT_HIP_H */

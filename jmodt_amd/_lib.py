@@ -1,0 +1,112 @@
+"""ctypes binding of libjmodt_hip.so (the C ABI declared in include/jmodt_hip.h).
+
+The HIP library is the ONLY compute path of this package: there is no CPU / eager-PyTorch
+fallback.  Importing this module never needs a GPU (the driver's build check and the CPU test
+tier load the library and check its symbols), but calling any op without the library or with
+non-GPU tensors raises immediately.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libjmodt_hip.so")
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_L = ctypes.c_int64
+_Z = ctypes.c_size_t
+
+
+class Mlp3(ctypes.Structure):
+    """jm_mlp3_t"""
+    _fields_ = [("c", _I), ("h1", _I), ("h2", _I), ("w1", _P), ("b1", _P), ("w2", _P), ("b2", _P), ("w3", _P),
+                ("b3", _P)]
+
+
+# name -> (restype, argtypes); mirrors include/jmodt_hip.h one to one
+SIGNATURES = {
+    "jm_version": (_I, []),
+    "jm_last_error": (ctypes.c_char_p, []),
+    "jm_furthest_point_sampling": (_I, [_I, _I, _I, _P, _P, _P, _P]),
+    "jm_gather_points": (_I, [_I, _I, _I, _I, _P, _P, _P, _P]),
+    "jm_gather_points_grad": (_I, [_I, _I, _I, _I, _P, _P, _P, _P]),
+    "jm_ball_query": (_I, [_I, _I, _I, _F, _I, _P, _P, _P, _P]),
+    "jm_ball_query_dual": (_I, [_I, _I, _I, _F, _I, _F, _I, _P, _P, _P, _P, _P]),
+    "jm_group_points": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "jm_group_points_grad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "jm_three_nn": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
+    "jm_three_interpolate": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "jm_three_interpolate_grad": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "jm_roipool3d_forward": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "jm_pts_in_boxes3d_cpu": (_I, [_I, _I, _P, _P, _P]),
+    "jm_roipool3d_cpu": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "jm_boxes_overlap_bev": (_I, [_I, _P, _I, _P, _P, _P]),
+    "jm_boxes_iou_bev": (_I, [_I, _P, _I, _P, _P, _P]),
+    "jm_nms_workspace_bytes": (_Z, [_I]),
+    "jm_nms": (_I, [_I, _P, _F, _I, _P, _P, _P, _Z, _P]),
+    "jm_nms_mask": (_I, [_I, _P, _F, _I, _P, _P]),
+    "jm_feature_gather": (_I, [_I, _I, _I, _I, _I, _P, _L, _L, _L, _L, _P, _P, _P]),
+    "jm_feature_gather_grad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _L, _L, _L, _L, _P]),
+    "jm_affinity_workspace_bytes": (_Z, [_I, _I, ctypes.POINTER(Mlp3), ctypes.POINTER(Mlp3)]),
+    "jm_affinity_forward": (_I, [_I, _I, _P, _P, ctypes.POINTER(Mlp3), ctypes.POINTER(Mlp3), _P, _P, _P, _P, _P, _Z,
+                                 _P]),
+    "jm_mlp3_workspace_bytes": (_Z, [_I, ctypes.POINTER(Mlp3)]),
+    "jm_mlp3_forward": (_I, [_I, _P, ctypes.POINTER(Mlp3), _P, _P, _Z, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library and bind every symbol of the ABI; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"jmodt_amd: {LIB_PATH} is missing. Build it with `python -m jmodt_amd.csrc.build` "
+            "(hipcc, gfx950). There is no CPU fallback for the jmodt ops.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().jm_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"jmodt_amd.{what} failed (code {rc}): {msg}")
+
+
+def stream_ptr():
+    """the hipStream_t torch is currently launching on (never the legacy default stream implicitly)"""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev(t: torch.Tensor, dtype, name: str):
+    """validate a device tensor argument and return its raw pointer"""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor (jmodt_amd has no CPU path); got device {t.device}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def host(t: torch.Tensor, dtype, name: str):
+    if t.is_cuda:
+        raise RuntimeError(f"{name} must be a CPU tensor")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,58 @@
+"""Build jmodt_amd/csrc/libjmodt_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m jmodt_amd.csrc.build [--force] [--save-temps]
+
+One translation unit per op family, compiled in parallel, linked into ONE shared library with a
+flat C ABI (include/jmodt_hip.h).  -ffp-contract=off: the kernels spell out every fused
+operation they want (see oracle/jmodt_oracle.c header for the floating-point conventions).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+SOURCES = ["capi.hip", "fps.hip", "ball_query.hip", "pointnet2_gather.hip", "roipool3d.hip", "iou3d.hip",
+           "feature_gather.hip", "affinity.hip"]
+HEADERS = ["jm_common.h", os.path.join(ROOT, "include", "jmodt_hip.h"), os.path.join(ROOT, "include", "jm_detmath.h")]
+LIB = os.path.join(HERE, "libjmodt_hip.so")
+OBJ_DIR = os.path.join(HERE, "build")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-fvisibility=hidden", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-DJM_BUILDING"]
+
+
+def _mtime(p):
+    return os.path.getmtime(p) if os.path.exists(p) else 0.0
+
+
+def _compile(src, force, save_temps):
+    obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+    deps = [os.path.join(HERE, src)] + [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS]
+    if not force and _mtime(obj) >= max(_mtime(d) for d in deps):
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ["-c", os.path.join(HERE, src), "-o", obj]
+    if save_temps:
+        cmd += ["-save-temps=obj"]
+    subprocess.check_call(cmd, cwd=OBJ_DIR)
+    return obj, True
+
+
+def build(force=False, save_temps=False, verbose=True):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        res = list(ex.map(lambda s: _compile(s, force, save_temps), SOURCES))
+    objs = [o for o, _ in res]
+    if force or any(ch for _, ch in res) or _mtime(LIB) < max(_mtime(o) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        subprocess.check_call(cmd)
+        if verbose:
+            print(f"built {LIB}")
+    elif verbose:
+        print(f"up to date: {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv)

@@ -1,0 +1,151 @@
+// feature_gather.hip — LI-Fusion point -> image bilinear gather for gfx950.
+//
+// Replaces feature_gather (jmodt/detection/modeling/backbone.py:79-89) =
+//   F.grid_sample(feature_map, xy[B,1,N,2], mode='bilinear', padding_mode='zeros',
+//                 align_corners=True).squeeze(2)
+//
+// Design: lane = point.  The 4 tap offsets / weights / validity are computed once per point and
+// reused for a block of channels; the feature map is addressed through element strides, so a
+// channels-last map (each tap = C contiguous floats) needs no copy and turns the 4*C scattered
+// 4-byte reads of the NCHW layout into 16-byte vector reads.  Output (B,C,N) stores are
+// contiguous along N.  Arithmetic follows ATen's grid_sampler_2d (unnormalise with
+// align_corners, corner weights as products of differences, out-of-range taps contribute 0).
+#include "jm_common.h"
+
+namespace jm {
+
+struct Taps {
+    long long o_nw, o_ne, o_sw, o_se;  // element offsets inside one (b, c=0) plane walk
+    float w_nw, w_ne, w_sw, w_se;      // 0 where the tap is outside the image
+};
+
+__device__ __forceinline__ Taps make_taps(float x, float y, int H, int W, long long sh, long long sw) {
+    Taps t;
+    const float ix = ((x + 1.f) / 2) * (W - 1);
+    const float iy = ((y + 1.f) / 2) * (H - 1);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const float nw = (fx + 1 - ix) * (fy + 1 - iy);
+    const float ne = (ix - fx) * (fy + 1 - iy);
+    const float sw_ = (fx + 1 - ix) * (iy - fy);
+    const float se = (ix - fx) * (iy - fy);
+    // compare in float before converting so huge / NaN coordinates cannot overflow the int cast
+    const bool x0ok = fx >= 0.f && fx <= (float)(W - 1), x1ok = fx + 1 >= 0.f && fx + 1 <= (float)(W - 1);
+    const bool y0ok = fy >= 0.f && fy <= (float)(H - 1), y1ok = fy + 1 >= 0.f && fy + 1 <= (float)(H - 1);
+    const int x0 = x0ok ? (int)fx : 0, x1 = x1ok ? (int)fx + 1 : 0;
+    const int y0 = y0ok ? (int)fy : 0, y1 = y1ok ? (int)fy + 1 : 0;
+    t.o_nw = y0 * sh + x0 * sw; t.o_ne = y0 * sh + x1 * sw;
+    t.o_sw = y1 * sh + x0 * sw; t.o_se = y1 * sh + x1 * sw;
+    t.w_nw = (x0ok && y0ok) ? nw : 0.f;
+    t.w_ne = (x1ok && y0ok) ? ne : 0.f;
+    t.w_sw = (x0ok && y1ok) ? sw_ : 0.f;
+    t.w_se = (x1ok && y1ok) ? se : 0.f;
+    return t;
+}
+
+constexpr int FG_CPT = 16;
+
+// generic strides (NCHW and anything else)
+__global__ void __launch_bounds__(256)
+feature_gather_kernel(int C, int H, int W, int N, const float* __restrict__ fmap, long long sb, long long sc,
+                      long long sh, long long sw, const float* __restrict__ xy, float* __restrict__ out) {
+    const int bi = blockIdx.z;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float2 p = *reinterpret_cast<const float2*>(xy + ((size_t)bi * N + n) * 2);
+    const Taps t = make_taps(p.x, p.y, H, W, sh, sw);
+    const int c0 = blockIdx.y * FG_CPT, c1 = min(C, c0 + FG_CPT);
+    const float* base = fmap + (size_t)bi * sb;
+#pragma unroll 4
+    for (int c = c0; c < c1; ++c) {
+        const float* pl = base + (size_t)c * sc;
+        // taps with zero weight are still read from a clamped in-range address (weight 0 kills them)
+        float acc = pl[t.o_nw] * t.w_nw;
+        acc += pl[t.o_ne] * t.w_ne;
+        acc += pl[t.o_sw] * t.w_sw;
+        acc += pl[t.o_se] * t.w_se;
+        out[((size_t)bi * C + c) * N + n] = acc;
+    }
+}
+
+// channels-last fast path: sc == 1, C % 4 == 0, 16-byte aligned taps
+__global__ void __launch_bounds__(256)
+feature_gather_cl_kernel(int C, int H, int W, int N, const float* __restrict__ fmap, long long sb, long long sh,
+                         long long sw, const float* __restrict__ xy, float* __restrict__ out) {
+    const int bi = blockIdx.z;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float2 p = *reinterpret_cast<const float2*>(xy + ((size_t)bi * N + n) * 2);
+    const Taps t = make_taps(p.x, p.y, H, W, sh, sw);
+    const int c0 = blockIdx.y * FG_CPT, c1 = min(C, c0 + FG_CPT);
+    const float* base = fmap + (size_t)bi * sb;
+    for (int c = c0; c < c1; c += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(base + t.o_nw + c);
+        const float4 b = *reinterpret_cast<const float4*>(base + t.o_ne + c);
+        const float4 d = *reinterpret_cast<const float4*>(base + t.o_sw + c);
+        const float4 e = *reinterpret_cast<const float4*>(base + t.o_se + c);
+        float r[4];
+        r[0] = a.x * t.w_nw; r[0] += b.x * t.w_ne; r[0] += d.x * t.w_sw; r[0] += e.x * t.w_se;
+        r[1] = a.y * t.w_nw; r[1] += b.y * t.w_ne; r[1] += d.y * t.w_sw; r[1] += e.y * t.w_se;
+        r[2] = a.z * t.w_nw; r[2] += b.z * t.w_ne; r[2] += d.z * t.w_sw; r[2] += e.z * t.w_se;
+        r[3] = a.w * t.w_nw; r[3] += b.w * t.w_ne; r[3] += d.w * t.w_sw; r[3] += e.w * t.w_se;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[((size_t)bi * C + c + q) * N + n] = r[q];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+feature_gather_grad_kernel(int C, int H, int W, int N, const float* __restrict__ grad_out,
+                           const float* __restrict__ xy, float* __restrict__ grad_fmap, long long sb, long long sc,
+                           long long sh, long long sw) {
+    const int bi = blockIdx.z;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float2 p = *reinterpret_cast<const float2*>(xy + ((size_t)bi * N + n) * 2);
+    const Taps t = make_taps(p.x, p.y, H, W, sh, sw);
+    const int c0 = blockIdx.y * FG_CPT, c1 = min(C, c0 + FG_CPT);
+    float* base = grad_fmap + (size_t)bi * sb;
+    for (int c = c0; c < c1; ++c) {
+        const float g = grad_out[((size_t)bi * C + c) * N + n];
+        float* pl = base + (size_t)c * sc;
+        if (t.w_nw != 0.f) unsafeAtomicAdd(pl + t.o_nw, g * t.w_nw);
+        if (t.w_ne != 0.f) unsafeAtomicAdd(pl + t.o_ne, g * t.w_ne);
+        if (t.w_sw != 0.f) unsafeAtomicAdd(pl + t.o_sw, g * t.w_sw);
+        if (t.w_se != 0.f) unsafeAtomicAdd(pl + t.o_se, g * t.w_se);
+    }
+}
+
+}  // namespace jm
+
+using namespace jm;
+
+extern "C" int jm_feature_gather(int b, int c, int h, int w, int n, const float* fmap, int64_t sb, int64_t sc,
+                                 int64_t sh, int64_t sw, const float* xy, float* out, jm_stream_t stream) {
+    JM_REQUIRE(b >= 0 && c >= 0 && h >= 1 && w >= 1 && n >= 0, "feature_gather: bad sizes");
+    if (b == 0 || c == 0 || n == 0) return JM_OK;
+    JM_REQUIRE(fmap && xy && out, "feature_gather: null pointer");
+    JM_REQUIRE(b <= 65535 && divup(c, FG_CPT) <= 65535, "feature_gather: shape too large");
+    JM_REQUIRE((reinterpret_cast<uintptr_t>(xy) & 7u) == 0, "feature_gather: xy must be 8-byte aligned");
+    dim3 grid(divup(n, 256), divup(c, FG_CPT), b), block(256);
+    const bool cl = sc == 1 && (c % 4 == 0) && (sw % 4 == 0) && (sh % 4 == 0) && (sb % 4 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(fmap) & 15u) == 0);
+    if (cl)
+        hipLaunchKernelGGL(feature_gather_cl_kernel, grid, block, 0, (hipStream_t)stream, c, h, w, n, fmap,
+                           (long long)sb, (long long)sh, (long long)sw, xy, out);
+    else
+        hipLaunchKernelGGL(feature_gather_kernel, grid, block, 0, (hipStream_t)stream, c, h, w, n, fmap,
+                           (long long)sb, (long long)sc, (long long)sh, (long long)sw, xy, out);
+    return check_launch("feature_gather");
+}
+
+extern "C" int jm_feature_gather_grad(int b, int c, int h, int w, int n, const float* grad_out, const float* xy,
+                                      float* grad_fmap, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                                      jm_stream_t stream) {
+    JM_REQUIRE(b >= 0 && c >= 0 && h >= 1 && w >= 1 && n >= 0, "feature_gather_grad: bad sizes");
+    if (b == 0 || c == 0 || n == 0) return JM_OK;
+    JM_REQUIRE(grad_out && xy && grad_fmap, "feature_gather_grad: null pointer");
+    JM_REQUIRE(b <= 65535 && divup(c, FG_CPT) <= 65535, "feature_gather_grad: shape too large");
+    hipLaunchKernelGGL(feature_gather_grad_kernel, dim3(divup(n, 256), divup(c, FG_CPT), b), dim3(256), 0,
+                       (hipStream_t)stream, c, h, w, n, grad_out, xy, grad_fmap, (long long)sb, (long long)sc,
+                       (long long)sh, (long long)sw);
+    return check_launch("feature_gather_grad");
+}

@@ -1,0 +1,344 @@
+// iou3d.hip — rotated / axis-aligned BEV overlap, IoU and NMS for gfx950.
+//
+// Replaces boxes_overlap_kernel, boxes_iou_bev_kernel, nms_kernel, nms_normal_kernel
+// (jmodt/ops/iou3d/src/iou3d_kernel.cu:223-348) and the HOST greedy reduce of nms_gpu /
+// nms_normal_gpu (iou3d.cpp:73-166).
+//
+// Design:
+//  * Per-box work is hoisted out of the pair loop: the rotated corners, centre and sin/cos of a
+//    box are computed once per workgroup tile and kept in LDS / registers (the reference
+//    recomputes cos/sin and the 4 rotated corners of BOTH boxes for every pair).
+//  * NMS never leaves the device: the 64x64-tile suppression mask is built for the upper
+//    triangle only (the reference launches the full square and discards half), and the greedy
+//    reduce runs as a single workgroup — wave 0 resolves the 64 boxes of a row block with a
+//    scalar loop over the diagonal tile (readlane, no memory), then all threads OR the kept
+//    rows into the removal mask held in LDS.  The reference cudaMalloc's, memcpy's 5 MB to the
+//    host, loops serially on the CPU and cudaFree's, twice per frame.
+//  * All arithmetic is the reference's float expression sequence with contraction off;
+//    sin/cos/atan2 through include/jm_detmath.h so the keep set is bit-identical to the oracle.
+#include "../../include/jm_detmath.h"
+#include "jm_common.h"
+
+namespace jm {
+
+struct Pt { float x, y; };
+
+struct RBox {           // per-box precomputation
+    float x1, y1, x2, y2;
+    float cs, sn;       // cos / sin of the heading
+    Pt c;               // centre
+    Pt corner[4];       // rotated corners
+    float area;
+};
+
+__device__ __forceinline__ float cross3(Pt p1, Pt p2, Pt p0) {
+    return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+}
+
+__device__ __forceinline__ Pt rotate_pt(Pt center, float c, float s, Pt p) {
+    Pt r;
+    r.x = (p.x - center.x) * c + (p.y - center.y) * s + center.x;
+    r.y = -(p.x - center.x) * s + (p.y - center.y) * c + center.y;
+    return r;
+}
+
+__device__ __forceinline__ RBox make_rbox(const float* b) {
+    RBox r;
+    r.x1 = b[0]; r.y1 = b[1]; r.x2 = b[2]; r.y2 = b[3];
+    jm_sincosf(b[4], &r.sn, &r.cs);
+    r.c.x = (r.x1 + r.x2) / 2; r.c.y = (r.y1 + r.y2) / 2;
+    const Pt raw[4] = {{r.x1, r.y1}, {r.x2, r.y1}, {r.x2, r.y2}, {r.x1, r.y2}};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.corner[k] = rotate_pt(r.c, r.cs, r.sn, raw[k]);
+    r.area = (r.x2 - r.x1) * (r.y2 - r.y1);
+    return r;
+}
+
+// check_in_box2d (iou3d_kernel.cu:50-65): rotate p by -angle (cos(-a)=cos a, sin(-a)=-sin a)
+__device__ __forceinline__ int in_box2d(const RBox& b, Pt p) {
+    const float MARGIN = 1e-5f;
+    const float angle_cos = b.cs, angle_sin = -b.sn;
+    const float rot_x = (p.x - b.c.x) * angle_cos + (p.y - b.c.y) * angle_sin + b.c.x;
+    const float rot_y = -(p.x - b.c.x) * angle_sin + (p.y - b.c.y) * angle_cos + b.c.y;
+    return (rot_x > b.x1 - MARGIN && rot_x < b.x2 + MARGIN && rot_y > b.y1 - MARGIN && rot_y < b.y2 + MARGIN);
+}
+
+// intersection (iou3d_kernel.cu:67-96)
+__device__ __forceinline__ int seg_intersection(Pt p1, Pt p0, Pt q1, Pt q0, Pt& ans) {
+    const int rect = fminf(p0.x, p1.x) <= fmaxf(q0.x, q1.x) && fminf(q0.x, q1.x) <= fmaxf(p0.x, p1.x) &&
+                     fminf(p0.y, p1.y) <= fmaxf(q0.y, q1.y) && fminf(q0.y, q1.y) <= fmaxf(p0.y, p1.y);
+    if (!rect) return 0;
+    const float s1 = cross3(q0, p1, p0);
+    const float s2 = cross3(p1, q1, p0);
+    const float s3 = cross3(p0, q1, q0);
+    const float s4 = cross3(q1, p1, q0);
+    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
+    const float s5 = cross3(q1, p1, p0);
+    if (fabs((double)(s5 - s1)) > 1e-8) {
+        ans.x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+        ans.y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+    } else {
+        const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+        const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+        const float D = a0 * b1 - a1 * b0;
+        ans.x = (b0 * c1 - b1 * c0) / D;
+        ans.y = (a1 * c0 - a0 * c1) / D;
+    }
+    return 1;
+}
+
+// box_overlap (iou3d_kernel.cu:108-212) on precomputed boxes
+__device__ float rbox_overlap(const RBox& A, const RBox& B) {
+    Pt cp[24];
+    float ang[24];
+    Pt center = {0.f, 0.f};
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Pt ans;
+            if (seg_intersection(A.corner[(i + 1) & 3], A.corner[i], B.corner[(j + 1) & 3], B.corner[j], ans)) {
+                cp[cnt] = ans;
+                center.x = center.x + ans.x;
+                center.y = center.y + ans.y;
+                ++cnt;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (in_box2d(A, B.corner[k])) {
+            center.x = center.x + B.corner[k].x; center.y = center.y + B.corner[k].y;
+            cp[cnt++] = B.corner[k];
+        }
+        if (in_box2d(B, A.corner[k])) {
+            center.x = center.x + A.corner[k].x; center.y = center.y + A.corner[k].y;
+            cp[cnt++] = A.corner[k];
+        }
+    }
+    if (cnt == 0) return 0.f;
+    center.x /= cnt;
+    center.y /= cnt;
+    for (int i = 0; i < cnt; ++i) ang[i] = jm_atan2f(cp[i].y - center.y, cp[i].x - center.x);
+    for (int j = 0; j < cnt - 1; ++j)
+        for (int i = 0; i < cnt - j - 1; ++i)
+            if (ang[i] > ang[i + 1]) {
+                const Pt t = cp[i]; cp[i] = cp[i + 1]; cp[i + 1] = t;
+                const float ta = ang[i]; ang[i] = ang[i + 1]; ang[i + 1] = ta;
+            }
+    float area = 0.f;
+    for (int k = 0; k < cnt - 1; ++k) {
+        const float ux = cp[k].x - cp[0].x, uy = cp[k].y - cp[0].y;
+        const float vx = cp[k + 1].x - cp[0].x, vy = cp[k + 1].y - cp[0].y;
+        area += ux * vy - uy * vx;
+    }
+    return (float)(fabs((double)area) / 2.0);
+}
+
+__device__ __forceinline__ float rbox_iou(const RBox& A, const RBox& B) {
+    const float s = rbox_overlap(A, B);
+    return s / fmaxf(A.area + B.area - s, (float)1e-8);
+}
+
+// iou_normal (iou3d_kernel.cu:295-303)
+__device__ __forceinline__ float iou_normal(const float* a, const float* b) {
+    const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+    const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+    const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+    const float interS = width * height;
+    const float Sa = (a[2] - a[0]) * (a[3] - a[1]);
+    const float Sb = (b[2] - b[0]) * (b[3] - b[1]);
+    return interS / fmaxf(Sa + Sb - interS, (float)1e-8);
+}
+
+// ------------------------------------------------------------------ pairwise overlap / IoU
+// block (16 x 16): threadIdx.y -> a, threadIdx.x -> b, per-box precompute shared through LDS
+template <bool IOU>
+__global__ void __launch_bounds__(256)
+boxes_pair_kernel(int num_a, const float* __restrict__ boxes_a, int num_b, const float* __restrict__ boxes_b,
+                  float* __restrict__ ans) {
+    __shared__ RBox sa[16], sb[16];
+    const int a0 = blockIdx.y * 16, b0 = blockIdx.x * 16;
+    const int t = threadIdx.y * 16 + threadIdx.x;
+    if (t < 16) { if (a0 + t < num_a) sa[t] = make_rbox(boxes_a + (size_t)(a0 + t) * 5); }
+    else if (t < 32) { if (b0 + t - 16 < num_b) sb[t - 16] = make_rbox(boxes_b + (size_t)(b0 + t - 16) * 5); }
+    __syncthreads();
+    const int ai = a0 + threadIdx.y, bi = b0 + threadIdx.x;
+    if (ai >= num_a || bi >= num_b) return;
+    ans[(size_t)ai * num_b + bi] = IOU ? rbox_iou(sa[threadIdx.y], sb[threadIdx.x]) : rbox_overlap(sa[threadIdx.y], sb[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------ NMS mask (upper triangle)
+template <bool NORMAL>
+__global__ void __launch_bounds__(64)
+nms_mask_kernel(int n, float thresh, const float* __restrict__ boxes, unsigned long long* __restrict__ mask) {
+    const int col_blocks = (n + 63) / 64;
+    // linear block id -> (row_start <= col_start) pair of the upper triangle
+    int rb = 0, cb = 0;
+    {
+        // row r owns (col_blocks - r) tiles; find r by solving the triangular number, then fix up
+        long long id = blockIdx.x;
+        const double cbd = (double)col_blocks;
+        int r = (int)floor((2.0 * cbd + 1.0 - sqrt((2.0 * cbd + 1.0) * (2.0 * cbd + 1.0) - 8.0 * (double)id)) / 2.0);
+        if (r < 0) r = 0;
+        if (r >= col_blocks) r = col_blocks - 1;
+        auto start_of = [&](int rr) { return (long long)rr * col_blocks - (long long)rr * (rr - 1) / 2; };
+        while (r > 0 && start_of(r) > id) --r;
+        while (r + 1 < col_blocks && start_of(r + 1) <= id) ++r;
+        rb = r; cb = r + (int)(id - start_of(r));
+    }
+    const int tx = threadIdx.x;
+    const int row_size = min(n - rb * 64, 64), col_size = min(n - cb * 64, 64);
+    __shared__ RBox scol[NORMAL ? 1 : 64];
+    __shared__ float sraw[64 * 5];
+    if (tx < col_size) {
+        const float* src = boxes + (size_t)(cb * 64 + tx) * 5;
+        if (NORMAL) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) sraw[tx * 5 + q] = src[q];
+        } else {
+            scol[tx] = make_rbox(src);
+        }
+    }
+    __syncthreads();
+    if (tx < row_size) {
+        const int cur = rb * 64 + tx;
+        const float* cur_box = boxes + (size_t)cur * 5;
+        unsigned long long t = 0;
+        const int start = (rb == cb) ? tx + 1 : 0;
+        if (NORMAL) {
+            const float cb5[5] = {cur_box[0], cur_box[1], cur_box[2], cur_box[3], cur_box[4]};
+            for (int i = start; i < col_size; ++i)
+                if (iou_normal(cb5, sraw + i * 5) > thresh) t |= 1ULL << i;
+        } else {
+            const RBox me = make_rbox(cur_box);
+            for (int i = start; i < col_size; ++i)
+                if (rbox_iou(me, scol[i]) > thresh) t |= 1ULL << i;
+        }
+        mask[(size_t)cur * col_blocks + cb] = t;
+    }
+}
+
+// ------------------------------------------------------------------ NMS greedy reduce (device)
+// Single workgroup.  remv (col_blocks x u64) lives in LDS.  Semantics of iou3d.cpp:98-114:
+// ascending i, keep i if its bit is not set in remv, then remv |= mask_row(i) for column
+// blocks >= i/64.
+__global__ void __launch_bounds__(1024)
+nms_reduce_kernel(int n, const unsigned long long* __restrict__ mask, long long* __restrict__ keep,
+                  int* __restrict__ num_keep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];  // [col_blocks] + 1 (kept bits)
+    const int col_blocks = (n + 63) / 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int j = tid; j <= col_blocks; j += blockDim.x) remv[j] = 0ULL;
+    __syncthreads();
+    int count = 0;  // uniform
+    for (int rb = 0; rb < col_blocks; ++rb) {
+        const int rows = min(64, n - rb * 64);
+        if (tid < 64) {  // wave 0
+            unsigned long long diag = 0ULL;
+            if (lane < rows) diag = mask[(size_t)(rb * 64 + lane) * col_blocks + rb];
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            unsigned long long r = remv[rb];
+            unsigned long long kept = 0ULL;
+            for (int bit = 0; bit < rows; ++bit) {  // uniform scalar loop
+                if (!((r >> bit) & 1ULL)) {
+                    kept |= 1ULL << bit;
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)dlo, bit);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)dhi, bit);
+                    r |= ((unsigned long long)hi << 32) | lo;
+                }
+            }
+            if ((kept >> lane) & 1ULL) keep[count + __popcll(kept & ((1ULL << lane) - 1ULL))] = rb * 64 + lane;
+            if (lane == 0) remv[col_blocks] = kept;
+        }
+        __syncthreads();
+        const unsigned long long kept = remv[col_blocks];
+        count += __popcll(kept);
+        // OR the kept rows of this block into the later column blocks
+        for (int j = rb + 1 + tid; j < col_blocks; j += blockDim.x) {
+            unsigned long long acc = remv[j];
+            unsigned long long kk = kept;
+            while (kk) {
+                const int i = __ffsll((long long)kk) - 1;
+                kk &= kk - 1ULL;
+                acc |= mask[(size_t)(rb * 64 + i) * col_blocks + j];
+            }
+            remv[j] = acc;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *num_keep = count;
+}
+
+}  // namespace jm
+
+using namespace jm;
+
+extern "C" int jm_boxes_overlap_bev(int num_a, const float* boxes_a, int num_b, const float* boxes_b,
+                                    float* ans_overlap, jm_stream_t stream) {
+    JM_REQUIRE(num_a >= 0 && num_b >= 0, "boxes_overlap_bev: bad sizes");
+    if (num_a == 0 || num_b == 0) return JM_OK;
+    JM_REQUIRE(boxes_a && boxes_b && ans_overlap, "boxes_overlap_bev: null pointer");
+    hipLaunchKernelGGL(boxes_pair_kernel<false>, dim3(divup(num_b, 16), divup(num_a, 16)), dim3(16, 16), 0,
+                       (hipStream_t)stream, num_a, boxes_a, num_b, boxes_b, ans_overlap);
+    return check_launch("boxes_overlap_bev");
+}
+
+extern "C" int jm_boxes_iou_bev(int num_a, const float* boxes_a, int num_b, const float* boxes_b, float* ans_iou,
+                                jm_stream_t stream) {
+    JM_REQUIRE(num_a >= 0 && num_b >= 0, "boxes_iou_bev: bad sizes");
+    if (num_a == 0 || num_b == 0) return JM_OK;
+    JM_REQUIRE(boxes_a && boxes_b && ans_iou, "boxes_iou_bev: null pointer");
+    hipLaunchKernelGGL(boxes_pair_kernel<true>, dim3(divup(num_b, 16), divup(num_a, 16)), dim3(16, 16), 0,
+                       (hipStream_t)stream, num_a, boxes_a, num_b, boxes_b, ans_iou);
+    return check_launch("boxes_iou_bev");
+}
+
+extern "C" size_t jm_nms_workspace_bytes(int boxes_num) {
+    if (boxes_num <= 0) return 0;
+    const size_t cb = (size_t)(boxes_num + 63) / 64;
+    return (size_t)boxes_num * cb * sizeof(unsigned long long);
+}
+
+extern "C" int jm_nms_mask(int boxes_num, const float* boxes, float nms_overlap_thresh, int normal,
+                           unsigned long long* mask, jm_stream_t stream) {
+    JM_REQUIRE(boxes_num >= 0, "nms_mask: bad size");
+    if (boxes_num == 0) return JM_OK;
+    JM_REQUIRE(boxes && mask, "nms_mask: null pointer");
+    const long long cb = (boxes_num + 63) / 64;
+    const long long tiles = cb * (cb + 1) / 2;
+    JM_REQUIRE(tiles < (1LL << 31), "nms_mask: too many boxes");
+    if (normal)
+        hipLaunchKernelGGL(nms_mask_kernel<true>, dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, boxes_num,
+                           nms_overlap_thresh, boxes, mask);
+    else
+        hipLaunchKernelGGL(nms_mask_kernel<false>, dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, boxes_num,
+                           nms_overlap_thresh, boxes, mask);
+    return check_launch("nms_mask");
+}
+
+extern "C" int jm_nms(int boxes_num, const float* boxes, float nms_overlap_thresh, int normal, int64_t* keep,
+                      int* num_keep, void* ws, size_t ws_bytes, jm_stream_t stream) {
+    JM_REQUIRE(boxes_num >= 0, "nms: bad size");
+    JM_REQUIRE(num_keep, "nms: null num_keep");
+    if (boxes_num == 0) {
+        (void)hipMemsetAsync(num_keep, 0, sizeof(int), (hipStream_t)stream);
+        return check_launch("nms(memset)");
+    }
+    JM_REQUIRE(boxes && keep && ws, "nms: null pointer");
+    if (ws_bytes < jm_nms_workspace_bytes(boxes_num)) {
+        set_error("nms: workspace %zu < %zu bytes", ws_bytes, jm_nms_workspace_bytes(boxes_num));
+        return JM_EWORKSPACE;
+    }
+    int rc = jm_nms_mask(boxes_num, boxes, nms_overlap_thresh, normal, (unsigned long long*)ws, stream);
+    if (rc) return rc;
+    const int cb = (boxes_num + 63) / 64;
+    const size_t lds = (size_t)(cb + 1) * sizeof(unsigned long long);
+    JM_REQUIRE(lds <= 160 * 1024, "nms: %d boxes exceed the on-device reduce capacity", boxes_num);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)nms_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int threads = cb >= 1024 ? 1024 : (cb <= 64 ? 64 : ((cb + 63) / 64 * 64));
+    hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, boxes_num,
+                       (const unsigned long long*)ws, (long long*)keep, num_keep);
+    return check_launch("nms_reduce");
+}

@@ -1,0 +1,88 @@
+// jm_common.h — shared helpers for the gfx950 kernels (wave64 everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/jmodt_hip.h"
+
+namespace jm {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return JM_ELAUNCH;
+    }
+    return JM_OK;
+}
+
+#define JM_REQUIRE(cond, ...)          \
+    do {                               \
+        if (!(cond)) {                 \
+            jm::set_error(__VA_ARGS__); \
+            return JM_EINVAL;          \
+        }                              \
+    } while (0)
+
+static inline int divup(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- wave64 DPP reductions ---------------------------------------------------------------
+// DPP control words (gfx9 encoding): quad_perm = 0x00..0xFF, row_mirror 0x140,
+// row_half_mirror 0x141, row_bcast15 0x142, row_bcast31 0x143.
+#define JM_DPP_XOR1 0xB1            /* quad_perm [1,0,3,2] */
+#define JM_DPP_XOR2 0x4E            /* quad_perm [2,3,0,1] */
+#define JM_DPP_HALF_MIRROR 0x141
+#define JM_DPP_MIRROR 0x140
+#define JM_DPP_BCAST15 0x142
+#define JM_DPP_BCAST31 0x143
+
+// max over the 64 lanes of a signed int, returned wave-uniform (SGPR via readlane 63).
+// 4 butterfly steps make every 16-lane row uniform, then two row broadcasts fold the rows.
+__device__ __forceinline__ int wave_max_i32(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, JM_DPP_XOR1, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, JM_DPP_XOR2, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, JM_DPP_HALF_MIRROR, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, JM_DPP_MIRROR, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, JM_DPP_BCAST15, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, JM_DPP_BCAST31, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1));
+    v = fmaxf(v, __shfl_xor(v, 2));
+    v = fmaxf(v, __shfl_xor(v, 4));
+    v = fmaxf(v, __shfl_xor(v, 8));
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ int mbcnt(unsigned long long mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// squared distance with the contraction nvcc/clang apply to dx*dx + dy*dy + dz*dz
+// (see oracle/jmodt_oracle.c header): fma(dz,dz, fma(dx,dx, dy*dy)).  The library is built
+// with -ffp-contract=off, so these are the only fused operations.
+__device__ __forceinline__ float sqdist3(float dx, float dy, float dz) {
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+}
+
+}  // namespace jm

@@ -1,0 +1,261 @@
+// pointnet2_gather.hip — gather / group / three_nn / three_interpolate (+ grads) for gfx950.
+//
+// Replaces gather_points_* (sampling_gpu.cu:8-83), group_points_* (group_points_gpu.cu:8-86),
+// three_nn / three_interpolate(_grad) (interpolate_gpu.cu:9-161) of jmodt/ops/pointnet2/src.
+//
+// Common shape of the gather kernels: the index is read ONCE per output position and reused
+// for a block of channels (the reference re-reads idx for every channel: grid.y = C), output
+// stores are contiguous along the fastest axis and 16 bytes wide where alignment allows.
+#include "jm_common.h"
+
+namespace jm {
+
+// ------------------------------------------------------------------ gather_points
+__global__ void gather_points_kernel(int c, int n, int m, const float* __restrict__ points,
+                                     const int* __restrict__ idx, float* __restrict__ out) {
+    const int bi = blockIdx.z;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int src = idx[(size_t)bi * m + j];
+    const int c0 = blockIdx.y * 8;
+    const int c1 = min(c, c0 + 8);
+    for (int ci = c0; ci < c1; ++ci)
+        out[((size_t)bi * c + ci) * m + j] = points[((size_t)bi * c + ci) * n + src];
+}
+
+__global__ void gather_points_grad_kernel(int c, int n, int m, const float* __restrict__ grad_out,
+                                          const int* __restrict__ idx, float* __restrict__ grad_points) {
+    const int bi = blockIdx.z;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int dst = idx[(size_t)bi * m + j];
+    const int c0 = blockIdx.y * 8;
+    const int c1 = min(c, c0 + 8);
+    for (int ci = c0; ci < c1; ++ci)
+        unsafeAtomicAdd(grad_points + ((size_t)bi * c + ci) * n + dst, grad_out[((size_t)bi * c + ci) * m + j]);
+}
+
+// ------------------------------------------------------------------ group_points
+// out[b,c,q] = points[b,c,idx[b,q]],  q = p*nsample + s  (contiguous).  Each thread owns 4
+// consecutive q (one int4 index load, one float4 store per channel) and CPT channels.
+constexpr int GP_CPT = 8;
+
+template <bool VEC4>
+__global__ void __launch_bounds__(256)
+group_points_kernel(int c, int n, int q_total, const float* __restrict__ points, const int* __restrict__ idx,
+                    float* __restrict__ out) {
+    const int bi = blockIdx.z;
+    const int c0 = blockIdx.y * GP_CPT;
+    const int c1 = min(c, c0 + GP_CPT);
+    const int* ix = idx + (size_t)bi * q_total;
+    if (VEC4) {
+        const int q = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+        if (q >= q_total) return;
+        const int4 i4 = *reinterpret_cast<const int4*>(ix + q);
+#pragma unroll 4
+        for (int ci = c0; ci < c1; ++ci) {
+            const float* src = points + ((size_t)bi * c + ci) * n;
+            float4 v;
+            v.x = src[i4.x]; v.y = src[i4.y]; v.z = src[i4.z]; v.w = src[i4.w];
+            *reinterpret_cast<float4*>(out + ((size_t)bi * c + ci) * q_total + q) = v;
+        }
+    } else {
+        const int q = blockIdx.x * blockDim.x + threadIdx.x;
+        if (q >= q_total) return;
+        const int i = ix[q];
+        for (int ci = c0; ci < c1; ++ci)
+            out[((size_t)bi * c + ci) * q_total + q] = points[((size_t)bi * c + ci) * n + i];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+group_points_grad_kernel(int c, int n, int q_total, const float* __restrict__ grad_out,
+                         const int* __restrict__ idx, float* __restrict__ grad_points) {
+    const int bi = blockIdx.z;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= q_total) return;
+    const int i = idx[(size_t)bi * q_total + q];
+    const int c0 = blockIdx.y * GP_CPT;
+    const int c1 = min(c, c0 + GP_CPT);
+    for (int ci = c0; ci < c1; ++ci)
+        unsafeAtomicAdd(grad_points + ((size_t)bi * c + ci) * n + i, grad_out[((size_t)bi * c + ci) * q_total + q]);
+}
+
+// ------------------------------------------------------------------ three_nn
+// Lane = unknown point; the known point is wave-uniform and arrives through scalar loads
+// (same structure as ball_query).  best* are kept in float with +inf start, which is
+// decision-for-decision identical to the reference's double bests initialised to 1e40
+// (every finite float d satisfies d < 1e40 and d < inf alike; inf < either is false).
+__global__ void __launch_bounds__(256)
+three_nn_kernel(int n, int m, const float* __restrict__ unknown, const float* __restrict__ known,
+                float* __restrict__ dist2, int* __restrict__ idx) {
+    const int bi = blockIdx.y;
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = pi < n;
+    const float* u = unknown + ((size_t)bi * n + (active ? pi : 0)) * 3;
+    const float ux = u[0], uy = u[1], uz = u[2];
+    const float* kn = known + (size_t)bi * m * 3;
+    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+    int i1 = 0, i2 = 0, i3 = 0;
+    auto visit = [&](int k, float x, float y, float z) {
+        const float d = sqdist3(ux - x, uy - y, uz - z);
+        const bool c1 = d < b1, c2 = d < b2, c3 = d < b3;
+        // if/else-if chain of interpolate_gpu.cu:37-49, branch-free (c1 => c2 => c3)
+        b3 = c2 ? b2 : (c3 ? d : b3);  i3 = c2 ? i2 : (c3 ? k : i3);
+        b2 = c1 ? b1 : (c2 ? d : b2);  i2 = c1 ? i1 : (c2 ? k : i2);
+        b1 = c1 ? d : b1;              i1 = c1 ? k : i1;
+    };
+    int k = 0;
+    if ((reinterpret_cast<uintptr_t>(kn) & 15u) == 0) {
+        for (; k + 4 <= m; k += 4) {
+            const float4* q = reinterpret_cast<const float4*>(kn + (size_t)k * 3);  // wave-uniform
+            const float4 a = q[0], b = q[1], c = q[2];
+            visit(k + 0, a.x, a.y, a.z);
+            visit(k + 1, a.w, b.x, b.y);
+            visit(k + 2, b.z, b.w, c.x);
+            visit(k + 3, c.y, c.z, c.w);
+        }
+    }
+    for (; k < m; ++k) visit(k, kn[k * 3 + 0], kn[k * 3 + 1], kn[k * 3 + 2]);
+    if (active) {
+        float* d = dist2 + ((size_t)bi * n + pi) * 3;
+        int* o = idx + ((size_t)bi * n + pi) * 3;
+        d[0] = b1; d[1] = b2; d[2] = b3;
+        o[0] = i1; o[1] = i2; o[2] = i3;
+    }
+}
+
+// ------------------------------------------------------------------ three_interpolate
+constexpr int TI_CPT = 8;
+
+__global__ void __launch_bounds__(256)
+three_interpolate_kernel(int c, int m, int n, const float* __restrict__ points, const int* __restrict__ idx,
+                         const float* __restrict__ weight, float* __restrict__ out) {
+    const int bi = blockIdx.z;
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= n) return;
+    const int* ix = idx + ((size_t)bi * n + pi) * 3;
+    const float* w = weight + ((size_t)bi * n + pi) * 3;
+    const int i0 = ix[0], i1 = ix[1], i2 = ix[2];
+    const float w0 = w[0], w1 = w[1], w2 = w[2];
+    const int c0 = blockIdx.y * TI_CPT;
+    const int c1 = min(c, c0 + TI_CPT);
+#pragma unroll 4
+    for (int ci = c0; ci < c1; ++ci) {
+        const float* src = points + ((size_t)bi * c + ci) * m;
+        // w0*p0 + w1*p1 + w2*p2 with the oracle's contraction
+        out[((size_t)bi * c + ci) * n + pi] = __builtin_fmaf(w2, src[i2], __builtin_fmaf(w0, src[i0], w1 * src[i1]));
+    }
+}
+
+__global__ void __launch_bounds__(256)
+three_interpolate_grad_kernel(int c, int n, int m, const float* __restrict__ grad_out,
+                              const int* __restrict__ idx, const float* __restrict__ weight,
+                              float* __restrict__ grad_points) {
+    const int bi = blockIdx.z;
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= n) return;
+    const int* ix = idx + ((size_t)bi * n + pi) * 3;
+    const float* w = weight + ((size_t)bi * n + pi) * 3;
+    const int i0 = ix[0], i1 = ix[1], i2 = ix[2];
+    const float w0 = w[0], w1 = w[1], w2 = w[2];
+    const int c0 = blockIdx.y * TI_CPT;
+    const int c1 = min(c, c0 + TI_CPT);
+    for (int ci = c0; ci < c1; ++ci) {
+        const float g = grad_out[((size_t)bi * c + ci) * n + pi];
+        float* dst = grad_points + ((size_t)bi * c + ci) * m;
+        unsafeAtomicAdd(dst + i0, g * w0);
+        unsafeAtomicAdd(dst + i1, g * w1);
+        unsafeAtomicAdd(dst + i2, g * w2);
+    }
+}
+
+}  // namespace jm
+
+using namespace jm;
+
+extern "C" int jm_gather_points(int b, int c, int n, int npoints, const float* points, const int* idx, float* out,
+                                jm_stream_t stream) {
+    JM_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0, "gather_points: bad sizes");
+    if (b == 0 || c == 0 || npoints == 0) return JM_OK;
+    JM_REQUIRE(points && idx && out, "gather_points: null pointer");
+    JM_REQUIRE(b <= 65535, "gather_points: batch %d > 65535", b);
+    hipLaunchKernelGGL(gather_points_kernel, dim3(divup(npoints, 256), divup(c, 8), b), dim3(256), 0,
+                       (hipStream_t)stream, c, n, npoints, points, idx, out);
+    return check_launch("gather_points");
+}
+
+extern "C" int jm_gather_points_grad(int b, int c, int n, int npoints, const float* grad_out, const int* idx,
+                                     float* grad_points, jm_stream_t stream) {
+    JM_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0, "gather_points_grad: bad sizes");
+    if (b == 0 || c == 0 || npoints == 0) return JM_OK;
+    JM_REQUIRE(grad_out && idx && grad_points, "gather_points_grad: null pointer");
+    JM_REQUIRE(b <= 65535, "gather_points_grad: batch %d > 65535", b);
+    hipLaunchKernelGGL(gather_points_grad_kernel, dim3(divup(npoints, 256), divup(c, 8), b), dim3(256), 0,
+                       (hipStream_t)stream, c, n, npoints, grad_out, idx, grad_points);
+    return check_launch("gather_points_grad");
+}
+
+extern "C" int jm_group_points(int b, int c, int n, int npoints, int nsample, const float* points, const int* idx,
+                               float* out, jm_stream_t stream) {
+    JM_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0, "group_points: bad sizes");
+    const long long qt = (long long)npoints * nsample;
+    if (b == 0 || c == 0 || qt == 0) return JM_OK;
+    JM_REQUIRE(points && idx && out, "group_points: null pointer");
+    JM_REQUIRE(b <= 65535 && divup(c, GP_CPT) <= 65535 && qt < (1LL << 31), "group_points: shape too large");
+    const int q_total = (int)qt;
+    const bool vec = (q_total % 4 == 0) && ((reinterpret_cast<uintptr_t>(idx) & 15u) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
+    if (vec)
+        hipLaunchKernelGGL(group_points_kernel<true>, dim3(divup(q_total / 4, 256), divup(c, GP_CPT), b), dim3(256), 0,
+                           (hipStream_t)stream, c, n, q_total, points, idx, out);
+    else
+        hipLaunchKernelGGL(group_points_kernel<false>, dim3(divup(q_total, 256), divup(c, GP_CPT), b), dim3(256), 0,
+                           (hipStream_t)stream, c, n, q_total, points, idx, out);
+    return check_launch("group_points");
+}
+
+extern "C" int jm_group_points_grad(int b, int c, int n, int npoints, int nsample, const float* grad_out,
+                                    const int* idx, float* grad_points, jm_stream_t stream) {
+    JM_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0, "group_points_grad: bad sizes");
+    const long long qt = (long long)npoints * nsample;
+    if (b == 0 || c == 0 || qt == 0) return JM_OK;
+    JM_REQUIRE(grad_out && idx && grad_points, "group_points_grad: null pointer");
+    JM_REQUIRE(b <= 65535 && divup(c, GP_CPT) <= 65535 && qt < (1LL << 31), "group_points_grad: shape too large");
+    hipLaunchKernelGGL(group_points_grad_kernel, dim3(divup((int)qt, 256), divup(c, GP_CPT), b), dim3(256), 0,
+                       (hipStream_t)stream, c, n, (int)qt, grad_out, idx, grad_points);
+    return check_launch("group_points_grad");
+}
+
+extern "C" int jm_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2, int* idx,
+                           jm_stream_t stream) {
+    JM_REQUIRE(b >= 0 && n >= 0 && m >= 0, "three_nn: bad sizes");
+    if (b == 0 || n == 0) return JM_OK;
+    JM_REQUIRE(unknown && dist2 && idx && (known || m == 0), "three_nn: null pointer");
+    JM_REQUIRE(b <= 65535, "three_nn: batch %d > 65535", b);
+    hipLaunchKernelGGL(three_nn_kernel, dim3(divup(n, 256), b), dim3(256), 0, (hipStream_t)stream, n, m, unknown,
+                       known, dist2, idx);
+    return check_launch("three_nn");
+}
+
+extern "C" int jm_three_interpolate(int b, int c, int m, int n, const float* points, const int* idx,
+                                    const float* weight, float* out, jm_stream_t stream) {
+    JM_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "three_interpolate: bad sizes");
+    if (b == 0 || c == 0 || n == 0) return JM_OK;
+    JM_REQUIRE(points && idx && weight && out, "three_interpolate: null pointer");
+    JM_REQUIRE(b <= 65535 && divup(c, TI_CPT) <= 65535, "three_interpolate: shape too large");
+    hipLaunchKernelGGL(three_interpolate_kernel, dim3(divup(n, 256), divup(c, TI_CPT), b), dim3(256), 0,
+                       (hipStream_t)stream, c, m, n, points, idx, weight, out);
+    return check_launch("three_interpolate");
+}
+
+extern "C" int jm_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out, const int* idx,
+                                         const float* weight, float* grad_points, jm_stream_t stream) {
+    JM_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "three_interpolate_grad: bad sizes");
+    if (b == 0 || c == 0 || n == 0) return JM_OK;
+    JM_REQUIRE(grad_out && idx && weight && grad_points, "three_interpolate_grad: null pointer");
+    JM_REQUIRE(b <= 65535 && divup(c, TI_CPT) <= 65535, "three_interpolate_grad: shape too large");
+    hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3(divup(n, 256), divup(c, TI_CPT), b), dim3(256), 0,
+                       (hipStream_t)stream, c, n, m, grad_out, idx, weight, grad_points);
+    return check_launch("three_interpolate_grad");
+}

@@ -1,0 +1,70 @@
+"""`pointnet2_cuda` extension-module shim (pointnet2_api.cpp:10-24) over the C ABI."""
+import torch
+
+from .. import _lib as L
+
+f32, i32 = torch.float32, torch.int32
+
+
+def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
+    lib = L.load()
+    L.check(lib.jm_ball_query(b, n, m, float(radius), nsample, L.dev(new_xyz, f32, "new_xyz"), L.dev(xyz, f32, "xyz"),
+                              L.dev(idx, i32, "idx"), L.stream_ptr()), "ball_query_wrapper")
+    return 1
+
+
+def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
+    lib = L.load()
+    L.check(lib.jm_group_points(b, c, n, npoints, nsample, L.dev(points, f32, "points"), L.dev(idx, i32, "idx"),
+                                L.dev(out, f32, "out"), L.stream_ptr()), "group_points_wrapper")
+    return 1
+
+
+def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
+    lib = L.load()
+    L.check(lib.jm_group_points_grad(b, c, n, npoints, nsample, L.dev(grad_out, f32, "grad_out"),
+                                     L.dev(idx, i32, "idx"), L.dev(grad_points, f32, "grad_points"), L.stream_ptr()),
+            "group_points_grad_wrapper")
+    return 1
+
+
+def gather_points_wrapper(b, c, n, npoints, points, idx, out):
+    lib = L.load()
+    L.check(lib.jm_gather_points(b, c, n, npoints, L.dev(points, f32, "points"), L.dev(idx, i32, "idx"),
+                                 L.dev(out, f32, "out"), L.stream_ptr()), "gather_points_wrapper")
+    return 1
+
+
+def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
+    lib = L.load()
+    L.check(lib.jm_gather_points_grad(b, c, n, npoints, L.dev(grad_out, f32, "grad_out"), L.dev(idx, i32, "idx"),
+                                      L.dev(grad_points, f32, "grad_points"), L.stream_ptr()),
+            "gather_points_grad_wrapper")
+    return 1
+
+
+def farthest_point_sampling_wrapper(b, n, m, points, temp, idx):
+    lib = L.load()
+    L.check(lib.jm_furthest_point_sampling(b, n, m, L.dev(points, f32, "points"), L.dev(temp, f32, "temp"),
+                                           L.dev(idx, i32, "idx"), L.stream_ptr()), "farthest_point_sampling_wrapper")
+    return 1
+
+
+def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
+    lib = L.load()
+    L.check(lib.jm_three_nn(b, n, m, L.dev(unknown, f32, "unknown"), L.dev(known, f32, "known"),
+                            L.dev(dist2, f32, "dist2"), L.dev(idx, i32, "idx"), L.stream_ptr()), "three_nn_wrapper")
+
+
+def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
+    lib = L.load()
+    L.check(lib.jm_three_interpolate(b, c, m, n, L.dev(points, f32, "points"), L.dev(idx, i32, "idx"),
+                                     L.dev(weight, f32, "weight"), L.dev(out, f32, "out"), L.stream_ptr()),
+            "three_interpolate_wrapper")
+
+
+def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
+    lib = L.load()
+    L.check(lib.jm_three_interpolate_grad(b, c, n, m, L.dev(grad_out, f32, "grad_out"), L.dev(idx, i32, "idx"),
+                                          L.dev(weight, f32, "weight"), L.dev(grad_points, f32, "grad_points"),
+                                          L.stream_ptr()), "three_interpolate_grad_wrapper")

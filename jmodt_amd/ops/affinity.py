@@ -1,0 +1,117 @@
+"""Pairwise link / start-end affinity head on the fp32 matrix cores.
+
+Mirrors the two pieces of the reference that the north star names:
+  * the heads themselves — `link_layer`, `se_layer` of jmodt/detection/modeling/rcnn.py:91-111:
+    Conv1d(512,512)+ReLU, Dropout(DP_RATIO=0), Conv1d(512,512)+ReLU, Conv1d(512,1), bias, no BN
+    (config.py:166-169); child indices 0/2/3 and `.conv.{weight,bias}` names are kept so a
+    reference checkpoint's `rcnn_net.link_layer.*` / `rcnn_net.se_layer.*` entries load as is;
+  * the inference-time affinity of jmodt/tracking/tracker.py:81-112:
+        cor = |pred_i - det_j|;  S = link(cor);  A = (softmax(S,1) + softmax(S,0)) / 2
+        start = se(cor.mean(0)),  end = se(cor.mean(1))
+    evaluated by ONE C-ABI call that never materialises the (P*D, 512) pair tensor.
+"""
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .pointnet2 import pytorch_utils as pt_utils
+
+_f32 = torch.float32
+
+
+def make_affinity_mlp(channel_in: int = 512, fc=(512, 512), dp_ratio: float = 0.0, use_bn: bool = False) -> nn.Sequential:
+    """builds link_layer / se_layer exactly as rcnn.py:91-111 does (xavier-normal weights, zero
+    bias: rcnn.py:116-134)"""
+    layers = []
+    pre = channel_in
+    for width in fc:
+        layers.append(pt_utils.Conv1d(pre, width, bn=use_bn))
+        pre = width
+    layers.append(pt_utils.Conv1d(pre, 1, activation=None))
+    if dp_ratio >= 0:
+        layers.insert(1, nn.Dropout(dp_ratio))
+    head = nn.Sequential(*layers)
+    for m in head.modules():
+        if isinstance(m, nn.Conv1d):
+            nn.init.xavier_normal_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+    return head
+
+
+def _pack(head: nn.Sequential):
+    """(Mlp3 struct, tensors kept alive) from a 3-conv head; supports exactly the reference layout"""
+    convs = [m for m in head.modules() if isinstance(m, nn.Conv1d)]
+    if len(convs) != 3 or any(isinstance(m, (nn.BatchNorm1d,)) for m in head.modules()):
+        raise NotImplementedError("affinity kernel supports the reference head: 3 Conv1d(k=1), no BN")
+    for m in head.modules():
+        if isinstance(m, nn.Dropout) and m.p != 0 and head.training:
+            raise NotImplementedError("affinity kernel: dropout p>0 in training mode")
+    c1, c2, c3 = convs
+    if c3.out_channels != 1 or any(c.kernel_size != (1,) for c in convs):
+        raise NotImplementedError("affinity kernel: kernel_size must be 1 and the last layer 1-wide")
+    keep = []
+
+    def dp(t):
+        t = t.detach().to(_f32).contiguous()
+        if not t.is_cuda:
+            raise RuntimeError("affinity head weights must live on the GPU (jmodt_amd has no CPU path)")
+        keep.append(t)
+        return ctypes.c_void_p(t.data_ptr())
+
+    def bias(c):
+        return c.bias if c.bias is not None else torch.zeros(c.out_channels, device=c.weight.device)
+
+    s = L.Mlp3(c1.in_channels, c1.out_channels, c2.out_channels, dp(c1.weight.view(c1.out_channels, -1)), dp(bias(c1)),
+               dp(c2.weight.view(c2.out_channels, -1)), dp(bias(c2)), dp(c3.weight.view(-1)), dp(bias(c3)))
+    return s, keep
+
+
+@torch.no_grad()
+def pairwise_affinity(pred_features: torch.Tensor, det_features: torch.Tensor, link_model: nn.Sequential,
+                      se_model: Optional[nn.Sequential] = None, return_raw: bool = False
+                      ) -> Tuple[torch.Tensor, ...]:
+    """pred_features (P, C), det_features (D, C) ->
+        link_scores (P, D)  dual-softmax affinity             (tracker.py:86-89)
+        start_logits (D), end_logits (P)  raw se outputs      (tracker.py:105-110 applies
+                                                               w_se * sigmoid on top)
+    (+ raw link scores (P, D) when return_raw)."""
+    lib = L.load()
+    pf = pred_features.to(_f32).contiguous()
+    df = det_features.to(_f32).contiguous()
+    P, D = pf.shape[0], df.shape[0]
+    dev = pf.device
+    link, keep1 = _pack(link_model)
+    se, keep2 = _pack(se_model) if se_model is not None else (None, [])
+    A = torch.empty((P, D), dtype=_f32, device=dev)
+    raw = torch.empty((P, D), dtype=_f32, device=dev) if return_raw else None
+    start = torch.empty((D,), dtype=_f32, device=dev)
+    end = torch.empty((P,), dtype=_f32, device=dev)
+    link_p = ctypes.byref(link)
+    se_p = ctypes.byref(se) if se is not None else None
+    ws_bytes = lib.jm_affinity_workspace_bytes(P, D, link_p, se_p)
+    ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+    L.check(lib.jm_affinity_forward(P, D, L.dev(pf, _f32, "pred_features"), L.dev(df, _f32, "det_features"), link_p,
+                                    se_p, ctypes.c_void_p(raw.data_ptr()) if raw is not None else None,
+                                    ctypes.c_void_p(A.data_ptr()), ctypes.c_void_p(start.data_ptr()),
+                                    ctypes.c_void_p(end.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws_bytes,
+                                    L.stream_ptr()), "pairwise_affinity")
+    out = (A, start, end) if se_model is not None else (A,)
+    return out + ((raw,) if return_raw else ())
+
+
+@torch.no_grad()
+def mlp3_forward(x: torch.Tensor, head: nn.Sequential) -> torch.Tensor:
+    """the same head on materialised rows x (M, C) -> (M)   (e.g. rcnn.py:272-285 start/end features)"""
+    lib = L.load()
+    x = x.to(_f32).contiguous()
+    mlp, keep = _pack(head)
+    y = torch.empty((x.shape[0],), dtype=_f32, device=x.device)
+    ws_bytes = lib.jm_mlp3_workspace_bytes(x.shape[0], ctypes.byref(mlp))
+    ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=x.device)
+    L.check(lib.jm_mlp3_forward(x.shape[0], L.dev(x, _f32, "x"), ctypes.byref(mlp), ctypes.c_void_p(y.data_ptr()),
+                                ctypes.c_void_p(ws.data_ptr()), ws_bytes, L.stream_ptr()), "mlp3_forward")
+    return y

@@ -1,0 +1,111 @@
+"""Set-abstraction / feature-propagation modules on the gfx950 operators.
+
+Mirror of jmodt/ops/pointnet2/pointnet2_modules.py: PointnetSAModuleMSG (:66-101),
+PointnetSAModule (:104-122), PointnetFPModule (:125-164) with keyword-only constructors and the
+same child names (`groupers`, `mlps`, `mlp`), so reference checkpoints load unchanged.  SA forward
+returns (new_xyz, new_features, idx); the third value is the FPS index list the LI-Fusion
+branch uses to carry image coordinates down the pyramid (backbone.py:167-171).
+
+MI355X-specific: when an SA level has exactly two ball-query scales (every RPN level,
+config.py:75-77) both neighbour lists come from ONE pass over the cloud (ball_query_dual).
+"""
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import pointnet2_utils
+from . import pytorch_utils as pt_utils
+
+
+class _PointnetSAModuleBase(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.npoint = None
+        self.groupers = None
+        self.mlps = None
+        self.pool_method = "max_pool"
+
+    def _pool(self, x: torch.Tensor) -> torch.Tensor:
+        # (B, C, npoint, nsample) -> (B, C, npoint)
+        if self.pool_method == "max_pool":
+            return x.amax(dim=3)
+        if self.pool_method == "avg_pool":
+            return x.mean(dim=3)
+        raise NotImplementedError(self.pool_method)
+
+    def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor] = None,
+                new_xyz: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+        """xyz (B, N, 3), features (B, C, N) -> new_xyz (B, npoint, 3),
+        new_features (B, sum_k mlps[k][-1], npoint), idx (B, npoint) or None"""
+        idx = None
+        if new_xyz is None and self.npoint is not None:
+            idx = pointnet2_utils.farthest_point_sample(xyz, self.npoint)
+            new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), idx) \
+                .transpose(1, 2).contiguous()
+
+        neigh: List[Optional[torch.Tensor]] = [None] * len(self.groupers)
+        if (len(self.groupers) == 2 and new_xyz is not None
+                and all(isinstance(g, pointnet2_utils.QueryAndGroup) for g in self.groupers)):
+            g0, g1 = self.groupers
+            neigh = list(pointnet2_utils.ball_query_dual(g0.radius, g0.nsample, g1.radius, g1.nsample, xyz, new_xyz))
+
+        pooled = []
+        for grouper, mlp, nb in zip(self.groupers, self.mlps, neigh):
+            if isinstance(grouper, pointnet2_utils.QueryAndGroup):
+                grouped = grouper(xyz, new_xyz, features, idx=nb)
+            else:
+                grouped = grouper(xyz, new_xyz, features)
+            pooled.append(self._pool(mlp(grouped)))
+        return new_xyz, torch.cat(pooled, dim=1), idx
+
+
+class PointnetSAModuleMSG(_PointnetSAModuleBase):
+    """set abstraction with multi-scale grouping"""
+
+    def __init__(self, *, npoint: int, radii: List[float], nsamples: List[int], mlps: List[List[int]], bn: bool = True,
+                 use_xyz: bool = True, pool_method="max_pool", instance_norm=False):
+        super().__init__()
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.npoint = npoint
+        self.pool_method = pool_method
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        for radius, nsample, spec in zip(radii, nsamples, mlps):
+            self.groupers.append(pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz)
+                                 if npoint is not None else pointnet2_utils.GroupAll(use_xyz))
+            if use_xyz:
+                spec[0] += 3  # in place, like the reference: callers observe the widened spec
+            self.mlps.append(pt_utils.SharedMLP(spec, bn=bn, instance_norm=instance_norm))
+
+
+class PointnetSAModule(PointnetSAModuleMSG):
+    """single-scale set abstraction"""
+
+    def __init__(self, *, mlp: List[int], npoint: int = None, radius: float = None, nsample: int = None,
+                 bn: bool = True, use_xyz: bool = True, pool_method="max_pool", instance_norm=False):
+        super().__init__(mlps=[mlp], npoint=npoint, radii=[radius], nsamples=[nsample], bn=bn, use_xyz=use_xyz,
+                         pool_method=pool_method, instance_norm=instance_norm)
+
+
+class PointnetFPModule(nn.Module):
+    """propagate features from a coarse set to a finer one: 3-NN inverse-distance interpolation,
+    skip concat, shared MLP"""
+
+    def __init__(self, *, mlp: List[int], bn: bool = True, activation="default"):
+        super().__init__()
+        self.mlp = pt_utils.SharedMLP(mlp, bn=bn, activation=activation)
+
+    def forward(self, unknown: torch.Tensor, known: Optional[torch.Tensor], unknow_feats: Optional[torch.Tensor],
+                known_feats: torch.Tensor) -> torch.Tensor:
+        """unknown (B, n, 3), known (B, m, 3), unknow_feats (B, C1, n), known_feats (B, C2, m)
+        -> (B, mlp[-1], n)"""
+        if known is not None:
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            dist_recip = 1.0 / (dist + 1e-8)
+            weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+            interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+        else:
+            interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
+        feats = interpolated if unknow_feats is None else torch.cat([interpolated, unknow_feats], dim=1)
+        return self.mlp(feats.unsqueeze(-1)).squeeze(-1)

@@ -1,0 +1,240 @@
+"""PointNet++ operator API on the gfx950 kernels.
+
+Mirror of jmodt/ops/pointnet2/pointnet2_utils.py: the same callables with the same argument
+meaning and return values —
+    farthest_point_sample(xyz, npoint)            (pointnet2_utils.py:10-36)
+    gather_operation(features, idx)               (:39-73)
+    three_nn(unknown, known) -> (dist, idx)       (:76-105)
+    three_interpolate(features, idx, weight)      (:108-153)
+    grouping_operation(features, idx)             (:156-197)
+    ball_query(radius, nsample, xyz, new_xyz)     (:200-228)
+    QueryAndGroup / GroupAll                      (:231-290)
+— all `torch.autograd.Function.apply`, backward defined for gather / group / interpolate only.
+Differences by design: outputs are allocated on the INPUT's device with torch.empty (the
+reference hard-codes `torch.cuda.*Tensor` on the current device), launches go to torch's current
+stream, and errors surface as Python exceptions instead of exit().
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from ... import _lib as L
+
+_f32, _i32 = torch.float32, torch.int32
+
+
+def _need(t: torch.Tensor, what: str):
+    assert t.is_contiguous(), f"{what} must be contiguous"
+
+
+class _FurthestPointSampling(Function):
+    @staticmethod
+    def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
+        """xyz (B, N, 3) -> (B, npoint) int32 indices of the iteratively farthest points"""
+        _need(xyz, "xyz")
+        B, N, _ = xyz.size()
+        idx = torch.empty((B, npoint), dtype=_i32, device=xyz.device)
+        temp = torch.full((B, N), 1e10, dtype=_f32, device=xyz.device)
+        L.check(L.load().jm_furthest_point_sampling(B, N, npoint, L.dev(xyz, _f32, "xyz"), L.dev(temp, _f32, "temp"),
+                                                    L.dev(idx, _i32, "idx"), L.stream_ptr()), "farthest_point_sample")
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, grad=None):
+        return None, None
+
+
+farthest_point_sample = _FurthestPointSampling.apply
+furthest_point_sample = farthest_point_sample
+
+
+class _GatherOperation(Function):
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """features (B, C, N), idx (B, npoint) -> (B, C, npoint)"""
+        _need(features, "features"); _need(idx, "idx")
+        B, npoint = idx.size()
+        _, C, N = features.size()
+        out = torch.empty((B, C, npoint), dtype=_f32, device=features.device)
+        L.check(L.load().jm_gather_points(B, C, N, npoint, L.dev(features, _f32, "features"), L.dev(idx, _i32, "idx"),
+                                          L.dev(out, _f32, "out"), L.stream_ptr()), "gather_operation")
+        ctx.save_for_backward(idx)
+        ctx.dims = (C, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        C, N = ctx.dims
+        B, npoint = idx.size()
+        grad_features = torch.zeros((B, C, N), dtype=_f32, device=grad_out.device)
+        g = grad_out.contiguous()
+        L.check(L.load().jm_gather_points_grad(B, C, N, npoint, L.dev(g, _f32, "grad_out"), L.dev(idx, _i32, "idx"),
+                                               L.dev(grad_features, _f32, "grad_features"), L.stream_ptr()),
+                "gather_operation.backward")
+        return grad_features, None
+
+
+gather_operation = _GatherOperation.apply
+
+
+class _ThreeNN(Function):
+    @staticmethod
+    def forward(ctx, unknown: torch.Tensor, known: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """unknown (B, N, 3), known (B, M, 3) -> dist (B, N, 3) L2 distances, idx (B, N, 3)"""
+        _need(unknown, "unknown"); _need(known, "known")
+        B, N, _ = unknown.size()
+        m = known.size(1)
+        dist2 = torch.empty((B, N, 3), dtype=_f32, device=unknown.device)
+        idx = torch.empty((B, N, 3), dtype=_i32, device=unknown.device)
+        L.check(L.load().jm_three_nn(B, N, m, L.dev(unknown, _f32, "unknown"), L.dev(known, _f32, "known"),
+                                     L.dev(dist2, _f32, "dist2"), L.dev(idx, _i32, "idx"), L.stream_ptr()), "three_nn")
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+three_nn = _ThreeNN.apply
+
+
+class _ThreeInterpolate(Function):
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+        """features (B, C, M), idx / weight (B, n, 3) -> (B, C, n)"""
+        _need(features, "features"); _need(idx, "idx"); _need(weight, "weight")
+        B, c, m = features.size()
+        n = idx.size(1)
+        feats = features.float()  # custom ops stay fp32 under autocast (pointnet2_utils.py:130)
+        out = torch.empty((B, c, n), dtype=_f32, device=features.device)
+        L.check(L.load().jm_three_interpolate(B, c, m, n, L.dev(feats, _f32, "features"), L.dev(idx, _i32, "idx"),
+                                              L.dev(weight, _f32, "weight"), L.dev(out, _f32, "out"), L.stream_ptr()),
+                "three_interpolate")
+        ctx.save_for_backward(idx, weight)
+        ctx.m = m
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        B, c, n = grad_out.size()
+        grad_features = torch.zeros((B, c, ctx.m), dtype=_f32, device=grad_out.device)
+        g = grad_out.contiguous()
+        L.check(L.load().jm_three_interpolate_grad(B, c, n, ctx.m, L.dev(g, _f32, "grad_out"), L.dev(idx, _i32, "idx"),
+                                                   L.dev(weight, _f32, "weight"),
+                                                   L.dev(grad_features, _f32, "grad_features"), L.stream_ptr()),
+                "three_interpolate.backward")
+        return grad_features, None, None
+
+
+three_interpolate = _ThreeInterpolate.apply
+
+
+class _GroupingOperation(Function):
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """features (B, C, N), idx (B, npoint, nsample) -> (B, C, npoint, nsample)"""
+        _need(features, "features"); _need(idx, "idx")
+        B, npoint, nsample = idx.size()
+        _, C, N = features.size()
+        feats = features.float()
+        out = torch.empty((B, C, npoint, nsample), dtype=_f32, device=features.device)
+        L.check(L.load().jm_group_points(B, C, N, npoint, nsample, L.dev(feats, _f32, "features"),
+                                         L.dev(idx, _i32, "idx"), L.dev(out, _f32, "out"), L.stream_ptr()),
+                "grouping_operation")
+        ctx.save_for_backward(idx)
+        ctx.N = N
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        B, C, npoint, nsample = grad_out.size()
+        grad_features = torch.zeros((B, C, ctx.N), dtype=_f32, device=grad_out.device)
+        g = grad_out.contiguous()
+        L.check(L.load().jm_group_points_grad(B, C, ctx.N, npoint, nsample, L.dev(g, _f32, "grad_out"),
+                                              L.dev(idx, _i32, "idx"), L.dev(grad_features, _f32, "grad_features"),
+                                              L.stream_ptr()), "grouping_operation.backward")
+        return grad_features, None
+
+
+grouping_operation = _GroupingOperation.apply
+
+
+class _BallQuery(Function):
+    @staticmethod
+    def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
+        """xyz (B, N, 3), new_xyz (B, npoint, 3) -> (B, npoint, nsample) int32 neighbour indices"""
+        _need(new_xyz, "new_xyz"); _need(xyz, "xyz")
+        B, N, _ = xyz.size()
+        npoint = new_xyz.size(1)
+        idx = torch.zeros((B, npoint, nsample), dtype=_i32, device=xyz.device)
+        L.check(L.load().jm_ball_query(B, N, npoint, float(radius), nsample, L.dev(new_xyz, _f32, "new_xyz"),
+                                       L.dev(xyz, _f32, "xyz"), L.dev(idx, _i32, "idx"), L.stream_ptr()), "ball_query")
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None
+
+
+ball_query = _BallQuery.apply
+
+
+def ball_query_dual(radius0: float, nsample0: int, radius1: float, nsample1: int, xyz: torch.Tensor,
+                    new_xyz: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """both MSG radii of an SA level in one pass over xyz (no reference counterpart; results are
+    identical to two ball_query calls)"""
+    _need(new_xyz, "new_xyz"); _need(xyz, "xyz")
+    B, N, _ = xyz.size()
+    npoint = new_xyz.size(1)
+    idx0 = torch.zeros((B, npoint, nsample0), dtype=_i32, device=xyz.device)
+    idx1 = torch.zeros((B, npoint, nsample1), dtype=_i32, device=xyz.device)
+    L.check(L.load().jm_ball_query_dual(B, N, npoint, float(radius0), nsample0, float(radius1), nsample1,
+                                        L.dev(new_xyz, _f32, "new_xyz"), L.dev(xyz, _f32, "xyz"),
+                                        L.dev(idx0, _i32, "idx0"), L.dev(idx1, _i32, "idx1"), L.stream_ptr()),
+            "ball_query_dual")
+    return idx0, idx1
+
+
+class QueryAndGroup(nn.Module):
+    """ball_query + grouping (xyz re-centred on the query point) + feature concat"""
+
+    def __init__(self, radius: float, nsample: int, use_xyz: bool = True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[torch.Tensor] = None,
+                idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """xyz (B, N, 3), new_xyz (B, npoint, 3), features (B, C, N) -> (B, 3 + C, npoint, nsample).
+        `idx` may carry a precomputed neighbour list (e.g. from ball_query_dual)."""
+        if idx is None:
+            idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)
+        grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is None:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            return grouped_xyz
+        grouped_features = grouping_operation(features, idx)
+        return torch.cat([grouped_xyz, grouped_features], dim=1) if self.use_xyz else grouped_features
+
+
+class GroupAll(nn.Module):
+    """one group containing every point: (B, 3 + C, 1, N)"""
+
+    def __init__(self, use_xyz: bool = True):
+        super().__init__()
+        self.use_xyz = use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: Optional[torch.Tensor], features: Optional[torch.Tensor] = None):
+        grouped_xyz = xyz.transpose(1, 2).contiguous().unsqueeze(2)
+        if features is None:
+            return grouped_xyz
+        grouped_features = features.unsqueeze(2)
+        return torch.cat([grouped_xyz, grouped_features], dim=1) if self.use_xyz else grouped_features

@@ -1,0 +1,83 @@
+"""RoI point pooling on the gfx950 kernel.
+
+Mirror of jmodt/ops/roipool3d/roipool3d_utils.py: roipool3d_gpu (:8-29), pts_in_boxes3d_cpu
+(:32-51), roipool_pc_cpu (:54-72), roipool3d_cpu (:75-109).
+"""
+import numpy as np
+import torch
+
+from ...ext import roipool3d_cuda
+
+
+def enlarge_box3d(boxes3d, extra_width):
+    """(N, 7) [x, y, z, h, w, l, ry]: h, w, l += 2*extra, y += extra  (jmodt/utils/kitti_utils.py:152-162)"""
+    large = boxes3d.copy() if isinstance(boxes3d, np.ndarray) else boxes3d.clone()
+    large[:, 3:6] += extra_width * 2
+    large[:, 1] += extra_width
+    return large
+
+
+def rotate_pc_along_y(pc, rot_angle):
+    """(N, 3+) rotate x,z by rot_angle about the y axis, in place  (jmodt/utils/kitti_utils.py:31-43)"""
+    cosval, sinval = np.cos(rot_angle), np.sin(rot_angle)
+    rotmat = np.array([[cosval, -sinval], [sinval, cosval]])
+    pc[:, [0, 2]] = np.dot(pc[:, [0, 2]], np.transpose(rotmat))
+    return pc
+
+
+def roipool3d_gpu(pts, pts_feature, boxes3d, pool_extra_width, sampled_pt_num=512):
+    """pts (B, N, 3), pts_feature (B, N, C), boxes3d (B, M, 7) ->
+    pooled_features (B, M, sampled_pt_num, 3 + C), pooled_empty_flag (B, M) int32"""
+    batch_size, boxes_num, feature_len = pts.shape[0], boxes3d.shape[1], pts_feature.shape[2]
+    pooled_boxes3d = enlarge_box3d(boxes3d.view(-1, 7), pool_extra_width).view(batch_size, -1, 7)
+    # uninitialised outputs: the kernel writes every row, zeros for empty boxes included
+    pooled_features = torch.empty((batch_size, boxes_num, sampled_pt_num, 3 + feature_len), dtype=torch.float32,
+                                  device=pts.device)
+    pooled_empty_flag = torch.empty((batch_size, boxes_num), dtype=torch.int32, device=pts.device)
+    roipool3d_cuda.forward(pts.contiguous(), pooled_boxes3d.contiguous(), pts_feature.contiguous(), pooled_features,
+                           pooled_empty_flag, zero_empty=1)
+    return pooled_features, pooled_empty_flag
+
+
+def pts_in_boxes3d_cpu(pts, boxes3d):
+    """pts (N, 3), boxes3d (M, 7) on the CPU -> list of M boolean masks (N)"""
+    if pts.is_cuda:
+        raise NotImplementedError
+    pts = pts.float().contiguous()
+    boxes3d = boxes3d.float().contiguous()
+    pts_flag = torch.zeros((boxes3d.size(0), pts.size(0)), dtype=torch.int64)
+    roipool3d_cuda.pts_in_boxes3d_cpu(pts_flag, pts, boxes3d)
+    return [pts_flag[k] > 0 for k in range(boxes3d.shape[0])]
+
+
+def roipool_pc_cpu(pts, pts_feature, boxes3d, sampled_pt_num):
+    """pts (N, 3), pts_feature (N, C), boxes3d (M, 7) -> pooled_pts (M, S, 3), pooled_features (M, S, C),
+    pooled_empty_flag (M) int64"""
+    pts = pts.cpu().float().contiguous()
+    pts_feature = pts_feature.cpu().float().contiguous()
+    boxes3d = boxes3d.cpu().float().contiguous()
+    assert pts.shape[0] == pts_feature.shape[0] and pts.shape[1] == 3, "%s %s" % (pts.shape, pts_feature.shape)
+    pooled_pts = torch.zeros((boxes3d.shape[0], sampled_pt_num, 3), dtype=torch.float32)
+    pooled_features = torch.zeros((boxes3d.shape[0], sampled_pt_num, pts_feature.shape[1]), dtype=torch.float32)
+    pooled_empty_flag = torch.zeros(boxes3d.shape[0], dtype=torch.int64)
+    roipool3d_cuda.roipool3d_cpu(pts, boxes3d, pts_feature, pooled_pts, pooled_features, pooled_empty_flag)
+    return pooled_pts, pooled_features, pooled_empty_flag
+
+
+def roipool3d_cpu(boxes3d, pts, pts_feature, pts_extra_input, pool_extra_width, sampled_pt_num=512,
+                  canonical_transform=True):
+    """numpy front end: boxes3d (M, 7), pts (N, 3), pts_feature (N, C), pts_extra_input (N, C2)"""
+    pooled_boxes3d = enlarge_box3d(boxes3d, pool_extra_width)
+    feature_all = np.concatenate((pts_extra_input, pts_feature), axis=1)
+    pooled_pts, pooled_features, pooled_empty_flag = roipool_pc_cpu(
+        torch.from_numpy(pts), torch.from_numpy(feature_all), torch.from_numpy(pooled_boxes3d), sampled_pt_num)
+    n_extra = pts_extra_input.shape[1]
+    sampled_pts_input = torch.cat((pooled_pts, pooled_features[:, :, 0:n_extra]), dim=2).numpy()
+    sampled_pts_feature = pooled_features[:, :, n_extra:].numpy()
+    if not canonical_transform:
+        return sampled_pts_input, sampled_pts_feature, pooled_empty_flag.numpy()
+    roi_ry = boxes3d[:, 6] % (2 * np.pi)
+    sampled_pts_input[:, :, 0:3] = sampled_pts_input[:, :, 0:3] - boxes3d[:, np.newaxis, 0:3]
+    for k in range(sampled_pts_input.shape[0]):
+        sampled_pts_input[k] = rotate_pc_along_y(sampled_pts_input[k], roi_ry[k])
+    return sampled_pts_input, sampled_pts_feature

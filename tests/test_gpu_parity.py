@@ -1,0 +1,378 @@
+"""GPU tier (-m gpu): the HIP kernels, called through the Python operator API -> ctypes -> C ABI
+(include/jmodt_hip.h), against the CPU oracle on the same seeded inputs, against the committed
+golden vectors, and — at BASELINE.json's full sizes — through size-independent properties.
+
+Bars: bit-exact for every index / integer output (FPS, ball query, three_nn indices, roipool
+indices and copied features, NMS keep lists, NMS masks); 1e-4 absolute for float results
+(interpolation, BEV overlap, gather, affinity scores), the tolerance BASELINE.json states.
+"""
+import numpy as np
+import pytest
+import torch
+
+from jmodt_amd import synth
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu_and_lib():
+    assert torch.cuda.is_available(), "GPU tier needs a GPU"
+    from jmodt_amd import _lib
+    _lib.load()
+
+
+# ------------------------------------------------------------------ FPS
+@pytest.mark.parametrize("B,N,m,kw", [
+    (2, 1024, 256, {}), (2, 1000, 200, {}), (1, 256, 64, dict(dup_frac=0.3)),
+    (2, 512, 128, dict(quantize=2.0 ** -3)), (3, 4096, 512, dict(dup_frac=0.1)),
+    (1, 64, 16, {}), (2, 40, 12, {}), (1, 1, 1, {}), (1, 5, 5, {}), (2, 2048, 300, {}), (1, 8192, 256, {}),
+    (64, 512, 128, {}), (64, 128, 32, {}),       # RCNN-stage shapes (config.py:134), many clouds
+])
+def test_fps_bit_exact(oracle, B, N, m, kw):
+    from jmodt_amd.ops.pointnet2.pointnet2_utils import farthest_point_sample
+    xyz = synth.cloud(B, N, seed=11, **kw)
+    got = farthest_point_sample(T(xyz), m).cpu().numpy()
+    assert got.dtype == np.int32
+    assert np.array_equal(got, oracle.furthest_point_sample(xyz, m))
+
+
+def test_fps_all_equal_and_golden(oracle):
+    from jmodt_amd.ops.pointnet2.pointnet2_utils import farthest_point_sample
+    assert not farthest_point_sample(T(np.ones((2, 300, 3), np.float32)), 20).cpu().numpy().any()
+    g = load_golden("fps.npz")
+    for tag in ("rand", "dup", "grid", "n1000", "n16384"):
+        want = g[f"{tag}_idx"]
+        assert np.array_equal(farthest_point_sample(T(g[f"{tag}_xyz"]), want.shape[1]).cpu().numpy(), want), tag
+
+
+def test_fps_large_n_stream_path(oracle):
+    """n > 16384 takes the streaming kernel (config 5: 65536 points)"""
+    from jmodt_amd.ops.pointnet2.pointnet2_utils import farthest_point_sample
+    xyz = synth.cloud(1, 20000, seed=5, dup_frac=0.05)
+    assert np.array_equal(farthest_point_sample(T(xyz), 64).cpu().numpy(), oracle.furthest_point_sample(xyz, 64))
+
+
+def test_fps_full_size_properties():
+    """B=8, 16384 -> 4096: indices in range, all distinct (distinct points), first is 0, and the
+    min-distance of each new pick to the already picked set is non-increasing (FPS invariant)."""
+    from jmodt_amd.ops.pointnet2.pointnet2_utils import farthest_point_sample
+    xyz = synth.cloud(8, 16384, seed=1235)
+    idx = farthest_point_sample(T(xyz), 4096).cpu().numpy()
+    assert idx.shape == (8, 4096) and (idx[:, 0] == 0).all() and idx.min() >= 0 and idx.max() < 16384
+    for b in range(8):
+        assert np.unique(idx[b]).size == 4096
+    p = torch.from_numpy(xyz[0][idx[0][:600]]).double()
+    d = torch.cdist(p, p)
+    gaps = [d[j, :j].min().item() for j in range(1, 600)]
+    assert all(gaps[i] >= gaps[i + 1] - 1e-6 for i in range(len(gaps) - 1))
+
+
+# ------------------------------------------------------------------ ball query / group / gather
+@pytest.mark.parametrize("radius,nsample,dense,N,M", [
+    (0.1, 16, False, 2048, 256), (0.5, 32, False, 2048, 256), (4.0, 64, False, 3000, 100),
+    (0.4, 16, True, 1024, 128), (1.0, 32, True, 1024, 128), (2.0, 64, True, 512, 70), (1.0, 8, True, 37, 5),
+    (0.2, 64, True, 512, 128),
+])
+def test_ball_query_bit_exact(oracle, radius, nsample, dense, N, M):
+    from jmodt_amd.ops.pointnet2.pointnet2_utils import ball_query
+    xyz = synth.dense_cloud(3, N, 5) if dense else synth.cloud(3, N, 5, dup_frac=0.1)
+    new_xyz = np.ascontiguousarray(xyz[:, :M])
+    got = ball_query(radius, nsample, T(xyz), T(new_xyz)).cpu().numpy()
+    assert np.array_equal(got, oracle.ball_query(radius, nsample, xyz, new_xyz))
+
+
+def test_ball_query_dual_and_golden(oracle):
+    from jmodt_amd.ops.pointnet2.pointnet2_utils import ball_query, ball_query_dual
+    g = load_golden("ball_query.npz")
+    xyz, new = T(g["xyz"]), T(g["new_xyz"])
+    i0, i1 = ball_query_dual(0.1, 16, 0.5, 32, xyz, new)
+    assert np.array_equal(i0.cpu().numpy(), g["sparse_r0.1_ns16"]) and np.array_equal(i1.cpu().numpy(), g["sparse_r0.5_ns32"])
+    assert np.array_equal(ball_query(4.0, 64, xyz, new).cpu().numpy(), g["sparse_r4.0_ns64"])
+    dense, dnew = T(g["dense"]), T(g["dnew"])
+    i0, i1 = ball_query_dual(0.4, 16, 1.0, 32, dense, dnew)
+    assert np.array_equal(i0.cpu().numpy(), g["dense_r0.4_ns16"]) and np.array_equal(i1.cpu().numpy(), g["dense_r1.0_ns32"])
+    assert np.array_equal(ball_query(2.0, 64, dense, dnew).cpu().numpy(), g["dense_r2.0_ns64"])
+
+
+def test_ball_query_edge_cases():
+    from jmodt_amd.ops.pointnet2.pointnet2_utils import ball_query
+    xyz = np.zeros((1, 8, 3), np.float32)
+    xyz[0, :, 0] = np.arange(8)
+    centres = np.array([[[100, 0, 0], [0.0, 0, 0], [2.0, 0, 0], [3.5, 0, 0]]], np.float32)
+    idx = ball_query(1.0, 4, T(xyz), T(centres)).cpu().numpy()
+    assert idx[0].tolist() == [[0, 0, 0, 0], [0, 0, 0, 0], [2, 2, 2, 2], [3, 4, 3, 3]]
+    assert ball_query(2.5, 3, T(xyz), T(centres[:, 2:3])).cpu().numpy()[0, 0].tolist() == [0, 1, 2]
+
+
+def test_sa_level1_full_size_vs_oracle(oracle):
+    """B=8 is BASELINE's batch; the oracle check runs on 2 frames x 512 centres to stay in seconds"""
+    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
+    xyz = synth.cloud(8, 16384, seed=1235)
+    txyz = T(xyz)
+    fidx = pu.farthest_point_sample(txyz, 4096)
+    new_xyz = pu.gather_operation(txyz.transpose(1, 2).contiguous(), fidx).transpose(1, 2).contiguous()
+    assert torch.equal(new_xyz, torch.gather(txyz, 1, fidx.long().unsqueeze(-1).expand(-1, -1, 3)))
+    i0, i1 = pu.ball_query_dual(0.1, 16, 0.5, 32, txyz, new_xyz)
+    nx = new_xyz.cpu().numpy()
+    for b in (0, 7):
+        sub = np.ascontiguousarray(nx[b:b + 1, 1000:1512])
+        assert np.array_equal(i0[b, 1000:1512].cpu().numpy(), oracle.ball_query(0.1, 16, xyz[b:b + 1], sub)[0])
+        assert np.array_equal(i1[b, 1000:1512].cpu().numpy(), oracle.ball_query(0.5, 32, xyz[b:b + 1], sub)[0])
+    # property at full size: every centre is its own neighbour => slot 0 is a point at distance 0
+    first = torch.gather(txyz, 1, i0[:, :, 0].long().unsqueeze(-1).expand(-1, -1, 3))
+    assert ((first - new_xyz).abs().sum(-1) == 0).all()
+    # grouping == torch.gather at full size (bit-exact copy)
+    feats = torch.randn(8, 96, 16384, device=DEV)
+    grouped = pu.grouping_operation(feats, i1)
+    want = torch.gather(feats.unsqueeze(2).expand(-1, -1, 4096, -1), 3, i1.long().unsqueeze(1).expand(-1, 96, -1, -1))
+    assert torch.equal(grouped, want)
+
+
+def test_group_gather_forward_backward(oracle):
+    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
+    rng = np.random.default_rng(3)
+    B, C, N, M, S = 2, 13, 200, 33, 5      # odd sizes: exercises the non-vectorised paths
+    feats = rng.normal(size=(B, C, N)).astype(np.float32)
+    gidx = rng.integers(0, N, (B, M, S)).astype(np.int32)
+    idx = rng.integers(0, N, (B, M)).astype(np.int32)
+    tf = T(feats).requires_grad_(True)
+    out = pu.grouping_operation(tf, T(gidx))
+    assert np.array_equal(out.detach().cpu().numpy(), oracle.grouping_operation(feats, gidx))
+    g = rng.normal(size=out.shape).astype(np.float32)
+    out.backward(T(g))
+    assert np.allclose(tf.grad.cpu().numpy(), oracle.grouping_operation_grad(g, gidx, N), atol=1e-5)
+    tf2 = T(feats).requires_grad_(True)
+    out2 = pu.gather_operation(tf2, T(idx))
+    assert np.array_equal(out2.detach().cpu().numpy(), oracle.gather_operation(feats, idx))
+    g2 = rng.normal(size=out2.shape).astype(np.float32)
+    out2.backward(T(g2))
+    assert np.allclose(tf2.grad.cpu().numpy(), oracle.gather_operation_grad(g2, idx, N), atol=1e-5)
+    # vectorised path (P*S % 4 == 0)
+    gidx4 = rng.integers(0, N, (B, 32, 8)).astype(np.int32)
+    assert np.array_equal(pu.grouping_operation(T(feats), T(gidx4)).cpu().numpy(), oracle.grouping_operation(feats, gidx4))
+
+
+# ------------------------------------------------------------------ three_nn / interpolate
+@pytest.mark.parametrize("n,m", [(300, 75), (1024, 256), (77, 2), (513, 131)])
+def test_three_nn_interpolate(oracle, n, m):
+    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
+    unknown = synth.cloud(2, n, 7, dup_frac=0.1)
+    known = np.ascontiguousarray(unknown[:, :m])
+    dist, idx = pu.three_nn(T(unknown), T(known))
+    d2, oidx = oracle.three_nn(unknown, known)
+    assert np.array_equal(idx.cpu().numpy(), oidx)
+    assert np.array_equal(dist.cpu().numpy(), np.sqrt(d2))
+    if m < 3:
+        return
+    rng = np.random.default_rng(2)
+    feats = rng.normal(size=(2, 19, m)).astype(np.float32)
+    w = 1.0 / (np.sqrt(d2) + 1e-8)
+    w = (w / w.sum(2, keepdims=True)).astype(np.float32)
+    tf = T(feats).requires_grad_(True)
+    out = pu.three_interpolate(tf, idx, T(w))
+    assert np.array_equal(out.detach().cpu().numpy(), oracle.three_interpolate(feats, oidx, w))
+    g = rng.normal(size=out.shape).astype(np.float32)
+    out.backward(T(g))
+    assert np.allclose(tf.grad.cpu().numpy(), oracle.three_interpolate_grad(g, oidx, w, m), atol=1e-4)
+
+
+def test_three_nn_golden():
+    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
+    g = load_golden("three_nn_interp.npz")
+    dist, idx = pu.three_nn(T(g["unknown"]), T(g["known"]))
+    assert np.array_equal(idx.cpu().numpy(), g["idx"]) and np.array_equal(dist.cpu().numpy(), np.sqrt(g["dist2"]))
+    assert np.array_equal(pu.three_interpolate(T(g["feats"]), idx, T(g["weight"])).cpu().numpy(), g["out"])
+
+
+# ------------------------------------------------------------------ roipool3d
+def test_roipool3d_reference_golden():
+    """expected values produced by the reference's own roipool3d.cpp (see make_golden.py)"""
+    from jmodt_amd.ops.roipool3d.roipool3d_utils import roipool3d_gpu
+    g = load_golden("roipool3d_ref.npz")
+    pooled, empty = roipool3d_gpu(T(g["pts"]), T(g["feat"]), T(g["boxes"]), 0.2, int(g["S"]))
+    assert np.array_equal(pooled.cpu().numpy(), g["pooled"])
+    assert np.array_equal(empty.cpu().numpy(), g["empty"])
+
+
+@pytest.mark.parametrize("N,M,C,S", [(4096, 40, 9, 128), (16384, 128, 130, 512), (1000, 7, 2, 30), (300, 3, 0, 64)])
+def test_roipool3d_vs_oracle(oracle, N, M, C, S):
+    from jmodt_amd.ext import roipool3d_cuda
+    B = 2
+    pts = synth.dense_cloud(B, N, 31, extent=20.0)
+    pts[..., 1] /= 10.0
+    boxes = synth.proposals(pts, M, 32)
+    boxes[0, 0, 0:3] = [500, 0, 500]
+    boxes[1, 1, 3:6] = [60, 60, 60]
+    boxes[0, 2, 3:6] = [0.8, 0.8, 1.2]
+    feat = np.random.default_rng(33).normal(size=(B, N, C)).astype(np.float32)
+    eb = oracle.enlarge_box3d(boxes, 0.2)
+    want_p, want_e = oracle.roipool3d(pts, feat, eb, S)
+    # reference contract (pre-zeroed outputs, empty rows untouched)
+    pooled = torch.zeros((B, M, S, 3 + C), device=DEV)
+    empty = torch.zeros((B, M), dtype=torch.int32, device=DEV)
+    roipool3d_cuda.forward(T(pts), T(eb), T(feat), pooled, empty)
+    assert np.array_equal(pooled.cpu().numpy(), want_p) and np.array_equal(empty.cpu().numpy(), want_e)
+    # zero_empty contract (uninitialised outputs)
+    pooled2 = torch.full((B, M, S, 3 + C), float("nan"), device=DEV)
+    empty2 = torch.full((B, M), 77, dtype=torch.int32, device=DEV)
+    roipool3d_cuda.forward(T(pts), T(eb), T(feat), pooled2, empty2, zero_empty=1)
+    assert np.array_equal(pooled2.cpu().numpy(), want_p) and np.array_equal(empty2.cpu().numpy(), want_e)
+    assert want_e.sum() >= 1 and (want_e == 0).sum() >= 1
+
+
+# ------------------------------------------------------------------ iou3d / NMS
+def test_overlap_iou_vs_oracle_and_golden(oracle):
+    from jmodt_amd.ops.iou3d import iou3d_utils
+    from jmodt_amd.ext import iou3d_cuda
+    g = load_golden("iou3d_nms.npz")
+    a, b = T(g["pair_a"]), T(g["pair_b"])
+    ov = torch.empty((a.shape[0], b.shape[0]), device=DEV)
+    iou3d_cuda.boxes_overlap_bev_gpu(a, b, ov)
+    assert np.array_equal(ov.cpu().numpy(), g["overlap"])          # deterministic math: bit-exact
+    assert np.array_equal(iou3d_utils.boxes_iou_bev(a, b).cpu().numpy(), g["iou"])
+    sq = np.array([[0, 0, 2, 2, 0.0], [0, 0, 2, 2, np.pi / 4], [10, 10, 12, 12, 0.3]], np.float32)
+    m = iou3d_utils.boxes_iou_bev(T(sq), T(sq)).cpu().numpy()
+    assert abs(m[0, 0] - 1) < 1e-6 and m[0, 2] == 0
+    assert abs(m[0, 1] - 8 * (np.sqrt(2) - 1) / (8 - 8 * (np.sqrt(2) - 1))) < 1e-5
+    pts = synth.dense_cloud(1, 256, 3, extent=10.0)
+    b3a, b3b = synth.proposals(pts, 70, 4)[0], synth.proposals(pts, 33, 5)[0]
+    got = iou3d_utils.boxes_iou3d_gpu(T(b3a), T(b3b)).cpu().numpy()
+    assert np.abs(got - oracle.boxes_iou3d(b3a, b3b)).max() < 1e-5
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 500, 1000, 6300])
+@pytest.mark.parametrize("thresh", [0.1, 0.8, 0.85])
+def test_nms_normal_bit_exact(oracle, n, thresh):
+    from jmodt_amd.ops.iou3d.iou3d_utils import nms_normal_gpu
+    boxes, scores = synth.bev_boxes(n, 100 + n)
+    got = nms_normal_gpu(T(boxes), T(scores), thresh).cpu().numpy()
+    assert got.dtype == np.int64
+    assert np.array_equal(got, oracle.nms(boxes, scores, thresh, normal=True))
+
+
+@pytest.mark.parametrize("n,thresh", [(100, 0.1), (400, 0.5), (64, 0.8), (2700, 0.8), (1, 0.5)])
+def test_nms_rotated_bit_exact(oracle, n, thresh):
+    from jmodt_amd.ops.iou3d.iou3d_utils import nms_gpu
+    boxes, scores = synth.bev_boxes(n, 7 + n)
+    got = nms_gpu(T(boxes), T(scores), thresh).cpu().numpy()
+    assert np.array_equal(got, oracle.nms(boxes, scores, thresh, normal=False))
+
+
+def test_nms_extension_level_api_and_golden(oracle):
+    from jmodt_amd.ext import iou3d_cuda
+    g = load_golden("iou3d_nms.npz")
+    order = np.argsort(-g["scores"], kind="stable")
+    keep = torch.zeros(1000, dtype=torch.int64)
+    num = iou3d_cuda.nms_normal_gpu(T(g["boxes"][order]), keep, 0.8)
+    assert np.array_equal(order[keep[:num].numpy()], g["normal_0.8"])
+    order = np.argsort(-g["scores_rot"], kind="stable")
+    keep = torch.zeros(300, dtype=torch.int64)
+    num = iou3d_cuda.nms_gpu(T(g["boxes_rot"][order]), keep, 0.1)
+    assert np.array_equal(order[keep[:num].numpy()], g["rot_0.1"])
+    k, nk = iou3d_cuda.nms_device(torch.zeros((0, 5), device=DEV), 0.5, 1)
+    assert int(nk.item()) == 0
+
+
+def test_nms_idempotent_full_size():
+    """property at RPN size: NMS of the kept set keeps everything (no kept pair exceeds thr)"""
+    from jmodt_amd.ops.iou3d.iou3d_utils import nms_normal_gpu
+    boxes, scores = synth.bev_boxes(6300, 9)
+    tb, ts = T(boxes), T(scores)
+    keep = nms_normal_gpu(tb, ts, 0.8)
+    again = nms_normal_gpu(tb[keep], ts[keep], 0.8)
+    assert again.numel() == keep.numel() and torch.equal(again, torch.arange(keep.numel(), device=DEV))
+    assert torch.all(ts[keep][:-1] >= ts[keep][1:])
+
+
+# ------------------------------------------------------------------ LI-Fusion gather
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("C,H,W,N", [(8, 24, 80, 300), (64, 192, 640, 4096), (5, 7, 9, 33)])
+def test_feature_gather_vs_oracle(oracle, channels_last, C, H, W, N):
+    from jmodt_amd.ops.fusion import feature_gather
+    rng = np.random.default_rng(5)
+    fm = rng.normal(size=(2, C, H, W)).astype(np.float32)
+    xy = rng.uniform(-1.1, 1.1, (2, N, 2)).astype(np.float32)
+    xy[0, 0] = [-1, -1]; xy[0, 1] = [1, 1]; xy[0, 2] = [1.5, 0.2]
+    tfm = T(fm)
+    if channels_last:
+        tfm = tfm.contiguous(memory_format=torch.channels_last)
+    got = feature_gather(tfm, T(xy)).cpu().numpy()
+    assert np.abs(got - oracle.feature_gather(fm, xy)).max() < 1e-5
+    assert not got[0, :, 2].any()
+
+
+def test_feature_gather_golden_and_grad():
+    from jmodt_amd.ops.fusion import feature_gather
+    import torch.nn.functional as F
+    g = load_golden("feature_gather_ref.npz")
+    assert np.abs(feature_gather(T(g["fmap"]), T(g["xy"])).cpu().numpy() - g["out"]).max() < 1e-5
+    fm = T(g["fmap"]).requires_grad_(True)
+    fm2 = T(g["fmap"]).requires_grad_(True)
+    xy = T(g["xy"])
+    go = torch.randn(2, 8, 300, device=DEV)
+    feature_gather(fm, xy).backward(go)
+    F.grid_sample(fm2, xy.unsqueeze(1), align_corners=True).squeeze(2).backward(go)
+    assert (fm.grad - fm2.grad).abs().max().item() < 1e-4
+
+
+# ------------------------------------------------------------------ affinity
+def _heads_from_golden(g):
+    from jmodt_amd.ops.affinity import make_affinity_mlp
+    heads = []
+    for name in ("link", "se"):
+        h = make_affinity_mlp()
+        h.load_state_dict({k[len(name) + 1:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(name + ".")})
+        heads.append(h.to(DEV).eval())
+    return heads
+
+
+def test_affinity_reference_golden():
+    """targets: the reference's layer builder + tracker.py:81-112 torch ops (make_golden.py)"""
+    from jmodt_amd.ops.affinity import pairwise_affinity
+    g = load_golden("affinity_ref.npz")
+    link, se = _heads_from_golden(g)
+    for tag in ("64x64", "3x5", "1x1"):
+        A, s, e, raw = pairwise_affinity(T(g[f"{tag}_pf"]), T(g[f"{tag}_df"]), link, se, return_raw=True)
+        assert np.abs(raw.cpu().numpy() - g[f"{tag}_raw"]).max() < 1e-4, tag
+        assert np.abs(A.cpu().numpy() - g[f"{tag}_A"]).max() < 1e-4, tag
+        assert np.abs(s.cpu().numpy() - g[f"{tag}_start"]).max() < 1e-4, tag
+        assert np.abs(e.cpu().numpy() - g[f"{tag}_end"]).max() < 1e-4, tag
+
+
+@pytest.mark.parametrize("P,D,C", [(7, 5, 64), (130, 67, 512), (256, 256, 512)])
+def test_affinity_vs_oracle(oracle, P, D, C):
+    from jmodt_amd.ops.affinity import make_affinity_mlp, mlp3_forward, pairwise_affinity
+    lw, sw = synth.mlp_weights(C, C, C, 1), synth.mlp_weights(C, C, C, 2)
+
+    def head(w):
+        h = make_affinity_mlp(C, (C, C))
+        with torch.no_grad():
+            h[0].conv.weight.copy_(torch.from_numpy(w[0])[..., None]); h[0].conv.bias.copy_(torch.from_numpy(w[1]))
+            h[2].conv.weight.copy_(torch.from_numpy(w[2])[..., None]); h[2].conv.bias.copy_(torch.from_numpy(w[3]))
+            h[3].conv.weight.copy_(torch.from_numpy(w[4])[None, :, None]); h[3].conv.bias.fill_(float(w[5]))
+        return h.to(DEV).eval()
+
+    pf, df = synth.roi_features(P, C, 3), synth.roi_features(D, C, 4)
+    A, s, e, raw = pairwise_affinity(T(pf), T(df), head(lw), head(sw), return_raw=True)
+    if P * D <= 130 * 67:
+        assert np.abs(raw.cpu().numpy() - oracle.link_scores(pf, df, lw)).max() < 1e-4
+        oA, os_, oe = oracle.affinity(pf, df, lw, sw)
+        assert np.abs(A.cpu().numpy() - oA).max() < 1e-4
+        assert np.abs(s.cpu().numpy() - os_).max() < 1e-4 and np.abs(e.cpu().numpy() - oe).max() < 1e-4
+    else:  # 256^2 (config 5): spot rows against the oracle + softmax properties at full size
+        rows = [0, 100, 255]
+        want = oracle.link_scores(pf[rows], df, lw)
+        assert np.abs(raw[rows].cpu().numpy() - want).max() < 1e-4
+        Ad = A.double()
+        rd = torch.softmax(raw.double(), 1) + torch.softmax(raw.double(), 0)
+        assert (Ad - rd / 2).abs().max().item() < 1e-5
+    y = mlp3_forward(T(pf), head(sw))
+    assert y.shape == (P,)
