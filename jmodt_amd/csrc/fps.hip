@@ -24,6 +24,8 @@ namespace jm {
 
 __device__ __forceinline__ unsigned bitrev_u(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
 
+constexpr int FPS_OUT_CHUNK = 4096;
+
 struct __attribute__((aligned(16))) FpsCand {
     int val;  // float bits of the best min-distance (>= 0) or of -1.0f (no valid point): signed-int order == float order
     int k;
@@ -36,6 +38,8 @@ __global__ void __launch_bounds__(1024)
 fps_regs_kernel(int n, int m, int bs, int bs_log2, const float* __restrict__ dataset, float* __restrict__ temp,
                 int* __restrict__ idxs) {
     __shared__ FpsCand cand[2][16];
+    __shared__ int out_buf[FPS_OUT_CHUNK];  // picks are staged here: a global store inside the loop would
+                                            // make every __syncthreads() wait for its write-ack (vmcnt(0))
     const int T = threadIdx.x;
     const int nwaves = (blockDim.x + 63) >> 6;
     const int wave = T >> 6;
@@ -62,15 +66,20 @@ fps_regs_kernel(int n, int m, int bs, int bs_log2, const float* __restrict__ dat
     }
 
     float x1 = ds[0], y1 = ds[1], z1 = ds[2];
-    if (T == 0) out[0] = 0;
+    if (T == 0) out_buf[0] = 0;
 
     for (int it = 1; it < m; ++it) {
+        if ((it & (FPS_OUT_CHUNK - 1)) == 0) {  // flush a full chunk of picks (uniform branch)
+            __syncthreads();
+            for (int e = T; e < FPS_OUT_CHUNK; e += blockDim.x) out[it - FPS_OUT_CHUNK + e] = out_buf[e];
+            __syncthreads();
+        }
         float best = -1.f;
         int bj = 0;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const float d = sqdist3(px[j] - x1, py[j] - y1, pz[j] - z1);
-            const float d2 = fminf(d, tm[j]);
+            const float d2 = fast_min(d, tm[j]);
             tm[j] = d2;
             const bool gt = d2 > best;
             bj = gt ? j : bj;
@@ -113,7 +122,12 @@ fps_regs_kernel(int n, int m, int bs, int bs_log2, const float* __restrict__ dat
             const FpsCand c = slot[ww];                        // uniform address: LDS broadcast
             old = c.k; x1 = c.x; y1 = c.y; z1 = c.z;
         }
-        if (T == 0) out[it] = old;
+        if (T == 0) out_buf[it & (FPS_OUT_CHUNK - 1)] = old;
+    }
+    __syncthreads();
+    {
+        const int done = ((m - 1) / FPS_OUT_CHUNK) * FPS_OUT_CHUNK;  // picks [done, m) are still staged
+        for (int e = T; e < m - done; e += blockDim.x) out[done + e] = out_buf[e];
     }
 
     // leave `temp` as the reference kernel does (it updates it in place every iteration)

@@ -42,14 +42,35 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 // max over the 64 lanes of a signed int, returned wave-uniform (SGPR via readlane 63).
 // 4 butterfly steps make every 16-lane row uniform, then two row broadcasts fold the rows.
+// Written as v_max_i32 with the DPP modifier on the source operand: one instruction per step
+// (hipcc lowers the update_dpp builtin to v_mov_b32 + s_nop + v_mov_b32_dpp + v_max, 4 issue
+// slots per step).  The s_nop 1 before each step is the VALU-write -> DPP-read hazard (2 wait
+// states), which hipcc does not insert inside an asm statement.
 __device__ __forceinline__ int wave_max_i32(int v) {
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, JM_DPP_XOR1, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, JM_DPP_XOR2, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, JM_DPP_HALF_MIRROR, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, JM_DPP_MIRROR, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, JM_DPP_BCAST15, 0xa, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, JM_DPP_BCAST31, 0xc, 0xf, false));
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return __builtin_amdgcn_readlane(v, 63);
+}
+
+// v_min_f32 / v_max_f32 without the canonicalising v_max hipcc puts in front of fminf/fmaxf
+// (inputs here are never signalling NaNs)
+__device__ __forceinline__ float fast_min(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 __device__ __forceinline__ float wave_sum_f32(float v) {

@@ -45,7 +45,7 @@ class _FeatureGather(Function):
         (xy,) = ctx.saved_tensors
         B, C, H, W, N, nchw = ctx.geom
         fmt = torch.contiguous_format if nchw else torch.channels_last
-        grad_map = torch.zeros((B, C, H, W), dtype=_f32, device=grad_out.device, memory_format=fmt)
+        grad_map = torch.empty((B, C, H, W), dtype=_f32, device=grad_out.device, memory_format=fmt).zero_()
         sb, sc, sh, sw = grad_map.stride()
         g = grad_out.contiguous()
         import ctypes

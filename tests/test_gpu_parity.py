@@ -126,9 +126,15 @@ def test_sa_level1_full_size_vs_oracle(oracle):
         sub = np.ascontiguousarray(nx[b:b + 1, 1000:1512])
         assert np.array_equal(i0[b, 1000:1512].cpu().numpy(), oracle.ball_query(0.1, 16, xyz[b:b + 1], sub)[0])
         assert np.array_equal(i1[b, 1000:1512].cpu().numpy(), oracle.ball_query(0.5, 32, xyz[b:b + 1], sub)[0])
-    # property at full size: every centre is its own neighbour => slot 0 is a point at distance 0
-    first = torch.gather(txyz, 1, i0[:, :, 0].long().unsqueeze(-1).expand(-1, -1, 3))
-    assert ((first - new_xyz).abs().sum(-1) == 0).all()
+    # properties at full size: every centre is one of the points, so every list is non-empty, each
+    # listed neighbour lies strictly inside the ball, and indices ascend until the back-fill starts
+    for nb, r in ((i0, 0.1), (i1, 0.5)):
+        pts = torch.gather(txyz.unsqueeze(1).expand(-1, 4096, -1, -1), 2,
+                           nb.long().unsqueeze(-1).expand(-1, -1, -1, 3))
+        d2 = ((pts.double() - new_xyz.double().unsqueeze(2)) ** 2).sum(-1)
+        assert (d2 < r * r * (1 + 1e-6)).all()
+        diff = nb[:, :, 1:] - nb[:, :, :-1]
+        assert ((diff > 0) | (nb[:, :, 1:] == nb[:, :, :1])).all()
     # grouping == torch.gather at full size (bit-exact copy)
     feats = torch.randn(8, 96, 16384, device=DEV)
     grouped = pu.grouping_operation(feats, i1)
