@@ -48,9 +48,12 @@ class KernelTimer:
     def __init__(self):
         self.records = {}   # name -> list of (start, end) events
         self.bytes = {}
+        self.flops = {}     # name -> flops per call (MFMA-bound kernels)
         self.enabled = False
 
-    def run(self, name, algo_bytes, fn):
+    def run(self, name, algo_bytes, fn, flops=0):
+        if flops:
+            self.flops[name] = flops
         if not self.enabled:
             return fn()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -67,9 +70,13 @@ class KernelTimer:
             ms = sum(s.elapsed_time(e) for s, e in evs) / steps   # per step (a name may cover several launches)
             launches = len(evs) / steps
             gbs = self.bytes[name] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            rows.append(dict(kernel=name, ms_per_step=round(ms, 5), launches_per_step=launches,
-                             algo_bytes_per_step=int(self.bytes[name]), achieved_gbs=round(gbs, 2),
-                             hbm_frac=round(gbs / HBM_PEAK_GBS, 5)))
+            row = dict(kernel=name, ms_per_step=round(ms, 5), launches_per_step=launches,
+                       algo_bytes_per_step=int(self.bytes[name]), achieved_gbs=round(gbs, 2),
+                       hbm_frac=round(gbs / HBM_PEAK_GBS, 5))
+            if name in self.flops:   # time covers the whole op (both MLP layers + softmax + se path)
+                tf = self.flops[name] * launches / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+                row.update(achieved_tflops=round(tf, 2), mfma_frac=round(tf / MFMA_F32_PEAK_TF, 4))
+            rows.append(row)
         rows.sort(key=lambda r: -r["ms_per_step"])
         return rows
 
@@ -105,6 +112,65 @@ def sa_step(xyz, feats, timer):
     return outs
 
 
+def make_ops_inputs(B, seed, dev):
+    """inputs for the remaining hot-path ops at SURVEY.md §8d shapes (config 3 sizes, M_roi = 128)"""
+    from jmodt_amd.ops.affinity import make_affinity_mlp
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    xyz_np = synth.cloud(B, 16384, seed=seed)
+    d = dict(xyz=torch.from_numpy(xyz_np).to(dev))
+    d["xy"] = torch.from_numpy(synth.pts_xy(xyz_np)).to(dev)
+    d["boxes"] = torch.from_numpy(synth.proposals(xyz_np, 128, seed + 1)).to(dev)
+    d["feat130"] = torch.randn(B, 16384, 130, generator=g).to(dev)
+    # FP levels (n, m, C of the coarse features)  config.py:75-82
+    d["fp"] = []
+    for n, m, c in ((256, 64, 1024), (1024, 256, 512), (4096, 1024, 512), (16384, 4096, 256)):
+        unknown = d["xyz"][:, :n].contiguous()
+        known = d["xyz"][:, :m].contiguous()
+        d["fp"].append((unknown, known, torch.randn(B, c, m, generator=g).to(dev)))
+    # LI-Fusion pyramid (C, H, W, npoints)  backbone.py:166-196
+    d["maps"] = [(torch.randn(B, c, h, w, generator=g).to(dev), d["xy"][:, :n].contiguous())
+                 for c, h, w, n in ((64, 192, 640, 4096), (128, 96, 320, 1024), (256, 48, 160, 256),
+                                    (512, 24, 80, 64), (32, 384, 1280, 16384))]
+    bev, sc = [], []
+    for b in range(B):
+        bb, ss = synth.bev_boxes(6300, seed + 10 + b)
+        bev.append(torch.from_numpy(bb).to(dev)); sc.append(torch.from_numpy(ss).to(dev))
+    d["bev"], d["scores"] = bev, sc
+    torch.manual_seed(seed)
+    d["link"], d["se"] = make_affinity_mlp().to(dev).eval(), make_affinity_mlp().to(dev).eval()
+    d["pf"] = torch.from_numpy(synth.roi_features(128, 512, seed + 2)).to(dev)
+    d["df"] = torch.from_numpy(synth.roi_features(128, 512, seed + 3)).to(dev)
+    return d
+
+
+def ops_step(d, timer):
+    """every other hot-path op once per frame batch: 3-NN + interpolate (4 FP levels), LI-Fusion
+    gather (5 maps), roipool3d, RPN NMS (6300 boxes per frame), 128x128 affinity per frame"""
+    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
+    from jmodt_amd.ops.fusion import feature_gather
+    from jmodt_amd.ops.roipool3d.roipool3d_utils import roipool3d_gpu
+    from jmodt_amd.ops.iou3d.iou3d_utils import nms_normal_gpu
+    from jmodt_amd.ops.affinity import pairwise_affinity
+    B = d["xyz"].shape[0]
+    for li, (unknown, known, feats) in enumerate(d["fp"]):
+        n, m, c = unknown.shape[1], known.shape[1], feats.shape[1]
+        dist, idx = timer.run(f"three_nn_FP{li + 1}", B * (12 * n + 12 * m + 24 * n), lambda: pu.three_nn(unknown, known))
+        w = 1.0 / (dist + 1e-8)
+        w = w / w.sum(2, keepdim=True)
+        timer.run(f"three_interpolate_FP{li + 1}", B * (4 * c * m + 24 * n + 4 * c * n),
+                  lambda: pu.three_interpolate(feats, idx, w))
+    for mi, (fm, xy) in enumerate(d["maps"]):
+        c, n = fm.shape[1], xy.shape[1]
+        timer.run(f"feature_gather_{mi + 1}", B * n * 4 * c * 4 + B * c * n * 4, lambda: feature_gather(fm, xy))
+    N, M, C, S = 16384, 128, 130, 512
+    timer.run("roipool3d", B * (12 * N + 28 * M + 4 * C * N) + B * M * S * (3 + C) * 4 + 4 * B * M,
+              lambda: roipool3d_gpu(d["xyz"], d["feat130"], d["boxes"], 0.2, S))
+    for b in range(B):
+        timer.run("nms_normal_6300", 6300 * 20 + 6300 * 99 * 8, lambda: nms_normal_gpu(d["bev"][b], d["scores"][b], 0.8))
+    for b in range(B):
+        timer.run("affinity_128x128", 0, lambda: pairwise_affinity(d["pf"], d["df"], d["link"], d["se"]), flops=128 * 128 * (2 * 512 * 512 * 2 + 2 * 512))
+
+
 def cpu_baseline_sa(B):
     """the oracle (CPU restatement, OpenMP) on ONE batch of the same workload"""
     from oracle import oracle as orc
@@ -135,6 +201,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="sa", choices=["sa", "ops"],
+                    help="sa = BASELINE configs[1] (default); ops = every other hot-path op at its §8d shape")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,10 +222,15 @@ def main():
     from jmodt_amd import _lib
     _lib.load()
 
-    xyz, feats = make_sa_inputs(args.batch, 1234 + 1 + rank, dev)
     timer = KernelTimer()
+    if args.workload == "sa":
+        xyz, feats = make_sa_inputs(args.batch, 1234 + 1 + rank, dev)
+        step = lambda: sa_step(xyz, feats, timer)  # noqa: E731
+    else:
+        ops_in = make_ops_inputs(args.batch, 1234 + 2 + rank, dev)
+        step = lambda: ops_step(ops_in, timer)  # noqa: E731
     for _ in range(args.warmup):
-        sa_step(xyz, feats, timer)
+        step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -165,7 +238,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sa_step(xyz, feats, timer)
+        step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -191,8 +264,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: pointnet2 FPS + ball_query(2 radii) + group_points over the "
-                                   "4 RPN SA levels (16384->4096->1024->256->64), 16384-pt synthetic clouds",
+            "config": {"workload": ("BASELINE configs[1]: pointnet2 FPS + ball_query(2 radii) + group_points over the "
+                                    "4 RPN SA levels (16384->4096->1024->256->64), 16384-pt synthetic clouds")
+                       if args.workload == "sa" else
+                       ("supplementary: three_nn+interpolate (4 FP levels), LI-Fusion gather (5 maps), roipool3d "
+                        "(128 RoIs x 512 pts x 133), RPN nms_normal (6300 boxes), 128x128 affinity, per frame"),
                        "frames_per_gpu_per_step": args.batch, "points": 16384, "parallelism": f"replicas x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_gbs"],
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["hbm_frac"], "traffic": None,
@@ -202,7 +278,7 @@ def main():
                          "measured_copy_ceiling_gbs": HBM_COPY_CEILING_GBS},
             "kernels": kernels,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.workload == "sa":
             try:
                 fps, dt = cpu_baseline_sa(args.batch)
                 result["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": os.cpu_count(),

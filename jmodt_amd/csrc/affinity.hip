@@ -20,13 +20,17 @@
 //    tile against w3 and adds one partial per row into the score vector — the second hidden
 //    activation is never written either.
 //  * Dual softmax and the start/end feature means are small bandwidth-trivial kernels.
+#include <stdlib.h>
+
+#include <mutex>
+
 #include "jm_common.h"
 
 namespace jm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16, LDP = BM + 4;
+constexpr int BM = 128, BN = 128, LDP = BM + 4;
 
 struct GemmParams {
     int M, N, K;
@@ -42,30 +46,44 @@ struct GemmParams {
     float* score;       // (M) pre-filled with b3, accumulated    [EMODE 1]
 };
 
-template <int AMODE, int EMODE>
+// Up to two independent problems per launch (grouped GEMM): the link head's P*D pair rows and
+// the start/end head's P+D rows have different weights but the same shapes per layer, and the
+// small problem would otherwise be a latency-bound 8-workgroup launch of its own.
+struct GemmGroup {
+    GemmParams p[2];
+    int tiles0;   // workgroups of problem 0 (1-D grid; the rest belong to problem 1)
+};
+
+template <int EMODE, int BK, bool PIN>
 __global__ void __launch_bounds__(256)
-mlp_gemm_kernel(GemmParams p) {
+mlp_gemm_kernel(GemmGroup grp) {
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDP];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDP];
+    constexpr int NLD = BK / 8;   // float4 loads per operand per thread per k-tile (128 rows x BK / 256 threads / 4)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const bool second = (int)blockIdx.x >= grp.tiles0;
+    const GemmParams& p = grp.p[second ? 1 : 0];
+    const int bid = second ? (int)blockIdx.x - grp.tiles0 : (int)blockIdx.x;
+    const int ntn = (p.N + BN - 1) / BN;
+    const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+    const bool pair_mode = p.pf != nullptr;   // wave-uniform: A rows are |p_i - d_j| formed on the fly
 
     // staging assignment: 2 float4 of A and 2 of B per thread per k-tile
-    int srow[2], skq[2];
-    const float *a_ptr[2], *a2_ptr[2], *b_ptr[2];
-    bool a_ok[2], b_ok[2];
+    int srow[NLD], skq[NLD];
+    const float *a_ptr[NLD], *a2_ptr[NLD], *b_ptr[NLD];
+    bool a_ok[NLD], b_ok[NLD];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NLD; ++i) {
         const int f = tid + 256 * i;
-        srow[i] = f >> 2;
-        skq[i] = (f & 3) * 4;
+        srow[i] = f / (BK / 4);
+        skq[i] = (f % (BK / 4)) * 4;
         const int m = m0 + srow[i], n = n0 + srow[i];
         a_ok[i] = m < p.M;
         b_ok[i] = n < p.N;
-        if (AMODE == 0) {
+        if (!pair_mode) {
             a_ptr[i] = p.A + (size_t)(a_ok[i] ? m : 0) * p.K + skq[i];
-            a2_ptr[i] = nullptr;
+            a2_ptr[i] = a_ptr[i];
         } else {
             const int mm = a_ok[i] ? m : 0;
             const int pi = mm / p.D, di = mm - pi * p.D;
@@ -75,27 +93,30 @@ mlp_gemm_kernel(GemmParams p) {
         b_ptr[i] = p.W + (size_t)(b_ok[i] ? n : 0) * p.K + skq[i];
     }
 
-    float4 ra[2], rb[2];
+    // Every staging load is UNCONDITIONAL on a clamped, always-valid pointer (rows >= M / N read
+    // row 0 and are discarded by the epilogue guards): a `cond ? load : 0` makes hipcc branch
+    // around each load and wait vmcnt(0) at every join, which serialises the prefetch.
+    float4 rv[NLD], ru[NLD], rb[NLD];   // raw staged operands; |v - u| is formed at store time so the
+                                  // loads are not waited for until after the MFMAs of this tile
     auto g_load = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a_ok[i]) {
-                v = *reinterpret_cast<const float4*>(a_ptr[i] + k0);
-                if (AMODE == 1) {
-                    const float4 u = *reinterpret_cast<const float4*>(a2_ptr[i] + k0);
-                    v.x = fabsf(v.x - u.x); v.y = fabsf(v.y - u.y); v.z = fabsf(v.z - u.z); v.w = fabsf(v.w - u.w);
-                }
-            }
-            ra[i] = v;
-            rb[i] = b_ok[i] ? *reinterpret_cast<const float4*>(b_ptr[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < NLD; ++i) {
+            rv[i] = *reinterpret_cast<const float4*>(a_ptr[i] + k0);
+            ru[i] = *reinterpret_cast<const float4*>(a2_ptr[i] + k0);
+            rb[i] = *reinterpret_cast<const float4*>(b_ptr[i] + k0);
         }
     };
     auto s_store = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            As[buf][skq[i] + 0][srow[i]] = ra[i].x; As[buf][skq[i] + 1][srow[i]] = ra[i].y;
-            As[buf][skq[i] + 2][srow[i]] = ra[i].z; As[buf][skq[i] + 3][srow[i]] = ra[i].w;
+        for (int i = 0; i < NLD; ++i) {
+            const float4 v = rv[i], u = ru[i];
+            float4 r;
+            r.x = pair_mode ? fabsf(v.x - u.x) : v.x;
+            r.y = pair_mode ? fabsf(v.y - u.y) : v.y;
+            r.z = pair_mode ? fabsf(v.z - u.z) : v.z;
+            r.w = pair_mode ? fabsf(v.w - u.w) : v.w;
+            As[buf][skq[i] + 0][srow[i]] = r.x; As[buf][skq[i] + 1][srow[i]] = r.y;
+            As[buf][skq[i] + 2][srow[i]] = r.z; As[buf][skq[i] + 3][srow[i]] = r.w;
             Bs[buf][skq[i] + 0][srow[i]] = rb[i].x; Bs[buf][skq[i] + 1][srow[i]] = rb[i].y;
             Bs[buf][skq[i] + 2][srow[i]] = rb[i].z; Bs[buf][skq[i] + 3][srow[i]] = rb[i].w;
         }
@@ -116,7 +137,9 @@ mlp_gemm_kernel(GemmParams p) {
     const int lr = lane & 31, lk = lane >> 5;
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nkt) g_load((kt + 1) * BK);
+        g_load(min(kt + 1, nkt - 1) * BK);   // unconditional (last tile re-read, unused): a branch here
+                                             // makes hipcc copy the loaded registers and wait early
+        if (PIN) __builtin_amdgcn_sched_barrier(0);   // ... and pin the loads ABOVE the MFMAs (hipcc sinks them otherwise)
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             const int k2 = kk * 2 + lk;
@@ -127,6 +150,9 @@ mlp_gemm_kernel(GemmParams p) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+        // keep the |v-u| arithmetic and the LDS writes of the prefetched tile BELOW the MFMAs:
+        // without this fence hipcc hoists them above the loop and waits for the loads first
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < nkt) s_store(buf ^ 1);
         __syncthreads();
     }
@@ -167,6 +193,81 @@ mlp_gemm_kernel(GemmParams p) {
     }
 }
 
+// Small-M variant: ONE wave per 32x32 output tile, operands straight from L2 into MFMA
+// registers (no LDS, no barrier), 3-deep register prefetch.  A (P+D)-row start/end problem is
+// (M/32)*(N/32) = 128 independent single-wave workgroups marching through K = 512 in ~10 us,
+// instead of 8 four-wave workgroups doing 32 barrier-separated k-tiles (~55 us, latency bound).
+// Lane (r = lane & 31, h = lane >> 5) loads 4 consecutive k of its row per 8-k step; MFMA step q
+// pairs k = 8*kk + q (lanes 0-31) with k = 8*kk + 4 + q (lanes 32-63) on both operands, so every
+// k is used exactly once (the summation order differs from the tiled kernel; tolerance 1e-4).
+template <int EMODE>
+__global__ void __launch_bounds__(64)
+mlp_gemm_small_kernel(GemmParams p) {
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const bool pair_mode = p.pf != nullptr;
+    const int row = min(m0 + r, p.M - 1), col = min(n0 + r, p.N - 1);
+    const float *a_ptr, *a2_ptr;
+    if (pair_mode) {
+        const int pi = row / p.D, di = row - pi * p.D;
+        a_ptr = p.pf + (size_t)pi * p.K + 4 * h;
+        a2_ptr = p.df + (size_t)di * p.K + 4 * h;
+    } else {
+        a_ptr = p.A + (size_t)row * p.K + 4 * h;
+        a2_ptr = a_ptr;
+    }
+    const float* b_ptr = p.W + (size_t)col * p.K + 4 * h;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    constexpr int PD = 3;
+    float4 ra[PD], ru[PD], rb[PD];
+    const int nk = p.K / 8;
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+        const int kk = min(s, nk - 1);
+        ra[s] = *reinterpret_cast<const float4*>(a_ptr + kk * 8);
+        ru[s] = *reinterpret_cast<const float4*>(a2_ptr + kk * 8);
+        rb[s] = *reinterpret_cast<const float4*>(b_ptr + kk * 8);
+    }
+    for (int kk = 0; kk < nk; kk += PD) {
+#pragma unroll
+        for (int s = 0; s < PD; ++s) {
+            if (kk + s < nk) {   // uniform
+                float4 a = ra[s];
+                const float4 u = ru[s], b = rb[s];
+                if (pair_mode) { a.x = fabsf(a.x - u.x); a.y = fabsf(a.y - u.y); a.z = fabsf(a.z - u.z); a.w = fabsf(a.w - u.w); }
+                const int nx = min(kk + s + PD, nk - 1);   // refill this slot (clamped: unconditional load)
+                ra[s] = *reinterpret_cast<const float4*>(a_ptr + nx * 8);
+                ru[s] = *reinterpret_cast<const float4*>(a2_ptr + nx * 8);
+                rb[s] = *reinterpret_cast<const float4*>(b_ptr + nx * 8);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
+    const int c = n0 + r;
+    const bool cok = c < p.N;
+    const float bv = cok ? p.bias[c] : 0.f;
+    const float wv = (EMODE == 1 && cok) ? p.w3[c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int orow = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const float hval = fmaxf(acc[i] + bv, 0.f);
+        if (EMODE == 0) {
+            if (cok && orow < p.M) p.H[(size_t)orow * p.N + c] = hval;
+        } else {
+            float v = hval * wv;
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+            if (r == 0 && orow < p.M) unsafeAtomicAdd(p.score + orow, v);
+        }
+    }
+}
+
 __global__ void fill_kernel(int n, const float* __restrict__ value, float* __restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = value[0];
@@ -182,10 +283,12 @@ se_feature_kernel(int P, int D, int C, const float* __restrict__ pf, const float
         float acc = 0.f;
         if (row < D) {
             const float dv = df[(size_t)row * C + k];
+#pragma unroll 8
             for (int i = 0; i < P; ++i) acc += fabsf(pf[(size_t)i * C + k] - dv);
             acc = acc / (float)P;
         } else {
             const float pv = pf[(size_t)(row - D) * C + k];
+#pragma unroll 8
             for (int j = 0; j < D; ++j) acc += fabsf(pv - df[(size_t)j * C + k]);
             acc = acc / (float)D;
         }
@@ -234,29 +337,83 @@ dual_softmax_kernel(int P, int D, const float* __restrict__ S, const float* __re
 
 static int check_mlp(const jm_mlp3_t* m, const char* who) {
     JM_REQUIRE(m && m->w1 && m->b1 && m->w2 && m->b2 && m->w3 && m->b3, "%s: null weights", who);
-    JM_REQUIRE(m->c >= 16 && m->c % 16 == 0 && m->h1 >= 16 && m->h1 % 16 == 0 && m->h2 >= 1,
-               "%s: channel sizes must be multiples of 16 (c=%d h1=%d h2=%d)", who, m->c, m->h1, m->h2);
+    JM_REQUIRE(m->c >= 32 && m->c % 32 == 0 && m->h1 >= 32 && m->h1 % 32 == 0 && m->h2 >= 1,
+               "%s: channel sizes must be multiples of 32 (c=%d h1=%d h2=%d)", who, m->c, m->h1, m->h2);
     JM_REQUIRE(((reinterpret_cast<uintptr_t>(m->w1) | reinterpret_cast<uintptr_t>(m->w2)) & 15u) == 0,
                "%s: weights must be 16-byte aligned", who);
     return JM_OK;
 }
 
-// run the 3-layer MLP with either plain rows x (M,C) or the implicit pair rows
-static int run_mlp(int M, const float* x, const float* pf, const float* df, int D, const jm_mlp3_t* mlp,
-                   float* hidden /* (M,H1) */, float* y /* (M) */, hipStream_t s) {
-    GemmParams g1{};
-    g1.M = M; g1.N = mlp->h1; g1.K = mlp->c;
-    g1.A = x; g1.pf = pf; g1.df = df; g1.D = D;
-    g1.W = mlp->w1; g1.bias = mlp->b1; g1.H = hidden;
-    dim3 grid1(divup(g1.N, BN), divup(M, BM));
-    if (x) hipLaunchKernelGGL((mlp_gemm_kernel<0, 0>), grid1, dim3(256), 0, s, g1);
-    else   hipLaunchKernelGGL((mlp_gemm_kernel<1, 0>), grid1, dim3(256), 0, s, g1);
-    hipLaunchKernelGGL(fill_kernel, dim3(divup(M, 256)), dim3(256), 0, s, M, mlp->b3, y);
-    GemmParams g2{};
-    g2.M = M; g2.N = mlp->h2; g2.K = mlp->h1;
-    g2.A = hidden; g2.W = mlp->w2; g2.bias = mlp->b2; g2.w3 = mlp->w3; g2.score = y;
-    dim3 grid2(divup(g2.N, BN), divup(M, BM));
-    hipLaunchKernelGGL((mlp_gemm_kernel<0, 1>), grid2, dim3(256), 0, s, g2);
+struct MlpJob {
+    int M;                 // rows
+    const float* x;        // plain rows (M,C), or nullptr for pair rows
+    const float *pf, *df;  // pair mode
+    int D;
+    const jm_mlp3_t* mlp;
+    float* hidden;         // (M,H1) scratch
+    float* y;              // (M) output
+};
+
+// one non-blocking side stream + fork/join events per device, created on first use
+struct SideStream { hipStream_t stream; hipEvent_t fork, join; };
+static SideStream* side_stream() {
+    static SideStream tab[16];
+    static bool made[16];
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!made[dev]) {
+        if (hipStreamCreateWithFlags(&tab[dev].stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&tab[dev].fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&tab[dev].join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        made[dev] = true;
+    }
+    return &tab[dev];
+}
+
+static int tiles_of(int M, int N) { return divup(M, BM) * divup(N, BN); }
+
+// run the 3-layer MLP for up to two jobs: 1 launch per layer (grouped) + 1 fill launch
+static int run_mlps(const MlpJob* jobs, int njobs, hipStream_t s) {
+    GemmGroup g1{}, g2{};
+    int t1 = 0, t2 = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const MlpJob& jb = jobs[j];
+        GemmParams& a = g1.p[j];
+        a.M = jb.M; a.N = jb.mlp->h1; a.K = jb.mlp->c;
+        a.A = jb.x; a.pf = jb.x ? nullptr : jb.pf; a.df = jb.df; a.D = jb.D;
+        a.W = jb.mlp->w1; a.bias = jb.mlp->b1; a.H = jb.hidden;
+        GemmParams& b = g2.p[j];
+        b.M = jb.M; b.N = jb.mlp->h2; b.K = jb.mlp->h1;
+        b.A = jb.hidden; b.pf = nullptr; b.W = jb.mlp->w2; b.bias = jb.mlp->b2; b.w3 = jb.mlp->w3; b.score = jb.y;
+        if (j == 0) { g1.tiles0 = tiles_of(a.M, a.N); g2.tiles0 = tiles_of(b.M, b.N); }
+        t1 += tiles_of(a.M, a.N);
+        t2 += tiles_of(b.M, b.N);
+    }
+    static const int small_m = getenv("JM_GEMM_SMALL_M") ? atoi(getenv("JM_GEMM_SMALL_M")) : 4096;
+    if (njobs == 1 && jobs[0].M <= small_m) {
+        const GemmParams& a = g1.p[0];
+        const GemmParams& b = g2.p[0];
+        hipLaunchKernelGGL((mlp_gemm_small_kernel<0>), dim3(divup(a.N, 32), divup(a.M, 32)), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(fill_kernel, dim3(divup(jobs[0].M, 256)), dim3(256), 0, s, jobs[0].M, jobs[0].mlp->b3, jobs[0].y);
+        hipLaunchKernelGGL((mlp_gemm_small_kernel<1>), dim3(divup(b.N, 32), divup(b.M, 32)), dim3(64), 0, s, b);
+        return check_launch("affinity mlp (small)");
+    }
+    static const int bk = getenv("JM_GEMM_BK") ? atoi(getenv("JM_GEMM_BK")) : 16;
+    static const int pin = getenv("JM_GEMM_PIN") ? atoi(getenv("JM_GEMM_PIN")) : 1;
+#define JM_GEMM_LAUNCH(E, T, G)                                                                          \
+    do {                                                                                                 \
+        if (bk == 32 && pin) hipLaunchKernelGGL((mlp_gemm_kernel<E, 32, true>), dim3(T), dim3(256), 0, s, G);        \
+        else if (bk == 32) hipLaunchKernelGGL((mlp_gemm_kernel<E, 32, false>), dim3(T), dim3(256), 0, s, G);        \
+        else if (pin) hipLaunchKernelGGL((mlp_gemm_kernel<E, 16, true>), dim3(T), dim3(256), 0, s, G);              \
+        else hipLaunchKernelGGL((mlp_gemm_kernel<E, 16, false>), dim3(T), dim3(256), 0, s, G);                      \
+    } while (0)
+    JM_GEMM_LAUNCH(0, t1, g1);
+    for (int j = 0; j < njobs; ++j)
+        hipLaunchKernelGGL(fill_kernel, dim3(divup(jobs[j].M, 256)), dim3(256), 0, s, jobs[j].M, jobs[j].mlp->b3, jobs[j].y);
+    JM_GEMM_LAUNCH(1, t2, g2);
+#undef JM_GEMM_LAUNCH
     return check_launch("affinity mlp");
 }
 
@@ -278,7 +435,8 @@ extern "C" int jm_mlp3_forward(int m, const float* x, const jm_mlp3_t* mlp, floa
     JM_REQUIRE(x && y && ws, "mlp3: null pointer");
     JM_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15u) == 0, "mlp3: x must be 16-byte aligned");
     if (ws_bytes < jm_mlp3_workspace_bytes(m, mlp)) { set_error("mlp3: workspace too small"); return JM_EWORKSPACE; }
-    return run_mlp(m, x, nullptr, nullptr, 1, mlp, (float*)ws, y, (hipStream_t)stream);
+    const MlpJob job{m, x, nullptr, nullptr, 1, mlp, (float*)ws, y};
+    return run_mlps(&job, 1, (hipStream_t)stream);
 }
 
 // workspace: [hidden link (P*D,H1)] [S raw (P*D)] [se feat (D+P,C)] [se hidden (D+P,H1)] [se logit (D+P)] [stats 2(P+D)]
@@ -314,21 +472,41 @@ extern "C" int jm_affinity_forward(int p, int d, const float* pred_feat, const f
     float* sraw = (float*)w;   w += align_up(pd * sizeof(float), 256);
     float* stats = (float*)w;  w += align_up(2 * r * sizeof(float), 256);
     float* S = link_raw ? link_raw : sraw;
-    rc = run_mlp((int)pd, nullptr, pred_feat, det_feat, d, link, hidden, S, s);
+    // The start/end head is a tiny, latency-bound problem ((P+D) rows: 8 workgroups marching
+    // through 32 k-tiles).  Grouping it into the link head's launches makes every launch as long
+    // as that slow chain (measured: +35 % per GEMM), so it runs as its own chain on a side stream
+    // forked from / joined to the caller's stream with events (capturable in a hipGraph).
+    float* logit = nullptr;
+    bool contiguous_out = false;
+    SideStream* side = nullptr;
+    if (se) {
+        float* feat = (float*)w;    w += align_up(r * se->c * sizeof(float), 256);
+        float* sehid = (float*)w;   w += align_up(r * se->h1 * sizeof(float), 256);
+        logit = (float*)w;
+        contiguous_out = (end == start + d);   // caller gave one (D+P) buffer: write logits in place
+        side = side_stream();
+        hipStream_t s2 = side ? side->stream : s;
+        if (side) {
+            (void)hipEventRecord(side->fork, s);
+            (void)hipStreamWaitEvent(s2, side->fork, 0);
+        }
+        hipLaunchKernelGGL(se_feature_kernel, dim3((unsigned)r), dim3(256), 0, s2, p, d, se->c, pred_feat, det_feat, feat);
+        const MlpJob sj{(int)r, feat, nullptr, nullptr, 1, se, sehid, contiguous_out ? start : logit};
+        rc = run_mlps(&sj, 1, s2);
+        if (rc) return rc;
+        if (!contiguous_out) {
+            (void)hipMemcpyAsync(start, logit, (size_t)d * sizeof(float), hipMemcpyDeviceToDevice, s2);
+            (void)hipMemcpyAsync(end, logit + d, (size_t)p * sizeof(float), hipMemcpyDeviceToDevice, s2);
+        }
+        if (side) (void)hipEventRecord(side->join, s2);
+    }
+    const MlpJob lj{(int)pd, nullptr, pred_feat, det_feat, d, link, hidden, S};
+    rc = run_mlps(&lj, 1, s);
     if (rc) return rc;
     if (link_out) {
         hipLaunchKernelGGL(softmax_stats_kernel, dim3((unsigned)r), dim3(256), 0, s, p, d, S, stats);
         hipLaunchKernelGGL(dual_softmax_kernel, dim3(divup((int)pd, 256)), dim3(256), 0, s, p, d, S, stats, link_out);
     }
-    if (se) {
-        float* feat = (float*)w;    w += align_up(r * se->c * sizeof(float), 256);
-        float* sehid = (float*)w;   w += align_up(r * se->h1 * sizeof(float), 256);
-        float* logit = (float*)w;
-        hipLaunchKernelGGL(se_feature_kernel, dim3((unsigned)r), dim3(256), 0, s, p, d, se->c, pred_feat, det_feat, feat);
-        rc = run_mlp((int)r, feat, nullptr, nullptr, 1, se, sehid, logit, s);
-        if (rc) return rc;
-        (void)hipMemcpyAsync(start, logit, (size_t)d * sizeof(float), hipMemcpyDeviceToDevice, s);
-        (void)hipMemcpyAsync(end, logit + d, (size_t)p * sizeof(float), hipMemcpyDeviceToDevice, s);
-    }
+    if (side) (void)hipStreamWaitEvent(s, side->join, 0);
     return check_launch("affinity");
 }

@@ -29,27 +29,60 @@ struct BqParams {
     int* idx[2];
     int lds_hits_off[2];  // int offsets into dynamic LDS of the per-radius hit lists
     int lds_cnt_off[2];   // per-radius counts [NW][64]
-    int chunk;            // points per wave slice (multiple of 4)
+    int chunk;            // points per wave slice (multiple of 8)
 };
 
-template <int NR>
-__device__ __forceinline__ void bq_visit(int k, float px, float py, float pz, float cx, float cy, float cz,
-                                         const BqParams& p, int (&cnt)[NR], int* lds, int wave, int lane) {
-    // (new_x - x)^2 + ... with the oracle's contraction
-    const float d2 = sqdist3(cx - px, cy - py, cz - pz);
+// HT = unsigned short when n <= 65536 (halves the LDS per wave -> twice the waves per CU)
+template <int NR, typename HT>
+__device__ __forceinline__ void bq_hit(int k, float d2, const BqParams& p, int (&cnt)[NR], HT* lds, int wave,
+                                       int lane) {
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         if (d2 < p.r2[r] && cnt[r] < p.ns[r]) {
-            lds[p.lds_hits_off[r] + (wave * p.ns[r] + cnt[r]) * 64 + lane] = k;
+            lds[p.lds_hits_off[r] + (wave * p.ns[r] + cnt[r]) * 64 + lane] = (HT)k;
             ++cnt[r];
         }
     }
 }
 
-template <int NR>
+// 8 consecutive points = 24 floats = 6 aligned float4, fetched through the scalar cache
+struct Pts8 { float4 q[6]; };
+
+__device__ __forceinline__ Pts8 load_pts8(const float* __restrict__ base) {  // wave-uniform address
+    Pts8 g;
+    const float4* q = reinterpret_cast<const float4*>(base);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g.q[i] = q[i];
+    return g;
+}
+
+template <int NR, typename HT>
+__device__ __forceinline__ void bq_group8(int k, const Pts8& g, float cx, float cy, float cz, float r2max,
+                                          const BqParams& p, int (&cnt)[NR], HT* lds, int wave, int lane) {
+    // (new_x - x)^2 + ... with the oracle's contraction, for the 8 points of the group
+    const float f[24] = {g.q[0].x, g.q[0].y, g.q[0].z, g.q[0].w, g.q[1].x, g.q[1].y, g.q[1].z, g.q[1].w,
+                         g.q[2].x, g.q[2].y, g.q[2].z, g.q[2].w, g.q[3].x, g.q[3].y, g.q[3].z, g.q[3].w,
+                         g.q[4].x, g.q[4].y, g.q[4].z, g.q[4].w, g.q[5].x, g.q[5].y, g.q[5].z, g.q[5].w};
+    float d2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d2[i] = sqdist3(cx - f[3 * i], cy - f[3 * i + 1], cz - f[3 * i + 2]);
+    // fast path: nobody in the wave has a hit among these 8 points (the common case: hits are a
+    // handful per centre per cloud) -> one min tree + one compare per 8 points
+    const float dmin = fminf(fminf(fminf(d2[0], d2[1]), fminf(d2[2], d2[3])), fminf(fminf(d2[4], d2[5]), fminf(d2[6], d2[7])));
+    bool open = false;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) open = open || (cnt[r] < p.ns[r]);
+    if (__any(open && dmin < r2max)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bq_hit<NR, HT>(k + i, d2[i], p, cnt, lds, wave, lane);
+    }
+}
+
+template <int NR, typename HT>
 __global__ void __launch_bounds__(1024)
 ball_query_kernel(BqParams p, const float* __restrict__ new_xyz, const float* __restrict__ xyz) {
-    extern __shared__ __attribute__((aligned(16))) int lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    HT* lds = reinterpret_cast<HT*>(lds_raw);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform -> scalar loads
     const int nw = blockDim.x >> 6;
@@ -60,39 +93,47 @@ ball_query_kernel(BqParams p, const float* __restrict__ new_xyz, const float* __
     const float* cptr = new_xyz + ((size_t)bi * p.m + (active ? ci : 0)) * 3;
     const float cx = cptr[0], cy = cptr[1], cz = cptr[2];
     const float* pts = xyz + (size_t)bi * p.n * 3;
+    const float r2max = NR == 2 ? fmaxf(p.r2[0], p.r2[1]) : p.r2[0];
 
     int cnt[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) cnt[r] = active ? 0 : p.ns[r];  // inactive lanes look "full"
 
-    const int k_begin = wave * p.chunk;
+    const int k_begin = wave * p.chunk;                 // multiple of 8
     const int k_end = min(p.n, k_begin + p.chunk);
     int k = k_begin;
-    // 16-byte aligned fast path: 4 points = 3 x s_load_dwordx4
+    // 16-byte aligned fast path: groups of 8 points, the next group's scalar loads are issued
+    // before the current group is processed (software prefetch through the scalar cache)
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(pts) & 15u) == 0);
-    if (aligned16) {
-        for (; k + 4 <= k_end; k += 4) {
+    if (aligned16 && k + 16 <= k_end) {
+        // two named buffers: while one group of 8 is being evaluated the other one's scalar loads
+        // are in flight (prefetch distance = a full group of work per wave)
+        Pts8 ga = load_pts8(pts + (size_t)k * 3);
+        Pts8 gb = load_pts8(pts + (size_t)(k + 8) * 3);
+        for (; k + 32 <= k_end; k += 16) {
+            bq_group8<NR, HT>(k, ga, cx, cy, cz, r2max, p, cnt, lds, wave, lane);
+            ga = load_pts8(pts + (size_t)(k + 16) * 3);
+            bq_group8<NR, HT>(k + 8, gb, cx, cy, cz, r2max, p, cnt, lds, wave, lane);
+            gb = load_pts8(pts + (size_t)(k + 24) * 3);
             bool full = true;
 #pragma unroll
             for (int r = 0; r < NR; ++r) full = full && (cnt[r] >= p.ns[r]);
-            if (__all(full)) { k = k_end; break; }
-            const float4* q = reinterpret_cast<const float4*>(pts + (size_t)k * 3);  // wave-uniform address
-            const float4 a = q[0], b = q[1], c = q[2];
-            bq_visit<NR>(k + 0, a.x, a.y, a.z, cx, cy, cz, p, cnt, lds, wave, lane);
-            bq_visit<NR>(k + 1, a.w, b.x, b.y, cx, cy, cz, p, cnt, lds, wave, lane);
-            bq_visit<NR>(k + 2, b.z, b.w, c.x, cx, cy, cz, p, cnt, lds, wave, lane);
-            bq_visit<NR>(k + 3, c.y, c.z, c.w, cx, cy, cz, p, cnt, lds, wave, lane);
+            if (__all(full)) { k = k_end - 16; break; }   // every list of this wave is full: done
         }
+        bq_group8<NR, HT>(k, ga, cx, cy, cz, r2max, p, cnt, lds, wave, lane);
+        bq_group8<NR, HT>(k + 8, gb, cx, cy, cz, r2max, p, cnt, lds, wave, lane);
+        k += 16;
     }
     for (; k < k_end; ++k) {
         bool full = true;
 #pragma unroll
         for (int r = 0; r < NR; ++r) full = full && (cnt[r] >= p.ns[r]);
         if (__all(full)) break;
-        bq_visit<NR>(k, pts[k * 3 + 0], pts[k * 3 + 1], pts[k * 3 + 2], cx, cy, cz, p, cnt, lds, wave, lane);
+        const float d2 = sqdist3(cx - pts[k * 3 + 0], cy - pts[k * 3 + 1], cz - pts[k * 3 + 2]);
+        bq_hit<NR, HT>(k, d2, p, cnt, lds, wave, lane);
     }
 #pragma unroll
-    for (int r = 0; r < NR; ++r) lds[p.lds_cnt_off[r] + wave * 64 + lane] = active ? cnt[r] : 0;
+    for (int r = 0; r < NR; ++r) lds[p.lds_cnt_off[r] + wave * 64 + lane] = (HT)(active ? cnt[r] : 0);
     __syncthreads();
 
     // merge: out row of centre l = concat over slices, truncated to ns, back-filled with the first
@@ -100,8 +141,8 @@ ball_query_kernel(BqParams p, const float* __restrict__ new_xyz, const float* __
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int ns = p.ns[r];
-        const int* hits = lds + p.lds_hits_off[r];
-        const int* cnts = lds + p.lds_cnt_off[r];
+        const HT* hits = lds + p.lds_hits_off[r];
+        const HT* cnts = lds + p.lds_cnt_off[r];
         int* out = p.idx[r] + ((size_t)bi * p.m + c0) * ns;
         const int valid = min(64, p.m - c0) * ns;
         for (int e = threadIdx.x; e < valid; e += blockDim.x) {
@@ -130,8 +171,10 @@ static int launch_ball_query(int b, int n, int m, int nr, const float* radius, c
     const int groups = b * divup(m, 64);
     int nw = 1;
     while (nw < 16 && groups * nw < 4096 && (n / (nw * 2)) >= 256) nw *= 2;
-    const int lds_budget = 64 * 1024;
-    while (nw > 1 && (nw * 64 * (ns_sum + nr)) * (int)sizeof(int) > lds_budget) nw /= 2;
+    const bool small = n <= 65536;   // indices (and counts <= 1024) fit 16 bits
+    const int esz = small ? 2 : 4;
+    const int lds_budget = 52 * 1024;  // <= 3 workgroups per CU
+    while (nw > 1 && (nw * 64 * (ns_sum + nr)) * esz > lds_budget) nw /= 2;
     BqParams p;
     p.n = n; p.m = m;
     int off = 0;
@@ -145,19 +188,20 @@ static int launch_ball_query(int b, int n, int m, int nr, const float* radius, c
         p.lds_cnt_off[r] = off;
         if (r < nr) off += nw * 64;
     }
-    p.chunk = (divup(n, nw) + 3) / 4 * 4;
-    const size_t lds_bytes = (size_t)off * sizeof(int);
+    p.chunk = (divup(n, nw) + 7) / 8 * 8;
+    const size_t lds_bytes = (size_t)off * esz;
     JM_REQUIRE(lds_bytes <= 160 * 1024, "ball_query: nsample too large for LDS (%zu B)", lds_bytes);
     dim3 grid(divup(m, 64), b), block(64 * nw);
-    if (nr == 1) {
-        if (lds_bytes > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)ball_query_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(ball_query_kernel<1>, grid, block, lds_bytes, s, p, new_xyz, xyz);
-    } else {
-        if (lds_bytes > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)ball_query_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(ball_query_kernel<2>, grid, block, lds_bytes, s, p, new_xyz, xyz);
-    }
+#define JM_BQ_LAUNCH(NRV, HTV)                                                                              \
+    do {                                                                                                   \
+        if (lds_bytes > 64 * 1024)                                                                         \
+            (void)hipFuncSetAttribute((const void*)ball_query_kernel<NRV, HTV>,                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);         \
+        hipLaunchKernelGGL((ball_query_kernel<NRV, HTV>), grid, block, lds_bytes, s, p, new_xyz, xyz);      \
+    } while (0)
+    if (nr == 1) { if (small) JM_BQ_LAUNCH(1, unsigned short); else JM_BQ_LAUNCH(1, int); }
+    else         { if (small) JM_BQ_LAUNCH(2, unsigned short); else JM_BQ_LAUNCH(2, int); }
+#undef JM_BQ_LAUNCH
     return check_launch("ball_query");
 }
 

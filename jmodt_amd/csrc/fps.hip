@@ -18,6 +18,8 @@
 //    broadcast ds_read_b128 — the next centre never goes through global memory.
 //  * Distances use d = fma(dz,dz, fma(dx,dx, dy*dy)) (oracle convention; library is built
 //    with -ffp-contract=off so nothing else fuses).
+#include <stdlib.h>
+
 #include "jm_common.h"
 
 namespace jm {
@@ -33,36 +35,42 @@ struct __attribute__((aligned(16))) FpsCand {
     int pad[3];
 };
 
-template <int J>
-__global__ void __launch_bounds__(1024)
-fps_regs_kernel(int n, int m, int bs, int bs_log2, const float* __restrict__ dataset, float* __restrict__ temp,
-                int* __restrict__ idxs) {
+// PTS points per thread, held in registers for the whole loop.  The workgroup has BT = blockDim.x
+// threads and impersonates the reference's BS = bs threads: thread T covers the R = bs / BT
+// consecutive *priority* indices P = T*R + r (reference thread t = bitreverse(P)), and for each
+// of them the J = ceil(n / bs) points k = t + bs*j.  Register slot i = r*J + j, visited in
+// ascending i with a strict `>`, so inside a thread — and, because lanes and waves are ordered by
+// P, across the whole workgroup — "first maximum wins" is exactly the reference's tie order.
+// Fewer, fatter waves (BT < bs) pay the per-iteration reduce/publish/barrier overhead once per
+// wave instead of once per 16 points.
+template <int PTS, int MAXBT>
+__global__ void __launch_bounds__(MAXBT)
+fps_regs_kernel(int n, int m, int bs, int bs_log2, int R, int J, int recipJ, const float* __restrict__ dataset,
+                float* __restrict__ temp, int* __restrict__ idxs) {
     __shared__ FpsCand cand[2][16];
     __shared__ int out_buf[FPS_OUT_CHUNK];  // picks are staged here: a global store inside the loop would
                                             // make every __syncthreads() wait for its write-ack (vmcnt(0))
     const int T = threadIdx.x;
     const int nwaves = (blockDim.x + 63) >> 6;
-    const int wave = T >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(T >> 6);
     const int lane = T & 63;
     const float* ds = dataset + (size_t)blockIdx.x * n * 3;
     float* tp = temp + (size_t)blockIdx.x * n;
     int* out = idxs + (size_t)blockIdx.x * m;
 
-    // reference thread id this thread impersonates (T >= bs only when bs < 64: idle lanes)
-    const bool live = T < bs;
-    const int t = live ? (int)bitrev_u((unsigned)T, bs_log2) : 0;
-
-    float px[J], py[J], pz[J], tm[J];
+    float px[PTS], py[PTS], pz[PTS], tm[PTS];
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const int k = t + bs * j;
-        const bool ok = live && k < n;
+    for (int i = 0; i < PTS; ++i) {
+        const int r = (i * recipJ) >> 16, j = i - r * J;   // i / J, i % J for i < 64
+        const int P = T * R + r;
+        const int k = (int)bitrev_u((unsigned)P, bs_log2) + bs * j;
+        const bool ok = r < R && P < bs && k < n;
         // padding slots: coordinates +inf (d = inf) and temp -1, so min(d, temp) stays -1 and
         // can never beat `best = -1` under strict >
-        px[j] = ok ? ds[k * 3 + 0] : INFINITY;
-        py[j] = ok ? ds[k * 3 + 1] : INFINITY;
-        pz[j] = ok ? ds[k * 3 + 2] : INFINITY;
-        tm[j] = ok ? tp[k] : -1.f;
+        px[i] = ok ? ds[k * 3 + 0] : INFINITY;
+        py[i] = ok ? ds[k * 3 + 1] : INFINITY;
+        pz[i] = ok ? ds[k * 3 + 2] : INFINITY;
+        tm[i] = ok ? tp[k] : -1.f;
     }
 
     float x1 = ds[0], y1 = ds[1], z1 = ds[2];
@@ -75,14 +83,14 @@ fps_regs_kernel(int n, int m, int bs, int bs_log2, const float* __restrict__ dat
             __syncthreads();
         }
         float best = -1.f;
-        int bj = 0;
+        int bi = 0;
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const float d = sqdist3(px[j] - x1, py[j] - y1, pz[j] - z1);
-            const float d2 = fast_min(d, tm[j]);
-            tm[j] = d2;
+        for (int i = 0; i < PTS; ++i) {
+            const float d = sqdist3(px[i] - x1, py[i] - y1, pz[i] - z1);
+            const float d2 = fast_min(d, tm[i]);
+            tm[i] = d2;
             const bool gt = d2 > best;
-            bj = gt ? j : bj;
+            bi = gt ? i : bi;
             best = gt ? d2 : best;
         }
         // wave arg-max: lanes are in tie-priority order, so the first lane holding the max wins
@@ -90,18 +98,13 @@ fps_regs_kernel(int n, int m, int bs, int bs_log2, const float* __restrict__ dat
         const int wmax = wave_max_i32(bits);
         const unsigned long long eq = __ballot(bits == wmax);
         const int wl = (int)__ffsll((long long)eq) - 1;
-        const int bj_u = __builtin_amdgcn_readlane(bj, wl);
-        int sx = 0, sy = 0, sz = 0;
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            if (bj_u == j) {  // wave-uniform branch
-                sx = __builtin_amdgcn_readlane(__float_as_int(px[j]), wl);
-                sy = __builtin_amdgcn_readlane(__float_as_int(py[j]), wl);
-                sz = __builtin_amdgcn_readlane(__float_as_int(pz[j]), wl);
-            }
-        }
-        const int t_w = (int)bitrev_u((unsigned)((wave << 6) | wl), bs_log2);
-        const int k_w = t_w + bs * bj_u;
+        const int bi_u = __builtin_amdgcn_readlane(bi, wl);
+        // wave-uniform dynamic index into the register arrays (s_set_gpr_idx_on + v_mov)
+        const int sx = __builtin_amdgcn_readlane(__float_as_int(px[bi_u]), wl);
+        const int sy = __builtin_amdgcn_readlane(__float_as_int(py[bi_u]), wl);
+        const int sz = __builtin_amdgcn_readlane(__float_as_int(pz[bi_u]), wl);
+        const int r_w = (bi_u * recipJ) >> 16, j_w = bi_u - r_w * J;
+        const int k_w = (int)bitrev_u((unsigned)(((wave << 6) | wl) * R + r_w), bs_log2) + bs * j_w;
         int old;
         if (nwaves == 1) {
             old = k_w;
@@ -132,9 +135,11 @@ fps_regs_kernel(int n, int m, int bs, int bs_log2, const float* __restrict__ dat
 
     // leave `temp` as the reference kernel does (it updates it in place every iteration)
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const int k = t + bs * j;
-        if (live && k < n) tp[k] = tm[j];
+    for (int i = 0; i < PTS; ++i) {
+        const int r = (i * recipJ) >> 16, j = i - r * J;
+        const int P = T * R + r;
+        const int k = (int)bitrev_u((unsigned)P, bs_log2) + bs * j;
+        if (r < R && P < bs && k < n) tp[k] = tm[i];
     }
 }
 
@@ -211,15 +216,35 @@ extern "C" int jm_furthest_point_sampling(int b, int n, int m, const float* xyz,
     int bs_log2 = 0;
     while ((1 << bs_log2) < bs) ++bs_log2;
     const int J = divup(n, bs);
-    const int block = bs < 64 ? 64 : bs;
-#define JM_FPS_LAUNCH(JJ) \
-    hipLaunchKernelGGL(fps_regs_kernel<JJ>, dim3(b), dim3(block), 0, s, n, m, bs, bs_log2, xyz, temp, idx)
-    if (J <= 1) JM_FPS_LAUNCH(1);
-    else if (J <= 2) JM_FPS_LAUNCH(2);
-    else if (J <= 4) JM_FPS_LAUNCH(4);
-    else if (J <= 8) JM_FPS_LAUNCH(8);
-    else if (J <= 16) JM_FPS_LAUNCH(16);
-    else hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(bs), 0, s, n, m, bs_log2, xyz, temp, idx);
+    if (J > 32 || (J > 16 && bs > 512)) {  // does not fit the register file: stream from L2
+        hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(bs), 0, s, n, m, bs_log2, xyz, temp, idx);
+        return check_launch("fps(stream)");
+    }
+    // threads per workgroup: points-per-thread target from a measured table,
+    // overridable for experiments with JM_FPS_PTS
+    // measured on MI355X (tools/fps_sweep.py): 16 points per lane is at or within 3 % of the best
+    // geometry for every n <= 16384 (n = 16384: 16 waves; 4096: 4 waves; <= 1024: ONE wave, no
+    // barrier, no LDS); 32 per lane is 5 % slower at n = 16384 and 40 % slower at 4096.
+    int want_pts = 16;
+    if (const char* e = getenv("JM_FPS_PTS")) want_pts = atoi(e);
+    if (want_pts < J) want_pts = J;
+    if (want_pts > 32) want_pts = 32;
+    int R = 1;
+    while (R * 2 * J <= want_pts && bs / (R * 2) >= 64) R *= 2;
+    int block = bs / R;
+    if (block < 64) block = 64;
+    const int pts = R * J;
+    const int recipJ = 65536 / J + 1;
+#define JM_FPS_LAUNCH(P, MB)                                                                                  \
+    hipLaunchKernelGGL((fps_regs_kernel<P, MB>), dim3(b), dim3(block), 0, s, n, m, bs, bs_log2, R, J, recipJ, \
+                       xyz, temp, idx)
+    if (pts <= 1) JM_FPS_LAUNCH(1, 1024);
+    else if (pts <= 2) JM_FPS_LAUNCH(2, 1024);
+    else if (pts <= 4) JM_FPS_LAUNCH(4, 1024);
+    else if (pts <= 8) JM_FPS_LAUNCH(8, 1024);
+    else if (pts <= 16) JM_FPS_LAUNCH(16, 1024);
+    else if (block <= 512) JM_FPS_LAUNCH(32, 512);
+    else { set_error("fps: internal geometry error (pts=%d block=%d)", pts, block); return JM_EINVAL; }
 #undef JM_FPS_LAUNCH
     return check_launch("fps");
 }

@@ -221,52 +221,111 @@ nms_mask_kernel(int n, float thresh, const float* __restrict__ boxes, unsigned l
 }
 
 // ------------------------------------------------------------------ NMS greedy reduce (device)
-// Single workgroup.  remv (col_blocks x u64) lives in LDS.  Semantics of iou3d.cpp:98-114:
-// ascending i, keep i if its bit is not set in remv, then remv |= mask_row(i) for column
-// blocks >= i/64.
-__global__ void __launch_bounds__(1024)
+// Single workgroup of 1024 threads.  remv (col_blocks x u64) lives in LDS.  Semantics of
+// iou3d.cpp:98-114: ascending i, keep i if its bit is not set in remv, then
+// remv |= mask_row(i) for column blocks >= i/64.
+//
+// The row blocks are inherently sequential (whether box i survives depends on every kept box
+// before it), so the kernel is built around the latency of one row-block step:
+//  * wave 0 resolves the 64 boxes of the block with a scalar loop over the *surviving
+//    candidates* only (ctz + readlane of the diagonal tile; no memory access);
+//  * the mask words the OR phase will need for row block rb+1 (64 rows x up to 128 later column
+//    blocks, 8 words per thread, coalesced along the row) and wave 0's next diagonal tile are
+//    PREFETCHED into registers during step rb, before it is known which rows survive; the
+//    barriers are raw s_barrier + lgkmcnt(0) so those global loads stay in flight across them
+//    (a __syncthreads() would drain vmcnt).
+//  * selected words are OR-ed in registers and merged with LDS atomics (ds_or_b64).
+constexpr int NMS_RT = 512;   // 4 row groups x 128 columns; 256-VGPR budget holds the 4-deep prefetch ring
+
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__global__ void __launch_bounds__(NMS_RT)
 nms_reduce_kernel(int n, const unsigned long long* __restrict__ mask, long long* __restrict__ keep,
                   int* __restrict__ num_keep) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];  // [col_blocks] + 1 (kept bits)
-    const int col_blocks = (n + 63) / 64;
+    const int cb = (n + 63) / 64;
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int j = tid; j <= col_blocks; j += blockDim.x) remv[j] = 0ULL;
-    __syncthreads();
+    const int c = tid & 127, g = tid >> 7;   // OR phase: column offset 0..127, row group 0..3 (rows g + 4q)
+    for (int j = tid; j <= cb; j += NMS_RT) remv[j] = 0ULL;
+
+    // ring of 4 register sets: the words of row blocks rb .. rb+3 are in flight / resident, so a
+    // load has ~3 row-block steps (resolve + 2 barriers each) to arrive from L2/HBM
+    unsigned long long W[4][16];
+    unsigned long long D[4] = {0ULL, 0ULL, 0ULL, 0ULL};  // wave 0: diagonal tile row of this lane
+    // Loads are UNCONDITIONAL on clamped (always in-bounds) addresses: a `cond ? load : 0` makes
+    // hipcc branch around every load and drain vmcnt(0) at each join.  Out-of-range words are
+    // never consumed: rows >= n cannot be kept (rowmask), columns >= cb are skipped at the OR.
+    auto prefetch = [&](int rb, unsigned long long (&w)[16], unsigned long long& d) {
+        const int rbc = min(rb, cb - 1);
+        const int col = min(rbc + 1 + c, cb - 1);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = min(rbc * 64 + g + 4 * q, n - 1);
+            w[q] = mask[(size_t)row * cb + col];
+        }
+        d = mask[(size_t)min(rbc * 64 + lane, n - 1) * cb + rbc];   // consumed by wave 0 only
+    };
     int count = 0;  // uniform
-    for (int rb = 0; rb < col_blocks; ++rb) {
+    auto step = [&](int rb, unsigned long long (&w)[16], unsigned long long& d) {
         const int rows = min(64, n - rb * 64);
-        if (tid < 64) {  // wave 0
-            unsigned long long diag = 0ULL;
-            if (lane < rows) diag = mask[(size_t)(rb * 64 + lane) * col_blocks + rb];
-            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-            unsigned long long r = remv[rb];
-            unsigned long long kept = 0ULL;
-            for (int bit = 0; bit < rows; ++bit) {  // uniform scalar loop
-                if (!((r >> bit) & 1ULL)) {
-                    kept |= 1ULL << bit;
-                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)dlo, bit);
-                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)dhi, bit);
-                    r |= ((unsigned long long)hi << 32) | lo;
-                }
+        if (tid < 64) {  // wave 0: resolve this row block
+            const unsigned long long r = remv[rb];
+            const unsigned long long rowmask = rows == 64 ? ~0ULL : ((1ULL << rows) - 1ULL);
+            unsigned long long cand = ~r & rowmask, kept = 0ULL;
+            // Greedy resolution of the block in PARALLEL ROUNDS instead of one candidate at a time:
+            // a candidate that no other current candidate suppresses can never be removed (everything
+            // that could remove it is itself a candidate with a lower index), so all such boxes are
+            // kept at once and what they suppress is dropped.  The lowest candidate is always safe,
+            // so every round makes progress; rounds = depth of the suppression chains (1-3 in
+            // practice) instead of one ~80-cycle scalar step per kept box.
+            const unsigned long long me = 1ULL << lane;
+            while (cand) {
+                const unsigned long long mine = (cand & me) ? (d & cand) : 0ULL;   // candidates this lane would suppress
+                const unsigned long long hit = wave_or_u64(mine);
+                const unsigned long long safe = cand & ~hit;
+                kept |= safe;
+                const unsigned long long drop = wave_or_u64((safe & me) ? d : 0ULL);
+                cand &= ~(safe | drop);
             }
             if ((kept >> lane) & 1ULL) keep[count + __popcll(kept & ((1ULL << lane) - 1ULL))] = rb * 64 + lane;
-            if (lane == 0) remv[col_blocks] = kept;
+            if (lane == 0) remv[cb] = kept;
         }
-        __syncthreads();
-        const unsigned long long kept = remv[col_blocks];
+        lds_barrier();
+        const unsigned long long kept = remv[cb];
         count += __popcll(kept);
-        // OR the kept rows of this block into the later column blocks
-        for (int j = rb + 1 + tid; j < col_blocks; j += blockDim.x) {
-            unsigned long long acc = remv[j];
-            unsigned long long kk = kept;
-            while (kk) {
-                const int i = __ffsll((long long)kk) - 1;
-                kk &= kk - 1ULL;
-                acc |= mask[(size_t)(rb * 64 + i) * col_blocks + j];
-            }
-            remv[j] = acc;
+        // OR the kept rows into the later column blocks: first 128 columns from the prefetched words
+        {
+            unsigned long long acc = 0ULL;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if ((kept >> (g + 4 * q)) & 1ULL) acc |= w[q];
+            const int col = rb + 1 + c;
+            if (acc != 0ULL && col < cb) atomicOr(&remv[col], acc);
         }
-        __syncthreads();
+        // columns beyond the prefetch window (n > ~8200 boxes): plain loads
+        for (int col = rb + 1 + 128 + c; col < cb; col += 128) {
+            unsigned long long acc = 0ULL;
+            for (int q = 0; q < 16; ++q) {
+                const int i = g + 4 * q;
+                if (((kept >> i) & 1ULL) && rb * 64 + i < n) acc |= mask[(size_t)(rb * 64 + i) * cb + col];
+            }
+            if (acc != 0ULL) atomicOr(&remv[col], acc);
+        }
+        prefetch(rb + 4, w, d);   // refill this ring slot; stays in flight across the barriers
+        lds_barrier();
+    };
+    prefetch(0, W[0], D[0]);
+    prefetch(1, W[1], D[1]);
+    prefetch(2, W[2], D[2]);
+    prefetch(3, W[3], D[3]);
+    __syncthreads();
+    for (int rb = 0; rb < cb; rb += 4) {
+        step(rb, W[0], D[0]);
+        if (rb + 1 < cb) step(rb + 1, W[1], D[1]);
+        if (rb + 2 < cb) step(rb + 2, W[2], D[2]);
+        if (rb + 3 < cb) step(rb + 3, W[3], D[3]);
     }
     if (tid == 0) *num_keep = count;
 }
@@ -337,8 +396,7 @@ extern "C" int jm_nms(int boxes_num, const float* boxes, float nms_overlap_thres
     const size_t lds = (size_t)(cb + 1) * sizeof(unsigned long long);
     JM_REQUIRE(lds <= 160 * 1024, "nms: %d boxes exceed the on-device reduce capacity", boxes_num);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)nms_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int threads = cb >= 1024 ? 1024 : (cb <= 64 ? 64 : ((cb + 63) / 64 * 64));
-    hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, boxes_num,
+    hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(NMS_RT), lds, (hipStream_t)stream, boxes_num,
                        (const unsigned long long*)ws, (long long*)keep, num_keep);
     return check_launch("nms_reduce");
 }

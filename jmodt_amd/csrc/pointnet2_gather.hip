@@ -106,15 +106,32 @@ three_nn_kernel(int n, int m, const float* __restrict__ unknown, const float* __
         b1 = c1 ? d : b1;              i1 = c1 ? k : i1;
     };
     int k = 0;
-    if ((reinterpret_cast<uintptr_t>(kn) & 15u) == 0) {
-        for (; k + 4 <= m; k += 4) {
-            const float4* q = reinterpret_cast<const float4*>(kn + (size_t)k * 3);  // wave-uniform
-            const float4 a = q[0], b = q[1], c = q[2];
-            visit(k + 0, a.x, a.y, a.z);
-            visit(k + 1, a.w, b.x, b.y);
-            visit(k + 2, b.z, b.w, c.x);
-            visit(k + 3, c.y, c.z, c.w);
+    if ((reinterpret_cast<uintptr_t>(kn) & 15u) == 0 && m >= 16) {
+        // groups of 8 known points = 6 aligned float4 through the scalar cache; two named buffers
+        // so one group's loads are in flight while the other is evaluated (see ball_query.hip)
+        auto load8 = [&](int kk, float4 (&q)[6]) {
+            const float4* src = reinterpret_cast<const float4*>(kn + (size_t)kk * 3);  // wave-uniform
+#pragma unroll
+            for (int i = 0; i < 6; ++i) q[i] = src[i];
+        };
+        auto eval8 = [&](int kk, const float4 (&q)[6]) {
+            visit(kk + 0, q[0].x, q[0].y, q[0].z); visit(kk + 1, q[0].w, q[1].x, q[1].y);
+            visit(kk + 2, q[1].z, q[1].w, q[2].x); visit(kk + 3, q[2].y, q[2].z, q[2].w);
+            visit(kk + 4, q[3].x, q[3].y, q[3].z); visit(kk + 5, q[3].w, q[4].x, q[4].y);
+            visit(kk + 6, q[4].z, q[4].w, q[5].x); visit(kk + 7, q[5].y, q[5].z, q[5].w);
+        };
+        float4 ga[6], gb[6];
+        load8(0, ga);
+        load8(8, gb);
+        for (; k + 32 <= m; k += 16) {
+            eval8(k, ga);
+            load8(k + 16, ga);
+            eval8(k + 8, gb);
+            load8(k + 24, gb);
         }
+        eval8(k, ga);
+        eval8(k + 8, gb);
+        k += 16;
     }
     for (; k < m; ++k) visit(k, kn[k * 3 + 0], kn[k * 3 + 1], kn[k * 3 + 2]);
     if (active) {

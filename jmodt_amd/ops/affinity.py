@@ -88,8 +88,8 @@ def pairwise_affinity(pred_features: torch.Tensor, det_features: torch.Tensor, l
     se, keep2 = _pack(se_model) if se_model is not None else (None, [])
     A = torch.empty((P, D), dtype=_f32, device=dev)
     raw = torch.empty((P, D), dtype=_f32, device=dev) if return_raw else None
-    start = torch.empty((D,), dtype=_f32, device=dev)
-    end = torch.empty((P,), dtype=_f32, device=dev)
+    se_out = torch.empty((D + P,), dtype=_f32, device=dev)   # contiguous: the kernel writes logits in place
+    start, end = se_out[:D], se_out[D:]
     link_p = ctypes.byref(link)
     se_p = ctypes.byref(se) if se is not None else None
     ws_bytes = lib.jm_affinity_workspace_bytes(P, D, link_p, se_p)
