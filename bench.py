@@ -250,6 +250,17 @@ def main():
     if rank == 0:
         kernels = timer.summary(args.steps)
         dom = kernels[0]
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes (collected separately, as
+        # the guide prescribes; bench.py itself runs un-profiled)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            for k in kernels:
+                if k["kernel"] in tj:
+                    k["traffic_bytes_per_launch"] = tj[k["kernel"]]["bytes"]
+            traffic = tj.get(dom["kernel"], {}).get("bytes")
+        except (OSError, ValueError):
+            pass
         frames = world * args.batch * args.steps
         result = {
             "metric": "frames/sec detect+affinity on 16384-pt KITTI frames; per-kernel HBM-BW fraction",
@@ -271,7 +282,7 @@ def main():
                         "(128 RoIs x 512 pts x 133), RPN nms_normal (6300 boxes), 128x128 affinity, per frame"),
                        "frames_per_gpu_per_step": args.batch, "points": 16384, "parallelism": f"replicas x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_gbs"],
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["hbm_frac"], "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["hbm_frac"], "traffic": traffic,
                          "basis": "algorithmic bytes per SURVEY.md §8(d) (FPS: streaming-equivalent B*m*20n — the "
                                   "kernel is latency/VALU-bound, its compulsory bytes are B*(12n+4m)); "
                                   "time = HIP events on the launch stream inside the timed region",

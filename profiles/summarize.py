@@ -1,12 +1,18 @@
-"""Turn a rocprofv3 (ROCm 7.2, rocpd SQLite) kernel trace into the per-kernel stats table that is
-committed under profiles/.   usage: python profiles/summarize.py <results.db> [out.txt]"""
+"""Turn rocprofv3 (ROCm 7.2, rocpd SQLite) output into the small text tables committed here.
+
+    python profiles/summarize.py <results.db> [out.txt]            per-kernel time stats
+    python profiles/summarize.py --pmc <results.db> [out.txt]      per-kernel PMC counter averages
+"""
 import sqlite3
 import sys
 
 
-def main(db_path, out_path=None):
-    db = sqlite3.connect(db_path)
-    cur = db.cursor()
+def short(name):
+    return name.split("(")[0][-64:]
+
+
+def stats(db_path, out_path=None):
+    cur = sqlite3.connect(db_path).cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
     rows = cur.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
@@ -14,8 +20,30 @@ def main(db_path, out_path=None):
     total = sum(r[2] for r in rows) or 1
     lines = [f"{'kernel':<64} {'calls':>6} {'total_us':>12} {'avg_us':>11} {'min_us':>10} {'max_us':>10} {'pct':>6}"]
     for n, c, s, a, mn, mx in rows:
-        short = n.split("(")[0][-64:]
-        lines.append(f"{short:<64} {c:>6} {s / 1e3:>12.1f} {a / 1e3:>11.2f} {mn / 1e3:>10.2f} {mx / 1e3:>10.2f} {100 * s / total:>6.2f}")
+        lines.append(f"{short(n):<64} {c:>6} {s / 1e3:>12.1f} {a / 1e3:>11.2f} {mn / 1e3:>10.2f} {mx / 1e3:>10.2f} {100 * s / total:>6.2f}")
+    text = "\n".join(lines) + "\n"
+    if out_path:
+        open(out_path, "w").write(text)
+    print(text)
+
+
+def pmc(db_path, out_path=None):
+    cur = sqlite3.connect(db_path).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+    if not cols:
+        print("no counters_collection view; tables:", [r[0] for r in cur.execute("select name from sqlite_master")][:80])
+        return
+    kcol = [c for c in cols if "kernel" in c and "name" in c] or [c for c in cols if c == "name"]
+    ccol = [c for c in cols if "counter" in c and "name" in c]
+    vcol = [c for c in cols if c in ("value", "counter_value")]
+    if not (kcol and ccol and vcol):
+        print("unexpected schema:", cols)
+        return
+    rows = cur.execute(f"select {kcol[0]}, {ccol[0]}, count(*), avg({vcol[0]}), min({vcol[0]}), max({vcol[0]}) "
+                       f"from counters_collection group by {kcol[0]}, {ccol[0]} order by {kcol[0]}").fetchall()
+    lines = [f"{'kernel':<64} {'counter':<14} {'dispatches':>10} {'avg':>16} {'min':>16} {'max':>16}"]
+    for k, c, n, a, mn, mx in rows:
+        lines.append(f"{short(k):<64} {c:<14} {n:>10} {a:>16.1f} {mn:>16.1f} {mx:>16.1f}")
     text = "\n".join(lines) + "\n"
     if out_path:
         open(out_path, "w").write(text)
@@ -23,4 +51,8 @@ def main(db_path, out_path=None):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
+    args = sys.argv[1:]
+    if args and args[0] == "--pmc":
+        pmc(args[1], args[2] if len(args) > 2 else None)
+    else:
+        stats(args[0], args[1] if len(args) > 1 else None)

@@ -1,0 +1,103 @@
+"""CPU tier: the multi-process paths with the gloo backend, world size 2 (N > 1 coverage without
+GPUs): frame sharding, bucketed gradient all-reduce, and the finetune DP step reproducing the
+single-process gradient step of the whole batch (what nn.DataParallel computes in the reference,
+tools/train.py:86-107)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from jmodt_amd import dist as jdist
+
+
+def test_shard_frames_keeps_pairs_together():
+    for frames, world in ((32, 8), (8, 8), (20, 8), (6, 4), (2, 2)):
+        spans = [jdist.shard_frames(frames, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == frames
+        for (b, e), (b2, _) in zip(spans, spans[1:] + [(frames, frames)]):
+            assert e == b2 and b % 2 == 0 and (e - b) % 2 == 0
+    with pytest.raises(ValueError):
+        jdist.shard_frames(7, 2, 0)
+    assert jdist.shard_frames(8, 3, 0, pair_aligned=False) == (0, 3)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make_batch(seed, frames=8, rois=12, C=32):
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.relu(torch.randn(frames, rois, C, generator=g))
+    tids = torch.randint(0, 5, (frames, rois), generator=g).float()   # 0 = background
+    return feats, tids
+
+
+def _make_heads(C=32):
+    from jmodt_amd.ops.affinity import make_affinity_mlp
+    torch.manual_seed(7)
+    return make_affinity_mlp(C, (C, C)), make_affinity_mlp(C, (C, C))
+
+
+def _worker(rank, world, port, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as tdist
+    from jmodt_amd.ops.affinity_train import finetune_step
+    r, lr, w = jdist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    # --- bucketed all-reduce: tiny buckets force several collectives, None grads are zero-filled
+    ps = [torch.nn.Parameter(torch.full((5,), float(rank + 1))), torch.nn.Parameter(torch.ones(3, 3)),
+          torch.nn.Parameter(torch.ones(7))]
+    ps[0].grad = torch.full((5,), float(rank + 1)); ps[1].grad = torch.full((3, 3), 10.0 * (rank + 1))
+    n = jdist.allreduce_gradients(ps, bucket_bytes=40, average=True)
+    assert n == 3
+    assert torch.allclose(ps[0].grad, torch.full((5,), 1.5)) and torch.allclose(ps[1].grad, torch.full((3, 3), 15.0))
+    assert torch.equal(ps[2].grad, torch.zeros(7))
+    # --- DP finetune step on this rank's frame-pair shard
+    feats, tids = _make_batch(123)
+    link, se = _make_heads()
+    opt = torch.optim.SGD(list(link.parameters()) + list(se.parameters()), lr=0.1)
+    b, e = jdist.shard_frames(feats.shape[0], world, rank)
+    loss = finetune_step(feats[b:e], tids[b:e], link, se, opt, world=world)
+    torch.save({"loss": loss, "link": link.state_dict(), "se": se.state_dict()}, os.path.join(tmpdir, f"r{rank}.pt"))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_dp_finetune_step_matches_single_process(tmp_path):
+    from jmodt_amd.ops.affinity_train import finetune_step, reid_loss, training_affinity
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    feats, tids = _make_batch(123)
+    link, se = _make_heads()
+    with torch.no_grad():
+        ref_loss = float(reid_loss(training_affinity(feats, tids, link, se)))
+    opt = torch.optim.SGD(list(link.parameters()) + list(se.parameters()), lr=0.1)
+    loss1 = finetune_step(feats, tids, link, se, opt, world=1)
+    assert abs(loss1 - ref_loss) < 1e-6
+    r0, r1 = (torch.load(tmp_path / f"r{r}.pt") for r in range(world))
+    assert abs(r0["loss"] - loss1) < 1e-5 and abs(r1["loss"] - loss1) < 1e-5
+    for name, ref in (("link", link.state_dict()), ("se", se.state_dict())):
+        for k, v in ref.items():
+            assert torch.allclose(r0[name][k], v, atol=1e-6), (name, k)     # DP == single process
+            assert torch.equal(r0[name][k], r1[name][k]), (name, k)         # replicas stay identical
+
+
+def test_training_affinity_matches_reference_shapes_and_labels():
+    from jmodt_amd.ops.affinity_train import get_unique_tid_feature, training_affinity
+    feats = torch.arange(24, dtype=torch.float32).view(2, 3, 4)
+    tids = torch.tensor([[3., 0., 3.], [5., 3., 0.]])
+    u, f = get_unique_tid_feature(tids[0][tids[0] > 0], feats[0][tids[0] > 0])
+    assert u.tolist() == [3.0] and torch.equal(f[0], (feats[0, 0] + feats[0, 2]) / 2)
+    link, se = _make_heads(4)
+    out = training_affinity(feats, tids, link, se)
+    assert out["rcnn_link"].shape == (2, 1) and out["gt_links"].tolist() == [1.0, 0.0]   # prev {3} x next {3, 5}
+    assert out["gt_starts"].tolist() == [0.0, 1.0] and out["gt_ends"].tolist() == [0.0]
+    assert out["rcnn_start"].shape == (2, 1) and out["rcnn_end"].shape == (1, 1)
+    # 1 x 2 score matrix: the row softmax sums to 1, each single-entry column softmax is 1 -> (1 + 2) / 2
+    assert abs(float(out["rcnn_link"].detach().sum()) - 1.5) < 1e-5
