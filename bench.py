@@ -43,38 +43,37 @@ SA_LEVELS = [
 
 
 class KernelTimer:
-    """HIP events on torch's current stream (the stream every jm_* launch goes to)."""
+    """HIP events on torch's current stream (the stream every jm_* launch goes to).  A name may be
+    launched several times per step (e.g. both MSG scales); bytes / flops / time are all SUMMED
+    over those launches, so achieved = sum(algorithmic bytes) / sum(time)."""
 
     def __init__(self):
-        self.records = {}   # name -> list of (start, end) events
-        self.bytes = {}
-        self.flops = {}     # name -> flops per call (MFMA-bound kernels)
+        self.records = {}   # name -> list of (start, end, algo_bytes, flops)
         self.enabled = False
 
     def run(self, name, algo_bytes, fn, flops=0):
-        if flops:
-            self.flops[name] = flops
         if not self.enabled:
             return fn()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         out = fn()
         e.record()
-        self.records.setdefault(name, []).append((s, e))
-        self.bytes[name] = algo_bytes
+        self.records.setdefault(name, []).append((s, e, algo_bytes, flops))
         return out
 
     def summary(self, steps):
         rows = []
         for name, evs in self.records.items():
-            ms = sum(s.elapsed_time(e) for s, e in evs) / steps   # per step (a name may cover several launches)
+            ms = sum(s.elapsed_time(e) for s, e, _, _ in evs) / steps
+            nbytes = sum(b for _, _, b, _ in evs) / steps
+            flops = sum(f for _, _, _, f in evs) / steps
             launches = len(evs) / steps
-            gbs = self.bytes[name] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             row = dict(kernel=name, ms_per_step=round(ms, 5), launches_per_step=launches,
-                       algo_bytes_per_step=int(self.bytes[name]), achieved_gbs=round(gbs, 2),
+                       algo_bytes_per_step=int(nbytes), achieved_gbs=round(gbs, 2),
                        hbm_frac=round(gbs / HBM_PEAK_GBS, 5))
-            if name in self.flops:   # time covers the whole op (both MLP layers + softmax + se path)
-                tf = self.flops[name] * launches / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            if flops:   # time covers the whole op (both MLP layers + softmax + se path)
+                tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
                 row.update(achieved_tflops=round(tf, 2), mfma_frac=round(tf / MFMA_F32_PEAK_TF, 4))
             rows.append(row)
         rows.sort(key=lambda r: -r["ms_per_step"])

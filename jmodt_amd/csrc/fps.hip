@@ -143,6 +143,112 @@ fps_regs_kernel(int n, int m, int bs, int bs_log2, int R, int J, int recipJ, con
     }
 }
 
+// Multi-wave variant with the candidate extraction done by ONE wave per iteration.
+//
+// In fps_regs_kernel every wave tracks (best, slot) per point and extracts its own candidate
+// {k, x, y, z} before the barrier, and every wave repeats the cross-wave reduce after it: with 16
+// waves that is ~110 overhead instructions x 4 waves per SIMD on top of the distance loop.  Here
+//   phase 1 (all waves)   distance update with a value-only running max (8 VALU per point:
+//                         3 sub, mul, 2 fma, min, max), wave max by DPP, publish ONE dword;
+//   barrier A
+//   phase 2 (all waves)   reduce the <=16 wave maxima -> winning wave (lowest index among ties);
+//   phase 3 (winner only) find the lane (first = highest priority) and the register slot (first
+//                         slot equal to the max), fetch its coordinates by wave-uniform register
+//                         indexing, publish {k, x, y, z};
+//   barrier B
+//   all waves read the 16-byte winner record.
+// Two barriers instead of one, but ~2.5x fewer issued instructions per iteration.
+template <int PTS, int MAXBT>
+__global__ void __launch_bounds__(MAXBT)
+fps_regs2_kernel(int n, int m, int bs, int bs_log2, int R, int J, int recipJ, const float* __restrict__ dataset,
+                 float* __restrict__ temp, int* __restrict__ idxs) {
+    __shared__ int vals[2][16];
+    __shared__ FpsCand win[2];
+    __shared__ int out_buf[FPS_OUT_CHUNK];
+    const int T = threadIdx.x;
+    const int nwaves = (blockDim.x + 63) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(T >> 6);
+    const int lane = T & 63;
+    const float* ds = dataset + (size_t)blockIdx.x * n * 3;
+    float* tp = temp + (size_t)blockIdx.x * n;
+    int* out = idxs + (size_t)blockIdx.x * m;
+
+    float px[PTS], py[PTS], pz[PTS], tm[PTS];
+#pragma unroll
+    for (int i = 0; i < PTS; ++i) {
+        const int r = (i * recipJ) >> 16, j = i - r * J;
+        const int P = T * R + r;
+        const int k = (int)bitrev_u((unsigned)P, bs_log2) + bs * j;
+        const bool ok = r < R && P < bs && k < n;
+        px[i] = ok ? ds[k * 3 + 0] : INFINITY;
+        py[i] = ok ? ds[k * 3 + 1] : INFINITY;
+        pz[i] = ok ? ds[k * 3 + 2] : INFINITY;
+        tm[i] = ok ? tp[k] : -1.f;
+    }
+    float x1 = ds[0], y1 = ds[1], z1 = ds[2];
+    if (T == 0) out_buf[0] = 0;
+    __syncthreads();
+
+    for (int it = 1; it < m; ++it) {
+        if ((it & (FPS_OUT_CHUNK - 1)) == 0) {
+            __syncthreads();
+            for (int e = T; e < FPS_OUT_CHUNK; e += blockDim.x) out[it - FPS_OUT_CHUNK + e] = out_buf[e];
+            __syncthreads();
+        }
+        float best = -1.f;
+#pragma unroll
+        for (int i = 0; i < PTS; ++i) {
+            const float d = sqdist3(px[i] - x1, py[i] - y1, pz[i] - z1);
+            const float d2 = fast_min(d, tm[i]);
+            tm[i] = d2;
+            best = fast_max(best, d2);
+        }
+        const int bits = __float_as_int(best);
+        const int wmax = wave_max_i32(bits);
+        if (lane == 0) vals[it & 1][wave] = wmax;
+        lds_barrier();                                                        // A
+        const int v = lane < nwaves ? vals[it & 1][lane] : (int)0x80000000;
+        const int gmax = wave_max_i32(v);
+        const unsigned long long weq = __ballot(v == gmax);
+        const int ww = (int)__ffsll((long long)weq) - 1;
+        if (wave == ww) {   // wave-uniform: exactly one wave extracts the winner
+            const unsigned long long eq = __ballot(bits == gmax);
+            const int wl = (int)__ffsll((long long)eq) - 1;
+            int bi = 0;
+#pragma unroll
+            for (int i = PTS - 1; i >= 0; --i) bi = (__float_as_int(tm[i]) == gmax) ? i : bi;
+            const int bi_u = __builtin_amdgcn_readlane(bi, wl);
+            const int sx = __builtin_amdgcn_readlane(__float_as_int(px[bi_u]), wl);
+            const int sy = __builtin_amdgcn_readlane(__float_as_int(py[bi_u]), wl);
+            const int sz = __builtin_amdgcn_readlane(__float_as_int(pz[bi_u]), wl);
+            const int r_w = (bi_u * recipJ) >> 16, j_w = bi_u - r_w * J;
+            const int k_w = (int)bitrev_u((unsigned)(((wave << 6) | wl) * R + r_w), bs_log2) + bs * j_w;
+            if (lane == 0) {
+                FpsCand c;
+                c.val = gmax; c.k = k_w;
+                c.x = __int_as_float(sx); c.y = __int_as_float(sy); c.z = __int_as_float(sz);
+                win[it & 1] = c;
+                out_buf[it & (FPS_OUT_CHUNK - 1)] = k_w;
+            }
+        }
+        lds_barrier();                                                        // B
+        const FpsCand c = win[it & 1];
+        x1 = c.x; y1 = c.y; z1 = c.z;
+    }
+    __syncthreads();
+    {
+        const int done = ((m - 1) / FPS_OUT_CHUNK) * FPS_OUT_CHUNK;
+        for (int e = T; e < m - done; e += blockDim.x) out[done + e] = out_buf[e];
+    }
+#pragma unroll
+    for (int i = 0; i < PTS; ++i) {
+        const int r = (i * recipJ) >> 16, j = i - r * J;
+        const int P = T * R + r;
+        const int k = (int)bitrev_u((unsigned)P, bs_log2) + bs * j;
+        if (r < R && P < bs && k < n) tp[k] = tm[i];
+    }
+}
+
 // Fallback for clouds that do not fit the register file (n > 16*1024): temp in LDS is not
 // possible either (n*4 B), so temp and xyz stream through global/L2 like the reference, but
 // keeping the same wave-level arg-max machinery and tie order.
@@ -222,10 +328,13 @@ extern "C" int jm_furthest_point_sampling(int b, int n, int m, const float* xyz,
     }
     // threads per workgroup: points-per-thread target from a measured table,
     // overridable for experiments with JM_FPS_PTS
-    // measured on MI355X (tools/fps_sweep.py): 16 points per lane is at or within 3 % of the best
-    // geometry for every n <= 16384 (n = 16384: 16 waves; 4096: 4 waves; <= 1024: ONE wave, no
-    // barrier, no LDS); 32 per lane is 5 % slower at n = 16384 and 40 % slower at 4096.
-    int want_pts = 16;
+    // measured on MI355X (tools/fps_sweep.py, us per iteration):
+    //   n = 16384: 16 waves x 16 pts 1.25 | 8 x 32: 1.32        n = 4096: 16 waves x 4 pts 0.68 | 4 x 16: 0.81
+    //   n = 1024 : 16 waves x 1 pt 0.52 | 1 wave x 16: 0.56     n = 256 : 4 waves x 1 pt 0.51 | 1 wave x 4: 0.41
+    //   1024 clouds of n = 512: 8 waves x 1 pt 0.77 | 1 wave x 8 pts 0.54
+    // -> a full 1024-thread workgroup (one reference thread per thread) when the reference block
+    //    is 1024 wide, otherwise ONE wave per cloud (no barrier, no LDS).
+    int want_pts = bs >= 1024 ? J : 16;
     if (const char* e = getenv("JM_FPS_PTS")) want_pts = atoi(e);
     if (want_pts < J) want_pts = J;
     if (want_pts > 32) want_pts = 32;
@@ -235,9 +344,16 @@ extern "C" int jm_furthest_point_sampling(int b, int n, int m, const float* xyz,
     if (block < 64) block = 64;
     const int pts = R * J;
     const int recipJ = 65536 / J + 1;
-#define JM_FPS_LAUNCH(P, MB)                                                                                  \
-    hipLaunchKernelGGL((fps_regs_kernel<P, MB>), dim3(b), dim3(block), 0, s, n, m, bs, bs_log2, R, J, recipJ, \
-                       xyz, temp, idx)
+    // multi-wave workgroups use the two-barrier kernel (one wave extracts the winner)
+    static const int force_v1 = getenv("JM_FPS_V1") ? atoi(getenv("JM_FPS_V1")) : 0;
+    const bool v2 = block > 64 && !force_v1;
+#define JM_FPS_LAUNCH(P, MB)                                                                                    \
+    do {                                                                                                        \
+        if (v2) hipLaunchKernelGGL((fps_regs2_kernel<P, MB>), dim3(b), dim3(block), 0, s, n, m, bs, bs_log2, R, \
+                                   J, recipJ, xyz, temp, idx);                                                  \
+        else hipLaunchKernelGGL((fps_regs_kernel<P, MB>), dim3(b), dim3(block), 0, s, n, m, bs, bs_log2, R, J,  \
+                                recipJ, xyz, temp, idx);                                                        \
+    } while (0)
     if (pts <= 1) JM_FPS_LAUNCH(1, 1024);
     else if (pts <= 2) JM_FPS_LAUNCH(2, 1024);
     else if (pts <= 4) JM_FPS_LAUNCH(4, 1024);

@@ -237,10 +237,6 @@ nms_mask_kernel(int n, float thresh, const float* __restrict__ boxes, unsigned l
 //  * selected words are OR-ed in registers and merged with LDS atomics (ds_or_b64).
 constexpr int NMS_RT = 512;   // 4 row groups x 128 columns; 256-VGPR budget holds the 4-deep prefetch ring
 
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 __global__ void __launch_bounds__(NMS_RT)
 nms_reduce_kernel(int n, const unsigned long long* __restrict__ mask, long long* __restrict__ keep,
                   int* __restrict__ num_keep) {

@@ -97,6 +97,18 @@ __device__ __forceinline__ float fast_min(float a, float b) {
     return r;
 }
 
+__device__ __forceinline__ float fast_max(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// workgroup barrier for LDS-only hand-offs: waits for this wave's LDS traffic, not for global
+// memory (a __syncthreads() also drains vmcnt)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ float wave_sum_f32(float v) {
     v += __shfl_xor(v, 1);
     v += __shfl_xor(v, 2);

@@ -82,48 +82,67 @@ group_points_grad_kernel(int c, int n, int q_total, const float* __restrict__ gr
 }
 
 // ------------------------------------------------------------------ three_nn
-// Lane = unknown point; the known point is wave-uniform and arrives through scalar loads
-// (same structure as ball_query).  best* are kept in float with +inf start, which is
-// decision-for-decision identical to the reference's double bests initialised to 1e40
-// (every finite float d satisfies d < 1e40 and d < inf alike; inf < either is false).
-__global__ void __launch_bounds__(256)
-three_nn_kernel(int n, int m, const float* __restrict__ unknown, const float* __restrict__ known,
-                float* __restrict__ dist2, int* __restrict__ idx) {
-    const int bi = blockIdx.y;
-    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = pi < n;
-    const float* u = unknown + ((size_t)bi * n + (active ? pi : 0)) * 3;
-    const float ux = u[0], uy = u[1], uz = u[2];
-    const float* kn = known + (size_t)bi * m * 3;
-    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
-    int i1 = 0, i2 = 0, i3 = 0;
-    auto visit = [&](int k, float x, float y, float z) {
-        const float d = sqdist3(ux - x, uy - y, uz - z);
+// Lane = unknown point; the known point is wave-uniform and arrives through scalar loads in
+// groups of 8 with two named buffers (same structure as ball_query.hip).  The scan of the known
+// set is split over the 4 waves of a workgroup (wave w scans the w-th contiguous slice); the four
+// partial top-3 lists are merged in slice order with the same strict `<` insertion, which yields
+// exactly the 3 smallest by (distance, index) — what the sequential scan of
+// interpolate_gpu.cu:30-51 produces.  Within a group of 8 the insertion logic only runs when some
+// lane of the wave has a candidate closer than its current third best.
+// best* are kept in float with +inf start, which is decision-for-decision identical to the
+// reference's double bests initialised to 1e40 (every finite float d satisfies d < 1e40 and
+// d < inf alike; inf < either is false).
+struct Top3 {
+    float b1, b2, b3;
+    int i1, i2, i3;
+    __device__ __forceinline__ void visit(int k, float d) {
         const bool c1 = d < b1, c2 = d < b2, c3 = d < b3;
         // if/else-if chain of interpolate_gpu.cu:37-49, branch-free (c1 => c2 => c3)
         b3 = c2 ? b2 : (c3 ? d : b3);  i3 = c2 ? i2 : (c3 ? k : i3);
         b2 = c1 ? b1 : (c2 ? d : b2);  i2 = c1 ? i1 : (c2 ? k : i2);
         b1 = c1 ? d : b1;              i1 = c1 ? k : i1;
-    };
-    int k = 0;
-    if ((reinterpret_cast<uintptr_t>(kn) & 15u) == 0 && m >= 16) {
-        // groups of 8 known points = 6 aligned float4 through the scalar cache; two named buffers
-        // so one group's loads are in flight while the other is evaluated (see ball_query.hip)
+    }
+};
+
+__global__ void __launch_bounds__(256)
+three_nn_kernel(int n, int m, int chunk, const float* __restrict__ unknown, const float* __restrict__ known,
+                float* __restrict__ dist2, int* __restrict__ idx) {
+    __shared__ float sd[4][3][64];
+    __shared__ int si[4][3][64];
+    const int bi = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pi = blockIdx.x * 64 + lane;
+    const bool active = pi < n;
+    const float* u = unknown + ((size_t)bi * n + (active ? pi : 0)) * 3;
+    const float ux = u[0], uy = u[1], uz = u[2];
+    const float* kn = known + (size_t)bi * m * 3;
+    Top3 t{INFINITY, INFINITY, INFINITY, 0, 0, 0};
+    const int k_begin = wave * chunk, k_end = min(m, k_begin + chunk);
+    int k = k_begin;
+    if ((reinterpret_cast<uintptr_t>(kn) & 15u) == 0 && k + 16 <= k_end) {
         auto load8 = [&](int kk, float4 (&q)[6]) {
             const float4* src = reinterpret_cast<const float4*>(kn + (size_t)kk * 3);  // wave-uniform
 #pragma unroll
             for (int i = 0; i < 6; ++i) q[i] = src[i];
         };
         auto eval8 = [&](int kk, const float4 (&q)[6]) {
-            visit(kk + 0, q[0].x, q[0].y, q[0].z); visit(kk + 1, q[0].w, q[1].x, q[1].y);
-            visit(kk + 2, q[1].z, q[1].w, q[2].x); visit(kk + 3, q[2].y, q[2].z, q[2].w);
-            visit(kk + 4, q[3].x, q[3].y, q[3].z); visit(kk + 5, q[3].w, q[4].x, q[4].y);
-            visit(kk + 6, q[4].z, q[4].w, q[5].x); visit(kk + 7, q[5].y, q[5].z, q[5].w);
+            const float f[24] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w,
+                                 q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w,
+                                 q[4].x, q[4].y, q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w};
+            float d[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d[i] = sqdist3(ux - f[3 * i], uy - f[3 * i + 1], uz - f[3 * i + 2]);
+            const float dmin = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
+            if (__any(dmin < t.b3)) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t.visit(kk + i, d[i]);
+            }
         };
         float4 ga[6], gb[6];
-        load8(0, ga);
-        load8(8, gb);
-        for (; k + 32 <= m; k += 16) {
+        load8(k, ga);
+        load8(k + 8, gb);
+        for (; k + 32 <= k_end; k += 16) {
             eval8(k, ga);
             load8(k + 16, ga);
             eval8(k + 8, gb);
@@ -133,12 +152,20 @@ three_nn_kernel(int n, int m, const float* __restrict__ unknown, const float* __
         eval8(k + 8, gb);
         k += 16;
     }
-    for (; k < m; ++k) visit(k, kn[k * 3 + 0], kn[k * 3 + 1], kn[k * 3 + 2]);
-    if (active) {
+    for (; k < k_end; ++k) t.visit(k, sqdist3(ux - kn[k * 3 + 0], uy - kn[k * 3 + 1], uz - kn[k * 3 + 2]));
+    sd[wave][0][lane] = t.b1; sd[wave][1][lane] = t.b2; sd[wave][2][lane] = t.b3;
+    si[wave][0][lane] = t.i1; si[wave][1][lane] = t.i2; si[wave][2][lane] = t.i3;
+    __syncthreads();
+    if (wave == 0 && active) {
+        Top3 r{INFINITY, INFINITY, INFINITY, 0, 0, 0};
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) r.visit(si[w][q][lane], sd[w][q][lane]);
         float* d = dist2 + ((size_t)bi * n + pi) * 3;
         int* o = idx + ((size_t)bi * n + pi) * 3;
-        d[0] = b1; d[1] = b2; d[2] = b3;
-        o[0] = i1; o[1] = i2; o[2] = i3;
+        d[0] = r.b1; d[1] = r.b2; d[2] = r.b3;
+        o[0] = r.i1; o[1] = r.i2; o[2] = r.i3;
     }
 }
 
@@ -162,6 +189,41 @@ three_interpolate_kernel(int c, int m, int n, const float* __restrict__ points, 
         const float* src = points + ((size_t)bi * c + ci) * m;
         // w0*p0 + w1*p1 + w2*p2 with the oracle's contraction
         out[((size_t)bi * c + ci) * n + pi] = __builtin_fmaf(w2, src[i2], __builtin_fmaf(w0, src[i0], w1 * src[i1]));
+    }
+}
+
+// LDS-staged variant for the forward pass.  The plain kernel is bound by the texture addresser:
+// every wave-level gather touches ~64 different cache lines of the (b,c) feature row, 3 per output.
+// Here a workgroup stages CB whole feature rows (CB * m floats) in LDS once, then every thread
+// walks points: idx / weights are read ONCE per point for all CB channels and the 3 taps per
+// channel are LDS reads.  One workgroup per (batch, channel block): with C = 256, m = 4096 that is
+// 8 rows = 128 KiB of LDS and exactly 256 workgroups.
+__global__ void __launch_bounds__(512)
+three_interpolate_lds_kernel(int c, int m, int n, int cb, const float* __restrict__ points,
+                             const int* __restrict__ idx, const float* __restrict__ weight, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];   // [cb][m]
+    const int bi = blockIdx.y;
+    const int c0 = blockIdx.x * cb;
+    const int nc = min(cb, c - c0);
+    const float* src = points + ((size_t)bi * c + c0) * m;          // nc consecutive rows are contiguous
+    const int tot = nc * m;
+    if (((reinterpret_cast<uintptr_t>(src) & 15u) == 0) && (tot % 4 == 0)) {
+        for (int e = threadIdx.x; e < tot / 4; e += blockDim.x)
+            reinterpret_cast<float4*>(rows)[e] = reinterpret_cast<const float4*>(src)[e];
+    } else {
+        for (int e = threadIdx.x; e < tot; e += blockDim.x) rows[e] = src[e];
+    }
+    __syncthreads();
+    const int* ixb = idx + (size_t)bi * n * 3;
+    const float* wb = weight + (size_t)bi * n * 3;
+    float* ob = out + ((size_t)bi * c + c0) * n;
+    for (int pi = threadIdx.x; pi < n; pi += blockDim.x) {
+        const int i0 = ixb[pi * 3 + 0], i1 = ixb[pi * 3 + 1], i2 = ixb[pi * 3 + 2];
+        const float w0 = wb[pi * 3 + 0], w1 = wb[pi * 3 + 1], w2 = wb[pi * 3 + 2];
+        for (int cc = 0; cc < nc; ++cc) {
+            const float* r = rows + cc * m;
+            ob[(size_t)cc * n + pi] = __builtin_fmaf(w2, r[i2], __builtin_fmaf(w0, r[i0], w1 * r[i1]));
+        }
     }
 }
 
@@ -250,8 +312,9 @@ extern "C" int jm_three_nn(int b, int n, int m, const float* unknown, const floa
     if (b == 0 || n == 0) return JM_OK;
     JM_REQUIRE(unknown && dist2 && idx && (known || m == 0), "three_nn: null pointer");
     JM_REQUIRE(b <= 65535, "three_nn: batch %d > 65535", b);
-    hipLaunchKernelGGL(three_nn_kernel, dim3(divup(n, 256), b), dim3(256), 0, (hipStream_t)stream, n, m, unknown,
-                       known, dist2, idx);
+    const int chunk = (divup(m, 4) + 7) / 8 * 8;   // slice per wave, multiple of 8 (16-byte aligned groups)
+    hipLaunchKernelGGL(three_nn_kernel, dim3(divup(n, 64), b), dim3(256), 0, (hipStream_t)stream, n, m, chunk,
+                       unknown, known, dist2, idx);
     return check_launch("three_nn");
 }
 
@@ -261,6 +324,22 @@ extern "C" int jm_three_interpolate(int b, int c, int m, int n, const float* poi
     if (b == 0 || c == 0 || n == 0) return JM_OK;
     JM_REQUIRE(points && idx && weight && out, "three_interpolate: null pointer");
     JM_REQUIRE(b <= 65535 && divup(c, TI_CPT) <= 65535, "three_interpolate: shape too large");
+    // LDS-staged path when a useful block of feature rows fits in LDS and there are enough
+    // points per row to amortise the staging
+    const size_t row_bytes = (size_t)m * sizeof(float);
+    int cb = (int)((128u * 1024u) / (row_bytes ? row_bytes : 1));
+    if (cb > 8) cb = 8;
+    if (cb > c) cb = c;
+    if (cb >= 1 && n >= 4 * m && m >= 64) {
+        while (cb > 1 && (long long)b * divup(c, cb) < 256) cb /= 2;   // keep >= 256 workgroups when possible
+        const size_t lds = (size_t)cb * row_bytes;
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)three_interpolate_lds_kernel,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(three_interpolate_lds_kernel, dim3(divup(c, cb), b), dim3(512), lds, (hipStream_t)stream,
+                           c, m, n, cb, points, idx, weight, out);
+        return check_launch("three_interpolate(lds)");
+    }
     hipLaunchKernelGGL(three_interpolate_kernel, dim3(divup(n, 256), divup(c, TI_CPT), b), dim3(256), 0,
                        (hipStream_t)stream, c, m, n, points, idx, weight, out);
     return check_launch("three_interpolate");

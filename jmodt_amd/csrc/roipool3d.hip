@@ -24,9 +24,15 @@
 
 namespace jm {
 
+// The reference writes the box test with double literals (`h / 2.0`, `-l / 2.0`), i.e. float values
+// promoted to double and compared against a double threshold.  Halving a float is exact, so each
+// threshold IS a float and `(double)f > (double)t` == `f > t`: the per-point test below is pure
+// float arithmetic with bit-identical decisions (the oracle keeps the literal double form and the
+// GPU tests compare against it).  Only cy = (float)(bottom_y - h / 2.0) is evaluated in double,
+// once per box, exactly as written.
 struct BoxTest {
     float cx, cz, cy, cosa, sina;
-    double half_h, half_l, half_w;
+    float half_h, half_l, half_w;
 };
 
 __host__ __device__ __forceinline__ BoxTest make_box_test(const float* bx) {
@@ -34,25 +40,32 @@ __host__ __device__ __forceinline__ BoxTest make_box_test(const float* bx) {
     const float bottom_y = bx[1], h = bx[3], w = bx[4], l = bx[5];
     t.cx = bx[0]; t.cz = bx[2];
     t.cy = (float)(bottom_y - h / 2.0);
-    t.half_h = h / 2.0; t.half_l = l / 2.0; t.half_w = w / 2.0;
+    t.half_h = h * 0.5f; t.half_l = l * 0.5f; t.half_w = w * 0.5f;   // exact
     jm_sincosf(bx[6], &t.sina, &t.cosa);
     return t;
 }
 
 __host__ __device__ __forceinline__ int pt_in_box(const BoxTest& t, float x, float y, float z) {
-    if ((fabsf(x - t.cx) > 10.0f) || ((double)fabsf(y - t.cy) > t.half_h) || (fabsf(z - t.cz) > 10.0f)) return 0;
+    if ((fabsf(x - t.cx) > 10.0f) || (fabsf(y - t.cy) > t.half_h) || (fabsf(z - t.cz) > 10.0f)) return 0;
     const float x_rot = (x - t.cx) * t.cosa + (z - t.cz) * (-t.sina);
     const float z_rot = (x - t.cx) * t.sina + (z - t.cz) * t.cosa;
-    return ((double)x_rot >= -t.half_l) & ((double)x_rot <= t.half_l) & ((double)z_rot >= -t.half_w) &
-           ((double)z_rot <= t.half_w);
+    return (x_rot >= -t.half_l) & (x_rot <= t.half_l) & (z_rot >= -t.half_w) & (z_rot <= t.half_w);
 }
 
+// 16-byte load from a 4-byte aligned address (one global_load_dwordx4; gfx950 handles the
+// misalignment in hardware)
+struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };
+
+constexpr int RP_T = 512;          // threads per box: 8 waves -> 32 waves per CU with 4 boxes resident
+constexpr int RP_W = RP_T / 64;
+constexpr int RP_TILE = RP_T * 4;  // points per compaction tile
+
 template <bool VEC4>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(RP_T)
 roipool3d_kernel(int N, int M, int C, int S, const float* __restrict__ xyz, const float* __restrict__ boxes3d,
                  const float* __restrict__ pts_feature, float* __restrict__ pooled, int* __restrict__ empty_flag,
                  int zero_empty) {
-    extern __shared__ __attribute__((aligned(16))) int lds[];  // [S] indices, then [2][4] wave totals
+    extern __shared__ __attribute__((aligned(16))) int lds[];  // [S] indices, then [2][RP_W] wave totals
     int* sel = lds;
     int* wtot = lds + ((S + 3) & ~3);
     const int mi = blockIdx.x, bi = blockIdx.y;
@@ -60,22 +73,62 @@ roipool3d_kernel(int N, int M, int C, int S, const float* __restrict__ xyz, cons
     const float* pts = xyz + (size_t)bi * N * 3;
     const BoxTest bt = make_box_test(boxes3d + ((size_t)bi * M + mi) * 7);
 
-    // ---- phase A: ordered compaction of in-box point indices
+    // ---- phase A: ordered compaction of in-box point indices.  Tile = 1024 points, thread t owns
+    // the 4 consecutive points base + 4t .. + 3 (three 16-byte loads), so the order inside a tile
+    // is thread-major: position = cnt + hits of earlier waves + hits of earlier lanes + own
+    // earlier hits.  One barrier per 1024 points (parity-buffered wave totals).
     int cnt = 0;  // identical in every thread
     int parity = 0;
-    for (int base = 0; base < N && cnt < S; base += 256, parity ^= 1) {
-        const int k = base + tid;
-        int in = 0;
-        if (k < N) in = pt_in_box(bt, pts[k * 3 + 0], pts[k * 3 + 1], pts[k * 3 + 2]);
-        const unsigned long long bal = __ballot(in);
-        if (lane == 0) wtot[parity * 4 + wave] = __popcll(bal);
-        __syncthreads();
-        const int t0 = wtot[parity * 4 + 0], t1 = wtot[parity * 4 + 1], t2 = wtot[parity * 4 + 2],
-                  t3 = wtot[parity * 4 + 3];
-        const int before = (wave > 0 ? t0 : 0) + (wave > 1 ? t1 : 0) + (wave > 2 ? t2 : 0);
-        const int pos = cnt + before + mbcnt(bal);
-        if (in && pos < S) sel[pos] = k;
-        cnt += t0 + t1 + t2 + t3;
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(pts) & 15u) == 0);
+    auto load_tile = [&](int base, float (&p)[12]) {   // unconditional, clamped: stays in flight across the barrier
+        const int k0 = base + tid * 4;
+        if (vec_ok && k0 + 4 <= N) {
+            const float4* q = reinterpret_cast<const float4*>(pts + (size_t)k0 * 3);
+            const float4 a = q[0], b = q[1], c = q[2];
+            p[0] = a.x; p[1] = a.y; p[2] = a.z; p[3] = a.w; p[4] = b.x; p[5] = b.y;
+            p[6] = b.z; p[7] = b.w; p[8] = c.x; p[9] = c.y; p[10] = c.z; p[11] = c.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int kk = min(max(k0 + q, 0), N - 1);
+                p[3 * q] = pts[kk * 3]; p[3 * q + 1] = pts[kk * 3 + 1]; p[3 * q + 2] = pts[kk * 3 + 2];
+            }
+        }
+    };
+    float pa[12], pb[12];
+    load_tile(0, pa);
+    for (int base = 0; base < N && cnt < S; base += RP_TILE, parity ^= 1) {
+        load_tile(min(base + RP_TILE, max(N - 4, 0) & ~3), pb);   // prefetch the next tile (clamped, 4-aligned, when past the end)
+        const int k0 = base + tid * 4;
+        int in[4];
+        int own = 0, before_lane = 0, wave_total = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            in[q] = (k0 + q < N) ? pt_in_box(bt, pa[3 * q], pa[3 * q + 1], pa[3 * q + 2]) : 0;
+            const unsigned long long bal = __ballot(in[q]);
+            before_lane += mbcnt(bal);
+            wave_total += (int)__popcll(bal);
+        }
+        if (lane == 0) wtot[parity * RP_W + wave] = wave_total;
+        lds_barrier();
+        int before_wave = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < RP_W; ++w) {
+            const int tw = wtot[parity * RP_W + w];
+            before_wave += (w < wave) ? tw : 0;
+            all += tw;
+        }
+        const int pos = cnt + before_wave + before_lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (in[q]) {
+                if (pos + own < S) sel[pos + own] = k0 + q;
+                ++own;
+            }
+        }
+        cnt += all;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) pa[q] = pb[q];
     }
     __syncthreads();
     if (cnt > S) cnt = S;
@@ -88,47 +141,69 @@ roipool3d_kernel(int N, int M, int C, int S, const float* __restrict__ xyz, cons
         if (zero_empty) {
             if (VEC4) {
                 float4* d4 = reinterpret_cast<float4*>(dst);
-                for (int e = tid; e < total / 4; e += 256) d4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int e = tid; e < total / 4; e += RP_T) d4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
-                for (int e = tid; e < total; e += 256) dst[e] = 0.f;
+                for (int e = tid; e < total; e += RP_T) dst[e] = 0.f;
             }
         }
         return;
     }
     if (zero_empty && tid == 0) empty_flag[(size_t)bi * M + mi] = 0;
+    // expand the cyclic padding once (sel[s] = sel[s % cnt]) so the copy loop never divides
+    for (int s2 = cnt + tid; s2 < S; s2 += RP_T) sel[s2] = sel[s2 % cnt];
+    __syncthreads();
 
-    // ---- phase B: flat coalesced copy; row s comes from point sel[s % cnt]
+    // ---- phase B: flat coalesced copy; row s comes from point sel[s].  The loop is latency
+    // bound (LDS index -> dependent global read -> store), so each thread keeps 4 independent
+    // 16-byte outputs (16 gathers) in flight per trip.
     const float* feat = pts_feature + (size_t)bi * N * C;
+    const unsigned rc_magic = (unsigned)(0x100000000ULL / (unsigned)RC) + 1u;  // e / RC = umulhi(e, magic), e < 2^31 / RC
     auto fetch = [&](int s, int j) -> float {
-        const int src = sel[s < cnt ? s : s % cnt];
-        return j < 3 ? pts[src * 3 + j] : feat[(size_t)src * C + (j - 3)];
+        // select the ADDRESS, then one unconditional load (a `cond ? load_a : load_b` becomes two
+        // branch-guarded loads with a vmcnt(0) at every join, which serialises the 16 gathers)
+        const int src = sel[s];
+        const float* a = j < 3 ? pts + (src * 3 + j) : feat + ((size_t)src * C + (j - 3));
+        return *a;
     };
     if (VEC4) {
-        // element index e4*4 .. e4*4+3 ; track (s, j) incrementally: step = 1024 elements
-        const int step_s = 1024 / RC, step_j = 1024 % RC;
-        int e = tid * 4;
-        int s = e / RC, j = e - s * RC;
-        float4* d4 = reinterpret_cast<float4*>(dst);
-        for (; e < total; e += 1024) {
-            float v[4];
-            int ss = s, jj = j;
+        const int nvec = total / 4;
+        for (int f0 = tid; f0 < nvec; f0 += 4 * RP_T) {
+            float v[4][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v[q] = fetch(ss, jj);
-                if (++jj == RC) { jj = 0; ++ss; }
+            for (int u = 0; u < 4; ++u) {
+                const int f = min(f0 + u * RP_T, nvec - 1);   // clamped: loads stay unconditional
+                const int e = f * 4;
+                int s = (int)__umulhi((unsigned)e, rc_magic), j = e - s * RC;
+                if (j >= 3 && j + 3 < RC) {
+                    // the 4 outputs lie inside one feature row: ONE 16-byte gather instead of four
+                    // lane-strided dword gathers (the copy was bound by the texture addresser)
+                    const F4u q = *reinterpret_cast<const F4u*>(feat + ((size_t)sel[s] * C + (j - 3)));
+                    v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v[u][q] = fetch(s, j);
+                        if (++j == RC) { j = 0; ++s; }
+                    }
+                }
             }
-            d4[e >> 2] = make_float4(v[0], v[1], v[2], v[3]);
-            s += step_s; j += step_j;
-            if (j >= RC) { j -= RC; ++s; }
+            float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (f0 + u * RP_T < nvec) d4[f0 + u * RP_T] = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
         }
     } else {
-        const int step_s = 256 / RC, step_j = 256 % RC;
-        int e = tid;
-        int s = e / RC, j = e - s * RC;
-        for (; e < total; e += 256) {
-            dst[e] = fetch(s, j);
-            s += step_s; j += step_j;
-            if (j >= RC) { j -= RC; ++s; }
+        for (int e0 = tid; e0 < total; e0 += 4 * RP_T) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(e0 + u * RP_T, total - 1);
+                const int s = (int)__umulhi((unsigned)e, rc_magic), j = e - s * RC;
+                v[u] = fetch(s, j);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + u * RP_T < total) dst[e0 + u * RP_T] = v[u];
         }
     }
 }
@@ -148,11 +223,11 @@ extern "C" int jm_roipool3d_forward(int batch_size, int pts_num, int boxes_num, 
                "roipool3d: null pointer");
     JM_REQUIRE(batch_size <= 65535, "roipool3d: batch %d > 65535", batch_size);
     JM_REQUIRE(sampled_pts_num <= 32768, "roipool3d: sampled_pts_num %d > 32768", sampled_pts_num);
-    const size_t lds = (size_t)(((sampled_pts_num + 3) & ~3) + 8) * sizeof(int);
+    const size_t lds = (size_t)(((sampled_pts_num + 3) & ~3) + 2 * RP_W) * sizeof(int);
     const long long slab = (long long)sampled_pts_num * (3 + feature_in_len);
     JM_REQUIRE(slab < (1LL << 31), "roipool3d: slab too large");
     const bool vec = (slab % 4 == 0) && ((reinterpret_cast<uintptr_t>(pooled_features) & 15u) == 0);
-    dim3 grid(boxes_num, batch_size), block(256);
+    dim3 grid(boxes_num, batch_size), block(RP_T);
     if (vec) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)roipool3d_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(roipool3d_kernel<true>, grid, block, lds, (hipStream_t)stream, pts_num, boxes_num,
