@@ -135,6 +135,13 @@ def make_ops_inputs(B, seed, dev):
         bb, ss = synth.bev_boxes(6300, seed + 10 + b)
         bev.append(torch.from_numpy(bb).to(dev)); sc.append(torch.from_numpy(ss).to(dev))
     d["bev"], d["scores"] = bev, sc
+    # RCNN SA1 on the pooled RoIs (config.py:134-139): B*128 RoIs x 512 pts x 128 ch -> 128 centres, r=0.2, ns=64
+    from jmodt_amd.ops.pointnet2.pointnet2_modules import PointnetSAModule
+    torch.manual_seed(seed)
+    R = B * 128
+    d["roi_xyz"] = (torch.rand(R, 512, 3, generator=g) - 0.5).mul_(torch.tensor([4.0, 2.0, 2.0])).to(dev)
+    d["roi_feat"] = torch.randn(R, 128, 512, generator=g).to(dev)
+    d["rcnn_sa1"] = PointnetSAModule(mlp=[128, 128, 128, 128], npoint=128, radius=0.2, nsample=64).to(dev).eval()
     torch.manual_seed(seed)
     d["link"], d["se"] = make_affinity_mlp().to(dev).eval(), make_affinity_mlp().to(dev).eval()
     d["pf"] = torch.from_numpy(synth.roi_features(128, 512, seed + 2)).to(dev)
@@ -166,6 +173,13 @@ def ops_step(d, timer):
               lambda: roipool3d_gpu(d["xyz"], d["feat130"], d["boxes"], 0.2, S))
     for b in range(B):
         timer.run("nms_normal_6300", 6300 * 20 + 6300 * 99 * 8, lambda: nms_normal_gpu(d["bev"][b], d["scores"][b], 0.8))
+    # RCNN SA1: FPS + ball query are timed inside too (they are part of the module); flops = the MLP only
+    R = d["roi_xyz"].shape[0]
+    rows = R * 128 * 64
+    mlp_flops = rows * 2 * (131 * 128 + 128 * 128 + 128 * 128)
+    with torch.no_grad():
+        timer.run("rcnn_sa1_fused(fps+ball+group+mlp+max)", 0, lambda: d["rcnn_sa1"](d["roi_xyz"], d["roi_feat"]),
+                  flops=mlp_flops)
     for b in range(B):
         timer.run("affinity_128x128", 0, lambda: pairwise_affinity(d["pf"], d["df"], d["link"], d["se"]), flops=128 * 128 * (2 * 512 * 512 * 2 + 2 * 512))
 

@@ -83,6 +83,18 @@ int jm_three_interpolate(int b, int c, int m, int n, const float* points, const 
 int jm_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out, const int* idx,
                               const float* weight, float* grad_points, jm_stream_t stream);
 
+/* Fused set-abstraction block (MI355X-native; replaces the per-scale body of
+ * _PointnetSAModuleBase.forward, pointnet2_modules.py:46-52 = QueryAndGroup + SharedMLP +
+ * max_pool2d): out[b, :, m] = max_s relu(W_L ... relu(W_1 [xyz[idx]-new_xyz | feat[idx]] + b_1) ... + b_L).
+ * xyz (B,N,3), new_xyz (B,M,3), features (B,C,N) or NULL (C = 0), idx (B,M,nsample) -> out (B, widths[L], M).
+ * widths[0] = 3 + C, widths[1..L] = layer outputs (hidden <= 128).  weights[l] is the 1x1 conv weight
+ * with eval-mode BatchNorm folded in, zero padded to (pad(widths[l+1]), pad16(widths[l])) row-major with
+ * pad = pad16 for hidden layers and pad128 for the last; biases[l] padded likewise.
+ * nsample in {16,32,64}, M*nsample % 128 == 0. */
+int jm_sa_mlp_forward(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
+                      const float* features, const int* idx, int num_layers, const int* widths,
+                      const float* const* weights, const float* const* biases, float* out, jm_stream_t stream);
+
 /* ------------------------------------------------------------------ roipool3d_cuda -------- */
 
 /* forward / forward_slow (roipool3d/src/roipool3d.cpp:16-79, roipool3d_kernel.cu:31-237).

@@ -40,6 +40,8 @@ SIGNATURES = {
     "jm_three_nn": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "jm_three_interpolate": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "jm_three_interpolate_grad": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "jm_sa_mlp_forward": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, ctypes.POINTER(_I), ctypes.POINTER(_P),
+                               ctypes.POINTER(_P), _P, _P]),
     "jm_roipool3d_forward": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "jm_pts_in_boxes3d_cpu": (_I, [_I, _I, _P, _P, _P]),
     "jm_roipool3d_cpu": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),

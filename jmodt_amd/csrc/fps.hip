@@ -24,6 +24,8 @@
 
 namespace jm {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ unsigned bitrev_u(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
 
 constexpr int FPS_OUT_CHUNK = 4096;
@@ -196,12 +198,29 @@ fps_regs2_kernel(int n, int m, int bs, int bs_log2, int R, int J, int recipJ, co
             __syncthreads();
         }
         float best = -1.f;
+        if constexpr (PTS % 2 == 0) {
+            // packed fp32 (v_pk_add/mul/fma_f32): two points per instruction.  Every component is
+            // the same IEEE operation sequence as the scalar path (sub, mul, fma, fma), so results
+            // are bit-identical; a wave64 packed op costs ~4 issue cycles against ~3 for a plain
+            // VALU op, i.e. 1.5x the distance throughput.
+            const f32x2 cx = {x1, x1}, cy = {y1, y1}, cz = {z1, z1};
 #pragma unroll
-        for (int i = 0; i < PTS; ++i) {
-            const float d = sqdist3(px[i] - x1, py[i] - y1, pz[i] - z1);
-            const float d2 = fast_min(d, tm[i]);
-            tm[i] = d2;
-            best = fast_max(best, d2);
+            for (int i = 0; i < PTS; i += 2) {
+                const f32x2 vx = {px[i], px[i + 1]}, vy = {py[i], py[i + 1]}, vz = {pz[i], pz[i + 1]};
+                const f32x2 dx = vx - cx, dy = vy - cy, dz = vz - cz;
+                const f32x2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+                const float a = fast_min(d[0], tm[i]), b = fast_min(d[1], tm[i + 1]);
+                tm[i] = a; tm[i + 1] = b;
+                best = fast_max3(best, a, b);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PTS; ++i) {
+                const float d = sqdist3(px[i] - x1, py[i] - y1, pz[i] - z1);
+                const float d2 = fast_min(d, tm[i]);
+                tm[i] = d2;
+                best = fast_max(best, d2);
+            }
         }
         const int bits = __float_as_int(best);
         const int wmax = wave_max_i32(bits);
@@ -247,6 +266,218 @@ fps_regs2_kernel(int n, int m, int bs, int bs_log2, int R, int J, int recipJ, co
         const int k = (int)bitrev_u((unsigned)P, bs_log2) + bs * j;
         if (r < R && P < bs && k < n) tp[k] = tm[i];
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Spatially pruned exact FPS (n = 4096 / 8192 / 16384, reference block size 1024).
+//
+// After a few hundred picks the coverage radius is small and a new sample changes the
+// min-distance of only the points near it.  Points are therefore laid out so that each of the 16
+// waves owns a spatially compact cluster (Morton order in x,z) and keeps that cluster's bounding
+// box; before its distance loop a wave evaluates the SAME distance expression on the box's
+// nearest corner offsets, which — rounding being monotone — is a lower bound LB of the computed
+// distance of every point in the box.  If LB >= the wave's current maximum min-distance, no
+// temp in the wave can change (min(d, temp) = temp for all of them), so the wave skips the loop
+// and republishes its cached candidate.  The result is bit-identical to the full scan.
+//
+// The reference tie order (min (bitreverse(k mod 1024), k / 1024) =: pk among tied maxima) no longer
+// follows from thread order, so it is carried by the layout: inside a wave the points are sorted
+// by pk (lane-major, then slot), so "first lane, first slot" is still the pk minimum; between
+// waves a tie on the value is resolved by comparing the published pk (rare, uniform branch).
+//
+// Setup (once per cloud, inside the kernel): two bitonic sorts of (key, index) pairs in LDS —
+// first by Morton code, then by (cluster, pk) — ~40 us for 16384 points against milliseconds of
+// sampling.
+__device__ __forceinline__ unsigned part1by1(unsigned v) {
+    v &= 0xFFFFu;
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+__device__ __forceinline__ void bitonic_sort_u64(unsigned long long* e, int n, int T, int NT) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = T; t < n / 2; t += NT) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int p = i | j;
+                const unsigned long long a = e[i], b = e[p];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { e[i] = b; e[p] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+struct __attribute__((aligned(16))) FpsCandP {
+    int val;   // float bits of the wave's max min-distance
+    int pk;    // tie priority of that point
+    int k;
+    float x, y, z;
+    int pad[2];
+};
+
+template <int PTS>
+__global__ void __launch_bounds__(1024)
+fps_pruned_kernel(int n, int m, const float* __restrict__ dataset, float* __restrict__ temp,
+                  int* __restrict__ idxs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* ent = reinterpret_cast<unsigned long long*>(lds_raw);   // [n] during setup
+    constexpr int J = PTS;                  // n / 1024
+    constexpr int JLOG = PTS == 16 ? 4 : (PTS == 8 ? 3 : 2);
+    const int T = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(T >> 6);
+    const int lane = T & 63;
+    const float* ds = dataset + (size_t)blockIdx.x * n * 3;
+    float* tp = temp + (size_t)blockIdx.x * n;
+    int* out = idxs + (size_t)blockIdx.x * m;
+    __shared__ float red[4][16];
+
+    // ---- cloud extent in x, z
+    float xmin = INFINITY, xmax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int k = T + 1024 * j;
+        const float x = ds[k * 3 + 0], z = ds[k * 3 + 2];
+        xmin = fminf(xmin, x); xmax = fmaxf(xmax, x); zmin = fminf(zmin, z); zmax = fmaxf(zmax, z);
+    }
+    xmin = -wave_max_f32(-xmin); xmax = wave_max_f32(xmax); zmin = -wave_max_f32(-zmin); zmax = wave_max_f32(zmax);
+    if (lane == 0) { red[0][wave] = xmin; red[1][wave] = xmax; red[2][wave] = zmin; red[3][wave] = zmax; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        xmin = fminf(xmin, red[0][w]); xmax = fmaxf(xmax, red[1][w]);
+        zmin = fminf(zmin, red[2][w]); zmax = fmaxf(zmax, red[3][w]);
+    }
+    const float sx = 65535.f / fmaxf(xmax - xmin, 1e-20f), sz = 65535.f / fmaxf(zmax - zmin, 1e-20f);
+    // ---- sort 1: Morton order (any key gives a valid permutation; exactness never depends on it)
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int k = T + 1024 * j;
+        const float qx = fminf(fmaxf((ds[k * 3 + 0] - xmin) * sx, 0.f), 65535.f);
+        const float qz = fminf(fmaxf((ds[k * 3 + 2] - zmin) * sz, 0.f), 65535.f);
+        const unsigned key = part1by1((unsigned)qx) | (part1by1((unsigned)qz) << 1);
+        ent[k] = ((unsigned long long)key << 32) | (unsigned)k;
+    }
+    __syncthreads();
+    bitonic_sort_u64(ent, n, T, 1024);
+    // ---- sort 2: (cluster = rank / (64*PTS), pk) -> lane-major pk order inside each wave
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int r = T + 1024 * j;
+        const unsigned k = (unsigned)ent[r];
+        const unsigned cluster = (unsigned)r / (64u * PTS);
+        const unsigned pk = (bitrev_u(k & 1023u, 10) << JLOG) | (k >> 10);
+        ent[r] = ((unsigned long long)((cluster << 20) | pk) << 32) | k;   // own entries only: no race
+    }
+    __syncthreads();
+    bitonic_sort_u64(ent, n, T, 1024);
+
+    float px[PTS], py[PTS], pz[PTS], tm[PTS];
+    const int rank0 = (wave * 64 + lane) * PTS;   // this thread owns sorted ranks rank0 .. rank0 + PTS - 1
+    {
+        int kk[PTS];
+#pragma unroll
+        for (int i = 0; i < PTS; ++i) {
+            const int k = (int)(unsigned)ent[rank0 + i];
+            kk[i] = k;
+            px[i] = ds[k * 3 + 0]; py[i] = ds[k * 3 + 1]; pz[i] = ds[k * 3 + 2];
+            tm[i] = tp[k];
+        }
+        __syncthreads();   // every entry has been read: compact the permutation to int32 in place
+        int* kidx_w = reinterpret_cast<int*>(lds_raw);
+#pragma unroll
+        for (int i = 0; i < PTS; ++i) kidx_w[rank0 + i] = kk[i];
+    }
+    const int* kidx = reinterpret_cast<const int*>(lds_raw);                                   // [n] rank -> point index
+    FpsCandP* cand = reinterpret_cast<FpsCandP*>(lds_raw + (size_t)n * 4);                     // [2][16]
+    int* out_buf = reinterpret_cast<int*>(lds_raw + (size_t)n * 4 + 2 * 16 * sizeof(FpsCandP));   // [FPS_OUT_CHUNK]
+
+    // ---- wave bounding box (all lanes hold the same values)
+    float bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY, bz0 = INFINITY, bz1 = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PTS; ++i) {
+        bx0 = fminf(bx0, px[i]); bx1 = fmaxf(bx1, px[i]);
+        by0 = fminf(by0, py[i]); by1 = fmaxf(by1, py[i]);
+        bz0 = fminf(bz0, pz[i]); bz1 = fmaxf(bz1, pz[i]);
+    }
+    bx0 = -wave_max_f32(-bx0); bx1 = wave_max_f32(bx1);
+    by0 = -wave_max_f32(-by0); by1 = wave_max_f32(by1);
+    bz0 = -wave_max_f32(-bz0); bz1 = wave_max_f32(bz1);
+
+    float x1 = ds[0], y1 = ds[1], z1 = ds[2];
+    if (T == 0) out_buf[0] = 0;
+    // cached candidate of this wave (wave-uniform); cval = +inf forces the first evaluation
+    float cval = INFINITY;
+    int c_pk = 0, c_k = 0, c_x = 0, c_y = 0, c_z = 0;
+    __syncthreads();
+
+    for (int it = 1; it < m; ++it) {
+        if ((it & (FPS_OUT_CHUNK - 1)) == 0) {
+            __syncthreads();
+            for (int e = T; e < FPS_OUT_CHUNK; e += 1024) out[it - FPS_OUT_CHUNK + e] = out_buf[e];
+            __syncthreads();
+        }
+        // lower bound of the computed distance over the wave's box (same expression, monotone rounding)
+        const float ddx = fmaxf(fmaxf(bx0 - x1, x1 - bx1), 0.f);
+        const float ddy = fmaxf(fmaxf(by0 - y1, y1 - by1), 0.f);
+        const float ddz = fmaxf(fmaxf(bz0 - z1, z1 - bz1), 0.f);
+        const float lb = sqdist3(ddx, ddy, ddz);
+        if (__builtin_amdgcn_readfirstlane(lb >= cval ? 0 : 1)) {   // wave-uniform: some temp may change
+            float best = -1.f;
+            int bi = 0;
+#pragma unroll
+            for (int i = 0; i < PTS; ++i) {
+                const float d = sqdist3(px[i] - x1, py[i] - y1, pz[i] - z1);
+                const float d2 = fast_min(d, tm[i]);
+                tm[i] = d2;
+                const bool gt = d2 > best;
+                bi = gt ? i : bi;
+                best = gt ? d2 : best;
+            }
+            const int bits = __float_as_int(best);
+            const int wmax = wave_max_i32(bits);
+            const unsigned long long eq = __ballot(bits == wmax);
+            const int wl = (int)__ffsll((long long)eq) - 1;     // lanes are in pk order inside the wave
+            const int bi_u = __builtin_amdgcn_readlane(bi, wl);
+            c_x = __builtin_amdgcn_readlane(__float_as_int(px[bi_u]), wl);
+            c_y = __builtin_amdgcn_readlane(__float_as_int(py[bi_u]), wl);
+            c_z = __builtin_amdgcn_readlane(__float_as_int(pz[bi_u]), wl);
+            c_k = kidx[(wave * 64 + wl) * PTS + bi_u];   // wave-uniform LDS read
+            c_pk = (int)((bitrev_u((unsigned)c_k & 1023u, 10) << JLOG) | ((unsigned)c_k >> 10));
+            cval = __int_as_float(wmax);
+        }
+        FpsCandP* slot = cand + (it & 1) * 16;
+        if (lane == 0) {
+            FpsCandP c;
+            c.val = __float_as_int(cval); c.pk = c_pk; c.k = c_k;
+            c.x = __int_as_float(c_x); c.y = __int_as_float(c_y); c.z = __int_as_float(c_z);
+            slot[wave] = c;
+        }
+        lds_barrier();
+        const int v = lane < 16 ? slot[lane & 15].val : (int)0x80000000;
+        const int gmax = wave_max_i32(v);
+        unsigned long long weq = __ballot(lane < 16 && v == gmax);
+        int ww = (int)__ffsll((long long)weq) - 1;
+        if (__popcll(weq) > 1) {   // value tie between waves: the smaller pk wins (uniform, rare)
+            const int pkv = ((weq >> lane) & 1ULL) ? slot[lane & 15].pk : 0x7FFFFFFF;
+            const int pmin = -wave_max_i32(-pkv);
+            ww = (int)__ffsll((long long)__ballot(pkv == pmin)) - 1;
+        }
+        const FpsCandP c = slot[ww];
+        x1 = c.x; y1 = c.y; z1 = c.z;
+        if (T == 0) out_buf[it & (FPS_OUT_CHUNK - 1)] = c.k;
+    }
+    __syncthreads();
+    {
+        const int done = ((m - 1) / FPS_OUT_CHUNK) * FPS_OUT_CHUNK;
+        for (int e = T; e < m - done; e += 1024) out[done + e] = out_buf[e];
+    }
+#pragma unroll
+    for (int i = 0; i < PTS; ++i) tp[kidx[rank0 + i]] = tm[i];
 }
 
 // Fallback for clouds that do not fit the register file (n > 16*1024): temp in LDS is not
@@ -325,6 +556,31 @@ extern "C" int jm_furthest_point_sampling(int b, int n, int m, const float* xyz,
     if (J > 32 || (J > 16 && bs > 512)) {  // does not fit the register file: stream from L2
         hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(bs), 0, s, n, m, bs_log2, xyz, temp, idx);
         return check_launch("fps(stream)");
+    }
+    // Spatially pruned kernel: OFF by default.  Measured on MI355X (B=8, 16384 -> 4096): the skip
+    // test removes 85 % of the wave-level distance loops (76.6 k of 524 k wave-iterations stay
+    // active), yet the kernel takes 5.68 ms against 4.74 ms for the full scan: an iteration is bound
+    // by the argmax / publish / barrier latency chain, and the few active waves run their loop
+    // latency-bound (one wave per SIMD) in about the time four interleaved waves need for the full
+    // scan.  Kept (bit-exact, covered by the GPU tests through JM_FPS_PRUNE=1) as the starting
+    // point for a slot-interleaved layout; see DESIGN.md §7.
+    static const int prune = getenv("JM_FPS_PRUNE") ? atoi(getenv("JM_FPS_PRUNE")) : 0;
+    if (prune && bs == 1024 && n % 1024 == 0 && (J == 4 || J == 8 || J == 16) && m > 1) {
+        const size_t need = (size_t)n * 8;   // sort buffer; the loop uses n*4 (rank -> index) + candidates + staged picks
+        const size_t loop_lds = (size_t)n * 4 + 2 * 16 * sizeof(FpsCandP) + FPS_OUT_CHUNK * sizeof(int);
+        const size_t lds = need > loop_lds ? need : loop_lds;
+#define JM_FPS_PRUNED(P)                                                                                    \
+    do {                                                                                                    \
+        if (lds > 64 * 1024)                                                                                \
+            (void)hipFuncSetAttribute((const void*)fps_pruned_kernel<P>,                                     \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+        hipLaunchKernelGGL((fps_pruned_kernel<P>), dim3(b), dim3(1024), lds, s, n, m, xyz, temp, idx);        \
+    } while (0)
+        if (J == 16) JM_FPS_PRUNED(16);
+        else if (J == 8) JM_FPS_PRUNED(8);
+        else JM_FPS_PRUNED(4);
+#undef JM_FPS_PRUNED
+        return check_launch("fps(pruned)");
     }
     // threads per workgroup: points-per-thread target from a measured table,
     // overridable for experiments with JM_FPS_PTS

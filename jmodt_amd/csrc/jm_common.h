@@ -103,6 +103,12 @@ __device__ __forceinline__ float fast_max(float a, float b) {
     return r;
 }
 
+__device__ __forceinline__ float fast_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // workgroup barrier for LDS-only hand-offs: waits for this wave's LDS traffic, not for global
 // memory (a __syncthreads() also drains vmcnt)
 __device__ __forceinline__ void lds_barrier() {

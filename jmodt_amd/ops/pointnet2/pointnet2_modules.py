@@ -14,6 +14,7 @@ from typing import List, Optional, Tuple
 import torch
 import torch.nn as nn
 
+from . import fused
 from . import pointnet2_utils
 from . import pytorch_utils as pt_utils
 
@@ -25,6 +26,7 @@ class _PointnetSAModuleBase(nn.Module):
         self.groupers = None
         self.mlps = None
         self.pool_method = "max_pool"
+        self.fuse = True   # use the fused kernel when eligible (inference); False forces the unfused path
 
     def _pool(self, x: torch.Tensor) -> torch.Tensor:
         # (B, C, npoint, nsample) -> (B, C, npoint)
@@ -52,6 +54,14 @@ class _PointnetSAModuleBase(nn.Module):
 
         pooled = []
         for grouper, mlp, nb in zip(self.groupers, self.mlps, neigh):
+            if (self.fuse and self.pool_method == "max_pool" and isinstance(grouper, pointnet2_utils.QueryAndGroup)
+                    and grouper.use_xyz and not torch.is_grad_enabled()
+                    and fused.can_fuse(mlp, new_xyz.shape[1], grouper.nsample, self.training)):
+                # eval / no-grad: group + MLP + max-pool in one fp32-MFMA kernel, nothing materialised
+                if nb is None:
+                    nb = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+                pooled.append(fused.sa_mlp_fused(xyz, new_xyz, features, nb, mlp))
+                continue
             if isinstance(grouper, pointnet2_utils.QueryAndGroup):
                 grouped = grouper(xyz, new_xyz, features, idx=nb)
             else:

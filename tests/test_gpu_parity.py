@@ -53,6 +53,29 @@ def test_fps_all_equal_and_golden(oracle):
         assert np.array_equal(farthest_point_sample(T(g[f"{tag}_xyz"]), want.shape[1]).cpu().numpy(), want), tag
 
 
+def test_fps_pruned_variant_bit_exact():
+    """the spatially pruned kernel (off by default, JM_FPS_PRUNE=1) must give the same picks"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from jmodt_amd import synth\n"
+        "from jmodt_amd.ops.pointnet2.pointnet2_utils import farthest_point_sample\n"
+        "g = np.load(%r)\n"
+        "ok = True\n"
+        "for tag in ('n16384',):\n"
+        "    ok &= np.array_equal(farthest_point_sample(torch.from_numpy(g[tag + '_xyz']).cuda(), g[tag + '_idx'].shape[1]).cpu().numpy(), g[tag + '_idx'])\n"
+        "x = synth.cloud(2, 4096, seed=9, dup_frac=0.2); from oracle import oracle as o\n"
+        "ok &= np.array_equal(farthest_point_sample(torch.from_numpy(x).cuda(), 700).cpu().numpy(), o.furthest_point_sample(x, 700))\n"
+        "print('PRUNED_OK' if ok else 'PRUNED_MISMATCH')\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+         os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fps.npz"))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, JM_FPS_PRUNE="1"), capture_output=True,
+                         text=True, timeout=300)
+    assert "PRUNED_OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_fps_large_n_stream_path(oracle):
     """n > 16384 takes the streaming kernel (config 5: 65536 points)"""
     from jmodt_amd.ops.pointnet2.pointnet2_utils import farthest_point_sample
@@ -382,3 +405,54 @@ def test_affinity_vs_oracle(oracle, P, D, C):
         assert (Ad - rd / 2).abs().max().item() < 1e-5
     y = mlp3_forward(T(pf), head(sw))
     assert y.shape == (P,)
+
+
+# ------------------------------------------------------------------ fused SA block (group + MLP + max-pool)
+def _randomise_bn(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.2)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.3)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+
+
+@pytest.mark.parametrize("N,npoint,C,radii,nsamples,mlps,bn", [
+    (2048, 512, 0, [0.5, 1.0], [16, 32], [[0, 16, 16, 32], [0, 32, 32, 64]], True),          # RPN level-1 shape
+    (1024, 256, 96, [1.0, 2.0], [16, 32], [[96, 64, 64, 128], [96, 64, 96, 128]], True),     # RPN level-2 widths
+    (512, 128, 128, [2.0], [64], [[128, 128, 128, 128]], True),                              # RCNN SA1 (config.py:137)
+    (512, 128, 128, [2.0], [64], [[128, 128, 128, 256]], True),                              # last layer wider than a tile
+    (700, 64, 5, [3.0], [32], [[5, 24, 40]], False),                                         # 2 layers, odd widths, no BN
+])
+def test_fused_sa_block_matches_unfused(N, npoint, C, radii, nsamples, mlps, bn):
+    """fused kernel (eval, no-grad) vs the same module on the unfused path (HIP group ops + torch
+    1x1 convs + BN + max), 1e-4 relative to the activation scale"""
+    from jmodt_amd.ops.pointnet2.pointnet2_modules import PointnetSAModuleMSG
+    torch.manual_seed(3)
+    sa = PointnetSAModuleMSG(npoint=npoint, radii=radii, nsamples=nsamples, mlps=[list(m) for m in mlps], bn=bn)
+    _randomise_bn(sa, 5)
+    sa = sa.to(DEV).eval()
+    xyz = T(synth.dense_cloud(2, N, 17, extent=6.0))
+    feats = torch.randn(2, C, N, device=DEV) if C else None
+    with torch.no_grad():
+        sa.fuse = True
+        nx1, f1, i1 = sa(xyz, feats)
+        sa.fuse = False
+        nx2, f2, i2 = sa(xyz, feats)
+    assert torch.equal(nx1, nx2) and torch.equal(i1, i2) and f1.shape == f2.shape
+    scale = f2.abs().max().item()
+    assert scale > 0.1
+    assert (f1 - f2).abs().max().item() <= 1e-4 * max(scale, 1.0), (f1 - f2).abs().max().item()
+
+
+def test_fused_sa_block_is_used_and_falls_back():
+    from jmodt_amd.ops.pointnet2 import fused
+    from jmodt_amd.ops.pointnet2.pointnet2_modules import PointnetSAModuleMSG
+    sa = PointnetSAModuleMSG(npoint=64, radii=[1.0], nsamples=[16], mlps=[[0, 16, 32]]).to(DEV)
+    assert fused.can_fuse(sa.mlps[0], 64, 16, training=False)
+    assert not fused.can_fuse(sa.mlps[0], 64, 16, training=True)        # batch statistics: not foldable
+    assert not fused.can_fuse(sa.mlps[0], 64, 24, training=False)       # nsample not in {16,32,64}
+    wide = PointnetSAModuleMSG(npoint=64, radii=[1.0], nsamples=[16], mlps=[[0, 196, 32]]).to(DEV)
+    assert not fused.can_fuse(wide.mlps[0], 64, 16, training=False)     # hidden width > 128
