@@ -123,6 +123,14 @@ int jm_boxes_overlap_bev(int num_a, const float* boxes_a, int num_b, const float
 int jm_boxes_iou_bev(int num_a, const float* boxes_a, int num_b, const float* boxes_b, float* ans_iou,
                      jm_stream_t stream);
 
+/* Tracker association cost (jmodt/tracking/data_association.py:10-28,42-45,117-119):
+ *   cost = link_scores * w_app + boxes_iou3d_gpu(pred, det) * w_iou + boxes_dist_gpu(pred, det) * w_dis
+ * pred_boxes (P,7), det_boxes (D,7) [x,y,z,h,w,l,ry]; link_scores (P,D) or NULL; outputs (P,D), any of
+ * cost / iou3d_out / dist_out may be NULL.  One launch instead of ~25 torch kernels. */
+int jm_association_cost(int num_pred, const float* pred_boxes, int num_det, const float* det_boxes,
+                        const float* link_scores, float w_app, float w_iou, float w_dis, float* cost,
+                        float* iou3d_out, float* dist_out, jm_stream_t stream);
+
 /* nms_gpu / nms_normal_gpu (iou3d.cpp:73-166, iou3d_kernel.cu:250-348,374-387).
  * boxes (N,5) score-sorted.  The suppression bit-mask AND the greedy reduce both run on the
  * device: keep (N) int64 and num_keep (1) int32 are DEVICE buffers; ws holds the mask

@@ -47,6 +47,7 @@ SIGNATURES = {
     "jm_roipool3d_cpu": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "jm_boxes_overlap_bev": (_I, [_I, _P, _I, _P, _P, _P]),
     "jm_boxes_iou_bev": (_I, [_I, _P, _I, _P, _P, _P]),
+    "jm_association_cost": (_I, [_I, _P, _I, _P, _P, _F, _F, _F, _P, _P, _P, _P]),
     "jm_nms_workspace_bytes": (_Z, [_I]),
     "jm_nms": (_I, [_I, _P, _F, _I, _P, _P, _P, _Z, _P]),
     "jm_nms_mask": (_I, [_I, _P, _F, _I, _P, _P]),

@@ -169,6 +169,74 @@ boxes_pair_kernel(int num_a, const float* __restrict__ boxes_a, int num_b, const
     ans[(size_t)ai * num_b + bi] = IOU ? rbox_iou(sa[threadIdx.y], sb[threadIdx.x]) : rbox_overlap(sa[threadIdx.y], sb[threadIdx.x]);
 }
 
+// ------------------------------------------------------------------ tracker association cost
+// cost[i,j] = link[i,j] * w_app + iou3d(pred_i, det_j) * w_iou + dist(pred_i, det_j) * w_dis
+// (jmodt/tracking/data_association.py:10-28,42-45,117-119): rotated BEV overlap x height overlap over
+// the volume union, and 1 - centre distance / farthest of the 64 corner-pair distances.  The
+// reference builds this from ~25 torch kernels and two (M,N,8,8,3) repeat() temporaries, then
+// copies it to the host; here it is one launch, per-box corners computed once per tile.
+struct Box3 {
+    RBox bev;
+    float cx, cy, cz, h, vol;
+    float corner[8][3];
+};
+
+__device__ __forceinline__ Box3 make_box3(const float* b) {
+    Box3 r;
+    const float x = b[0], y = b[1], z = b[2], h = b[3], w = b[4], l = b[5];
+    // boxes3d_to_bev_torch (kitti_utils.py:136-149)
+    const float bev[5] = {x - l / 2, z - w / 2, x + l / 2, z + w / 2, b[6]};
+    r.bev = make_rbox(bev);
+    r.cx = x; r.cy = y; r.cz = z; r.h = h; r.vol = h * w * l;
+    const float xs[8] = {l / 2, l / 2, -l / 2, -l / 2, l / 2, l / 2, -l / 2, -l / 2};
+    const float ys[8] = {0.f, 0.f, 0.f, 0.f, -h, -h, -h, -h};
+    const float zs[8] = {w / 2, -w / 2, -w / 2, w / 2, w / 2, -w / 2, -w / 2, w / 2};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {   // boxes3d_to_corners3d_torch (kitti_utils.py:107-133)
+        r.corner[i][0] = r.bev.cs * xs[i] + r.bev.sn * zs[i] + x;
+        r.corner[i][1] = ys[i] + y;
+        r.corner[i][2] = -r.bev.sn * xs[i] + r.bev.cs * zs[i] + z;
+    }
+    return r;
+}
+
+__global__ void __launch_bounds__(256)
+association_cost_kernel(int np, const float* __restrict__ pred, int nd, const float* __restrict__ det,
+                        const float* __restrict__ link, float w_app, float w_iou, float w_dis,
+                        float* __restrict__ cost, float* __restrict__ iou_out, float* __restrict__ dist_out) {
+    __shared__ Box3 sa[16], sb[16];
+    const int a0 = blockIdx.y * 16, b0 = blockIdx.x * 16;
+    const int t = threadIdx.y * 16 + threadIdx.x;
+    if (t < 16) { if (a0 + t < np) sa[t] = make_box3(pred + (size_t)(a0 + t) * 7); }
+    else if (t < 32) { if (b0 + t - 16 < nd) sb[t - 16] = make_box3(det + (size_t)(b0 + t - 16) * 7); }
+    __syncthreads();
+    const int ai = a0 + threadIdx.y, bi = b0 + threadIdx.x;
+    if (ai >= np || bi >= nd) return;
+    const Box3& A = sa[threadIdx.y];
+    const Box3& B = sb[threadIdx.x];
+    // iou3d_utils.py:36-52 (y is the box BOTTOM, y - h the top)
+    const float ov_bev = rbox_overlap(A.bev, B.bev);
+    const float hmin = fmaxf(A.cy - A.h, B.cy - B.h), hmax = fminf(A.cy, B.cy);
+    const float ov3 = ov_bev * fmaxf(hmax - hmin, 0.f);
+    const float iou = ov3 / fmaxf(A.vol + B.vol - ov3, 1e-7f);
+    const float dx = A.cx - B.cx, dy = A.cy - B.cy, dz = A.cz - B.cz;
+    const float centre = sqrtf(dx * dx + dy * dy + dz * dz);
+    float far2 = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float ex = A.corner[p][0] - B.corner[q][0], ey = A.corner[p][1] - B.corner[q][1],
+                        ez = A.corner[p][2] - B.corner[q][2];
+            far2 = fmaxf(far2, ex * ex + ey * ey + ez * ez);
+        }
+    const float dist = 1.f - centre / sqrtf(far2);
+    const size_t o = (size_t)ai * nd + bi;
+    if (iou_out) iou_out[o] = iou;
+    if (dist_out) dist_out[o] = dist;
+    if (cost) cost[o] = (link ? link[o] * w_app : 0.f) + iou * w_iou + dist * w_dis;
+}
+
 // ------------------------------------------------------------------ NMS mask (upper triangle)
 template <bool NORMAL>
 __global__ void __launch_bounds__(64)
@@ -348,6 +416,18 @@ extern "C" int jm_boxes_iou_bev(int num_a, const float* boxes_a, int num_b, cons
     hipLaunchKernelGGL(boxes_pair_kernel<true>, dim3(divup(num_b, 16), divup(num_a, 16)), dim3(16, 16), 0,
                        (hipStream_t)stream, num_a, boxes_a, num_b, boxes_b, ans_iou);
     return check_launch("boxes_iou_bev");
+}
+
+extern "C" int jm_association_cost(int num_pred, const float* pred_boxes, int num_det, const float* det_boxes,
+                                   const float* link_scores, float w_app, float w_iou, float w_dis, float* cost,
+                                   float* iou3d_out, float* dist_out, jm_stream_t stream) {
+    JM_REQUIRE(num_pred >= 0 && num_det >= 0, "association_cost: bad sizes");
+    if (num_pred == 0 || num_det == 0) return JM_OK;
+    JM_REQUIRE(pred_boxes && det_boxes && (cost || iou3d_out || dist_out), "association_cost: null pointer");
+    hipLaunchKernelGGL(association_cost_kernel, dim3(divup(num_det, 16), divup(num_pred, 16)), dim3(16, 16), 0,
+                       (hipStream_t)stream, num_pred, pred_boxes, num_det, det_boxes, link_scores, w_app, w_iou, w_dis,
+                       cost, iou3d_out, dist_out);
+    return check_launch("association_cost");
 }
 
 extern "C" size_t jm_nms_workspace_bytes(int boxes_num) {

@@ -564,6 +564,50 @@ ORC_API int orc_nms(int n, const float* boxes, float thresh, int normal, int64_t
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Tracker association cost terms (jmodt/tracking/data_association.py:10-28,42-45)
+ *   boxes_dist = 1 - ||centre_a - centre_b|| / max_{i,j} ||corner_a_i - corner_b_j||   (8 x 8 corner pairs)
+ *   corners: jmodt/utils/kitti_utils.py:107-133 (x: +-l/2, y: 0 / -h, z: +-w/2, rotated about y, + centre)
+ *   cost = link * w_app + iou3d * w_iou + dist * w_dis
+ * Accumulated in double and rounded once: an accuracy reference for the 1e-4 tolerance.
+ * ---------------------------------------------------------------------------------------- */
+static void orc_corners3d(const float* b, double c[8][3]) {
+    const double h = b[3], w = b[4], l = b[5];
+    float sn, cs;
+    jm_sincosf(b[6], &sn, &cs);
+    const double xs[8] = {l / 2, l / 2, -l / 2, -l / 2, l / 2, l / 2, -l / 2, -l / 2};
+    const double ys[8] = {0, 0, 0, 0, -h, -h, -h, -h};
+    const double zs[8] = {w / 2, -w / 2, -w / 2, w / 2, w / 2, -w / 2, -w / 2, w / 2};
+    for (int i = 0; i < 8; ++i) {
+        c[i][0] = cs * xs[i] + sn * zs[i] + b[0];
+        c[i][1] = ys[i] + b[1];
+        c[i][2] = -sn * xs[i] + cs * zs[i] + b[2];
+    }
+}
+
+ORC_API void orc_boxes_dist(int na, const float* boxes_a, int nb, const float* boxes_b, float* out) {
+    for (int i = 0; i < na; ++i) {
+        double ca[8][3];
+        orc_corners3d(boxes_a + i * 7, ca);
+        for (int j = 0; j < nb; ++j) {
+            double cb[8][3];
+            orc_corners3d(boxes_b + j * 7, cb);
+            const float* a = boxes_a + i * 7;
+            const float* b = boxes_b + j * 7;
+            const double dx = (double)a[0] - b[0], dy = (double)a[1] - b[1], dz = (double)a[2] - b[2];
+            const double centre = sqrt(dx * dx + dy * dy + dz * dz);
+            double far2 = 0;
+            for (int p = 0; p < 8; ++p)
+                for (int q = 0; q < 8; ++q) {
+                    const double ex = ca[p][0] - cb[q][0], ey = ca[p][1] - cb[q][1], ez = ca[p][2] - cb[q][2];
+                    const double d2 = ex * ex + ey * ey + ez * ez;
+                    if (d2 > far2) far2 = d2;
+                }
+            out[(size_t)i * nb + j] = (float)(1.0 - centre / sqrt(far2));
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * LI-Fusion point -> image gather  (jmodt/detection/modeling/backbone.py:79-89)
  *   F.grid_sample(feature_map, xy[B,1,N,2], mode='bilinear', padding_mode='zeros',
  *                 align_corners=True)

@@ -229,6 +229,20 @@ def boxes_iou3d(boxes_a, boxes_b):
     return (o3 / np.clip(va + vb - o3, np.float32(1e-7), None)).astype(np.float32)
 
 
+def boxes_dist(boxes_a, boxes_b):
+    """data_association.py:10-28: 1 - centre distance / farthest corner-pair distance, (M, N)"""
+    a, b = _f32(boxes_a), _f32(boxes_b)
+    out = np.zeros((a.shape[0], b.shape[0]), dtype=np.float32)
+    lib().orc_boxes_dist(a.shape[0], _p(a, _f), b.shape[0], _p(b, _f), _p(out, _f))
+    return out
+
+
+def association_cost(pred_boxes, det_boxes, link_scores, w_app, w_iou, w_dis):
+    """data_association.py:42-45: link * w_app + iou3d * w_iou + dist * w_dis"""
+    return (_f32(link_scores) * np.float32(w_app) + boxes_iou3d(pred_boxes, det_boxes) * np.float32(w_iou)
+            + boxes_dist(pred_boxes, det_boxes) * np.float32(w_dis)).astype(np.float32)
+
+
 def nms_mask(boxes_sorted, thresh, normal):
     b = _f32(boxes_sorted)
     n = b.shape[0]

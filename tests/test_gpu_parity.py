@@ -456,3 +456,19 @@ def test_fused_sa_block_is_used_and_falls_back():
     assert not fused.can_fuse(sa.mlps[0], 64, 24, training=False)       # nsample not in {16,32,64}
     wide = PointnetSAModuleMSG(npoint=64, radii=[1.0], nsamples=[16], mlps=[[0, 196, 32]]).to(DEV)
     assert not fused.can_fuse(wide.mlps[0], 64, 16, training=False)     # hidden width > 128
+
+
+# ------------------------------------------------------------------ tracker association cost (§8f row 1)
+@pytest.mark.parametrize("P,D", [(20, 14), (64, 64), (1, 3), (130, 37)])
+def test_association_cost_vs_oracle(oracle, P, D):
+    from jmodt_amd.ops.association import association_cost, boxes_dist_gpu
+    pts = synth.dense_cloud(1, 512, 3, extent=12.0)
+    a, b = synth.proposals(pts, P, 4)[0], synth.proposals(pts, D, 5)[0]
+    link = np.random.default_rng(0).random((P, D)).astype(np.float32)
+    cost, iou, dist = association_cost(T(a), T(b), T(link), 0.5, 0.3, 0.2, return_parts=True)
+    assert np.abs(dist.cpu().numpy() - oracle.boxes_dist(a, b)).max() < 1e-4
+    assert np.abs(iou.cpu().numpy() - oracle.boxes_iou3d(a, b)).max() < 1e-5
+    assert np.abs(cost.cpu().numpy() - oracle.association_cost(a, b, link, 0.5, 0.3, 0.2)).max() < 1e-4
+    assert np.abs(boxes_dist_gpu(T(a), T(b)).cpu().numpy() - oracle.boxes_dist(a, b)).max() < 1e-4
+    from jmodt_amd.ops.iou3d.iou3d_utils import boxes_iou3d_gpu
+    assert torch.equal(boxes_iou3d_gpu(T(a), T(b)), iou)       # same kernel arithmetic as the iou3d op

@@ -355,3 +355,35 @@ def test_affinity_vs_torch(oracle, P, D, C):
     gA, gs, ge = oracle.affinity(pf, df, lw, sw)
     assert np.abs(gA - A.numpy()).max() < 1e-5
     assert np.abs(gs - st.numpy()).max() < 1e-4 and np.abs(ge - en.numpy()).max() < 1e-4
+
+
+# ------------------------------------------------------------------ tracker association cost (§8f row 1)
+def _np_boxes_dist(a, b):
+    """independent float64 restatement of data_association.py:10-28 / kitti_utils.py:107-133"""
+    def corners(bx):
+        x, y, z, h, w, l, ry = [float(v) for v in bx]
+        xs = np.array([l, l, -l, -l, l, l, -l, -l]) / 2
+        ys = np.array([0, 0, 0, 0, -h, -h, -h, -h])
+        zs = np.array([w, -w, -w, w, w, -w, -w, w]) / 2
+        R = np.array([[np.cos(ry), 0, np.sin(ry)], [0, 1, 0], [-np.sin(ry), 0, np.cos(ry)]])
+        return (R @ np.stack([xs, ys, zs])).T + np.array([x, y, z])
+    out = np.zeros((len(a), len(b)))
+    for i in range(len(a)):
+        ca = corners(a[i])
+        for j in range(len(b)):
+            cb = corners(b[j])
+            far = np.linalg.norm(ca[:, None, :] - cb[None, :, :], axis=-1).max()
+            out[i, j] = 1 - np.linalg.norm(a[i, :3].astype(np.float64) - b[j, :3]) / far
+    return out
+
+
+def test_boxes_dist_and_association_cost(oracle):
+    pts = synth.dense_cloud(1, 256, 3, extent=10.0)
+    a, b = synth.proposals(pts, 20, 4)[0], synth.proposals(pts, 14, 5)[0]
+    d = oracle.boxes_dist(a, b)
+    assert np.abs(d - _np_boxes_dist(a, b)).max() < 1e-5
+    assert np.abs(np.diag(oracle.boxes_dist(a, a)) - 1.0).max() < 1e-6      # same box: centre distance 0
+    link = np.random.default_rng(0).random((20, 14)).astype(np.float32)
+    cost = oracle.association_cost(a, b, link, 0.5, 0.3, 0.2)
+    want = link * 0.5 + oracle.boxes_iou3d(a, b) * 0.3 + d * 0.2
+    assert np.abs(cost - want).max() < 1e-6
