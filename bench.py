@@ -135,6 +135,8 @@ def make_ops_inputs(B, seed, dev):
         bb, ss = synth.bev_boxes(6300, seed + 10 + b)
         bev.append(torch.from_numpy(bb).to(dev)); sc.append(torch.from_numpy(ss).to(dev))
     d["bev"], d["scores"] = bev, sc
+    rs, rp = synth.rpn_output(B, 16384, seed + 20)
+    d["rpn_scores"], d["rpn_props"] = torch.from_numpy(rs).to(dev), torch.from_numpy(rp).to(dev)
     # RCNN SA1 on the pooled RoIs (config.py:134-139): B*128 RoIs x 512 pts x 128 ch -> 128 centres, r=0.2, ns=64
     from jmodt_amd.ops.pointnet2.pointnet2_modules import PointnetSAModule
     torch.manual_seed(seed)
@@ -173,6 +175,10 @@ def ops_step(d, timer):
               lambda: roipool3d_gpu(d["xyz"], d["feat130"], d["boxes"], 0.2, S))
     for b in range(B):
         timer.run("nms_normal_6300", 6300 * 20 + 6300 * 99 * 8, lambda: nms_normal_gpu(d["bev"][b], d["scores"][b], 0.8))
+    # the whole batch's proposal selection (sort, band split, 2B batched NMS problems, stitch), TEST budgets
+    from jmodt_amd.ops.proposal import distance_based_proposal
+    timer.run("proposal_select_batched(B frames, pre 9000, post 100)", B * (6300 + 2700) * (20 + 8 * 99),
+              lambda: distance_based_proposal(d["rpn_scores"], d["rpn_props"], 9000, 100, 0.8, "normal"))
     # RCNN SA1: FPS + ball query are timed inside too (they are part of the module); flops = the MLP only
     R = d["roi_xyz"].shape[0]
     rows = R * 128 * 64

@@ -138,6 +138,14 @@ int jm_association_cost(int num_pred, const float* pred_boxes, int num_det, cons
 size_t jm_nms_workspace_bytes(int boxes_num);
 int jm_nms(int boxes_num, const float* boxes, float nms_overlap_thresh, int normal, int64_t* keep,
            int* num_keep, void* ws, size_t ws_bytes, jm_stream_t stream);
+/* Batched form (the RPN runs 2 distance bands x B frames of NMS per batch,
+ * proposal_layer.py:41-117, one after the other with a host sync each in the reference): problem p
+ * has counts[p] (device int, <= max_boxes) score-sorted boxes at boxes + p*max_boxes*5; keep is
+ * (P, max_boxes) int64, num_keep (P) int32; ws >= P * jm_nms_workspace_bytes(max_boxes).
+ * All problems run concurrently and nothing touches the host. */
+int jm_nms_batched(int num_problems, int max_boxes, const int* counts, const float* boxes,
+                   float nms_overlap_thresh, int normal, int64_t* keep, int* num_keep, void* ws, size_t ws_bytes,
+                   jm_stream_t stream);
 /* mask only (N, ceil(N/64)) uint64; tiles with col_block < row_block are never consumed by the
  * reduce (iou3d.cpp:108) and are left unwritten. */
 int jm_nms_mask(int boxes_num, const float* boxes, float nms_overlap_thresh, int normal,

@@ -238,10 +238,17 @@ association_cost_kernel(int np, const float* __restrict__ pred, int nd, const fl
 }
 
 // ------------------------------------------------------------------ NMS mask (upper triangle)
+// Batched over blockIdx.y: problem p has counts[p] (<= nmax) score-sorted boxes at boxes + p*nmax*5 and a
+// mask slab of nmax rows x stride_cb words.  counts == nullptr: one problem of exactly nmax boxes.
 template <bool NORMAL>
 __global__ void __launch_bounds__(64)
-nms_mask_kernel(int n, float thresh, const float* __restrict__ boxes, unsigned long long* __restrict__ mask) {
-    const int col_blocks = (n + 63) / 64;
+nms_mask_kernel(int nmax, const int* __restrict__ counts, int stride_cb, float thresh,
+                const float* __restrict__ boxes_all, unsigned long long* __restrict__ mask_all) {
+    const int prob = blockIdx.y;
+    const int n = counts ? min(counts[prob], nmax) : nmax;
+    const float* boxes = boxes_all + (size_t)prob * nmax * 5;
+    unsigned long long* mask = mask_all + (size_t)prob * nmax * stride_cb;
+    const int col_blocks = (nmax + 63) / 64;   // tile enumeration over the padded size
     // linear block id -> (row_start <= col_start) pair of the upper triangle
     int rb = 0, cb = 0;
     {
@@ -256,6 +263,7 @@ nms_mask_kernel(int n, float thresh, const float* __restrict__ boxes, unsigned l
         while (r + 1 < col_blocks && start_of(r + 1) <= id) ++r;
         rb = r; cb = r + (int)(id - start_of(r));
     }
+    if (rb * 64 >= n || cb * 64 >= n) return;   // tile lies in the padding of this problem
     const int tx = threadIdx.x;
     const int row_size = min(n - rb * 64, 64), col_size = min(n - cb * 64, 64);
     __shared__ RBox scol[NORMAL ? 1 : 64];
@@ -284,7 +292,7 @@ nms_mask_kernel(int n, float thresh, const float* __restrict__ boxes, unsigned l
             for (int i = start; i < col_size; ++i)
                 if (rbox_iou(me, scol[i]) > thresh) t |= 1ULL << i;
         }
-        mask[(size_t)cur * col_blocks + cb] = t;
+        mask[(size_t)cur * stride_cb + cb] = t;
     }
 }
 
@@ -306,9 +314,16 @@ nms_mask_kernel(int n, float thresh, const float* __restrict__ boxes, unsigned l
 constexpr int NMS_RT = 512;   // 4 row groups x 128 columns; 256-VGPR budget holds the 4-deep prefetch ring
 
 __global__ void __launch_bounds__(NMS_RT)
-nms_reduce_kernel(int n, const unsigned long long* __restrict__ mask, long long* __restrict__ keep,
-                  int* __restrict__ num_keep) {
+nms_reduce_kernel(int nmax, const int* __restrict__ counts, int stride_cb,
+                  const unsigned long long* __restrict__ mask_all, long long* __restrict__ keep_all,
+                  int* __restrict__ num_keep_all) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];  // [col_blocks] + 1 (kept bits)
+    const int prob = blockIdx.x;
+    const int n = counts ? min(counts[prob], nmax) : nmax;
+    const unsigned long long* mask = mask_all + (size_t)prob * nmax * stride_cb;
+    long long* keep = keep_all + (size_t)prob * nmax;
+    int* num_keep = num_keep_all + prob;
+    if (n <= 0) { if (threadIdx.x == 0) *num_keep = 0; return; }
     const int cb = (n + 63) / 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int c = tid & 127, g = tid >> 7;   // OR phase: column offset 0..127, row group 0..3 (rows g + 4q)
@@ -327,9 +342,9 @@ nms_reduce_kernel(int n, const unsigned long long* __restrict__ mask, long long*
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int row = min(rbc * 64 + g + 4 * q, n - 1);
-            w[q] = mask[(size_t)row * cb + col];
+            w[q] = mask[(size_t)row * stride_cb + col];
         }
-        d = mask[(size_t)min(rbc * 64 + lane, n - 1) * cb + rbc];   // consumed by wave 0 only
+        d = mask[(size_t)min(rbc * 64 + lane, n - 1) * stride_cb + rbc];   // consumed by wave 0 only
     };
     int count = 0;  // uniform
     auto step = [&](int rb, unsigned long long (&w)[16], unsigned long long& d) {
@@ -373,7 +388,7 @@ nms_reduce_kernel(int n, const unsigned long long* __restrict__ mask, long long*
             unsigned long long acc = 0ULL;
             for (int q = 0; q < 16; ++q) {
                 const int i = g + 4 * q;
-                if (((kept >> i) & 1ULL) && rb * 64 + i < n) acc |= mask[(size_t)(rb * 64 + i) * cb + col];
+                if (((kept >> i) & 1ULL) && rb * 64 + i < n) acc |= mask[(size_t)(rb * 64 + i) * stride_cb + col];
             }
             if (acc != 0ULL) atomicOr(&remv[col], acc);
         }
@@ -436,21 +451,36 @@ extern "C" size_t jm_nms_workspace_bytes(int boxes_num) {
     return (size_t)boxes_num * cb * sizeof(unsigned long long);
 }
 
+static int launch_nms_mask(int nprob, int nmax, const int* counts, const float* boxes, float thresh, int normal,
+                           unsigned long long* mask, hipStream_t s) {
+    const long long cb = (nmax + 63) / 64;
+    const long long tiles = cb * (cb + 1) / 2;
+    JM_REQUIRE(tiles < (1LL << 31) && nprob <= 65535, "nms_mask: too many boxes / problems");
+    dim3 grid((unsigned)tiles, (unsigned)nprob);
+    if (normal)
+        hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(64), 0, s, nmax, counts, (int)cb, thresh, boxes, mask);
+    else
+        hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(64), 0, s, nmax, counts, (int)cb, thresh, boxes, mask);
+    return check_launch("nms_mask");
+}
+
+static int launch_nms_reduce(int nprob, int nmax, const int* counts, const unsigned long long* mask, int64_t* keep,
+                             int* num_keep, hipStream_t s) {
+    const int cb = (nmax + 63) / 64;
+    const size_t lds = (size_t)(cb + 1) * sizeof(unsigned long long);
+    JM_REQUIRE(lds <= 160 * 1024, "nms: %d boxes exceed the on-device reduce capacity", nmax);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)nms_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(nms_reduce_kernel, dim3(nprob), dim3(NMS_RT), lds, s, nmax, counts, cb, mask, (long long*)keep,
+                       num_keep);
+    return check_launch("nms_reduce");
+}
+
 extern "C" int jm_nms_mask(int boxes_num, const float* boxes, float nms_overlap_thresh, int normal,
                            unsigned long long* mask, jm_stream_t stream) {
     JM_REQUIRE(boxes_num >= 0, "nms_mask: bad size");
     if (boxes_num == 0) return JM_OK;
     JM_REQUIRE(boxes && mask, "nms_mask: null pointer");
-    const long long cb = (boxes_num + 63) / 64;
-    const long long tiles = cb * (cb + 1) / 2;
-    JM_REQUIRE(tiles < (1LL << 31), "nms_mask: too many boxes");
-    if (normal)
-        hipLaunchKernelGGL(nms_mask_kernel<true>, dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, boxes_num,
-                           nms_overlap_thresh, boxes, mask);
-    else
-        hipLaunchKernelGGL(nms_mask_kernel<false>, dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, boxes_num,
-                           nms_overlap_thresh, boxes, mask);
-    return check_launch("nms_mask");
+    return launch_nms_mask(1, boxes_num, nullptr, boxes, nms_overlap_thresh, normal, mask, (hipStream_t)stream);
 }
 
 extern "C" int jm_nms(int boxes_num, const float* boxes, float nms_overlap_thresh, int normal, int64_t* keep,
@@ -466,13 +496,27 @@ extern "C" int jm_nms(int boxes_num, const float* boxes, float nms_overlap_thres
         set_error("nms: workspace %zu < %zu bytes", ws_bytes, jm_nms_workspace_bytes(boxes_num));
         return JM_EWORKSPACE;
     }
-    int rc = jm_nms_mask(boxes_num, boxes, nms_overlap_thresh, normal, (unsigned long long*)ws, stream);
+    int rc = launch_nms_mask(1, boxes_num, nullptr, boxes, nms_overlap_thresh, normal, (unsigned long long*)ws, (hipStream_t)stream);
     if (rc) return rc;
-    const int cb = (boxes_num + 63) / 64;
-    const size_t lds = (size_t)(cb + 1) * sizeof(unsigned long long);
-    JM_REQUIRE(lds <= 160 * 1024, "nms: %d boxes exceed the on-device reduce capacity", boxes_num);
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)nms_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(NMS_RT), lds, (hipStream_t)stream, boxes_num,
-                       (const unsigned long long*)ws, (long long*)keep, num_keep);
-    return check_launch("nms_reduce");
+    return launch_nms_reduce(1, boxes_num, nullptr, (const unsigned long long*)ws, keep, num_keep, (hipStream_t)stream);
+}
+
+extern "C" int jm_nms_batched(int num_problems, int max_boxes, const int* counts, const float* boxes,
+                              float nms_overlap_thresh, int normal, int64_t* keep, int* num_keep, void* ws,
+                              size_t ws_bytes, jm_stream_t stream) {
+    JM_REQUIRE(num_problems >= 0 && max_boxes >= 0, "nms_batched: bad sizes");
+    if (num_problems == 0) return JM_OK;
+    JM_REQUIRE(num_keep, "nms_batched: null num_keep");
+    if (max_boxes == 0) {
+        (void)hipMemsetAsync(num_keep, 0, sizeof(int) * num_problems, (hipStream_t)stream);
+        return check_launch("nms_batched(memset)");
+    }
+    JM_REQUIRE(counts && boxes && keep && ws, "nms_batched: null pointer");
+    const size_t need = jm_nms_workspace_bytes(max_boxes) * (size_t)num_problems;
+    if (ws_bytes < need) { set_error("nms_batched: workspace %zu < %zu bytes", ws_bytes, need); return JM_EWORKSPACE; }
+    int rc = launch_nms_mask(num_problems, max_boxes, counts, boxes, nms_overlap_thresh, normal, (unsigned long long*)ws,
+                             (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_nms_reduce(num_problems, max_boxes, counts, (const unsigned long long*)ws, keep, num_keep,
+                             (hipStream_t)stream);
 }

@@ -38,6 +38,23 @@ def nms_device(boxes, thresh, normal):
     return keep, num
 
 
+def nms_batched_device(boxes, counts, thresh, normal):
+    """P independent NMS problems in one mask launch + one reduce launch (jm_nms_batched).
+    boxes (P, Nmax, 5) score-sorted per problem, counts (P) int32 device
+    -> keep (P, Nmax) int64 (first num_keep[p] entries valid), num_keep (P) int32; nothing syncs."""
+    lib = L.load()
+    nprob, nmax = boxes.size(0), boxes.size(1)
+    keep = torch.empty((nprob, max(nmax, 1)), dtype=torch.int64, device=boxes.device)
+    num = torch.empty((max(nprob, 1),), dtype=torch.int32, device=boxes.device)
+    ws_bytes = lib.jm_nms_workspace_bytes(nmax) * nprob
+    ws = torch.empty((max(ws_bytes, 8),), dtype=torch.uint8, device=boxes.device)
+    L.check(lib.jm_nms_batched(nprob, nmax, L.dev(counts, torch.int32, "counts"), L.dev(boxes, f32, "boxes"),
+                               float(thresh), int(normal), ctypes.c_void_p(keep.data_ptr()),
+                               ctypes.c_void_p(num.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws_bytes,
+                               L.stream_ptr()), "nms_batched")
+    return keep, num[:nprob]
+
+
 def _nms_to_cpu_keep(boxes, keep, thresh, normal):
     if keep.is_cuda or keep.dtype != torch.int64 or not keep.is_contiguous():
         raise RuntimeError("keep must be a contiguous CPU int64 tensor (iou3d.cpp:76-82)")

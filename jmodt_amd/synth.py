@@ -88,3 +88,31 @@ def mlp_weights(C, H1, H2, seed, scale=None):
     b2 = rng.normal(0, 0.05, H2).astype(np.float32)
     b3 = np.float32(rng.normal(0, 0.05))
     return W1, b1, W2, b2, w3, b3
+
+
+def rpn_output(B, N, seed, z_range=(0.5, 90.0), empty_far=(), empty_near=()):
+    """decoded RPN proposals (B, N, 7) [x, y_bottom, z, h, w, l, ry] clustered around N//20 objects per
+    frame with depths over z_range (some beyond the 80 m band edge), + distinct scores (B, N).
+    Frames listed in empty_far / empty_near get no object in (40, 80] / (0, 40] m."""
+    rng = np.random.default_rng(seed)
+    props = np.zeros((B, N, 7), dtype=np.float32)
+    scores = np.zeros((B, N), dtype=np.float32)
+    for b in range(B):
+        nc = max(1, N // 20)
+        lo, hi = z_range
+        if b in empty_far:
+            hi = 39.0
+        if b in empty_near:
+            lo = 41.0
+        cz = rng.uniform(lo, hi, nc).astype(np.float32)
+        cx = rng.uniform(-30, 30, nc).astype(np.float32)
+        which = rng.integers(0, nc, N)
+        jit = rng.normal(0, 0.4, (N, 2)).astype(np.float32)
+        hwl = np.array([1.526, 1.629, 3.883], dtype=np.float32) * rng.uniform(0.9, 1.1, (N, 3)).astype(np.float32)
+        props[b, :, 0] = cx[which] + jit[:, 0]
+        props[b, :, 1] = rng.uniform(1.2, 2.0, N).astype(np.float32)
+        props[b, :, 2] = cz[which] + jit[:, 1]
+        props[b, :, 3:6] = hwl
+        props[b, :, 6] = rng.uniform(-np.pi, np.pi, N).astype(np.float32)
+        scores[b] = (rng.permutation(N).astype(np.float32) - N / 2) / np.float32(N / 8)   # logits, all distinct
+    return scores, props

@@ -268,6 +268,49 @@ def nms(boxes, scores, thresh, normal):
     return order[keep].astype(np.int64)
 
 
+def proposal_select(scores, proposals, pre_nms_top_n, post_nms_top_n, nms_thresh, nms_type="normal",
+                    distance_based=True):
+    """ProposalLayer.forward after the decode, frame by frame (proposal_layer.py:34-55) with
+    distance_based_proposal (:57-117) or score_based_proposal (:119-144).  Stable score sorts."""
+    scores = _f32(scores)
+    proposals = _f32(proposals)
+    B = scores.shape[0]
+    ret_boxes = np.zeros((B, post_nms_top_n, 7), np.float32)
+    ret_scores = np.zeros((B, post_nms_top_n), np.float32)
+    normal = {"normal": 1, "rotate": 0}[nms_type]
+    for k in range(B):
+        order = np.argsort(-scores[k], kind="stable")
+        so, po = scores[k][order], proposals[k][order]
+        out_s, out_p = [], []
+        if distance_based:
+            ranges = [0.0, 40.0, 80.0]
+            pre = [0, int(pre_nms_top_n * 0.7), pre_nms_top_n - int(pre_nms_top_n * 0.7)]
+            post = [0, int(post_nms_top_n * 0.7), post_nms_top_n - int(post_nms_top_n * 0.7)]
+            dist = po[:, 2]
+            first = (dist > ranges[0]) & (dist <= ranges[1])
+            for i in (1, 2):
+                m = (dist > ranges[i - 1]) & (dist <= ranges[i])
+                if m.sum() != 0:
+                    cs, cp = so[m][:pre[i]], po[m][:pre[i]]
+                else:
+                    if i == 1:
+                        continue
+                    cs, cp = so[first][pre[i - 1]:][:pre[i]], po[first][pre[i - 1]:][:pre[i]]
+                keep = nms(boxes3d_to_bev(cp), cs, nms_thresh, normal)[:post[i]] if len(cs) else np.zeros(0, np.int64)
+                out_s.append(cs[keep])
+                out_p.append(cp[keep])
+        else:
+            cs, cp = so[:pre_nms_top_n], po[:pre_nms_top_n]
+            keep = nms(boxes3d_to_bev(cp), cs, nms_thresh, 0)[:post_nms_top_n]
+            out_s.append(cs[keep])
+            out_p.append(cp[keep])
+        s1 = np.concatenate(out_s) if out_s else np.zeros(0, np.float32)
+        p1 = np.concatenate(out_p) if out_p else np.zeros((0, 7), np.float32)
+        ret_boxes[k, :len(s1)] = p1
+        ret_scores[k, :len(s1)] = s1
+    return ret_boxes, ret_scores
+
+
 # ---------------------------------------------------------------- LI-Fusion gather
 def feature_gather(feature_map, xy):
     """feature_map (B,C,H,W) any strides, xy (B,N,2) in [-1,1] -> (B,C,N)"""

@@ -472,3 +472,49 @@ def test_association_cost_vs_oracle(oracle, P, D):
     assert np.abs(boxes_dist_gpu(T(a), T(b)).cpu().numpy() - oracle.boxes_dist(a, b)).max() < 1e-4
     from jmodt_amd.ops.iou3d.iou3d_utils import boxes_iou3d_gpu
     assert torch.equal(boxes_iou3d_gpu(T(a), T(b)), iou)       # same kernel arithmetic as the iou3d op
+
+
+# ------------------------------------------------------------------ batched NMS + RPN proposal selection (§8f row 2)
+@pytest.mark.parametrize("normal", [1, 0])
+def test_nms_batched_matches_single_problem_oracle(oracle, normal):
+    """ragged problems (incl. empty, 1 box, one exactly max_boxes) through one jm_nms_batched call"""
+    from jmodt_amd.ext import iou3d_cuda
+    counts = [700, 0, 1, 64, 65, 333, 1000, 129]
+    nmax = 1000
+    boxes = np.zeros((len(counts), nmax, 5), np.float32)
+    for p, c in enumerate(counts):
+        b, s = synth.bev_boxes(max(c, 1), 50 + p)
+        boxes[p, :c] = b[np.argsort(-s, kind="stable")][:c]
+        boxes[p, c:] = np.nan    # padding must never be read as a box
+    keep, num = iou3d_cuda.nms_batched_device(T(boxes), T(np.array(counts, np.int32)), 0.6, normal)
+    keep, num = keep.cpu().numpy(), num.cpu().numpy()
+    for p, c in enumerate(counts):
+        want = oracle.nms_sorted(boxes[p, :c], 0.6, normal) if c else np.zeros(0, np.int64)
+        assert num[p] == len(want), p
+        assert np.array_equal(keep[p, :num[p]], want), p
+
+
+@pytest.mark.parametrize("B,N,pre,post,thresh,nms_type,kw", [
+    (4, 16384, 9000, 100, 0.8, "normal", dict(empty_far=(1,), empty_near=(2,))),   # TEST config (config.py:226-230)
+    (2, 16384, 9000, 512, 0.85, "normal", {}),                                    # TRAIN config (config.py:201-205)
+    (3, 2000, 9000, 100, 0.8, "rotate", dict(empty_far=(0,))),                     # fewer points than the budget
+    (2, 600, 300, 40, 0.7, "normal", dict(empty_far=(1,))),                        # far band falls back to near[pre1:]
+    (2, 300, 100, 500, 0.99, "normal", {}),                                        # post budget never reached
+])
+def test_proposal_select_distance_based(oracle, B, N, pre, post, thresh, nms_type, kw):
+    from jmodt_amd.ops.proposal import distance_based_proposal
+    scores, props = synth.rpn_output(B, N, seed=B * N + post, **kw)
+    got_b, got_s = distance_based_proposal(T(scores), T(props), pre, post, thresh, nms_type)
+    want_b, want_s = oracle.proposal_select(scores, props, pre, post, thresh, nms_type)
+    assert got_b.shape == (B, post, 7) and got_s.shape == (B, post)
+    assert np.array_equal(got_s.cpu().numpy(), want_s)
+    assert np.array_equal(got_b.cpu().numpy(), want_b)
+    assert (want_s != 0).any(axis=1).all()
+
+
+def test_proposal_select_score_based(oracle):
+    from jmodt_amd.ops.proposal import score_based_proposal
+    scores, props = synth.rpn_output(3, 4096, seed=77)
+    got_b, got_s = score_based_proposal(T(scores), T(props), 1500, 100, 0.8)
+    want_b, want_s = oracle.proposal_select(scores, props, 1500, 100, 0.8, distance_based=False)
+    assert np.array_equal(got_s.cpu().numpy(), want_s) and np.array_equal(got_b.cpu().numpy(), want_b)

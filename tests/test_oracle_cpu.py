@@ -387,3 +387,22 @@ def test_boxes_dist_and_association_cost(oracle):
     cost = oracle.association_cost(a, b, link, 0.5, 0.3, 0.2)
     want = link * 0.5 + oracle.boxes_iou3d(a, b) * 0.3 + d * 0.2
     assert np.abs(cost - want).max() < 1e-6
+
+
+def test_proposal_select_band_budgets(oracle):
+    """proposal_layer.py:57-117: 70/30 budgets, empty far band falls back to the next near slice,
+    empty near band contributes nothing; rows past the kept count are zero"""
+    from jmodt_amd import synth
+    scores, props = synth.rpn_output(3, 3000, seed=5, empty_far=(1,), empty_near=(2,))
+    boxes, sc = oracle.proposal_select(scores, props, 1000, 50, 0.8)
+    near, far = int(50 * 0.7), 50 - int(50 * 0.7)
+    z = boxes[:, :, 2]
+    assert ((z[0, :near] > 0) & (z[0, :near] <= 40)).all() and ((z[0, near:] > 40) & (z[0, near:] <= 80)).all()
+    assert (z[1] <= 40).all() and (sc[1] != 0).all()          # far band empty: all 50 from the near band
+    assert (sc[2, :far] != 0).all() and not sc[2, far:].any() and not boxes[2, far:].any()
+    for k in range(3):                                          # each band's kept scores descend
+        assert (np.diff(sc[k, :near]) <= 0).all()
+    # frame 1's second slice starts below the first slice's pre-NMS budget in score order
+    order = np.argsort(-scores[1], kind="stable")
+    so = scores[1][order][(props[1][order][:, 2] > 0) & (props[1][order][:, 2] <= 40)]
+    assert sc[1, near] == so[int(1000 * 0.7)]
