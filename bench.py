@@ -87,18 +87,34 @@ def make_sa_inputs(B, seed, dev):
     return xyz, feats
 
 
-def sa_step(xyz, feats, timer):
-    """FPS + dual ball_query + group_points (xyz and features, both scales) over the 4 levels"""
+def sa_step(xyz, feats, timer, overlap=True):
+    """FPS + dual ball_query + group_points (xyz and features, both scales) over the 4 levels.
+    overlap: the FPS chain (coordinates only) runs ahead on a side stream (ops/pointnet2/pyramid.py)
+    while the main stream searches / groups the earlier levels; same kernels, same results."""
     from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
+    from jmodt_amd.ops.pointnet2.pyramid import _side_stream
     B = xyz.shape[0]
-    cur = xyz
+    main = torch.cuda.current_stream()
+    side = _side_stream(xyz.device) if overlap else main
+    levels = []
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        cur = xyz
+        for li, lv in enumerate(SA_LEVELS):
+            n, m = lv["n"], lv["m"]
+            idx = timer.run(f"fps_L{li + 1}", B * m * 20 * n, lambda: pu.farthest_point_sample(cur, m))
+            cur_t = cur.transpose(1, 2).contiguous()
+            new_xyz = timer.run("gather_points", B * (4 * m + 12 * n + 12 * m),
+                                lambda: pu.gather_operation(cur_t, idx)).transpose(1, 2).contiguous()
+            ev = torch.cuda.Event()
+            ev.record(side)
+            levels.append((cur, cur_t, new_xyz, ev))
+            cur = new_xyz
     outs = []
     for li, lv in enumerate(SA_LEVELS):
         n, m, (r0, r1), (ns0, ns1), c = lv["n"], lv["m"], lv["radii"], lv["ns"], lv["c"]
-        idx = timer.run(f"fps_L{li + 1}", B * m * 20 * n, lambda: pu.farthest_point_sample(cur, m))
-        cur_t = cur.transpose(1, 2).contiguous()
-        new_xyz = timer.run("gather_points", B * (4 * m + 12 * n + 12 * m),
-                            lambda: pu.gather_operation(cur_t, idx)).transpose(1, 2).contiguous()
+        cur, cur_t, new_xyz, ev = levels[li]
+        main.wait_event(ev)
         i0, i1 = timer.run(f"ball_query_dual_L{li + 1}", B * (12 * n + 12 * m + 4 * m * (ns0 + ns1)),
                            lambda: pu.ball_query_dual(r0, ns0, r1, ns1, cur, new_xyz))
         for ns, nb in ((ns0, i0), (ns1, i1)):
@@ -107,7 +123,7 @@ def sa_step(xyz, feats, timer):
             if c:
                 outs.append(timer.run(f"group_points_feat_L{li + 1}", B * (4 * m * ns + 4 * c * n + 4 * c * m * ns),
                                       lambda: pu.grouping_operation(feats[li], nb)))
-        cur = new_xyz
+    side.wait_stream(main)   # buffers of this pass are not recycled on the side stream before the main stream is done
     return outs
 
 
@@ -220,6 +236,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run the FPS chain on the main stream (no side stream)")
     ap.add_argument("--workload", default="sa", choices=["sa", "ops"],
                     help="sa = BASELINE configs[1] (default); ops = every other hot-path op at its §8d shape")
     args = ap.parse_args()
@@ -244,7 +261,7 @@ def main():
     timer = KernelTimer()
     if args.workload == "sa":
         xyz, feats = make_sa_inputs(args.batch, 1234 + 1 + rank, dev)
-        step = lambda: sa_step(xyz, feats, timer)  # noqa: E731
+        step = lambda: sa_step(xyz, feats, timer, overlap=not args.no_overlap)  # noqa: E731
     else:
         ops_in = make_ops_inputs(args.batch, 1234 + 2 + rank, dev)
         step = lambda: ops_step(ops_in, timer)  # noqa: E731

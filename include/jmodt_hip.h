@@ -87,10 +87,15 @@ int jm_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out,
  * _PointnetSAModuleBase.forward, pointnet2_modules.py:46-52 = QueryAndGroup + SharedMLP +
  * max_pool2d): out[b, :, m] = max_s relu(W_L ... relu(W_1 [xyz[idx]-new_xyz | feat[idx]] + b_1) ... + b_L).
  * xyz (B,N,3), new_xyz (B,M,3), features (B,C,N) or NULL (C = 0), idx (B,M,nsample) -> out (B, widths[L], M).
- * widths[0] = 3 + C, widths[1..L] = layer outputs (hidden <= 128).  weights[l] is the 1x1 conv weight
- * with eval-mode BatchNorm folded in, zero padded to (pad(widths[l+1]), pad16(widths[l])) row-major with
- * pad = pad16 for hidden layers and pad128 for the last; biases[l] padded likewise.
+ * widths[0] = 3 + C, widths[1..L] = layer outputs (hidden <= 128).  weights[l] / biases[l] are the 1x1
+ * conv weight (widths[l+1], widths[l]) and bias with eval-mode BatchNorm folded in, in the device layout
+ * produced by jm_sa_mlp_pack (k-tile-major, so that one lane's MFMA B operand for a 16-deep k-tile is 8
+ * consecutive floats; zero padded to pad16(widths[l]) x pad128(widths[l+1])).
  * nsample in {16,32,64}, M*nsample % 128 == 0. */
+size_t jm_sa_mlp_packed_weight_elems(int cout, int cin);
+size_t jm_sa_mlp_packed_bias_elems(int cout);
+/* w (cout, cin) row-major and b (cout) or NULL, both on the device -> wp, bp (sizes above) */
+int jm_sa_mlp_pack(int cout, int cin, const float* w, const float* b, float* wp, float* bp, jm_stream_t stream);
 int jm_sa_mlp_forward(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                       const float* features, const int* idx, int num_layers, const int* widths,
                       const float* const* weights, const float* const* biases, float* out, jm_stream_t stream);

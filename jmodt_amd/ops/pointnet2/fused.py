@@ -40,13 +40,62 @@ def fold_shared_mlp(mlp: nn.Sequential) -> Optional[List[Tuple[torch.Tensor, tor
     return layers
 
 
+_shape_cache = {}
+
+
+def _layer_shapes(mlp: nn.Sequential):
+    """[(cout, cin)] if every unit is Conv2d(1x1)[+BN]+ReLU in post-activation order, else None.
+    Structure only (no tensor math), cached per module object."""
+    hit = _shape_cache.get(id(mlp))
+    if hit is not None and hit[0] is mlp:
+        return hit[1]
+    shapes = []
+    for unit in mlp.children():
+        conv = getattr(unit, "conv", None)
+        if (not isinstance(conv, nn.Conv2d) or conv.kernel_size != (1, 1) or getattr(unit, "activation", None) is None
+                or list(unit._modules)[0] != "conv" or hasattr(unit, "in") or not isinstance(unit.activation, nn.ReLU)):
+            shapes = None
+            break
+        shapes.append((conv.out_channels, conv.in_channels))
+    _shape_cache[id(mlp)] = (mlp, shapes)
+    return shapes
+
+
 def can_fuse(mlp: nn.Sequential, npoint: int, nsample: int, training: bool) -> bool:
     if training or nsample not in (16, 32, 64) or (npoint * nsample) % 128:
         return False
-    layers = fold_shared_mlp(mlp)
-    if not layers or len(layers) > 4:
+    shapes = _layer_shapes(mlp)
+    if not shapes or len(shapes) > 4:
         return False
-    return all(W.shape[0] <= 128 for W, _ in layers[:-1]) and layers[0][0].is_cuda
+    if len(shapes) == 1 and shapes[0][1] > 128:
+        return False
+    return all(cout <= 128 for cout, _ in shapes[:-1]) and next(mlp.parameters()).is_cuda
+
+
+_packed_cache = {}
+
+
+def _packed_layers(mlp: nn.Sequential, device):
+    """[(wp, bp, cout, cin)] in the kernel's device layout (jm_sa_mlp_pack), cached per module until a
+    parameter or BatchNorm buffer changes (torch bumps `_version` on every in-place update)."""
+    tensors = [t for t in list(mlp.parameters()) + list(mlp.buffers())]
+    sig = tuple((t.data_ptr(), t._version) for t in tensors) + (str(device),)
+    hit = _packed_cache.get(id(mlp))
+    if hit is not None and hit[0] == sig:
+        return hit[1]
+    lib = L.load()
+    packed = []
+    for W, b in fold_shared_mlp(mlp):
+        W = W.to(device=device, dtype=_f32).contiguous()
+        b = b.to(device=device, dtype=_f32).contiguous()
+        cout, cin = W.shape
+        wp = torch.empty((lib.jm_sa_mlp_packed_weight_elems(cout, cin),), dtype=_f32, device=device)
+        bp = torch.empty((lib.jm_sa_mlp_packed_bias_elems(cout),), dtype=_f32, device=device)
+        L.check(lib.jm_sa_mlp_pack(cout, cin, L.dev(W, _f32, "W"), L.dev(b, _f32, "b"), ctypes.c_void_p(wp.data_ptr()),
+                                   ctypes.c_void_p(bp.data_ptr()), L.stream_ptr()), "sa_mlp_pack")
+        packed.append((wp, bp, cout, cin))
+    _packed_cache[id(mlp)] = (sig, packed, mlp)   # keep `mlp` alive so id() is not recycled
+    return packed
 
 
 @torch.no_grad()
@@ -54,28 +103,18 @@ def sa_mlp_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[to
                  mlp: nn.Sequential) -> torch.Tensor:
     """xyz (B,N,3), new_xyz (B,M,3), features (B,C,N) or None, idx (B,M,ns) int32 -> (B, mlp_out, M)"""
     lib = L.load()
-    layers = fold_shared_mlp(mlp)
+    layers = _packed_layers(mlp, xyz.device)
     B, N, _ = xyz.shape
     M, ns = idx.shape[1], idx.shape[2]
     C = 0 if features is None else features.shape[1]
-    widths = [3 + C] + [W.shape[0] for W, _ in layers]
-    if layers[0][0].shape[1] != widths[0]:
-        raise ValueError(f"SharedMLP expects {layers[0][0].shape[1]} input channels, got 3 + {C}")
+    widths = [3 + C] + [cout for _, _, cout, _ in layers]
+    if layers[0][3] != widths[0]:
+        raise ValueError(f"SharedMLP expects {layers[0][3]} input channels, got 3 + {C}")
     nl = len(layers)
-    keep, wp, bp = [], [], []
-    for l, (W, b) in enumerate(layers):
-        kp = _pad(widths[l], 16)
-        npad = _pad(widths[l + 1], 128 if l == nl - 1 else 16)
-        Wp = torch.zeros((npad, kp), dtype=_f32, device=xyz.device)
-        Wp[: W.shape[0], : W.shape[1]] = W
-        bpad = torch.zeros((npad,), dtype=_f32, device=xyz.device)
-        bpad[: b.shape[0]] = b
-        keep += [Wp, bpad]
-        wp.append(Wp.data_ptr()); bp.append(bpad.data_ptr())
     out = torch.empty((B, widths[-1], M), dtype=_f32, device=xyz.device)
     feats = features.to(_f32).contiguous() if features is not None else None
-    warr = (ctypes.c_void_p * nl)(*wp)
-    barr = (ctypes.c_void_p * nl)(*bp)
+    warr = (ctypes.c_void_p * nl)(*[wp.data_ptr() for wp, _, _, _ in layers])
+    barr = (ctypes.c_void_p * nl)(*[bp.data_ptr() for _, bp, _, _ in layers])
     widths_c = (ctypes.c_int * (nl + 1))(*widths)
     L.check(lib.jm_sa_mlp_forward(B, N, M, C, ns, L.dev(xyz.contiguous(), _f32, "xyz"),
                                   L.dev(new_xyz.contiguous(), _f32, "new_xyz"),

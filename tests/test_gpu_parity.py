@@ -425,6 +425,9 @@ def _randomise_bn(module, seed):
     (512, 128, 128, [2.0], [64], [[128, 128, 128, 128]], True),                              # RCNN SA1 (config.py:137)
     (512, 128, 128, [2.0], [64], [[128, 128, 128, 256]], True),                              # last layer wider than a tile
     (700, 64, 5, [3.0], [32], [[5, 24, 40]], False),                                         # 2 layers, odd widths, no BN
+    (600, 64, 300, [2.5], [32], [[300, 64, 96, 200]], True),                                 # 3 input chunks (303 channels)
+    (600, 128, 253, [2.5], [16], [[253, 128, 128]], True),                                   # exactly 2 full chunks
+    (512, 64, 40, [2.5], [64], [[40, 72]], True),                                            # single layer
 ])
 def test_fused_sa_block_matches_unfused(N, npoint, C, radii, nsamples, mlps, bn):
     """fused kernel (eval, no-grad) vs the same module on the unfused path (HIP group ops + torch
@@ -445,6 +448,23 @@ def test_fused_sa_block_matches_unfused(N, npoint, C, radii, nsamples, mlps, bn)
     scale = f2.abs().max().item()
     assert scale > 0.1
     assert (f1 - f2).abs().max().item() <= 1e-4 * max(scale, 1.0), (f1 - f2).abs().max().item()
+
+
+def test_fused_sa_block_repacks_after_weight_update():
+    """the packed-weight cache follows in-place parameter updates (optimizer steps, load_state_dict)"""
+    from jmodt_amd.ops.pointnet2.pointnet2_modules import PointnetSAModuleMSG
+    torch.manual_seed(4)
+    sa = PointnetSAModuleMSG(npoint=64, radii=[1.5], nsamples=[32], mlps=[[8, 32, 48]]).to(DEV).eval()
+    xyz, feats = T(synth.dense_cloud(1, 400, 19, extent=5.0)), torch.randn(1, 8, 400, device=DEV)
+    with torch.no_grad():
+        a = sa(xyz, feats)[1].clone()
+        for prm in sa.parameters():
+            prm.mul_(1.5)
+        b = sa(xyz, feats)[1]
+        sa.fuse = False
+        c = sa(xyz, feats)[1]
+    assert (a - b).abs().max().item() > 1e-3
+    assert (b - c).abs().max().item() <= 1e-4 * max(c.abs().max().item(), 1.0)
 
 
 def test_fused_sa_block_is_used_and_falls_back():
@@ -518,3 +538,23 @@ def test_proposal_select_score_based(oracle):
     got_b, got_s = score_based_proposal(T(scores), T(props), 1500, 100, 0.8)
     want_b, want_s = oracle.proposal_select(scores, props, 1500, 100, 0.8, distance_based=False)
     assert np.array_equal(got_s.cpu().numpy(), want_s) and np.array_equal(got_b.cpu().numpy(), want_b)
+
+
+def test_fps_pyramid_side_stream_matches_sequential(oracle):
+    """the FPS chain run ahead on a side stream hands the main stream the same indices / centres"""
+    from jmodt_amd.ops.pointnet2.pyramid import FpsPyramid
+    from jmodt_amd.ops.pointnet2.pointnet2_utils import ball_query
+    xyz = synth.cloud(3, 4096, seed=41)
+    t = T(xyz)
+    for _ in range(3):   # repeated use recycles the side-stream buffers
+        pyr = FpsPyramid(t, [1024, 256, 64])
+        cur = xyz
+        for k, m in enumerate((1024, 256, 64)):
+            idx, new_xyz = pyr.level(k)
+            nb = ball_query(0.8, 16, T(cur), new_xyz)           # a main-stream consumer
+            want = oracle.furthest_point_sample(cur, m)
+            assert np.array_equal(idx.cpu().numpy(), want)
+            nxt = np.take_along_axis(cur, want[..., None].astype(np.int64), axis=1)
+            assert np.array_equal(new_xyz.cpu().numpy(), nxt)
+            assert np.array_equal(nb.cpu().numpy(), oracle.ball_query(0.8, 16, cur, nxt))
+            cur = nxt
