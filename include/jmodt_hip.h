@@ -92,10 +92,13 @@ int jm_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out,
  * produced by jm_sa_mlp_pack (k-tile-major, so that one lane's MFMA B operand for a 16-deep k-tile is 8
  * consecutive floats; zero padded to pad16(widths[l]) x pad128(widths[l+1])).
  * nsample in {16,32,64}, M*nsample % 128 == 0. */
-size_t jm_sa_mlp_packed_weight_elems(int cout, int cin);
+size_t jm_sa_mlp_packed_weight_elems(int cout, int cin, int first_layer);
 size_t jm_sa_mlp_packed_bias_elems(int cout);
-/* w (cout, cin) row-major and b (cout) or NULL, both on the device -> wp, bp (sizes above) */
-int jm_sa_mlp_pack(int cout, int cin, const float* w, const float* b, float* wp, float* bp, jm_stream_t stream);
+/* w (cout, cin) row-major and b (cout) or NULL, both on the device -> wp, bp (sizes above).
+ * first_layer != 0 for layer 0, whose cin = 3 + C input channels are QueryAndGroup's [xyz | features]
+ * (pointnet2_utils.py:258-262): the kernel consumes them as [features | xyz], each part padded to 16. */
+int jm_sa_mlp_pack(int cout, int cin, int first_layer, const float* w, const float* b, float* wp, float* bp,
+                   jm_stream_t stream);
 int jm_sa_mlp_forward(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                       const float* features, const int* idx, int num_layers, const int* widths,
                       const float* const* weights, const float* const* biases, float* out, jm_stream_t stream);

@@ -40,9 +40,9 @@ SIGNATURES = {
     "jm_three_nn": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "jm_three_interpolate": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "jm_three_interpolate_grad": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P]),
-    "jm_sa_mlp_packed_weight_elems": (_Z, [_I, _I]),
+    "jm_sa_mlp_packed_weight_elems": (_Z, [_I, _I, _I]),
     "jm_sa_mlp_packed_bias_elems": (_Z, [_I]),
-    "jm_sa_mlp_pack": (_I, [_I, _I, _P, _P, _P, _P, _P]),
+    "jm_sa_mlp_pack": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "jm_sa_mlp_forward": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, ctypes.POINTER(_I), ctypes.POINTER(_P),
                                ctypes.POINTER(_P), _P, _P]),
     "jm_roipool3d_forward": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),

@@ -8,16 +8,25 @@
 // For the RCNN's first SA level that grouped tensor alone is 4.4 GB per 1024 RoIs;
 // here neither it nor any hidden activation ever leaves the chip.
 //
-// One workgroup (4 waves, one per SIMD) = 128 consecutive (centre, sample) rows of one frame.
-//   * Activations live in two 128(k) x 128(row) LDS buffers, k-major, used in ping-pong: a layer reads
-//     its A operand straight from one and its epilogue (bias + ReLU) writes the other with 16-byte
-//     stores in the MFMA accumulator's own row order.  Layer 1's input is gathered through idx into a
-//     buffer in chunks of 128 channels (first 3 channels = xyz - centre).
-//   * Weights never touch LDS: they are pre-packed (jm_sa_mlp_pack) so that the B operand of lane
-//     (col, khalf) for one 16-deep k-tile is 8 consecutive floats -> two global_load_dwordx4 per
-//     32-column block per k-tile, coalesced over the wave, served by L1/L2 (a layer is <= 64 KB and
-//     every workgroup reads the same one), prefetched one k-tile ahead in registers.
-//   * Hence the k-loops contain NO barrier: one __syncthreads() per layer.
+// Persistent workgroups (one per CU), each walking over tiles of 128 consecutive (centre, sample) rows,
+// split into two roles (wave specialisation):
+//   * waves 0-3, one per SIMD, do nothing but MFMA + epilogues.  Activations live in two
+//     144(k) x 128(row) LDS buffers, k-major, used in ping-pong: a layer reads its A operand straight
+//     from one and its epilogue (bias + ReLU) writes the other with 16-byte stores in the accumulator's
+//     own row order.  Weights never touch LDS: they are pre-packed (jm_sa_mlp_pack) so that the B
+//     operand of lane (col, khalf) for one 16-deep k-tile is 8 consecutive floats -> two
+//     global_load_dwordx4 per 32-column block per k-tile, coalesced over the wave, served by L1/L2
+//     (a layer is <= 64 KB and every workgroup reads the same one), prefetched one k-tile ahead in
+//     registers; the last prefetch of a stage fetches the NEXT stage's first operand, so no stage
+//     starts on a cold load and the k-loops contain no barrier.
+//   * waves 4-7 gather: layer 1's input (first 3 channels = xyz - centre, then the point features
+//     through idx) in chunks of 144 channels — chunk c+1 while chunk c is being multiplied, and the next
+//     tile's first chunk during the current tile's later layers (its loads are in flight for two layers
+//     before they are parked in the buffer that has just become free).  The gather's long scattered-load
+//     latencies and its vmcnt waits therefore never touch the MFMA waves.
+//   Both roles execute the same sequence of workgroup barriers (one per stage).
+//   * Whole frames per XCD when there are enough of them: a frame's features are then pulled into one
+//     L2 instead of all eight.
 //   * Last layer: any width (128-column tiles); its epilogue reduces max over each centre's nsample
 //     rows straight out of the accumulator layout, then bias + ReLU (both commute with max).
 // v_mfma_f32_32x32x2_f32 everywhere: exact-f32 products (1e-4 parity with the fp32 reference path).
@@ -29,7 +38,8 @@ namespace jm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int SM_BM = 128, SM_KC = 128, SM_LDP = SM_BM + 4;
+constexpr int SM_BM = 128, SM_KC = 144, SM_LDP = SM_BM + 4;   // 144: 3 + 128 channels (both RCNN SA levels) in one chunk
+constexpr int SM_GRP = SM_KC / 16;                     // gather groups (16 channels each) per chunk
 constexpr int SM_BUF = SM_KC * SM_LDP;                 // floats per activation buffer
 constexpr size_t SM_LDS_BYTES = 2 * (size_t)SM_BUF * sizeof(float);
 
@@ -48,35 +58,202 @@ struct SaMlpParams {
     const float* bias[4];            // (np[l]) zero padded
     float* out;                      // (B, cout, M)
     int cout;
+    int tiles_per_frame, total_tiles, xcd_frames;
 };
 
-// packed layout: Wp[kt][n][khalf][kk] = W[n][16 kt + 2 kk + khalf]   (kt < Kp/16, n < Np, khalf < 2, kk < 8)
-__global__ void sa_mlp_pack_kernel(int cout, int cin, int Kp, int Np, const float* __restrict__ w,
+// packed layout: Wp[kt][n][khalf][kk] = W'[n][16 kt + 2 kk + khalf]   (kt < Kp/16, n < Np, khalf < 2, kk < 8)
+// W' = W zero padded, except for the FIRST layer, whose input channels [xyz(3) | C features]
+// (QueryAndGroup's cat order, pointnet2_utils.py:258-262) are reordered to
+//     [C features | zeros to pad16(C) | xyz(3) | zeros to +16]
+// so that the gather works in whole 16-channel groups of plain feature rows, with xyz in a group of its own.
+__host__ __device__ inline int sa_first_kp(int cin) { return pad_to(cin - 3, 16) + 16; }
+
+__global__ void sa_mlp_pack_kernel(int cout, int cin, int Kp, int Np, int first, const float* __restrict__ w,
                                    const float* __restrict__ b, float* __restrict__ wp, float* __restrict__ bp) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < Np) bp[e] = (e < cout && b) ? b[e] : 0.f;
     if (e >= Kp * Np) return;
     const int kk = e & 7, kh = (e >> 3) & 1, n = (e >> 4) % Np, kt = (e >> 4) / Np;
     const int k = 16 * kt + 2 * kk + kh;
-    wp[e] = (n < cout && k < cin) ? w[(size_t)n * cin + k] : 0.f;
+    int src = k;                                  // column of the unpacked weight, or -1 for padding
+    if (first) {
+        const int C = cin - 3, Cp = pad_to(C, 16);
+        src = k < C ? 3 + k : ((k >= Cp && k < Cp + 3) ? k - Cp : -1);
+    } else if (k >= cin) {
+        src = -1;
+    }
+    wp[e] = (n < cout && src >= 0) ? w[(size_t)n * cin + src] : 0.f;
 }
 
-// acc += A(128 rows x 16 nkt, LDS k-major) x W-tile; this wave owns rows wm*64.., columns ncol0.. (+32 if two)
-//   A : LDS buffer [k][SM_LDP], rows of this tile
-//   bp: packed weights of this lane for k-tile 0 of the range, column block 0; kt_stride floats per k-tile
+// ---- persistent tile schedule, shared by both roles.  xcd_frames: workgroup b runs on XCD b % 8
+// (round-robin dispatch), so every XCD gets whole frames; otherwise tiles are dealt out linearly.
+struct SaSchedule {
+    int n_local;
+    int xcd, slot, per, nwg, tpf, mode;
+    __device__ SaSchedule(const SaMlpParams& p) {
+        nwg = gridDim.x; tpf = p.tiles_per_frame; mode = p.xcd_frames;
+        xcd = blockIdx.x & 7; slot = blockIdx.x >> 3; per = nwg >> 3;
+        if (mode) {
+            const int nb = p.total_tiles / tpf;
+            const int local_tiles = ((nb - xcd + 7) >> 3) * tpf;
+            n_local = local_tiles > slot ? (local_tiles - slot + per - 1) / per : 0;
+        } else {
+            n_local = p.total_tiles > (int)blockIdx.x ? (p.total_tiles - (int)blockIdx.x + nwg - 1) / nwg : 0;
+        }
+    }
+    __device__ void tile(int i, int& bi, int& row0) const {
+        if (mode) {
+            const int lt = slot + i * per;
+            bi = xcd + 8 * (lt / tpf);
+            row0 = (lt % tpf) * SM_BM;
+        } else {
+            const int t = blockIdx.x + i * nwg;
+            bi = t / tpf;
+            row0 = (t % tpf) * SM_BM;
+        }
+    }
+};
+
+// =============================================================================== gather role
+// 256 threads: thread fills row `grow` of the tile, channels gk0, gk0 + 2, ... of a chunk.  gk0 is
+// wave-uniform: with it in an SGPR every channel index, base pointer and padding test is scalar and the
+// gathers use the saddr + 32-bit-offset form (no per-element address VGPRs).
+struct SaRow {
+    int gidx;            // this thread's neighbour index
+    float cx, cy, cz;    // its centre (named fields: a runtime-indexed array would live in scratch)
+    int bi;
+};
+
+__device__ __forceinline__ void sa_gather_role(const SaMlpParams& p, float* lds, int ltid) {
+    const SaSchedule sch(p);
+    if (sch.n_local == 0) return;
+    const int grow = ltid & 127, gk0 = __builtin_amdgcn_readfirstlane(ltid >> 7);
+    const int K0 = p.kp[0];
+    const int nchunks = (K0 + SM_KC - 1) / SM_KC;
+    const bool single = (p.L == 1);
+    // first-layer channel order (see sa_mlp_pack_kernel): nfast whole groups of features, an optional
+    // partial feature group (index nfast), then the xyz group (index gxyz = pad16(C)/16, the last one)
+    const int C = p.C, nfast = C >> 4, gxyz = (C + 15) >> 4;
+    const bool has_tail = (C & 15) != 0;
+
+    auto load_row = [&](int i) {
+        SaRow t;
+        int row0;
+        sch.tile(i, t.bi, row0);
+        t.gidx = p.idx[(size_t)t.bi * p.M * p.ns + row0 + grow];
+        const float* cp = p.new_xyz + ((size_t)t.bi * p.M + (row0 + grow) / p.ns) * 3;
+        t.cx = cp[0]; t.cy = cp[1]; t.cz = cp[2];
+        return t;
+    };
+    float g[8 * SM_GRP];   // one chunk in flight: SM_KC channels x 128 rows / 256 threads
+    float gt[8], gx[2];    // the partial feature group and the xyz group of this thread
+    // A whole feature group is the lean path: one scalar base pointer, 8 loads / 8 ds_writes and nothing per
+    // element in between.  This matters: the wave shares its SIMD with an MFMA wave and gets few issue slots.
+    auto issue = [&](const SaRow& t, int c) {
+        const float* xyz_b = p.xyz + (size_t)t.bi * p.N * 3;
+        const float* feat_b = p.feat ? p.feat + (size_t)t.bi * C * p.N : xyz_b;   // never dereferenced when C == 0
+        const unsigned off_f = (unsigned)t.gidx;
+        const size_t two_n = 2 * (size_t)p.N;
+        const int g0 = c * SM_GRP;                           // first group of the chunk
+        const float* cb = feat_b + ((size_t)g0 * 16 + gk0) * p.N;
+#pragma unroll
+        for (int grp = 0; grp < SM_GRP; ++grp) {
+            if (g0 + grp < nfast) {                          // uniform
+                const float* rp = cb + (size_t)grp * 16 * p.N;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[grp * 8 + j] = rp[j * two_n + off_f];
+                // one group's scalar base pointers at a time (left alone, the scheduler forms all of them first
+                // and spills SGPRs into VGPR lanes, which costs VALU slots on the MFMA wave's SIMD)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (has_tail && nfast >= g0 && nfast < g0 + SM_GRP) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kcl = min(nfast * 16 + gk0 + 2 * j, C - 1);      // unconditional load, clamped address
+                gt[j] = feat_b[(size_t)kcl * p.N + off_f];
+            }
+        }
+        if (gxyz >= g0 && gxyz < g0 + SM_GRP) {
+            const float* q = xyz_b + (size_t)t.gidx * 3;
+            gx[0] = q[gk0];                                  // x (gk0 = 0) or y (gk0 = 1)
+            gx[1] = q[2];                                    // z, used by gk0 = 0 only
+        }
+    };
+    auto store = [&](const SaRow& t, int c, float* G) {   // centre subtraction / zero padding happen here
+        float* Gt = G + gk0 * SM_LDP + grow;                 // element i of this thread: + 2 i SM_LDP
+        const int g0 = c * SM_GRP;
+#pragma unroll
+        for (int grp = 0; grp < SM_GRP; ++grp) {
+            if (g0 + grp < nfast) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Gt[2 * (grp * 8 + j) * SM_LDP] = g[grp * 8 + j];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (has_tail && nfast >= g0 && nfast < g0 + SM_GRP) {
+            float* Gq = Gt + (size_t)(nfast - g0) * 16 * SM_LDP;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Gq[2 * j * SM_LDP] = (nfast * 16 + gk0 + 2 * j < C) ? gt[j] : 0.f;
+        }
+        if (gxyz >= g0 && gxyz < g0 + SM_GRP) {
+            float* Gq = Gt + (size_t)(gxyz - g0) * 16 * SM_LDP;
+            Gq[0] = gx[0] - (gk0 == 0 ? t.cx : t.cy);
+            Gq[2 * SM_LDP] = gk0 == 0 ? gx[1] - t.cz : 0.f;
+#pragma unroll
+            for (int j = 2; j < 8; ++j) Gq[2 * j * SM_LDP] = 0.f;
+        }
+    };
+
+    SaRow ct = load_row(0);
+    issue(ct, 0);
+    store(ct, 0, lds);
+    lds_barrier();                                                   // B0: chunk 0 of the first tile published
+    int cur = 0;
+    for (int it = 0; it < sch.n_local; ++it) {
+        const bool has_next = it + 1 < sch.n_local;
+        const SaRow nt = load_row(has_next ? it + 1 : it);
+        if (!single) {
+            for (int c = 0; c + 1 < nchunks; ++c) {                  // chunk c+1 while chunk c is multiplied
+                issue(ct, c + 1);
+                store(ct, c + 1, lds + (cur ^ 1) * SM_BUF);
+                lds_barrier();
+                cur ^= 1;
+            }
+        }
+        if (single) {
+            if (has_next) issue(nt, 0);
+        } else {
+            lds_barrier(); cur ^= 1;                                 // first hidden epilogue's barrier
+            if (has_next) issue(nt, 0);
+            for (int l = 1; l < p.L - 1; ++l) { lds_barrier(); cur ^= 1; }   // the other hidden epilogues' barriers
+        }
+        if (has_next) {
+            store(nt, 0, lds + (cur ^ 1) * SM_BUF);                  // the buffer the last layer does not read
+            lds_barrier();
+            cur ^= 1;
+        }
+        ct = nt;
+    }
+}
+
+// =============================================================================== MFMA role
+// acc += A(128 rows x 16 nkt, LDS k-major) x W-tile; this wave owns rows wm*64.., columns of bp (+32 if TWO)
+//   A      : LDS buffer [k][SM_LDP]
+//   bp     : this lane's packed weights for k-tile 0 of the range; kt_stride floats per k-tile
+//   bpre   : in  = k-tile 0's B operand, already loaded by the previous stage;
+//            out = the first B operand of the NEXT stage (next_bp)
 template <bool TWO>
 __device__ __forceinline__ void mfma_ktiles(const float* __restrict__ A, int nkt, const float* __restrict__ bp,
-                                            size_t kt_stride, int a_off, f32x16 (&acc)[2][2]) {
+                                            size_t kt_stride, int a_off, f32x16 (&acc)[2][2], float4 (&bpre)[4],
+                                            const float* __restrict__ next_bp) {
     float4 bc[4], bn[4];
     float ac[16], an[16];
-    auto loadB = [&](float4 (&b)[4], int kt) {
-        const float* q = bp + (size_t)kt * kt_stride;
+    auto loadB = [&](float4 (&b)[4], const float* q) {
         b[0] = *reinterpret_cast<const float4*>(q);
         b[1] = *reinterpret_cast<const float4*>(q + 4);
-        if (TWO) {
-            b[2] = *reinterpret_cast<const float4*>(q + 512);       // column + 32: (32 * 2) * 8 floats on
-            b[3] = *reinterpret_cast<const float4*>(q + 516);
-        }
+        b[2] = *reinterpret_cast<const float4*>(q + 512);       // column + 32: (32 * 2) * 8 floats on
+        b[3] = *reinterpret_cast<const float4*>(q + 516);
     };
     auto loadA = [&](float (&a)[16], int kt) {
         const float* q = A + (size_t)kt * 16 * SM_LDP + a_off;       // a_off = khalf * SM_LDP + wm * 64 + lr
@@ -101,226 +278,231 @@ __device__ __forceinline__ void mfma_ktiles(const float* __restrict__ A, int nkt
     };
     // sched_barrier(0): keep the prefetches where they are written — left alone, the scheduler sinks
     // them to their first use and the L2 latency lands on the MFMA pipe
-    loadB(bc, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bc[q] = bpre[q];
     loadA(ac, 0);
     int kt = 0;
     for (; kt + 2 <= nkt; kt += 2) {
-        loadB(bn, kt + 1);
+        loadB(bn, bp + (size_t)(kt + 1) * kt_stride);
         loadA(an, kt + 1);
         __builtin_amdgcn_sched_barrier(0);
         mm(ac, bc);
         __builtin_amdgcn_sched_barrier(0);
-        const int nx = min(kt + 2, nkt - 1);    // clamped: unconditional loads, no branchy waits
-        loadB(bc, nx);
-        loadA(ac, nx);
+        // the k-tile after next — or, on the last trip, the NEXT stage's first B operand;
+        // unconditional loads on a selected address, no branchy waits
+        const bool more = kt + 2 < nkt;
+        loadB(bc, more ? bp + (size_t)(kt + 2) * kt_stride : next_bp);
+        loadA(ac, more ? kt + 2 : kt);
         __builtin_amdgcn_sched_barrier(0);
         mm(an, bn);
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (kt < nkt) mm(ac, bc);
+    if (kt < nkt) {            // odd tail: bc / ac hold k-tile nkt-1
+        loadB(bpre, next_bp);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ac, bc);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bpre[q] = bc[q];
+    }
 }
 
-__global__ void __launch_bounds__(256)
-sa_mlp_kernel(SaMlpParams p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
+__device__ __forceinline__ void sa_mfma_role(const SaMlpParams& p, float* lds, int tid) {
+    const SaSchedule sch(p);
+    if (sch.n_local == 0) return;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lk = lane >> 5;
-    const int bi = blockIdx.y;
-    const int row0 = blockIdx.x * SM_BM;            // first (centre, sample) row of this tile
-
-    // gather identity: this thread fills row `grow`, channels gk0, gk0 + 2, ... of every chunk
-    const int grow = tid & 127, gk0 = tid >> 7;
-    const int gidx = p.idx[(size_t)bi * p.M * p.ns + row0 + grow];
-    float cen[3];
-    {
-        const int m = (row0 + grow) / p.ns;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) cen[q] = p.new_xyz[((size_t)bi * p.M + m) * 3 + q];
-    }
-    const float* xyz_b = p.xyz + (size_t)bi * p.N * 3;
-    const float* feat_b = p.feat ? p.feat + (size_t)bi * p.C * p.N : xyz_b;   // never dereferenced when C == 0
-    const int c_in = 3 + p.C;
     const int a_off = lk * SM_LDP + wm * 64 + lr;
-
-    f32x16 acc[2][2];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    };
-    // lane's packed-weight pointer: layer l, k-tile kt0, column n
-    auto wptr = [&](int l, int kt0, int n) {
-        return p.W[l] + ((size_t)kt0 * p.np[l] + n) * 16 + lk * 8;
-    };
-    auto run = [&](const float* A, int nkt, int l, int kt0, int ncol0, int ncols) {
-        // ncols: valid (padded-to-16) columns from ncol0 on; a wave without columns idles
-        if (ncols <= 0) return;
-        const float* bp = wptr(l, kt0, ncol0 + lr);
-        const size_t st = (size_t)p.np[l] * 16;
-        if (ncols > 32) mfma_ktiles<true>(A, nkt, bp, st, a_off, acc);
-        else mfma_ktiles<false>(A, nkt, bp, st, a_off, acc);
-    };
-
-    int cur = 0;   // buffer the next consumer reads
-    // ---------------- layer 1: gather chunks of <= 128 input channels, accumulate over chunks
     const bool single = (p.L == 1);
+    const int L = p.L;
+    auto KP = [&](int i) { return p.kp[i]; };
+    auto NP = [&](int i) { return p.np[i]; };
+    auto WW = [&](int i) { return p.W[i]; };
+    auto BS = [&](int i) { return p.bias[i]; };
+    const int kp1 = p.kp[1];
+    const float* bs0 = p.bias[0];
     const int K0 = p.kp[0];
     const int nchunks = (K0 + SM_KC - 1) / SM_KC;
-    if (!single) zero_acc();
-    for (int c = 0; c < nchunks; ++c) {
-        const int kc = min(SM_KC, K0 - c * SM_KC);     // multiple of 16
-        float* G = lds + (c & 1) * SM_BUF;
-        if (c >= 2) __syncthreads();                   // the chunk two back has been consumed by every wave
-        auto src = [&](int k) {                        // unconditional load on a clamped address
-            const int kcl = min(k, c_in - 1);
-            return kcl < 3 ? xyz_b + (size_t)gidx * 3 + kcl : feat_b + (size_t)(kcl - 3) * p.N + gidx;
-        };
-        auto fix = [&](float v, int k) {               // centre subtraction / zero padding
-            if (k < 3) v = v - cen[k];
-            return k >= c_in ? 0.f : v;
-        };
-        if (kc == SM_KC) {                             // full chunk: all 64 loads of this thread in flight
-            float g[64];
-#pragma unroll
-            for (int i = 0; i < 64; ++i) g[i] = *src(c * SM_KC + gk0 + 2 * i);
-#pragma unroll
-            for (int i = 0; i < 64; ++i) G[(gk0 + 2 * i) * SM_LDP + grow] = fix(g[i], c * SM_KC + gk0 + 2 * i);
-        } else {                                       // tail chunk: 16 channels (8 loads) per trip
-            for (int kb = 0; kb < kc; kb += 16) {
-                float g[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) g[i] = *src(c * SM_KC + kb + gk0 + 2 * i);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    G[(kb + gk0 + 2 * i) * SM_LDP + grow] = fix(g[i], c * SM_KC + kb + gk0 + 2 * i);
-            }
-        }
-        __syncthreads();
-        if (!single) run(G, kc / 16, 0, c * (SM_KC / 16), wn * 64, p.kp[1] - wn * 64);
-        cur = c & 1;
-    }
 
+    f32x16 acc[2][2];
+    // accumulators start at the layer's bias (the epilogues then only clamp): columns ncol0 + 32 j + lr
+    auto init_acc = [&](const float* bl, int ncol0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float bv = bl[ncol0 + j * 32 + lr];          // biases are zero padded to np (multiple of 128)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+        }
+    };
+    // this lane's packed-weight pointer: layer l, k-tile kt0, column block starting at ncol0
+    auto wptr = [&](int l, int kt0, int ncol0) {
+        return WW(l) + ((size_t)kt0 * NP(l) + ncol0 + lr) * 16 + lk * 8;
+    };
+    float4 bpre[4];
+    auto preload = [&](const float* q) {
+        bpre[0] = *reinterpret_cast<const float4*>(q);
+        bpre[1] = *reinterpret_cast<const float4*>(q + 4);
+        bpre[2] = *reinterpret_cast<const float4*>(q + 512);
+        bpre[3] = *reinterpret_cast<const float4*>(q + 516);
+    };
+    // ncols: valid (padded-to-16) columns from ncol0 on; a wave without columns idles but keeps the
+    // preload chain going
+    auto run = [&](const float* A, int nkt, int l, int kt0, int ncol0, int ncols, const float* next_bp) {
+        if (ncols <= 0) { preload(next_bp); return; }
+        const float* bp = wptr(l, kt0, ncol0);
+        const size_t st = (size_t)NP(l) * 16;
+        if (ncols > 32) mfma_ktiles<true>(A, nkt, bp, st, a_off, acc, bpre, next_bp);
+        else mfma_ktiles<false>(A, nkt, bp, st, a_off, acc, bpre, next_bp);
+    };
     auto hidden_epilogue = [&](int l, float* Y) {
-        const float* bl = p.bias[l];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = wn * 64 + j * 32 + lr;
-            if (wn * 64 + j * 32 >= p.kp[l + 1]) continue;     // wave-uniform: columns the next layer never reads
-            const float bv = bl[col];
+            if (wn * 64 + j * 32 >= KP(l + 1)) continue;     // wave-uniform: columns the next layer never reads
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
                     // accumulator r = 4 rq + t  <->  row 8 rq + 4 lk + t of the 32-row block: 4 consecutive rows
                     float4 v;
-                    v.x = fmaxf(acc[i][j][4 * rq + 0] + bv, 0.f); v.y = fmaxf(acc[i][j][4 * rq + 1] + bv, 0.f);
-                    v.z = fmaxf(acc[i][j][4 * rq + 2] + bv, 0.f); v.w = fmaxf(acc[i][j][4 * rq + 3] + bv, 0.f);
+                    v.x = fmaxf(acc[i][j][4 * rq + 0], 0.f); v.y = fmaxf(acc[i][j][4 * rq + 1], 0.f);
+                    v.z = fmaxf(acc[i][j][4 * rq + 2], 0.f); v.w = fmaxf(acc[i][j][4 * rq + 3], 0.f);
                     *reinterpret_cast<float4*>(Y + (size_t)col * SM_LDP + wm * 64 + i * 32 + 8 * rq + 4 * lk) = v;
                 }
         }
     };
 
-    int l = 0;
-    if (!single) {
-        // layer 1 epilogue -> the buffer the last chunk did not use (its readers finished before the
-        // barrier that preceded the last chunk's MFMAs)
-        float* Y = lds + ((cur ^ 1)) * SM_BUF;
-        hidden_epilogue(0, Y);
-        __syncthreads();
-        cur ^= 1;
-        // ---------------- hidden layers 2 .. L-1
-        for (l = 1; l < p.L - 1; ++l) {
-            zero_acc();
-            run(lds + cur * SM_BUF, p.kp[l] / 16, l, 0, wn * 64, p.kp[l + 1] - wn * 64);
-            hidden_epilogue(l, lds + (cur ^ 1) * SM_BUF);
-            __syncthreads();
+    preload(wptr(0, 0, wn * 64));
+    init_acc(bs0, wn * 64);
+    lds_barrier();                                                   // B0
+    int cur = 0;   // buffer the next consumer reads
+    for (int it = 0; it < sch.n_local; ++it) {
+        const bool has_next = it + 1 < sch.n_local;
+        int bi, row0;
+        sch.tile(it, bi, row0);
+        int l = 0;
+        if (!single) {
+            // ---------------- layer 1: chunks of <= 128 input channels (the gather waves stay one chunk ahead)
+            for (int c = 0; c < nchunks; ++c) {
+                const int kc = min(SM_KC, K0 - c * SM_KC);     // multiple of 16
+                const bool more = c + 1 < nchunks;
+                run(lds + cur * SM_BUF, kc / 16, 0, c * (SM_KC / 16), wn * 64, kp1 - wn * 64,
+                    more ? wptr(0, (c + 1) * (SM_KC / 16), wn * 64) : wptr(1, 0, wn * 64));
+                if (more) { lds_barrier(); cur ^= 1; }
+            }
+            // the other buffer held chunk nchunks-2 (or the previous tile's last input): every wave left it
+            // before the last barrier
+            hidden_epilogue(0, lds + (cur ^ 1) * SM_BUF);
+            init_acc(BS(1), wn * 64);                          // next layer's bias, set while waiting
+            lds_barrier();
             cur ^= 1;
-        }
-    }
-    // ---------------- last layer: 128-column tiles, max-pool epilogue  (l == L - 1)
-    {
-        const float* A = lds + cur * SM_BUF;
-        const int nkt = single ? K0 / 16 : p.kp[l] / 16;   // single: host guarantees one chunk
-        const float* bl = p.bias[l];
-        for (int n0 = 0; n0 < p.np[l]; n0 += 128) {
-            zero_acc();
-            run(A, nkt, l, 0, n0 + wn * 64, p.kp[l + 1] - (n0 + wn * 64));
-            // max over each centre's nsample rows, straight from the accumulator layout
-            // row(i, r, lk) = 32 i + (r & 3) + 8 (r >> 2) + 4 lk  within this wave's 64 rows
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + wn * 64 + j * 32 + lr;
-                if (n0 + wn * 64 + j * 32 >= p.cout) continue;   // wave-uniform
-                const float bv = bl[col];
-                float v[4];   // up to 4 centres per wave (nsample 16)
-                if (p.ns == 64) {
-                    float t = -INFINITY;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) t = fmaxf(t, acc[i][j][r]);
-                    v[0] = t; v[1] = v[2] = v[3] = -INFINITY;
-                } else if (p.ns == 32) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        float t = -INFINITY;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) t = fmaxf(t, acc[i][j][r]);
-                        v[i] = t;
-                    }
-                    v[2] = v[3] = -INFINITY;
-                } else {   // 16: rows 0-15 of a 32-block are r < 8, rows 16-31 are r >= 8
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        float t0 = -INFINITY, t1 = -INFINITY;
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) { t0 = fmaxf(t0, acc[i][j][r]); t1 = fmaxf(t1, acc[i][j][r + 8]); }
-                        v[2 * i] = t0; v[2 * i + 1] = t1;
-                    }
-                }
-                const int per_wave = 64 / p.ns;   // centres per wave-row-block
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (c < per_wave) {
-                        float t = fmaxf(v[c], __shfl_xor(v[c], 32));   // the other lane half holds the rows + 4
-                        const int m = (row0 + wm * 64) / p.ns + c;
-                        if (lk == 0 && col < p.cout)
-                            p.out[((size_t)bi * p.cout + col) * p.M + m] = fmaxf(t + bv, 0.f);
-                    }
-                }
+            // ---------------- hidden layers 2 .. L-1
+            for (l = 1; l < L - 1; ++l) {
+                run(lds + cur * SM_BUF, KP(l) / 16, l, 0, wn * 64, KP(l + 1) - wn * 64, wptr(l + 1, 0, wn * 64));
+                hidden_epilogue(l, lds + (cur ^ 1) * SM_BUF);
+                init_acc(BS(l + 1), wn * 64);
+                lds_barrier();
+                cur ^= 1;
             }
         }
+        // ---------------- last layer (l == L - 1): 128-column tiles, max-pool epilogue
+        {
+            const float* A = lds + cur * SM_BUF;
+            const int nkt = KP(l) / 16;                        // single: host guarantees one chunk
+            const float* bl = BS(l);
+            const int npl = NP(l), kpl1 = KP(l + 1);
+            for (int n0 = 0; n0 < npl; n0 += 128) {
+                const bool last_n = n0 + 128 >= npl;
+                run(A, nkt, l, 0, n0 + wn * 64, kpl1 - (n0 + wn * 64),
+                    last_n ? wptr(0, 0, wn * 64) : wptr(l, 0, n0 + 128 + wn * 64));
+                // max over each centre's nsample rows, straight from the accumulator layout
+                // row(i, r, lk) = 32 i + (r & 3) + 8 (r >> 2) + 4 lk  within this wave's 64 rows
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = n0 + wn * 64 + j * 32 + lr;
+                    if (n0 + wn * 64 + j * 32 >= p.cout) continue;   // wave-uniform
+                    float v[4];   // up to 4 centres per wave (nsample 16)
+                    if (p.ns == 64) {
+                        float t = -INFINITY;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) t = fmaxf(t, acc[i][j][r]);
+                        v[0] = t; v[1] = v[2] = v[3] = -INFINITY;
+                    } else if (p.ns == 32) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            float t = -INFINITY;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) t = fmaxf(t, acc[i][j][r]);
+                            v[i] = t;
+                        }
+                        v[2] = v[3] = -INFINITY;
+                    } else {   // 16: rows 0-15 of a 32-block are r < 8, rows 16-31 are r >= 8
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            float t0 = -INFINITY, t1 = -INFINITY;
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) { t0 = fmaxf(t0, acc[i][j][r]); t1 = fmaxf(t1, acc[i][j][r + 8]); }
+                            v[2 * i] = t0; v[2 * i + 1] = t1;
+                        }
+                    }
+                    const int per_wave = 64 / p.ns;   // centres per wave-row-block
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (c < per_wave) {
+                            float t = fmaxf(v[c], __shfl_xor(v[c], 32));   // the other lane half holds the rows + 4
+                            const int m = (row0 + wm * 64) / p.ns + c;
+                            if (lk == 0 && col < p.cout)
+                                p.out[((size_t)bi * p.cout + col) * p.M + m] = fmaxf(t, 0.f);
+                        }
+                    }
+                }
+                // next column tile of this layer, or the next tile's first layer
+                if (last_n) init_acc(bs0, wn * 64); else init_acc(bl, n0 + 128 + wn * 64);
+            }
+            if (has_next) { lds_barrier(); cur ^= 1; }         // the gather waves parked the next tile's chunk 0
+        }
     }
+}
+
+
+__global__ void __launch_bounds__(512)
+sa_mlp_kernel(SaMlpParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    if (__builtin_amdgcn_readfirstlane(tid >> 8)) sa_gather_role(p, lds, tid - 256);
+    else sa_mfma_role(p, lds, tid);
 }
 
 }  // namespace jm
 
 using namespace jm;
 
-extern "C" size_t jm_sa_mlp_packed_weight_elems(int cout, int cin) {
-    return cout < 1 || cin < 1 ? 0 : (size_t)pad_to(cin, 16) * pad_to(cout, 128);
+extern "C" size_t jm_sa_mlp_packed_weight_elems(int cout, int cin, int first_layer) {
+    if (cout < 1 || cin < 1 || (first_layer && cin < 3)) return 0;
+    return (size_t)(first_layer ? sa_first_kp(cin) : pad_to(cin, 16)) * pad_to(cout, 128);
 }
 
 extern "C" size_t jm_sa_mlp_packed_bias_elems(int cout) { return cout < 1 ? 0 : (size_t)pad_to(cout, 128); }
 
-extern "C" int jm_sa_mlp_pack(int cout, int cin, const float* w, const float* b, float* wp, float* bp,
+extern "C" int jm_sa_mlp_pack(int cout, int cin, int first_layer, const float* w, const float* b, float* wp, float* bp,
                               jm_stream_t stream) {
-    JM_REQUIRE(cout >= 1 && cin >= 1, "sa_mlp_pack: bad sizes");
+    JM_REQUIRE(cout >= 1 && cin >= 1 && (!first_layer || cin >= 3), "sa_mlp_pack: bad sizes");
     JM_REQUIRE(w && wp && bp, "sa_mlp_pack: null pointer");
-    const int Kp = pad_to(cin, 16), Np = pad_to(cout, 128);
+    const int Kp = first_layer ? sa_first_kp(cin) : pad_to(cin, 16), Np = pad_to(cout, 128);
     const long long total = (long long)Kp * Np;
     hipLaunchKernelGGL(sa_mlp_pack_kernel, dim3((unsigned)divup(total, 256)), dim3(256), 0, (hipStream_t)stream, cout, cin,
-                       Kp, Np, w, b, wp, bp);
+                       Kp, Np, first_layer ? 1 : 0, w, b, wp, bp);
     return check_launch("sa_mlp_pack");
 }
 
 /* layer widths: widths[0] = 3 + C (input), widths[1..L] = layer outputs.
- * weights[l] / biases[l]: packed by jm_sa_mlp_pack(widths[l+1], widths[l], ...). */
+ * weights[l] / biases[l]: packed by jm_sa_mlp_pack(widths[l+1], widths[l], l == 0, ...). */
 extern "C" int jm_sa_mlp_forward(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                                  const float* features, const int* idx, int num_layers, const int* widths,
                                  const float* const* weights, const float* const* biases, float* out,
@@ -333,7 +515,7 @@ extern "C" int jm_sa_mlp_forward(int b, int n, int m, int c, int nsample, const 
     JM_REQUIRE(num_layers >= 1 && num_layers <= 4, "sa_mlp: %d layers unsupported", num_layers);
     JM_REQUIRE(widths[0] == 3 + c, "sa_mlp: widths[0] = %d != 3 + C = %d", widths[0], 3 + c);
     JM_REQUIRE(b <= 65535, "sa_mlp: batch too large");
-    JM_REQUIRE(num_layers > 1 || widths[0] <= SM_KC, "sa_mlp: a single layer needs 3 + C <= 128");
+    JM_REQUIRE(num_layers > 1 || sa_first_kp(widths[0]) <= SM_KC, "sa_mlp: a single layer needs C <= 128");
     SaMlpParams p{};
     p.N = n; p.M = m; p.C = c; p.ns = nsample;
     p.xyz = xyz; p.new_xyz = new_xyz; p.feat = features; p.idx = idx;
@@ -341,7 +523,7 @@ extern "C" int jm_sa_mlp_forward(int b, int n, int m, int c, int nsample, const 
     for (int l = 0; l <= num_layers; ++l) {
         JM_REQUIRE(widths[l] >= 1, "sa_mlp: bad width");
         JM_REQUIRE(l == 0 || l == num_layers || widths[l] <= 128, "sa_mlp: hidden width %d > 128", widths[l]);
-        p.kp[l] = pad_to(widths[l], 16);
+        p.kp[l] = l == 0 ? sa_first_kp(widths[0]) : pad_to(widths[l], 16);
     }
     for (int l = 0; l < num_layers; ++l) {
         JM_REQUIRE(weights[l] && biases[l], "sa_mlp: null layer %d", l);
@@ -351,7 +533,17 @@ extern "C" int jm_sa_mlp_forward(int b, int n, int m, int c, int nsample, const 
     }
     p.out = out; p.cout = widths[num_layers];
     (void)hipFuncSetAttribute((const void*)sa_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM_LDS_BYTES);
-    hipLaunchKernelGGL(sa_mlp_kernel, dim3((unsigned)((long long)m * nsample / SM_BM), b), dim3(256), SM_LDS_BYTES,
-                       (hipStream_t)stream, p);
+    // persistent: one workgroup per CU (135 KB of LDS each), whole frames per XCD when there are enough of them
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+    cus -= cus % 8;
+    p.tiles_per_frame = (int)((long long)m * nsample / SM_BM);
+    const long long total = (long long)p.tiles_per_frame * b;
+    JM_REQUIRE(total < (1LL << 31), "sa_mlp: too many tiles");
+    p.total_tiles = (int)total;
+    p.xcd_frames = b >= 16 ? 1 : 0;
+    const int grid = p.xcd_frames ? cus : (int)(total < cus ? total : cus);
+    hipLaunchKernelGGL(sa_mlp_kernel, dim3((unsigned)grid), dim3(512), SM_LDS_BYTES, (hipStream_t)stream, p);
     return check_launch("sa_mlp");
 }

@@ -85,13 +85,14 @@ def _packed_layers(mlp: nn.Sequential, device):
         return hit[1]
     lib = L.load()
     packed = []
-    for W, b in fold_shared_mlp(mlp):
+    for li, (W, b) in enumerate(fold_shared_mlp(mlp)):
         W = W.to(device=device, dtype=_f32).contiguous()
         b = b.to(device=device, dtype=_f32).contiguous()
         cout, cin = W.shape
-        wp = torch.empty((lib.jm_sa_mlp_packed_weight_elems(cout, cin),), dtype=_f32, device=device)
+        first = 1 if li == 0 else 0
+        wp = torch.empty((lib.jm_sa_mlp_packed_weight_elems(cout, cin, first),), dtype=_f32, device=device)
         bp = torch.empty((lib.jm_sa_mlp_packed_bias_elems(cout),), dtype=_f32, device=device)
-        L.check(lib.jm_sa_mlp_pack(cout, cin, L.dev(W, _f32, "W"), L.dev(b, _f32, "b"), ctypes.c_void_p(wp.data_ptr()),
+        L.check(lib.jm_sa_mlp_pack(cout, cin, first, L.dev(W, _f32, "W"), L.dev(b, _f32, "b"), ctypes.c_void_p(wp.data_ptr()),
                                    ctypes.c_void_p(bp.data_ptr()), L.stream_ptr()), "sa_mlp_pack")
         packed.append((wp, bp, cout, cin))
     _packed_cache[id(mlp)] = (sig, packed, mlp)   # keep `mlp` alive so id() is not recycled
