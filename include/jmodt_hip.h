@@ -46,6 +46,13 @@ const char* jm_last_error(void);
  * xyz (B,N,3); temp (B,N) pre-filled by the caller (1e10) and updated in place; idx (B,M) i32.
  * Bit-exact with the reference's block-tree arg-max tie order. */
 int jm_furthest_point_sampling(int b, int n, int m, const float* xyz, float* temp, int* idx, jm_stream_t stream);
+/* Same, with a caller-provided workspace: clouds of 16384 < n <= 131072 points (config 5: 65536) are then
+ * split over ceil(n/16384) co-operating workgroups instead of being streamed from L2 by one.
+ * ws: >= jm_fps_workspace_bytes(b, n) bytes (0 when no workspace is needed), 64-byte aligned.  Two such
+ * launches must not run concurrently on one device (their workgroups wait for each other). */
+size_t jm_fps_workspace_bytes(int b, int n);
+int jm_furthest_point_sampling_ws(int b, int n, int m, const float* xyz, float* temp, int* idx, void* ws,
+                                  size_t ws_bytes, jm_stream_t stream);
 
 /* gather_points_wrapper / gather_points_grad_wrapper (sampling.cpp:11-33, sampling_gpu.cu:8-83).
  * points (B,C,N), idx (B,M) -> out (B,C,M);  grad_points (B,C,N) pre-zeroed, accumulated. */

@@ -480,6 +480,158 @@ fps_pruned_kernel(int n, int m, const float* __restrict__ dataset, float* __rest
     for (int i = 0; i < PTS; ++i) tp[kidx[rank0 + i]] = tm[i];
 }
 
+// ------------------------------------------------------------------------------------------
+// Cooperative FPS for clouds larger than one register file (16384 < n <= 131072; config 5's
+// 65536 points): the cloud is split over G = ceil(n / 16384) workgroups, each keeping its 16 slots x
+// 1024 threads register-resident exactly like fps_regs2_kernel, and the G local candidates are
+// exchanged through global memory once per iteration.
+//
+//   * Workgroup g owns the reference threads' slots j in [16 g, 16 g + 16), i.e. points
+//     k in [16384 g, 16384 (g + 1)); inside it "lowest thread, lowest slot" is still the reference
+//     tie order; between workgroups a tie on the value is resolved by the smaller
+//     pk = (bitreverse10(k mod 1024), k / 1024).
+//   * Exchange record = 5 self-validating 64-bit words {iteration | payload}: a reader issues the 5
+//     agent-scope loads of a peer's record at once and accepts them when all carry the current
+//     iteration number — one L2 round trip, no flag-then-data dependency, no fences.  Records are
+//     double-buffered by iteration parity (a peer cannot get two iterations ahead: it needs this
+//     workgroup's record of the next iteration first).  The buffer is zeroed before each launch.
+//   * The G workgroups of a cloud get block ids that differ by multiples of 8, i.e. (as dispatched
+//     today) the same XCD and the same L2; correctness does not depend on that.
+//   * All workgroups of a launch must be co-resident (they spin on each other): the host launches at
+//     most (#CUs / G) clouds per kernel, and callers must not overlap two cooperative FPS launches on
+//     one device (the Python wrapper serialises them with an event).
+// Measured: 65536 -> 4096, B = 8: see DESIGN.md §4 (the streaming fallback below takes 410 ms).
+struct __attribute__((aligned(64))) FpsXchg { unsigned long long w[8]; };
+
+__device__ __forceinline__ unsigned fps_pk(int k) {
+    return (bitrev_u((unsigned)k & 1023u, 10) << 8) | ((unsigned)k >> 10);   // k / 1024 < 256
+}
+
+__global__ void __launch_bounds__(1024)
+fps_coop_kernel(int n, int m, int G, int nclouds, const float* __restrict__ dataset, float* __restrict__ temp,
+                int* __restrict__ idxs, FpsXchg* __restrict__ xchg) {
+    constexpr int PTS = 16;
+    __shared__ int vals[2][16];
+    __shared__ FpsCand win[2];
+    __shared__ int out_buf[FPS_OUT_CHUNK];
+    const int T = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(T >> 6);
+    const int lane = T & 63;
+    // block -> (cloud, part): parts of one cloud are 8 block ids apart
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int cloud = xcd + 8 * (slot / G), g = slot % G;
+    if (cloud >= nclouds) return;
+    const float* ds = dataset + (size_t)cloud * n * 3;
+    float* tp = temp + (size_t)cloud * n;
+    int* out = idxs + (size_t)cloud * m;
+    FpsXchg* xc = xchg + (size_t)cloud * 2 * G;          // [parity][part]
+
+    const int kT = (int)bitrev_u((unsigned)T, 10) + 1024 * PTS * g;   // this thread's first point
+    float px[PTS], py[PTS], pz[PTS], tm[PTS];
+#pragma unroll
+    for (int i = 0; i < PTS; ++i) {
+        const int k = kT + 1024 * i;
+        const bool ok = k < n;
+        px[i] = ok ? ds[k * 3 + 0] : INFINITY;
+        py[i] = ok ? ds[k * 3 + 1] : INFINITY;
+        pz[i] = ok ? ds[k * 3 + 2] : INFINITY;
+        tm[i] = ok ? tp[k] : -1.f;
+    }
+    float x1 = ds[0], y1 = ds[1], z1 = ds[2];
+    if (T == 0) out_buf[0] = 0;
+    __syncthreads();
+
+    for (int it = 1; it < m; ++it) {
+        if (g == 0 && (it & (FPS_OUT_CHUNK - 1)) == 0) {
+            __syncthreads();
+            for (int e = T; e < FPS_OUT_CHUNK; e += 1024) out[it - FPS_OUT_CHUNK + e] = out_buf[e];
+            __syncthreads();
+        }
+        float best = -1.f;
+        const f32x2 cx = {x1, x1}, cy = {y1, y1}, cz = {z1, z1};
+#pragma unroll
+        for (int i = 0; i < PTS; i += 2) {
+            const f32x2 vx = {px[i], px[i + 1]}, vy = {py[i], py[i + 1]}, vz = {pz[i], pz[i + 1]};
+            const f32x2 dx = vx - cx, dy = vy - cy, dz = vz - cz;
+            const f32x2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+            const float a = fast_min(d[0], tm[i]), b = fast_min(d[1], tm[i + 1]);
+            tm[i] = a; tm[i + 1] = b;
+            best = fast_max3(best, a, b);
+        }
+        const int bits = __float_as_int(best);
+        const int wmax = wave_max_i32(bits);
+        if (lane == 0) vals[it & 1][wave] = wmax;
+        lds_barrier();                                                        // A
+        const int v = lane < 16 ? vals[it & 1][lane] : (int)0x80000000;
+        const int lmax = wave_max_i32(v);
+        const int ww = (int)__ffsll((long long)__ballot(v == lmax)) - 1;
+        FpsXchg* mine = xc + (it & 1) * G + g;
+        if (wave == ww) {   // wave-uniform: this workgroup's candidate goes straight to the exchange record
+            const int wl = (int)__ffsll((long long)__ballot(bits == lmax)) - 1;
+            int bi = 0;
+#pragma unroll
+            for (int i = PTS - 1; i >= 0; --i) bi = (__float_as_int(tm[i]) == lmax) ? i : bi;
+            const int bi_u = __builtin_amdgcn_readlane(bi, wl);
+            const unsigned sx = (unsigned)__builtin_amdgcn_readlane(__float_as_int(px[bi_u]), wl);
+            const unsigned sy = (unsigned)__builtin_amdgcn_readlane(__float_as_int(py[bi_u]), wl);
+            const unsigned sz = (unsigned)__builtin_amdgcn_readlane(__float_as_int(pz[bi_u]), wl);
+            const unsigned k_w = bitrev_u((unsigned)((wave << 6) | wl), 10) + 1024u * (unsigned)(PTS * g + bi_u);
+            if (lane < 5) {   // five lanes, one 64-bit word each: {iteration | payload}
+                const unsigned pay = lane == 0 ? (unsigned)lmax : lane == 1 ? k_w : lane == 2 ? sx : lane == 3 ? sy : sz;
+                __hip_atomic_store(&mine->w[lane], ((unsigned long long)(unsigned)it << 32) | pay, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (wave == 0) {    // poll the G records of this iteration (lane q reads part q), pick the global winner
+            const int q = lane < G ? lane : 0;
+            const FpsXchg* rec = xc + (it & 1) * G + q;
+            unsigned long long w0, w1, w2, w3, w4;
+            int spins = 0;
+            for (;;) {
+                w0 = __hip_atomic_load(&rec->w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w1 = __hip_atomic_load(&rec->w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w2 = __hip_atomic_load(&rec->w[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w3 = __hip_atomic_load(&rec->w[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w4 = __hip_atomic_load(&rec->w[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned tag = (unsigned)it;
+                const bool okk = (unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag && (unsigned)(w2 >> 32) == tag &&
+                                 (unsigned)(w3 >> 32) == tag && (unsigned)(w4 >> 32) == tag;
+                if (__all(okk) || ++spins > (1 << 24)) break;   // bounded: a lost peer must not hang the GPU
+            }
+            const int cv = lane < G ? (int)(unsigned)w0 : (int)0x80000000;
+            const int ck = (int)(unsigned)w1;
+            const int gmax = wave_max_i32(cv);
+            const int npk = (lane < G && cv == gmax) ? -(int)fps_pk(ck) : (int)0x80000000;   // smaller pk wins
+            const int pbest = wave_max_i32(npk);
+            const int wq = (int)__ffsll((long long)__ballot(npk == pbest)) - 1;
+            const int k_g = __builtin_amdgcn_readlane(ck, wq);
+            const int gx = __builtin_amdgcn_readlane((int)(unsigned)w2, wq);
+            const int gy = __builtin_amdgcn_readlane((int)(unsigned)w3, wq);
+            const int gz = __builtin_amdgcn_readlane((int)(unsigned)w4, wq);
+            if (lane == 0) {
+                FpsCand c;
+                c.val = gmax; c.k = k_g;
+                c.x = __int_as_float(gx); c.y = __int_as_float(gy); c.z = __int_as_float(gz);
+                win[it & 1] = c;
+                out_buf[it & (FPS_OUT_CHUNK - 1)] = k_g;
+            }
+        }
+        lds_barrier();                                                        // B
+        const FpsCand c = win[it & 1];
+        x1 = c.x; y1 = c.y; z1 = c.z;
+    }
+    __syncthreads();
+    if (g == 0) {
+        const int done = ((m - 1) / FPS_OUT_CHUNK) * FPS_OUT_CHUNK;
+        for (int e = T; e < m - done; e += 1024) out[done + e] = out_buf[e];
+    }
+#pragma unroll
+    for (int i = 0; i < PTS; ++i) {
+        const int k = kT + 1024 * i;
+        if (k < n) tp[k] = tm[i];
+    }
+}
+
 // Fallback for clouds that do not fit the register file (n > 16*1024): temp in LDS is not
 // possible either (n*4 B), so temp and xyz stream through global/L2 like the reference, but
 // keeping the same wave-level arg-max machinery and tie order.
@@ -542,8 +694,29 @@ static int opt_n_threads(int work_size) {
 
 }  // namespace jm
 
+constexpr int FPS_COOP_MAX_N = 131072;
+
+extern "C" size_t jm_fps_workspace_bytes(int b, int n) {
+    if (b < 1 || n <= 16 * 1024 || n > FPS_COOP_MAX_N) return 0;
+    const int G = (n + 16383) / 16384;
+    return (size_t)b * 2 * G * sizeof(jm::FpsXchg);
+}
+
+static int fps_impl(int b, int n, int m, const float* xyz, float* temp, int* idx, void* ws, size_t ws_bytes,
+                    jm_stream_t stream);
+
 extern "C" int jm_furthest_point_sampling(int b, int n, int m, const float* xyz, float* temp, int* idx,
                                           jm_stream_t stream) {
+    return fps_impl(b, n, m, xyz, temp, idx, nullptr, 0, stream);
+}
+
+extern "C" int jm_furthest_point_sampling_ws(int b, int n, int m, const float* xyz, float* temp, int* idx, void* ws,
+                                             size_t ws_bytes, jm_stream_t stream) {
+    return fps_impl(b, n, m, xyz, temp, idx, ws, ws_bytes, stream);
+}
+
+static int fps_impl(int b, int n, int m, const float* xyz, float* temp, int* idx, void* ws, size_t ws_bytes,
+                    jm_stream_t stream) {
     using namespace jm;
     JM_REQUIRE(b >= 0 && n >= 1 && m >= 0, "fps: bad sizes b=%d n=%d m=%d", b, n, m);
     if (b == 0 || m == 0) return JM_OK;
@@ -553,7 +726,30 @@ extern "C" int jm_furthest_point_sampling(int b, int n, int m, const float* xyz,
     int bs_log2 = 0;
     while ((1 << bs_log2) < bs) ++bs_log2;
     const int J = divup(n, bs);
-    if (J > 32 || (J > 16 && bs > 512)) {  // does not fit the register file: stream from L2
+    if (J > 32 || (J > 16 && bs > 512)) {  // does not fit one workgroup's register file
+        const size_t need = jm_fps_workspace_bytes(b, n);
+        static const int no_coop = getenv("JM_FPS_NO_COOP") ? atoi(getenv("JM_FPS_NO_COOP")) : 0;
+        if (ws && need && !no_coop) {
+            // cooperative: G workgroups per cloud, exchange records in the caller's workspace
+            if (ws_bytes < need) { set_error("fps: workspace %zu < %zu bytes", ws_bytes, need); return JM_EWORKSPACE; }
+            JM_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 63u) == 0, "fps: workspace must be 64-byte aligned");
+            const int G = (n + 16383) / 16384;
+            int dev = 0, cus = 256;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8 * G) cus = 256;
+            const int per_launch = 8 * (cus / 8 / G);          // clouds per launch: all workgroups co-resident
+            JM_REQUIRE(per_launch >= 8, "fps: device too small for the cooperative kernel");
+            (void)hipMemsetAsync(ws, 0, need, s);
+            for (int c0 = 0; c0 < b; c0 += per_launch) {
+                const int nc = b - c0 < per_launch ? b - c0 : per_launch;
+                const int grid = 8 * ((nc + 7) / 8) * G;
+                hipLaunchKernelGGL(fps_coop_kernel, dim3(grid), dim3(1024), 0, s, n, m, G, nc, xyz + (size_t)c0 * n * 3,
+                                   temp + (size_t)c0 * n, idx + (size_t)c0 * m,
+                                   reinterpret_cast<FpsXchg*>(ws) + (size_t)c0 * 2 * G);
+            }
+            return check_launch("fps(coop)");
+        }
+        // no workspace (legacy 7-argument entry) or n beyond the cooperative limit: stream from L2
         hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(bs), 0, s, n, m, bs_log2, xyz, temp, idx);
         return check_launch("fps(stream)");
     }

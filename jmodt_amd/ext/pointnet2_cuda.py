@@ -1,4 +1,6 @@
 """`pointnet2_cuda` extension-module shim (pointnet2_api.cpp:10-24) over the C ABI."""
+import ctypes
+
 import torch
 
 from .. import _lib as L
@@ -43,10 +45,33 @@ def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
     return 1
 
 
+_coop_fps_done = {}   # device index -> event recorded after the last co-operative FPS launch
+
+
 def farthest_point_sampling_wrapper(b, n, m, points, temp, idx):
     lib = L.load()
-    L.check(lib.jm_furthest_point_sampling(b, n, m, L.dev(points, f32, "points"), L.dev(temp, f32, "temp"),
-                                           L.dev(idx, i32, "idx"), L.stream_ptr()), "farthest_point_sampling_wrapper")
+    ws_bytes = lib.jm_fps_workspace_bytes(b, n)
+    if ws_bytes == 0:
+        L.check(lib.jm_furthest_point_sampling(b, n, m, L.dev(points, f32, "points"), L.dev(temp, f32, "temp"),
+                                               L.dev(idx, i32, "idx"), L.stream_ptr()), "farthest_point_sampling_wrapper")
+        return 1
+    # clouds larger than one register file (n > 16384): several workgroups per cloud exchange candidates
+    # through this workspace; such launches must not overlap on a device (their workgroups wait for each
+    # other), so each one is ordered after the previous one, whatever stream that ran on
+    dev_i = points.device.index if points.device.index is not None else torch.cuda.current_device()
+    stream = torch.cuda.current_stream(points.device)
+    prev = _coop_fps_done.get(dev_i)
+    if prev is not None:
+        stream.wait_event(prev)
+    ws = torch.empty((ws_bytes + 64,), dtype=torch.uint8, device=points.device)
+    base = ws.data_ptr()
+    aligned = (base + 63) // 64 * 64
+    L.check(lib.jm_furthest_point_sampling_ws(b, n, m, L.dev(points, f32, "points"), L.dev(temp, f32, "temp"),
+                                              L.dev(idx, i32, "idx"), ctypes.c_void_p(aligned), ws_bytes, L.stream_ptr()),
+            "farthest_point_sampling_wrapper")
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    _coop_fps_done[dev_i] = ev
     return 1
 
 

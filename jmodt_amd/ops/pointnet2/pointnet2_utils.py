@@ -21,6 +21,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from ... import _lib as L
+from ...ext import pointnet2_cuda
 
 _f32, _i32 = torch.float32, torch.int32
 
@@ -37,8 +38,8 @@ class _FurthestPointSampling(Function):
         B, N, _ = xyz.size()
         idx = torch.empty((B, npoint), dtype=_i32, device=xyz.device)
         temp = torch.full((B, N), 1e10, dtype=_f32, device=xyz.device)
-        L.check(L.load().jm_furthest_point_sampling(B, N, npoint, L.dev(xyz, _f32, "xyz"), L.dev(temp, _f32, "temp"),
-                                                    L.dev(idx, _i32, "idx"), L.stream_ptr()), "farthest_point_sample")
+        # (the shim picks the co-operative multi-workgroup kernel for clouds of more than 16384 points)
+        pointnet2_cuda.farthest_point_sampling_wrapper(B, N, npoint, xyz, temp, idx)
         ctx.mark_non_differentiable(idx)
         return idx
 

@@ -83,6 +83,26 @@ def test_fps_large_n_stream_path(oracle):
     assert np.array_equal(farthest_point_sample(T(xyz), 64).cpu().numpy(), oracle.furthest_point_sample(xyz, 64))
 
 
+@pytest.mark.parametrize("B,N,m,kw", [
+    (1, 20000, 64, dict(dup_frac=0.05)),       # 2 workgroups, the second partly filled
+    (3, 65536, 300, {}),                       # config 5 cloud size: 4 workgroups per cloud
+    (2, 40000, 200, dict(quantize=2.0 ** -2)), # heavy value ties across workgroups
+    (1, 131072, 40, dict(dup_frac=0.3)),       # the largest supported cloud, 8 workgroups
+    (9, 16385, 33, {}),                        # more clouds than XCDs, one point over the single-workgroup limit
+])
+def test_fps_cooperative_multi_workgroup_bit_exact(oracle, B, N, m, kw):
+    """n > 16384: the cloud is split over co-operating workgroups (jm_furthest_point_sampling_ws)"""
+    from jmodt_amd.ops.pointnet2.pointnet2_utils import farthest_point_sample
+    xyz = synth.cloud(B, N, seed=N % 97, **kw)
+    got = farthest_point_sample(T(xyz), m).cpu().numpy()
+    assert np.array_equal(got, oracle.furthest_point_sample(xyz, m))
+
+
+def test_fps_cooperative_all_equal_points():
+    from jmodt_amd.ops.pointnet2.pointnet2_utils import farthest_point_sample
+    assert not farthest_point_sample(T(np.full((2, 30000, 3), 0.5, np.float32)), 50).cpu().numpy().any()
+
+
 def test_fps_full_size_properties():
     """B=8, 16384 -> 4096: indices in range, all distinct (distinct points), first is 0, and the
     min-distance of each new pick to the already picked set is non-increasing (FPS invariant)."""
