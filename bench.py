@@ -189,6 +189,9 @@ def ops_step(d, timer):
     N, M, C, S = 16384, 128, 130, 512
     timer.run("roipool3d", B * (12 * N + 28 * M + 4 * C * N) + B * M * S * (3 + C) * 4 + 4 * B * M,
               lambda: roipool3d_gpu(d["xyz"], d["feat130"], d["boxes"], 0.2, S))
+    from jmodt_amd.ops.roipool3d.roipool3d_utils import roipool3d_canonical_gpu
+    timer.run("roipool3d+canonical_transform", B * (12 * N + 28 * M + 4 * C * N) + B * M * S * (3 + C) * 4 + 4 * B * M,
+              lambda: roipool3d_canonical_gpu(d["xyz"], d["feat130"], d["boxes"], 0.2, S))
     for b in range(B):
         timer.run("nms_normal_6300", 6300 * 20 + 6300 * 99 * 8, lambda: nms_normal_gpu(d["bev"][b], d["scores"][b], 0.8))
     # the whole batch's proposal selection (sort, band split, 2B batched NMS problems, stitch), TEST budgets

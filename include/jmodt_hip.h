@@ -123,6 +123,15 @@ int jm_roipool3d_forward(int batch_size, int pts_num, int boxes_num, int feature
                          const float* xyz, const float* boxes3d, const float* pts_feature,
                          float* pooled_features, int* pooled_empty_flag, int zero_empty, jm_stream_t stream);
 
+/* roipool3d + the canonical transformation that always follows it (SURVEY.md §8f row 3;
+ * proposal_target_layer.py:100-112, :45-69): rois (B,M,7) are the ORIGINAL boxes; the kernel enlarges them
+ * by extra_width (kitti_utils.py:152-162) for the in-box test and writes pooled xyz relative to the RoI:
+ * minus rois[...,0:3], then (x, z) rotated by rois[...,6] (kitti_utils.py:46-64).  Every row and flag is
+ * written (RoIs without points get the transform of the reference's pre-filled zero row). */
+int jm_roipool3d_canonical(int batch_size, int pts_num, int boxes_num, int feature_in_len, int sampled_pts_num,
+                           const float* xyz, const float* rois, float extra_width, const float* pts_feature,
+                           float* pooled_features, int* pooled_empty_flag, jm_stream_t stream);
+
 /* pts_in_boxes3d_cpu / roipool3d_cpu (roipool3d.cpp:97-195): HOST pointers, synchronous. */
 int jm_pts_in_boxes3d_cpu(int boxes_num, int pts_num, const float* pts, const float* boxes3d, int64_t* pts_flag);
 int jm_roipool3d_cpu(int pts_num, int boxes_num, int feature_len, int sampled_pts_num, const float* pts,

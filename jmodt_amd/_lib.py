@@ -48,6 +48,7 @@ SIGNATURES = {
     "jm_sa_mlp_forward": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, ctypes.POINTER(_I), ctypes.POINTER(_P),
                                ctypes.POINTER(_P), _P, _P]),
     "jm_roipool3d_forward": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "jm_roipool3d_canonical": (_I, [_I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P]),
     "jm_pts_in_boxes3d_cpu": (_I, [_I, _I, _P, _P, _P]),
     "jm_roipool3d_cpu": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "jm_boxes_overlap_bev": (_I, [_I, _P, _I, _P, _P, _P]),

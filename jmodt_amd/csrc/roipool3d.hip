@@ -60,18 +60,29 @@ constexpr int RP_T = 512;          // threads per box: 8 waves -> 32 waves per C
 constexpr int RP_W = RP_T / 64;
 constexpr int RP_TILE = RP_T * 4;  // points per compaction tile
 
-template <bool VEC4>
+// CANON: boxes3d are the ORIGINAL RoIs; the kernel enlarges them itself (h, w, l += e2; y += e1 —
+// kitti_utils.py:152-162 in float32) for the in-box test, and writes the pooled coordinates in the
+// RoI's canonical frame: (x, y, z) - roi centre, then (x, z) rotated by ry
+// (proposal_target_layer.py:106-112; kitti_utils.py:46-64: [x z] @ R^T, R = [[cos, -sin], [sin, cos]]).
+// Empty RoIs get the transform of the zero row the reference pre-fills, features 0.
+template <bool VEC4, bool CANON>
 __global__ void __launch_bounds__(RP_T)
 roipool3d_kernel(int N, int M, int C, int S, const float* __restrict__ xyz, const float* __restrict__ boxes3d,
                  const float* __restrict__ pts_feature, float* __restrict__ pooled, int* __restrict__ empty_flag,
-                 int zero_empty) {
+                 int zero_empty, float e1, float e2) {
     extern __shared__ __attribute__((aligned(16))) int lds[];  // [S] indices, then [2][RP_W] wave totals
     int* sel = lds;
     int* wtot = lds + ((S + 3) & ~3);
     const int mi = blockIdx.x, bi = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* pts = xyz + (size_t)bi * N * 3;
-    const BoxTest bt = make_box_test(boxes3d + ((size_t)bi * M + mi) * 7);
+    const float* braw = boxes3d + ((size_t)bi * M + mi) * 7;
+    float bx[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) bx[q] = braw[q];
+    const float ccx = bx[0], ccy = bx[1], ccz = bx[2];      // canonical frame origin: the un-enlarged RoI
+    if (CANON) { bx[1] += e1; bx[3] += e2; bx[4] += e2; bx[5] += e2; }
+    const BoxTest bt = make_box_test(bx);
 
     // ---- phase A: ordered compaction of in-box point indices.  Tile = 1024 points, thread t owns
     // the 4 consecutive points base + 4t .. + 3 (three 16-byte loads), so the order inside a tile
@@ -138,7 +149,14 @@ roipool3d_kernel(int N, int M, int C, int S, const float* __restrict__ xyz, cons
     const int total = S * RC;
     if (cnt == 0) {
         if (tid == 0) empty_flag[(size_t)bi * M + mi] = 1;
-        if (zero_empty) {
+        if (CANON) {
+            const float x = 0.f - ccx, y = 0.f - ccy, z = 0.f - ccz;
+            const float t0 = x * bt.cosa + z * (-bt.sina), t2 = x * bt.sina + z * bt.cosa;
+            for (int e = tid; e < total; e += RP_T) {
+                const int j = e % RC;
+                dst[e] = j == 0 ? t0 : (j == 1 ? y : (j == 2 ? t2 : 0.f));
+            }
+        } else if (zero_empty) {
             if (VEC4) {
                 float4* d4 = reinterpret_cast<float4*>(dst);
                 for (int e = tid; e < total / 4; e += RP_T) d4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -148,7 +166,7 @@ roipool3d_kernel(int N, int M, int C, int S, const float* __restrict__ xyz, cons
         }
         return;
     }
-    if (zero_empty && tid == 0) empty_flag[(size_t)bi * M + mi] = 0;
+    if ((zero_empty || CANON) && tid == 0) empty_flag[(size_t)bi * M + mi] = 0;
     // expand the cyclic padding once (sel[s] = sel[s % cnt]) so the copy loop never divides
     for (int s2 = cnt + tid; s2 < S; s2 += RP_T) sel[s2] = sel[s2 % cnt];
     __syncthreads();
@@ -163,7 +181,12 @@ roipool3d_kernel(int N, int M, int C, int S, const float* __restrict__ xyz, cons
         // branch-guarded loads with a vmcnt(0) at every join, which serialises the 16 gathers)
         const int src = sel[s];
         const float* a = j < 3 ? pts + (src * 3 + j) : feat + ((size_t)src * C + (j - 3));
-        return *a;
+        const float v = *a;
+        if (!CANON) return v;
+        // canonical coordinates need x and z together: two more (always valid) loads, then a select
+        const float x = pts[src * 3] - ccx, z = pts[src * 3 + 2] - ccz;
+        const float r0 = x * bt.cosa + z * (-bt.sina), r2 = x * bt.sina + z * bt.cosa;
+        return j == 0 ? r0 : (j == 1 ? v - ccy : (j == 2 ? r2 : v));
     };
     if (VEC4) {
         const int nvec = total / 4;
@@ -212,10 +235,10 @@ roipool3d_kernel(int N, int M, int C, int S, const float* __restrict__ xyz, cons
 
 using namespace jm;
 
-extern "C" int jm_roipool3d_forward(int batch_size, int pts_num, int boxes_num, int feature_in_len,
-                                    int sampled_pts_num, const float* xyz, const float* boxes3d,
-                                    const float* pts_feature, float* pooled_features, int* pooled_empty_flag,
-                                    int zero_empty, jm_stream_t stream) {
+template <bool CANON>
+static int roipool3d_launch(int batch_size, int pts_num, int boxes_num, int feature_in_len, int sampled_pts_num,
+                            const float* xyz, const float* boxes3d, const float* pts_feature, float* pooled_features,
+                            int* pooled_empty_flag, int zero_empty, float e1, float e2, jm_stream_t stream) {
     JM_REQUIRE(batch_size >= 0 && pts_num >= 0 && boxes_num >= 0 && feature_in_len >= 0 && sampled_pts_num >= 1,
                "roipool3d: bad sizes");
     if (batch_size == 0 || boxes_num == 0) return JM_OK;
@@ -229,17 +252,36 @@ extern "C" int jm_roipool3d_forward(int batch_size, int pts_num, int boxes_num, 
     const bool vec = (slab % 4 == 0) && ((reinterpret_cast<uintptr_t>(pooled_features) & 15u) == 0);
     dim3 grid(boxes_num, batch_size), block(RP_T);
     if (vec) {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)roipool3d_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(roipool3d_kernel<true>, grid, block, lds, (hipStream_t)stream, pts_num, boxes_num,
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)roipool3d_kernel<true, CANON>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((roipool3d_kernel<true, CANON>), grid, block, lds, (hipStream_t)stream, pts_num, boxes_num,
                            feature_in_len, sampled_pts_num, xyz, boxes3d, pts_feature, pooled_features,
-                           pooled_empty_flag, zero_empty);
+                           pooled_empty_flag, zero_empty, e1, e2);
     } else {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)roipool3d_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(roipool3d_kernel<false>, grid, block, lds, (hipStream_t)stream, pts_num, boxes_num,
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)roipool3d_kernel<false, CANON>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((roipool3d_kernel<false, CANON>), grid, block, lds, (hipStream_t)stream, pts_num, boxes_num,
                            feature_in_len, sampled_pts_num, xyz, boxes3d, pts_feature, pooled_features,
-                           pooled_empty_flag, zero_empty);
+                           pooled_empty_flag, zero_empty, e1, e2);
     }
     return check_launch("roipool3d");
+}
+
+extern "C" int jm_roipool3d_forward(int batch_size, int pts_num, int boxes_num, int feature_in_len,
+                                    int sampled_pts_num, const float* xyz, const float* boxes3d,
+                                    const float* pts_feature, float* pooled_features, int* pooled_empty_flag,
+                                    int zero_empty, jm_stream_t stream) {
+    return roipool3d_launch<false>(batch_size, pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d,
+                                   pts_feature, pooled_features, pooled_empty_flag, zero_empty, 0.f, 0.f, stream);
+}
+
+extern "C" int jm_roipool3d_canonical(int batch_size, int pts_num, int boxes_num, int feature_in_len,
+                                      int sampled_pts_num, const float* xyz, const float* rois, float extra_width,
+                                      const float* pts_feature, float* pooled_features, int* pooled_empty_flag,
+                                      jm_stream_t stream) {
+    // the reference enlarges with `+= extra_width * 2` / `+= extra_width` on float32 tensors: the Python
+    // scalars are rounded to float32 first
+    const float e1 = extra_width, e2 = (float)((double)extra_width * 2.0);
+    return roipool3d_launch<true>(batch_size, pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, rois,
+                                  pts_feature, pooled_features, pooled_empty_flag, 1, e1, e2, stream);
 }
 
 // ---- host CPU entry points of the reference API (roipool3d.cpp:97-195); synchronous ----------

@@ -18,6 +18,20 @@ def forward(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag, zero_
     return 1
 
 
+def forward_canonical(xyz, rois, extra_width, pts_feature, pooled_features, pooled_empty_flag):
+    """MI355X-native: pooling + the canonical transformation of proposal_target_layer.py:106-112 in one pass;
+    `rois` are the un-enlarged boxes"""
+    lib = L.load()
+    B, N = xyz.size(0), xyz.size(1)
+    M, C, S = rois.size(1), pts_feature.size(2), pooled_features.size(2)
+    L.check(lib.jm_roipool3d_canonical(B, N, M, C, S, L.dev(xyz, f32, "xyz"), L.dev(rois, f32, "rois"),
+                                       float(extra_width), L.dev(pts_feature, f32, "pts_feature"),
+                                       L.dev(pooled_features, f32, "pooled_features"),
+                                       L.dev(pooled_empty_flag, i32, "pooled_empty_flag"), L.stream_ptr()),
+            "roipool3d.forward_canonical")
+    return 1
+
+
 # the reference exposes a second, slower kernel under this name that computes the same result
 # (roipool3d_kernel.cu:31-94); it is never called from Python.  One implementation serves both.
 forward_slow = forward

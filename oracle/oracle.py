@@ -172,6 +172,23 @@ def roipool3d(pts, pts_feature, boxes3d_enlarged, sampled_pt_num=512, return_idx
     return (pooled, empty, pidx) if return_idx else (pooled, empty)
 
 
+def roipool3d_canonical(pts, pts_feature, boxes3d, extra_width, sampled_pt_num=512):
+    """roipool3d_gpu + canonical transformation, as the RCNN stage's inference branch does it
+    (proposal_target_layer.py:100-112; rotate_pc_along_y_torch kitti_utils.py:46-64), float32 throughout.
+    pts (B,N,3), pts_feature (B,N,C), boxes3d (B,M,7) un-enlarged -> pooled (B,M,S,3+C), empty (B,M)"""
+    pts, pts_feature, boxes3d = _f32(pts), _f32(pts_feature), _f32(boxes3d)
+    B, M = boxes3d.shape[:2]
+    enlarged = np.stack([enlarge_box3d(boxes3d[b], extra_width) for b in range(B)])
+    pooled, empty = roipool3d(pts, pts_feature, enlarged, sampled_pt_num)
+    pooled = pooled.copy()
+    pooled[..., 0:3] -= boxes3d[:, :, None, 0:3]
+    cosa, sina = np.cos(boxes3d[..., 6]), np.sin(boxes3d[..., 6])           # float32
+    x, z = pooled[..., 0].copy(), pooled[..., 2].copy()
+    pooled[..., 0] = x * cosa[..., None] + z * (-sina[..., None])
+    pooled[..., 2] = x * sina[..., None] + z * cosa[..., None]
+    return pooled, empty
+
+
 def pts_in_boxes3d(pts, boxes3d):
     pts, boxes = _f32(pts), _f32(boxes3d)
     M, N = boxes.shape[0], pts.shape[0]

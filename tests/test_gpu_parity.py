@@ -514,6 +514,37 @@ def test_association_cost_vs_oracle(oracle, P, D):
     assert torch.equal(boxes_iou3d_gpu(T(a), T(b)), iou)       # same kernel arithmetic as the iou3d op
 
 
+# ------------------------------------------------------------------ roipool3d + canonical transformation (§8f row 3)
+@pytest.mark.parametrize("B,N,M,C,S", [(2, 4096, 24, 6, 128), (2, 2048, 10, 5, 64), (3, 16384, 32, 130, 512)])
+def test_roipool3d_canonical_vs_oracle_and_unfused(oracle, B, N, M, C, S):
+    """the fused kernel == oracle restatement of proposal_target_layer.py:100-112 (1e-4), == our own
+    roipool3d_gpu followed by the reference's torch ops; index behaviour (first S, cyclic padding, empty
+    RoIs -> transform of the zero row) is inherited from roipool3d"""
+    from jmodt_amd.ops.roipool3d.roipool3d_utils import roipool3d_canonical_gpu, roipool3d_gpu
+    pts = synth.dense_cloud(B, N, 601, extent=14.0)
+    pts[..., 1] = pts[..., 1] / 7.0
+    boxes = synth.proposals(pts, M, 602)
+    boxes[0, 0, 0:3] = [500, 0, 500]           # empty
+    boxes[0, 1, 3:6] = [60, 60, 60]            # > S points
+    boxes[-1, 2, 3:6] = [1.0, 0.8, 1.5]        # few points: cyclic padding
+    feat = np.random.default_rng(603).normal(size=(B, N, C)).astype(np.float32)
+    got, gflag = roipool3d_canonical_gpu(T(pts), T(feat), T(boxes), 0.2, S)
+    want, wflag = oracle.roipool3d_canonical(pts, feat, boxes, 0.2, S)
+    assert np.array_equal(gflag.cpu().numpy(), wflag)
+    g = got.cpu().numpy()
+    assert np.array_equal(g[..., 3:], want[..., 3:])                     # copied features: bit-exact
+    assert np.abs(g[..., :3] - want[..., :3]).max() < 1e-4
+    # the reference's own sequence of torch ops on top of the unfused kernel
+    ref, _ = roipool3d_gpu(T(pts), T(feat), T(boxes), 0.2, S)
+    tb = T(boxes)
+    ref[:, :, :, 0:3] -= tb[:, :, 0:3].unsqueeze(2)
+    cosa, sina = torch.cos(tb[..., 6]), torch.sin(tb[..., 6])
+    R = torch.stack((torch.stack((cosa, -sina), -1), torch.stack((sina, cosa), -1)), -2)       # (B, M, 2, 2)
+    ref[..., [0, 2]] = torch.matmul(ref[..., [0, 2]], R.transpose(-1, -2))
+    assert (got - ref).abs().max().item() < 1e-4
+    assert wflag[0, 0] == 1 and np.abs(g[0, 0, :, 3:]).max() == 0
+
+
 # ------------------------------------------------------------------ batched NMS + RPN proposal selection (§8f row 2)
 @pytest.mark.parametrize("normal", [1, 0])
 def test_nms_batched_matches_single_problem_oracle(oracle, normal):
