@@ -596,7 +596,7 @@ fps_coop_kernel(int n, int m, int G, int nclouds, const float* __restrict__ data
                 const unsigned tag = (unsigned)it;
                 const bool okk = (unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag && (unsigned)(w2 >> 32) == tag &&
                                  (unsigned)(w3 >> 32) == tag && (unsigned)(w4 >> 32) == tag;
-                if (__all(okk) || ++spins > (1 << 24)) break;   // bounded: a lost peer must not hang the GPU
+                if (__all(okk) || ++spins > (1 << 21)) break;   // bounded (~seconds): a lost peer must not hang the GPU
             }
             const int cv = lane < G ? (int)(unsigned)w0 : (int)0x80000000;
             const int ck = (int)(unsigned)w1;
