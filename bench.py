@@ -209,6 +209,46 @@ def ops_step(d, timer):
         timer.run("affinity_128x128", 0, lambda: pairwise_affinity(d["pf"], d["df"], d["link"], d["se"]), flops=128 * 128 * (2 * 512 * 512 * 2 + 2 * 512))
 
 
+def make_dense_inputs(B, seed, dev):
+    """BASELINE configs[4] shapes: 65536 points per frame, 256 proposals, 256 x 256 affinity"""
+    from jmodt_amd.ops.affinity import make_affinity_mlp
+    N = 65536
+    xyz_np = synth.cloud(B, N, seed=seed)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    d = dict(xyz=torch.from_numpy(xyz_np).to(dev), N=N)
+    d["boxes"] = torch.from_numpy(synth.proposals(xyz_np, 256, seed + 1)).to(dev)
+    d["feat130"] = torch.randn(B, N, 130, generator=g).to(dev)
+    torch.manual_seed(seed)
+    d["link"], d["se"] = make_affinity_mlp().to(dev).eval(), make_affinity_mlp().to(dev).eval()
+    d["pf"] = torch.from_numpy(synth.roi_features(256, 512, seed + 2)).to(dev)
+    d["df"] = torch.from_numpy(synth.roi_features(256, 512, seed + 3)).to(dev)
+    return d
+
+
+def dense_step(d, timer):
+    """config 5: level-1 set abstraction inputs on 65536-point clouds (co-operative FPS, dual ball query,
+    grouping), 3-NN back onto the full cloud, roipool3d with the canonical transform for 256 RoIs, 256^2 affinity"""
+    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
+    from jmodt_amd.ops.roipool3d.roipool3d_utils import roipool3d_canonical_gpu
+    from jmodt_amd.ops.affinity import pairwise_affinity
+    xyz, N = d["xyz"], d["N"]
+    B, m = xyz.shape[0], 4096
+    idx = timer.run("fps_65536->4096(coop)", B * m * 20 * N, lambda: pu.farthest_point_sample(xyz, m))
+    xyz_t = xyz.transpose(1, 2).contiguous()
+    new_xyz = pu.gather_operation(xyz_t, idx).transpose(1, 2).contiguous()
+    i0, i1 = timer.run("ball_query_dual_65536", B * (12 * N + 12 * m + 4 * m * 48),
+                       lambda: pu.ball_query_dual(0.1, 16, 0.5, 32, xyz, new_xyz))
+    for ns, nb in ((16, i0), (32, i1)):
+        timer.run("group_points_xyz_65536", B * (4 * m * ns + 12 * N + 12 * m * ns), lambda: pu.grouping_operation(xyz_t, nb))
+    timer.run("three_nn_65536x4096", B * (12 * N + 12 * m + 24 * N), lambda: pu.three_nn(xyz, new_xyz))
+    M, C, S = 256, 130, 512
+    timer.run("roipool3d+canonical_65536x256", B * (12 * N + 28 * M + 4 * C * N) + B * M * S * (3 + C) * 4 + 4 * B * M,
+              lambda: roipool3d_canonical_gpu(xyz, d["feat130"], d["boxes"], 0.2, S))
+    for b in range(B):
+        timer.run("affinity_256x256", 0, lambda: pairwise_affinity(d["pf"], d["df"], d["link"], d["se"]),
+                  flops=256 * 256 * (2 * 512 * 512 * 2 + 2 * 512))
+
+
 def cpu_baseline_sa(B):
     """the oracle (CPU restatement, OpenMP) on ONE batch of the same workload"""
     from oracle import oracle as orc
@@ -240,8 +280,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the FPS chain on the main stream (no side stream)")
-    ap.add_argument("--workload", default="sa", choices=["sa", "ops"],
-                    help="sa = BASELINE configs[1] (default); ops = every other hot-path op at its §8d shape")
+    ap.add_argument("--workload", default="sa", choices=["sa", "ops", "dense"],
+                    help="sa = BASELINE configs[1] (default); ops = every other hot-path op at its §8d shape; "
+                         "dense = configs[4] shapes (65536 points, 256 RoIs, 256^2 affinity)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -265,9 +306,12 @@ def main():
     if args.workload == "sa":
         xyz, feats = make_sa_inputs(args.batch, 1234 + 1 + rank, dev)
         step = lambda: sa_step(xyz, feats, timer, overlap=not args.no_overlap)  # noqa: E731
-    else:
+    elif args.workload == "ops":
         ops_in = make_ops_inputs(args.batch, 1234 + 2 + rank, dev)
         step = lambda: ops_step(ops_in, timer)  # noqa: E731
+    else:
+        dense_in = make_dense_inputs(args.batch, 1234 + 4 + rank, dev)
+        step = lambda: dense_step(dense_in, timer)  # noqa: E731
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -318,8 +362,12 @@ def main():
                                     "4 RPN SA levels (16384->4096->1024->256->64), 16384-pt synthetic clouds")
                        if args.workload == "sa" else
                        ("supplementary: three_nn+interpolate (4 FP levels), LI-Fusion gather (5 maps), roipool3d "
-                        "(128 RoIs x 512 pts x 133), RPN nms_normal (6300 boxes), 128x128 affinity, per frame"),
-                       "frames_per_gpu_per_step": args.batch, "points": 16384, "parallelism": f"replicas x{world}"},
+                        "(128 RoIs x 512 pts x 133), RPN nms_normal (6300 boxes), 128x128 affinity, per frame")
+                       if args.workload == "ops" else
+                       ("supplementary, BASELINE configs[4] shapes: 65536-pt clouds (co-operative FPS -> 4096, dual "
+                        "ball query, grouping, 3-NN), roipool3d+canonical for 256 RoIs, 256x256 affinity per frame"),
+                       "frames_per_gpu_per_step": args.batch, "points": 65536 if args.workload == "dense" else 16384,
+                       "parallelism": f"replicas x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_gbs"],
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["hbm_frac"], "traffic": traffic,
                          "basis": "algorithmic bytes per SURVEY.md §8(d) (FPS: streaming-equivalent B*m*20n — the "
