@@ -2,6 +2,7 @@
 (jmodt_amd/csrc/sa_mlp.hip).  No reference counterpart as a function: it replaces the per-scale
 body of `_PointnetSAModuleBase.forward` (jmodt/ops/pointnet2/pointnet2_modules.py:46-52)."""
 import ctypes
+import weakref
 from typing import List, Optional, Tuple
 
 import torch
@@ -40,15 +41,14 @@ def fold_shared_mlp(mlp: nn.Sequential) -> Optional[List[Tuple[torch.Tensor, tor
     return layers
 
 
-_shape_cache = {}
+_shape_cache = weakref.WeakKeyDictionary()    # module -> [(cout, cin)] | None
 
 
 def _layer_shapes(mlp: nn.Sequential):
     """[(cout, cin)] if every unit is Conv2d(1x1)[+BN]+ReLU in post-activation order, else None.
     Structure only (no tensor math), cached per module object."""
-    hit = _shape_cache.get(id(mlp))
-    if hit is not None and hit[0] is mlp:
-        return hit[1]
+    if mlp in _shape_cache:
+        return _shape_cache[mlp]
     shapes = []
     for unit in mlp.children():
         conv = getattr(unit, "conv", None)
@@ -57,7 +57,7 @@ def _layer_shapes(mlp: nn.Sequential):
             shapes = None
             break
         shapes.append((conv.out_channels, conv.in_channels))
-    _shape_cache[id(mlp)] = (mlp, shapes)
+    _shape_cache[mlp] = shapes
     return shapes
 
 
@@ -72,7 +72,7 @@ def can_fuse(mlp: nn.Sequential, npoint: int, nsample: int, training: bool) -> b
     return all(cout <= 128 for cout, _ in shapes[:-1]) and next(mlp.parameters()).is_cuda
 
 
-_packed_cache = {}
+_packed_cache = weakref.WeakKeyDictionary()   # module -> (signature, packed layers)
 
 
 def _packed_layers(mlp: nn.Sequential, device):
@@ -80,7 +80,7 @@ def _packed_layers(mlp: nn.Sequential, device):
     parameter or BatchNorm buffer changes (torch bumps `_version` on every in-place update)."""
     tensors = [t for t in list(mlp.parameters()) + list(mlp.buffers())]
     sig = tuple((t.data_ptr(), t._version) for t in tensors) + (str(device),)
-    hit = _packed_cache.get(id(mlp))
+    hit = _packed_cache.get(mlp)
     if hit is not None and hit[0] == sig:
         return hit[1]
     lib = L.load()
@@ -95,7 +95,7 @@ def _packed_layers(mlp: nn.Sequential, device):
         L.check(lib.jm_sa_mlp_pack(cout, cin, first, L.dev(W, _f32, "W"), L.dev(b, _f32, "b"), ctypes.c_void_p(wp.data_ptr()),
                                    ctypes.c_void_p(bp.data_ptr()), L.stream_ptr()), "sa_mlp_pack")
         packed.append((wp, bp, cout, cin))
-    _packed_cache[id(mlp)] = (sig, packed, mlp)   # keep `mlp` alive so id() is not recycled
+    _packed_cache[mlp] = (sig, packed)
     return packed
 
 
