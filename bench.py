@@ -146,6 +146,7 @@ def make_ops_inputs(B, seed, dev):
     d["maps"] = [(torch.randn(B, c, h, w, generator=g).to(dev), d["xy"][:, :n].contiguous())
                  for c, h, w, n in ((64, 192, 640, 4096), (128, 96, 320, 1024), (256, 48, 160, 256),
                                     (512, 24, 80, 64), (32, 384, 1280, 16384))]
+    d["maps_cl"] = [(fm.contiguous(memory_format=torch.channels_last), xy) for fm, xy in d["maps"]]
     bev, sc = [], []
     for b in range(B):
         bb, ss = synth.bev_boxes(6300, seed + 10 + b)
@@ -186,6 +187,9 @@ def ops_step(d, timer):
     for mi, (fm, xy) in enumerate(d["maps"]):
         c, n = fm.shape[1], xy.shape[1]
         timer.run(f"feature_gather_{mi + 1}", B * n * 4 * c * 4 + B * c * n * 4, lambda: feature_gather(fm, xy))
+    for mi, (fm, xy) in enumerate(d["maps_cl"]):   # same maps in channels_last memory format (no copy inside the op)
+        c, n = fm.shape[1], xy.shape[1]
+        timer.run(f"feature_gather_{mi + 1}_channels_last", B * n * 4 * c * 4 + B * c * n * 4, lambda: feature_gather(fm, xy))
     N, M, C, S = 16384, 128, 130, 512
     timer.run("roipool3d", B * (12 * N + 28 * M + 4 * C * N) + B * M * S * (3 + C) * 4 + 4 * B * M,
               lambda: roipool3d_gpu(d["xyz"], d["feat130"], d["boxes"], 0.2, S))
