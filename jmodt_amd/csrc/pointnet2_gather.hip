@@ -135,8 +135,11 @@ three_nn_kernel(int n, int m, int chunk, const float* __restrict__ unknown, cons
             for (int i = 0; i < 8; ++i) d[i] = sqdist3(ux - f[3 * i], uy - f[3 * i + 1], uz - f[3 * i + 2]);
             const float dmin = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
             if (__any(dmin < t.b3)) {
+                // only the points that improve SOME lane's list run the insertion (uniform branch per point;
+                // a point no lane wants leaves every list unchanged, so skipping it is exact)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) t.visit(kk + i, d[i]);
+                for (int i = 0; i < 8; ++i)
+                    if (__any(d[i] < t.b3)) t.visit(kk + i, d[i]);
             }
         };
         float4 ga[6], gb[6];
