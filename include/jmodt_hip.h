@@ -170,6 +170,16 @@ int jm_nms(int boxes_num, const float* boxes, float nms_overlap_thresh, int norm
 int jm_nms_batched(int num_problems, int max_boxes, const int* counts, const float* boxes,
                    float nms_overlap_thresh, int normal, int64_t* keep, int* num_keep, void* ws, size_t ws_bytes,
                    jm_stream_t stream);
+/* RPN proposal selection for a whole batch (ProposalLayer.forward after the decode,
+ * proposal_layer.py:34-144): scores (B,N), proposals (B,N,7) [x, y_bottom, z, h, w, l, ry], order (B,N) =
+ * indices of the scores in descending order.  distance_based != 0: depth bands (0,40] / (40,80] with the
+ * 70 % / 30 % budgets, empty far band -> next slice of the near band (:57-117), NMS variant nms_normal;
+ * distance_based == 0: one problem per frame (:119-144; the reference uses rotated NMS there).
+ * out_boxes (B, post_nms_top_n, 7), out_scores (B, post_nms_top_n), zero padded.  No host round trip. */
+size_t jm_proposal_select_workspace_bytes(int b, int distance_based, int pre_nms_top_n);
+int jm_proposal_select(int b, int n, const float* scores, const float* proposals, const int64_t* order,
+                       int distance_based, int pre_nms_top_n, int post_nms_top_n, float nms_thresh, int nms_normal,
+                       float* out_boxes, float* out_scores, void* ws, size_t ws_bytes, jm_stream_t stream);
 /* mask only (N, ceil(N/64)) uint64; tiles with col_block < row_block are never consumed by the
  * reduce (iou3d.cpp:108) and are left unwritten. */
 int jm_nms_mask(int boxes_num, const float* boxes, float nms_overlap_thresh, int normal,

@@ -57,6 +57,8 @@ SIGNATURES = {
     "jm_nms_workspace_bytes": (_Z, [_I]),
     "jm_nms": (_I, [_I, _P, _F, _I, _P, _P, _P, _Z, _P]),
     "jm_nms_batched": (_I, [_I, _I, _P, _P, _F, _I, _P, _P, _P, _Z, _P]),
+    "jm_proposal_select_workspace_bytes": (_Z, [_I, _I, _I]),
+    "jm_proposal_select": (_I, [_I, _I, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _Z, _P]),
     "jm_nms_mask": (_I, [_I, _P, _F, _I, _P, _P]),
     "jm_feature_gather": (_I, [_I, _I, _I, _I, _I, _P, _L, _L, _L, _L, _P, _P, _P]),
     "jm_feature_gather_grad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _L, _L, _L, _L, _P]),

@@ -501,6 +501,16 @@ extern "C" int jm_nms(int boxes_num, const float* boxes, float nms_overlap_thres
     return launch_nms_reduce(1, boxes_num, nullptr, (const unsigned long long*)ws, keep, num_keep, (hipStream_t)stream);
 }
 
+namespace jm {
+// mask + reduce for nprob problems; shared with proposal.hip
+int launch_nms_batched(int nprob, int nmax, const int* counts, const float* boxes, float thresh, int normal,
+                       int64_t* keep, int* num_keep, void* mask_ws, hipStream_t s) {
+    int rc = launch_nms_mask(nprob, nmax, counts, boxes, thresh, normal, (unsigned long long*)mask_ws, s);
+    if (rc) return rc;
+    return launch_nms_reduce(nprob, nmax, counts, (const unsigned long long*)mask_ws, keep, num_keep, s);
+}
+}  // namespace jm
+
 extern "C" int jm_nms_batched(int num_problems, int max_boxes, const int* counts, const float* boxes,
                               float nms_overlap_thresh, int normal, int64_t* keep, int* num_keep, void* ws,
                               size_t ws_bytes, jm_stream_t stream) {

@@ -1,0 +1,192 @@
+// proposal.hip — RPN proposal selection for a whole batch.
+//
+// Replaces the per-frame Python loop of ProposalLayer.forward after the box decode
+// (jmodt/detection/layers/proposal_layer.py:34-144: score order -> depth bands with their pre-NMS
+// budgets -> BEV NMS per band -> post-NMS budgets -> zero-padded result).  The reference runs, per
+// frame and band, ~10 indexing ops, one NMS with a device->host copy of the whole mask and a CPU loop;
+// here the batch needs FOUR launches after the score sort and nothing touches the host:
+//   proposal_compact_kernel  one workgroup per frame: walks the score order once, ranks the members of
+//                            each band with wave ballots + prefix popcounts, writes the BEV boxes of the
+//                            selected ones straight into the padded NMS problem buffers
+//   nms_mask / nms_reduce    (iou3d.hip) all 2 B problems at once, counts read on the device
+//   proposal_stitch_kernel   kept boxes of band 0 then band 1, post budgets, zero padding
+#include "jm_common.h"
+
+namespace jm {
+
+int launch_nms_batched(int nprob, int nmax, const int* counts, const float* boxes, float thresh, int normal,
+                       int64_t* keep, int* num_keep, void* mask_ws, hipStream_t s);   // iou3d.hip
+
+constexpr int PC_T = 1024, PC_W = PC_T / 64;
+
+// mode 0: distance based (two bands (r0, r1] and (r1, r2] on z; an empty far band takes near members
+//         pre1 .. pre1+pre2-1 instead, proposal_layer.py:88-98);  mode 1: score based (one problem)
+__global__ void __launch_bounds__(PC_T)
+proposal_compact_kernel(int n, int mode, int pre1, int pre2, float r0, float r1, float r2, int pmax,
+                        const float* __restrict__ proposals, const long long* __restrict__ order,
+                        float* __restrict__ bev, int* __restrict__ src, int* __restrict__ counts) {
+    __shared__ int wtot[2][2][PC_W];   // [parity][band][wave]
+    __shared__ int red[PC_W];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = mode == 0 ? 2 : 1;
+    const float* pr = proposals + (size_t)b * n * 7;
+    const long long* ord = order + (size_t)b * n;
+    float* bev_b = bev + (size_t)b * K * pmax * 5;
+    int* src_b = src + (size_t)b * K * pmax;
+
+    bool far_empty = false;
+    if (mode == 0) {   // pass 1: is the far band populated at all?
+        int any = 0;
+        for (int p = tid; p < n; p += PC_T) {
+            const float z = pr[(size_t)ord[p] * 7 + 2];
+            any |= (z > r1 && z <= r2) ? 1 : 0;
+        }
+        const unsigned long long bal = __ballot(any);
+        if (lane == 0) red[wave] = bal != 0ULL;
+        __syncthreads();
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < PC_W; ++w) tot |= red[w];
+        far_empty = tot == 0;
+    }
+    auto emit = [&](int prob, int slot, int k) {
+        const float* q = pr + (size_t)k * 7;
+        const float cu = q[0], cv = q[2], half_w = q[4] / 2, half_l = q[5] / 2;   // kitti_utils.py:136-149
+        float* o = bev_b + ((size_t)prob * pmax + slot) * 5;
+        o[0] = cu - half_l; o[1] = cv - half_w; o[2] = cu + half_l; o[3] = cv + half_w; o[4] = q[6];
+        src_b[(size_t)prob * pmax + slot] = k;
+    };
+    const int near_budget = pre1 + ((mode == 0 && far_empty) ? pre2 : 0);
+    int c1 = 0, c2 = 0, parity = 0;   // members seen so far (identical in every thread)
+    for (int base = 0; base < n; base += PC_T, parity ^= 1) {
+        const int p = base + tid;
+        int k = 0;
+        bool m1 = false, m2 = false;
+        if (p < n) {
+            k = (int)ord[p];
+            if (mode == 0) {
+                const float z = pr[(size_t)k * 7 + 2];
+                m1 = z > r0 && z <= r1;
+                m2 = z > r1 && z <= r2;
+            } else {
+                m1 = true;
+            }
+        }
+        const unsigned long long b1 = __ballot(m1), b2 = __ballot(m2);
+        if (lane == 0) { wtot[parity][0][wave] = (int)__popcll(b1); wtot[parity][1][wave] = (int)__popcll(b2); }
+        lds_barrier();
+        int before1 = 0, before2 = 0, all1 = 0, all2 = 0;
+#pragma unroll
+        for (int w = 0; w < PC_W; ++w) {
+            const int t1 = wtot[parity][0][w], t2 = wtot[parity][1][w];
+            before1 += w < wave ? t1 : 0; before2 += w < wave ? t2 : 0;
+            all1 += t1; all2 += t2;
+        }
+        if (m1) {
+            const int rank = c1 + before1 + mbcnt(b1);
+            if (rank < pre1) emit(0, rank, k);
+            else if (far_empty && rank < pre1 + pre2) emit(1, rank - pre1, k);
+        }
+        if (m2) {
+            const int rank = c2 + before2 + mbcnt(b2);
+            if (rank < pre2) emit(1, rank, k);
+        }
+        c1 += all1; c2 += all2;
+        if (c1 >= near_budget && (mode == 1 || far_empty || c2 >= pre2)) break;   // uniform: budgets are full
+    }
+    if (mode == 0 && !far_empty) {
+        // the loop may have stopped before the populations were fully counted; counts are clamped anyway
+    }
+    if (tid == 0) {
+        counts[b * K] = min(c1, pre1);
+        if (K == 2) counts[b * K + 1] = far_empty ? max(0, min(c1 - pre1, pre2)) : min(c2, pre2);
+    }
+}
+
+__global__ void proposal_stitch_kernel(int n, int K, int pmax, int post1, int post2, const float* __restrict__ scores,
+                                       const float* __restrict__ proposals, const int* __restrict__ src,
+                                       const long long* __restrict__ keep, const int* __restrict__ num_keep,
+                                       float* __restrict__ out_boxes, float* __restrict__ out_scores) {
+    const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int post = post1 + post2;
+    if (t >= post) return;
+    const int nk1 = min(num_keep[b * K], post1);
+    const int nk2 = K == 2 ? min(num_keep[b * K + 1], post2) : 0;
+    float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s = 0.f;
+    if (t < nk1 + nk2) {
+        const int band = t < nk1 ? 0 : 1, j = t - (band ? nk1 : 0);
+        const int slot = (int)keep[((size_t)b * K + band) * pmax + j];
+        const int k = src[((size_t)b * K + band) * pmax + slot];
+        const float* q = proposals + ((size_t)b * n + k) * 7;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) v[c] = q[c];
+        s = scores[(size_t)b * n + k];
+    }
+    float* o = out_boxes + ((size_t)b * post + t) * 7;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) o[c] = v[c];
+    out_scores[(size_t)b * post + t] = s;
+}
+
+struct ProposalWs {
+    float* bev; int* src; int* counts; int64_t* keep; int* num_keep; void* mask; size_t total;
+};
+
+static ProposalWs carve(void* ws, int b, int K, int pmax) {
+    ProposalWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { void* p = ws ? (char*)ws + off : nullptr; off += align_up(bytes, (size_t)256); return p; };
+    const size_t P = (size_t)b * K;
+    w.bev = (float*)take(P * pmax * 5 * sizeof(float));
+    w.src = (int*)take(P * pmax * sizeof(int));
+    w.counts = (int*)take(P * sizeof(int));
+    w.keep = (int64_t*)take(P * pmax * sizeof(int64_t));
+    w.num_keep = (int*)take(P * sizeof(int));
+    w.mask = take(P * jm_nms_workspace_bytes(pmax));
+    w.total = off;
+    return w;
+}
+
+}  // namespace jm
+
+using namespace jm;
+
+extern "C" size_t jm_proposal_select_workspace_bytes(int b, int distance_based, int pre_nms_top_n) {
+    if (b < 1 || pre_nms_top_n < 1) return 0;
+    const int pre1 = distance_based ? (int)(pre_nms_top_n * 0.7) : pre_nms_top_n;
+    const int pre2 = distance_based ? pre_nms_top_n - pre1 : 0;
+    const int pmax = pre1 > pre2 ? pre1 : pre2;
+    return carve(nullptr, b, distance_based ? 2 : 1, pmax < 1 ? 1 : pmax).total;
+}
+
+extern "C" int jm_proposal_select(int b, int n, const float* scores, const float* proposals, const int64_t* order,
+                                  int distance_based, int pre_nms_top_n, int post_nms_top_n, float nms_thresh,
+                                  int nms_normal, float* out_boxes, float* out_scores, void* ws, size_t ws_bytes,
+                                  jm_stream_t stream) {
+    JM_REQUIRE(b >= 0 && n >= 0 && pre_nms_top_n >= 1 && post_nms_top_n >= 1, "proposal_select: bad sizes");
+    if (b == 0) return JM_OK;
+    JM_REQUIRE(scores && proposals && order && out_boxes && out_scores && ws, "proposal_select: null pointer");
+    JM_REQUIRE(b <= 32767, "proposal_select: batch too large");
+    hipStream_t s = (hipStream_t)stream;
+    // proposal_layer.py:63-69: int(total * 0.7) and the rest
+    const int pre1 = distance_based ? (int)(pre_nms_top_n * 0.7) : pre_nms_top_n;
+    const int pre2 = distance_based ? pre_nms_top_n - pre1 : 0;
+    const int post1 = distance_based ? (int)(post_nms_top_n * 0.7) : post_nms_top_n;
+    const int post2 = distance_based ? post_nms_top_n - post1 : 0;
+    const int K = distance_based ? 2 : 1;
+    int pmax = pre1 > pre2 ? pre1 : pre2;
+    if (pmax < 1) pmax = 1;
+    const ProposalWs w = carve(ws, b, K, pmax);
+    if (ws_bytes < w.total) { set_error("proposal_select: workspace %zu < %zu bytes", ws_bytes, w.total); return JM_EWORKSPACE; }
+    JM_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255u) == 0, "proposal_select: workspace must be 256-byte aligned");
+    hipLaunchKernelGGL(proposal_compact_kernel, dim3(b), dim3(PC_T), 0, s, n, distance_based ? 0 : 1, pre1, pre2, 0.0f,
+                       40.0f, 80.0f, pmax, proposals, (const long long*)order, w.bev, w.src, w.counts);
+    int rc = check_launch("proposal_compact");
+    if (rc) return rc;
+    rc = launch_nms_batched(b * K, pmax, w.counts, w.bev, nms_thresh, nms_normal, w.keep, w.num_keep, w.mask, s);
+    if (rc) return rc;
+    const int post = post1 + post2;
+    hipLaunchKernelGGL(proposal_stitch_kernel, dim3(divup(post, 128), b), dim3(128), 0, s, n, K, pmax, post1, post2, scores,
+                       proposals, w.src, (const long long*)w.keep, w.num_keep, out_boxes, out_scores);
+    return check_launch("proposal_stitch");
+}

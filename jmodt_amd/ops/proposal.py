@@ -7,53 +7,41 @@ sort, split into the (0, 40] m and (40, 80] m depth bands with the 70 % / 30 % p
 zero-padded (B, POST_TOP_N, 7) result.
 
 The reference walks the frames in Python and runs 2 B NMS calls one after the other, each with
-a device->host copy of the whole suppression mask.  Here the band split is a prefix-sum
-compaction, the 2 B NMS problems run as ONE batched launch pair (jm_nms_batched) with device-side
-counts, and the ragged results are stitched by index arithmetic — the only sync is whatever the
-caller does with the result.
+a device->host copy of the whole suppression mask.  Here the score sort is one torch call and the
+rest is `jm_proposal_select` (csrc/proposal.hip): one compaction kernel, the 2 B NMS problems as
+ONE batched launch pair with device-side counts, one stitch kernel — the only sync is whatever
+the caller does with the result.
 
 The bin-based box decode (bbox_transform.py:28-132) is not part of this module: it takes decoded
 proposals (B, N, 7) [x, y_bottom, z, h, w, l, ry].
 """
+import ctypes
 from typing import Tuple
 
 import torch
 
-from ..ext import iou3d_cuda
-from .iou3d.iou3d_utils import boxes3d_to_bev_torch
+from .. import _lib as L
 
-NMS_RANGES = (0.0, 40.0, 80.0)  # proposal_layer.py:63
-
-
-def _budgets(total: int) -> Tuple[int, int]:
-    near = int(total * 0.7)  # proposal_layer.py:65-67
-    return near, total - near
+_f32 = torch.float32
 
 
-def _finish(scores_o, props_o, src, counts, thresh, normal, post_budgets, post_total):
-    """src (B, K, Pmax) sorted positions feeding each problem, counts (B, K) -> padded outputs"""
-    B, K, pmax = src.shape
-    bev = boxes3d_to_bev_torch(props_o.reshape(-1, 7)).view(B, -1, 5)
-    boxes = torch.gather(bev, 1, src.view(B, K * pmax, 1).expand(-1, -1, 5)).view(B * K, pmax, 5).contiguous()
-    keep, num = iou3d_cuda.nms_batched_device(boxes, counts.reshape(-1).to(torch.int32).contiguous(), thresh, normal)
-    keep = keep.view(B, K, pmax)
-    budget = torch.tensor(post_budgets, device=src.device, dtype=torch.int64).view(1, K)
-    nk = torch.minimum(num.view(B, K).to(torch.int64), budget)          # kept per problem after the post budget
-    start = torch.cumsum(nk, dim=1) - nk                                 # exclusive prefix: where each band lands
-    t = torch.arange(post_total, device=src.device).view(1, post_total)
-    band = (t.unsqueeze(1) >= start.unsqueeze(2)).sum(dim=1) - 1         # (B, post_total) band of output row t
-    band = band.clamp_(0, K - 1)
-    j = t - torch.gather(start, 1, band)
-    valid = t < nk.sum(dim=1, keepdim=True)
-    j = torch.where(valid, j, torch.zeros_like(j)).clamp_(0, pmax - 1)
-    flat = band * pmax + j
-    kept_slot = torch.gather(keep.view(B, K * pmax), 1, flat).clamp_(0, pmax - 1)
-    pos = torch.gather(src.view(B, K * pmax), 1, band * pmax + kept_slot)
-    out_boxes = torch.gather(props_o, 1, pos.unsqueeze(2).expand(-1, -1, 7)) * valid.unsqueeze(2)
-    out_scores = torch.gather(scores_o, 1, pos) * valid
-    # `x * False` keeps the sign of zero / propagates inf-nan; select instead so padding is +0 like .zero_()
-    out_boxes = torch.where(valid.unsqueeze(2), out_boxes, torch.zeros_like(out_boxes))
-    out_scores = torch.where(valid, out_scores, torch.zeros_like(out_scores))
+def _select(scores, proposals, distance_based, pre, post, thresh, normal):
+    lib = L.load()
+    B, N = scores.shape
+    scores = scores.contiguous().to(_f32)
+    proposals = proposals.contiguous().to(_f32)
+    # stable, so equal scores keep their index order (the reference's torch.sort leaves that unspecified)
+    order = torch.sort(scores, dim=1, descending=True, stable=True)[1].contiguous()
+    out_boxes = torch.empty((B, post, 7), dtype=_f32, device=scores.device)
+    out_scores = torch.empty((B, post), dtype=_f32, device=scores.device)
+    ws_bytes = lib.jm_proposal_select_workspace_bytes(B, int(distance_based), pre)
+    ws = torch.empty((ws_bytes + 256,), dtype=torch.uint8, device=scores.device)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    L.check(lib.jm_proposal_select(B, N, L.dev(scores, _f32, "scores"), L.dev(proposals, _f32, "proposals"),
+                                   L.dev(order, torch.int64, "order"), int(distance_based), int(pre), int(post),
+                                   float(thresh), int(normal), ctypes.c_void_p(out_boxes.data_ptr()),
+                                   ctypes.c_void_p(out_scores.data_ptr()), ctypes.c_void_p(base), ws_bytes,
+                                   L.stream_ptr()), "proposal_select")
     return out_boxes, out_scores
 
 
@@ -64,48 +52,11 @@ def distance_based_proposal(scores: torch.Tensor, proposals: torch.Tensor, pre_n
     (proposal_layer.py:34-117 for every frame of the batch at once)"""
     if nms_type not in ("normal", "rotate"):
         raise NotImplementedError(nms_type)  # proposal_layer.py:107-108
-    B, N = scores.shape
-    order = torch.sort(scores, dim=1, descending=True, stable=True)[1]
-    scores_o = torch.gather(scores, 1, order)
-    props_o = torch.gather(proposals, 1, order.unsqueeze(2).expand(-1, -1, 7)).contiguous()
-    pre1, pre2 = _budgets(pre_nms_top_n)
-    post = _budgets(post_nms_top_n)
-    pmax = max(pre1, pre2, 1)
-
-    dist = props_o[:, :, 2]
-    m1 = (dist > NMS_RANGES[0]) & (dist <= NMS_RANGES[1])
-    m2 = (dist > NMS_RANGES[1]) & (dist <= NMS_RANGES[2])
-    r1 = torch.cumsum(m1, dim=1) - 1          # rank of each near-band element in score order
-    r2 = torch.cumsum(m2, dim=1) - 1
-    c1, c2 = r1[:, -1:] + 1, r2[:, -1:] + 1   # (B, 1) band populations
-    far_empty = c2 == 0
-    # near band: first pre1 members.  far band: first pre2 members, or, when it is empty, near members
-    # pre1 .. pre1+pre2-1 (proposal_layer.py:88-98)
-    sel1 = m1 & (r1 < pre1)
-    sel2 = torch.where(far_empty, m1 & (r1 >= pre1) & (r1 < pre1 + pre2), m2 & (r2 < pre2))
-    slot2 = torch.where(far_empty, r1 - pre1, r2)
-    n1 = c1.clamp(max=pre1)
-    n2 = torch.where(far_empty, (c1 - pre1).clamp(min=0, max=pre2), c2.clamp(max=pre2))
-
-    # scatter the sorted positions of the selected boxes into their problem slots (+1 dump slot)
-    pos = torch.arange(N, device=scores.device).view(1, N).expand(B, N)
-    src = torch.zeros((B, 2, pmax + 1), dtype=torch.int64, device=scores.device)
-    src[:, 0].scatter_(1, torch.where(sel1, r1, torch.full_like(r1, pmax)), pos)
-    src[:, 1].scatter_(1, torch.where(sel2, slot2, torch.full_like(r1, pmax)), pos)
-    src = src[:, :, :pmax].contiguous()
-    counts = torch.cat([n1, n2], dim=1)
-    return _finish(scores_o, props_o, src, counts, nms_thresh, 1 if nms_type == "normal" else 0, post, post_nms_top_n)
+    return _select(scores, proposals, True, pre_nms_top_n, post_nms_top_n, nms_thresh, nms_type == "normal")
 
 
 @torch.no_grad()
 def score_based_proposal(scores: torch.Tensor, proposals: torch.Tensor, pre_nms_top_n: int, post_nms_top_n: int,
                          nms_thresh: float) -> Tuple[torch.Tensor, torch.Tensor]:
     """proposal_layer.py:119-144 (always rotated NMS) for every frame of the batch at once"""
-    B, N = scores.shape
-    order = torch.sort(scores, dim=1, descending=True, stable=True)[1]
-    scores_o = torch.gather(scores, 1, order)
-    props_o = torch.gather(proposals, 1, order.unsqueeze(2).expand(-1, -1, 7)).contiguous()
-    pmax = max(min(pre_nms_top_n, N), 1)
-    src = torch.arange(pmax, device=scores.device).view(1, 1, pmax).expand(B, 1, pmax).contiguous()
-    counts = torch.full((B, 1), min(pre_nms_top_n, N), dtype=torch.int64, device=scores.device)
-    return _finish(scores_o, props_o, src, counts, nms_thresh, 0, (post_nms_top_n,), post_nms_top_n)
+    return _select(scores, proposals, False, pre_nms_top_n, post_nms_top_n, nms_thresh, False)
