@@ -59,6 +59,10 @@ struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };
 constexpr int RP_T = 512;          // threads per box: 8 waves -> 32 waves per CU with 4 boxes resident
 constexpr int RP_W = RP_T / 64;
 constexpr int RP_TILE = RP_T * 4;  // points per compaction tile
+#ifndef RP_U
+#define RP_U 4
+#endif
+constexpr int RP_UNROLL = RP_U;    // independent 16-byte outputs in flight per thread per copy trip
 
 // CANON: boxes3d are the ORIGINAL RoIs; the kernel enlarges them itself (h, w, l += e2; y += e1 —
 // kitti_utils.py:152-162 in float32) for the in-box test, and writes the pooled coordinates in the
@@ -190,10 +194,10 @@ roipool3d_kernel(int N, int M, int C, int S, const float* __restrict__ xyz, cons
     };
     if (VEC4) {
         const int nvec = total / 4;
-        for (int f0 = tid; f0 < nvec; f0 += 4 * RP_T) {
-            float v[4][4];
+        for (int f0 = tid; f0 < nvec; f0 += RP_UNROLL * RP_T) {
+            float v[RP_UNROLL][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < RP_UNROLL; ++u) {
                 const int f = min(f0 + u * RP_T, nvec - 1);   // clamped: loads stay unconditional
                 const int e = f * 4;
                 int s = (int)__umulhi((unsigned)e, rc_magic), j = e - s * RC;
@@ -212,7 +216,7 @@ roipool3d_kernel(int N, int M, int C, int S, const float* __restrict__ xyz, cons
             }
             float4* d4 = reinterpret_cast<float4*>(dst);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < RP_UNROLL; ++u)
                 if (f0 + u * RP_T < nvec) d4[f0 + u * RP_T] = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
         }
     } else {
