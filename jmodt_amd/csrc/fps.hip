@@ -233,6 +233,8 @@ fps_regs2_kernel(int n, int m, int bs, int bs_log2, int R, int J, int recipJ, co
         if (wave == ww) {   // wave-uniform: exactly one wave extracts the winner
             const unsigned long long eq = __ballot(bits == gmax);
             const int wl = (int)__ffsll((long long)eq) - 1;
+            // (a scalar-unit variant — one ballot per slot, then bit tests of the winner lane — measured
+            //  8 % slower per iteration: 1.25 vs 1.16 us)
             int bi = 0;
 #pragma unroll
             for (int i = PTS - 1; i >= 0; --i) bi = (__float_as_int(tm[i]) == gmax) ? i : bi;
