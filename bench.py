@@ -380,7 +380,7 @@ def main():
                          "measured_copy_ceiling_gbs": HBM_COPY_CEILING_GBS},
             "kernels": kernels,
         }
-        if not args.no_cpu_baseline and args.workload == "sa":
+        if not args.no_cpu_baseline and args.workload == "sa" and world == 1:   # rank 0 at N = 1 only
             try:
                 fps, dt = cpu_baseline_sa(args.batch)
                 result["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": os.cpu_count(),
