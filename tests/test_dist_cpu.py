@@ -5,7 +5,6 @@ tools/train.py:86-107)."""
 import os
 import socket
 
-import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp

@@ -1,7 +1,7 @@
 """config 5 (dense scene: 65536 pts/frame, 256 proposals, 256^2 affinity) op timings, B frames per GPU"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from jmodt_amd import synth
 from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
 from jmodt_amd.ops.roipool3d.roipool3d_utils import roipool3d_gpu
