@@ -239,6 +239,8 @@ fps_regs2_kernel(int n, int m, int bs, int bs_log2, int R, int J, int recipJ, co
 #pragma unroll
             for (int i = PTS - 1; i >= 0; --i) bi = (__float_as_int(tm[i]) == gmax) ? i : bi;
             const int bi_u = __builtin_amdgcn_readlane(bi, wl);
+            // (a scalar switch over the slot with statically indexed v_readlanes instead of the three
+            //  s_set_gpr_idx windows measured slower: 1.23 vs 1.16 us per iteration)
             const int sx = __builtin_amdgcn_readlane(__float_as_int(px[bi_u]), wl);
             const int sy = __builtin_amdgcn_readlane(__float_as_int(py[bi_u]), wl);
             const int sz = __builtin_amdgcn_readlane(__float_as_int(pz[bi_u]), wl);
@@ -480,6 +482,232 @@ fps_pruned_kernel(int n, int m, const float* __restrict__ dataset, float* __rest
     }
 #pragma unroll
     for (int i = 0; i < PTS; ++i) tp[kidx[rank0 + i]] = tm[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// Slot-clustered exact FPS (n = 8192 / 16384, reference block size 1024): pruning that shortens EVERY
+// wave's loop instead of skipping whole waves.
+//
+// The wave-clustered kernel above skips 85 % of the wave-loops and is still slower, because each
+// iteration waits for the one wave that owns the neighbourhood of the new sample and runs its full
+// 16-slot loop alone.  Here the spatial clusters are the register SLOTS: slot i of all 1024 threads
+// holds the 1024 points of Morton cluster i, so an iteration touches the same few slots in every wave
+// and the work stays balanced.  Per iteration a wave
+//   1. evaluates the distance expression on the nearest corner offsets of the 16 slot boxes (lane i does
+//      box i) — by monotone rounding a lower bound LB_i of the computed distance of every point of the
+//      slot — and keeps the slots with LB_i < G, where G is the maximum min-distance before this update
+//      (the value the previous iteration just selected, known to everybody for free): a slot with
+//      LB_i >= G >= temp cannot change any temp;
+//   2. updates only those slots (2.2 of 16 on average on the bench cloud, 3.2 on a 1/z-dense one);
+//   3. recomputes its per-lane maximum over the 16 temps and enters the usual reduce / publish chain.
+// Tie order: slots no longer follow the reference's thread order, so every slot carries the key
+// (pk << 4 | slot), pk = (bitreverse10(k mod 1024), k / 1024) being the reference's priority; the
+// winner is the minimum key among the (lane, slot) pairs that hold the maximum — inside the winning
+// wave by a min-chain + one DPP min, between waves (value ties: duplicates, grids) by comparing the
+// published pk.  The (slot, thread) -> point index table lives in LDS and is only read by the winner.
+//
+// Measured (MI355X, B = 8, 16384 -> 4096): 1.15 us / iteration on the bench cloud, 1.17 on a 1/z-dense
+// one — the SAME as the plain scan (1.16): the distance loop shrinks from 72 to ~40 instructions per wave,
+// but the iteration is dominated by the reduce / winner-extraction / barrier chain (≈1900 of 2770 cycles
+// are barrier waits for the slowest wave and the winner), and the uniform branching costs what the
+// skipped arithmetic saves.  Off by default (JM_FPS_PRUNE=2); bit-exact, covered by the GPU tests.
+template <int PTS>
+__global__ void __launch_bounds__(1024)
+fps_slotprune_kernel(int n, int m, const float* __restrict__ dataset, float* __restrict__ temp,
+                     int* __restrict__ idxs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* ent = reinterpret_cast<unsigned long long*>(lds_raw);   // [n] during setup
+    constexpr int J = PTS;                  // n / 1024 = number of clusters = slots per thread
+    constexpr int JLOG = PTS == 16 ? 4 : 3;
+    static_assert(PTS == 16 || PTS == 8, "slot-clustered FPS: 8 or 16 slots");
+    const int T = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(T >> 6);
+    const int lane = T & 63;
+    const float* ds = dataset + (size_t)blockIdx.x * n * 3;
+    float* tp = temp + (size_t)blockIdx.x * n;
+    int* out = idxs + (size_t)blockIdx.x * m;
+    __shared__ float red[6][16];
+
+    // ---- cloud extent in x, z
+    float xmin = INFINITY, xmax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int k = T + 1024 * j;
+        const float x = ds[k * 3 + 0], z = ds[k * 3 + 2];
+        xmin = fminf(xmin, x); xmax = fmaxf(xmax, x); zmin = fminf(zmin, z); zmax = fmaxf(zmax, z);
+    }
+    xmin = -wave_max_f32(-xmin); xmax = wave_max_f32(xmax); zmin = -wave_max_f32(-zmin); zmax = wave_max_f32(zmax);
+    if (lane == 0) { red[0][wave] = xmin; red[1][wave] = xmax; red[2][wave] = zmin; red[3][wave] = zmax; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        xmin = fminf(xmin, red[0][w]); xmax = fmaxf(xmax, red[1][w]);
+        zmin = fminf(zmin, red[2][w]); zmax = fmaxf(zmax, red[3][w]);
+    }
+    const float sx = 65535.f / fmaxf(xmax - xmin, 1e-20f), sz = 65535.f / fmaxf(zmax - zmin, 1e-20f);
+    // ---- sort 1: Morton order (any key gives a valid permutation; exactness never depends on it)
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int k = T + 1024 * j;
+        const float qx = fminf(fmaxf((ds[k * 3 + 0] - xmin) * sx, 0.f), 65535.f);
+        const float qz = fminf(fmaxf((ds[k * 3 + 2] - zmin) * sz, 0.f), 65535.f);
+        const unsigned key = part1by1((unsigned)qx) | (part1by1((unsigned)qz) << 1);
+        ent[k] = ((unsigned long long)key << 32) | (unsigned)k;
+    }
+    __syncthreads();
+    bitonic_sort_u64(ent, n, T, 1024);
+    // ---- sort 2: (cluster = rank / 1024, pk): thread T of slot i gets the T-th priority of cluster i
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int r = T + 1024 * j;
+        const unsigned k = (unsigned)ent[r];
+        const unsigned cluster = (unsigned)r >> 10;
+        const unsigned pk = (bitrev_u(k & 1023u, 10) << JLOG) | (k >> 10);
+        ent[r] = ((unsigned long long)((cluster << 20) | pk) << 32) | k;   // own entries only: no race
+    }
+    __syncthreads();
+    bitonic_sort_u64(ent, n, T, 1024);
+
+    float px[PTS], py[PTS], pz[PTS], tm[PTS];
+    int* kidx = reinterpret_cast<int*>(lds_raw);            // [PTS][1024]: point index of (slot, thread)
+    {
+        int kk[PTS];
+#pragma unroll
+        for (int i = 0; i < PTS; ++i) {
+            kk[i] = (int)(unsigned)ent[i * 1024 + T];
+            px[i] = ds[kk[i] * 3 + 0]; py[i] = ds[kk[i] * 3 + 1]; pz[i] = ds[kk[i] * 3 + 2];
+            tm[i] = tp[kk[i]];
+        }
+        __syncthreads();   // every sorted entry has been read: compact the permutation to int32 in place
+#pragma unroll
+        for (int i = 0; i < PTS; ++i) kidx[i * 1024 + T] = kk[i];
+    }
+    unsigned char* after = lds_raw + (size_t)n * 4;
+
+    // ---- slot bounding boxes: lane i (< PTS) of every wave ends up with box i; other lanes get an
+    // empty box (LB = +inf, never active)
+    float* bred = reinterpret_cast<float*>(after);          // [6][PTS][16 waves]
+#pragma unroll
+    for (int i = 0; i < PTS; ++i) {
+        const float a0 = -wave_max_f32(-px[i]), a1 = wave_max_f32(px[i]);
+        const float b0 = -wave_max_f32(-py[i]), b1 = wave_max_f32(py[i]);
+        const float c0 = -wave_max_f32(-pz[i]), c1 = wave_max_f32(pz[i]);
+        if (lane == 0) {
+            bred[(0 * PTS + i) * 16 + wave] = a0; bred[(1 * PTS + i) * 16 + wave] = a1;
+            bred[(2 * PTS + i) * 16 + wave] = b0; bred[(3 * PTS + i) * 16 + wave] = b1;
+            bred[(4 * PTS + i) * 16 + wave] = c0; bred[(5 * PTS + i) * 16 + wave] = c1;
+        }
+    }
+    __syncthreads();
+    float blx = INFINITY, bhx = -INFINITY, bly = INFINITY, bhy = -INFINITY, blz = INFINITY, bhz = -INFINITY;
+    if (lane < PTS) {
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            blx = fminf(blx, bred[(0 * PTS + lane) * 16 + w]); bhx = fmaxf(bhx, bred[(1 * PTS + lane) * 16 + w]);
+            bly = fminf(bly, bred[(2 * PTS + lane) * 16 + w]); bhy = fmaxf(bhy, bred[(3 * PTS + lane) * 16 + w]);
+            blz = fminf(blz, bred[(4 * PTS + lane) * 16 + w]); bhz = fmaxf(bhz, bred[(5 * PTS + lane) * 16 + w]);
+        }
+    }
+    __syncthreads();
+    int* vals = reinterpret_cast<int*>(after);                                     // [2][16]
+    FpsCandP* cand = reinterpret_cast<FpsCandP*>(after + 256);                     // [2][16]
+    int* out_buf = reinterpret_cast<int*>(after + 256 + 2 * 16 * sizeof(FpsCandP));   // [FPS_OUT_CHUNK]
+    auto pk_of = [&](int k) { return (int)((bitrev_u((unsigned)k & 1023u, 10) << JLOG) | ((unsigned)k >> 10)); };
+
+    float x1 = ds[0], y1 = ds[1], z1 = ds[2];
+    float G = INFINITY;          // max min-distance before the coming update (all temps start at 1e10)
+    float best = INFINITY;       // per-lane max over the slots; recomputed whenever a slot is touched
+    if (T == 0) out_buf[0] = 0;
+    __syncthreads();
+
+    for (int it = 1; it < m; ++it) {
+        if ((it & (FPS_OUT_CHUNK - 1)) == 0) {
+            __syncthreads();
+            for (int e = T; e < FPS_OUT_CHUNK; e += 1024) out[it - FPS_OUT_CHUNK + e] = out_buf[e];
+            __syncthreads();
+        }
+        // 1. which slots can change?  (same expression as the distance, on the box's nearest offsets)
+        const float ddx = fast_max3(blx - x1, x1 - bhx, 0.f);
+        const float ddy = fast_max3(bly - y1, y1 - bhy, 0.f);
+        const float ddz = fast_max3(blz - z1, z1 - bhz, 0.f);
+        const float lb = sqdist3(ddx, ddy, ddz);
+        const unsigned act = (unsigned)__ballot(lb < G) & ((1u << PTS) - 1u);   // wave-uniform
+        // 2. update those slots only
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < PTS; ++i) {
+                if (act & (1u << i)) {   // uniform branch, static registers
+                    const float d = sqdist3(px[i] - x1, py[i] - y1, pz[i] - z1);
+                    tm[i] = fast_min(d, tm[i]);
+                }
+            }
+            // 3. per-lane maximum over all slots
+            float b = tm[0];
+#pragma unroll
+            for (int i = 1; i + 1 < PTS; i += 2) b = fast_max3(b, tm[i], tm[i + 1]);
+            best = fast_max(b, tm[PTS - 1]);
+        }
+        const int bits = __float_as_int(best);
+        const int wmax = wave_max_i32(bits);
+        if (lane == 0) vals[(it & 1) * 16 + wave] = wmax;
+        lds_barrier();                                                        // A
+        const int v = lane < 16 ? vals[(it & 1) * 16 + lane] : (int)0x80000000;
+        const int gmax = wave_max_i32(v);
+        const unsigned long long weq = __ballot(v == gmax);
+        FpsCandP* slot_c = cand + (it & 1) * 16;
+        if ((weq >> wave) & 1ULL) {   // wave-uniform: normally exactly one wave holds the maximum
+            const unsigned long long eq = __ballot(bits == gmax);
+            int wl = (int)__ffsll((long long)eq) - 1;
+            // first matching slot and number of matching slots of every lane
+            int bi = 0, cnt = 0;
+#pragma unroll
+            for (int i = PTS - 1; i >= 0; --i) {
+                const bool mt = __float_as_int(tm[i]) == gmax;
+                bi = mt ? i : bi;
+                cnt += mt ? 1 : 0;
+            }
+            int si = __builtin_amdgcn_readlane(bi, wl);
+            if (__popcll(eq) > 1 || __builtin_amdgcn_readlane(cnt, wl) > 1) {
+                // several (lane, slot) pairs hold the maximum (duplicated or grid-aligned points): the
+                // reference's priority decides — smallest pk, read from the index table
+                int lmin = 0x7FFFFFFF;
+#pragma unroll
+                for (int i = 0; i < PTS; ++i)
+                    if (__float_as_int(tm[i]) == gmax) lmin = min(lmin, (pk_of(kidx[i * 1024 + T]) << 4) | i);
+                const int kmin = -wave_max_i32(-lmin);
+                wl = (int)__ffsll((long long)__ballot(lmin == kmin)) - 1;
+                si = kmin & 15;
+            }
+            const int k_w = kidx[si * 1024 + (wave << 6) + wl];   // wave-uniform LDS read
+            const int cx = __builtin_amdgcn_readlane(__float_as_int(px[si]), wl);
+            const int cy = __builtin_amdgcn_readlane(__float_as_int(py[si]), wl);
+            const int cz = __builtin_amdgcn_readlane(__float_as_int(pz[si]), wl);
+            if (lane == 0) {
+                FpsCandP c;
+                c.val = gmax; c.pk = pk_of(k_w); c.k = k_w;
+                c.x = __int_as_float(cx); c.y = __int_as_float(cy); c.z = __int_as_float(cz);
+                slot_c[wave] = c;
+            }
+        }
+        lds_barrier();                                                        // B
+        int ww = (int)__ffsll((long long)weq) - 1;
+        if (__popcll(weq) > 1) {   // value tie between waves: the smaller pk wins (uniform, rare)
+            const int pkv = ((weq >> lane) & 1ULL) ? slot_c[lane & 15].pk : 0x7FFFFFFF;
+            const int pmin = -wave_max_i32(-pkv);
+            ww = (int)__ffsll((long long)__ballot(pkv == pmin)) - 1;
+        }
+        const FpsCandP c = slot_c[ww];
+        x1 = c.x; y1 = c.y; z1 = c.z;
+        G = __int_as_float(c.val);
+        if (T == 0) out_buf[it & (FPS_OUT_CHUNK - 1)] = c.k;
+    }
+    __syncthreads();
+    {
+        const int done = ((m - 1) / FPS_OUT_CHUNK) * FPS_OUT_CHUNK;
+        for (int e = T; e < m - done; e += 1024) out[done + e] = out_buf[e];
+    }
+#pragma unroll
+    for (int i = 0; i < PTS; ++i) tp[kidx[i * 1024 + T]] = tm[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -763,7 +991,18 @@ static int fps_impl(int b, int n, int m, const float* xyz, float* temp, int* idx
     // scan.  Kept (bit-exact, covered by the GPU tests through JM_FPS_PRUNE=1) as the starting
     // point for a slot-interleaved layout; see DESIGN.md §7.
     static const int prune = getenv("JM_FPS_PRUNE") ? atoi(getenv("JM_FPS_PRUNE")) : 0;
-    if (prune && bs == 1024 && n % 1024 == 0 && (J == 4 || J == 8 || J == 16) && m > 1) {
+    if (prune == 2 && bs == 1024 && n % 1024 == 0 && (J == 8 || J == 16) && m > 1) {
+        const size_t lds = (size_t)n * 8;   // sort entries; later: index table (n * 4) + boxes / candidates / picks (< n * 4)
+        if (J == 16) {
+            (void)hipFuncSetAttribute((const void*)fps_slotprune_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((fps_slotprune_kernel<16>), dim3(b), dim3(1024), lds, s, n, m, xyz, temp, idx);
+        } else {
+            (void)hipFuncSetAttribute((const void*)fps_slotprune_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((fps_slotprune_kernel<8>), dim3(b), dim3(1024), lds, s, n, m, xyz, temp, idx);
+        }
+        return check_launch("fps(slot-pruned)");
+    }
+    if (prune == 1 && bs == 1024 && n % 1024 == 0 && (J == 4 || J == 8 || J == 16) && m > 1) {
         const size_t need = (size_t)n * 8;   // sort buffer; the loop uses n*4 (rank -> index) + candidates + staged picks
         const size_t loop_lds = (size_t)n * 4 + 2 * 16 * sizeof(FpsCandP) + FPS_OUT_CHUNK * sizeof(int);
         const size_t lds = need > loop_lds ? need : loop_lds;

@@ -53,8 +53,11 @@ def test_fps_all_equal_and_golden(oracle):
         assert np.array_equal(farthest_point_sample(T(g[f"{tag}_xyz"]), want.shape[1]).cpu().numpy(), want), tag
 
 
-def test_fps_pruned_variant_bit_exact():
-    """the spatially pruned kernel (off by default, JM_FPS_PRUNE=1) must give the same picks"""
+@pytest.mark.parametrize("variant", ["1", "2"])
+def test_fps_pruned_variants_bit_exact(variant):
+    """the spatially pruned kernels (JM_FPS_PRUNE=1: wave clusters, off; =2: slot clusters) must give the
+    same picks as the plain scan — golden cloud, duplicates (permanent ties), a grid (ties across clusters),
+    identical points (every pair tied), 8192 and 16384 points"""
     import os
     import subprocess
     import sys
@@ -62,17 +65,20 @@ def test_fps_pruned_variant_bit_exact():
         "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
         "from jmodt_amd import synth\n"
         "from jmodt_amd.ops.pointnet2.pointnet2_utils import farthest_point_sample\n"
+        "from oracle import oracle as o\n"
         "g = np.load(%r)\n"
-        "ok = True\n"
-        "for tag in ('n16384',):\n"
-        "    ok &= np.array_equal(farthest_point_sample(torch.from_numpy(g[tag + '_xyz']).cuda(), g[tag + '_idx'].shape[1]).cpu().numpy(), g[tag + '_idx'])\n"
-        "x = synth.cloud(2, 4096, seed=9, dup_frac=0.2); from oracle import oracle as o\n"
-        "ok &= np.array_equal(farthest_point_sample(torch.from_numpy(x).cuda(), 700).cpu().numpy(), o.furthest_point_sample(x, 700))\n"
+        "ok = np.array_equal(farthest_point_sample(torch.from_numpy(g['n16384_xyz']).cuda(), g['n16384_idx'].shape[1]).cpu().numpy(), g['n16384_idx'])\n"
+        "cases = [synth.cloud(2, 4096, seed=9, dup_frac=0.2), synth.cloud(2, 16384, seed=10, dup_frac=0.3),\n"
+        "         synth.cloud(1, 16384, seed=11, quantize=2.0 ** -1), synth.cloud(2, 8192, seed=12, dup_frac=0.1),\n"
+        "         np.full((1, 16384, 3), 0.25, np.float32), synth.dense_cloud(1, 16384, 13)]\n"
+        "for x in cases:\n"
+        "    m = 600 if x.shape[1] > 4096 else 700\n"
+        "    ok &= np.array_equal(farthest_point_sample(torch.from_numpy(x).cuda(), m).cpu().numpy(), o.furthest_point_sample(x, m))\n"
         "print('PRUNED_OK' if ok else 'PRUNED_MISMATCH')\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
          os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fps.npz"))
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, JM_FPS_PRUNE="1"), capture_output=True,
-                         text=True, timeout=300)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, JM_FPS_PRUNE=variant), capture_output=True,
+                         text=True, timeout=600)
     assert "PRUNED_OK" in out.stdout, out.stdout + out.stderr
 
 
