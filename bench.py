@@ -64,14 +64,15 @@ class KernelTimer:
     def summary(self, steps):
         rows = []
         for name, evs in self.records.items():
-            ms = sum(s.elapsed_time(e) for s, e, _, _ in evs) / steps
+            times = [s.elapsed_time(e) for s, e, _, _ in evs]
+            ms = sum(times) / steps
             nbytes = sum(b for _, _, b, _ in evs) / steps
             flops = sum(f for _, _, _, f in evs) / steps
             launches = len(evs) / steps
             gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             row = dict(kernel=name, ms_per_step=round(ms, 5), launches_per_step=launches,
                        algo_bytes_per_step=int(nbytes), achieved_gbs=round(gbs, 2),
-                       hbm_frac=round(gbs / HBM_PEAK_GBS, 5))
+                       hbm_frac=round(gbs / HBM_PEAK_GBS, 5), max_launch_ms=round(max(times), 5))
             if flops:   # time covers the whole op (both MLP layers + softmax + se path)
                 tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
                 row.update(achieved_tflops=round(tf, 2), mfma_frac=round(tf / MFMA_F32_PEAK_TF, 4))
@@ -316,9 +317,12 @@ def main():
     else:
         dense_in = make_dense_inputs(args.batch, 1234 + 4 + rank, dev)
         step = lambda: dense_step(dense_in, timer)  # noqa: E731
+    import gc
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()   # a generation-2 collection in the middle of the timed region is a 30-40 ms host stall
     if dist is not None:
         dist.barrier()
     timer.enabled = True

@@ -20,7 +20,8 @@ MAP = {
     "group_points_feat_L2": ("sa", "group_points_kernel<true>"),
     "roipool3d": ("ops", "roipool3d_kernel"),
     "three_interpolate_FP4": ("ops", "three_interpolate_lds_kernel"),
-    "feature_gather_5": ("ops", "feature_gather_kernel"),
+    "feature_gather_5": ("ops", "feature_gather_rowpair_kernel"),
+    "feature_gather_5_channels_last": ("ops", "feature_gather_cl_kernel"),
     "three_nn_FP4": ("ops", "three_nn_kernel"),
     "rcnn_sa1_fused(fps+ball+group+mlp+max)": ("ops", "sa_mlp_kernel"),
     "nms_normal_6300": ("ops", "nms_mask_kernel<true>"),
