@@ -180,6 +180,14 @@ size_t jm_proposal_select_workspace_bytes(int b, int distance_based, int pre_nms
 int jm_proposal_select(int b, int n, const float* scores, const float* proposals, const int64_t* order,
                        int distance_based, int pre_nms_top_n, int post_nms_top_n, float nms_thresh, int nms_normal,
                        float* out_boxes, float* out_scores, void* ws, size_t ws_bytes, jm_stream_t stream);
+/* RPN box decode = decode_bbox_target as ProposalLayer calls it (proposal_layer.py:24-34;
+ * bbox_transform.py:27-260 with get_xz_fine=True, get_y_by_bin=False, get_ry_fine=False, RY_WITH_BIN=False):
+ * xyz (P,3), rpn_reg (P, 4*nb + 1 + 2*num_head_bin + 3) with nb = int(loc_scope / loc_bin_size) * 2,
+ * anchor_hwl = HOST pointer to cfg.CLS_MEAN_SIZE[0] (3 floats), avg_by_bin = cfg.*.BBOX_AVG_BY_BIN.
+ * proposals (P,7) = [x, y_bottom, z, h, w, l, ry] (the `+= h/2` of proposal_layer.py:33 included). */
+int jm_decode_rpn_proposals(long long num_points, int reg_channels, const float* xyz, const float* rpn_reg,
+                            float loc_scope, float loc_bin_size, int num_head_bin, const float* anchor_hwl,
+                            int avg_by_bin, float* proposals, jm_stream_t stream);
 /* mask only (N, ceil(N/64)) uint64; tiles with col_block < row_block are never consumed by the
  * reduce (iou3d.cpp:108) and are left unwritten. */
 int jm_nms_mask(int boxes_num, const float* boxes, float nms_overlap_thresh, int normal,

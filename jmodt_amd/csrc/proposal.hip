@@ -190,3 +190,79 @@ extern "C" int jm_proposal_select(int b, int n, const float* scores, const float
                        proposals, w.src, (const long long*)w.keep, w.num_keep, out_boxes, out_scores);
     return check_launch("proposal_stitch");
 }
+
+// ------------------------------------------------------------------------------------------------
+// RPN box decode (the first half of ProposalLayer.forward, proposal_layer.py:24-34 ->
+// decode_bbox_target, jmodt/utils/bbox_transform.py:27-260) for the RPN's configuration:
+// roi = the point itself (N,3), get_xz_fine = True, get_y_by_bin = False, get_ry_fine = False,
+// RY_WITH_BIN = False.  One thread per point, the 4*nb + 1 + 2*nh + 3 regression channels of a point read
+// as 16-byte vectors.  avg_by_bin selects cfg.*.BBOX_AVG_BY_BIN (config.py:197,207,216 default True):
+//   1: x = sum_i softmax(bin)_i * (centre_i + res_i * bin_size)        (:74-103)
+//   0: x = centre_argmax + res_argmax * bin_size                        (:52-72)
+// heading: argmax bin, ry = (bin * 2pi/nh + res * pi/nh) mod 2pi, wrapped to (-pi, pi]  (:127-145)
+// size: res * anchor + anchor (:237-242); y = point y + offset, then += h / 2 (proposal_layer.py:33).
+// NOTE parity: the reference function cannot be imported in the authoring container (jmodt.config needs
+// easydict), so this kernel is checked against the oracle's restatement only ("parity unpinned").
+namespace jm {
+
+__global__ void __launch_bounds__(256)
+decode_rpn_kernel(long long total, int C, int nb, int nh, float loc_scope, float bin_size, float a_h, float a_w,
+                  float a_l, int avg_by_bin, const float* __restrict__ xyz, const float* __restrict__ reg,
+                  float* __restrict__ out) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    const float* r = reg + p * C;
+    auto axis = [&](int bin_off, int res_off) {
+        if (avg_by_bin) {
+            float mx = -INFINITY;
+            for (int i = 0; i < nb; ++i) mx = fmaxf(mx, r[bin_off + i]);
+            float den = 0.f, num = 0.f;
+            for (int i = 0; i < nb; ++i) {
+                const float e = expf(r[bin_off + i] - mx);
+                const float centre = (float)i * bin_size + bin_size / 2 - loc_scope;
+                den += e;
+                num += e * (centre + r[res_off + i] * bin_size);
+            }
+            return num / den;
+        }
+        int best = 0;
+        float bv = r[bin_off];
+        for (int i = 1; i < nb; ++i) if (r[bin_off + i] > bv) { bv = r[bin_off + i]; best = i; }   // first maximum
+        return (float)best * bin_size + bin_size / 2 - loc_scope + r[res_off + best] * bin_size;
+    };
+    const float pos_x = axis(0, 2 * nb) + xyz[p * 3 + 0];
+    const float pos_z = axis(nb, 3 * nb) + xyz[p * 3 + 2];
+    int off = 4 * nb;
+    float pos_y = xyz[p * 3 + 1] + r[off];
+    off += 1;
+    int rb = 0;
+    float rv = r[off];
+    for (int i = 1; i < nh; ++i) if (r[off + i] > rv) { rv = r[off + i]; rb = i; }
+    const float two_pi = 6.283185307179586f, pi = 3.141592653589793f;
+    const float apc = two_pi / (float)nh;
+    float ry = fmodf((float)rb * apc + r[off + nh + rb] * (apc / 2), two_pi);
+    if (ry < 0.f) ry += two_pi;          // python % is non-negative
+    if (ry > pi) ry -= two_pi;
+    off += 2 * nh;
+    const float h = r[off] * a_h + a_h, w = r[off + 1] * a_w + a_w, l = r[off + 2] * a_l + a_l;
+    pos_y += h / 2;                      // proposal_layer.py:33: y becomes the bottom centre
+    float* o = out + p * 7;
+    o[0] = pos_x; o[1] = pos_y; o[2] = pos_z; o[3] = h; o[4] = w; o[5] = l; o[6] = ry;
+}
+
+}  // namespace jm
+
+extern "C" int jm_decode_rpn_proposals(long long num_points, int reg_channels, const float* xyz, const float* rpn_reg,
+                                       float loc_scope, float loc_bin_size, int num_head_bin, const float* anchor_hwl,
+                                       int avg_by_bin, float* proposals, jm_stream_t stream) {
+    JM_REQUIRE(num_points >= 0 && loc_bin_size > 0.f && num_head_bin >= 1 && anchor_hwl, "decode_rpn: bad arguments");
+    if (num_points == 0) return JM_OK;
+    JM_REQUIRE(xyz && rpn_reg && proposals, "decode_rpn: null pointer");
+    const int nb = (int)(loc_scope / loc_bin_size) * 2;          // per_loc_bin_num (bbox_transform.py:45)
+    JM_REQUIRE(nb >= 1 && reg_channels == 4 * nb + 1 + 2 * num_head_bin + 3,
+               "decode_rpn: %d regression channels, expected 4*%d + 1 + 2*%d + 3", reg_channels, nb, num_head_bin);
+    hipLaunchKernelGGL(decode_rpn_kernel, dim3((unsigned)divup(num_points, 256LL)), dim3(256), 0, (hipStream_t)stream,
+                       num_points, reg_channels, nb, num_head_bin, loc_scope, loc_bin_size, anchor_hwl[0], anchor_hwl[1],
+                       anchor_hwl[2], avg_by_bin ? 1 : 0, xyz, rpn_reg, proposals);
+    return check_launch("decode_rpn");
+}

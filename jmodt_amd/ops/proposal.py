@@ -12,8 +12,10 @@ rest is `jm_proposal_select` (csrc/proposal.hip): one compaction kernel, the 2 B
 ONE batched launch pair with device-side counts, one stitch kernel — the only sync is whatever
 the caller does with the result.
 
-The bin-based box decode (bbox_transform.py:28-132) is not part of this module: it takes decoded
-proposals (B, N, 7) [x, y_bottom, z, h, w, l, ry].
+`decode_rpn_proposals` is the bin-based box decode in front of it (bbox_transform.py:27-260 in the RPN's
+configuration); `proposal_layer` chains the two.  The decode's parity is UNPINNED: the reference function
+cannot be imported where the fixtures are made (jmodt.config needs easydict), so it is tested against the
+oracle's restatement and an independent torch restatement only.
 """
 import ctypes
 from typing import Tuple
@@ -43,6 +45,40 @@ def _select(scores, proposals, distance_based, pre, post, thresh, normal):
                                    ctypes.c_void_p(out_scores.data_ptr()), ctypes.c_void_p(base), ws_bytes,
                                    L.stream_ptr()), "proposal_select")
     return out_boxes, out_scores
+
+
+CLS_MEAN_SIZE = (1.52563191462, 1.62856739989, 3.88311640418)   # cfg.CLS_MEAN_SIZE[0] (config.py:38): h, w, l
+
+
+@torch.no_grad()
+def decode_rpn_proposals(xyz: torch.Tensor, rpn_reg: torch.Tensor, loc_scope: float = 3.0, loc_bin_size: float = 0.5,
+                         num_head_bin: int = 12, anchor_size=CLS_MEAN_SIZE, avg_by_bin: bool = True) -> torch.Tensor:
+    """xyz (B, N, 3), rpn_reg (B, N, C) -> proposals (B, N, 7) [x, y_bottom, z, h, w, l, ry]
+    = decode_bbox_target(xyz, rpn_reg, ...) followed by `proposals[:, 1] += proposals[:, 3] / 2`
+    (proposal_layer.py:24-34; defaults = cfg.RPN.* of config.py:65-68, BBOX_AVG_BY_BIN of config.py:207)"""
+    lib = L.load()
+    B, N, C = rpn_reg.shape
+    xyz = xyz.contiguous().to(_f32)
+    rpn_reg = rpn_reg.contiguous().to(_f32)
+    out = torch.empty((B, N, 7), dtype=_f32, device=xyz.device)
+    anchor = (ctypes.c_float * 3)(*[float(a) for a in anchor_size])
+    L.check(lib.jm_decode_rpn_proposals(B * N, C, L.dev(xyz, _f32, "xyz"), L.dev(rpn_reg, _f32, "rpn_reg"),
+                                        float(loc_scope), float(loc_bin_size), int(num_head_bin), anchor,
+                                        int(bool(avg_by_bin)), ctypes.c_void_p(out.data_ptr()), L.stream_ptr()),
+            "decode_rpn_proposals")
+    return out
+
+
+@torch.no_grad()
+def proposal_layer(rpn_scores: torch.Tensor, rpn_reg: torch.Tensor, xyz: torch.Tensor, pre_nms_top_n: int = 9000,
+                   post_nms_top_n: int = 100, nms_thresh: float = 0.8, nms_type: str = "normal",
+                   distance_based: bool = True, **decode_kw) -> Tuple[torch.Tensor, torch.Tensor]:
+    """ProposalLayer.forward (proposal_layer.py:16-55) for a whole batch: decode + selection, 6 launches.
+    Defaults = the TEST configuration (config.py:226-230)."""
+    proposals = decode_rpn_proposals(xyz, rpn_reg, **decode_kw)
+    if distance_based:
+        return distance_based_proposal(rpn_scores, proposals, pre_nms_top_n, post_nms_top_n, nms_thresh, nms_type)
+    return score_based_proposal(rpn_scores, proposals, pre_nms_top_n, post_nms_top_n, nms_thresh)
 
 
 @torch.no_grad()

@@ -285,6 +285,47 @@ def nms(boxes, scores, thresh, normal):
     return order[keep].astype(np.int64)
 
 
+def decode_rpn_proposals(xyz, rpn_reg, loc_scope=3.0, loc_bin_size=0.5, num_head_bin=12,
+                         anchor_size=(1.52563191462, 1.62856739989, 3.88311640418), avg_by_bin=True):
+    """decode_bbox_target as ProposalLayer calls it + `y += h / 2` (proposal_layer.py:24-34;
+    bbox_transform.py:27-260 with roi = xyz (N,3), get_xz_fine=True, get_y_by_bin=False, get_ry_fine=False,
+    RY_WITH_BIN=False), float32.  PARITY UNPINNED: restated from reading the reference; the reference
+    function itself is not importable here (jmodt.config -> easydict)."""
+    xyz = _f32(xyz).reshape(-1, 3)
+    reg = _f32(rpn_reg).reshape(xyz.shape[0], -1)
+    f = np.float32
+    nb = int(loc_scope / loc_bin_size) * 2
+    bs, sc = f(loc_bin_size), f(loc_scope)
+
+    def axis(bin_off, res_off):
+        if avg_by_bin:                                              # :74-103
+            z = reg[:, bin_off:bin_off + nb]
+            e = np.exp(z - z.max(1, keepdims=True)).astype(f)
+            pbin = e / e.sum(1, keepdims=True, dtype=f)
+            centre = (np.arange(nb, dtype=f) * bs + bs / f(2) - sc).astype(f)
+            absx = centre[None] + reg[:, res_off:res_off + nb] * bs
+            return (absx * pbin).sum(1, dtype=f)
+        b = np.argmax(reg[:, bin_off:bin_off + nb], 1)              # :52-72
+        res = np.take_along_axis(reg[:, res_off:res_off + nb], b[:, None], 1)[:, 0]
+        return (b.astype(f) * bs + bs / f(2) - sc + res * bs).astype(f)
+
+    pos_x = axis(0, 2 * nb) + xyz[:, 0]
+    pos_z = axis(nb, 3 * nb) + xyz[:, 2]
+    off = 4 * nb
+    pos_y = xyz[:, 1] + reg[:, off]
+    off += 1
+    rb = np.argmax(reg[:, off:off + num_head_bin], 1)
+    rres = np.take_along_axis(reg[:, off + num_head_bin:off + 2 * num_head_bin], rb[:, None], 1)[:, 0]
+    apc = f(2 * np.pi / num_head_bin)
+    ry = np.mod(rb.astype(f) * apc + rres * (apc / f(2)), f(2 * np.pi)).astype(f)   # :137-145
+    ry = np.where(ry > f(np.pi), ry - f(2 * np.pi), ry).astype(f)
+    off += 2 * num_head_bin
+    anchor = np.asarray(anchor_size, dtype=f)
+    hwl = reg[:, off:off + 3] * anchor + anchor
+    out = np.concatenate([pos_x[:, None], (pos_y + hwl[:, 0] / f(2))[:, None], pos_z[:, None], hwl, ry[:, None]], 1)
+    return out.astype(f).reshape(np.shape(rpn_reg)[:-1] + (7,))
+
+
 def proposal_select(scores, proposals, pre_nms_top_n, post_nms_top_n, nms_thresh, nms_type="normal",
                     distance_based=True):
     """ProposalLayer.forward after the decode, frame by frame (proposal_layer.py:34-55) with

@@ -589,6 +589,25 @@ def test_proposal_select_distance_based(oracle, B, N, pre, post, thresh, nms_typ
     assert (want_s != 0).any(axis=1).all()
 
 
+@pytest.mark.parametrize("avg_by_bin", [True, False])
+def test_decode_rpn_proposals_and_whole_proposal_layer(oracle, avg_by_bin):
+    """RPN box decode vs the oracle restatement (1e-4; parity unpinned, see ops/proposal.py), then the whole
+    ProposalLayer (decode + selection) on the device vs the oracle selection fed with the same decoded boxes"""
+    from jmodt_amd.ops.proposal import decode_rpn_proposals, proposal_layer
+    rng = np.random.default_rng(11)
+    B, N = 3, 16384
+    xyz = synth.cloud(B, N, seed=21)
+    reg = rng.normal(0, 1.5, (B, N, 76)).astype(np.float32)
+    scores = (rng.permutation(B * N).reshape(B, N).astype(np.float32) - B * N / 2) / np.float32(B * N / 8)
+    dec = decode_rpn_proposals(T(xyz), T(reg), avg_by_bin=avg_by_bin)
+    want = oracle.decode_rpn_proposals(xyz, reg, avg_by_bin=avg_by_bin)
+    assert dec.shape == (B, N, 7)
+    assert np.abs(dec.cpu().numpy() - want).max() < 1e-4
+    boxes, sc = proposal_layer(T(scores), T(reg), T(xyz), avg_by_bin=avg_by_bin)
+    wb, ws = oracle.proposal_select(scores, dec.cpu().numpy(), 9000, 100, 0.8, "normal")
+    assert np.array_equal(sc.cpu().numpy(), ws) and np.array_equal(boxes.cpu().numpy(), wb)
+
+
 def test_proposal_select_score_based(oracle):
     from jmodt_amd.ops.proposal import score_based_proposal
     scores, props = synth.rpn_output(3, 4096, seed=77)
