@@ -25,4 +25,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
     run sa_pmc_$c  "--pmc $c" "--pmc" --steps 3 --warmup 1 --no-cpu-baseline
     run ops_pmc_$c "--pmc $c" "--pmc" --workload ops --steps 3 --warmup 1 --no-cpu-baseline
 done
+# matrix-core counters for the MFMA kernels (fused SA block, affinity GEMMs): one counter per pass
+for c in MfmaUtil SQ_INSTS_VALU_MFMA_MOPS_F32; do
+    run ops_pmc_$c "--pmc $c" "--pmc" --workload ops --steps 3 --warmup 1 --no-cpu-baseline
+done
 ls -la "$OUT"
