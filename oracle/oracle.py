@@ -67,13 +67,14 @@ def opt_n_threads(n):
     return lib().orc_opt_n_threads(int(n))
 
 
-def furthest_point_sample(xyz, npoint):
+def furthest_point_sample(xyz, npoint, return_temp=False):
+    """idx (B, npoint) int32 [, temp (B, N): the running min-distance buffer as the kernel leaves it]"""
     xyz = _f32(xyz)
     B, N, _ = xyz.shape
     temp = np.full((B, N), 1e10, dtype=np.float32)
     idx = np.zeros((B, npoint), dtype=np.int32)
     lib().orc_furthest_point_sampling(B, N, int(npoint), _p(xyz, _f), _p(temp, _f), _p(idx, _i))
-    return idx
+    return (idx, temp) if return_temp else idx
 
 
 def gather_operation(features, idx):

@@ -44,6 +44,23 @@ def test_fps_bit_exact(oracle, B, N, m, kw):
     assert np.array_equal(got, oracle.furthest_point_sample(xyz, m))
 
 
+@pytest.mark.parametrize("B,N,m", [(2, 1000, 100), (2, 4096, 300), (1, 16384, 200), (3, 256, 64), (40, 512, 128),
+                                   (2, 40000, 120)])
+def test_fps_extension_level_temp_buffer(oracle, B, N, m):
+    """pointnet2_cuda.farthest_point_sampling_wrapper also leaves `temp` (the caller's 1e10-filled scratch,
+    pointnet2_utils.py:25-27) exactly as the reference kernel does: the running min-distances after m-1
+    updates — checked for the single-wave, multi-wave and co-operative kernels"""
+    from jmodt_amd.ext import pointnet2_cuda
+    xyz = synth.cloud(B, N, seed=N + m, dup_frac=0.05)
+    t = T(xyz)
+    temp = torch.full((B, N), 1e10, dtype=torch.float32, device=DEV)
+    idx = torch.zeros((B, m), dtype=torch.int32, device=DEV)
+    assert pointnet2_cuda.farthest_point_sampling_wrapper(B, N, m, t, temp, idx) == 1
+    want_idx, want_temp = oracle.furthest_point_sample(xyz, m, return_temp=True)
+    assert np.array_equal(idx.cpu().numpy(), want_idx)
+    assert np.array_equal(temp.cpu().numpy(), want_temp)
+
+
 def test_fps_all_equal_and_golden(oracle):
     from jmodt_amd.ops.pointnet2.pointnet2_utils import farthest_point_sample
     assert not farthest_point_sample(T(np.ones((2, 300, 3), np.float32)), 20).cpu().numpy().any()
