@@ -651,3 +651,30 @@ def test_fps_pyramid_side_stream_matches_sequential(oracle):
             assert np.array_equal(new_xyz.cpu().numpy(), nxt)
             assert np.array_equal(nb.cpu().numpy(), oracle.ball_query(0.8, 16, cur, nxt))
             cur = nxt
+
+
+# ------------------------------------------------------------------ BASELINE configs[4] sizes (dense scene)
+def test_dense_config_sizes_vs_oracle(oracle):
+    """65536-point cloud: dual ball query, 3-NN, roipool3d + canonical transform for 256 RoIs — the index
+    outputs bit-exact against the oracle at full size (one frame)"""
+    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
+    from jmodt_amd.ops.roipool3d.roipool3d_utils import roipool3d_canonical_gpu
+    N, m = 65536, 4096
+    xyz = synth.cloud(1, N, seed=65)
+    t = T(xyz)
+    idx = pu.farthest_point_sample(t, m)
+    new_xyz = pu.gather_operation(t.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+    nx = new_xyz.cpu().numpy()
+    i0, i1 = pu.ball_query_dual(0.1, 16, 0.5, 32, t, new_xyz)
+    assert np.array_equal(i0.cpu().numpy(), oracle.ball_query(0.1, 16, xyz, nx))
+    assert np.array_equal(i1.cpu().numpy(), oracle.ball_query(0.5, 32, xyz, nx))
+    dist, nn = pu.three_nn(t, new_xyz)
+    wd, wi = oracle.three_nn(xyz, nx)
+    assert np.array_equal(nn.cpu().numpy(), wi) and np.abs(dist.cpu().numpy() - np.sqrt(wd)).max() < 1e-5
+    boxes = synth.proposals(xyz, 256, 66)
+    feat = np.random.default_rng(67).normal(size=(1, N, 16)).astype(np.float32)
+    got, flag = roipool3d_canonical_gpu(t, T(feat), T(boxes), 0.2, 512)
+    want, wflag = oracle.roipool3d_canonical(xyz, feat, boxes, 0.2, 512)
+    assert np.array_equal(flag.cpu().numpy(), wflag)
+    g = got.cpu().numpy()
+    assert np.array_equal(g[..., 3:], want[..., 3:]) and np.abs(g[..., :3] - want[..., :3]).max() < 1e-4
