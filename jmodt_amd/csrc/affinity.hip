@@ -20,6 +20,16 @@
 //    tile against w3 and adds one partial per row into the score vector — the second hidden
 //    activation is never written either.
 //  * Dual softmax and the start/end feature means are small bandwidth-trivial kernels.
+//
+// Tried and rejected (MI355X, 128^2 / 256^2 pairs; this kernel: 216 / 759 us per affinity call):
+//  * a wave-specialised persistent variant (4 MFMA waves + 4 loader waves forming |p - d| chunks, weights
+//    straight from L2 in the packed layout of sa_mlp.hip): 236 / 728 us.  In-kernel cycle counters: the MFMA
+//    stream itself runs at 87 % of the pipe, but a wave that shares a SIMD with an MFMA wave gets roughly
+//    one VALU issue slot per MFMA — the loader needed 21 k cycles per 128-deep chunk (5.5 k alone) against
+//    19 k of MFMA work, so the MFMA waves waited for it;
+//  * the same tiling as here with packed weights from L2 and A staged 64 deep (1 barrier per 4 k-tiles):
+//    270 / 893 us.
+//  MfmaUtil of this kernel: 54-56 % (profiles/r01_ops_pmc_MfmaUtil.txt).
 #include <stdlib.h>
 
 #include <mutex>
@@ -183,11 +193,9 @@ mlp_gemm_kernel(GemmGroup grp) {
         if (EMODE == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = part[r];
-                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+                const float v = half_sum_f32_dpp(part[r]);   // sum over the 32 columns of this lane half
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (lr == 0 && row < p.M) unsafeAtomicAdd(p.score + row, v);
+                if (lr == 31 && row < p.M) unsafeAtomicAdd(p.score + row, v);
             }
         }
     }
@@ -260,10 +268,8 @@ mlp_gemm_small_kernel(GemmParams p) {
         if (EMODE == 0) {
             if (cok && orow < p.M) p.H[(size_t)orow * p.N + c] = hval;
         } else {
-            float v = hval * wv;
-            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
-            v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
-            if (r == 0 && orow < p.M) unsafeAtomicAdd(p.score + orow, v);
+            const float v = half_sum_f32_dpp(hval * wv);
+            if (r == 31 && orow < p.M) unsafeAtomicAdd(p.score + orow, v);
         }
     }
 }

@@ -65,6 +65,26 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// float sum over each 32-lane half of the wave (lanes 0-31 / 32-63); the total is valid in the UPPER
+// 16 lanes of each half (16-31 / 48-63).  5 fused DPP adds; a __shfl_xor tree costs a ds_bpermute
+// round trip per step.
+__device__ __forceinline__ float half_sum_f32_dpp(float v) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return v;
+}
+
 // bitwise OR over the 64 lanes (same DPP pattern as wave_max_i32), wave-uniform result
 __device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
     asm volatile(

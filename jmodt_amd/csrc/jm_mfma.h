@@ -1,0 +1,85 @@
+// jm_mfma.h — the fp32 MFMA inner block shared by the fused SA kernel (sa_mlp.hip) and the affinity GEMMs
+// (affinity.hip): A operand k-major in LDS, B operand straight from L1/L2 in the packed layout of
+// jm_sa_mlp_pack ( Wp[kt][n][khalf][kk] = W[n][16 kt + 2 kk + khalf] ), one k-tile of register prefetch,
+// no barrier inside.
+#pragma once
+#include "jm_common.h"
+
+namespace jm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int SM_BM = 128, SM_LDP = SM_BM + 4;   // rows per tile, padded row stride of the k-major LDS tiles
+
+__host__ __device__ inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+// acc += A(128 rows x 16 nkt, LDS k-major) x W-tile; this wave owns rows wm*64.., columns of bp (+32 if TWO)
+//   A      : LDS buffer [k][SM_LDP]
+//   bp     : this lane's packed weights for k-tile 0 of the range; kt_stride floats per k-tile
+//   bpre   : in  = k-tile 0's B operand, already loaded by the previous stage;
+//            out = the first B operand of the NEXT stage (next_bp)
+template <bool TWO>
+__device__ __forceinline__ void mfma_ktiles(const float* __restrict__ A, int nkt, const float* __restrict__ bp,
+                                            size_t kt_stride, int a_off, f32x16 (&acc)[2][2], float4 (&bpre)[4],
+                                            const float* __restrict__ next_bp) {
+    float4 bc[4], bn[4];
+    float ac[16], an[16];
+    auto loadB = [&](float4 (&b)[4], const float* q) {
+        b[0] = *reinterpret_cast<const float4*>(q);
+        b[1] = *reinterpret_cast<const float4*>(q + 4);
+        b[2] = *reinterpret_cast<const float4*>(q + 512);       // column + 32: (32 * 2) * 8 floats on
+        b[3] = *reinterpret_cast<const float4*>(q + 516);
+    };
+    auto loadA = [&](float (&a)[16], int kt) {
+        const float* q = A + (size_t)kt * 16 * SM_LDP + a_off;       // a_off = khalf * SM_LDP + wm * 64 + lr
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            a[2 * kk] = q[(2 * kk) * SM_LDP];
+            a[2 * kk + 1] = q[(2 * kk) * SM_LDP + 32];
+        }
+    };
+    auto mm = [&](const float (&a)[16], const float4 (&b)[4]) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const float b0 = reinterpret_cast<const float*>(&b[0])[kk];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * kk], b0, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * kk + 1], b0, acc[1][0], 0, 0, 0);
+            if (TWO) {
+                const float b1 = reinterpret_cast<const float*>(&b[2])[kk];
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * kk], b1, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * kk + 1], b1, acc[1][1], 0, 0, 0);
+            }
+        }
+    };
+    // sched_barrier(0): keep the prefetches where they are written — left alone, the scheduler sinks
+    // them to their first use and the L2 latency lands on the MFMA pipe
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bc[q] = bpre[q];
+    loadA(ac, 0);
+    int kt = 0;
+    for (; kt + 2 <= nkt; kt += 2) {
+        loadB(bn, bp + (size_t)(kt + 1) * kt_stride);
+        loadA(an, kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ac, bc);
+        __builtin_amdgcn_sched_barrier(0);
+        // the k-tile after next — or, on the last trip, the NEXT stage's first B operand;
+        // unconditional loads on a selected address, no branchy waits
+        const bool more = kt + 2 < nkt;
+        loadB(bc, more ? bp + (size_t)(kt + 2) * kt_stride : next_bp);
+        loadA(ac, more ? kt + 2 : kt);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(an, bn);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kt < nkt) {            // odd tail: bc / ac hold k-tile nkt-1
+        loadB(bpre, next_bp);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ac, bc);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bpre[q] = bc[q];
+    }
+}
+
+}  // namespace jm

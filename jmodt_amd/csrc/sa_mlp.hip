@@ -32,18 +32,14 @@
 // v_mfma_f32_32x32x2_f32 everywhere: exact-f32 products (1e-4 parity with the fp32 reference path).
 // Constraints (the Python module falls back to the unfused path otherwise): nsample in {16,32,64},
 // npoint*nsample % 128 == 0, hidden widths <= 128, eval-mode BatchNorm (folded by the caller).
-#include "jm_common.h"
+#include "jm_mfma.h"
 
 namespace jm {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int SM_BM = 128, SM_KC = 144, SM_LDP = SM_BM + 4;   // 144: 3 + 128 channels (both RCNN SA levels) in one chunk
+constexpr int SM_KC = 144;   // channels per activation buffer: 3 + 128 (both RCNN SA levels) in one chunk
 constexpr int SM_GRP = SM_KC / 16;                     // gather groups (16 channels each) per chunk
 constexpr int SM_BUF = SM_KC * SM_LDP;                 // floats per activation buffer
 constexpr size_t SM_LDS_BYTES = 2 * (size_t)SM_BUF * sizeof(float);
-
-__host__ __device__ inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 
 struct SaMlpParams {
     int N, M, C, ns;                 // points per frame, centres per frame, feature channels, nsample
@@ -238,75 +234,6 @@ __device__ __forceinline__ void sa_gather_role(const SaMlpParams& p, float* lds,
 }
 
 // =============================================================================== MFMA role
-// acc += A(128 rows x 16 nkt, LDS k-major) x W-tile; this wave owns rows wm*64.., columns of bp (+32 if TWO)
-//   A      : LDS buffer [k][SM_LDP]
-//   bp     : this lane's packed weights for k-tile 0 of the range; kt_stride floats per k-tile
-//   bpre   : in  = k-tile 0's B operand, already loaded by the previous stage;
-//            out = the first B operand of the NEXT stage (next_bp)
-template <bool TWO>
-__device__ __forceinline__ void mfma_ktiles(const float* __restrict__ A, int nkt, const float* __restrict__ bp,
-                                            size_t kt_stride, int a_off, f32x16 (&acc)[2][2], float4 (&bpre)[4],
-                                            const float* __restrict__ next_bp) {
-    float4 bc[4], bn[4];
-    float ac[16], an[16];
-    auto loadB = [&](float4 (&b)[4], const float* q) {
-        b[0] = *reinterpret_cast<const float4*>(q);
-        b[1] = *reinterpret_cast<const float4*>(q + 4);
-        b[2] = *reinterpret_cast<const float4*>(q + 512);       // column + 32: (32 * 2) * 8 floats on
-        b[3] = *reinterpret_cast<const float4*>(q + 516);
-    };
-    auto loadA = [&](float (&a)[16], int kt) {
-        const float* q = A + (size_t)kt * 16 * SM_LDP + a_off;       // a_off = khalf * SM_LDP + wm * 64 + lr
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            a[2 * kk] = q[(2 * kk) * SM_LDP];
-            a[2 * kk + 1] = q[(2 * kk) * SM_LDP + 32];
-        }
-    };
-    auto mm = [&](const float (&a)[16], const float4 (&b)[4]) {
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            const float b0 = reinterpret_cast<const float*>(&b[0])[kk];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * kk], b0, acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * kk + 1], b0, acc[1][0], 0, 0, 0);
-            if (TWO) {
-                const float b1 = reinterpret_cast<const float*>(&b[2])[kk];
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * kk], b1, acc[0][1], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * kk + 1], b1, acc[1][1], 0, 0, 0);
-            }
-        }
-    };
-    // sched_barrier(0): keep the prefetches where they are written — left alone, the scheduler sinks
-    // them to their first use and the L2 latency lands on the MFMA pipe
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bc[q] = bpre[q];
-    loadA(ac, 0);
-    int kt = 0;
-    for (; kt + 2 <= nkt; kt += 2) {
-        loadB(bn, bp + (size_t)(kt + 1) * kt_stride);
-        loadA(an, kt + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(ac, bc);
-        __builtin_amdgcn_sched_barrier(0);
-        // the k-tile after next — or, on the last trip, the NEXT stage's first B operand;
-        // unconditional loads on a selected address, no branchy waits
-        const bool more = kt + 2 < nkt;
-        loadB(bc, more ? bp + (size_t)(kt + 2) * kt_stride : next_bp);
-        loadA(ac, more ? kt + 2 : kt);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(an, bn);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (kt < nkt) {            // odd tail: bc / ac hold k-tile nkt-1
-        loadB(bpre, next_bp);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(ac, bc);
-    } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bpre[q] = bc[q];
-    }
-}
-
 __device__ __forceinline__ void sa_mfma_role(const SaMlpParams& p, float* lds, int tid) {
     const SaSchedule sch(p);
     if (sch.n_local == 0) return;
