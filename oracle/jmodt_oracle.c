@@ -8,12 +8,16 @@
  * Every function restates the algorithm of one reference kernel and cites it
  * (paths relative to /root/reference).  Pinning status:
  *   - roipool3d / pts_in_boxes3d : checked against the reference's own CPU code compiled from
- *     jmodt/ops/roipool3d/src/roipool3d.cpp (oracle/_ref, tests/test_oracle_vs_reference.py).
+ *     jmodt/ops/roipool3d/src/roipool3d.cpp (oracle/_ref; tests/test_oracle_cpu.py::test_roipool3d_vs_compiled_reference).
  *   - affinity head, feature_gather, boxes3d_to_bev/enlarge_box3d, 3D-IoU torch math : checked
  *     against the reference's importable Python / torch ops (tests/golden/make_golden.py).
  *   - FPS, ball_query, group/gather, three_nn, three_interpolate, BEV overlap, NMS : the
  *     reference has NO CPU code and NO tests for these ("parity unpinned" by the reference);
  *     pinned here against independent brute-force numpy restatements + analytic cases.
+ *   - oracle.py additionally restates, on top of these functions, the ProposalLayer selection
+ *     (proposal_layer.py:34-144), the RPN box decode (bbox_transform.py:27-260; PARITY UNPINNED: the
+ *     reference function is not importable here) and the canonical transformation after roipool3d
+ *     (proposal_target_layer.py:100-112).
  *
  * Floating-point conventions (build: gcc -O2 -ffp-contract=off):
  *   - squared distance in FPS / ball_query / three_nn uses the contraction nvcc/clang apply to
