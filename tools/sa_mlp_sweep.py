@@ -1,5 +1,5 @@
 """fused SA kernel timing on the RCNN SA1 shape (1024 RoIs x 512 pts x 128 ch, 128 centres, ns 64)
-    python tools/sa_mlp_sweep.py [dbg masks...]     (JM_SA_DBG ablation bits, one subprocess each)"""
+    R=<rois> python tools/sa_mlp_sweep.py"""
 import os
 import subprocess
 import sys
@@ -26,8 +26,6 @@ with torch.no_grad():
     e.record(); torch.cuda.synchronize()
     ms = s.elapsed_time(e) / 10
 fl = R * 128 * 64 * 2 * (131 * 128 + 128 * 128 + 128 * 128)
-print(f"  dbg={os.environ.get('JM_SA_DBG', '0'):>3} R={R}: {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TF  ({fl / ms / 1e9 / 157.3 * 100:.1f}% of fp32 MFMA peak)")
+print(f"  R={R}: {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TF  ({fl / ms / 1e9 / 157.3 * 100:.1f}% of fp32 MFMA peak)")
 '''
-for dbg in (sys.argv[1:] or ["0"]):
-    env = dict(os.environ, JM_SA_DBG=dbg)
-    subprocess.run([sys.executable, "-c", CHILD], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ), cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
