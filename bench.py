@@ -103,18 +103,17 @@ def sa_step(xyz, feats, timer, overlap=True):
         cur = xyz
         for li, lv in enumerate(SA_LEVELS):
             n, m = lv["n"], lv["m"]
-            idx = timer.run(f"fps_L{li + 1}", B * m * 20 * n, lambda: pu.farthest_point_sample(cur, m))
-            cur_t = cur.transpose(1, 2).contiguous()
-            new_xyz = timer.run("gather_points", B * (4 * m + 12 * n + 12 * m),
-                                lambda: pu.gather_operation(cur_t, idx)).transpose(1, 2).contiguous()
+            # sampling + coordinate gather in one call: nothing else sits between two FPS levels
+            idx, new_xyz = timer.run(f"fps_L{li + 1}", B * m * 20 * n, lambda: pu.farthest_point_sample_xyz(cur, m))
             ev = torch.cuda.Event()
             ev.record(side)
-            levels.append((cur, cur_t, new_xyz, ev))
+            levels.append((cur, new_xyz, ev))
             cur = new_xyz
     outs = []
     for li, lv in enumerate(SA_LEVELS):
         n, m, (r0, r1), (ns0, ns1), c = lv["n"], lv["m"], lv["radii"], lv["ns"], lv["c"]
-        cur, cur_t, new_xyz, ev = levels[li]
+        cur, new_xyz, ev = levels[li]
+        cur_t = cur.transpose(1, 2).contiguous()      # (B, 3, n) layout for group_points (cur is ready: previous event)
         main.wait_event(ev)
         i0, i1 = timer.run(f"ball_query_dual_L{li + 1}", B * (12 * n + 12 * m + 4 * m * (ns0 + ns1)),
                            lambda: pu.ball_query_dual(r0, ns0, r1, ns1, cur, new_xyz))

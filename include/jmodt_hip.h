@@ -51,6 +51,11 @@ int jm_furthest_point_sampling(int b, int n, int m, const float* xyz, float* tem
  * ws: >= jm_fps_workspace_bytes(b, n) bytes (0 when no workspace is needed), 64-byte aligned.  Two such
  * launches must not run concurrently on one device (their workgroups wait for each other). */
 size_t jm_fps_workspace_bytes(int b, int n);
+/* sampling + the gather of the sampled coordinates that always follows it (pointnet2_modules.py:35-39):
+ * additionally writes new_xyz (B, m, 3) = xyz[b, idx[b, j], :].  ws may be NULL when
+ * jm_fps_workspace_bytes(b, n) == 0. */
+int jm_furthest_point_sampling_xyz(int b, int n, int m, const float* xyz, float* temp, int* idx, float* new_xyz,
+                                   void* ws, size_t ws_bytes, jm_stream_t stream);
 int jm_furthest_point_sampling_ws(int b, int n, int m, const float* xyz, float* temp, int* idx, void* ws,
                                   size_t ws_bytes, jm_stream_t stream);
 

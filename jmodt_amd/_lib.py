@@ -32,6 +32,7 @@ SIGNATURES = {
     "jm_last_error": (ctypes.c_char_p, []),
     "jm_furthest_point_sampling": (_I, [_I, _I, _I, _P, _P, _P, _P]),
     "jm_fps_workspace_bytes": (_Z, [_I, _I]),
+    "jm_furthest_point_sampling_xyz": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "jm_furthest_point_sampling_ws": (_I, [_I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "jm_gather_points": (_I, [_I, _I, _I, _I, _P, _P, _P, _P]),
     "jm_gather_points_grad": (_I, [_I, _I, _I, _I, _P, _P, _P, _P]),

@@ -913,6 +913,18 @@ fps_stream_kernel(int n, int m, int bs_log2, const float* __restrict__ dataset, 
     }
 }
 
+// new_xyz[b, j, :] = xyz[b, idx[b, j], :]: the centres every caller gathers right after sampling
+// (pointnet2_modules.py:36-39 does it with two transposes around gather_operation)
+__global__ void fps_gather_xyz_kernel(int n, int m, long long total, const float* __restrict__ xyz,
+                                      const int* __restrict__ idx, float* __restrict__ new_xyz) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const long long b = e / m;
+    const float* q = xyz + ((size_t)b * n + idx[e]) * 3;
+    float* o = new_xyz + e * 3;
+    o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
+}
+
 static int opt_n_threads(int work_size) {
     // cuda_utils.h:10-14: 2^floor(log2 n) clamped to [1,1024].  Integer form (exact).
     int p = 0;
@@ -943,6 +955,17 @@ extern "C" int jm_furthest_point_sampling(int b, int n, int m, const float* xyz,
 extern "C" int jm_furthest_point_sampling_ws(int b, int n, int m, const float* xyz, float* temp, int* idx, void* ws,
                                              size_t ws_bytes, jm_stream_t stream) {
     return fps_impl(b, n, m, xyz, temp, idx, ws, ws_bytes, stream);
+}
+
+extern "C" int jm_furthest_point_sampling_xyz(int b, int n, int m, const float* xyz, float* temp, int* idx,
+                                              float* new_xyz, void* ws, size_t ws_bytes, jm_stream_t stream) {
+    int rc = fps_impl(b, n, m, xyz, temp, idx, ws, ws_bytes, stream);
+    if (rc || b == 0 || m == 0) return rc;
+    JM_REQUIRE(new_xyz, "fps_xyz: null new_xyz");
+    const long long total = (long long)b * m;
+    hipLaunchKernelGGL(jm::fps_gather_xyz_kernel, dim3((unsigned)jm::divup(total, 256LL)), dim3(256), 0, (hipStream_t)stream,
+                       n, m, total, xyz, idx, new_xyz);
+    return jm::check_launch("fps_xyz(gather)");
 }
 
 static int fps_impl(int b, int n, int m, const float* xyz, float* temp, int* idx, void* ws, size_t ws_bytes,

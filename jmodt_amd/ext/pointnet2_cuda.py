@@ -48,12 +48,20 @@ def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
 _coop_fps_done = {}   # device index -> event recorded after the last co-operative FPS launch
 
 
-def farthest_point_sampling_wrapper(b, n, m, points, temp, idx):
+def farthest_point_sampling_wrapper(b, n, m, points, temp, idx, new_xyz=None):
+    """reference signature (pointnet2_api.cpp:22) + optional new_xyz (B, m, 3): the sampled coordinates,
+    gathered inside the same call"""
     lib = L.load()
     ws_bytes = lib.jm_fps_workspace_bytes(b, n)
+    nx = L.dev(new_xyz, f32, "new_xyz") if new_xyz is not None else None
     if ws_bytes == 0:
-        L.check(lib.jm_furthest_point_sampling(b, n, m, L.dev(points, f32, "points"), L.dev(temp, f32, "temp"),
-                                               L.dev(idx, i32, "idx"), L.stream_ptr()), "farthest_point_sampling_wrapper")
+        if nx is None:
+            L.check(lib.jm_furthest_point_sampling(b, n, m, L.dev(points, f32, "points"), L.dev(temp, f32, "temp"),
+                                                   L.dev(idx, i32, "idx"), L.stream_ptr()), "farthest_point_sampling_wrapper")
+        else:
+            L.check(lib.jm_furthest_point_sampling_xyz(b, n, m, L.dev(points, f32, "points"), L.dev(temp, f32, "temp"),
+                                                       L.dev(idx, i32, "idx"), nx, None, 0, L.stream_ptr()),
+                    "farthest_point_sampling_wrapper")
         return 1
     # clouds larger than one register file (n > 16384): several workgroups per cloud exchange candidates
     # through this workspace; such launches must not overlap on a device (their workgroups wait for each
@@ -66,9 +74,14 @@ def farthest_point_sampling_wrapper(b, n, m, points, temp, idx):
     ws = torch.empty((ws_bytes + 64,), dtype=torch.uint8, device=points.device)
     base = ws.data_ptr()
     aligned = (base + 63) // 64 * 64
-    L.check(lib.jm_furthest_point_sampling_ws(b, n, m, L.dev(points, f32, "points"), L.dev(temp, f32, "temp"),
-                                              L.dev(idx, i32, "idx"), ctypes.c_void_p(aligned), ws_bytes, L.stream_ptr()),
-            "farthest_point_sampling_wrapper")
+    if nx is None:
+        L.check(lib.jm_furthest_point_sampling_ws(b, n, m, L.dev(points, f32, "points"), L.dev(temp, f32, "temp"),
+                                                  L.dev(idx, i32, "idx"), ctypes.c_void_p(aligned), ws_bytes,
+                                                  L.stream_ptr()), "farthest_point_sampling_wrapper")
+    else:
+        L.check(lib.jm_furthest_point_sampling_xyz(b, n, m, L.dev(points, f32, "points"), L.dev(temp, f32, "temp"),
+                                                   L.dev(idx, i32, "idx"), nx, ctypes.c_void_p(aligned), ws_bytes,
+                                                   L.stream_ptr()), "farthest_point_sampling_wrapper")
     ev = torch.cuda.Event()
     ev.record(stream)
     _coop_fps_done[dev_i] = ev

@@ -42,9 +42,12 @@ class _PointnetSAModuleBase(nn.Module):
         new_features (B, sum_k mlps[k][-1], npoint), idx (B, npoint) or None"""
         idx = None
         if new_xyz is None and self.npoint is not None:
-            idx = pointnet2_utils.farthest_point_sample(xyz, self.npoint)
-            new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), idx) \
-                .transpose(1, 2).contiguous()
+            if xyz.requires_grad:   # (never in the reference pipeline; keeps the autograd path available)
+                idx = pointnet2_utils.farthest_point_sample(xyz, self.npoint)
+                new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), idx) \
+                    .transpose(1, 2).contiguous()
+            else:                   # sampling + coordinate gather in one call
+                idx, new_xyz = pointnet2_utils.farthest_point_sample_xyz(xyz, self.npoint)
 
         neigh: List[Optional[torch.Tensor]] = [None] * len(self.groupers)
         if (len(self.groupers) == 2 and new_xyz is not None

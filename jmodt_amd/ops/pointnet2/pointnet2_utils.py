@@ -52,6 +52,20 @@ farthest_point_sample = _FurthestPointSampling.apply
 furthest_point_sample = farthest_point_sample
 
 
+@torch.no_grad()
+def farthest_point_sample_xyz(xyz: torch.Tensor, npoint: int):
+    """xyz (B, N, 3) -> (idx (B, npoint) int32, new_xyz (B, npoint, 3)) in ONE call: the sampling and the
+    coordinate gather that pointnet2_modules.py:35-39 spells as transpose + gather_operation + transpose.
+    Coordinates carry no gradient in the reference either (only features do), so this is a drop-in for it."""
+    _need(xyz, "xyz")
+    B, N, _ = xyz.size()
+    idx = torch.empty((B, npoint), dtype=_i32, device=xyz.device)
+    new_xyz = torch.empty((B, npoint, 3), dtype=_f32, device=xyz.device)
+    temp = torch.full((B, N), 1e10, dtype=_f32, device=xyz.device)
+    pointnet2_cuda.farthest_point_sampling_wrapper(B, N, npoint, xyz, temp, idx, new_xyz)
+    return idx, new_xyz
+
+
 class _GatherOperation(Function):
     @staticmethod
     def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:

@@ -39,9 +39,7 @@ class FpsPyramid:
         with torch.cuda.stream(side):
             cur = xyz
             for m in npoints:
-                idx = pointnet2_utils.farthest_point_sample(cur, m)
-                new_xyz = pointnet2_utils.gather_operation(cur.transpose(1, 2).contiguous(), idx) \
-                    .transpose(1, 2).contiguous()
+                idx, new_xyz = pointnet2_utils.farthest_point_sample_xyz(cur, m)
                 ev = torch.cuda.Event()
                 ev.record(side)
                 # handed to the main stream: keep the allocator from recycling them under it

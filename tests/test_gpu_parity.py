@@ -61,6 +61,16 @@ def test_fps_extension_level_temp_buffer(oracle, B, N, m):
     assert np.array_equal(temp.cpu().numpy(), want_temp)
 
 
+def test_fps_with_coordinates_in_one_call(oracle):
+    from jmodt_amd.ops.pointnet2.pointnet2_utils import farthest_point_sample_xyz
+    for B, N, m in ((3, 3000, 257), (2, 40000, 100), (70, 512, 128)):
+        xyz = synth.cloud(B, N, seed=B + N)
+        idx, new_xyz = farthest_point_sample_xyz(T(xyz), m)
+        want = oracle.furthest_point_sample(xyz, m)
+        assert np.array_equal(idx.cpu().numpy(), want)
+        assert np.array_equal(new_xyz.cpu().numpy(), np.take_along_axis(xyz, want[..., None].astype(np.int64), axis=1))
+
+
 def test_fps_all_equal_and_golden(oracle):
     from jmodt_amd.ops.pointnet2.pointnet2_utils import farthest_point_sample
     assert not farthest_point_sample(T(np.ones((2, 300, 3), np.float32)), 20).cpu().numpy().any()
