@@ -174,6 +174,34 @@ def gen_reference_vectors():
     want = F.grid_sample(torch.from_numpy(fm), torch.from_numpy(xy).unsqueeze(1), align_corners=True).squeeze(2)
     save("feature_gather_ref.npz", source="reference", fmap=fm, xy=xy, out=want.numpy())
 
+    # ---- layer builders: the reference's SharedMLP / Conv1d / FC (pytorch_utils.py) in eval mode with random
+    # BatchNorm statistics; state_dict + input + output.  Pins the build's mirror of the builders (same
+    # parameter names, same arithmetic) that the SA / FP modules and the fused SA kernel's BN folding rest on.
+    torch.manual_seed(11)
+    g = torch.Generator().manual_seed(12)
+    mlp = ref_pt.SharedMLP([9, 16, 24, 40], bn=True)
+    conv1 = ref_pt.Conv1d(12, 20, bn=True)
+    fc = ref_pt.FC(10, 6, bn=True)
+    for mod in (mlp, conv1, fc):
+        for m_ in mod.modules():
+            if isinstance(m_, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                with torch.no_grad():
+                    m_.weight.copy_(torch.rand(m_.weight.shape, generator=g) + 0.5)
+                    m_.bias.copy_(torch.randn(m_.bias.shape, generator=g) * 0.2)
+                    m_.running_mean.copy_(torch.randn(m_.running_mean.shape, generator=g) * 0.3)
+                    m_.running_var.copy_(torch.rand(m_.running_var.shape, generator=g) + 0.5)
+        mod.eval()
+    x_mlp = torch.randn(2, 9, 7, 5, generator=g)
+    x_c1 = torch.randn(3, 12, 11, generator=g)
+    x_fc = torch.randn(4, 10, generator=g)
+    out = {"source": "reference", "x_mlp": x_mlp.numpy(), "x_conv1d": x_c1.numpy(), "x_fc": x_fc.numpy()}
+    with torch.no_grad():
+        out["y_mlp"], out["y_conv1d"], out["y_fc"] = mlp(x_mlp).numpy(), conv1(x_c1).numpy(), fc(x_fc).numpy()
+    for tag, mod in (("mlp", mlp), ("conv1d", conv1), ("fc", fc)):
+        for k, v in mod.state_dict().items():
+            out[f"{tag}.{k}"] = v.numpy()
+    save("layer_builders_ref.npz", **out)
+
 
 if __name__ == "__main__":
     gen_oracle_vectors()

@@ -166,3 +166,36 @@ def test_state_dict_names_match_reference_layout():
     assert sa.mlps[0].layer0.conv.weight.shape == (16, 9, 1, 1)   # use_xyz adds 3 input channels
     fp = PointnetFPModule(mlp=[32, 16])
     assert "mlp.layer0.conv.weight" in fp.state_dict()
+
+
+def test_layer_builders_match_reference_modules():
+    """pytorch_utils mirror vs the REFERENCE's own SharedMLP / Conv1d / FC (pytorch_utils.py:6-205), eval mode,
+    random BatchNorm statistics: the reference state_dict loads by name and the outputs agree"""
+    import torch
+    from jmodt_amd.ops.pointnet2 import pytorch_utils as pt
+    g = load_golden("layer_builders_ref.npz")
+    mods = {"mlp": pt.SharedMLP([9, 16, 24, 40], bn=True), "conv1d": pt.Conv1d(12, 20, bn=True), "fc": pt.FC(10, 6, bn=True)}
+    for tag, mod in mods.items():
+        sd = {k[len(tag) + 1:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + ".")}
+        missing, unexpected = mod.load_state_dict(sd, strict=True)
+        assert not missing and not unexpected
+        mod.eval()
+        with torch.no_grad():
+            y = mod(torch.from_numpy(g[f"x_{tag}"])).numpy()
+        assert np.abs(y - g[f"y_{tag}"]).max() < 1e-5, tag
+
+
+def test_fold_shared_mlp_equals_eval_forward():
+    """BN folding used by the fused SA kernel == the module's eval-mode forward (on the reference's weights)"""
+    import torch
+    from jmodt_amd.ops.pointnet2 import pytorch_utils as pt
+    from jmodt_amd.ops.pointnet2.fused import fold_shared_mlp
+    g = load_golden("layer_builders_ref.npz")
+    mlp = pt.SharedMLP([9, 16, 24, 40], bn=True)
+    mlp.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("mlp.")})
+    mlp.eval()
+    x = torch.from_numpy(g["x_mlp"])                       # (B, C, H, W)
+    h = x
+    for W, b in fold_shared_mlp(mlp):
+        h = torch.relu(torch.einsum("oc,bchw->bohw", W, h) + b[None, :, None, None])
+    assert (h - torch.from_numpy(g["y_mlp"])).abs().max().item() < 1e-5
