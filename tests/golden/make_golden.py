@@ -174,6 +174,26 @@ def gen_reference_vectors():
     want = F.grid_sample(torch.from_numpy(fm), torch.from_numpy(xy).unsqueeze(1), align_corners=True).squeeze(2)
     save("feature_gather_ref.npz", source="reference", fmap=fm, xy=xy, out=want.numpy())
 
+    # ---- geometry helpers of the reference that the "next" rows build on (kitti_utils.py)
+    # canonical transformation: proposal_target_layer.py:106-112 = subtract the RoI centre, then
+    # rotate_pc_along_y_torch (kitti_utils.py:46-64) — executed with the reference's function
+    rng = np.random.default_rng(21)
+    rois = synth.proposals(synth.dense_cloud(1, 256, 22, extent=25.0), 12, 23)[0]                   # (12, 7)
+    pooled_xyz = (rois[:, None, 0:3] + rng.normal(0, 1.5, (12, 40, 3))).astype(np.float32)           # points near each RoI
+    canon = torch.from_numpy(pooled_xyz.copy())
+    canon -= torch.from_numpy(rois[:, 0:3]).unsqueeze(1)
+    canon = kitti_utils.rotate_pc_along_y_torch(canon, torch.from_numpy(rois[:, 6]))
+    # tracker distance term: data_association.py:10-28 written with the reference's (numpy) corner function
+    # boxes3d_to_corners3d (kitti_utils.py:66-104; its torch twin :107-133 allocates torch.cuda tensors and
+    # cannot run here): 1 - centre distance / largest of the 64 corner-pair distances
+    ba = synth.proposals(synth.dense_cloud(1, 256, 24, extent=25.0), 9, 25)[0]
+    bb = synth.proposals(synth.dense_cloud(1, 256, 26, extent=25.0), 7, 27)[0]
+    ca, cb = kitti_utils.boxes3d_to_corners3d(ba), kitti_utils.boxes3d_to_corners3d(bb)              # (M, 8, 3)
+    centre = np.linalg.norm(ba[:, None, :3] - bb[None, :, :3], axis=-1)
+    corner = np.linalg.norm(ca[:, None, :, None, :] - cb[None, :, None, :, :], axis=-1).reshape(9, 7, 64).max(-1)
+    save("geometry_ref.npz", source="reference", rois=rois, pooled_xyz=pooled_xyz, canonical=canon.numpy(),
+         boxes_a=ba, boxes_b=bb, corners_a=ca, boxes_dist=(1.0 - centre / corner).astype(np.float32))
+
     # ---- layer builders: the reference's SharedMLP / Conv1d / FC (pytorch_utils.py) in eval mode with random
     # BatchNorm statistics; state_dict + input + output.  Pins the build's mirror of the builders (same
     # parameter names, same arithmetic) that the SA / FP modules and the fused SA kernel's BN folding rest on.

@@ -199,3 +199,28 @@ def test_fold_shared_mlp_equals_eval_forward():
     for W, b in fold_shared_mlp(mlp):
         h = torch.relu(torch.einsum("oc,bchw->bohw", W, h) + b[None, :, None, None])
     assert (h - torch.from_numpy(g["y_mlp"])).abs().max().item() < 1e-5
+
+
+def test_canonical_transform_and_boxes_dist_vs_reference_geometry(oracle):
+    """the oracle's canonical transformation (used by roipool3d_canonical) vs the reference's own
+    rotate_pc_along_y_torch, and oracle.boxes_dist vs data_association.py:10-28 evaluated with the reference's
+    corner function (tests/golden/make_golden.py)"""
+    g = load_golden("geometry_ref.npz")
+    rois, xyz = g["rois"], g["pooled_xyz"]
+    f = np.float32
+    c = xyz - rois[:, None, 0:3]
+    cosa, sina = np.cos(rois[:, 6]).astype(f)[:, None], np.sin(rois[:, 6]).astype(f)[:, None]
+    x, z = c[..., 0].copy(), c[..., 2].copy()
+    c[..., 0] = x * cosa + z * (-sina)
+    c[..., 2] = x * sina + z * cosa
+    assert np.abs(c - g["canonical"]).max() < 1e-5
+    # the same through the oracle entry: one point per "cloud slot" that lies inside its RoI is pooled unchanged
+    pts = rois[None, :, 0:3].copy()
+    pts[..., 1] -= rois[None, :, 3] / 2                                 # box centres (y = bottom - h/2): inside
+    got, flag = oracle.roipool3d_canonical(pts, np.zeros((1, len(rois), 1), f), rois[None], 0.0, 4)
+    assert not flag.any()
+    want0 = np.zeros(3, f)
+    for i, r in enumerate(rois):
+        assert np.abs(got[0, i, 0, 0] - want0[0]).max() < 1e-5 and np.abs(got[0, i, 0, 2]).max() < 1e-5
+        assert abs(got[0, i, 0, 1] + r[3] / 2) < 1e-5                   # centre is h/2 above the bottom: y' = -h/2
+    assert np.abs(oracle.boxes_dist(g["boxes_a"], g["boxes_b"]) - g["boxes_dist"]).max() < 2e-5

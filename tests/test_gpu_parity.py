@@ -547,6 +547,30 @@ def test_association_cost_vs_oracle(oracle, P, D):
     assert torch.equal(boxes_iou3d_gpu(T(a), T(b)), iou)       # same kernel arithmetic as the iou3d op
 
 
+def test_boxes_dist_and_canonical_vs_reference_geometry_golden():
+    """device kernels vs vectors produced with the reference's own kitti_utils functions (geometry_ref.npz)"""
+    from jmodt_amd.ops.association import boxes_dist_gpu
+    from jmodt_amd.ops.roipool3d.roipool3d_utils import roipool3d_canonical_gpu
+    g = load_golden("geometry_ref.npz")
+    assert np.abs(boxes_dist_gpu(T(g["boxes_a"]), T(g["boxes_b"])).cpu().numpy() - g["boxes_dist"]).max() < 1e-4
+    # each RoI pools exactly its own cloud here (one frame per RoI): the pooled points come back in index order,
+    # so the canonical coordinates must equal the reference's transform of the same points
+    rois, xyz = g["rois"], g["pooled_xyz"]
+    M, S = xyz.shape[0], xyz.shape[1]
+    big = rois.copy()
+    big[:, 3:6] = 60.0                                    # every point of the frame is inside its (huge) RoI
+    big[:, 1] = rois[:, 1] + 30.0
+    feat = np.zeros((M, S, 1), np.float32)
+    got, flag = roipool3d_canonical_gpu(T(xyz), T(feat), T(big[:, None, :]), 0.0, S)
+    # centre subtraction uses the RoI's (x, y_bottom, z): rebuild the reference transform for the moved y
+    want = g["canonical"].copy()
+    want[..., 1] = xyz[..., 1] - big[:, None, 1]
+    inside = np.abs(xyz[..., 0] - rois[:, None, 0]) <= 10.0
+    inside &= np.abs(xyz[..., 2] - rois[:, None, 2]) <= 10.0
+    assert inside.all() and not flag.cpu().numpy().any()
+    assert np.abs(got.cpu().numpy()[:, 0, :, :3] - want).max() < 1e-4
+
+
 # ------------------------------------------------------------------ roipool3d + canonical transformation (§8f row 3)
 @pytest.mark.parametrize("B,N,M,C,S", [(2, 4096, 24, 6, 128), (2, 2048, 10, 5, 64), (3, 16384, 32, 130, 512)])
 def test_roipool3d_canonical_vs_oracle_and_unfused(oracle, B, N, M, C, S):
