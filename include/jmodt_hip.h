@@ -53,7 +53,9 @@ int jm_furthest_point_sampling(int b, int n, int m, const float* xyz, float* tem
 size_t jm_fps_workspace_bytes(int b, int n);
 /* sampling + the gather of the sampled coordinates that always follows it (pointnet2_modules.py:35-39):
  * additionally writes new_xyz (B, m, 3) = xyz[b, idx[b, j], :].  ws may be NULL when
- * jm_fps_workspace_bytes(b, n) == 0. */
+ * jm_fps_workspace_bytes(b, n) == 0.  temp may be NULL for n <= 131072: the kernels then start from the
+ * reference's 1e10 fill themselves and do not store the final distances (nobody reads them after the
+ * call in the reference: pointnet2_utils.py:25-27 allocates the buffer per call). */
 int jm_furthest_point_sampling_xyz(int b, int n, int m, const float* xyz, float* temp, int* idx, float* new_xyz,
                                    void* ws, size_t ws_bytes, jm_stream_t stream);
 int jm_furthest_point_sampling_ws(int b, int n, int m, const float* xyz, float* temp, int* idx, void* ws,

@@ -57,7 +57,7 @@ fps_regs_kernel(int n, int m, int bs, int bs_log2, int R, int J, int recipJ, con
     const int wave = __builtin_amdgcn_readfirstlane(T >> 6);
     const int lane = T & 63;
     const float* ds = dataset + (size_t)blockIdx.x * n * 3;
-    float* tp = temp + (size_t)blockIdx.x * n;
+    float* tp = temp ? temp + (size_t)blockIdx.x * n : nullptr;   // null: start from 1e10, final distances not stored
     int* out = idxs + (size_t)blockIdx.x * m;
 
     float px[PTS], py[PTS], pz[PTS], tm[PTS];
@@ -72,7 +72,7 @@ fps_regs_kernel(int n, int m, int bs, int bs_log2, int R, int J, int recipJ, con
         px[i] = ok ? ds[k * 3 + 0] : INFINITY;
         py[i] = ok ? ds[k * 3 + 1] : INFINITY;
         pz[i] = ok ? ds[k * 3 + 2] : INFINITY;
-        tm[i] = ok ? tp[k] : -1.f;
+        tm[i] = ok ? (tp ? tp[k] : 1e10f) : -1.f;
     }
 
     float x1 = ds[0], y1 = ds[1], z1 = ds[2];
@@ -141,7 +141,7 @@ fps_regs_kernel(int n, int m, int bs, int bs_log2, int R, int J, int recipJ, con
         const int r = (i * recipJ) >> 16, j = i - r * J;
         const int P = T * R + r;
         const int k = (int)bitrev_u((unsigned)P, bs_log2) + bs * j;
-        if (r < R && P < bs && k < n) tp[k] = tm[i];
+        if (tp && r < R && P < bs && k < n) tp[k] = tm[i];
     }
 }
 
@@ -172,7 +172,7 @@ fps_regs2_kernel(int n, int m, int bs, int bs_log2, int R, int J, int recipJ, co
     const int wave = __builtin_amdgcn_readfirstlane(T >> 6);
     const int lane = T & 63;
     const float* ds = dataset + (size_t)blockIdx.x * n * 3;
-    float* tp = temp + (size_t)blockIdx.x * n;
+    float* tp = temp ? temp + (size_t)blockIdx.x * n : nullptr;   // null: start from 1e10, final distances not stored
     int* out = idxs + (size_t)blockIdx.x * m;
 
     float px[PTS], py[PTS], pz[PTS], tm[PTS];
@@ -185,7 +185,7 @@ fps_regs2_kernel(int n, int m, int bs, int bs_log2, int R, int J, int recipJ, co
         px[i] = ok ? ds[k * 3 + 0] : INFINITY;
         py[i] = ok ? ds[k * 3 + 1] : INFINITY;
         pz[i] = ok ? ds[k * 3 + 2] : INFINITY;
-        tm[i] = ok ? tp[k] : -1.f;
+        tm[i] = ok ? (tp ? tp[k] : 1e10f) : -1.f;
     }
     float x1 = ds[0], y1 = ds[1], z1 = ds[2];
     if (T == 0) out_buf[0] = 0;
@@ -270,7 +270,7 @@ fps_regs2_kernel(int n, int m, int bs, int bs_log2, int R, int J, int recipJ, co
         const int r = (i * recipJ) >> 16, j = i - r * J;
         const int P = T * R + r;
         const int k = (int)bitrev_u((unsigned)P, bs_log2) + bs * j;
-        if (r < R && P < bs && k < n) tp[k] = tm[i];
+        if (tp && r < R && P < bs && k < n) tp[k] = tm[i];
     }
 }
 
@@ -338,7 +338,7 @@ fps_pruned_kernel(int n, int m, const float* __restrict__ dataset, float* __rest
     const int wave = __builtin_amdgcn_readfirstlane(T >> 6);
     const int lane = T & 63;
     const float* ds = dataset + (size_t)blockIdx.x * n * 3;
-    float* tp = temp + (size_t)blockIdx.x * n;
+    float* tp = temp ? temp + (size_t)blockIdx.x * n : nullptr;   // null: start from 1e10, final distances not stored
     int* out = idxs + (size_t)blockIdx.x * m;
     __shared__ float red[4][16];
 
@@ -391,7 +391,7 @@ fps_pruned_kernel(int n, int m, const float* __restrict__ dataset, float* __rest
             const int k = (int)(unsigned)ent[rank0 + i];
             kk[i] = k;
             px[i] = ds[k * 3 + 0]; py[i] = ds[k * 3 + 1]; pz[i] = ds[k * 3 + 2];
-            tm[i] = tp[k];
+            tm[i] = tp ? tp[k] : 1e10f;
         }
         __syncthreads();   // every entry has been read: compact the permutation to int32 in place
         int* kidx_w = reinterpret_cast<int*>(lds_raw);
@@ -483,7 +483,7 @@ fps_pruned_kernel(int n, int m, const float* __restrict__ dataset, float* __rest
         for (int e = T; e < m - done; e += 1024) out[done + e] = out_buf[e];
     }
 #pragma unroll
-    for (int i = 0; i < PTS; ++i) tp[kidx[rank0 + i]] = tm[i];
+    for (int i = 0; i < PTS; ++i) if (tp) tp[kidx[rank0 + i]] = tm[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -526,7 +526,7 @@ fps_slotprune_kernel(int n, int m, const float* __restrict__ dataset, float* __r
     const int wave = __builtin_amdgcn_readfirstlane(T >> 6);
     const int lane = T & 63;
     const float* ds = dataset + (size_t)blockIdx.x * n * 3;
-    float* tp = temp + (size_t)blockIdx.x * n;
+    float* tp = temp ? temp + (size_t)blockIdx.x * n : nullptr;   // null: start from 1e10, final distances not stored
     int* out = idxs + (size_t)blockIdx.x * m;
     __shared__ float red[6][16];
 
@@ -578,7 +578,7 @@ fps_slotprune_kernel(int n, int m, const float* __restrict__ dataset, float* __r
         for (int i = 0; i < PTS; ++i) {
             kk[i] = (int)(unsigned)ent[i * 1024 + T];
             px[i] = ds[kk[i] * 3 + 0]; py[i] = ds[kk[i] * 3 + 1]; pz[i] = ds[kk[i] * 3 + 2];
-            tm[i] = tp[kk[i]];
+            tm[i] = tp ? tp[kk[i]] : 1e10f;
         }
         __syncthreads();   // every sorted entry has been read: compact the permutation to int32 in place
 #pragma unroll
@@ -709,7 +709,7 @@ fps_slotprune_kernel(int n, int m, const float* __restrict__ dataset, float* __r
         for (int e = T; e < m - done; e += 1024) out[done + e] = out_buf[e];
     }
 #pragma unroll
-    for (int i = 0; i < PTS; ++i) tp[kidx[i * 1024 + T]] = tm[i];
+    for (int i = 0; i < PTS; ++i) if (tp) tp[kidx[i * 1024 + T]] = tm[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -754,7 +754,7 @@ fps_coop_kernel(int n, int m, int G, int nclouds, const float* __restrict__ data
     const int cloud = xcd + 8 * (slot / G), g = slot % G;
     if (cloud >= nclouds) return;
     const float* ds = dataset + (size_t)cloud * n * 3;
-    float* tp = temp + (size_t)cloud * n;
+    float* tp = temp ? temp + (size_t)cloud * n : nullptr;
     int* out = idxs + (size_t)cloud * m;
     FpsXchg* xc = xchg + (size_t)cloud * 2 * G;          // [parity][part]
 
@@ -767,7 +767,7 @@ fps_coop_kernel(int n, int m, int G, int nclouds, const float* __restrict__ data
         px[i] = ok ? ds[k * 3 + 0] : INFINITY;
         py[i] = ok ? ds[k * 3 + 1] : INFINITY;
         pz[i] = ok ? ds[k * 3 + 2] : INFINITY;
-        tm[i] = ok ? tp[k] : -1.f;
+        tm[i] = ok ? (tp ? tp[k] : 1e10f) : -1.f;
     }
     float x1 = ds[0], y1 = ds[1], z1 = ds[2];
     if (T == 0) out_buf[0] = 0;
@@ -860,7 +860,7 @@ fps_coop_kernel(int n, int m, int G, int nclouds, const float* __restrict__ data
 #pragma unroll
     for (int i = 0; i < PTS; ++i) {
         const int k = kT + 1024 * i;
-        if (k < n) tp[k] = tm[i];
+        if (tp && k < n) tp[k] = tm[i];
     }
 }
 
@@ -876,7 +876,7 @@ fps_stream_kernel(int n, int m, int bs_log2, const float* __restrict__ dataset, 
     const int nwaves = bs >> 6;
     const int wave = T >> 6, lane = T & 63;
     const float* ds = dataset + (size_t)blockIdx.x * n * 3;
-    float* tp = temp + (size_t)blockIdx.x * n;
+    float* tp = temp ? temp + (size_t)blockIdx.x * n : nullptr;   // null: start from 1e10, final distances not stored
     int* out = idxs + (size_t)blockIdx.x * m;
     const int t = (int)bitrev_u((unsigned)T, bs_log2);
     float x1 = ds[0], y1 = ds[1], z1 = ds[2];
@@ -975,7 +975,7 @@ static int fps_impl(int b, int n, int m, const float* xyz, float* temp, int* idx
     using namespace jm;
     JM_REQUIRE(b >= 0 && n >= 1 && m >= 0, "fps: bad sizes b=%d n=%d m=%d", b, n, m);
     if (b == 0 || m == 0) return JM_OK;
-    JM_REQUIRE(xyz && temp && idx, "fps: null pointer");
+    JM_REQUIRE(xyz && idx, "fps: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int bs = opt_n_threads(n);
     int bs_log2 = 0;
@@ -999,12 +999,13 @@ static int fps_impl(int b, int n, int m, const float* xyz, float* temp, int* idx
                 const int nc = b - c0 < per_launch ? b - c0 : per_launch;
                 const int grid = 8 * ((nc + 7) / 8) * G;
                 hipLaunchKernelGGL(fps_coop_kernel, dim3(grid), dim3(1024), 0, s, n, m, G, nc, xyz + (size_t)c0 * n * 3,
-                                   temp + (size_t)c0 * n, idx + (size_t)c0 * m,
+                                   temp ? temp + (size_t)c0 * n : nullptr, idx + (size_t)c0 * m,
                                    reinterpret_cast<FpsXchg*>(ws) + (size_t)c0 * 2 * G);
             }
             return check_launch("fps(coop)");
         }
         // no workspace (legacy 7-argument entry) or n beyond the cooperative limit: stream from L2
+        JM_REQUIRE(temp, "fps: the streaming kernel needs the temp buffer");
         hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(bs), 0, s, n, m, bs_log2, xyz, temp, idx);
         return check_launch("fps(stream)");
     }

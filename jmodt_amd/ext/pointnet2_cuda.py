@@ -54,12 +54,13 @@ def farthest_point_sampling_wrapper(b, n, m, points, temp, idx, new_xyz=None):
     lib = L.load()
     ws_bytes = lib.jm_fps_workspace_bytes(b, n)
     nx = L.dev(new_xyz, f32, "new_xyz") if new_xyz is not None else None
+    tmp = L.dev(temp, f32, "temp") if temp is not None else None      # None: allowed with new_xyz (n <= 131072)
     if ws_bytes == 0:
         if nx is None:
             L.check(lib.jm_furthest_point_sampling(b, n, m, L.dev(points, f32, "points"), L.dev(temp, f32, "temp"),
                                                    L.dev(idx, i32, "idx"), L.stream_ptr()), "farthest_point_sampling_wrapper")
         else:
-            L.check(lib.jm_furthest_point_sampling_xyz(b, n, m, L.dev(points, f32, "points"), L.dev(temp, f32, "temp"),
+            L.check(lib.jm_furthest_point_sampling_xyz(b, n, m, L.dev(points, f32, "points"), tmp,
                                                        L.dev(idx, i32, "idx"), nx, None, 0, L.stream_ptr()),
                     "farthest_point_sampling_wrapper")
         return 1
@@ -79,7 +80,7 @@ def farthest_point_sampling_wrapper(b, n, m, points, temp, idx, new_xyz=None):
                                                   L.dev(idx, i32, "idx"), ctypes.c_void_p(aligned), ws_bytes,
                                                   L.stream_ptr()), "farthest_point_sampling_wrapper")
     else:
-        L.check(lib.jm_furthest_point_sampling_xyz(b, n, m, L.dev(points, f32, "points"), L.dev(temp, f32, "temp"),
+        L.check(lib.jm_furthest_point_sampling_xyz(b, n, m, L.dev(points, f32, "points"), tmp,
                                                    L.dev(idx, i32, "idx"), nx, ctypes.c_void_p(aligned), ws_bytes,
                                                    L.stream_ptr()), "farthest_point_sampling_wrapper")
     ev = torch.cuda.Event()

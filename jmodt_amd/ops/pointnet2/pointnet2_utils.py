@@ -61,7 +61,9 @@ def farthest_point_sample_xyz(xyz: torch.Tensor, npoint: int):
     B, N, _ = xyz.size()
     idx = torch.empty((B, npoint), dtype=_i32, device=xyz.device)
     new_xyz = torch.empty((B, npoint, 3), dtype=_f32, device=xyz.device)
-    temp = torch.full((B, N), 1e10, dtype=_f32, device=xyz.device)
+    # no temp buffer: the kernels start from the 1e10 fill themselves (one fill launch and 4 B / point less on
+    # the sampling chain); only clouds beyond the co-operative kernel's limit still need it
+    temp = torch.full((B, N), 1e10, dtype=_f32, device=xyz.device) if N > 131072 else None
     pointnet2_cuda.farthest_point_sampling_wrapper(B, N, npoint, xyz, temp, idx, new_xyz)
     return idx, new_xyz
 
