@@ -113,12 +113,13 @@ class PointnetFPModule(nn.Module):
                 known_feats: torch.Tensor) -> torch.Tensor:
         """unknown (B, n, 3), known (B, m, 3), unknow_feats (B, C1, n), known_feats (B, C2, m)
         -> (B, mlp[-1], n)"""
-        if known is not None:
-            dist, idx = pointnet2_utils.three_nn(unknown, known)
-            dist_recip = 1.0 / (dist + 1e-8)
-            weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
-            interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+        if known is None:
+            # a single global feature vector: broadcast it to every fine point
+            carried = known_feats.expand(known_feats.shape[0], known_feats.shape[1], unknown.shape[1])
         else:
-            interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
-        feats = interpolated if unknow_feats is None else torch.cat([interpolated, unknow_feats], dim=1)
-        return self.mlp(feats.unsqueeze(-1)).squeeze(-1)
+            # inverse-distance weights over the three nearest coarse points (pointnet2_modules.py:147-152)
+            d3, nn3 = pointnet2_utils.three_nn(unknown, known)
+            inv = (d3 + 1e-8).reciprocal()
+            carried = pointnet2_utils.three_interpolate(known_feats, nn3, inv / inv.sum(dim=2, keepdim=True))
+        stacked = carried if unknow_feats is None else torch.cat((carried, unknow_feats), dim=1)
+        return self.mlp(stacked.unsqueeze(-1)).squeeze(-1)

@@ -53,45 +53,49 @@ def roipool3d_canonical_gpu(pts, pts_feature, boxes3d, pool_extra_width, sampled
     return pooled, empty
 
 
+def _host_f32(t):
+    """a contiguous float32 CPU tensor (the CPU entry points take host pointers)"""
+    return t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+
+
 def pts_in_boxes3d_cpu(pts, boxes3d):
     """pts (N, 3), boxes3d (M, 7) on the CPU -> list of M boolean masks (N)"""
     if pts.is_cuda:
-        raise NotImplementedError
-    pts = pts.float().contiguous()
-    boxes3d = boxes3d.float().contiguous()
-    pts_flag = torch.zeros((boxes3d.size(0), pts.size(0)), dtype=torch.int64)
-    roipool3d_cuda.pts_in_boxes3d_cpu(pts_flag, pts, boxes3d)
-    return [pts_flag[k] > 0 for k in range(boxes3d.shape[0])]
+        raise NotImplementedError   # as the reference: this entry point is CPU only
+    p, b = _host_f32(pts), _host_f32(boxes3d)
+    flags = torch.zeros((b.shape[0], p.shape[0]), dtype=torch.int64)
+    roipool3d_cuda.pts_in_boxes3d_cpu(flags, p, b)
+    return list((flags > 0).unbind(0))
 
 
 def roipool_pc_cpu(pts, pts_feature, boxes3d, sampled_pt_num):
     """pts (N, 3), pts_feature (N, C), boxes3d (M, 7) -> pooled_pts (M, S, 3), pooled_features (M, S, C),
     pooled_empty_flag (M) int64"""
-    pts = pts.cpu().float().contiguous()
-    pts_feature = pts_feature.cpu().float().contiguous()
-    boxes3d = boxes3d.cpu().float().contiguous()
-    assert pts.shape[0] == pts_feature.shape[0] and pts.shape[1] == 3, "%s %s" % (pts.shape, pts_feature.shape)
-    pooled_pts = torch.zeros((boxes3d.shape[0], sampled_pt_num, 3), dtype=torch.float32)
-    pooled_features = torch.zeros((boxes3d.shape[0], sampled_pt_num, pts_feature.shape[1]), dtype=torch.float32)
-    pooled_empty_flag = torch.zeros(boxes3d.shape[0], dtype=torch.int64)
-    roipool3d_cuda.roipool3d_cpu(pts, boxes3d, pts_feature, pooled_pts, pooled_features, pooled_empty_flag)
-    return pooled_pts, pooled_features, pooled_empty_flag
+    p, f, b = _host_f32(pts), _host_f32(pts_feature), _host_f32(boxes3d)
+    assert p.shape[0] == f.shape[0] and p.shape[1] == 3, "%s %s" % (p.shape, f.shape)
+    m = b.shape[0]
+    out_xyz = torch.zeros((m, sampled_pt_num, 3), dtype=torch.float32)
+    out_feat = torch.zeros((m, sampled_pt_num, f.shape[1]), dtype=torch.float32)
+    empty = torch.zeros(m, dtype=torch.int64)
+    roipool3d_cuda.roipool3d_cpu(p, b, f, out_xyz, out_feat, empty)
+    return out_xyz, out_feat, empty
 
 
 def roipool3d_cpu(boxes3d, pts, pts_feature, pts_extra_input, pool_extra_width, sampled_pt_num=512,
                   canonical_transform=True):
-    """numpy front end: boxes3d (M, 7), pts (N, 3), pts_feature (N, C), pts_extra_input (N, C2)"""
-    pooled_boxes3d = enlarge_box3d(boxes3d, pool_extra_width)
-    feature_all = np.concatenate((pts_extra_input, pts_feature), axis=1)
-    pooled_pts, pooled_features, pooled_empty_flag = roipool_pc_cpu(
-        torch.from_numpy(pts), torch.from_numpy(feature_all), torch.from_numpy(pooled_boxes3d), sampled_pt_num)
+    """numpy front end: boxes3d (M, 7), pts (N, 3), pts_feature (N, C), pts_extra_input (N, C2) ->
+    (sampled_pts_input (M, S, 3 + C2), sampled_pts_feature (M, S, C)[, pooled_empty_flag when not canonical])"""
     n_extra = pts_extra_input.shape[1]
-    sampled_pts_input = torch.cat((pooled_pts, pooled_features[:, :, 0:n_extra]), dim=2).numpy()
-    sampled_pts_feature = pooled_features[:, :, n_extra:].numpy()
+    stacked = np.concatenate((pts_extra_input, pts_feature), axis=1)        # extra channels first, as the reference
+    xyz, feat, empty = roipool_pc_cpu(torch.from_numpy(pts), torch.from_numpy(stacked),
+                                      torch.from_numpy(enlarge_box3d(boxes3d, pool_extra_width)), sampled_pt_num)
+    pts_input = np.concatenate((xyz.numpy(), feat[:, :, :n_extra].numpy()), axis=2)
+    pts_feat = feat[:, :, n_extra:].numpy()
     if not canonical_transform:
-        return sampled_pts_input, sampled_pts_feature, pooled_empty_flag.numpy()
-    roi_ry = boxes3d[:, 6] % (2 * np.pi)
-    sampled_pts_input[:, :, 0:3] = sampled_pts_input[:, :, 0:3] - boxes3d[:, np.newaxis, 0:3]
-    for k in range(sampled_pts_input.shape[0]):
-        sampled_pts_input[k] = rotate_pc_along_y(sampled_pts_input[k], roi_ry[k])
-    return sampled_pts_input, sampled_pts_feature
+        return pts_input, pts_feat, empty.numpy()
+    # canonical frame of each RoI: origin at the box (x, y_bottom, z), heading along +x
+    pts_input[:, :, 0:3] -= boxes3d[:, np.newaxis, 0:3]
+    headings = boxes3d[:, 6] % (2 * np.pi)
+    for box_i, angle in enumerate(headings):
+        rotate_pc_along_y(pts_input[box_i], angle)                          # in place
+    return pts_input, pts_feat
