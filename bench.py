@@ -253,6 +253,28 @@ def dense_step(d, timer):
                   flops=256 * 256 * (2 * 512 * 512 * 2 + 2 * 512))
 
 
+def make_train_state(frames, seed, dev):
+    """BASELINE configs[3] per-GPU share: `frames` frames (= frames/2 (prev, next) pairs), 64 sampled RoIs per
+    frame (config.py:204) with 512-d RCNN features and track ids; link / start-end heads + Adam as
+    tools/train.py:96-107 (finetune: only these two heads train)"""
+    from jmodt_amd.ops.affinity import make_affinity_mlp
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    feats = torch.relu(torch.randn(frames, 64, 512, generator=g)).to(dev)
+    tids = torch.randint(0, 13, (frames, 64), generator=g).float().to(dev)     # 0 = background, 12 tracks
+    torch.manual_seed(seed)
+    link, se = make_affinity_mlp().to(dev).train(), make_affinity_mlp().to(dev).train()
+    opt = torch.optim.Adam(list(link.parameters()) + list(se.parameters()), lr=1e-4)
+    return dict(feats=feats, tids=tids, link=link, se=se, opt=opt)
+
+
+def train_step(st, timer, world):
+    """one data-parallel finetune step: local forward/backward of the pairwise affinity losses, ONE bucketed
+    gradient all-reduce over RCCL (4.2 MB of fp32 gradients), optimizer step"""
+    from jmodt_amd.ops.affinity_train import finetune_step
+    timer.run("finetune_step(fwd+bwd+allreduce+adam)", 0,
+              lambda: finetune_step(st["feats"], st["tids"], st["link"], st["se"], st["opt"], world=world))
+
+
 def cpu_baseline_sa(B):
     """the oracle (CPU restatement, OpenMP) on ONE batch of the same workload"""
     from oracle import oracle as orc
@@ -284,9 +306,10 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the FPS chain on the main stream (no side stream)")
-    ap.add_argument("--workload", default="sa", choices=["sa", "ops", "dense"],
+    ap.add_argument("--workload", default="sa", choices=["sa", "ops", "dense", "train"],
                     help="sa = BASELINE configs[1] (default); ops = every other hot-path op at its §8d shape; "
-                         "dense = configs[4] shapes (65536 points, 256 RoIs, 256^2 affinity)")
+                         "dense = configs[4] shapes (65536 points, 256 RoIs, 256^2 affinity); "
+                         "train = configs[3]: DP finetune step of the affinity heads (gradient all-reduce over RCCL)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -313,9 +336,12 @@ def main():
     elif args.workload == "ops":
         ops_in = make_ops_inputs(args.batch, 1234 + 2 + rank, dev)
         step = lambda: ops_step(ops_in, timer)  # noqa: E731
-    else:
+    elif args.workload == "dense":
         dense_in = make_dense_inputs(args.batch, 1234 + 4 + rank, dev)
         step = lambda: dense_step(dense_in, timer)  # noqa: E731
+    else:
+        train_st = make_train_state(args.batch, 1234 + 3 + rank, dev)
+        step = lambda: train_step(train_st, timer, world)  # noqa: E731
     import gc
     for _ in range(args.warmup):
         step()
@@ -371,10 +397,13 @@ def main():
                        ("supplementary: three_nn+interpolate (4 FP levels), LI-Fusion gather (5 maps), roipool3d "
                         "(128 RoIs x 512 pts x 133), RPN nms_normal (6300 boxes), 128x128 affinity, per frame")
                        if args.workload == "ops" else
+                       ("supplementary, BASELINE configs[3]: data-parallel finetune step of the link / start-end heads "
+                        "(64 RoIs x 512-d per frame, pairwise affinity losses, bucketed fp32 gradient all-reduce, Adam)")
+                       if args.workload == "train" else
                        ("supplementary, BASELINE configs[4] shapes: 65536-pt clouds (co-operative FPS -> 4096, dual "
                         "ball query, grouping, 3-NN), roipool3d+canonical for 256 RoIs, 256x256 affinity per frame"),
                        "frames_per_gpu_per_step": args.batch, "points": 65536 if args.workload == "dense" else 16384,
-                       "parallelism": f"replicas x{world}"},
+                       "parallelism": f"dp{world} (gradient all-reduce)" if args.workload == "train" else f"replicas x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_gbs"],
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["hbm_frac"], "traffic": traffic,
                          "basis": "algorithmic bytes per SURVEY.md §8(d) (FPS: streaming-equivalent B*m*20n — the "
