@@ -322,9 +322,21 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("JM_BENCH_FORCE_DIST") == "1":   # (the env switch exercises the RCCL path on one GPU)
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        # stdout carries exactly one JSON line.  RCCL prints a version banner to fd 1 when the communicator is
+        # created (NCCL_DEBUG=VERSION in this image), so fd 1 points at stderr while that happens.
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()                       # creates the communicator (and prints the banner) now
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from jmodt_amd import _lib
     _lib.load()
