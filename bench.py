@@ -76,6 +76,9 @@ class KernelTimer:
             if flops:   # time covers the whole op (both MLP layers + softmax + se path)
                 tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
                 row.update(achieved_tflops=round(tf, 2), mfma_frac=round(tf / MFMA_F32_PEAK_TF, 4))
+            if name.startswith("fps_L") and name[5:].isdigit():   # the figure of merit SURVEY.md §8(d) asks for
+                m = SA_LEVELS[int(name[5:]) - 1]["m"]
+                row["us_per_fps_iteration"] = round(ms * 1e3 / (m - 1), 4)
             rows.append(row)
         rows.sort(key=lambda r: -r["ms_per_step"])
         return rows
@@ -421,7 +424,8 @@ def main():
                          "basis": "algorithmic bytes per SURVEY.md §8(d) (FPS: streaming-equivalent B*m*20n — the "
                                   "kernel is latency/VALU-bound, its compulsory bytes are B*(12n+4m)); "
                                   "time = HIP events on the launch stream inside the timed region",
-                         "measured_copy_ceiling_gbs": HBM_COPY_CEILING_GBS},
+                         "measured_copy_ceiling_gbs": HBM_COPY_CEILING_GBS,
+                         **({"us_per_fps_iteration": dom["us_per_fps_iteration"]} if "us_per_fps_iteration" in dom else {})},
             "kernels": kernels,
         }
         if not args.no_cpu_baseline and args.workload == "sa" and world == 1:   # rank 0 at N = 1 only
