@@ -1,21 +1,33 @@
-"""bench.py — throughput of the detection+association hot path on MI355X.
+"""bench.py — throughput of JMODT's detection + association hot path on MI355X.
 
-Default workload (BASELINE.json configs[1]): one "step" = FPS +
-ball_query (both MSG radii) + group_points over ALL FOUR RPN set-abstraction levels
-(16384 -> 4096 -> 1024 -> 256 -> 64 points; jmodt/config.py:75-77) for a batch of 8 synthetic
-KITTI-shaped frames resident in HBM.  value = frames/s, whole job.
+Default workload = the thing BASELINE.json's metric names: the composed detect + affinity forward
+(BASELINE configs[2] "Full RPN + LI-Fusion + roipool3d + iou3d_nms forward, KITTI-shape batch=8" plus the
+pairwise link / start-end affinity of configs[0]) on synthetic KITTI-shaped frames resident in HBM:
+16384 points, 384x1280 image canvas (native 375x1242 zero padded), 128 proposals per frame.  One "step" =
+one batch of 8 frames through jmodt_amd.detector.DetectAffinityEngine.  value = frames/s, whole job.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload sa|roipool|affinity|all]
+    python bench.py [--gpus N --steps K --warmup W] [--workload detect|sa|ops|dense|train]
 
-N > 1 is launched by torch.distributed.run, one rank per GPU; frames are independent, so every
-rank processes its own batch with no data-path collective (weak scaling); the
-timed region is bracketed by barrier + synchronize and the MAX over ranks is used.
+  detect  configs[2] + affinity (default)
+  sa      configs[1]: FPS + dual ball_query + group_points over the four RPN SA levels
+  ops     every hot-path op once at its SURVEY.md §8(d) shape
+  dense   configs[4] shapes: 65536-pt clouds, 256 RoIs, 256^2 affinity
+  train   configs[3]: frozen detector forward + data-parallel finetune step of the link / start-end heads
+          (one bucketed fp32 gradient all-reduce over RCCL)
 
-One JSON line on rank 0 with `roofline` (dominant kernel) and `cpu_baseline` (the oracle — a
-restatement, kind "port" — timed on this host's cores on a bounded sample) plus a `kernels` list
-with every kernel's own algorithmic bytes / time / HBM fraction.
+N > 1 is launched by torch.distributed.run, one rank per GPU; frames are independent, so every rank processes
+its own batch with no data-path collective (weak scaling); the timed region is bracketed by
+barrier + synchronize and the MAX over ranks is used.
+
+One JSON line on rank 0.  `kernels` lists every C-ABI entry point of the step with its algorithmic bytes /
+flops (jmodt_amd/profile.py: SURVEY.md §8(d) formulas evaluated on the call's own arguments) and its time from
+HIP events recorded on the launching stream inside the timed region, plus the caller-side torch spans
+(MIOpen / rocBLAS) and the exposed waits on the FPS / image side streams; `roofline` is the dominant jm
+entry; `cpu_baseline` is the chained CPU oracle (oracle/pipeline.py: the C restatement for the jmodt ops + the
+same PyTorch-CPU operators the reference calls for everything else) on a bounded sample.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -28,10 +40,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from jmodt_amd import synth  # noqa: E402
+from jmodt_amd.profile import prof  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
 MFMA_F32_PEAK_TF = 157.3
+METRIC = "frames/sec detect+affinity on 16384-pt KITTI frames; per-kernel HBM-BW fraction"
 
 # jmodt/config.py:75-77 (RPN.SA_CONFIG) + channel widths entering each level (config.py:78-82)
 SA_LEVELS = [
@@ -42,48 +56,41 @@ SA_LEVELS = [
 ]
 
 
-class KernelTimer:
-    """HIP events on torch's current stream (the stream every jm_* launch goes to).  A name may be
-    launched several times per step (e.g. both MSG scales); bytes / flops / time are all SUMMED
-    over those launches, so achieved = sum(algorithmic bytes) / sum(time)."""
-
-    def __init__(self):
-        self.records = {}   # name -> list of (start, end, algo_bytes, flops)
-        self.enabled = False
-
-    def run(self, name, algo_bytes, fn, flops=0):
-        if not self.enabled:
-            return fn()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        out = fn()
-        e.record()
-        self.records.setdefault(name, []).append((s, e, algo_bytes, flops))
-        return out
-
-    def summary(self, steps):
-        rows = []
-        for name, evs in self.records.items():
-            times = [s.elapsed_time(e) for s, e, _, _ in evs]
-            ms = sum(times) / steps
-            nbytes = sum(b for _, _, b, _ in evs) / steps
-            flops = sum(f for _, _, _, f in evs) / steps
-            launches = len(evs) / steps
-            gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            row = dict(kernel=name, ms_per_step=round(ms, 5), launches_per_step=launches,
-                       algo_bytes_per_step=int(nbytes), achieved_gbs=round(gbs, 2),
-                       hbm_frac=round(gbs / HBM_PEAK_GBS, 5), max_launch_ms=round(max(times), 5))
-            if flops:   # time covers the whole op (both MLP layers + softmax + se path)
-                tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-                row.update(achieved_tflops=round(tf, 2), mfma_frac=round(tf / MFMA_F32_PEAK_TF, 4))
-            if name.startswith("fps_L") and name[5:].isdigit():   # the figure of merit SURVEY.md §8(d) asks for
-                m = SA_LEVELS[int(name[5:]) - 1]["m"]
-                row["us_per_fps_iteration"] = round(ms * 1e3 / (m - 1), 4)
-            rows.append(row)
-        rows.sort(key=lambda r: -r["ms_per_step"])
-        return rows
+# ---------------------------------------------------------------------------------------------- detect
+def make_detect_state(B, seed, dev, tiny=False):
+    from jmodt_amd.detector import DetectAffinityEngine, DetectorConfig
+    torch.manual_seed(seed)
+    cfg = DetectorConfig.tiny() if tiny else DetectorConfig()
+    eng = DetectAffinityEngine(cfg).to(dev)
+    if tiny:
+        xyz, img, xy = synth.frames(B, 2048, seed, H=96, W=320, native=(94, 310))
+    else:
+        xyz, img, xy = synth.frames(B, 16384, seed)
+    return dict(engine=eng, xyz=torch.from_numpy(xyz).to(dev), image=torch.from_numpy(img).to(dev),
+                pts_xy=torch.from_numpy(xy).to(dev))
 
 
+def detect_step(st):
+    return st["engine"](st["xyz"], st["image"], st["pts_xy"])
+
+
+def cpu_baseline_detect(frames=2):
+    """the chained CPU oracle (float32, the reference's arithmetic) on `frames` full-size frames"""
+    from jmodt_amd.detector import DetectAffinityEngine, DetectorConfig
+    from oracle.pipeline import Chain
+    torch.manual_seed(99)
+    cfg = DetectorConfig()
+    sd = DetectAffinityEngine(cfg).state_dict()
+    xyz, img, xy = synth.frames(frames, 16384, 4321)
+    chain = Chain(sd, cfg, torch.float32)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        chain.forward(xyz, img, xy)
+    dt = time.perf_counter() - t0
+    return frames / dt, dt
+
+
+# ---------------------------------------------------------------------------------------------- sa
 def make_sa_inputs(B, seed, dev):
     xyz = torch.from_numpy(synth.cloud(B, 16384, seed=seed)).to(dev)
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -91,195 +98,32 @@ def make_sa_inputs(B, seed, dev):
     return xyz, feats
 
 
-def sa_step(xyz, feats, timer, overlap=True):
-    """FPS + dual ball_query + group_points (xyz and features, both scales) over the 4 levels.
-    overlap: the FPS chain (coordinates only) runs ahead on a side stream (ops/pointnet2/pyramid.py)
-    while the main stream searches / groups the earlier levels; same kernels, same results."""
+def sa_step(xyz, feats, overlap=True):
+    """FPS + dual ball_query + group_points (xyz and features, both scales) over the 4 levels; the FPS chain
+    (coordinates only) runs ahead on a side stream (ops/pointnet2/pyramid.py)"""
     from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
-    from jmodt_amd.ops.pointnet2.pyramid import _side_stream
-    B = xyz.shape[0]
-    main = torch.cuda.current_stream()
-    side = _side_stream(xyz.device) if overlap else main
-    levels = []
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        cur = xyz
-        for li, lv in enumerate(SA_LEVELS):
-            n, m = lv["n"], lv["m"]
-            # sampling + coordinate gather in one call: nothing else sits between two FPS levels
-            idx, new_xyz = timer.run(f"fps_L{li + 1}", B * m * 20 * n, lambda: pu.farthest_point_sample_xyz(cur, m))
-            ev = torch.cuda.Event()
-            ev.record(side)
-            levels.append((cur, new_xyz, ev))
-            cur = new_xyz
-    outs = []
+    from jmodt_amd.ops.pointnet2.pyramid import FpsPyramid
+    pyr = FpsPyramid(xyz, [lv["m"] for lv in SA_LEVELS], overlap=overlap)
+    outs, cur = [], xyz
     for li, lv in enumerate(SA_LEVELS):
-        n, m, (r0, r1), (ns0, ns1), c = lv["n"], lv["m"], lv["radii"], lv["ns"], lv["c"]
-        cur, new_xyz, ev = levels[li]
-        cur_t = cur.transpose(1, 2).contiguous()      # (B, 3, n) layout for group_points (cur is ready: previous event)
-        main.wait_event(ev)
-        i0, i1 = timer.run(f"ball_query_dual_L{li + 1}", B * (12 * n + 12 * m + 4 * m * (ns0 + ns1)),
-                           lambda: pu.ball_query_dual(r0, ns0, r1, ns1, cur, new_xyz))
-        for ns, nb in ((ns0, i0), (ns1, i1)):
-            outs.append(timer.run(f"group_points_xyz_L{li + 1}", B * (4 * m * ns + 4 * 3 * n + 4 * 3 * m * ns),
-                                  lambda: pu.grouping_operation(cur_t, nb)))
-            if c:
-                outs.append(timer.run(f"group_points_feat_L{li + 1}", B * (4 * m * ns + 4 * c * n + 4 * c * m * ns),
-                                      lambda: pu.grouping_operation(feats[li], nb)))
-    side.wait_stream(main)   # buffers of this pass are not recycled on the side stream before the main stream is done
+        (r0, r1), (ns0, ns1), c = lv["radii"], lv["ns"], lv["c"]
+        _, new_xyz = pyr.level(li)
+        cur_t = cur.transpose(1, 2).contiguous()      # (B, 3, n) layout for group_points
+        with prof.scope(f"L{li + 1}"):
+            i0, i1 = pu.ball_query_dual(r0, ns0, r1, ns1, cur, new_xyz)
+            for nb in (i0, i1):
+                with prof.scope("xyz"):
+                    outs.append(pu.grouping_operation(cur_t, nb))
+                if c:
+                    with prof.scope("feat"):
+                        outs.append(pu.grouping_operation(feats[li], nb))
+        cur = new_xyz
+    pyr.release()
     return outs
 
 
-def make_ops_inputs(B, seed, dev):
-    """inputs for the remaining hot-path ops at SURVEY.md §8d shapes (config 3 sizes, M_roi = 128)"""
-    from jmodt_amd.ops.affinity import make_affinity_mlp
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    xyz_np = synth.cloud(B, 16384, seed=seed)
-    d = dict(xyz=torch.from_numpy(xyz_np).to(dev))
-    d["xy"] = torch.from_numpy(synth.pts_xy(xyz_np)).to(dev)
-    d["boxes"] = torch.from_numpy(synth.proposals(xyz_np, 128, seed + 1)).to(dev)
-    d["feat130"] = torch.randn(B, 16384, 130, generator=g).to(dev)
-    # FP levels (n, m, C of the coarse features)  config.py:75-82
-    d["fp"] = []
-    for n, m, c in ((256, 64, 1024), (1024, 256, 512), (4096, 1024, 512), (16384, 4096, 256)):
-        unknown = d["xyz"][:, :n].contiguous()
-        known = d["xyz"][:, :m].contiguous()
-        d["fp"].append((unknown, known, torch.randn(B, c, m, generator=g).to(dev)))
-    # LI-Fusion pyramid (C, H, W, npoints)  backbone.py:166-196
-    d["maps"] = [(torch.randn(B, c, h, w, generator=g).to(dev), d["xy"][:, :n].contiguous())
-                 for c, h, w, n in ((64, 192, 640, 4096), (128, 96, 320, 1024), (256, 48, 160, 256),
-                                    (512, 24, 80, 64), (32, 384, 1280, 16384))]
-    d["maps_cl"] = [(fm.contiguous(memory_format=torch.channels_last), xy) for fm, xy in d["maps"]]
-    bev, sc = [], []
-    for b in range(B):
-        bb, ss = synth.bev_boxes(6300, seed + 10 + b)
-        bev.append(torch.from_numpy(bb).to(dev)); sc.append(torch.from_numpy(ss).to(dev))
-    d["bev"], d["scores"] = bev, sc
-    rs, rp = synth.rpn_output(B, 16384, seed + 20)
-    d["rpn_scores"], d["rpn_props"] = torch.from_numpy(rs).to(dev), torch.from_numpy(rp).to(dev)
-    # RCNN SA1 on the pooled RoIs (config.py:134-139): B*128 RoIs x 512 pts x 128 ch -> 128 centres, r=0.2, ns=64
-    from jmodt_amd.ops.pointnet2.pointnet2_modules import PointnetSAModule
-    torch.manual_seed(seed)
-    R = B * 128
-    d["roi_xyz"] = (torch.rand(R, 512, 3, generator=g) - 0.5).mul_(torch.tensor([4.0, 2.0, 2.0])).to(dev)
-    d["roi_feat"] = torch.randn(R, 128, 512, generator=g).to(dev)
-    d["rcnn_sa1"] = PointnetSAModule(mlp=[128, 128, 128, 128], npoint=128, radius=0.2, nsample=64).to(dev).eval()
-    torch.manual_seed(seed)
-    d["link"], d["se"] = make_affinity_mlp().to(dev).eval(), make_affinity_mlp().to(dev).eval()
-    d["pf"] = torch.from_numpy(synth.roi_features(128, 512, seed + 2)).to(dev)
-    d["df"] = torch.from_numpy(synth.roi_features(128, 512, seed + 3)).to(dev)
-    return d
-
-
-def ops_step(d, timer):
-    """every other hot-path op once per frame batch: 3-NN + interpolate (4 FP levels), LI-Fusion
-    gather (5 maps), roipool3d, RPN NMS (6300 boxes per frame), 128x128 affinity per frame"""
-    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
-    from jmodt_amd.ops.fusion import feature_gather
-    from jmodt_amd.ops.roipool3d.roipool3d_utils import roipool3d_gpu
-    from jmodt_amd.ops.iou3d.iou3d_utils import nms_normal_gpu
-    from jmodt_amd.ops.affinity import pairwise_affinity
-    B = d["xyz"].shape[0]
-    for li, (unknown, known, feats) in enumerate(d["fp"]):
-        n, m, c = unknown.shape[1], known.shape[1], feats.shape[1]
-        dist, idx = timer.run(f"three_nn_FP{li + 1}", B * (12 * n + 12 * m + 24 * n), lambda: pu.three_nn(unknown, known))
-        w = 1.0 / (dist + 1e-8)
-        w = w / w.sum(2, keepdim=True)
-        timer.run(f"three_interpolate_FP{li + 1}", B * (4 * c * m + 24 * n + 4 * c * n),
-                  lambda: pu.three_interpolate(feats, idx, w))
-    for mi, (fm, xy) in enumerate(d["maps"]):
-        c, n = fm.shape[1], xy.shape[1]
-        timer.run(f"feature_gather_{mi + 1}", B * n * 4 * c * 4 + B * c * n * 4, lambda: feature_gather(fm, xy))
-    for mi, (fm, xy) in enumerate(d["maps_cl"]):   # same maps in channels_last memory format (no copy inside the op)
-        c, n = fm.shape[1], xy.shape[1]
-        timer.run(f"feature_gather_{mi + 1}_channels_last", B * n * 4 * c * 4 + B * c * n * 4, lambda: feature_gather(fm, xy))
-    N, M, C, S = 16384, 128, 130, 512
-    timer.run("roipool3d", B * (12 * N + 28 * M + 4 * C * N) + B * M * S * (3 + C) * 4 + 4 * B * M,
-              lambda: roipool3d_gpu(d["xyz"], d["feat130"], d["boxes"], 0.2, S))
-    from jmodt_amd.ops.roipool3d.roipool3d_utils import roipool3d_canonical_gpu
-    timer.run("roipool3d+canonical_transform", B * (12 * N + 28 * M + 4 * C * N) + B * M * S * (3 + C) * 4 + 4 * B * M,
-              lambda: roipool3d_canonical_gpu(d["xyz"], d["feat130"], d["boxes"], 0.2, S))
-    for b in range(B):
-        timer.run("nms_normal_6300", 6300 * 20 + 6300 * 99 * 8, lambda: nms_normal_gpu(d["bev"][b], d["scores"][b], 0.8))
-    # the whole batch's proposal selection (sort, band split, 2B batched NMS problems, stitch), TEST budgets
-    from jmodt_amd.ops.proposal import distance_based_proposal
-    timer.run("proposal_select_batched(B frames, pre 9000, post 100)", B * (6300 + 2700) * (20 + 8 * 99),
-              lambda: distance_based_proposal(d["rpn_scores"], d["rpn_props"], 9000, 100, 0.8, "normal"))
-    # RCNN SA1: FPS + ball query are timed inside too (they are part of the module); flops = the MLP only
-    R = d["roi_xyz"].shape[0]
-    rows = R * 128 * 64
-    mlp_flops = rows * 2 * (131 * 128 + 128 * 128 + 128 * 128)
-    with torch.no_grad():
-        timer.run("rcnn_sa1_fused(fps+ball+group+mlp+max)", 0, lambda: d["rcnn_sa1"](d["roi_xyz"], d["roi_feat"]),
-                  flops=mlp_flops)
-    for b in range(B):
-        timer.run("affinity_128x128", 0, lambda: pairwise_affinity(d["pf"], d["df"], d["link"], d["se"]), flops=128 * 128 * (2 * 512 * 512 * 2 + 2 * 512))
-
-
-def make_dense_inputs(B, seed, dev):
-    """BASELINE configs[4] shapes: 65536 points per frame, 256 proposals, 256 x 256 affinity"""
-    from jmodt_amd.ops.affinity import make_affinity_mlp
-    N = 65536
-    xyz_np = synth.cloud(B, N, seed=seed)
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    d = dict(xyz=torch.from_numpy(xyz_np).to(dev), N=N)
-    d["boxes"] = torch.from_numpy(synth.proposals(xyz_np, 256, seed + 1)).to(dev)
-    d["feat130"] = torch.randn(B, N, 130, generator=g).to(dev)
-    torch.manual_seed(seed)
-    d["link"], d["se"] = make_affinity_mlp().to(dev).eval(), make_affinity_mlp().to(dev).eval()
-    d["pf"] = torch.from_numpy(synth.roi_features(256, 512, seed + 2)).to(dev)
-    d["df"] = torch.from_numpy(synth.roi_features(256, 512, seed + 3)).to(dev)
-    return d
-
-
-def dense_step(d, timer):
-    """config 5: level-1 set abstraction inputs on 65536-point clouds (co-operative FPS, dual ball query,
-    grouping), 3-NN back onto the full cloud, roipool3d with the canonical transform for 256 RoIs, 256^2 affinity"""
-    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
-    from jmodt_amd.ops.roipool3d.roipool3d_utils import roipool3d_canonical_gpu
-    from jmodt_amd.ops.affinity import pairwise_affinity
-    xyz, N = d["xyz"], d["N"]
-    B, m = xyz.shape[0], 4096
-    idx = timer.run("fps_65536->4096(coop)", B * m * 20 * N, lambda: pu.farthest_point_sample(xyz, m))
-    xyz_t = xyz.transpose(1, 2).contiguous()
-    new_xyz = pu.gather_operation(xyz_t, idx).transpose(1, 2).contiguous()
-    i0, i1 = timer.run("ball_query_dual_65536", B * (12 * N + 12 * m + 4 * m * 48),
-                       lambda: pu.ball_query_dual(0.1, 16, 0.5, 32, xyz, new_xyz))
-    for ns, nb in ((16, i0), (32, i1)):
-        timer.run("group_points_xyz_65536", B * (4 * m * ns + 12 * N + 12 * m * ns), lambda: pu.grouping_operation(xyz_t, nb))
-    timer.run("three_nn_65536x4096", B * (12 * N + 12 * m + 24 * N), lambda: pu.three_nn(xyz, new_xyz))
-    M, C, S = 256, 130, 512
-    timer.run("roipool3d+canonical_65536x256", B * (12 * N + 28 * M + 4 * C * N) + B * M * S * (3 + C) * 4 + 4 * B * M,
-              lambda: roipool3d_canonical_gpu(xyz, d["feat130"], d["boxes"], 0.2, S))
-    for b in range(B):
-        timer.run("affinity_256x256", 0, lambda: pairwise_affinity(d["pf"], d["df"], d["link"], d["se"]),
-                  flops=256 * 256 * (2 * 512 * 512 * 2 + 2 * 512))
-
-
-def make_train_state(frames, seed, dev):
-    """BASELINE configs[3] per-GPU share: `frames` frames (= frames/2 (prev, next) pairs), 64 sampled RoIs per
-    frame (config.py:204) with 512-d RCNN features and track ids; link / start-end heads + Adam as
-    tools/train.py:96-107 (finetune: only these two heads train)"""
-    from jmodt_amd.ops.affinity import make_affinity_mlp
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    feats = torch.relu(torch.randn(frames, 64, 512, generator=g)).to(dev)
-    tids = torch.randint(0, 13, (frames, 64), generator=g).float().to(dev)     # 0 = background, 12 tracks
-    torch.manual_seed(seed)
-    link, se = make_affinity_mlp().to(dev).train(), make_affinity_mlp().to(dev).train()
-    opt = torch.optim.Adam(list(link.parameters()) + list(se.parameters()), lr=1e-4)
-    return dict(feats=feats, tids=tids, link=link, se=se, opt=opt)
-
-
-def train_step(st, timer, world):
-    """one data-parallel finetune step: local forward/backward of the pairwise affinity losses, ONE bucketed
-    gradient all-reduce over RCCL (4.2 MB of fp32 gradients), optimizer step"""
-    from jmodt_amd.ops.affinity_train import finetune_step
-    timer.run("finetune_step(fwd+bwd+allreduce+adam)", 0,
-              lambda: finetune_step(st["feats"], st["tids"], st["link"], st["se"], st["opt"], world=world))
-
-
 def cpu_baseline_sa(B):
-    """the oracle (CPU restatement, OpenMP) on ONE batch of the same workload"""
+    """the oracle (CPU restatement, OpenMP) on ONE batch of the sa workload"""
     from oracle import oracle as orc
     xyz = synth.cloud(B, 16384, seed=4321)
     rng = np.random.default_rng(0)
@@ -301,19 +145,197 @@ def cpu_baseline_sa(B):
     return B / dt, dt
 
 
+# ---------------------------------------------------------------------------------------------- ops
+def make_ops_inputs(B, seed, dev, small=False):
+    """inputs for the hot-path ops at SURVEY.md §8d shapes (config 3 sizes, M_roi = 128)"""
+    from jmodt_amd.ops.affinity import make_affinity_mlp
+    from jmodt_amd.ops.pointnet2.pointnet2_modules import PointnetSAModule
+    N = 2048 if small else 16384
+    sc = 8 if small else 1
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    xyz_np = synth.cloud(B, N, seed=seed)
+    d = dict(xyz=torch.from_numpy(xyz_np).to(dev), N=N)
+    d["xy"] = torch.from_numpy(synth.pts_xy(xyz_np)).to(dev)
+    d["M"] = 16 if small else 128
+    d["boxes"] = torch.from_numpy(synth.proposals(xyz_np, d["M"], seed + 1)).to(dev)
+    d["feat130"] = torch.randn(B, N, 130, generator=g).to(dev)
+    d["fp"] = []
+    for n, m, c in ((256, 64, 1024), (1024, 256, 512), (4096, 1024, 512), (16384, 4096, 256)):
+        n, m = n // sc, max(m // sc, 3)
+        d["fp"].append((d["xyz"][:, :n].contiguous(), d["xyz"][:, :m].contiguous(), torch.randn(B, c // sc, m, generator=g).to(dev)))
+    d["maps"] = [(torch.randn(B, c // sc, h // sc, w // sc, generator=g).to(dev), d["xy"][:, :n // sc].contiguous())
+                 for c, h, w, n in ((64, 192, 640, 4096), (128, 96, 320, 1024), (256, 48, 160, 256),
+                                    (512, 24, 80, 64), (32, 384, 1280, 16384))]
+    d["maps_cl"] = [(fm.contiguous(memory_format=torch.channels_last), xy) for fm, xy in d["maps"]]
+    nb = 6300 // sc
+    d["bev"], d["scores"] = [], []
+    for b in range(B):
+        bb, ss = synth.bev_boxes(nb, seed + 10 + b)
+        d["bev"].append(torch.from_numpy(bb).to(dev)); d["scores"].append(torch.from_numpy(ss).to(dev))
+    rs, rp = synth.rpn_output(B, N, seed + 20)
+    d["rpn_scores"], d["rpn_props"] = torch.from_numpy(rs).to(dev), torch.from_numpy(rp).to(dev)
+    torch.manual_seed(seed)
+    R = B * d["M"]
+    d["roi_xyz"] = (torch.rand(R, 512, 3, generator=g) - 0.5).mul_(torch.tensor([4.0, 2.0, 2.0])).to(dev)
+    d["roi_feat"] = torch.randn(R, 128, 512, generator=g).to(dev)
+    d["rcnn_sa1"] = PointnetSAModule(mlp=[128, 128, 128, 128], npoint=128, radius=0.2, nsample=64, bn=False).to(dev).eval()
+    d["link"], d["se"] = make_affinity_mlp().to(dev).eval(), make_affinity_mlp().to(dev).eval()
+    P = 32 if small else 128
+    d["pf"] = torch.from_numpy(synth.roi_features(P, 512, seed + 2)).to(dev)
+    d["df"] = torch.from_numpy(synth.roi_features(P, 512, seed + 3)).to(dev)
+    return d
+
+
+def ops_step(d):
+    from jmodt_amd.ops.affinity import pairwise_affinity
+    from jmodt_amd.ops.fusion import feature_gather
+    from jmodt_amd.ops.iou3d.iou3d_utils import nms_normal_gpu
+    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
+    from jmodt_amd.ops.proposal import distance_based_proposal
+    from jmodt_amd.ops.roipool3d.roipool3d_utils import roipool3d_canonical_gpu, roipool3d_gpu
+    B = d["xyz"].shape[0]
+    for li, (unknown, known, feats) in enumerate(d["fp"]):
+        with prof.scope(f"FP{li + 1}"):
+            dist, idx = pu.three_nn(unknown, known)
+            w = 1.0 / (dist + 1e-8)
+            pu.three_interpolate(feats, idx, w / w.sum(2, keepdim=True))
+    for mi, (fm, xy) in enumerate(d["maps"]):
+        with prof.scope(f"map{mi + 1}_nchw"):
+            feature_gather(fm, xy)
+    for mi, (fm, xy) in enumerate(d["maps_cl"]):   # same maps in channels_last memory format (no copy inside the op)
+        with prof.scope(f"map{mi + 1}_channels_last"):
+            feature_gather(fm, xy)
+    roipool3d_gpu(d["xyz"], d["feat130"], d["boxes"], 0.2, 512)
+    roipool3d_canonical_gpu(d["xyz"], d["feat130"], d["boxes"], 0.2, 512)
+    with prof.scope("single"):
+        for b in range(B):
+            nms_normal_gpu(d["bev"][b], d["scores"][b], 0.8)
+    distance_based_proposal(d["rpn_scores"], d["rpn_props"], 9000, 100, 0.8, "normal")
+    with torch.no_grad(), prof.scope("rcnn_sa1"):
+        d["rcnn_sa1"](d["roi_xyz"], d["roi_feat"])
+    for b in range(B):
+        pairwise_affinity(d["pf"], d["df"], d["link"], d["se"])
+
+
+# ---------------------------------------------------------------------------------------------- dense
+def make_dense_inputs(B, seed, dev, small=False):
+    """BASELINE configs[4] shapes: 65536 points per frame, 256 proposals, 256 x 256 affinity"""
+    from jmodt_amd.ops.affinity import make_affinity_mlp
+    N = 32768 if small else 65536
+    M = 32 if small else 256
+    xyz_np = synth.cloud(B, N, seed=seed)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    d = dict(xyz=torch.from_numpy(xyz_np).to(dev), N=N, M=M, m=512 if small else 4096)
+    d["boxes"] = torch.from_numpy(synth.proposals(xyz_np, M, seed + 1)).to(dev)
+    d["feat130"] = torch.randn(B, N, 130, generator=g).to(dev)
+    torch.manual_seed(seed)
+    d["link"], d["se"] = make_affinity_mlp().to(dev).eval(), make_affinity_mlp().to(dev).eval()
+    d["pf"] = torch.from_numpy(synth.roi_features(M, 512, seed + 2)).to(dev)
+    d["df"] = torch.from_numpy(synth.roi_features(M, 512, seed + 3)).to(dev)
+    return d
+
+
+def dense_step(d):
+    from jmodt_amd.ops.affinity import pairwise_affinity
+    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
+    from jmodt_amd.ops.roipool3d.roipool3d_utils import roipool3d_canonical_gpu
+    xyz, m = d["xyz"], d["m"]
+    B = xyz.shape[0]
+    idx, new_xyz = pu.farthest_point_sample_xyz(xyz, m)
+    xyz_t = xyz.transpose(1, 2).contiguous()
+    i0, i1 = pu.ball_query_dual(0.1, 16, 0.5, 32, xyz, new_xyz)
+    for nb in (i0, i1):
+        pu.grouping_operation(xyz_t, nb)
+    pu.three_nn(xyz, new_xyz)
+    roipool3d_canonical_gpu(xyz, d["feat130"], d["boxes"], 0.2, 512)
+    for b in range(B):
+        pairwise_affinity(d["pf"], d["df"], d["link"], d["se"])
+
+
+# ---------------------------------------------------------------------------------------------- train
+def make_train_state(frames, seed, dev, tiny=False):
+    """BASELINE configs[3] per-GPU share: `frames` frames (= frames/2 (prev, next) pairs) through the FROZEN
+    detector (cfg.RPN.FIXED + finetune: tools/train.py:96-107 trains only the link / start-end heads), then the
+    pairwise affinity losses on the 64 sampled RoIs per frame (config.py:153) and Adam"""
+    st = make_detect_state(frames, seed, dev, tiny=tiny)
+    eng = st["engine"]
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    rois_per_frame = min(64, eng.cfg.rpn_post_nms_top_n)
+    st["tids"] = torch.randint(0, 13, (frames, rois_per_frame), generator=g).float().to(dev)     # 0 = background, 12 tracks
+    link, se = eng.rcnn_net.link_layer.train(), eng.rcnn_net.se_layer.train()
+    for p in eng.parameters():
+        p.requires_grad_(False)
+    for p in list(link.parameters()) + list(se.parameters()):
+        p.requires_grad_(True)
+    st["opt"] = torch.optim.Adam(list(link.parameters()) + list(se.parameters()), lr=2e-4, weight_decay=1e-2)
+    st["rois_per_frame"] = rois_per_frame
+    return st
+
+
+def train_step(st, world):
+    """one data-parallel finetune step: frozen composed detector forward (no grad) -> 512-d RoI features ->
+    local forward/backward of the pairwise affinity losses -> ONE bucketed gradient all-reduce over RCCL -> Adam"""
+    from jmodt_amd.ops.affinity_train import finetune_step
+    eng = st["engine"]
+    with torch.no_grad():
+        _, inter = eng.detect(st["xyz"], st["image"], st["pts_xy"])
+    B = st["xyz"].shape[0]
+    feats = inter["rcnn_feat"].view(B, -1, inter["rcnn_feat"].shape[1])[:, :st["rois_per_frame"]].contiguous()
+    return prof.region("finetune(fwd+bwd+allreduce+adam)", lambda: finetune_step(
+        feats, st["tids"], eng.rcnn_net.link_layer, eng.rcnn_net.se_layer, st["opt"], world=world))
+
+
+# ---------------------------------------------------------------------------------------------- main
+WORKLOAD_TEXT = {
+    "detect": "BASELINE configs[2] + affinity: composed detect+affinity forward (LI-Fusion backbone 4xSA-MSG + 4xFP, RPN "
+              "heads, proposal layer, roipool3d+canonical, RCNN 3xSA + heads, box decode, detection NMS, pairwise "
+              "affinity of consecutive frames), 16384-pt frames, 384x1280 image canvas, 128 proposals/frame",
+    "sa": "BASELINE configs[1]: pointnet2 FPS + ball_query(2 radii) + group_points over the 4 RPN SA levels "
+          "(16384->4096->1024->256->64), 16384-pt synthetic clouds",
+    "ops": "supplementary: three_nn+interpolate (4 FP levels), LI-Fusion gather (5 maps), roipool3d (128 RoIs x 512 "
+           "pts x 133), RPN nms_normal (6300 boxes), proposal selection, fused RCNN SA1, 128x128 affinity, per frame",
+    "train": "BASELINE configs[3]: frozen composed detector forward + data-parallel finetune step of the link / "
+             "start-end heads (64 RoIs x 512-d per frame, pairwise affinity losses, bucketed fp32 gradient all-reduce, Adam)",
+    "dense": "supplementary, BASELINE configs[4] shapes: 65536-pt clouds (co-operative FPS -> 4096, dual ball query, "
+             "grouping, 3-NN), roipool3d+canonical for 256 RoIs, 256x256 affinity per frame",
+}
+
+
+def pick_roofline(kernels, traffic_json):
+    """the dominant jm_* entry (caller-side torch spans and stream waits are listed but are not ours to price)"""
+    own = [k for k in kernels if not k.get("stall") and ("algo_bytes_per_step" in k or "algo_flops_per_step" in k)
+           and "(" not in k["kernel"]]
+    if not own:
+        return None
+    dom = own[0]
+    traffic = traffic_json.get(dom["kernel"], {}).get("bytes") if traffic_json else None
+    if "mfma_frac" in dom:
+        return {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_tflops"], "peak": MFMA_F32_PEAK_TF,
+                "unit": "TFLOP/s", "frac": dom["mfma_frac"], "traffic": traffic,
+                "basis": "algorithmic flops 2*rows*sum(c_in*c_out) of the fused MLP (SURVEY.md §8d), time = HIP events "
+                         "around the entry point on its launch stream inside the timed region (includes launch gaps)"}
+    r = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": dom["hbm_frac"], "traffic": traffic, "measured_copy_ceiling_gbs": HBM_COPY_CEILING_GBS,
+         "basis": "algorithmic bytes per SURVEY.md §8(d) (FPS: streaming-equivalent B*m*20n — latency/VALU-bound, "
+                  "compulsory bytes listed alongside); time = HIP events on the launch stream inside the timed region"}
+    if "us_per_fps_iteration" in dom:
+        r["us_per_fps_iteration"] = dom["us_per_fps_iteration"]
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 8; train: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="run the FPS chain on the main stream (no side stream)")
-    ap.add_argument("--workload", default="sa", choices=["sa", "ops", "dense", "train"],
-                    help="sa = BASELINE configs[1] (default); ops = every other hot-path op at its §8d shape; "
-                         "dense = configs[4] shapes (65536 points, 256 RoIs, 256^2 affinity); "
-                         "train = configs[3]: DP finetune step of the affinity heads (gradient all-reduce over RCCL)")
+    ap.add_argument("--no-overlap", action="store_true", help="FPS chain and image branch on the main stream")
+    ap.add_argument("--tiny", action="store_true", help="smoke-sized shapes (tests only; the JSON says so)")
+    ap.add_argument("--workload", default="detect", choices=list(WORKLOAD_TEXT))
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 4 if args.workload == "train" else 8
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -344,20 +366,24 @@ def main():
     from jmodt_amd import _lib
     _lib.load()
 
-    timer = KernelTimer()
-    if args.workload == "sa":
-        xyz, feats = make_sa_inputs(args.batch, 1234 + 1 + rank, dev)
-        step = lambda: sa_step(xyz, feats, timer, overlap=not args.no_overlap)  # noqa: E731
+    seed = 1234 + rank
+    if args.workload == "detect":
+        st = make_detect_state(args.batch, seed + 2, dev, tiny=args.tiny)
+        st["engine"].overlap = not args.no_overlap
+        step = lambda: detect_step(st)  # noqa: E731
+    elif args.workload == "sa":
+        xyz, feats = make_sa_inputs(args.batch, seed + 1, dev)
+        step = lambda: sa_step(xyz, feats, overlap=not args.no_overlap)  # noqa: E731
     elif args.workload == "ops":
-        ops_in = make_ops_inputs(args.batch, 1234 + 2 + rank, dev)
-        step = lambda: ops_step(ops_in, timer)  # noqa: E731
+        ops_in = make_ops_inputs(args.batch, seed + 2, dev, small=args.tiny)
+        step = lambda: ops_step(ops_in)  # noqa: E731
     elif args.workload == "dense":
-        dense_in = make_dense_inputs(args.batch, 1234 + 4 + rank, dev)
-        step = lambda: dense_step(dense_in, timer)  # noqa: E731
+        dense_in = make_dense_inputs(args.batch, seed + 4, dev, small=args.tiny)
+        step = lambda: dense_step(dense_in)  # noqa: E731
     else:
-        train_st = make_train_state(args.batch, 1234 + 3 + rank, dev)
-        step = lambda: train_step(train_st, timer, world)  # noqa: E731
-    import gc
+        train_st = make_train_state(args.batch, seed + 3, dev, tiny=args.tiny)
+        train_st["engine"].overlap = not args.no_overlap
+        step = lambda: train_step(train_st, world)  # noqa: E731
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -365,13 +391,15 @@ def main():
     gc.disable()   # a generation-2 collection in the middle of the timed region is a 30-40 ms host stall
     if dist is not None:
         dist.barrier()
-    timer.enabled = True
+    prof.reset()
+    prof.enabled = True
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    prof.enabled = False
     if dist is not None:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -379,66 +407,67 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        kernels = timer.summary(args.steps)
-        dom = kernels[0]
-        # HBM bytes per launch from the committed rocprofv3 --pmc passes (collected separately, as
-        # the guide prescribes; bench.py itself runs un-profiled)
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        kernels = prof.summary(args.steps, HBM_PEAK_GBS, MFMA_F32_PEAK_TF)
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes (collected separately, as the guide
+        # prescribes; bench.py itself runs un-profiled)
+        tj = None
+        for rnd in ("r02", "r01"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")))
+                break
+            except (OSError, ValueError):
+                continue
+        if tj:
             for k in kernels:
                 if k["kernel"] in tj:
                     k["traffic_bytes_per_launch"] = tj[k["kernel"]]["bytes"]
-            traffic = tj.get(dom["kernel"], {}).get("bytes")
-        except (OSError, ValueError):
-            pass
+        ms_step = elapsed / args.steps * 1e3
+        exposed = sum(k["ms_per_step"] for k in kernels if k.get("stall") and k["kernel"].startswith("fps_exposed"))
+        fps_total = sum(k["ms_per_step"] for k in kernels if k["kernel"].startswith("fps_pyramid/"))
+        img_exposed = sum(k["ms_per_step"] for k in kernels if k.get("stall") and k["kernel"].startswith("image_exposed"))
         frames = world * args.batch * args.steps
         result = {
-            "metric": "frames/sec detect+affinity on 16384-pt KITTI frames; per-kernel HBM-BW fraction",
+            "metric": METRIC,
             "value": round(frames / elapsed, 2),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step": round(ms_step, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: pointnet2 FPS + ball_query(2 radii) + group_points over the "
-                                    "4 RPN SA levels (16384->4096->1024->256->64), 16384-pt synthetic clouds")
-                       if args.workload == "sa" else
-                       ("supplementary: three_nn+interpolate (4 FP levels), LI-Fusion gather (5 maps), roipool3d "
-                        "(128 RoIs x 512 pts x 133), RPN nms_normal (6300 boxes), 128x128 affinity, per frame")
-                       if args.workload == "ops" else
-                       ("supplementary, BASELINE configs[3]: data-parallel finetune step of the link / start-end heads "
-                        "(64 RoIs x 512-d per frame, pairwise affinity losses, bucketed fp32 gradient all-reduce, Adam)")
-                       if args.workload == "train" else
-                       ("supplementary, BASELINE configs[4] shapes: 65536-pt clouds (co-operative FPS -> 4096, dual "
-                        "ball query, grouping, 3-NN), roipool3d+canonical for 256 RoIs, 256x256 affinity per frame"),
-                       "frames_per_gpu_per_step": args.batch, "points": 65536 if args.workload == "dense" else 16384,
+            "config": {"workload": WORKLOAD_TEXT[args.workload] + (" [TINY smoke shapes: not a benchmark]" if args.tiny else ""),
+                       "frames_per_gpu_per_step": args.batch,
+                       "points": (65536 if args.workload == "dense" else 16384) if not args.tiny else "tiny",
                        "parallelism": f"dp{world} (gradient all-reduce)" if args.workload == "train" else f"replicas x{world}"},
-            "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_gbs"],
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["hbm_frac"], "traffic": traffic,
-                         "basis": "algorithmic bytes per SURVEY.md §8(d) (FPS: streaming-equivalent B*m*20n — the "
-                                  "kernel is latency/VALU-bound, its compulsory bytes are B*(12n+4m)); "
-                                  "time = HIP events on the launch stream inside the timed region",
-                         "measured_copy_ceiling_gbs": HBM_COPY_CEILING_GBS,
-                         **({"us_per_fps_iteration": dom["us_per_fps_iteration"]} if "us_per_fps_iteration" in dom else {})},
+            "roofline": pick_roofline(kernels, tj),
+            "overlap": {"fps_chain_ms": round(fps_total, 4), "fps_exposed_ms": round(exposed, 4),
+                        "fps_critical_path_share": round(exposed / ms_step, 4) if ms_step else None,
+                        "image_branch_exposed_ms": round(img_exposed, 4),
+                        "note": "exposed = time the main stream is held at its wait on the side stream (HIP events "
+                                "either side of the wait); chain = sum of the FPS entry points on the side stream"},
             "kernels": kernels,
         }
-        if not args.no_cpu_baseline and args.workload == "sa" and world == 1:   # rank 0 at N = 1 only
+        if not args.no_cpu_baseline and world == 1 and not args.tiny and args.workload in ("detect", "sa"):
+            cores = torch.get_num_threads()
             try:
-                fps, dt = cpu_baseline_sa(args.batch)
-                result["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": os.cpu_count(),
-                                          "kind": "port",
-                                          "sample": f"one batch of {args.batch} frames of the same workload "
-                                                    f"({dt:.1f} s), oracle C restatement with OpenMP over "
-                                                    f"batch/centres (the reference has no CPU code for these ops)"}
+                if args.workload == "detect":
+                    fps, dt = cpu_baseline_detect(2)
+                    sample = (f"2 full-size frames (one (prev, next) pair) through the chained CPU oracle in {dt:.1f} s: "
+                              "oracle C restatement for the jmodt ops (the reference has no CPU code for them), the "
+                              "same PyTorch-CPU operators the reference calls for conv / BN / Linear / grid_sample / "
+                              f"softmax, float32, torch threads = {cores}, os.cpu_count() = {os.cpu_count()}")
+                else:
+                    fps, dt = cpu_baseline_sa(args.batch)
+                    sample = (f"one batch of {args.batch} frames of the same workload ({dt:.1f} s), oracle C restatement "
+                              "with OpenMP over batch/centres (the reference has no CPU code for these ops)")
+                    cores = os.cpu_count()
+                result["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample}
             except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
-                result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
-                                          "sample": f"failed: {ex}"}
+                result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": cores, "kind": "port", "sample": f"failed: {ex!r}"}
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()

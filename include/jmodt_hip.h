@@ -195,6 +195,20 @@ int jm_proposal_select(int b, int n, const float* scores, const float* proposals
 int jm_decode_rpn_proposals(long long num_points, int reg_channels, const float* xyz, const float* rpn_reg,
                             float loc_scope, float loc_bin_size, int num_head_bin, const float* anchor_hwl,
                             int avg_by_bin, float* proposals, jm_stream_t stream);
+/* RCNN box decode = decode_bbox_target as the detection post-processing calls it (tools/eval.py:108-116;
+ * bbox_transform.py:27-260 with roi_box3d (P,7), get_xz_fine=True, get_y_by_bin=False, get_ry_fine=True,
+ * RY_WITH_BIN=False): offsets are in the RoI's canonical frame; the result is rotated back by the RoI heading
+ * and shifted by the RoI centre (bbox_transform.py:8-24,251-258).  rois (P,7), rcnn_reg (P, 4*nb+1+2*nh+3),
+ * anchor_hwl = HOST pointer (3 floats) -> boxes (P,7) [x, y, z, h, w, l, ry]. */
+int jm_decode_rcnn_boxes(long long num_rois, int reg_channels, const float* rois, const float* rcnn_reg,
+                         float loc_scope, float loc_bin_size, int num_head_bin, const float* anchor_hwl,
+                         int avg_by_bin, float* boxes, jm_stream_t stream);
+/* boxes_iou3d_gpu (iou3d_utils.py:25-54) for a whole batch (the RoI sampler's per-frame
+ * Python loop, proposal_target_layer.py:137-151,288): boxes_a (B,Na,7), boxes_b (B,Nb,7) [x,y,z,h,w,l,ry] with
+ * y = box bottom -> iou3d (B,Na,Nb).  counts_b (B) device int32 or NULL: valid boxes per frame in boxes_b
+ * (zero-padded ground-truth lists, :141-145); columns beyond it are written as 0. */
+int jm_boxes_iou3d_batched(int batch, int num_a, const float* boxes_a, int num_b, const float* boxes_b,
+                           const int* counts_b, float* iou3d, jm_stream_t stream);
 /* mask only (N, ceil(N/64)) uint64; tiles with col_block < row_block are never consumed by the
  * reduce (iou3d.cpp:108) and are left unwritten. */
 int jm_nms_mask(int boxes_num, const float* boxes, float nms_overlap_thresh, int normal,

@@ -61,6 +61,8 @@ SIGNATURES = {
     "jm_proposal_select_workspace_bytes": (_Z, [_I, _I, _I]),
     "jm_proposal_select": (_I, [_I, _I, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _Z, _P]),
     "jm_decode_rpn_proposals": (_I, [ctypes.c_longlong, _I, _P, _P, _F, _F, _I, ctypes.POINTER(_F), _I, _P, _P]),
+    "jm_decode_rcnn_boxes": (_I, [ctypes.c_longlong, _I, _P, _P, _F, _F, _I, ctypes.POINTER(_F), _I, _P, _P]),
+    "jm_boxes_iou3d_batched": (_I, [_I, _I, _P, _I, _P, _P, _P, _P]),
     "jm_nms_mask": (_I, [_I, _P, _F, _I, _P, _P]),
     "jm_feature_gather": (_I, [_I, _I, _I, _I, _I, _P, _L, _L, _L, _L, _P, _P, _P]),
     "jm_feature_gather_grad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _L, _L, _L, _L, _P]),
@@ -88,8 +90,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
-    return lib
+    from .profile import LibProxy
+    _lib = LibProxy(lib)     # plain forwarding unless jmodt_amd.profile.prof is enabled (bench.py)
+    return _lib
 
 
 def check(rc, what):
@@ -109,6 +112,12 @@ def dev(t: torch.Tensor, dtype, name: str):
         raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
     if not t.is_cuda:
         raise RuntimeError(f"{name} must be a GPU tensor (jmodt_amd has no CPU path); got device {t.device}")
+    if t.device.index != torch.cuda.current_device():
+        # the launch goes to the CURRENT device's current stream (stream_ptr); a tensor living elsewhere would be
+        # dereferenced on the wrong GPU.  Callers switch with `torch.cuda.device(t.device)` (one process per GPU
+        # never needs to).
+        raise RuntimeError(f"{name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "wrap the call in `with torch.cuda.device(tensor.device):`")
     if t.dtype != dtype:
         raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
     if not t.is_contiguous():

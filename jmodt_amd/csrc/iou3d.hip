@@ -445,6 +445,51 @@ extern "C" int jm_association_cost(int num_pred, const float* pred_boxes, int nu
     return check_launch("association_cost");
 }
 
+// ------------------------------------------------------------------ batched 3D IoU (RoI sampling)
+// boxes_iou3d_gpu (iou3d_utils.py:25-54) for every frame of a batch in one launch: the training-time RoI
+// sampler calls it once per frame in a Python loop (proposal_target_layer.py:137-151, :288), each call being
+// two BEV conversions, one overlap kernel and ~12 torch element-wise kernels.  blockIdx.z = frame; counts_b[f]
+// (device, may be NULL) is the number of valid boxes of frame f in boxes_b (ground-truth lists are zero-padded,
+// proposal_target_layer.py:141-145); columns beyond it are written as 0.
+namespace jm {
+__global__ void __launch_bounds__(256)
+iou3d_batched_kernel(int na, const float* __restrict__ boxes_a, int nb, const float* __restrict__ boxes_b,
+                     const int* __restrict__ counts_b, float* __restrict__ iou_out) {
+    __shared__ Box3 sa[16], sb[16];
+    const int f = blockIdx.z;
+    const float* A0 = boxes_a + (size_t)f * na * 7;
+    const float* B0 = boxes_b + (size_t)f * nb * 7;
+    const int nbv = counts_b ? min(max(counts_b[f], 0), nb) : nb;
+    const int a0 = blockIdx.y * 16, b0 = blockIdx.x * 16;
+    const int t = threadIdx.y * 16 + threadIdx.x;
+    if (t < 16) { if (a0 + t < na) sa[t] = make_box3(A0 + (size_t)(a0 + t) * 7); }
+    else if (t < 32) { if (b0 + t - 16 < nbv) sb[t - 16] = make_box3(B0 + (size_t)(b0 + t - 16) * 7); }
+    __syncthreads();
+    const int ai = a0 + threadIdx.y, bi = b0 + threadIdx.x;
+    if (ai >= na || bi >= nb) return;
+    float iou = 0.f;
+    if (bi < nbv) {
+        const Box3& A = sa[threadIdx.y];
+        const Box3& B = sb[threadIdx.x];
+        const float ov_bev = rbox_overlap(A.bev, B.bev);
+        const float hmin = fmaxf(A.cy - A.h, B.cy - B.h), hmax = fminf(A.cy, B.cy);
+        const float ov3 = ov_bev * fmaxf(hmax - hmin, 0.f);
+        iou = ov3 / fmaxf(A.vol + B.vol - ov3, 1e-7f);
+    }
+    iou_out[((size_t)f * na + ai) * nb + bi] = iou;
+}
+}  // namespace jm
+
+extern "C" int jm_boxes_iou3d_batched(int batch, int num_a, const float* boxes_a, int num_b, const float* boxes_b,
+                                      const int* counts_b, float* iou3d, jm_stream_t stream) {
+    JM_REQUIRE(batch >= 0 && num_a >= 0 && num_b >= 0 && batch <= 65535, "boxes_iou3d_batched: bad sizes");
+    if (batch == 0 || num_a == 0 || num_b == 0) return JM_OK;
+    JM_REQUIRE(boxes_a && boxes_b && iou3d, "boxes_iou3d_batched: null pointer");
+    hipLaunchKernelGGL(iou3d_batched_kernel, dim3(divup(num_b, 16), divup(num_a, 16), batch), dim3(16, 16), 0,
+                       (hipStream_t)stream, num_a, boxes_a, num_b, boxes_b, counts_b, iou3d);
+    return check_launch("boxes_iou3d_batched");
+}
+
 extern "C" size_t jm_nms_workspace_bytes(int boxes_num) {
     if (boxes_num <= 0) return 0;
     const size_t cb = (size_t)(boxes_num + 63) / 64;

@@ -11,6 +11,7 @@
 //   nms_mask / nms_reduce    (iou3d.hip) all 2 B problems at once, counts read on the device
 //   proposal_stitch_kernel   kept boxes of band 0 then band 1, post budgets, zero padding
 #include "jm_common.h"
+#include "../../include/jm_detmath.h"
 
 namespace jm {
 
@@ -265,4 +266,80 @@ extern "C" int jm_decode_rpn_proposals(long long num_points, int reg_channels, c
                        num_points, reg_channels, nb, num_head_bin, loc_scope, loc_bin_size, anchor_hwl[0], anchor_hwl[1],
                        anchor_hwl[2], avg_by_bin ? 1 : 0, xyz, rpn_reg, proposals);
     return check_launch("decode_rpn");
+}
+
+// ------------------------------------------------------------------------------------------------
+// RCNN box decode = decode_bbox_target as the detection post-processing calls it (tools/eval.py:108-116;
+// bbox_transform.py:27-260 with roi_box3d (P,7), get_xz_fine = True, get_y_by_bin = False, get_ry_fine = True,
+// RY_WITH_BIN = False): the offsets are predicted in the RoI's canonical frame, so the decoded centre is
+// rotated back by the RoI heading (rotate_pc_along_y_torch(box, -roi_ry), bbox_transform.py:8-24,251-256)
+// and shifted by the RoI centre; heading bins cover (-pi/4, pi/4) around the RoI heading (:131-135).
+// y is NOT moved to the bottom face here (that `+= h/2` belongs to the RPN's ProposalLayer only).
+namespace jm {
+
+__global__ void __launch_bounds__(256)
+decode_rcnn_kernel(long long total, int C, int nb, int nh, float loc_scope, float bin_size, float a_h, float a_w,
+                   float a_l, int avg_by_bin, const float* __restrict__ rois, const float* __restrict__ reg,
+                   float* __restrict__ out) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    const float* r = reg + p * C;
+    const float* roi = rois + p * 7;
+    auto axis = [&](int bin_off, int res_off) {
+        if (avg_by_bin) {
+            float mx = -INFINITY;
+            for (int i = 0; i < nb; ++i) mx = fmaxf(mx, r[bin_off + i]);
+            float den = 0.f, num = 0.f;
+            for (int i = 0; i < nb; ++i) {
+                const float e = expf(r[bin_off + i] - mx);
+                const float centre = (float)i * bin_size + bin_size / 2 - loc_scope;
+                den += e;
+                num += e * (centre + r[res_off + i] * bin_size);
+            }
+            return num / den;
+        }
+        int best = 0;
+        float bv = r[bin_off];
+        for (int i = 1; i < nb; ++i) if (r[bin_off + i] > bv) { bv = r[bin_off + i]; best = i; }
+        return (float)best * bin_size + bin_size / 2 - loc_scope + r[res_off + best] * bin_size;
+    };
+    const float pos_x = axis(0, 2 * nb);
+    const float pos_z = axis(nb, 3 * nb);
+    int off = 4 * nb;
+    const float pos_y = roi[1] + r[off];
+    off += 1;
+    int rb = 0;
+    float rv = r[off];
+    for (int i = 1; i < nh; ++i) if (r[off + i] > rv) { rv = r[off + i]; rb = i; }
+    const float half_pi = 1.5707963267948966f, quarter_pi = 0.7853981633974483f;
+    const float apc = half_pi / (float)nh;
+    float ry = ((float)rb * apc + apc / 2) + r[off + nh + rb] * (apc / 2) - quarter_pi;
+    off += 2 * nh;
+    const float h = r[off] * a_h + a_h, w = r[off + 1] * a_w + a_w, l = r[off + 2] * a_l + a_l;
+    // rotate (x, z) by -roi_ry: [x, z] @ [[cos, -sin], [sin, cos]]^T with the angle -roi_ry
+    const float roi_ry = roi[6];
+    float sn, cs;
+    jm_sincosf(-roi_ry, &sn, &cs);
+    const float x = pos_x * cs + pos_z * (-sn);
+    const float z = pos_x * sn + pos_z * cs;
+    ry += roi_ry;
+    float* o = out + p * 7;
+    o[0] = x + roi[0]; o[1] = pos_y; o[2] = z + roi[2]; o[3] = h; o[4] = w; o[5] = l; o[6] = ry;
+}
+
+}  // namespace jm
+
+extern "C" int jm_decode_rcnn_boxes(long long num_rois, int reg_channels, const float* rois, const float* rcnn_reg,
+                                    float loc_scope, float loc_bin_size, int num_head_bin, const float* anchor_hwl,
+                                    int avg_by_bin, float* boxes, jm_stream_t stream) {
+    JM_REQUIRE(num_rois >= 0 && loc_bin_size > 0.f && num_head_bin >= 1 && anchor_hwl, "decode_rcnn: bad arguments");
+    if (num_rois == 0) return JM_OK;
+    JM_REQUIRE(rois && rcnn_reg && boxes, "decode_rcnn: null pointer");
+    const int nb = (int)(loc_scope / loc_bin_size) * 2;
+    JM_REQUIRE(nb >= 1 && reg_channels == 4 * nb + 1 + 2 * num_head_bin + 3,
+               "decode_rcnn: %d regression channels, expected 4*%d + 1 + 2*%d + 3", reg_channels, nb, num_head_bin);
+    hipLaunchKernelGGL(decode_rcnn_kernel, dim3((unsigned)divup(num_rois, 256LL)), dim3(256), 0, (hipStream_t)stream,
+                       num_rois, reg_channels, nb, num_head_bin, loc_scope, loc_bin_size, anchor_hwl[0], anchor_hwl[1],
+                       anchor_hwl[2], avg_by_bin ? 1 : 0, rois, rcnn_reg, boxes);
+    return check_launch("decode_rcnn");
 }

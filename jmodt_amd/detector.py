@@ -1,0 +1,498 @@
+"""The composed detect + affinity forward: the CALLER of the jmodt.ops hot path (SURVEY.md §2 rows 9-12,
+BASELINE.json configs[2] + the pairwise affinity of configs[0]).
+
+What the reference spreads over jmodt/detection/modeling/{backbone,rpn,rcnn,point_rcnn}.py,
+layers/{proposal_layer,proposal_target_layer}.py and tracking/tracker.py:81-112 is ONE inference
+pipeline here, laid out for a single MI355X:
+
+    stream F  FPS pyramid 16384 -> 4096 -> 1024 -> 256 -> 64 (coordinates only; one workgroup / frame)
+    stream I  image branch: 4 x (conv3x3 + BN + ReLU + conv3x3/2), channels-last, then the fused image map
+    stream M  per level: fused SA scale kernels (ball query + group + MLP + max) -> LI-Fusion gather
+              -> attention fusion; 4 x feature propagation; RPN heads; proposal layer (decode + banded NMS,
+              whole batch, no host sync); roipool3d + canonical transform; RCNN (xyz lift + 3 SA levels
+              + heads); box decode; per-frame detection NMS on the device; pairwise affinity of
+              consecutive frames straight from the resident RoI features.
+
+The parameter containers keep the reference's attribute names (`rpn.backbone_net.SA_modules.0.mlps.1.layer2.conv`,
+`rpn.backbone_net.Fusion_Conv.2.IA_Layer.fc1`, `rcnn_net.link_layer.3.conv`, ...), so a JMODT checkpoint's
+`model_state` loads with `load_state_dict`; the forward code is this package's own.  All dense arithmetic is
+float32 (the reference's arithmetic; `dtype` of bench.py).  Eval mode only: BatchNorm is folded into the
+neighbouring 1x1 convolution where that removes a pass over a tensor.
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .ops import proposal as proposal_ops
+from .ops.affinity import make_affinity_mlp, pairwise_affinity
+from .ops.detections import DetectionCache, decode_rcnn_boxes, select_detections
+from .ops.fusion import feature_gather
+from .ops.pointnet2 import pytorch_utils as pt_utils
+from .ops.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModule, PointnetSAModuleMSG
+from .ops.pointnet2.pyramid import FpsPyramid, side_stream
+from .profile import prof
+from .ops.roipool3d.roipool3d_utils import roipool3d_canonical_gpu
+
+
+@dataclass
+class DetectorConfig:
+    """the values of jmodt/config.py the forward depends on (line numbers of that file)"""
+    # RPN backbone (config.py:71-82)
+    sa_npoints: Sequence[int] = (4096, 1024, 256, 64)
+    sa_radius: Sequence[Sequence[float]] = ((0.1, 0.5), (0.5, 1.0), (1.0, 2.0), (2.0, 4.0))
+    sa_nsample: Sequence[Sequence[int]] = ((16, 32), (16, 32), (16, 32), (16, 32))
+    sa_mlps: Sequence[Sequence[Sequence[int]]] = (((16, 16, 32), (32, 32, 64)), ((64, 64, 128), (64, 96, 128)),
+                                                  ((128, 196, 256), (128, 196, 256)), ((256, 256, 512), (256, 384, 512)))
+    fp_mlps: Sequence[Sequence[int]] = ((128, 128), (256, 256), (512, 512), (512, 512))
+    rpn_cls_fc: Sequence[int] = (128,)
+    rpn_reg_fc: Sequence[int] = (128,)
+    rpn_dp_ratio: float = 0.5
+    rpn_loc_scope: float = 3.0            # :65-68
+    rpn_loc_bin_size: float = 0.5
+    rpn_num_head_bin: int = 12
+    rpn_score_thresh: float = 0.2         # :97
+    # LI-Fusion (config.py:43-52)
+    img_channels: Sequence[int] = (3, 64, 128, 256, 512)
+    point_channels: Sequence[int] = (96, 256, 512, 1024)
+    deconv_reduce: Sequence[int] = (16, 16, 16, 16)
+    deconv_kernels: Sequence[int] = (2, 4, 8, 16)
+    img_features_channel: int = 128
+    # proposal layer, TEST mode (config.py:224-230); post_nms_top_n is 100 in the reference, SURVEY.md §8 uses 128
+    rpn_pre_nms_top_n: int = 9000
+    rpn_post_nms_top_n: int = 128
+    rpn_nms_thresh: float = 0.8
+    rpn_nms_type: str = "normal"          # :94
+    # RCNN (config.py:100-139)
+    pool_extra_width: float = 0.2         # :115
+    rcnn_num_points: int = 512            # :132
+    rcnn_xyz_up: Sequence[int] = (128, 128)
+    rcnn_sa_npoints: Sequence[int] = (128, 32, -1)
+    rcnn_sa_radius: Sequence[float] = (0.2, 0.4, 100.0)
+    rcnn_sa_nsample: Sequence[int] = (64, 64, 64)
+    rcnn_sa_mlps: Sequence[Sequence[int]] = ((128, 128, 128), (128, 128, 256), (256, 256, 512))
+    rcnn_cls_fc: Sequence[int] = (512, 512)
+    rcnn_reg_fc: Sequence[int] = (512, 512)
+    rcnn_loc_scope: float = 1.5           # :118-124
+    rcnn_loc_bin_size: float = 0.5
+    rcnn_num_head_bin: int = 9
+    rcnn_score_thresh: float = 0.2        # :159-160
+    rcnn_nms_thresh: float = 0.1
+    # re-id heads (config.py:163-169)
+    link_fc: Sequence[int] = (512, 512)
+    se_fc: Sequence[int] = (512, 512)
+    mean_size: Sequence[float] = proposal_ops.CLS_MEAN_SIZE    # :38
+
+    @property
+    def rpn_reg_channels(self) -> int:   # rpn.py:31-37 with LOC_XZ_FINE
+        return int(self.rpn_loc_scope / self.rpn_loc_bin_size) * 2 * 4 + self.rpn_num_head_bin * 2 + 3 + 1
+
+    @property
+    def rcnn_reg_channels(self) -> int:  # rcnn.py:73-77 with LOC_Y_BY_BIN = False
+        return int(self.rcnn_loc_scope / self.rcnn_loc_bin_size) * 2 * 4 + self.rcnn_num_head_bin * 2 + 3 + 1
+
+    @staticmethod
+    def tiny() -> "DetectorConfig":
+        """same topology, small widths / point counts: the chained-oracle tests and smoke runs"""
+        return DetectorConfig(
+            sa_npoints=(256, 128, 64, 32), sa_radius=((0.6, 1.5), (1.5, 3.0), (3.0, 6.0), (6.0, 12.0)),
+            sa_mlps=(((16, 16, 16), (16, 16, 32)), ((16, 16, 32), (16, 32, 32)), ((32, 32, 64), (32, 48, 64)),
+                     ((64, 64, 64), (64, 80, 64))),
+            fp_mlps=((32, 32), (32, 32), (64, 64), (64, 64)), rpn_cls_fc=(32,), rpn_reg_fc=(32,),
+            img_channels=(3, 8, 16, 16, 32), point_channels=(48, 64, 128, 128), deconv_reduce=(4, 4, 4, 4),
+            img_features_channel=32, rpn_pre_nms_top_n=300, rpn_post_nms_top_n=16, rcnn_num_points=64,
+            rcnn_xyz_up=(32, 32), rcnn_sa_npoints=(32, 8, -1), rcnn_sa_radius=(0.8, 1.6, 100.0),
+            rcnn_sa_nsample=(16, 16, 16), rcnn_sa_mlps=((32, 32, 32), (32, 32, 64), (64, 64, 64)),
+            rcnn_cls_fc=(64, 64), rcnn_reg_fc=(64, 64), link_fc=(64, 64), se_fc=(64, 64))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# parameter containers (reference attribute names; forward code below is the engine's)
+# ---------------------------------------------------------------------------------------------------------
+
+class ImageBlock(nn.Module):
+    """conv3x3 + BN + ReLU + conv3x3 stride 2 (BasicBlock of backbone.py:16-32 with stride=1)"""
+
+    def __init__(self, cin: int, cout: int):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride=1, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, stride=2, padding=1, bias=False)
+
+    def forward(self, x):
+        return self.conv2(F.relu(self.bn1(self.conv1(x)), inplace=True))
+
+
+class IALayer(nn.Module):
+    """point-wise attention of the image feature by the point feature (backbone.py:35-63)"""
+
+    def __init__(self, ic: int, pc: int):
+        super().__init__()
+        rc = pc // 4
+        self.conv1 = nn.Sequential(nn.Conv1d(ic, pc, 1), nn.BatchNorm1d(pc), nn.ReLU())
+        self.fc1, self.fc2, self.fc3 = nn.Linear(ic, rc), nn.Linear(pc, rc), nn.Linear(rc, 1)
+
+    def forward(self, img_feats, point_feats):
+        # (B, C, n) operands; the Linear layers act on the channel axis
+        gate = torch.sigmoid(self.fc3(torch.tanh(self.fc1(img_feats.transpose(1, 2)) + self.fc2(point_feats.transpose(1, 2)))))
+        return self.conv1(img_feats) * gate.transpose(1, 2)
+
+
+class AttentionFusion(nn.Module):
+    """backbone.py:66-81"""
+
+    def __init__(self, ic: int, pc: int, oc: int):
+        super().__init__()
+        self.IA_Layer = IALayer(ic, pc)
+        self.conv1 = nn.Conv1d(pc + pc, oc, 1)
+        self.bn1 = nn.BatchNorm1d(oc)
+
+    def forward(self, point_feats, img_feats):
+        return F.relu(self.bn1(self.conv1(torch.cat((point_feats, self.IA_Layer(img_feats, point_feats)), dim=1))))
+
+
+class PointNet2MSG(nn.Module):
+    """parameters of the LI-Fusion backbone (backbone.py:92-157)"""
+
+    def __init__(self, cfg: DetectorConfig, input_channels: int = 0):
+        super().__init__()
+        self.SA_modules = nn.ModuleList()
+        cin, skip = input_channels, [input_channels]
+        for k, npoint in enumerate(cfg.sa_npoints):
+            specs = [[cin] + list(m) for m in cfg.sa_mlps[k]]
+            self.SA_modules.append(PointnetSAModuleMSG(npoint=npoint, radii=list(cfg.sa_radius[k]),
+                                                       nsamples=list(cfg.sa_nsample[k]), mlps=specs, use_xyz=True, bn=True))
+            cin = sum(m[-1] for m in cfg.sa_mlps[k])
+            skip.append(cin)
+        self.Img_Block, self.Fusion_Conv, self.DeConv = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        for i in range(len(cfg.img_channels) - 1):
+            self.Img_Block.append(ImageBlock(cfg.img_channels[i], cfg.img_channels[i + 1]))
+            self.Fusion_Conv.append(AttentionFusion(cfg.img_channels[i + 1], cfg.point_channels[i], cfg.point_channels[i]))
+            self.DeConv.append(nn.ConvTranspose2d(cfg.img_channels[i + 1], cfg.deconv_reduce[i],
+                                                  kernel_size=cfg.deconv_kernels[i], stride=cfg.deconv_kernels[i]))
+        q = cfg.img_features_channel // 4
+        self.image_fusion_conv = nn.Conv2d(sum(cfg.deconv_reduce), q, kernel_size=1)
+        self.image_fusion_bn = nn.BatchNorm2d(q)
+        self.final_fusion_img_point = AttentionFusion(q, cfg.img_features_channel, cfg.img_features_channel)
+        self.FP_modules = nn.ModuleList()
+        for k in range(len(cfg.fp_mlps)):
+            pre = cfg.fp_mlps[k + 1][-1] if k + 1 < len(cfg.fp_mlps) else cin
+            self.FP_modules.append(PointnetFPModule(mlp=[pre + skip[k]] + list(cfg.fp_mlps[k])))
+
+
+def _head(cin: int, fc: Sequence[int], cout: int, bn: bool, dp_ratio: float) -> nn.Sequential:
+    """Conv1d(+BN)+ReLU per hidden width, Dropout after the first one when dp_ratio >= 0, plain Conv1d last
+    (rpn.py:20-46, rcnn.py:43-89)"""
+    layers: List[nn.Module] = []
+    pre = cin
+    for width in fc:
+        layers.append(pt_utils.Conv1d(pre, width, bn=bn))
+        pre = width
+    layers.append(pt_utils.Conv1d(pre, cout, activation=None))
+    if dp_ratio >= 0:
+        layers.insert(1, nn.Dropout(dp_ratio))
+    return nn.Sequential(*layers)
+
+
+class RPN(nn.Module):
+    def __init__(self, cfg: DetectorConfig):
+        super().__init__()
+        self.backbone_net = PointNet2MSG(cfg)
+        width = cfg.fp_mlps[0][-1]
+        self.rpn_cls_layer = _head(width, cfg.rpn_cls_fc, 1, True, cfg.rpn_dp_ratio)
+        self.rpn_reg_layer = _head(width, cfg.rpn_reg_fc, cfg.rpn_reg_channels, True, cfg.rpn_dp_ratio)
+        # rpn.py:64-69: focal-loss prior on the objectness bias, small regression weights
+        nn.init.constant_(self.rpn_cls_layer[2].conv.bias, -4.59511985013459)
+        nn.init.normal_(self.rpn_reg_layer[-1].conv.weight, mean=0, std=0.001)
+
+
+class RCNN(nn.Module):
+    def __init__(self, cfg: DetectorConfig, input_channels: int):
+        super().__init__()
+        self.rcnn_input_channel = 5          # xyz + mask + depth (rcnn.py:21)
+        self.xyz_up_layer = pt_utils.SharedMLP([self.rcnn_input_channel] + list(cfg.rcnn_xyz_up), bn=False)
+        c_out = cfg.rcnn_xyz_up[-1]
+        self.merge_down_layer = pt_utils.SharedMLP([c_out * 2, c_out], bn=False)
+        self.SA_modules = nn.ModuleList()
+        cin = input_channels
+        for k, npoint in enumerate(cfg.rcnn_sa_npoints):
+            self.SA_modules.append(PointnetSAModule(npoint=npoint if npoint != -1 else None, radius=cfg.rcnn_sa_radius[k],
+                                                    nsample=cfg.rcnn_sa_nsample[k], mlp=[cin] + list(cfg.rcnn_sa_mlps[k]),
+                                                    use_xyz=True, bn=False))
+            cin = cfg.rcnn_sa_mlps[k][-1]
+        self.cls_layer = _head(cin, cfg.rcnn_cls_fc, 1, False, 0.0)
+        self.reg_layer = _head(cin, cfg.rcnn_reg_fc, cfg.rcnn_reg_channels, False, 0.0)
+        self.link_layer = make_affinity_mlp(cin, tuple(cfg.link_fc))
+        self.se_layer = make_affinity_mlp(cin, tuple(cfg.se_fc))
+        for m in self.modules():             # rcnn.py:116-134
+            if isinstance(m, (nn.Conv1d, nn.Conv2d)):
+                nn.init.xavier_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        nn.init.normal_(self.reg_layer[-1].conv.weight, mean=0, std=0.001)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the engine
+# ---------------------------------------------------------------------------------------------------------
+
+def _fold_conv_bn(conv: nn.Module, bn: Optional[nn.Module]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(W (out, in), b (out)) of a 1x1 convolution / Linear followed by an eval-mode BatchNorm"""
+    W = conv.weight.detach().reshape(conv.weight.shape[0], -1)
+    b = conv.bias.detach() if conv.bias is not None else W.new_zeros(W.shape[0])
+    if bn is not None:
+        scale = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+        W = W * scale[:, None]
+        b = (b - bn.running_mean.detach()) * scale + bn.bias.detach()
+    return W.contiguous(), b.contiguous()
+
+
+def _unit_wb(unit: nn.Module) -> Tuple[torch.Tensor, torch.Tensor]:
+    """folded (W, b) of a pytorch_utils Conv1d/Conv2d unit (conv [+ bn.bn])"""
+    bn = unit.bn.bn if hasattr(unit, "bn") else None
+    return _fold_conv_bn(unit.conv, bn)
+
+
+class DetectAffinityEngine(nn.Module):
+    """PointRCNN-with-affinity inference (point_rcnn.py:24-70 in EVAL mode + tools/eval.py:84-190 post-processing +
+    tracker.py:81-112 affinity), batch-level, device-resident end to end."""
+
+    def __init__(self, cfg: Optional[DetectorConfig] = None):
+        super().__init__()
+        self.cfg = cfg or DetectorConfig()
+        self.rpn = RPN(self.cfg)
+        self.rcnn_net = RCNN(self.cfg, input_channels=self.cfg.fp_mlps[0][-1])
+        self.eval()
+        self._folded: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.overlap = True                # FPS pyramid + image branch on side streams
+        self.last_fps_idx: List[torch.Tensor] = []
+
+    # -- helpers -------------------------------------------------------------------------------------
+    @staticmethod
+    def _t(name: str, algo_bytes: int, fn, flops: int = 0):
+        """caller-side (torch / MIOpen / rocBLAS) span, timed when jmodt_amd.profile.prof is enabled; the jm_*
+        entry points time themselves"""
+        return prof.region(name, fn, algo_bytes, flops)
+
+    def _wb(self, key: str, make):
+        hit = self._folded.get(key)
+        if hit is None:
+            hit = self._folded[key] = make()
+        return hit
+
+    def invalidate(self):
+        """drop folded weights (call after loading a checkpoint)"""
+        self._folded.clear()
+
+    def _attention_fusion(self, tag: str, mod: AttentionFusion, point_feats: torch.Tensor, img_feats: torch.Tensor):
+        """AttentionFusion.forward on (B, C, n) operands with the BatchNorms folded (backbone.py:44-81)"""
+        W_i, b_i = self._wb(tag + ".ia", lambda: _fold_conv_bn(mod.IA_Layer.conv1[0], mod.IA_Layer.conv1[1]))
+        W_f, b_f = self._wb(tag + ".fuse", lambda: _fold_conv_bn(mod.conv1, mod.bn1))
+        ia = mod.IA_Layer
+        it, pt = img_feats.transpose(1, 2), point_feats.transpose(1, 2)                    # (B, n, C) views
+        gate = torch.sigmoid(ia.fc3(torch.tanh(ia.fc1(it) + ia.fc2(pt))))                  # (B, n, 1)
+        img_new = torch.relu(torch.baddbmm(b_i[None, :, None], W_i.expand(img_feats.shape[0], -1, -1), img_feats))
+        img_new = img_new * gate.transpose(1, 2)
+        pc = point_feats.shape[1]
+        # conv1 on the concatenation = two GEMMs accumulating into one output (no cat tensor)
+        out = torch.baddbmm(b_f[None, :, None], W_f[:, :pc].expand(point_feats.shape[0], -1, -1), point_feats)
+        out = torch.baddbmm(out, W_f[:, pc:].expand(point_feats.shape[0], -1, -1), img_new)
+        return torch.relu_(out)
+
+    def _head_forward(self, tag: str, head: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+        """a Conv1d head on (B, C, n): folded 1x1 convolutions as batched GEMMs"""
+        units = [m for m in head if not isinstance(m, nn.Dropout)]
+        for li, unit in enumerate(units):
+            W, b = self._wb(f"{tag}.{li}", lambda u=unit: _unit_wb(u))
+            x = torch.baddbmm(b[None, :, None], W.expand(x.shape[0], -1, -1), x)
+            if getattr(unit, "activation", None) is not None:
+                x = torch.relu_(x)
+        return x
+
+    # -- stage 1: backbone + RPN heads -----------------------------------------------------------------
+    @torch.no_grad()
+    def backbone(self, xyz: torch.Tensor, image: torch.Tensor, pts_xy: torch.Tensor) -> torch.Tensor:
+        """xyz (B, N, 3), image (B, 3, H, W), pts_xy (B, N, 2) in [-1, 1] -> point features (B, 128, N)
+        (PointNet2MSG.forward, backbone.py:159-196)"""
+        cfg, net = self.cfg, self.rpn.backbone_net
+        dev = xyz.device
+        main = torch.cuda.current_stream(dev)
+        B, N, _ = xyz.shape
+        # --- stream F: the whole FPS chain (coordinates only) ---
+        pyr = FpsPyramid(xyz, list(cfg.sa_npoints), overlap=self.overlap)
+        # --- stream I: image pyramid, channels-last ---
+        img_stream = side_stream(dev, 1) if self.overlap else main
+        img_stream.wait_stream(main)
+        img_maps, img_events = [], []
+        with torch.cuda.stream(img_stream):
+            cur = image.contiguous(memory_format=torch.channels_last)
+            for i, blk in enumerate(net.Img_Block):
+                cur = self._t(f"image_block_{i + 1}(MIOpen)", 0, lambda b=blk, c=cur: b(c))
+                ev = torch.cuda.Event()
+                ev.record(img_stream)
+                cur.record_stream(main)
+                img_maps.append(cur)
+                img_events.append(ev)
+            fused_map = self._t("image_deconv+fusion_conv(MIOpen)", 0, lambda: self._image_fusion_map(img_maps))
+            fused_ev = torch.cuda.Event()
+            fused_ev.record(img_stream)
+            fused_map.record_stream(main)
+        # --- stream M: set abstraction + LI-Fusion per level ---
+        l_xyz, l_feats, l_xy = [xyz], [None], [pts_xy]
+        for i, sa in enumerate(net.SA_modules):
+            idx, new_xyz = pyr.level(i)
+            with prof.scope(f"rpn_sa{i + 1}"):
+                _, feats, _ = sa(l_xyz[i], l_feats[i], new_xyz=new_xyz)
+            xy_i = torch.gather(l_xy[i], 1, idx.long().unsqueeze(-1).expand(-1, -1, 2))       # backbone.py:170-171
+            prof.stall(f"image_exposed_wait_L{i + 1}", lambda e=img_events[i]: main.wait_event(e))
+            with prof.scope(f"li_fusion{i + 1}"):
+                gathered = feature_gather(img_maps[i], xy_i)
+                feats = self._t("attention_fusion(rocBLAS)", 0, lambda f=feats, g=gathered, k=i: self._attention_fusion(
+                    f"fusion{k}", net.Fusion_Conv[k], f, g))
+            l_xyz.append(new_xyz); l_feats.append(feats); l_xy.append(xy_i)
+        # --- feature propagation, coarse to fine (backbone.py:182-185) ---
+        for i in range(-1, -(len(net.FP_modules) + 1), -1):
+            with prof.scope(f"fp{len(net.FP_modules) + 1 + i}"):
+                l_feats[i - 1] = net.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i])
+        # --- final image fusion on the full cloud (backbone.py:187-195) ---
+        prof.stall("image_exposed_wait_final", lambda: main.wait_event(fused_ev))
+        with prof.scope("li_fusion_final"):
+            gathered = feature_gather(fused_map, pts_xy)
+            out = self._t("attention_fusion(rocBLAS)", 0, lambda: self._attention_fusion(
+                "fusion_final", net.final_fusion_img_point, l_feats[0], gathered))
+        if self.overlap:
+            img_stream.wait_stream(main)     # image buffers are not recycled under the main stream's readers
+        self.last_fps_idx = [pyr.level(i)[0] for i in range(len(cfg.sa_npoints))]
+        pyr.release()
+        return out
+
+    def _image_fusion_map(self, img_maps: List[torch.Tensor]) -> torch.Tensor:
+        """relu(bn(conv1x1(cat_i deconv_i(img_i)))) (backbone.py:187-193).  The 1x1 fusion convolution is linear,
+        so its slice for pyramid level i is composed with that level's kernel==stride transposed convolution into
+        ONE transposed convolution per level writing the 32-channel result directly: the 64-channel concatenation
+        (1 GB at 384x1280, batch 8) is never materialised."""
+        net = self.rpn.backbone_net
+
+        def make():
+            Wf, bf = _fold_conv_bn(net.image_fusion_conv, net.image_fusion_bn)     # (q, sum reduce)
+            ws, off = [], 0
+            bias = bf.clone()
+            for dc in net.DeConv:
+                r = dc.out_channels
+                Wi = dc.weight.detach()                                           # (cin, r, k, k)
+                Ws = Wf[:, off:off + r]                                           # (q, r)
+                ws.append(torch.einsum("crhw,qr->cqhw", Wi, Ws).contiguous())
+                bias += Ws @ dc.bias.detach()
+                off += r
+            return ws, bias
+        ws, bias = self._wb("img_fusion", make)
+        acc = None
+        for i, (m, w) in enumerate(zip(img_maps, ws)):
+            k = net.DeConv[i].kernel_size[0]
+            y = F.conv_transpose2d(m, w, bias if i == 0 else None, stride=k)
+            acc = y if acc is None else acc.add_(y)
+        return torch.relu_(acc)
+
+    @torch.no_grad()
+    def rpn_forward(self, xyz, image, pts_xy) -> Dict[str, torch.Tensor]:
+        """RPN.forward (rpn.py:71-87): backbone features + objectness / box regression per point"""
+        feats = self.backbone(xyz, image, pts_xy)
+        def heads():
+            cls = self._head_forward("rpn_cls", self.rpn.rpn_cls_layer, feats).transpose(1, 2).contiguous()   # (B, N, 1)
+            reg = self._head_forward("rpn_reg", self.rpn.rpn_reg_layer, feats).transpose(1, 2).contiguous()   # (B, N, C)
+            return cls, reg
+        rpn_cls, rpn_reg = self._t("rpn_heads(rocBLAS)", 0, heads)
+        return dict(rpn_cls=rpn_cls, rpn_reg=rpn_reg, backbone_xyz=xyz, backbone_features=feats)
+
+    # -- stage 2: proposals + RoI pooling + RCNN ---------------------------------------------------------
+    @torch.no_grad()
+    def proposals(self, rpn_out: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+        """ProposalLayer.forward for the batch (proposal_layer.py:16-55; point_rcnn.py:47)"""
+        cfg = self.cfg
+        B, N = rpn_out["rpn_cls"].shape[:2]
+        with prof.scope("proposal_layer"):
+            return proposal_ops.proposal_layer(
+                rpn_out["rpn_cls"][:, :, 0], rpn_out["rpn_reg"], rpn_out["backbone_xyz"],
+                pre_nms_top_n=cfg.rpn_pre_nms_top_n, post_nms_top_n=cfg.rpn_post_nms_top_n,
+                nms_thresh=cfg.rpn_nms_thresh, nms_type=cfg.rpn_nms_type, loc_scope=cfg.rpn_loc_scope,
+                loc_bin_size=cfg.rpn_loc_bin_size, num_head_bin=cfg.rpn_num_head_bin, anchor_size=cfg.mean_size)
+
+    @torch.no_grad()
+    def roi_pool(self, rpn_out: Dict[str, torch.Tensor], rois: torch.Tensor) -> torch.Tensor:
+        """ProposalTargetLayer.forward in EVAL mode (proposal_target_layer.py:16-34,99-115): per-point
+        [mask, depth, rpn features] -> pooled (B*M, S, 3 + 2 + C) in each RoI's canonical frame"""
+        cfg = self.cfg
+        xyz, feats = rpn_out["backbone_xyz"], rpn_out["backbone_features"]
+        B, N, _ = xyz.shape
+        C = feats.shape[1]
+        pts_feature = torch.empty((B, N, 2 + C), dtype=torch.float32, device=xyz.device)
+        pts_feature[:, :, 0] = (torch.sigmoid(rpn_out["rpn_cls"][:, :, 0]) > cfg.rpn_score_thresh).float()   # point_rcnn.py:42-43
+        pts_feature[:, :, 1] = torch.norm(xyz, p=2, dim=2) / 70.0 - 0.5                                       # :44; ptl.py:26
+        pts_feature[:, :, 2:] = feats.transpose(1, 2)
+        M, S = rois.shape[1], cfg.rcnn_num_points
+        pooled, _ = roipool3d_canonical_gpu(xyz, pts_feature, rois, cfg.pool_extra_width, S)
+        return pooled.view(B * M, S, 5 + C)
+
+    @torch.no_grad()
+    def rcnn_forward(self, pts_input: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """RCNN.forward in EVAL mode (rcnn.py:158-202,288-289): pts_input (R, S, 5 + C) ->
+        rcnn_cls (R, 1), rcnn_reg (R, 46), rcnn_feat (R, 512, 1)"""
+        net = self.rcnn_net
+        R, S, Cin = pts_input.shape
+        k = net.rcnn_input_channel
+        rows = pts_input.view(R * S, Cin)
+        up = [self._wb(f"xyz_up.{i}", lambda u=u: _unit_wb(u)) for i, u in enumerate(net.xyz_up_layer)]
+        Wm, bm = self._wb("merge_down", lambda: _unit_wb(net.merge_down_layer[0]))
+        c_up = up[-1][0].shape[0]
+
+        def lift():
+            h = rows[:, :k]                                   # strided view (row stride Cin): no copy, BLAS lda = Cin
+            for W, b in up:
+                h = torch.relu_(torch.addmm(b, h, W.t()))
+            m = torch.addmm(bm, h, Wm[:, :c_up].t())
+            m = torch.addmm(m, rows[:, k:], Wm[:, c_up:].t())  # merge_down on [xyz_feature | rpn_feature] without the cat
+            return torch.relu_(m).view(R, S, -1).transpose(1, 2).contiguous()       # (R, C, S) for the SA kernels
+        flops = 2 * R * S * (sum(W.numel() for W, _ in up) + Wm.numel())
+        feats = self._t("rcnn_xyz_lift+merge(rocBLAS)", 0, lift, flops=flops)
+        xyz = pts_input[:, :, 0:3].contiguous()
+        l_xyz, l_feats = xyz, feats
+        for i, sa in enumerate(net.SA_modules):
+            with prof.scope(f"rcnn_sa{i + 1}"):
+                l_xyz, l_feats, _ = sa(l_xyz, l_feats)
+        rcnn_cls, rcnn_reg = self._t("rcnn_heads(rocBLAS)", 0, lambda: (
+            self._head_forward("rcnn_cls", net.cls_layer, l_feats).squeeze(-1),
+            self._head_forward("rcnn_reg", net.reg_layer, l_feats).squeeze(-1)))
+        return dict(rcnn_cls=rcnn_cls, rcnn_reg=rcnn_reg, rcnn_feat=l_feats)
+
+    # -- the whole path ----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def detect(self, xyz, image, pts_xy) -> Tuple[DetectionCache, Dict[str, torch.Tensor]]:
+        """frames -> device-resident detections (boxes, scores, 512-d features, per-frame counts)"""
+        cfg = self.cfg
+        rpn_out = self.rpn_forward(xyz, image, pts_xy)
+        rois, roi_scores = self.proposals(rpn_out)
+        pts_input = self.roi_pool(rpn_out, rois)
+        out = self.rcnn_forward(pts_input)
+        B, M = rois.shape[:2]
+        with prof.scope("detections"):
+            boxes = decode_rcnn_boxes(rois.view(-1, 7), out["rcnn_reg"], cfg.rcnn_loc_scope, cfg.rcnn_loc_bin_size,
+                                      cfg.rcnn_num_head_bin, cfg.mean_size).view(B, M, 7)
+            feats = out["rcnn_feat"].view(B, M, -1)
+            cache = select_detections(boxes, out["rcnn_cls"].view(B, M), feats, cfg.rcnn_score_thresh, cfg.rcnn_nms_thresh)
+        inter = dict(rpn_out, rois=rois, roi_scores_raw=roi_scores, pts_input=pts_input, pred_boxes3d=boxes, **out)
+        return cache, inter
+
+    @torch.no_grad()
+    def forward(self, xyz, image, pts_xy):
+        """detect + affinity of every frame against its predecessor in the batch (frame 0 against the last):
+        returns (DetectionCache, [(A (M, M), start (M), end (M)) per frame]) with all M RoI slots as the
+        affinity operands (fixed work per frame: P = D = M)."""
+        cache, inter = self.detect(xyz, image, pts_xy)
+        feats = inter["rcnn_feat"].view(cache.boxes.shape[0], cache.boxes.shape[1], -1)
+        B, M, C = feats.shape
+        link, se = self.rcnn_net.link_layer, self.rcnn_net.se_layer
+        with prof.scope(f"affinity_{M}x{M}"):
+            aff = [pairwise_affinity(feats[b - 1], feats[b], link, se) for b in range(B)]
+        return cache, aff, inter

@@ -14,6 +14,7 @@ from typing import List, Optional, Tuple
 import torch
 import torch.nn as nn
 
+from ...profile import prof
 from . import fused
 from . import pointnet2_utils
 from . import pytorch_utils as pt_utils
@@ -69,7 +70,7 @@ class _PointnetSAModuleBase(nn.Module):
                 grouped = grouper(xyz, new_xyz, features, idx=nb)
             else:
                 grouped = grouper(xyz, new_xyz, features)
-            pooled.append(self._pool(mlp(grouped)))
+            pooled.append(prof.region("unfused_mlp+pool(MIOpen)", lambda g=grouped, f=mlp: self._pool(f(g))))
         return new_xyz, torch.cat(pooled, dim=1), idx
 
 
@@ -122,4 +123,4 @@ class PointnetFPModule(nn.Module):
             inv = (d3 + 1e-8).reciprocal()
             carried = pointnet2_utils.three_interpolate(known_feats, nn3, inv / inv.sum(dim=2, keepdim=True))
         stacked = carried if unknow_feats is None else torch.cat((carried, unknow_feats), dim=1)
-        return self.mlp(stacked.unsqueeze(-1)).squeeze(-1)
+        return prof.region("fp_mlp(MIOpen)", lambda: self.mlp(stacked.unsqueeze(-1)).squeeze(-1))

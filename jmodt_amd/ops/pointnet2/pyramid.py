@@ -11,6 +11,7 @@ compete for the machine.
     for k, sa in enumerate(sa_modules):
         idx, new_xyz = pyr.level(k)                    # main stream waits for level k only
         xyz_k, feats_k, _ = sa(xyz_k, feats_k, new_xyz=new_xyz)
+    pyr.release()
 
 `PointnetSAModuleMSG.forward` already takes `new_xyz` (pointnet2_modules.py:24-33).
 """
@@ -18,38 +19,57 @@ from typing import List, Tuple
 
 import torch
 
+from ...profile import prof
 from . import pointnet2_utils
 
 _side = {}
 
 
-def _side_stream(device) -> torch.cuda.Stream:
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+def side_stream(device, slot: int = 0) -> torch.cuda.Stream:
+    """a per-(device, slot) auxiliary stream, created once (slot 0: FPS chain, slot 1: image branch)"""
+    d = torch.device(device)
+    key = (d.index if d.index is not None else torch.cuda.current_device(), slot)
     if key not in _side:
-        _side[key] = torch.cuda.Stream(device=key)
+        _side[key] = torch.cuda.Stream(device=key[0])
     return _side[key]
 
 
+_side_stream = side_stream   # round-1 name
+
+
 class FpsPyramid:
-    def __init__(self, xyz: torch.Tensor, npoints: List[int]):
+    def __init__(self, xyz: torch.Tensor, npoints: List[int], overlap: bool = True):
         main = torch.cuda.current_stream(xyz.device)
-        side = _side_stream(xyz.device)
+        side = side_stream(xyz.device) if overlap else main
+        self._main, self._side, self._xyz = main, side, xyz   # xyz stays referenced until release()
         side.wait_stream(main)           # xyz is ready; previous consumers of our buffers are done
+        if side is not main:
+            xyz.record_stream(side)      # allocated on the main stream, read by the side stream
         self._levels: List[Tuple[torch.Tensor, torch.Tensor, torch.cuda.Event]] = []
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), prof.scope("fps_pyramid"):
             cur = xyz
-            for m in npoints:
-                idx, new_xyz = pointnet2_utils.farthest_point_sample_xyz(cur, m)
+            for k, m in enumerate(npoints):
+                with prof.scope(f"L{k + 1}"):
+                    idx, new_xyz = pointnet2_utils.farthest_point_sample_xyz(cur, m)
                 ev = torch.cuda.Event()
                 ev.record(side)
-                # handed to the main stream: keep the allocator from recycling them under it
-                idx.record_stream(main)
-                new_xyz.record_stream(main)
+                if side is not main:     # handed to the main stream: keep the allocator from recycling them under it
+                    idx.record_stream(main)
+                    new_xyz.record_stream(main)
                 self._levels.append((idx, new_xyz, ev))
                 cur = new_xyz
 
     def level(self, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """(idx (B, m_k) int32, new_xyz (B, m_k, 3)) of level k, ordered after its FPS on the current stream"""
         idx, new_xyz, ev = self._levels[k]
-        torch.cuda.current_stream(idx.device).wait_event(ev)
+        cur = torch.cuda.current_stream(idx.device)
+        if cur is not self._side and cur != self._side:
+            # how long the consumer is actually held up = the EXPOSED part of this level's sampling
+            prof.stall(f"fps_exposed_wait_L{k + 1}", lambda: cur.wait_event(ev))
         return idx, new_xyz
+
+    def release(self):
+        """the consumer is done with every level: order the side stream after it, drop the references"""
+        if self._side is not self._main:
+            self._side.wait_stream(torch.cuda.current_stream(self._xyz.device))
+        self._levels, self._xyz = [], None

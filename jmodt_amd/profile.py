@@ -1,0 +1,209 @@
+"""Per-entry-point timing with HIP events + the ALGORITHMIC work of every C-ABI call.
+
+`_lib.load()` hands out a proxy of libjmodt_hip.so; while the profiler is enabled every `jm_*` call is
+bracketed by two events recorded on the stream the call launches on (torch's current stream — the ops pass
+exactly that stream to the library), and its algorithmic bytes / flops are computed from the call's own
+integer arguments with the formulas of SURVEY.md §8(d).  Nothing else changes: same library, same kernels,
+same stream.  Disabled (the default) the proxy forwards straight to ctypes.
+
+bench.py reads `summary()`; `scope("rpn_sa1")` prefixes the records made inside it so the same entry point
+at different pyramid levels stays distinguishable; `region()` times a span of non-library work (MIOpen /
+rocBLAS calls of the caller) the same way so the step's time is fully accounted for.
+"""
+import contextlib
+import ctypes
+from typing import Callable, Dict, List, Tuple
+
+import torch
+
+
+def _i(a, k):
+    v = a[k]
+    return int(v.value) if hasattr(v, "value") else int(v)
+
+
+def _mlp3(arg):
+    s = getattr(arg, "_obj", None)
+    return (int(s.c), int(s.h1), int(s.h2)) if s is not None else None
+
+
+def _mlp3_flops(rows, dims):
+    c, h1, h2 = dims
+    return rows * (2 * c * h1 + 2 * h1 * h2 + 2 * h2)
+
+
+def _fps(a):
+    b, n, m = _i(a, 0), _i(a, 1), _i(a, 2)
+    # streaming-equivalent bytes (what the reference re-reads per iteration); the compulsory
+    # bytes b*(12n+4m) and the iteration count ride along in `extra`
+    return b * m * 20 * n, 0, dict(compulsory_bytes=b * (12 * n + 4 * m), evals=b * m * n, iterations=max(m - 1, 1))
+
+
+def _sa_mlp(a):
+    b, n, m, c, ns, nl = _i(a, 0), _i(a, 1), _i(a, 2), _i(a, 3), _i(a, 4), _i(a, 9)
+    w = [int(a[10][k]) for k in range(nl + 1)]
+    flops = 2 * b * m * ns * sum(w[k] * w[k + 1] for k in range(nl))
+    return b * (12 * n + 12 * m + 4 * c * n + 4 * m * ns + 4 * w[-1] * m), flops, {}
+
+
+def _roipool(a):
+    B, N, M, C, S = (_i(a, k) for k in range(5))
+    return B * (12 * N + 28 * M + 4 * C * N) + B * M * S * (3 + C) * 4 + 4 * B * M, 0, dict(evals=B * M * N)
+
+
+def _nms_bytes(n):
+    return n * 20 + n * ((n + 63) // 64) * 8
+
+
+def _affinity(a):
+    p, d = _i(a, 0), _i(a, 1)
+    link, se = _mlp3(a[4]), _mlp3(a[5]) if a[5] is not None else None
+    flops = _mlp3_flops(p * d, link) + (_mlp3_flops(p + d, se) if se else 0)
+    nbytes = (p + d) * link[0] * 4 + 4 * (link[0] * link[1] + link[1] * link[2] + link[2]) * (2 if se else 1) + 4 * p * d
+    return nbytes, flops, {}
+
+
+# symbol -> f(args) -> (algorithmic bytes, flops, extra)
+ALGO: Dict[str, Callable] = {
+    "jm_furthest_point_sampling": _fps,
+    "jm_furthest_point_sampling_xyz": _fps,
+    "jm_furthest_point_sampling_ws": _fps,
+    "jm_gather_points": lambda a: (_i(a, 0) * (4 * _i(a, 3) + 4 * _i(a, 1) * _i(a, 2) + 4 * _i(a, 1) * _i(a, 3)), 0, {}),
+    "jm_ball_query": lambda a: (_i(a, 0) * (12 * _i(a, 1) + 12 * _i(a, 2) + 4 * _i(a, 2) * _i(a, 4)), 0,
+                                dict(evals=_i(a, 0) * _i(a, 1) * _i(a, 2))),
+    "jm_ball_query_dual": lambda a: (_i(a, 0) * (12 * _i(a, 1) + 12 * _i(a, 2) + 4 * _i(a, 2) * (_i(a, 4) + _i(a, 6))), 0,
+                                     dict(evals=_i(a, 0) * _i(a, 1) * _i(a, 2))),
+    "jm_group_points": lambda a: (_i(a, 0) * (4 * _i(a, 3) * _i(a, 4) + 4 * _i(a, 1) * _i(a, 2)
+                                              + 4 * _i(a, 1) * _i(a, 3) * _i(a, 4)), 0, {}),
+    "jm_three_nn": lambda a: (_i(a, 0) * (12 * _i(a, 1) + 12 * _i(a, 2) + 24 * _i(a, 1)), 0,
+                              dict(evals=_i(a, 0) * _i(a, 1) * _i(a, 2))),
+    "jm_three_interpolate": lambda a: (_i(a, 0) * (4 * _i(a, 1) * _i(a, 2) + 24 * _i(a, 3) + 4 * _i(a, 1) * _i(a, 3)), 0, {}),
+    "jm_sa_mlp_forward": _sa_mlp,
+    "jm_roipool3d_forward": _roipool,
+    "jm_roipool3d_canonical": _roipool,
+    "jm_nms": lambda a: (_nms_bytes(_i(a, 0)), 0, dict(evals=_i(a, 0) * _i(a, 0) // 2)),
+    "jm_nms_batched": lambda a: (_i(a, 0) * _nms_bytes(_i(a, 1)), 0, dict(evals=_i(a, 0) * _i(a, 1) * _i(a, 1) // 2)),
+    "jm_proposal_select": lambda a: (_i(a, 0) * (_i(a, 1) * 40 + _nms_bytes(int(_i(a, 6) * 0.7)) + _nms_bytes(_i(a, 6) - int(_i(a, 6) * 0.7))),
+                                     0, {}),
+    "jm_decode_rpn_proposals": lambda a: (_i(a, 0) * (_i(a, 1) + 3 + 7) * 4, 0, {}),
+    "jm_decode_rcnn_boxes": lambda a: (_i(a, 0) * (_i(a, 1) + 7 + 7) * 4, 0, {}),
+    "jm_feature_gather": lambda a: (_i(a, 0) * _i(a, 4) * 4 * _i(a, 1) * 4 + _i(a, 0) * _i(a, 1) * _i(a, 4) * 4, 0, {}),
+    "jm_affinity_forward": _affinity,
+    "jm_mlp3_forward": lambda a: (0, _mlp3_flops(_i(a, 0), _mlp3(a[2])), {}),
+    "jm_association_cost": lambda a: ((_i(a, 0) + _i(a, 2)) * 28 + 4 * _i(a, 0) * _i(a, 2), 0, {}),
+    "jm_boxes_overlap_bev": lambda a: ((_i(a, 0) + _i(a, 2)) * 20 + 4 * _i(a, 0) * _i(a, 2), 0, {}),
+    "jm_boxes_iou_bev": lambda a: ((_i(a, 0) + _i(a, 2)) * 20 + 4 * _i(a, 0) * _i(a, 2), 0, {}),
+    "jm_boxes_iou3d_batched": lambda a: (_i(a, 0) * ((_i(a, 1) + _i(a, 3)) * 28 + 4 * _i(a, 1) * _i(a, 3)), 0, {}),
+}
+
+
+class Profiler:
+    def __init__(self):
+        self.enabled = False
+        self.records: Dict[str, List[Tuple]] = {}   # name -> [(start, end, bytes, flops, extra)]
+        self._scope: List[str] = []
+
+    def reset(self):
+        self.records = {}
+
+    @contextlib.contextmanager
+    def scope(self, name: str):
+        self._scope.append(name)
+        try:
+            yield
+        finally:
+            self._scope.pop()
+
+    def _key(self, name: str) -> str:
+        return "/".join(self._scope + [name]) if self._scope else name
+
+    def call(self, sym: str, fn, args):
+        """a jm_* entry point under the profiler"""
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = fn(*args)
+        e.record()
+        algo = ALGO.get(sym)
+        nbytes, flops, extra = algo(args) if algo else (0, 0, {})
+        self.records.setdefault(self._key(sym[3:]), []).append((s, e, nbytes, flops, extra))
+        return rc
+
+    def region(self, name: str, fn, algo_bytes: int = 0, flops: int = 0):
+        """time a span of caller-side work (torch / MIOpen / rocBLAS) on the current stream"""
+        if not self.enabled:
+            return fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = fn()
+        e.record()
+        self.records.setdefault(self._key(name), []).append((s, e, algo_bytes, flops, {}))
+        return out
+
+    def stall(self, name: str, wait: Callable[[], None]):
+        """time how long the CURRENT stream is held up by `wait()` (a wait_event / wait_stream): the exposed part
+        of work running on another stream"""
+        if not self.enabled:
+            return wait()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        wait()
+        e.record()
+        self.records.setdefault(self._key(name), []).append((s, e, 0, 0, dict(stall=True)))
+
+    def summary(self, steps: int, hbm_peak_gbs: float, mfma_peak_tf: float) -> List[dict]:
+        rows = []
+        for name, evs in self.records.items():
+            times = [s.elapsed_time(e) for s, e, *_ in evs]
+            ms = sum(times) / steps
+            nbytes = sum(r[2] for r in evs) / steps
+            flops = sum(r[3] for r in evs) / steps
+            row = dict(kernel=name, ms_per_step=round(ms, 5), launches_per_step=len(evs) / steps,
+                       max_launch_ms=round(max(times), 5))
+            if evs[0][4].get("stall"):
+                row["stall"] = True
+            if nbytes:
+                gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                row.update(algo_bytes_per_step=int(nbytes), achieved_gbs=round(gbs, 2), hbm_frac=round(gbs / hbm_peak_gbs, 5))
+            if flops:
+                tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+                row.update(algo_flops_per_step=int(flops), achieved_tflops=round(tf, 2), mfma_frac=round(tf / mfma_peak_tf, 4))
+            ex = evs[0][4]
+            if "evals" in ex:
+                ev = sum(r[4].get("evals", 0) for r in evs) / steps
+                row["evals_per_s"] = round(ev / (ms * 1e-3), 1) if ms > 0 else 0.0
+            if "iterations" in ex:
+                it = sum(r[4]["iterations"] for r in evs) / steps
+                row["us_per_fps_iteration"] = round(ms * 1e3 / it, 4)
+                row["compulsory_bytes_per_step"] = int(sum(r[4]["compulsory_bytes"] for r in evs) / steps)
+            rows.append(row)
+        rows.sort(key=lambda r: -r["ms_per_step"])
+        return rows
+
+
+prof = Profiler()
+
+
+class LibProxy:
+    """attribute access returns the bound ctypes function, routed through the profiler when it is enabled"""
+
+    def __init__(self, cdll: ctypes.CDLL):
+        object.__setattr__(self, "_cdll", cdll)
+        object.__setattr__(self, "_cache", {})
+
+    def __getattr__(self, sym: str):
+        cache = object.__getattribute__(self, "_cache")
+        hit = cache.get(sym)
+        if hit is not None:
+            return hit
+        fn = getattr(object.__getattribute__(self, "_cdll"), sym)
+        if not sym.startswith("jm_") or sym.endswith("_bytes") or sym.endswith("_elems") or sym in (
+                "jm_version", "jm_last_error", "jm_sa_mlp_pack", "jm_pts_in_boxes3d_cpu", "jm_roipool3d_cpu"):
+            cache[sym] = fn
+            return fn
+
+        def routed(*args, _fn=fn, _sym=sym):
+            if prof.enabled:
+                return prof.call(_sym, _fn, args)
+            return _fn(*args)
+        cache[sym] = routed
+        return routed

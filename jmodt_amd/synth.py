@@ -116,3 +116,19 @@ def rpn_output(B, N, seed, z_range=(0.5, 90.0), empty_far=(), empty_near=()):
         props[b, :, 6] = rng.uniform(-np.pi, np.pi, N).astype(np.float32)
         scores[b] = (rng.permutation(N).astype(np.float32) - N / 2) / np.float32(N / 8)   # logits, all distinct
     return scores, props
+
+
+def image(B, seed, H=384, W=1280, native=(375, 1242)):
+    """(B, 3, H, W) N(0,1) image on the 384x1280 canvas, rows / columns beyond the native KITTI size zero
+    (kitti_dataset.py:105-106 pads the 375x1242 image)"""
+    rng = np.random.default_rng(seed)
+    img = rng.standard_normal((B, 3, H, W), dtype=np.float32)
+    img[:, :, min(native[0], H):, :] = 0
+    img[:, :, :, min(native[1], W):] = 0
+    return img
+
+
+def frames(B, N, seed, H=384, W=1280, native=(375, 1242), dup_frac=0.1):
+    """(xyz (B,N,3), image (B,3,H,W), pts_xy (B,N,2)): one synthetic KITTI-shaped input batch"""
+    pts = cloud(B, N, seed, dup_frac=dup_frac)
+    return pts, image(B, seed + 1, H, W, native), pts_xy(pts, W, H)

@@ -327,6 +327,64 @@ def decode_rpn_proposals(xyz, rpn_reg, loc_scope=3.0, loc_bin_size=0.5, num_head
     return out.astype(f).reshape(np.shape(rpn_reg)[:-1] + (7,))
 
 
+def decode_rcnn_boxes(rois, rcnn_reg, loc_scope=1.5, loc_bin_size=0.5, num_head_bin=9,
+                      anchor_size=(1.52563191462, 1.62856739989, 3.88311640418), avg_by_bin=True):
+    """decode_bbox_target as the detection post-processing calls it (tools/eval.py:108-116; bbox_transform.py:27-260
+    with roi (N,7), get_xz_fine=True, get_y_by_bin=False, get_ry_fine=True, RY_WITH_BIN=False), float32; the
+    rotation by -roi_ry (bbox_transform.py:8-24,251-256) uses the deterministic sin/cos of include/jm_detmath.h."""
+    rois = _f32(rois).reshape(-1, 7)
+    reg = _f32(rcnn_reg).reshape(rois.shape[0], -1)
+    f = np.float32
+    nb = int(loc_scope / loc_bin_size) * 2
+    bs, sc = f(loc_bin_size), f(loc_scope)
+
+    def axis(bin_off, res_off):
+        if avg_by_bin:
+            z = reg[:, bin_off:bin_off + nb]
+            e = np.exp(z - z.max(1, keepdims=True)).astype(f)
+            pbin = e / e.sum(1, keepdims=True, dtype=f)
+            centre = (np.arange(nb, dtype=f) * bs + bs / f(2) - sc).astype(f)
+            return ((centre[None] + reg[:, res_off:res_off + nb] * bs) * pbin).sum(1, dtype=f)
+        b = np.argmax(reg[:, bin_off:bin_off + nb], 1)
+        res = np.take_along_axis(reg[:, res_off:res_off + nb], b[:, None], 1)[:, 0]
+        return (b.astype(f) * bs + bs / f(2) - sc + res * bs).astype(f)
+
+    pos_x, pos_z = axis(0, 2 * nb), axis(nb, 3 * nb)
+    off = 4 * nb
+    pos_y = rois[:, 1] + reg[:, off]
+    off += 1
+    rb = np.argmax(reg[:, off:off + num_head_bin], 1)
+    rres = np.take_along_axis(reg[:, off + num_head_bin:off + 2 * num_head_bin], rb[:, None], 1)[:, 0]
+    apc = f(f(np.pi / 2) / f(num_head_bin))
+    ry = ((rb.astype(f) * apc + apc / f(2)) + rres * (apc / f(2)) - f(np.pi / 4)).astype(f)   # :131-135
+    off += 2 * num_head_bin
+    anchor = np.asarray(anchor_size, dtype=f)
+    hwl = reg[:, off:off + 3] * anchor + anchor
+    sn, cs = detmath_sincos(-rois[:, 6])
+    x = pos_x * cs + pos_z * (-sn)
+    z = pos_x * sn + pos_z * cs
+    out = np.concatenate([(x + rois[:, 0])[:, None], pos_y[:, None], (z + rois[:, 2])[:, None], hwl,
+                          (ry + rois[:, 6])[:, None]], 1)
+    return out.astype(f)
+
+
+def select_detections(pred_boxes3d, raw_scores, score_thresh=0.2, nms_thresh=0.1):
+    """tools/eval.py:171-193 per frame: sigmoid(score) > thresh, rotated BEV NMS by raw score (stable order);
+    returns a list of index arrays (RoI slots kept, in keep order), one per frame."""
+    boxes = _f32(pred_boxes3d)
+    raw = _f32(raw_scores)
+    out = []
+    for k in range(boxes.shape[0]):
+        norm = (1.0 / (1.0 + np.exp(-raw[k].astype(np.float64)))).astype(np.float32)
+        inds = np.nonzero(norm > np.float32(score_thresh))[0]
+        if len(inds) == 0:
+            out.append(np.zeros(0, np.int64))
+            continue
+        keep = nms(boxes3d_to_bev(boxes[k][inds]), raw[k][inds], nms_thresh, 0)
+        out.append(inds[keep].astype(np.int64))
+    return out
+
+
 def proposal_select(scores, proposals, pre_nms_top_n, post_nms_top_n, nms_thresh, nms_type="normal",
                     distance_based=True):
     """ProposalLayer.forward after the decode, frame by frame (proposal_layer.py:34-55) with

@@ -1,0 +1,291 @@
+"""GPU tier (-m gpu): the COMPOSED detect + affinity forward (jmodt_amd/detector.py, BASELINE configs[2] + affinity)
+against the chained CPU oracle (oracle/pipeline.py), plus the detection post-processing / hand-off entry points
+ and smoke-sized runs of every bench.py workload (configs[3] included).
+
+Chained parity is checked the way a sequential pipeline with discrete decisions has to be checked:
+  * free-running for the continuous part (backbone + RPN heads): GPU vs float64 oracle from the same inputs;
+  * teacher-forced across discrete decisions: each later oracle stage consumes the GPU's previous stage, so a
+    1e-6 score difference cannot turn into a different RoI set and hide (or fake) an error downstream.
+Bars: index / selection outputs bit-exact, float outputs 1e-4 (BASELINE.json), scaled by the tensor's magnitude
+where activations exceed 1.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from jmodt_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def close(got, want, tol=1e-4):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    scale = max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max())
+    assert err <= tol * scale, f"max |diff| {err:.3e} > {tol} * {scale:.3g}"
+
+
+def tiny_frames(B, N, seed):
+    """dense little scene so that balls / RoIs actually contain neighbours"""
+    rng = np.random.default_rng(seed)
+    lo, hi = np.array([-8.0, -1.0, 2.0], np.float32), np.array([8.0, 1.0, 18.0], np.float32)
+    xyz = (rng.random((B, N, 3), dtype=np.float32) * (hi - lo) + lo).astype(np.float32)
+    xyz[:, N - N // 10:] = xyz[:, :N // 10]          # exact duplicates, as kitti_dataset.py:243-247 produces
+    img = synth.image(B, seed + 1, 96, 320, native=(94, 310))
+    xy = synth.pts_xy(xyz, 320, 96)
+    return xyz, img, xy
+
+
+def make_engine(seed=0):
+    from jmodt_amd.detector import DetectAffinityEngine, DetectorConfig
+    torch.manual_seed(seed)
+    eng = DetectAffinityEngine(DetectorConfig.tiny())
+    g = torch.Generator().manual_seed(seed + 1)
+    for m in eng.modules():     # non-trivial BatchNorm statistics, non-zero biases, larger head weights
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+        elif isinstance(m, (torch.nn.Conv1d, torch.nn.Conv2d, torch.nn.Linear)) and m.bias is not None:
+            m.bias.data.copy_(torch.randn(m.bias.shape, generator=g) * 0.05)
+    with torch.no_grad():       # make the heads say something: scores around 0, visible box regression
+        eng.rpn.rpn_cls_layer[2].conv.bias.zero_()
+        eng.rpn.rpn_cls_layer[2].conv.weight.mul_(8.0)
+        eng.rpn.rpn_reg_layer[2].conv.weight.copy_(torch.randn(eng.rpn.rpn_reg_layer[2].conv.weight.shape, generator=g) * 0.3)
+        eng.rcnn_net.reg_layer[-1].conv.weight.copy_(torch.randn(eng.rcnn_net.reg_layer[-1].conv.weight.shape, generator=g) * 0.3)
+        eng.rcnn_net.cls_layer[-1].conv.weight.mul_(6.0)
+    return eng.eval()
+
+
+@pytest.fixture(scope="module")
+def run():
+    from oracle.pipeline import Chain
+    eng = make_engine().to(DEV)
+    xyz, img, xy = tiny_frames(2, 2048, 17)
+    with torch.no_grad():
+        cache, aff, inter = eng(T(xyz), T(img), T(xy))
+    torch.cuda.synchronize()
+    chain = Chain(eng.state_dict(), eng.cfg, torch.float64)
+    return dict(eng=eng, xyz=xyz, img=img, xy=xy, cache=cache, aff=aff, inter=inter, chain=chain)
+
+
+def test_backbone_and_rpn_heads_free_running(run):
+    want = run["chain"].rpn(run["xyz"], run["img"], run["xy"])
+    inter = run["inter"]
+    for lv, (got_idx, want_idx) in enumerate(zip(run["eng"].last_fps_idx, run["chain"].last["fps_idx"])):
+        assert np.array_equal(got_idx.cpu().numpy(), want_idx), f"FPS level {lv + 1}"
+    close(inter["backbone_features"], want["backbone_features"])
+    close(inter["rpn_cls"], want["rpn_cls"])
+    close(inter["rpn_reg"], want["rpn_reg"])
+
+
+def test_proposals_roipool_rcnn_teacher_forced(run, oracle):
+    inter, chain, cfg = run["inter"], run["chain"], run["eng"].cfg
+    rpn_cls, rpn_reg = inter["rpn_cls"].cpu().numpy(), inter["rpn_reg"].cpu().numpy()
+    feats = inter["backbone_features"].cpu().numpy()
+    # proposal layer: the oracle selects from the GPU's decoded boxes (decode itself is compared at 1e-4)
+    from jmodt_amd.ops.proposal import decode_rpn_proposals
+    dec = decode_rpn_proposals(T(run["xyz"]), inter["rpn_reg"], cfg.rpn_loc_scope, cfg.rpn_loc_bin_size,
+                               cfg.rpn_num_head_bin, cfg.mean_size).cpu().numpy()
+    close(dec, oracle.decode_rpn_proposals(run["xyz"], rpn_reg, cfg.rpn_loc_scope, cfg.rpn_loc_bin_size,
+                                           cfg.rpn_num_head_bin, cfg.mean_size))
+    wb, ws = oracle.proposal_select(rpn_cls[:, :, 0], dec, cfg.rpn_pre_nms_top_n, cfg.rpn_post_nms_top_n,
+                                    cfg.rpn_nms_thresh, cfg.rpn_nms_type)
+    rois = inter["rois"].cpu().numpy()
+    assert np.array_equal(rois, wb) and np.array_equal(inter["roi_scores_raw"].cpu().numpy(), ws)
+    assert (ws != 0).sum() >= cfg.rpn_post_nms_top_n      # the scene fills every RoI slot
+    # RoI pooling + canonical transform on the GPU's RoIs / features
+    want_pts, _ = chain.roi_pool(run["xyz"], rpn_cls, feats, rois)
+    got_pts = inter["pts_input"].cpu().numpy()
+    assert np.array_equal(got_pts[..., 3:], want_pts[..., 3:])
+    close(got_pts[..., :3], want_pts[..., :3])
+    assert (np.abs(got_pts[..., 5:]).sum(axis=(1, 2)) > 0).mean() > 0.5      # most RoIs are not empty
+    # RCNN on the GPU's pooled points
+    want = chain.rcnn(got_pts)
+    close(inter["rcnn_feat"], want["rcnn_feat"])
+    close(inter["rcnn_cls"], want["rcnn_cls"])
+    close(inter["rcnn_reg"], want["rcnn_reg"])
+
+
+def test_detections_and_affinity_teacher_forced(run, oracle):
+    inter, chain, cfg, cache = run["inter"], run["chain"], run["eng"].cfg, run["cache"]
+    rois = inter["rois"].cpu().numpy()
+    B, M = rois.shape[:2]
+    reg = inter["rcnn_reg"].cpu().numpy()
+    boxes = inter["pred_boxes3d"].cpu().numpy()
+    close(boxes, oracle.decode_rcnn_boxes(rois.reshape(-1, 7), reg, cfg.rcnn_loc_scope, cfg.rcnn_loc_bin_size,
+                                          cfg.rcnn_num_head_bin, cfg.mean_size).reshape(B, M, 7))
+    raw = inter["rcnn_cls"].cpu().numpy().reshape(B, M)
+    keep = oracle.select_detections(boxes, raw, cfg.rcnn_score_thresh, cfg.rcnn_nms_thresh)
+    counts = cache.counts_host()
+    assert sum(counts) > 0
+    feats = inter["rcnn_feat"].view(B, M, -1).cpu().numpy()
+    for b in range(B):
+        assert counts[b] == len(keep[b])
+        assert np.array_equal(cache.roi_index[b, :counts[b]].cpu().numpy(), keep[b])
+        bx, sc, ft = cache.to_host(b)
+        assert np.array_equal(bx, boxes[b][keep[b]]) and np.array_equal(ft, feats[b][keep[b]])
+        assert (cache.boxes[b, counts[b]:] == 0).all() and (cache.feats[b, counts[b]:] == 0).all()
+    f64 = torch.from_numpy(feats).double()
+    for b in range(B):
+        A, s, e = run["aff"][b]
+        wA, ws, we = chain.affinity(f64[b - 1], f64[b])
+        close(A, wA); close(s, ws); close(e, we)
+
+
+def test_engine_without_side_streams_gives_identical_results(run):
+    eng = run["eng"]
+    eng.overlap = False
+    try:
+        with torch.no_grad():
+            cache, aff, inter = eng(T(run["xyz"]), T(run["img"]), T(run["xy"]))
+    finally:
+        eng.overlap = True
+    for k in ("backbone_features", "rpn_reg", "rois", "pts_input", "rcnn_feat", "pred_boxes3d"):
+        assert torch.equal(inter[k], run["inter"][k]), k
+    assert torch.equal(cache.count, run["cache"].count) and torch.equal(aff[1][0], run["aff"][1][0])
+
+
+def test_unfused_sa_path_matches_fused(run):
+    """the same engine with the fused SA kernel disabled (QueryAndGroup + GroupAll + torch convs) — a8 / a5"""
+    eng = run["eng"]
+    mods = [m for m in eng.modules() if hasattr(m, "fuse")]
+    for m in mods:
+        m.fuse = False
+    try:
+        with torch.no_grad():
+            rpn_out = eng.rpn_forward(T(run["xyz"]), T(run["img"]), T(run["xy"]))
+            out = eng.rcnn_forward(run["inter"]["pts_input"])
+    finally:
+        for m in mods:
+            m.fuse = True
+    close(rpn_out["backbone_features"], run["inter"]["backbone_features"])
+    close(out["rcnn_feat"], run["inter"]["rcnn_feat"])
+
+
+def test_detection_cache_association_matches_oracle(run, oracle):
+    """§8f-4: affinity + association cost straight from the resident cache vs the oracle on the host copies"""
+    cache, eng = run["cache"], run["eng"]
+    counts = cache.counts_host()
+    link, se = eng.rcnn_net.link_layer, eng.rcnn_net.se_layer
+
+    def w(h):
+        return tuple(a.detach().cpu().numpy().copy() for a in (
+            h[0].conv.weight[..., 0], h[0].conv.bias, h[2].conv.weight[..., 0], h[2].conv.bias,
+            h[3].conv.weight.reshape(-1), h[3].conv.bias))
+    res = cache.associate(0, 1, link, se, 0.6, 0.3, 0.1)
+    if counts[0] == 0 or counts[1] == 0:
+        assert res is None
+        return
+    cost, A, s, e = res
+    pb, _, pf = cache.to_host(0)
+    db, _, df = cache.to_host(1)
+    wA, ws, we = oracle.affinity(pf, df, w(link), w(se))
+    close(A, wA); close(s, ws); close(e, we)
+    close(cost, oracle.association_cost(pb, db, wA, 0.6, 0.3, 0.1))
+
+
+def test_decode_rcnn_boxes_vs_oracle(oracle):
+    from jmodt_amd.ops.detections import decode_rcnn_boxes
+    rng = np.random.default_rng(5)
+    P = 1000
+    rois = synth.proposals(synth.cloud(1, 4096, 3), P, 4)[0]
+    reg = rng.normal(0, 1.2, (P, 46)).astype(np.float32)
+    for avg in (True, False):
+        got = decode_rcnn_boxes(T(rois), T(reg), avg_by_bin=avg)
+        close(got, oracle.decode_rcnn_boxes(rois, reg, avg_by_bin=avg))
+    assert decode_rcnn_boxes(T(rois[:0]), T(reg[:0])).shape == (0, 7)
+
+
+@pytest.mark.parametrize("B,Na,Nb", [(4, 512, 20), (2, 64, 64), (3, 17, 1), (1, 1, 33)])
+def test_boxes_iou3d_batched_vs_oracle(oracle, B, Na, Nb):
+    """§8f-3b: the RoI sampler's per-frame boxes_iou3d_gpu loop as one launch, zero-padded ground truth"""
+    from jmodt_amd.ops.detections import boxes_iou3d_batched
+    from jmodt_amd.ops.iou3d.iou3d_utils import boxes_iou3d_gpu
+    pts = synth.cloud(B, 2048, 9)
+    gt = synth.proposals(pts, Nb, 10)
+    rng = np.random.default_rng(11)
+    rois = np.repeat(gt, (Na + Nb - 1) // Nb, axis=1)[:, :Na].copy()
+    rois[..., :3] += rng.normal(0, 0.4, rois[..., :3].shape).astype(np.float32)
+    rois[..., 6] += rng.normal(0, 0.3, rois[..., 6].shape).astype(np.float32)
+    counts = rng.integers(1, Nb + 1, B).astype(np.int32)
+    for b in range(B):
+        gt[b, counts[b]:] = 0
+    got = boxes_iou3d_batched(T(rois), T(gt), T(counts)).cpu().numpy()
+    assert got.shape == (B, Na, Nb)
+    for b in range(B):
+        k = counts[b]
+        want = oracle.boxes_iou3d(rois[b], gt[b, :k])
+        assert np.abs(got[b, :, :k] - want).max() < 1e-5
+        assert (got[b, :, k:] == 0).all()
+        single = boxes_iou3d_gpu(T(rois[b]), T(gt[b, :k])).cpu().numpy()       # the per-frame API it replaces
+        assert np.abs(got[b, :, :k] - single).max() < 1e-6
+    assert got.max() > 0.3
+    full = boxes_iou3d_batched(T(rois), T(gt)).cpu().numpy()                  # counts = None: every column valid
+    assert np.array_equal(full[:, :, :1], got[:, :, :1])
+
+
+def test_select_detections_synthetic(oracle):
+    """score threshold + rotated NMS for a batch with clustered boxes, empty frames and full frames"""
+    from jmodt_amd.ops.detections import select_detections
+    rng = np.random.default_rng(2)
+    B, M, C = 5, 128, 32
+    pts = synth.cloud(B, 512, 1)
+    base = synth.proposals(pts, 16, 2)
+    boxes = np.repeat(base, M // 16, axis=1)
+    boxes[..., :3] += rng.normal(0, 0.5, boxes[..., :3].shape).astype(np.float32)
+    raw = rng.permutation(B * M).reshape(B, M).astype(np.float32) / (B * M) * 8 - 4
+    raw[1] = -9.0          # nothing passes the score threshold
+    raw[2] = np.abs(raw[2]) + 1.0   # everything passes
+    feats = rng.normal(size=(B, M, C)).astype(np.float32)
+    cache = select_detections(T(boxes), T(raw), T(feats), 0.2, 0.1)
+    keep = oracle.select_detections(boxes, raw, 0.2, 0.1)
+    counts = cache.counts_host()
+    assert counts[1] == 0
+    for b in range(B):
+        assert counts[b] == len(keep[b]) and np.array_equal(cache.roi_index[b, :counts[b]].cpu().numpy(), keep[b])
+        bx, sc, ft = cache.to_host(b)
+        assert np.array_equal(bx, boxes[b][keep[b]]) and np.array_equal(ft, feats[b][keep[b]])
+        assert np.allclose(sc, 1 / (1 + np.exp(-raw[b][keep[b]])), atol=1e-6)
+
+
+@pytest.mark.parametrize("workload,extra", [("detect", []), ("sa", []), ("ops", []), ("dense", ["--batch", "2"]),
+                                            ("train", []), ("detect", ["--no-overlap"])])
+def test_bench_workloads_smoke(workload, extra):
+    """every bench.py workload end to end at smoke size (configs[3]'s training step included): one JSON line with
+    the contract's keys; `detect` must list the jm entry points of the whole composed path"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"] + (["--tiny"] if workload != "sa" else []) + extra
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "kernels"):
+        assert key in r, key
+    assert r["value"] > 0 and r["steps"] == 2 and r["n_gpus"] == 1
+    names = " ".join(k["kernel"] for k in r["kernels"])
+    if workload in ("detect", "train"):
+        for needle in ("fps_pyramid/L1/furthest_point_sampling_xyz", "rpn_sa1/", "li_fusion1/feature_gather", "three_nn",
+                       "three_interpolate", "proposal_layer/", "roipool3d_canonical", "rcnn_sa1/sa_mlp_forward",
+                       "detections/decode_rcnn_boxes", "nms_batched"):
+            assert needle in names, (needle, names)
+    if workload == "detect":
+        assert "affinity_forward" in names and r["roofline"] is not None
+    if workload == "train":
+        assert "finetune" in names
