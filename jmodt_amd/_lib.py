@@ -43,6 +43,7 @@ SIGNATURES = {
     "jm_three_nn": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "jm_three_interpolate": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "jm_three_interpolate_grad": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "jm_sa_mlp_supported": (_I, [_I, _I, _I, _I, _I, _I, _I, ctypes.POINTER(_I)]),
     "jm_sa_mlp_packed_weight_elems": (_Z, [_I, _I, _I]),
     "jm_sa_mlp_packed_bias_elems": (_Z, [_I]),
     "jm_sa_mlp_pack": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),

@@ -408,7 +408,24 @@ sa_mlp_kernel(SaMlpParams p) {
 
 }  // namespace jm
 
+namespace jm {
+int sa_mlp_wide_launch(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
+                       const float* features, const int* idx, int L, const int* widths, const float* const* weights,
+                       const float* const* biases, float* out, hipStream_t s);                     // sa_mlp_wide.hip
+const char* sa_wide_unsupported(long long b, int n, int m, int c, int nsample, int group_all, int L, const int* widths);
+}
+
 using namespace jm;
+
+extern "C" int jm_sa_mlp_supported(int b, int n, int m, int c, int nsample, int group_all, int num_layers,
+                                   const int* widths) {
+    if (b < 0 || n < 1 || m < 0 || c < 0 || num_layers < 1 || !widths || widths[0] != 3 + c) return 0;
+    bool narrow = !group_all && (nsample == 16 || nsample == 32 || nsample == 64) && ((long long)m * nsample) % SM_BM == 0 &&
+                  num_layers <= 4 && (num_layers > 1 || sa_first_kp(widths[0]) <= SM_KC);
+    for (int l = 1; l < num_layers && narrow; ++l) narrow = widths[l] >= 1 && widths[l] <= 128;
+    if (narrow) return 1;
+    return sa_wide_unsupported(b, n, m, c, nsample, group_all, num_layers, widths) == nullptr ? 2 : 0;
+}
 
 extern "C" size_t jm_sa_mlp_packed_weight_elems(int cout, int cin, int first_layer) {
     if (cout < 1 || cin < 1 || (first_layer && cin < 3)) return 0;
@@ -436,7 +453,13 @@ extern "C" int jm_sa_mlp_forward(int b, int n, int m, int c, int nsample, const 
                                  jm_stream_t stream) {
     JM_REQUIRE(b >= 0 && n >= 1 && m >= 0 && c >= 0, "sa_mlp: bad sizes");
     if (b == 0 || m == 0) return JM_OK;
-    JM_REQUIRE(xyz && new_xyz && idx && out && widths && weights && biases && (features || c == 0), "sa_mlp: null pointer");
+    JM_REQUIRE(xyz && out && widths && weights && biases && (features || c == 0), "sa_mlp: null pointer");
+    JM_REQUIRE((idx == nullptr) == (new_xyz == nullptr), "sa_mlp: idx and new_xyz are both given or both NULL (GroupAll)");
+    JM_REQUIRE(num_layers >= 1 && widths[0] == 3 + c, "sa_mlp: widths[0] = %d != 3 + C = %d", widths[0], 3 + c);
+    if (jm_sa_mlp_supported(b, n, m, c, nsample, idx == nullptr, num_layers, widths) == 2)   // wide / GroupAll variant
+        return sa_mlp_wide_launch(b, n, m, c, nsample, xyz, new_xyz, features, idx, num_layers, widths, weights, biases,
+                                  out, (hipStream_t)stream);
+    JM_REQUIRE(idx && new_xyz, "sa_mlp: GroupAll (idx == NULL) needs a shape of the wide variant");
     JM_REQUIRE(nsample == 16 || nsample == 32 || nsample == 64, "sa_mlp: nsample %d not in {16,32,64}", nsample);
     JM_REQUIRE(((long long)m * nsample) % SM_BM == 0, "sa_mlp: npoint*nsample = %lld is not a multiple of 128", (long long)m * nsample);
     JM_REQUIRE(num_layers >= 1 && num_layers <= 4, "sa_mlp: %d layers unsupported", num_layers);

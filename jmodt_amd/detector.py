@@ -268,6 +268,7 @@ class DetectAffinityEngine(nn.Module):
         self._folded: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.overlap = True                # FPS pyramid + image branch on side streams
         self.last_fps_idx: List[torch.Tensor] = []
+        self._prefetched = None
 
     # -- helpers -------------------------------------------------------------------------------------
     @staticmethod
@@ -313,15 +314,35 @@ class DetectAffinityEngine(nn.Module):
 
     # -- stage 1: backbone + RPN heads -----------------------------------------------------------------
     @torch.no_grad()
-    def backbone(self, xyz: torch.Tensor, image: torch.Tensor, pts_xy: torch.Tensor) -> torch.Tensor:
+    def prefetch(self, xyz: torch.Tensor) -> None:
+        """announce the NEXT batch's cloud: its FPS pyramid (coordinates only, one workgroup per frame, ~6 ms of
+        latency-bound sampling) starts now on the side stream, under the current batch's set abstraction /
+        RCNN work, instead of at the head of the next call's critical path.  The next call must pass the same
+        tensor object."""
+        if self.overlap:
+            self._prefetched = (xyz, FpsPyramid(xyz, list(self.cfg.sa_npoints), overlap=True))
+
+    def _take_prefetched(self, xyz: torch.Tensor):
+        hit, self._prefetched = self._prefetched, None
+        if hit is not None and hit[0] is xyz:
+            return hit[1]
+        if hit is not None:
+            hit[1].release()
+        return None
+
+    @torch.no_grad()
+    def backbone(self, xyz: torch.Tensor, image: torch.Tensor, pts_xy: torch.Tensor,
+                 next_xyz: Optional[torch.Tensor] = None) -> torch.Tensor:
         """xyz (B, N, 3), image (B, 3, H, W), pts_xy (B, N, 2) in [-1, 1] -> point features (B, 128, N)
         (PointNet2MSG.forward, backbone.py:159-196)"""
         cfg, net = self.cfg, self.rpn.backbone_net
         dev = xyz.device
         main = torch.cuda.current_stream(dev)
         B, N, _ = xyz.shape
-        # --- stream F: the whole FPS chain (coordinates only) ---
-        pyr = FpsPyramid(xyz, list(cfg.sa_npoints), overlap=self.overlap)
+        # --- stream F: the whole FPS chain (coordinates only); already running if this batch was announced ---
+        pyr = self._take_prefetched(xyz) or FpsPyramid(xyz, list(cfg.sa_npoints), overlap=self.overlap)
+        if next_xyz is not None:
+            self.prefetch(next_xyz)
         # --- stream I: image pyramid, channels-last ---
         img_stream = side_stream(dev, 1) if self.overlap else main
         img_stream.wait_stream(main)
@@ -341,8 +362,10 @@ class DetectAffinityEngine(nn.Module):
             fused_map.record_stream(main)
         # --- stream M: set abstraction + LI-Fusion per level ---
         l_xyz, l_feats, l_xy = [xyz], [None], [pts_xy]
+        self.last_fps_idx = []
         for i, sa in enumerate(net.SA_modules):
             idx, new_xyz = pyr.level(i)
+            self.last_fps_idx.append(idx)
             with prof.scope(f"rpn_sa{i + 1}"):
                 _, feats, _ = sa(l_xyz[i], l_feats[i], new_xyz=new_xyz)
             xy_i = torch.gather(l_xy[i], 1, idx.long().unsqueeze(-1).expand(-1, -1, 2))       # backbone.py:170-171
@@ -364,7 +387,6 @@ class DetectAffinityEngine(nn.Module):
                 "fusion_final", net.final_fusion_img_point, l_feats[0], gathered))
         if self.overlap:
             img_stream.wait_stream(main)     # image buffers are not recycled under the main stream's readers
-        self.last_fps_idx = [pyr.level(i)[0] for i in range(len(cfg.sa_npoints))]
         pyr.release()
         return out
 
@@ -396,9 +418,9 @@ class DetectAffinityEngine(nn.Module):
         return torch.relu_(acc)
 
     @torch.no_grad()
-    def rpn_forward(self, xyz, image, pts_xy) -> Dict[str, torch.Tensor]:
+    def rpn_forward(self, xyz, image, pts_xy, next_xyz=None) -> Dict[str, torch.Tensor]:
         """RPN.forward (rpn.py:71-87): backbone features + objectness / box regression per point"""
-        feats = self.backbone(xyz, image, pts_xy)
+        feats = self.backbone(xyz, image, pts_xy, next_xyz)
         def heads():
             cls = self._head_forward("rpn_cls", self.rpn.rpn_cls_layer, feats).transpose(1, 2).contiguous()   # (B, N, 1)
             reg = self._head_forward("rpn_reg", self.rpn.rpn_reg_layer, feats).transpose(1, 2).contiguous()   # (B, N, C)
@@ -468,10 +490,10 @@ class DetectAffinityEngine(nn.Module):
 
     # -- the whole path ----------------------------------------------------------------------------------
     @torch.no_grad()
-    def detect(self, xyz, image, pts_xy) -> Tuple[DetectionCache, Dict[str, torch.Tensor]]:
+    def detect(self, xyz, image, pts_xy, next_xyz=None) -> Tuple[DetectionCache, Dict[str, torch.Tensor]]:
         """frames -> device-resident detections (boxes, scores, 512-d features, per-frame counts)"""
         cfg = self.cfg
-        rpn_out = self.rpn_forward(xyz, image, pts_xy)
+        rpn_out = self.rpn_forward(xyz, image, pts_xy, next_xyz)
         rois, roi_scores = self.proposals(rpn_out)
         pts_input = self.roi_pool(rpn_out, rois)
         out = self.rcnn_forward(pts_input)
@@ -485,11 +507,11 @@ class DetectAffinityEngine(nn.Module):
         return cache, inter
 
     @torch.no_grad()
-    def forward(self, xyz, image, pts_xy):
+    def forward(self, xyz, image, pts_xy, next_xyz=None):
         """detect + affinity of every frame against its predecessor in the batch (frame 0 against the last):
         returns (DetectionCache, [(A (M, M), start (M), end (M)) per frame]) with all M RoI slots as the
         affinity operands (fixed work per frame: P = D = M)."""
-        cache, inter = self.detect(xyz, image, pts_xy)
+        cache, inter = self.detect(xyz, image, pts_xy, next_xyz)
         feats = inter["rcnn_feat"].view(cache.boxes.shape[0], cache.boxes.shape[1], -1)
         B, M, C = feats.shape
         link, se = self.rcnn_net.link_layer, self.rcnn_net.se_layer

