@@ -18,6 +18,7 @@
  *   - Return value: 0 on success, a JM_E* code otherwise (the reference returns a meaningless 1
  *     and exit()s the process on kernel failure: ball_query_gpu.cu:62-66, iou3d.cpp:13-21).
  *     jm_last_error() describes the most recent failure on the calling thread.
+ *   - No environment variables are read: experiment switches exist only in the tools build (JM_TOOLS_BUILD).
  */
 #ifndef JMODT_HIP_H
 #define JMODT_HIP_H
@@ -247,8 +248,14 @@ typedef struct {
  *   link     (P,D)  (softmax(S,dim=1)+softmax(S,dim=0))/2
  *   start    (D)    se(mean_i |p_i-d_j|)  raw logit (tracker applies w_se*sigmoid)
  *   end      (P)    se(mean_j |p_i-d_j|)  raw logit
- * The (P*D,C) pair tensor is never materialised.  fp32 MFMA, exact-f32 products. */
+ * The (P*D,C) pair tensor is never materialised.  fp32 MFMA, exact-f32 products.
+ * Everything runs on `stream`.  The start/end head is a short, latency-bound chain of its own: a caller that wants
+ * it to overlap the link head calls jm_affinity_start_end on a second stream it owns (se = NULL here) — the library
+ * itself keeps no streams, events or other per-device state. */
 size_t jm_affinity_workspace_bytes(int p, int d, const jm_mlp3_t* link, const jm_mlp3_t* se);
+size_t jm_affinity_start_end_workspace_bytes(int p, int d, const jm_mlp3_t* se);
+int jm_affinity_start_end(int p, int d, const float* pred_feat, const float* det_feat, const jm_mlp3_t* se,
+                          float* start, float* end, void* ws, size_t ws_bytes, jm_stream_t stream);
 int jm_affinity_forward(int p, int d, const float* pred_feat, const float* det_feat, const jm_mlp3_t* link,
                         const jm_mlp3_t* se, float* link_raw, float* link_out, float* start, float* end, void* ws,
                         size_t ws_bytes, jm_stream_t stream);

@@ -32,7 +32,6 @@
 //  MfmaUtil of this kernel: 54-56 % (profiles/r01_ops_pmc_MfmaUtil.txt).
 #include <stdlib.h>
 
-#include <mutex>
 
 #include "jm_common.h"
 
@@ -360,24 +359,6 @@ struct MlpJob {
     float* y;              // (M) output
 };
 
-// one non-blocking side stream + fork/join events per device, created on first use
-struct SideStream { hipStream_t stream; hipEvent_t fork, join; };
-static SideStream* side_stream() {
-    static SideStream tab[16];
-    static bool made[16];
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!made[dev]) {
-        if (hipStreamCreateWithFlags(&tab[dev].stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&tab[dev].fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&tab[dev].join, hipEventDisableTiming) != hipSuccess) return nullptr;
-        made[dev] = true;
-    }
-    return &tab[dev];
-}
-
 static int tiles_of(int M, int N) { return divup(M, BM) * divup(N, BN); }
 
 // run the 3-layer MLP for up to two jobs: 1 launch per layer (grouped) + 1 fill launch
@@ -397,7 +378,7 @@ static int run_mlps(const MlpJob* jobs, int njobs, hipStream_t s) {
         t1 += tiles_of(a.M, a.N);
         t2 += tiles_of(b.M, b.N);
     }
-    static const int small_m = getenv("JM_GEMM_SMALL_M") ? atoi(getenv("JM_GEMM_SMALL_M")) : 4096;
+    static const int small_m = tune_env("JM_GEMM_SMALL_M", 4096);
     if (njobs == 1 && jobs[0].M <= small_m) {
         const GemmParams& a = g1.p[0];
         const GemmParams& b = g2.p[0];
@@ -406,8 +387,8 @@ static int run_mlps(const MlpJob* jobs, int njobs, hipStream_t s) {
         hipLaunchKernelGGL((mlp_gemm_small_kernel<1>), dim3(divup(b.N, 32), divup(b.M, 32)), dim3(64), 0, s, b);
         return check_launch("affinity mlp (small)");
     }
-    static const int bk = getenv("JM_GEMM_BK") ? atoi(getenv("JM_GEMM_BK")) : 16;
-    static const int pin = getenv("JM_GEMM_PIN") ? atoi(getenv("JM_GEMM_PIN")) : 1;
+    static const int bk = tune_env("JM_GEMM_BK", 16);
+    static const int pin = tune_env("JM_GEMM_PIN", 1);
 #define JM_GEMM_LAUNCH(E, T, G)                                                                          \
     do {                                                                                                 \
         if (bk == 32 && pin) hipLaunchKernelGGL((mlp_gemm_kernel<E, 32, true>), dim3(T), dim3(256), 0, s, G);        \
@@ -456,6 +437,41 @@ extern "C" size_t jm_affinity_workspace_bytes(int p, int d, const jm_mlp3_t* lin
     return b;
 }
 
+// workspace: [se feat (D+P,C)] [se hidden (D+P,H1)] [se logit (D+P)]
+extern "C" size_t jm_affinity_start_end_workspace_bytes(int p, int d, const jm_mlp3_t* se) {
+    if (p <= 0 || d <= 0 || !se) return 0;
+    const size_t r = (size_t)p + d;
+    return align_up(r * se->c * sizeof(float), 256) + align_up(r * se->h1 * sizeof(float), 256) + align_up(r * sizeof(float), 256);
+}
+
+extern "C" int jm_affinity_start_end(int p, int d, const float* pred_feat, const float* det_feat, const jm_mlp3_t* se,
+                                     float* start, float* end, void* ws, size_t ws_bytes, jm_stream_t stream) {
+    JM_REQUIRE(p >= 0 && d >= 0, "affinity start/end: bad sizes");
+    if (p == 0 || d == 0) return JM_OK;
+    int rc = check_mlp(se, "affinity se_layer");
+    if (rc) return rc;
+    JM_REQUIRE(pred_feat && det_feat && start && end && ws, "affinity start/end: null pointer");
+    JM_REQUIRE(((reinterpret_cast<uintptr_t>(pred_feat) | reinterpret_cast<uintptr_t>(det_feat)) & 15u) == 0,
+               "affinity: features must be 16-byte aligned");
+    if (ws_bytes < jm_affinity_start_end_workspace_bytes(p, d, se)) { set_error("affinity start/end: workspace too small"); return JM_EWORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t r = (size_t)p + d;
+    char* w = (char*)ws;
+    float* feat = (float*)w;    w += align_up(r * se->c * sizeof(float), 256);
+    float* sehid = (float*)w;   w += align_up(r * se->h1 * sizeof(float), 256);
+    float* logit = (float*)w;
+    const bool contiguous_out = (end == start + d);   // caller gave one (D+P) buffer: write logits in place
+    hipLaunchKernelGGL(se_feature_kernel, dim3((unsigned)r), dim3(256), 0, s, p, d, se->c, pred_feat, det_feat, feat);
+    const MlpJob sj{(int)r, feat, nullptr, nullptr, 1, se, sehid, contiguous_out ? start : logit};
+    rc = run_mlps(&sj, 1, s);
+    if (rc) return rc;
+    if (!contiguous_out) {
+        (void)hipMemcpyAsync(start, logit, (size_t)d * sizeof(float), hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(end, logit + d, (size_t)p * sizeof(float), hipMemcpyDeviceToDevice, s);
+    }
+    return check_launch("affinity start/end");
+}
+
 extern "C" int jm_affinity_forward(int p, int d, const float* pred_feat, const float* det_feat,
                                    const jm_mlp3_t* link, const jm_mlp3_t* se, float* link_raw, float* link_out,
                                    float* start, float* end, void* ws, size_t ws_bytes, jm_stream_t stream) {
@@ -478,33 +494,14 @@ extern "C" int jm_affinity_forward(int p, int d, const float* pred_feat, const f
     float* sraw = (float*)w;   w += align_up(pd * sizeof(float), 256);
     float* stats = (float*)w;  w += align_up(2 * r * sizeof(float), 256);
     float* S = link_raw ? link_raw : sraw;
-    // The start/end head is a tiny, latency-bound problem ((P+D) rows: 8 workgroups marching
-    // through 32 k-tiles).  Grouping it into the link head's launches makes every launch as long
-    // as that slow chain (measured: +35 % per GEMM), so it runs as its own chain on a side stream
-    // forked from / joined to the caller's stream with events (capturable in a hipGraph).
-    float* logit = nullptr;
-    bool contiguous_out = false;
-    SideStream* side = nullptr;
+    // The start/end head is a tiny, latency-bound problem ((P+D) rows: 8 workgroups marching through 32 k-tiles).
+    // Grouping it into the link head's launches makes every launch as long as that slow chain (measured: +35 % per
+    // GEMM), so it is its own short chain — here in front of the link head on the caller's stream; a caller that
+    // wants the two to overlap runs jm_affinity_start_end on a second stream of its own (the library keeps no
+    // streams or events: ops/affinity.py does exactly that).
     if (se) {
-        float* feat = (float*)w;    w += align_up(r * se->c * sizeof(float), 256);
-        float* sehid = (float*)w;   w += align_up(r * se->h1 * sizeof(float), 256);
-        logit = (float*)w;
-        contiguous_out = (end == start + d);   // caller gave one (D+P) buffer: write logits in place
-        side = side_stream();
-        hipStream_t s2 = side ? side->stream : s;
-        if (side) {
-            (void)hipEventRecord(side->fork, s);
-            (void)hipStreamWaitEvent(s2, side->fork, 0);
-        }
-        hipLaunchKernelGGL(se_feature_kernel, dim3((unsigned)r), dim3(256), 0, s2, p, d, se->c, pred_feat, det_feat, feat);
-        const MlpJob sj{(int)r, feat, nullptr, nullptr, 1, se, sehid, contiguous_out ? start : logit};
-        rc = run_mlps(&sj, 1, s2);
+        rc = jm_affinity_start_end(p, d, pred_feat, det_feat, se, start, end, w, ws_bytes - (size_t)(w - (char*)ws), stream);
         if (rc) return rc;
-        if (!contiguous_out) {
-            (void)hipMemcpyAsync(start, logit, (size_t)d * sizeof(float), hipMemcpyDeviceToDevice, s2);
-            (void)hipMemcpyAsync(end, logit + d, (size_t)p * sizeof(float), hipMemcpyDeviceToDevice, s2);
-        }
-        if (side) (void)hipEventRecord(side->join, s2);
     }
     const MlpJob lj{(int)pd, nullptr, pred_feat, det_feat, d, link, hidden, S};
     rc = run_mlps(&lj, 1, s);
@@ -513,6 +510,5 @@ extern "C" int jm_affinity_forward(int p, int d, const float* pred_feat, const f
         hipLaunchKernelGGL(softmax_stats_kernel, dim3((unsigned)r), dim3(256), 0, s, p, d, S, stats);
         hipLaunchKernelGGL(dual_softmax_kernel, dim3(divup((int)pd, 256)), dim3(256), 0, s, p, d, S, stats, link_out);
     }
-    if (side) (void)hipStreamWaitEvent(s, side->join, 0);
     return check_launch("affinity");
 }

@@ -384,7 +384,11 @@ fps_coop_kernel(int n, int m, int G, int nclouds, const float* __restrict__ data
                 const unsigned tag = (unsigned)it;
                 const bool okk = (unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag && (unsigned)(w2 >> 32) == tag &&
                                  (unsigned)(w3 >> 32) == tag && (unsigned)(w4 >> 32) == tag;
-                if (__all(okk) || ++spins > (1 << 21)) break;   // bounded (~seconds): a lost peer must not hang the GPU
+                if (__all(okk)) break;
+                // bounded (~seconds): a peer that never publishes (the host sizes every launch to be co-resident, so
+                // this means a broken device partition) must neither hang the GPU nor be papered over with stale
+                // records: abort the kernel — the error surfaces as a launch failure at the caller's next sync
+                if (++spins > (1 << 21)) __builtin_trap();
             }
             const int cv = lane < G ? (int)(unsigned)w0 : (int)0x80000000;
             const int ck = (int)(unsigned)w1;
@@ -539,17 +543,25 @@ static int fps_impl(int b, int n, int m, const float* xyz, float* temp, int* idx
     const int J = divup(n, bs);
     if (J > 32 || (J > 16 && bs > 512)) {  // does not fit one workgroup's register file
         const size_t need = jm_fps_workspace_bytes(b, n);
-        static const int no_coop = getenv("JM_FPS_NO_COOP") ? atoi(getenv("JM_FPS_NO_COOP")) : 0;
+        static const int no_coop = tune_env("JM_FPS_NO_COOP", 0);
         if (ws && need && !no_coop) {
             // cooperative: G workgroups per cloud, exchange records in the caller's workspace
             if (ws_bytes < need) { set_error("fps: workspace %zu < %zu bytes", ws_bytes, need); return JM_EWORKSPACE; }
             JM_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 63u) == 0, "fps: workspace must be 64-byte aligned");
             const int G = (n + 16383) / 16384;
-            int dev = 0, cus = 256;
+            // every workgroup of a launch must be resident at once (they wait for each other): size the launch from
+            // the CU count the runtime reports — a partitioned / masked device with fewer than 8 G CUs cannot host
+            // even one round of 8 clouds and takes the streaming kernel instead of spinning on peers that never run
+            int dev = 0, cus = 0;
             (void)hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8 * G) cus = 256;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
             const int per_launch = 8 * (cus / 8 / G);          // clouds per launch: all workgroups co-resident
-            JM_REQUIRE(per_launch >= 8, "fps: device too small for the cooperative kernel");
+            if (per_launch < 8) {
+                JM_REQUIRE(temp, "fps: %d CUs cannot host the cooperative kernel (needs %d) and the streaming kernel needs "
+                                 "the temp buffer", cus, 8 * G);
+                hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(bs), 0, s, n, m, bs_log2, xyz, temp, idx);
+                return check_launch("fps(stream)");
+            }
             (void)hipMemsetAsync(ws, 0, need, s);
             for (int c0 = 0; c0 < b; c0 += per_launch) {
                 const int nc = b - c0 < per_launch ? b - c0 : per_launch;
@@ -565,9 +577,11 @@ static int fps_impl(int b, int n, int m, const float* xyz, float* temp, int* idx
         hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(bs), 0, s, n, m, bs_log2, xyz, temp, idx);
         return check_launch("fps(stream)");
     }
-    // exact spatially pruned variants (fps_pruned.hip): off by default, measured no faster
-    static const int prune = getenv("JM_FPS_PRUNE") ? atoi(getenv("JM_FPS_PRUNE")) : 0;
+#ifdef JM_TOOLS_BUILD
+    // exact spatially pruned variants (tools/csrc/fps_pruned.hip, tools build only): measured no faster
+    static const int prune = tune_env("JM_FPS_PRUNE", 0);
     if (prune && bs == 1024 && temp && launch_fps_pruned(prune, b, n, m, xyz, temp, idx, s)) return check_launch("fps(pruned)");
+#endif
     // threads per workgroup: points-per-thread target from a measured table,
     // overridable for experiments with JM_FPS_PTS
     // measured on MI355X (tools/fps_sweep.py, us per iteration):
@@ -577,7 +591,7 @@ static int fps_impl(int b, int n, int m, const float* xyz, float* temp, int* idx
     // -> a full 1024-thread workgroup (one reference thread per thread) when the reference block
     //    is 1024 wide, otherwise ONE wave per cloud (no barrier, no LDS).
     int want_pts = bs >= 1024 ? J : 16;
-    if (const char* e = getenv("JM_FPS_PTS")) want_pts = atoi(e);
+    want_pts = tune_env("JM_FPS_PTS", want_pts);
     if (want_pts < J) want_pts = J;
     if (want_pts > 32) want_pts = 32;
     int R = 1;
@@ -587,7 +601,7 @@ static int fps_impl(int b, int n, int m, const float* xyz, float* temp, int* idx
     const int pts = R * J;
     const int recipJ = 65536 / J + 1;
     // multi-wave workgroups use the two-barrier kernel (one wave extracts the winner)
-    static const int force_v1 = getenv("JM_FPS_V1") ? atoi(getenv("JM_FPS_V1")) : 0;
+    static const int force_v1 = tune_env("JM_FPS_V1", 0);
     const bool v2 = block > 64 && !force_v1;
 #define JM_FPS_LAUNCH(P, MB)                                                                                    \
     do {                                                                                                        \

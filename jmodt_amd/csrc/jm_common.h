@@ -27,6 +27,16 @@ inline int check_launch(const char* what) {
         }                              \
     } while (0)
 
+// Experiment switches (JM_* environment variables) exist only in the TOOLS build of the library
+// (python -m jmodt_amd.csrc.build --tools -> tools/bin/libjmodt_hip_tools.so, used by tools/*.py); the product
+// library is compiled without JM_TOOLS_BUILD and every switch folds to its default.
+#ifdef JM_TOOLS_BUILD
+#include <stdlib.h>
+static inline int tune_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static inline constexpr int tune_env(const char*, int dflt) { return dflt; }
+#endif
+
 static inline int divup(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -111,7 +111,7 @@ roipool3d_kernel(int N, int M, int C, int S, const float* __restrict__ xyz, cons
         }
     };
     float pa[12], pb[12];
-    load_tile(0, pa);
+    if (N > 0) load_tile(0, pa);   // (no points at all: nothing to read, every box takes the empty path below)
     for (int base = 0; base < N && cnt < S; base += RP_TILE, parity ^= 1) {
         load_tile(min(base + RP_TILE, max(N - 4, 0) & ~3), pb);   // prefetch the next tile (clamped, 4-aligned, when past the end)
         const int k0 = base + tid * 4;
@@ -253,6 +253,8 @@ static int roipool3d_launch(int batch_size, int pts_num, int boxes_num, int feat
     const size_t lds = (size_t)(((sampled_pts_num + 3) & ~3) + 2 * RP_W) * sizeof(int);
     const long long slab = (long long)sampled_pts_num * (3 + feature_in_len);
     JM_REQUIRE(slab < (1LL << 31), "roipool3d: slab too large");
+    // the copy loop divides flat offsets e <= S*(3+C) by (3+C) with umulhi(e, 2^32/(3+C) + 1): exact while e*(3+C) < 2^32
+    JM_REQUIRE(slab * (3 + feature_in_len) < (1LL << 32), "roipool3d: sampled_pts_num * (3 + C)^2 must stay below 2^32");
     const bool vec = (slab % 4 == 0) && ((reinterpret_cast<uintptr_t>(pooled_features) & 15u) == 0);
     dim3 grid(boxes_num, batch_size), block(RP_T);
     if (vec) {

@@ -18,6 +18,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .pointnet2 import pytorch_utils as pt_utils
+from .pointnet2.pyramid import side_stream
 
 _f32 = torch.float32
 
@@ -72,8 +73,8 @@ def _pack(head: nn.Sequential):
 
 @torch.no_grad()
 def pairwise_affinity(pred_features: torch.Tensor, det_features: torch.Tensor, link_model: nn.Sequential,
-                      se_model: Optional[nn.Sequential] = None, return_raw: bool = False
-                      ) -> Tuple[torch.Tensor, ...]:
+                      se_model: Optional[nn.Sequential] = None, return_raw: bool = False,
+                      overlap_start_end: bool = True) -> Tuple[torch.Tensor, ...]:
     """pred_features (P, C), det_features (D, C) ->
         link_scores (P, D)  dual-softmax affinity             (tracker.py:86-89)
         start_logits (D), end_logits (P)  raw se outputs      (tracker.py:105-110 applies
@@ -91,14 +92,31 @@ def pairwise_affinity(pred_features: torch.Tensor, det_features: torch.Tensor, l
     se_out = torch.empty((D + P,), dtype=_f32, device=dev)   # contiguous: the kernel writes logits in place
     start, end = se_out[:D], se_out[D:]
     link_p = ctypes.byref(link)
-    se_p = ctypes.byref(se) if se is not None else None
-    ws_bytes = lib.jm_affinity_workspace_bytes(P, D, link_p, se_p)
+    main = torch.cuda.current_stream(dev)
+    if se is not None:
+        # the start/end head is a short latency-bound chain ((P+D) rows): it runs on a side stream owned HERE, under
+        # the link head's GEMMs (fork / join with stream waits; the library itself keeps no streams)
+        se_p = ctypes.byref(se)
+        side = side_stream(dev, 2) if overlap_start_end else main
+        se_bytes = lib.jm_affinity_start_end_workspace_bytes(P, D, se_p)
+        se_ws = torch.empty((max(se_bytes, 16),), dtype=torch.uint8, device=dev)
+        if side is not main:
+            side.wait_stream(main)
+            for t in (pf, df, se_out, se_ws, *keep2):
+                t.record_stream(side)
+        with torch.cuda.stream(side):
+            L.check(lib.jm_affinity_start_end(P, D, L.dev(pf, _f32, "pred_features"), L.dev(df, _f32, "det_features"), se_p,
+                                              ctypes.c_void_p(start.data_ptr()), ctypes.c_void_p(end.data_ptr()),
+                                              ctypes.c_void_p(se_ws.data_ptr()), se_bytes, L.stream_ptr()),
+                    "pairwise_affinity(start/end)")
+    ws_bytes = lib.jm_affinity_workspace_bytes(P, D, link_p, None)
     ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
     L.check(lib.jm_affinity_forward(P, D, L.dev(pf, _f32, "pred_features"), L.dev(df, _f32, "det_features"), link_p,
-                                    se_p, ctypes.c_void_p(raw.data_ptr()) if raw is not None else None,
-                                    ctypes.c_void_p(A.data_ptr()), ctypes.c_void_p(start.data_ptr()),
-                                    ctypes.c_void_p(end.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws_bytes,
+                                    None, ctypes.c_void_p(raw.data_ptr()) if raw is not None else None,
+                                    ctypes.c_void_p(A.data_ptr()), None, None, ctypes.c_void_p(ws.data_ptr()), ws_bytes,
                                     L.stream_ptr()), "pairwise_affinity")
+    if se is not None and side is not main:
+        main.wait_stream(side)
     out = (A, start, end) if se_model is not None else (A,)
     return out + ((raw,) if return_raw else ())
 

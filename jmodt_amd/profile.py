@@ -89,6 +89,7 @@ ALGO: Dict[str, Callable] = {
     "jm_decode_rcnn_boxes": lambda a: (_i(a, 0) * (_i(a, 1) + 7 + 7) * 4, 0, {}),
     "jm_feature_gather": lambda a: (_i(a, 0) * _i(a, 4) * 4 * _i(a, 1) * 4 + _i(a, 0) * _i(a, 1) * _i(a, 4) * 4, 0, {}),
     "jm_affinity_forward": _affinity,
+    "jm_affinity_start_end": lambda a: (0, _mlp3_flops(_i(a, 0) + _i(a, 1), _mlp3(a[4])), {}),
     "jm_mlp3_forward": lambda a: (0, _mlp3_flops(_i(a, 0), _mlp3(a[2])), {}),
     "jm_association_cost": lambda a: ((_i(a, 0) + _i(a, 2)) * 28 + 4 * _i(a, 0) * _i(a, 2), 0, {}),
     "jm_boxes_overlap_bev": lambda a: ((_i(a, 0) + _i(a, 2)) * 20 + 4 * _i(a, 0) * _i(a, 2), 0, {}),

@@ -82,15 +82,20 @@ def test_fps_all_equal_and_golden(oracle):
 
 @pytest.mark.parametrize("variant", ["1", "2"])
 def test_fps_pruned_variants_bit_exact(variant):
-    """the spatially pruned kernels (JM_FPS_PRUNE=1: wave clusters, off; =2: slot clusters) must give the
-    same picks as the plain scan — golden cloud, duplicates (permanent ties), a grid (ties across clusters),
-    identical points (every pair tied), 8192 and 16384 points"""
+    """the spatially pruned kernels (tools/csrc/fps_pruned.hip; TOOLS build of the library only — the product
+    library does not contain them; JM_FPS_PRUNE=1: wave clusters, =2: slot clusters) must give the same picks as the
+    plain scan — golden cloud, duplicates (permanent ties), a grid (ties across clusters), identical points (every
+    pair tied), 8192 and 16384 points"""
     import os
     import subprocess
     import sys
+    from jmodt_amd.csrc import build as hip_build
+    assert os.path.isfile(hip_build.TOOLS_LIB), "tools library missing: python -m jmodt_amd.csrc.build --tools"
     code = (
         "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
-        "from jmodt_amd import synth\n"
+        "from jmodt_amd import synth, _lib\n"
+        "from jmodt_amd.csrc import build as hip_build\n"
+        "_lib.LIB_PATH = hip_build.TOOLS_LIB\n"
         "from jmodt_amd.ops.pointnet2.pointnet2_utils import farthest_point_sample\n"
         "from oracle import oracle as o\n"
         "g = np.load(%r)\n"

@@ -134,6 +134,7 @@ def test_training_affinity_and_finetune_step_on_gpu():
                            list(link.parameters()) + list(se.parameters())):
         # Adam's first step is lr * sign(grad) wherever |grad| >> eps: compare where the float64 gradient is not tiny
         big = p64.grad.abs() > 1e-7
-        assert (pd.detach().double().cpu() - p64.detach())[big].abs().max().item() < 2e-4
+        if big.any():
+            assert (pd.detach().double().cpu() - p64.detach())[big].abs().max().item() < 2e-4
         moved = max(moved, (pd.detach().cpu() - p0).abs().max().item())
     assert moved > 5e-4

@@ -4,7 +4,9 @@ CHILD = r'''
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
-from jmodt_amd import synth
+from jmodt_amd import synth, _lib
+from jmodt_amd.csrc import build as _hip_build
+_lib.LIB_PATH = _hip_build.TOOLS_LIB   # the JM_* switches exist only in the tools build (python -m jmodt_amd.csrc.build --tools)
 from jmodt_amd.ops.pointnet2.pointnet2_utils import farthest_point_sample
 def timeit(fn, iters=5):
     fn(); torch.cuda.synchronize()

@@ -5,7 +5,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from jmodt_amd import synth
+from jmodt_amd import synth, _lib
+from jmodt_amd.csrc import build as _hip_build
+_lib.LIB_PATH = _hip_build.TOOLS_LIB   # the JM_* switches exist only in the tools build (python -m jmodt_amd.csrc.build --tools)
 from jmodt_amd.ops.pointnet2.pointnet2_utils import farthest_point_sample
 
 

@@ -6,7 +6,9 @@ import sys
 CHILD = r'''
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(sys.argv[0]))) if False else os.getcwd())
-from jmodt_amd import synth
+from jmodt_amd import synth, _lib
+from jmodt_amd.csrc import build as _hip_build
+_lib.LIB_PATH = _hip_build.TOOLS_LIB   # the JM_* switches exist only in the tools build (python -m jmodt_amd.csrc.build --tools)
 from jmodt_amd.ops.affinity import make_affinity_mlp, pairwise_affinity, mlp3_forward
 torch.manual_seed(0)
 link, se = make_affinity_mlp().cuda().eval(), make_affinity_mlp().cuda().eval()
