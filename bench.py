@@ -403,6 +403,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_enqueue = time.perf_counter() - t0      # host time to ENQUEUE the steps (the GPU runs behind it)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof.enabled = False
@@ -440,6 +441,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4),
+            "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

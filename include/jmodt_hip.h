@@ -232,6 +232,35 @@ int jm_feature_gather(int b, int c, int h, int w, int n, const float* fmap, int6
 int jm_feature_gather_grad(int b, int c, int h, int w, int n, const float* grad_out, const float* xy,
                            float* grad_fmap, int64_t sb, int64_t sc, int64_t sh, int64_t sw, jm_stream_t stream);
 
+/* The final LI-Fusion image feature AT THE POINTS (jmodt/detection/modeling/backbone.py:187-195):
+ *   feature_gather(relu(bn(conv1x1(cat_i deconv_i(img_i)))), xy)
+ * without the (B, q, H, W) map: only the pixels under a bilinear tap are evaluated (sorted by sub-pixel phase, one
+ * fp32-MFMA tile of 32 taps per wave).  maps[i] (B, H/k_i, W/k_i, C_i) CHANNELS-LAST, C_i % 16 == 0, strides k_i
+ * (powers of two <= 16, kernel == stride of the level's ConvTranspose2d); packed_weights[i] from
+ * jm_image_fusion_pack(C_i, q, k_i, wc_i) with wc_i (C_i, q, k_i, k_i) = the deconvolution weight composed with the
+ * level's slice of the BatchNorm-folded 1x1 fusion convolution; bias32 = the folded bias (deconvolution biases
+ * included), zero padded to 32; xy (B, N, 2) in [-1, 1] on the (h, w) canvas -> out (B, q, N), q <= 32. */
+size_t jm_image_fusion_gather_workspace_bytes(int b, int n);
+size_t jm_image_fusion_packed_elems(int cin, int k);
+int jm_image_fusion_pack(int cin, int q, int k, const float* wc, float* wp, jm_stream_t stream);
+int jm_image_fusion_gather(int b, int n, int h, int w, int q, int num_levels, const int* channels, const int* strides,
+                           const float* const* maps, const float* const* packed_weights, const float* bias32,
+                           const float* xy, float* out, void* ws, size_t ws_bytes, jm_stream_t stream);
+
+/* LI-Fusion attention block (jmodt/detection/modeling/backbone.py:35-81, AttentionFusion + IALayer, eval mode):
+ *   att = sigmoid(fc3(tanh(fc1(I^T) + fc2(P^T))));  G = relu(bn(conv1(I))) * att;  out = relu(bn1(conv1(cat[P, G])))
+ * img_feats I (B, ic, n), point_feats P (B, pc, n) -> out (B, oc, n), one launch (the reference: ~16 kernels).
+ * All matrices in the device layout of jm_sa_mlp_pack(cout, cin, first_layer = 0): w_fc1 (rc x ic), w_fc2 (rc x pc),
+ * w_img (pc x ic, BatchNorm folded), w_fuse_point / w_fuse_img = the two column halves of the fusion convolution
+ * (oc x pc each, BatchNorm folded); b_fc12 = b_fc1 + b_fc2, b_img, b_fuse = packed biases (pad128); w_fc3 (rc) plain,
+ * b_fc3 by value.  n % 32 == 0 and the 32-point tile of [I | P | T | G] must fit the LDS (jm_attention_fusion_supported). */
+int jm_attention_fusion_supported(int b, int n, int ic, int pc, int rc, int oc);
+int jm_attention_fusion_forward(int b, int n, int ic, int pc, int rc, int oc, const float* img_feats,
+                                const float* point_feats, const float* w_fc1, const float* w_fc2, const float* b_fc12,
+                                const float* w_fc3, float b_fc3, const float* w_img, const float* b_img,
+                                const float* w_fuse_point, const float* w_fuse_img, const float* b_fuse, float* out,
+                                jm_stream_t stream);
+
 /* ------------------------------------------------------------------ affinity head --------- */
 
 /* link_layer / se_layer MLP (jmodt/detection/modeling/rcnn.py:91-111):

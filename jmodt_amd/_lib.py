@@ -67,6 +67,13 @@ SIGNATURES = {
     "jm_nms_mask": (_I, [_I, _P, _F, _I, _P, _P]),
     "jm_feature_gather": (_I, [_I, _I, _I, _I, _I, _P, _L, _L, _L, _L, _P, _P, _P]),
     "jm_feature_gather_grad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _L, _L, _L, _L, _P]),
+    "jm_image_fusion_gather_workspace_bytes": (_Z, [_I, _I]),
+    "jm_image_fusion_packed_elems": (_Z, [_I, _I]),
+    "jm_image_fusion_pack": (_I, [_I, _I, _I, _P, _P, _P]),
+    "jm_image_fusion_gather": (_I, [_I, _I, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_P),
+                                    ctypes.POINTER(_P), _P, _P, _P, _P, _Z, _P]),
+    "jm_attention_fusion_supported": (_I, [_I, _I, _I, _I, _I, _I]),
+    "jm_attention_fusion_forward": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P]),
     "jm_affinity_workspace_bytes": (_Z, [_I, _I, ctypes.POINTER(Mlp3), ctypes.POINTER(Mlp3)]),
     "jm_affinity_forward": (_I, [_I, _I, _P, _P, ctypes.POINTER(Mlp3), ctypes.POINTER(Mlp3), _P, _P, _P, _P, _P, _Z,
                                  _P]),

@@ -24,7 +24,7 @@
 
 namespace jm {
 
-constexpr int SW_BM = 32, SW_LD = SW_BM + 4;     // rows per tile, padded row stride of the k-major LDS tiles
+// (SW_BM = 32 rows per tile, SW_LD = 36: padded row stride of the k-major LDS tiles; wide_ktiles: jm_mfma.h)
 constexpr int SW_KC = 128;                       // first-layer channels per gather chunk
 constexpr int SW_XBUF = SW_KC * SW_LD;           // floats per input chunk buffer
 
@@ -43,53 +43,6 @@ struct SaWideParams {
     int cout;
     int rows_per_frame;
 };
-
-// acc[j] += A(32 rows x 16 nkt, LDS k-major) x W-tile of this wave's column blocks cb0 + 4 j, j < NOWN
-//   bp : this lane's packed weights for k-tile 0 of block cb0; kt_stride floats per k-tile
-template <int NOWN>
-__device__ __forceinline__ void wide_ktiles(const float* __restrict__ A, int nkt, const float* __restrict__ bp,
-                                            size_t kt_stride, int a_off, f32x16 (&acc)[2]) {
-    float bc[NOWN][8], bn[NOWN][8];
-    float ac[8], an[8];
-    auto loadB = [&](float (&b)[NOWN][8], const float* q) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < NOWN; ++j) {          // column block + 4: 4 blocks x 32 columns x 16 floats further on
-            const float4 lo = *reinterpret_cast<const float4*>(q + j * 2048);
-            const float4 hi = *reinterpret_cast<const float4*>(q + j * 2048 + 4);
-            b[j][0] = lo.x; b[j][1] = lo.y; b[j][2] = lo.z; b[j][3] = lo.w;
-            b[j][4] = hi.x; b[j][5] = hi.y; b[j][6] = hi.z; b[j][7] = hi.w;
-        }
-    };
-    auto loadA = [&](float (&a)[8], int kt) __attribute__((always_inline)) {
-        const float* q = A + (size_t)kt * 16 * SW_LD + a_off;         // a_off = khalf * SW_LD + row
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) a[kk] = q[(2 * kk) * SW_LD];
-    };
-    auto mm = [&](const float (&a)[8], const float (&b)[NOWN][8]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-            for (int j = 0; j < NOWN; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[j][kk], acc[j], 0, 0, 0);
-    };
-    loadB(bc, bp);
-    loadA(ac, 0);
-    int kt = 0;
-    for (; kt + 2 <= nkt; kt += 2) {
-        loadB(bn, bp + (size_t)(kt + 1) * kt_stride);
-        loadA(an, kt + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(ac, bc);
-        __builtin_amdgcn_sched_barrier(0);
-        const int nx = kt + 2 < nkt ? kt + 2 : kt;                    // unconditional loads on a clamped address
-        loadB(bc, bp + (size_t)nx * kt_stride);
-        loadA(ac, nx);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(an, bn);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (kt < nkt) mm(ac, bc);
-}
 
 // Column blocks: a layer's packed weights / biases are zero padded to np = pad128(width) columns, i.e. nb = np / 128
 // blocks for EACH of the four waves (block w + 4 j of wave w); padding blocks produce zeros.  Blocks are processed

@@ -29,7 +29,7 @@ import torch.nn.functional as F
 from .ops import proposal as proposal_ops
 from .ops.affinity import make_affinity_mlp, pairwise_affinity
 from .ops.detections import DetectionCache, decode_rcnn_boxes, select_detections
-from .ops.fusion import feature_gather
+from .ops.fusion import PackedAttentionFusion, PackedImageFusion, feature_gather
 from .ops.pointnet2 import pytorch_utils as pt_utils
 from .ops.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModule, PointnetSAModuleMSG
 from .ops.pointnet2.pyramid import FpsPyramid, side_stream
@@ -101,7 +101,7 @@ class DetectorConfig:
             sa_mlps=(((16, 16, 16), (16, 16, 32)), ((16, 16, 32), (16, 32, 32)), ((32, 32, 64), (32, 48, 64)),
                      ((64, 64, 64), (64, 80, 64))),
             fp_mlps=((32, 32), (32, 32), (64, 64), (64, 64)), rpn_cls_fc=(32,), rpn_reg_fc=(32,),
-            img_channels=(3, 8, 16, 16, 32), point_channels=(48, 64, 128, 128), deconv_reduce=(4, 4, 4, 4),
+            img_channels=(3, 16, 16, 16, 32), point_channels=(48, 64, 128, 128), deconv_reduce=(4, 4, 4, 4),
             img_features_channel=32, rpn_pre_nms_top_n=300, rpn_post_nms_top_n=16, rcnn_num_points=64,
             rcnn_xyz_up=(32, 32), rcnn_sa_npoints=(32, 8, -1), rcnn_sa_radius=(0.8, 1.6, 100.0),
             rcnn_sa_nsample=(16, 16, 16), rcnn_sa_mlps=((32, 32, 32), (32, 32, 64), (64, 64, 64)),
@@ -268,6 +268,8 @@ class DetectAffinityEngine(nn.Module):
         self._folded: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.overlap = True                # FPS pyramid + image branch on side streams
         self.last_fps_idx: List[torch.Tensor] = []
+        self.sparse_image_fusion = True    # final image feature only under the bilinear taps (else dense deconvolutions)
+        self.fuse_attention = True         # LI-Fusion attention block as one kernel where it fits (else rocBLAS GEMMs)
         self._prefetched = None
 
     # -- helpers -------------------------------------------------------------------------------------
@@ -292,6 +294,12 @@ class DetectAffinityEngine(nn.Module):
         W_i, b_i = self._wb(tag + ".ia", lambda: _fold_conv_bn(mod.IA_Layer.conv1[0], mod.IA_Layer.conv1[1]))
         W_f, b_f = self._wb(tag + ".fuse", lambda: _fold_conv_bn(mod.conv1, mod.bn1))
         ia = mod.IA_Layer
+        if point_feats.is_cuda and point_feats.dtype == torch.float32 and self.fuse_attention:
+            # the whole block as ONE fp32-MFMA kernel on 32-point tiles (csrc/li_fusion.hip) where the tile fits the LDS
+            packed = self._wb(tag + ".packed", lambda: PackedAttentionFusion(
+                ia.fc1.weight, ia.fc1.bias, ia.fc2.weight, ia.fc2.bias, ia.fc3.weight, ia.fc3.bias, W_i, b_i, W_f, b_f))
+            if packed.supported(point_feats.shape[0], point_feats.shape[2]):
+                return packed(point_feats, img_feats)
         it, pt = img_feats.transpose(1, 2), point_feats.transpose(1, 2)                    # (B, n, C) views
         gate = torch.sigmoid(ia.fc3(torch.tanh(ia.fc1(it) + ia.fc2(pt))))                  # (B, n, 1)
         img_new = torch.relu(torch.baddbmm(b_i[None, :, None], W_i.expand(img_feats.shape[0], -1, -1), img_feats))
@@ -356,10 +364,19 @@ class DetectAffinityEngine(nn.Module):
                 cur.record_stream(main)
                 img_maps.append(cur)
                 img_events.append(ev)
-            fused_map = self._t("image_deconv+fusion_conv(MIOpen)", 0, lambda: self._image_fusion_map(img_maps))
+            H, W = image.shape[2], image.shape[3]
+            sparse = None
+            if self.sparse_image_fusion and image.is_cuda:
+                sparse = self._wb("img_fusion.packed", lambda: PackedImageFusion(
+                    *self._composed_image_fusion(), [dc.kernel_size[0] for dc in net.DeConv]))
+                if not sparse.supported(img_maps, H, W):
+                    sparse = None
+            fused_map = None
+            if sparse is None:      # dense fall-back: the full-resolution fused map, gathered afterwards
+                fused_map = self._t("image_deconv+fusion_conv(MIOpen)", 0, lambda: self._image_fusion_map(img_maps))
+                fused_map.record_stream(main)
             fused_ev = torch.cuda.Event()
             fused_ev.record(img_stream)
-            fused_map.record_stream(main)
         # --- stream M: set abstraction + LI-Fusion per level ---
         l_xyz, l_feats, l_xy = [xyz], [None], [pts_xy]
         self.last_fps_idx = []
@@ -382,7 +399,8 @@ class DetectAffinityEngine(nn.Module):
         # --- final image fusion on the full cloud (backbone.py:187-195) ---
         prof.stall("image_exposed_wait_final", lambda: main.wait_event(fused_ev))
         with prof.scope("li_fusion_final"):
-            gathered = feature_gather(fused_map, pts_xy)
+            # sparse: the fused image feature evaluated only under the points' bilinear taps (csrc/image_fusion.hip)
+            gathered = sparse(img_maps, pts_xy, H, W) if sparse is not None else feature_gather(fused_map, pts_xy)
             out = self._t("attention_fusion(rocBLAS)", 0, lambda: self._attention_fusion(
                 "fusion_final", net.final_fusion_img_point, l_feats[0], gathered))
         if self.overlap:
@@ -416,6 +434,25 @@ class DetectAffinityEngine(nn.Module):
             y = F.conv_transpose2d(m, w, bias if i == 0 else None, stride=k)
             acc = y if acc is None else acc.add_(y)
         return torch.relu_(acc)
+
+    def _composed_image_fusion(self):
+        """([wc_i (C_i, q, k_i, k_i)], bias (q)): each level's transposed convolution composed with its slice of the
+        BatchNorm-folded 1x1 fusion convolution (linear o linear), deconvolution biases folded into the bias"""
+        net = self.rpn.backbone_net
+
+        def make():
+            Wf, bf = _fold_conv_bn(net.image_fusion_conv, net.image_fusion_bn)     # (q, sum reduce)
+            ws, off = [], 0
+            bias = bf.clone()
+            for dc in net.DeConv:
+                r = dc.out_channels
+                Wi = dc.weight.detach()                                           # (cin, r, k, k)
+                Ws = Wf[:, off:off + r]                                           # (q, r)
+                ws.append(torch.einsum("crhw,qr->cqhw", Wi, Ws).contiguous())
+                bias += Ws @ dc.bias.detach()
+                off += r
+            return ws, bias
+        return self._wb("img_fusion", make)
 
     @torch.no_grad()
     def rpn_forward(self, xyz, image, pts_xy, next_xyz=None) -> Dict[str, torch.Tensor]:

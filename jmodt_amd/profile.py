@@ -88,6 +88,12 @@ ALGO: Dict[str, Callable] = {
     "jm_decode_rpn_proposals": lambda a: (_i(a, 0) * (_i(a, 1) + 3 + 7) * 4, 0, {}),
     "jm_decode_rcnn_boxes": lambda a: (_i(a, 0) * (_i(a, 1) + 7 + 7) * 4, 0, {}),
     "jm_feature_gather": lambda a: (_i(a, 0) * _i(a, 4) * 4 * _i(a, 1) * 4 + _i(a, 0) * _i(a, 1) * _i(a, 4) * 4, 0, {}),
+    "jm_attention_fusion_forward": lambda a: (
+        _i(a, 0) * _i(a, 1) * 4 * (_i(a, 2) + _i(a, 3) + _i(a, 5)),
+        2 * _i(a, 0) * _i(a, 1) * (_i(a, 4) * (_i(a, 2) + _i(a, 3) + 1) + _i(a, 3) * _i(a, 2) + 2 * _i(a, 3) * _i(a, 5)), {}),
+    "jm_image_fusion_gather": lambda a: (
+        _i(a, 0) * _i(a, 1) * 4 * 4 * sum(int(a[6][k]) for k in range(_i(a, 5))) + _i(a, 0) * _i(a, 1) * _i(a, 4) * 4,
+        2 * _i(a, 0) * _i(a, 1) * 4 * 32 * sum(int(a[6][k]) for k in range(_i(a, 5))), {}),
     "jm_affinity_forward": _affinity,
     "jm_affinity_start_end": lambda a: (0, _mlp3_flops(_i(a, 0) + _i(a, 1), _mlp3(a[4])), {}),
     "jm_mlp3_forward": lambda a: (0, _mlp3_flops(_i(a, 0), _mlp3(a[2])), {}),
@@ -198,7 +204,7 @@ class LibProxy:
             return hit
         fn = getattr(object.__getattribute__(self, "_cdll"), sym)
         if not sym.startswith("jm_") or sym.endswith("_bytes") or sym.endswith("_elems") or sym in (
-                "jm_version", "jm_last_error", "jm_sa_mlp_pack", "jm_pts_in_boxes3d_cpu", "jm_roipool3d_cpu"):
+                "jm_version", "jm_last_error", "jm_sa_mlp_pack", "jm_image_fusion_pack", "jm_pts_in_boxes3d_cpu", "jm_roipool3d_cpu"):
             cache[sym] = fn
             return fn
 

@@ -131,7 +131,7 @@ def main():
 
     # ---------------- LI-Fusion blocks forward (reduced channel configuration written into the reference's cfg)
     from jmodt.detection.modeling import backbone as ref_bb
-    cfg.LI_FUSION.IMG_CHANNELS = [3, 8, 16, 16, 32]
+    cfg.LI_FUSION.IMG_CHANNELS = [3, 16, 16, 16, 32]
     cfg.LI_FUSION.POINT_CHANNELS = [48, 64, 128, 128]
     cfg.LI_FUSION.DeConv_Reduce = [4, 4, 4, 4]
     cfg.LI_FUSION.IMG_FEATURES_CHANNEL = 32

@@ -307,3 +307,95 @@ def test_bench_workloads_smoke(workload, extra):
         assert "affinity_forward" in names and r["roofline"] is not None
     if workload == "train":
         assert "finetune" in names
+
+
+@pytest.mark.parametrize("ic,pc,n,B", [(64, 96, 4096, 2), (128, 256, 1024, 3), (32, 128, 16384, 1), (8, 48, 64, 2), (20, 40, 96, 1)])
+def test_attention_fusion_kernel_vs_module(ic, pc, n, B):
+    """csrc/li_fusion.hip against the parameter container's own forward (Linear / Conv1d / BatchNorm1d modules =
+    the reference's op sequence, backbone.py:44-81) in float64 on the CPU, at the shapes of LI-Fusion levels 1, 2 and
+    the final fusion (config.py:46-47) + odd widths"""
+    from jmodt_amd.detector import AttentionFusion, DetectAffinityEngine, DetectorConfig
+    torch.manual_seed(ic * pc)
+    mod = AttentionFusion(ic, pc, pc)
+    g = torch.Generator().manual_seed(1)
+    for m in mod.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+    mod.eval()
+    P, I = torch.randn(B, pc, n, generator=g), torch.randn(B, ic, n, generator=g)
+    with torch.no_grad():
+        want = mod.double()(P.double(), I.double())
+    mod = mod.float().to(DEV)
+    eng = DetectAffinityEngine(DetectorConfig.tiny())
+    with torch.no_grad():
+        got = eng._attention_fusion("t", mod, P.to(DEV), I.to(DEV))
+        assert "t.packed" in eng._folded                                      # the fused kernel ran
+        eng.fuse_attention = False
+        eng.invalidate()
+        got_gemm = eng._attention_fusion("t", mod, P.to(DEV), I.to(DEV))       # rocBLAS path
+    close(got, want)
+    close(got_gemm, want)
+
+
+def test_li_fusion_blocks_on_gpu_vs_reference_golden():
+    """the reference's AttentionFusion outputs (tests/golden/fusion_ref.npz) from the fused kernel"""
+    from jmodt_amd.detector import DetectAffinityEngine, DetectorConfig
+    from tests.conftest import load_golden
+    gd = load_golden("fusion_ref.npz")
+    eng = DetectAffinityEngine(DetectorConfig.tiny())
+    net = eng.rpn.backbone_net
+    net.load_state_dict({k[3:]: torch.from_numpy(gd[k]) for k in gd.files if k.startswith("sd.")}, strict=False)
+    eng = eng.to(DEV)
+    with torch.no_grad():
+        for i, mod in enumerate(net.Fusion_Conv):
+            P, I = gd[f"fusion{i}_point"], gd[f"fusion{i}_img"]
+            # 29 points in the golden: pad the point axis to 32 for the tile kernel, compare the first 29
+            Pp, Ip = np.zeros(P.shape[:2] + (32,), np.float32), np.zeros(I.shape[:2] + (32,), np.float32)
+            Pp[..., :29], Ip[..., :29] = P, I
+            got = eng._attention_fusion(f"g{i}", mod, T(Pp), T(Ip))
+            assert f"g{i}.packed" in eng._folded
+            close(got[..., :29], gd[f"fusion{i}_out"])
+        from jmodt_amd.ops.fusion import feature_gather
+        close(feature_gather(T(gd["fused_map"]), T(gd["xy"])), gd["gathered"], 1e-5)
+
+
+@pytest.mark.parametrize("full,B,N,H,W", [(False, 2, 1000, 32, 64), (False, 1, 37, 48, 160), (True, 1, 16384, 384, 1280)])
+def test_sparse_image_fusion_gather_vs_dense(full, B, N, H, W):
+    """csrc/image_fusion.hip (fused image feature evaluated only under the bilinear taps) vs the dense route it
+    replaces: composed transposed convolutions -> (B, q, H, W) map -> feature_gather; points on pixel centres, on the
+    border, outside the canvas (zeros padding) and everywhere in between"""
+    from jmodt_amd.detector import DetectAffinityEngine, DetectorConfig
+    from jmodt_amd.ops.fusion import PackedImageFusion, feature_gather
+    torch.manual_seed(7)
+    eng = DetectAffinityEngine(DetectorConfig() if full else DetectorConfig.tiny())
+    net = eng.rpn.backbone_net
+    g = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        net.image_fusion_bn.running_mean.copy_(torch.randn(net.image_fusion_bn.running_mean.shape, generator=g) * 0.1)
+        net.image_fusion_bn.running_var.copy_(torch.rand(net.image_fusion_bn.running_var.shape, generator=g) + 0.5)
+        net.image_fusion_bn.bias.copy_(torch.randn(net.image_fusion_bn.bias.shape, generator=g) * 0.2)
+        for dc in net.DeConv:
+            dc.bias.copy_(torch.randn(dc.bias.shape, generator=g) * 0.1)
+    eng = eng.to(DEV)
+    cfg = eng.cfg
+    maps = [torch.randn(B, c, H // k, W // k, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+            for c, k in zip(cfg.img_channels[1:], cfg.deconv_kernels)]
+    xy = torch.rand(B, N, 2, generator=g) * 2.3 - 1.15
+    xy[0, 0] = torch.tensor([-1.0, -1.0]); xy[0, 1] = torch.tensor([1.0, 1.0]); xy[0, 2] = torch.tensor([1.4, 0.1])
+    xy[0, 3] = torch.tensor([2 * 5 / (W - 1) - 1, 2 * 7 / (H - 1) - 1])       # exactly on a pixel centre
+    xy = xy.to(DEV)
+    with torch.no_grad():
+        dense = feature_gather(eng._image_fusion_map(maps), xy)
+        sparse = PackedImageFusion(*eng._composed_image_fusion(), list(cfg.deconv_kernels))
+        assert sparse.supported(maps, H, W)
+        got = sparse(maps, xy, H, W)
+        again = sparse(maps, xy, H, W)
+    assert got.shape == dense.shape == (B, cfg.img_features_channel // 4, N)
+    assert dense.abs().max().item() > 0.1
+    close(got, dense)
+    assert torch.equal(got, again)                     # deterministic whatever order the phase sort produced
+    out_of_canvas = (xy.abs() > 1.0 + 2.0 / (min(H, W) - 1) + 1e-3).any(dim=2)     # more than one pixel outside
+    assert out_of_canvas.any() and (got.transpose(1, 2)[out_of_canvas].abs().max().item() == 0.0)
