@@ -122,6 +122,16 @@ int jm_sa_mlp_pack(int cout, int cin, int first_layer, const float* w, const flo
 int jm_sa_mlp_forward(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                       const float* features, const int* idx, int num_layers, const int* widths,
                       const float* const* weights, const float* const* biases, float* out, jm_stream_t stream);
+/* Pre-projected form of the same block.  The first layer is linear in its input, so
+ *   W_1 [xyz_j - c_i | f_j] + b_1 = u_j - W_1x c_i,      u = W_1 [xyz | f] + b_1 per POINT (B, C, N), W_1x = W_1[:, 0:3]
+ * (C = the first layer's width, <= 128, multiple of 16): one small GEMM by the caller replaces the first layer's work
+ * on every (centre, sample) ROW — 31 % of the RCNN SA1 flops.  The kernel gathers u through idx, forms
+ * relu(u_j - W_1x c_i) while parking the tile in LDS (w1x: (C, 4) row-major, 4th column unused; new_xyz (B, M, 3)) and
+ * runs layers 2..L: widths[0] = C, widths[1..num_layers] = the remaining layer outputs, weights packed with
+ * first_layer = 0.  Same shape limits as the persistent kernel of jm_sa_mlp_forward. */
+int jm_sa_mlp_forward_pre(int b, int n, int m, int c, int nsample, const float* u, const float* w1x, const float* new_xyz,
+                          const int* idx, int num_layers, const int* widths, const float* const* weights,
+                          const float* const* biases, float* out, jm_stream_t stream);
 
 /* ------------------------------------------------------------------ roipool3d_cuda -------- */
 

@@ -47,6 +47,9 @@ struct SaMlpParams {
     const float* new_xyz;            // (B,M,3)
     const float* feat;               // (B,C,N) or null
     const int* idx;                  // (B,M,ns)
+    const float* w1x;                // (C,4) or null.  Non-null = "pre-projected" mode: `feat` holds u = W1 [xyz | f] + b1
+                                     // per POINT and w1x the xyz columns of W1 (4th column padding); the gather forms
+                                     // relu(u[idx] - W1x . centre) = the first layer's output, and the layers given are 2..L
     int L;                           // layers (1..4)
     int kp[5];                       // kp[l] = pad16(width_l), l = 0..L
     int np[4];                       // np[l] = pad128(width_{l+1}): packed rows of layer l
@@ -117,7 +120,7 @@ struct SaSchedule {
 struct SaRow {
     int gidx;            // this thread's neighbour index
     float cx, cy, cz;    // its centre (named fields: a runtime-indexed array would live in scratch)
-    int bi;
+    int bi, centre;
 };
 
 __device__ __forceinline__ void sa_gather_role(const SaMlpParams& p, float* lds, int ltid) {
@@ -129,7 +132,8 @@ __device__ __forceinline__ void sa_gather_role(const SaMlpParams& p, float* lds,
     const bool single = (p.L == 1);
     // first-layer channel order (see sa_mlp_pack_kernel): nfast whole groups of features, an optional
     // partial feature group (index nfast), then the xyz group (index gxyz = pad16(C)/16, the last one)
-    const int C = p.C, nfast = C >> 4, gxyz = (C + 15) >> 4;
+    const bool pre = p.w1x != nullptr;
+    const int C = p.C, nfast = C >> 4, gxyz = pre ? (1 << 20) : (C + 15) >> 4;   // pre-projected mode has no xyz group
     const bool has_tail = (C & 15) != 0;
 
     auto load_row = [&](int i) {
@@ -137,7 +141,8 @@ __device__ __forceinline__ void sa_gather_role(const SaMlpParams& p, float* lds,
         int row0;
         sch.tile(i, t.bi, row0);
         t.gidx = p.idx[(size_t)t.bi * p.M * p.ns + row0 + grow];
-        const float* cp = p.new_xyz + ((size_t)t.bi * p.M + (row0 + grow) / p.ns) * 3;
+        t.centre = (row0 + grow) / p.ns;
+        const float* cp = p.new_xyz + ((size_t)t.bi * p.M + t.centre) * 3;
         t.cx = cp[0]; t.cy = cp[1]; t.cz = cp[2];
         return t;
     };
@@ -158,6 +163,7 @@ __device__ __forceinline__ void sa_gather_role(const SaMlpParams& p, float* lds,
                 const float* rp = cb + (size_t)grp * 16 * p.N;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) g[grp * 8 + j] = rp[j * two_n + off_f];
+
                 // one group's scalar base pointers at a time (left alone, the scheduler forms all of them first
                 // and spills SGPRs into VGPR lanes, which costs VALU slots on the MFMA wave's SIMD)
                 __builtin_amdgcn_sched_barrier(0);
@@ -182,8 +188,20 @@ __device__ __forceinline__ void sa_gather_role(const SaMlpParams& p, float* lds,
 #pragma unroll
         for (int grp = 0; grp < SM_GRP; ++grp) {
             if (g0 + grp < nfast) {
+                if (pre) {
+                    // channel (wave-uniform) -> its three xyz weights by scalar loads; value = relu(u_j - W1x . c_i)
+                    const float* wv = p.w1x + ((size_t)(g0 + grp) * 16 + gk0) * 4;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) Gt[2 * (grp * 8 + j) * SM_LDP] = g[grp * 8 + j];
+                    for (int j = 0; j < 8; ++j) {
+                        float val = __builtin_fmaf(-wv[8 * j], t.cx, g[grp * 8 + j]);
+                        val = __builtin_fmaf(-wv[8 * j + 1], t.cy, val);
+                        val = __builtin_fmaf(-wv[8 * j + 2], t.cz, val);
+                        Gt[2 * (grp * 8 + j) * SM_LDP] = fmaxf(val, 0.f);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) Gt[2 * (grp * 8 + j) * SM_LDP] = g[grp * 8 + j];
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -447,6 +465,21 @@ extern "C" int jm_sa_mlp_pack(int cout, int cin, int first_layer, const float* w
 
 /* layer widths: widths[0] = 3 + C (input), widths[1..L] = layer outputs.
  * weights[l] / biases[l]: packed by jm_sa_mlp_pack(widths[l+1], widths[l], l == 0, ...). */
+static int sa_mlp_narrow_launch(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
+                                const float* features, const float* w1x, const int* idx, int num_layers, const int* widths,
+                                const float* const* weights, const float* const* biases, float* out, jm_stream_t stream);
+
+/* pre-projected form (see the header): layers 2..L on relu(u[idx] - v[centre]) */
+extern "C" int jm_sa_mlp_forward_pre(int b, int n, int m, int c, int nsample, const float* u, const float* w1x,
+                                     const float* new_xyz, const int* idx, int num_layers, const int* widths,
+                                     const float* const* weights, const float* const* biases, float* out, jm_stream_t stream) {
+    JM_REQUIRE(b >= 0 && n >= 1 && m >= 0 && c >= 16 && c % 16 == 0 && c <= 128, "sa_mlp_pre: C must be a multiple of 16, <= 128");
+    if (b == 0 || m == 0) return JM_OK;
+    JM_REQUIRE(u && w1x && new_xyz && idx && out && widths && weights && biases, "sa_mlp_pre: null pointer");
+    JM_REQUIRE(num_layers >= 1 && num_layers <= 3 && widths[0] == c, "sa_mlp_pre: widths[0] must equal C");
+    return sa_mlp_narrow_launch(b, n, m, c, nsample, nullptr, new_xyz, u, w1x, idx, num_layers, widths, weights, biases, out, stream);
+}
+
 extern "C" int jm_sa_mlp_forward(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                                  const float* features, const int* idx, int num_layers, const int* widths,
                                  const float* const* weights, const float* const* biases, float* out,
@@ -460,20 +493,28 @@ extern "C" int jm_sa_mlp_forward(int b, int n, int m, int c, int nsample, const 
         return sa_mlp_wide_launch(b, n, m, c, nsample, xyz, new_xyz, features, idx, num_layers, widths, weights, biases,
                                   out, (hipStream_t)stream);
     JM_REQUIRE(idx && new_xyz, "sa_mlp: GroupAll (idx == NULL) needs a shape of the wide variant");
+    JM_REQUIRE(widths[0] == 3 + c, "sa_mlp: widths[0] = %d != 3 + C = %d", widths[0], 3 + c);
+    return sa_mlp_narrow_launch(b, n, m, c, nsample, xyz, new_xyz, features, nullptr, idx, num_layers, widths, weights, biases,
+                                out, stream);
+}
+
+static int sa_mlp_narrow_launch(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
+                                const float* features, const float* w1x, const int* idx, int num_layers, const int* widths,
+                                const float* const* weights, const float* const* biases, float* out, jm_stream_t stream) {
+    const bool pre = w1x != nullptr;
     JM_REQUIRE(nsample == 16 || nsample == 32 || nsample == 64, "sa_mlp: nsample %d not in {16,32,64}", nsample);
     JM_REQUIRE(((long long)m * nsample) % SM_BM == 0, "sa_mlp: npoint*nsample = %lld is not a multiple of 128", (long long)m * nsample);
     JM_REQUIRE(num_layers >= 1 && num_layers <= 4, "sa_mlp: %d layers unsupported", num_layers);
-    JM_REQUIRE(widths[0] == 3 + c, "sa_mlp: widths[0] = %d != 3 + C = %d", widths[0], 3 + c);
     JM_REQUIRE(b <= 65535, "sa_mlp: batch too large");
-    JM_REQUIRE(num_layers > 1 || sa_first_kp(widths[0]) <= SM_KC, "sa_mlp: a single layer needs C <= 128");
+    JM_REQUIRE(num_layers > 1 || (pre ? c : sa_first_kp(widths[0])) <= SM_KC, "sa_mlp: a single layer needs C <= 128");
     SaMlpParams p{};
     p.N = n; p.M = m; p.C = c; p.ns = nsample;
-    p.xyz = xyz; p.new_xyz = new_xyz; p.feat = features; p.idx = idx;
+    p.xyz = xyz; p.new_xyz = new_xyz; p.feat = features; p.idx = idx; p.w1x = w1x;
     p.L = num_layers;
     for (int l = 0; l <= num_layers; ++l) {
         JM_REQUIRE(widths[l] >= 1, "sa_mlp: bad width");
         JM_REQUIRE(l == 0 || l == num_layers || widths[l] <= 128, "sa_mlp: hidden width %d > 128", widths[l]);
-        p.kp[l] = l == 0 ? sa_first_kp(widths[0]) : pad_to(widths[l], 16);
+        p.kp[l] = l == 0 ? (pre ? pad_to(c, 16) : sa_first_kp(widths[0])) : pad_to(widths[l], 16);
     }
     for (int l = 0; l < num_layers; ++l) {
         JM_REQUIRE(weights[l] && biases[l], "sa_mlp: null layer %d", l);

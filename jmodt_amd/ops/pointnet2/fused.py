@@ -103,12 +103,79 @@ def _packed_layers(mlp: nn.Sequential, device):
     return packed
 
 
+_pre_cache = weakref.WeakKeyDictionary()      # module -> (signature, (W1, b1, packed layers 2..L))
+PRE_PROJECT = True    # first layer as per-point / per-centre GEMMs in front of the kernel where that applies
+
+
+def _pre_layers(mlp: nn.Sequential, device):
+    """the pre-projected form's operands: (W1 (H1, 3 + C) folded, b1, W1x (H1, 4), [(wp, bp, cout, cin)] of layers 2..L)"""
+    tensors = list(mlp.parameters()) + list(mlp.buffers())
+    sig = tuple((t.data_ptr(), t._version) for t in tensors) + (str(device), "pre")
+    hit = _pre_cache.get(mlp)
+    if hit is not None and hit[0] == sig:
+        return hit[1]
+    lib = L.load()
+    folded = fold_shared_mlp(mlp)
+    W1, b1 = folded[0][0].to(device=device, dtype=_f32).contiguous(), folded[0][1].to(device=device, dtype=_f32).contiguous()
+    packed = []
+    for W, b in folded[1:]:
+        W = W.to(device=device, dtype=_f32).contiguous()
+        b = b.to(device=device, dtype=_f32).contiguous()
+        cout, cin = W.shape
+        wp = torch.empty((lib.jm_sa_mlp_packed_weight_elems(cout, cin, 0),), dtype=_f32, device=device)
+        bp = torch.empty((lib.jm_sa_mlp_packed_bias_elems(cout),), dtype=_f32, device=device)
+        L.check(lib.jm_sa_mlp_pack(cout, cin, 0, L.dev(W, _f32, "W"), L.dev(b, _f32, "b"), ctypes.c_void_p(wp.data_ptr()),
+                                   ctypes.c_void_p(bp.data_ptr()), L.stream_ptr()), "sa_mlp_pack")
+        packed.append((wp, bp, cout, cin))
+    w1x = torch.zeros((W1.shape[0], 4), dtype=_f32, device=device)
+    w1x[:, :3] = W1[:, :3]
+    val = (W1, b1, w1x, packed)
+    _pre_cache[mlp] = (sig, val)
+    return val
+
+
+def _can_pre_project(mlp: nn.Sequential, features, idx, M: int, ns: int) -> bool:
+    shapes = _layer_shapes(mlp)
+    if not PRE_PROJECT or features is None or idx is None or not shapes or len(shapes) < 2 or len(shapes) > 4:
+        return False
+    h1 = shapes[0][0]
+    return (h1 % 16 == 0 and h1 <= 128 and all(c <= 128 for c, _ in shapes[:-1]) and ns in (16, 32, 64)
+            and (M * ns) % 128 == 0)
+
+
+@torch.no_grad()
+def _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp):
+    """QueryAndGroup + SharedMLP + max-pool with the first layer hoisted in front of the gather: W1 [xyz_j - c_i | f_j] + b1
+    = u_j - W1x c_i with u = W1 [xyz | f] + b1 per point (two small batched GEMMs accumulating into one tensor); the
+    kernel forms relu(u_j - W1x c_i) while gathering and runs layers 2..L (jm_sa_mlp_forward_pre)"""
+    lib = L.load()
+    W1, b1, w1x, packed = _pre_layers(mlp, xyz.device)
+    B, N, _ = xyz.shape
+    M, ns = idx.shape[1], idx.shape[2]
+    H1 = W1.shape[0]
+    feats = features.to(_f32)
+    u = torch.baddbmm(b1[None, :, None], W1[:, 3:].expand(B, -1, -1), feats)
+    u = torch.baddbmm(u, W1[:, :3].expand(B, -1, -1), xyz.transpose(1, 2))            # (B, H1, N)
+    widths = [H1] + [cout for _, _, cout, _ in packed]
+    nl = len(packed)
+    out = torch.empty((B, widths[-1], M), dtype=_f32, device=xyz.device)
+    warr = (ctypes.c_void_p * nl)(*[wp.data_ptr() for wp, _, _, _ in packed])
+    barr = (ctypes.c_void_p * nl)(*[bp.data_ptr() for _, bp, _, _ in packed])
+    widths_c = (ctypes.c_int * (nl + 1))(*widths)
+    L.check(lib.jm_sa_mlp_forward_pre(B, N, M, H1, ns, L.dev(u.contiguous(), _f32, "u"), L.dev(w1x, _f32, "w1x"),
+                                      L.dev(new_xyz.contiguous(), _f32, "new_xyz"), L.dev(idx, _i32, "idx"), nl, widths_c, warr,
+                                      barr, ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "sa_mlp_fused(pre)")
+    return out
+
+
 @torch.no_grad()
 def sa_mlp_fused(xyz: torch.Tensor, new_xyz: Optional[torch.Tensor], features: Optional[torch.Tensor],
                  idx: Optional[torch.Tensor], mlp: nn.Sequential) -> torch.Tensor:
     """xyz (B,N,3), new_xyz (B,M,3), features (B,C,N) or None, idx (B,M,ns) int32 -> (B, mlp_out, M);
     idx = new_xyz = None: GroupAll (one group of all N points per frame, xyz not re-centred) -> (B, mlp_out, 1)"""
     lib = L.load()
+    if idx is not None and _can_pre_project(mlp, features, idx, idx.shape[1], idx.shape[2]):
+        return _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp)
     layers = _packed_layers(mlp, xyz.device)
     B, N, _ = xyz.shape
     M, ns = (idx.shape[1], idx.shape[2]) if idx is not None else (1, N)

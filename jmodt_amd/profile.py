@@ -46,6 +46,13 @@ def _sa_mlp(a):
     return b * (12 * n + 12 * m + 4 * c * n + 4 * m * ns + 4 * w[-1] * m), flops, {}
 
 
+def _sa_mlp_pre(a):
+    b, n, m, c, ns, nl = _i(a, 0), _i(a, 1), _i(a, 2), _i(a, 3), _i(a, 4), _i(a, 9)
+    w = [int(a[10][k]) for k in range(nl + 1)]
+    flops = 2 * b * m * ns * sum(w[k] * w[k + 1] for k in range(nl))
+    return b * (4 * c * n + 12 * m + 4 * m * ns + 4 * w[-1] * m), flops, {}
+
+
 def _roipool(a):
     B, N, M, C, S = (_i(a, k) for k in range(5))
     return B * (12 * N + 28 * M + 4 * C * N) + B * M * S * (3 + C) * 4 + 4 * B * M, 0, dict(evals=B * M * N)
@@ -79,6 +86,7 @@ ALGO: Dict[str, Callable] = {
                               dict(evals=_i(a, 0) * _i(a, 1) * _i(a, 2))),
     "jm_three_interpolate": lambda a: (_i(a, 0) * (4 * _i(a, 1) * _i(a, 2) + 24 * _i(a, 3) + 4 * _i(a, 1) * _i(a, 3)), 0, {}),
     "jm_sa_mlp_forward": _sa_mlp,
+    "jm_sa_mlp_forward_pre": _sa_mlp_pre,
     "jm_roipool3d_forward": _roipool,
     "jm_roipool3d_canonical": _roipool,
     "jm_nms": lambda a: (_nms_bytes(_i(a, 0)), 0, dict(evals=_i(a, 0) * _i(a, 0) // 2)),

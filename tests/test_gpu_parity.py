@@ -787,3 +787,36 @@ def test_dense_config_sizes_vs_oracle(oracle):
     assert np.array_equal(flag.cpu().numpy(), wflag)
     g = got.cpu().numpy()
     assert np.array_equal(g[..., 3:], want[..., 3:]) and np.abs(g[..., :3] - want[..., :3]).max() < 1e-4
+
+
+@pytest.mark.parametrize("N,npoint,C,ns,mlp,extent", [(512, 128, 128, 64, [128, 128, 128, 128], 3.0),       # RCNN SA1
+                                                      (128, 32, 128, 64, [128, 128, 128, 256], 3.0),       # RCNN SA2
+                                                      (4096, 1024, 96, 32, [96, 64, 96, 128], 60.0),        # RPN SA2, KITTI-sized coordinates
+                                                      (600, 64, 40, 16, [40, 32, 72], 8.0)])                # 2 layers
+def test_fused_sa_pre_projected_first_layer(N, npoint, C, ns, mlp, extent):
+    """the first layer hoisted in front of the gather (u = W1 [xyz | f] + b1 per point, relu(u_j - W1x c_i) formed in the
+    kernel: jm_sa_mlp_forward_pre) vs the same kernel with the first layer evaluated per (centre, sample) row vs the
+    un-fused module; coordinates up to the KITTI range (the subtraction u_j - W1x c_i cancels W1x-scaled coordinates)"""
+    from jmodt_amd.ops.pointnet2 import fused
+    from jmodt_amd.ops.pointnet2.pointnet2_modules import PointnetSAModule
+    torch.manual_seed(11)
+    sa = PointnetSAModule(mlp=list(mlp), npoint=npoint, radius=extent / 6, nsample=ns, bn=True)
+    _randomise_bn(sa, 7)
+    sa = sa.to(DEV).eval()
+    B = 3
+    xyz = T(synth.dense_cloud(B, N, 29, extent=extent) + np.float32(extent))
+    feats = torch.randn(B, C, N, device=DEV)
+    assert fused._can_pre_project(sa.mlps[0], feats, torch.zeros(B, npoint, ns), npoint, ns)
+    with torch.no_grad():
+        nx, f_pre, _ = sa(xyz, feats)
+        fused.PRE_PROJECT = False
+        try:
+            _, f_row, _ = sa(xyz, feats)
+        finally:
+            fused.PRE_PROJECT = True
+        sa.fuse = False
+        _, f_ref, _ = sa(xyz, feats)
+    scale = max(f_ref.abs().max().item(), 1.0)
+    assert f_ref.abs().max().item() > 0.1
+    assert (f_pre - f_ref).abs().max().item() <= 1e-4 * scale, (f_pre - f_ref).abs().max().item()
+    assert (f_row - f_ref).abs().max().item() <= 1e-4 * scale
