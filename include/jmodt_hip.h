@@ -242,6 +242,11 @@ int jm_feature_gather(int b, int c, int h, int w, int n, const float* fmap, int6
 int jm_feature_gather_grad(int b, int c, int h, int w, int n, const float* grad_out, const float* xy,
                            float* grad_fmap, int64_t sb, int64_t sc, int64_t sh, int64_t sw, jm_stream_t stream);
 
+/* x = relu(x + bias[c]) in place on CHANNELS-LAST data (numel = pixels * channels, channels % 4 == 0): the one
+ * element-wise pass of the image branch's BasicBlock (backbone.py:16-32) once its eval-mode BatchNorm is folded into
+ * the first convolution (replaces a BatchNorm pass + a ReLU pass over up to 1 GB). */
+int jm_bias_relu_channels_last(long long numel, int channels, float* x, const float* bias, jm_stream_t stream);
+
 /* The final LI-Fusion image feature AT THE POINTS (jmodt/detection/modeling/backbone.py:187-195):
  *   feature_gather(relu(bn(conv1x1(cat_i deconv_i(img_i)))), xy)
  * without the (B, q, H, W) map: only the pixels under a bilinear tap are evaluated (sorted by sub-pixel phase, one

@@ -87,11 +87,12 @@ __device__ __forceinline__ void mfma_ktiles(const float* __restrict__ A, int nkt
 // columns (wave w owns 32-column blocks w, w+4, ...)
 constexpr int SW_BM = 32, SW_LD = SW_BM + 4;     // rows per tile, padded row stride of the k-major LDS tiles
 
-// acc[j] += A(32 rows x 16 nkt, LDS k-major) x W-tile of this wave's column blocks cb0 + 4 j, j < NOWN
-//   bp : this lane's packed weights for k-tile 0 of block cb0; kt_stride floats per k-tile
+// acc[j] += A(32 rows x 16 nkt, k-major with row stride lda: an LDS tile, or a (C, n) global tensor read in place)
+//           x W-tile of this wave's column blocks cb0 + 4 j, j < NOWN
+//   bp : this lane's packed weights for k-tile 0 of block cb0; kt_stride floats per k-tile;  a_off = khalf * lda + row
 template <int NOWN>
 __device__ __forceinline__ void wide_ktiles(const float* __restrict__ A, int nkt, const float* __restrict__ bp,
-                                            size_t kt_stride, int a_off, f32x16 (&acc)[2]) {
+                                            size_t kt_stride, int a_off, f32x16 (&acc)[2], size_t lda = SW_LD) {
     float bc[NOWN][8], bn[NOWN][8];
     float ac[8], an[8];
     auto loadB = [&](float (&b)[NOWN][8], const float* q) __attribute__((always_inline)) {
@@ -104,9 +105,9 @@ __device__ __forceinline__ void wide_ktiles(const float* __restrict__ A, int nkt
         }
     };
     auto loadA = [&](float (&a)[8], int kt) __attribute__((always_inline)) {
-        const float* q = A + (size_t)kt * 16 * SW_LD + a_off;         // a_off = khalf * SW_LD + row
+        const float* q = A + (size_t)kt * 16 * lda + a_off;
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) a[kk] = q[(2 * kk) * SW_LD];
+        for (int kk = 0; kk < 8; ++kk) a[kk] = q[(2 * kk) * lda];
     };
     auto mm = [&](const float (&a)[8], const float (&b)[NOWN][8]) __attribute__((always_inline)) {
 #pragma unroll

@@ -31,6 +31,7 @@ struct LiFusionParams {
     float b3;
     float* out;                       // (B, oc, n)
     int tiles_per_frame;
+    int p_in_lds;                     // 0: the point-feature tile does not fit next to I, T and G — read in place
 };
 
 __global__ void __launch_bounds__(256)
@@ -41,9 +42,10 @@ attention_fusion_kernel(LiFusionParams p) {
     const int lr = lane & 31, lk = lane >> 5;
     const int a_off = lk * SW_LD + lr;
     const int ic = p.ic, pc = p.pc, rc = p.rc, oc = p.oc, icp = p.icp, pcp = p.pcp, n = p.n;
+    const bool p_lds = p.p_in_lds != 0;
     float* XI = lds;                                  // [icp][36]
-    float* XP = XI + (size_t)icp * SW_LD;             // [pcp][36]
-    float* T = XP + (size_t)pcp * SW_LD;              // [np_a][36]  tanh(ri + rp)
+    float* XP = XI + (size_t)icp * SW_LD;             // [pcp][36] (only when it fits)
+    float* T = XP + (p_lds ? (size_t)pcp * SW_LD : 0);   // [np_a][36]  tanh(ri + rp)
     float* G = T + (size_t)p.np_a * SW_LD;            // [np_c][36]  gated image features
     float* att = G + (size_t)p.np_c * SW_LD;          // [32]
     const int bi_ = blockIdx.x / p.tiles_per_frame;
@@ -54,9 +56,15 @@ attention_fusion_kernel(LiFusionParams p) {
         const float* Ib = p.I + (size_t)bi_ * ic * n + row0 + r;
         const float* Pb = p.P + (size_t)bi_ * pc * n + row0 + r;
         for (int c = c0; c < icp; c += 8) XI[c * SW_LD + r] = c < ic ? Ib[(size_t)c * n] : 0.f;
-        for (int c = c0; c < pcp; c += 8) XP[c * SW_LD + r] = c < pc ? Pb[(size_t)c * n] : 0.f;
+        if (p_lds)
+            for (int c = c0; c < pcp; c += 8) XP[c * SW_LD + r] = c < pc ? Pb[(size_t)c * n] : 0.f;
     }
     lds_barrier();
+    // the P operand: the LDS tile, or — wide levels — the (pc, n) tensor itself: a k-major tile of consecutive points is
+    // exactly the MFMA A-operand layout with row stride n (128-byte coalesced reads per k; host: pc % 16 == 0 then)
+    const float* PA = p_lds ? XP : p.P + (size_t)bi_ * pc * n + row0;
+    const size_t p_lda = p_lds ? (size_t)SW_LD : (size_t)n;
+    const int p_off = p_lds ? a_off : lk * n + lr;
 
     auto set_bias = [=](f32x16& a, const float* bias, int cb) __attribute__((always_inline)) {
         const float bv = bias[cb * 32 + lr];
@@ -65,8 +73,8 @@ attention_fusion_kernel(LiFusionParams p) {
     };
     // one GEMM stage over one or two (A, W) operand pairs accumulating into the same columns; `fin(acc, cb)` consumes
     // a finished 32x32 block
-    auto stage = [&](const float* A0, int k0p, const float* Wa, const float* A1, int k1p, const float* Wb, int np,
-                     const float* bias, auto fin) __attribute__((always_inline)) {
+    auto stage = [&](const float* A0, int k0p, size_t lda0, int off0, const float* Wa, const float* A1, int k1p, size_t lda1,
+                     int off1, const float* Wb, int np, const float* bias, auto fin) __attribute__((always_inline)) {
         const int nb = np >> 7;
         const size_t st = (size_t)np * 16;
         for (int j0 = 0; j0 < nb; j0 += 2) {
@@ -76,19 +84,19 @@ attention_fusion_kernel(LiFusionParams p) {
             set_bias(acc[0], bias, cb);
             if (j0 + 1 < nb) {
                 set_bias(acc[1], bias, cb + 4);
-                wide_ktiles<2>(A0, k0p / 16, Wa + off, st, a_off, acc);
-                if (A1) wide_ktiles<2>(A1, k1p / 16, Wb + off, st, a_off, acc);
+                wide_ktiles<2>(A0, k0p / 16, Wa + off, st, off0, acc, lda0);
+                if (A1) wide_ktiles<2>(A1, k1p / 16, Wb + off, st, off1, acc, lda1);
                 fin(acc[0], cb); fin(acc[1], cb + 4);
             } else {
-                wide_ktiles<1>(A0, k0p / 16, Wa + off, st, a_off, acc);
-                if (A1) wide_ktiles<1>(A1, k1p / 16, Wb + off, st, a_off, acc);
+                wide_ktiles<1>(A0, k0p / 16, Wa + off, st, off0, acc, lda0);
+                if (A1) wide_ktiles<1>(A1, k1p / 16, Wb + off, st, off1, acc, lda1);
                 fin(acc[0], cb);
             }
         }
     };
     // accumulator r = 4 rq + t  <->  row 8 rq + 4 lk + t, column cb * 32 + lr
     // ---- stage A: T = tanh(W1 . I + W2 . P + b1 + b2)
-    stage(XI, icp, p.W1, XP, pcp, p.W2, p.np_a, p.ba, [=](const f32x16& a, int cb) __attribute__((always_inline)) {
+    stage(XI, icp, SW_LD, a_off, p.W1, PA, pcp, p_lda, p_off, p.W2, p.np_a, p.ba, [=](const f32x16& a, int cb) __attribute__((always_inline)) {
         float* Tc = T + (size_t)(cb * 32 + lr) * SW_LD + 4 * lk;
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
@@ -105,7 +113,7 @@ attention_fusion_kernel(LiFusionParams p) {
     }
     lds_barrier();
     // ---- stage C: G = relu(Wi . I + bi) * att
-    stage(XI, icp, p.Wi, nullptr, 0, nullptr, p.np_c, p.bi, [=](const f32x16& a, int cb) __attribute__((always_inline)) {
+    stage(XI, icp, SW_LD, a_off, p.Wi, nullptr, 0, 0, 0, nullptr, p.np_c, p.bi, [=](const f32x16& a, int cb) __attribute__((always_inline)) {
         float* Gc = G + (size_t)(cb * 32 + lr) * SW_LD + 4 * lk;
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
@@ -119,7 +127,7 @@ attention_fusion_kernel(LiFusionParams p) {
     lds_barrier();
     // ---- stage D: out = relu(WfP . P + WfG . G + bf)
     float* outb = p.out + (size_t)bi_ * oc * n + row0;
-    stage(XP, pcp, p.WfP, G, pcp, p.WfG, p.np_d, p.bf, [=](const f32x16& a, int cb) __attribute__((always_inline)) {
+    stage(PA, pcp, p_lda, p_off, p.WfP, G, pcp, SW_LD, a_off, p.WfG, p.np_d, p.bf, [=](const f32x16& a, int cb) __attribute__((always_inline)) {
         const int col = cb * 32 + lr;
         if (col >= oc) return;
         float* o = outb + (size_t)col * n + 4 * lk;
@@ -133,8 +141,14 @@ attention_fusion_kernel(LiFusionParams p) {
     });
 }
 
-static size_t li_fusion_lds_bytes(int ic, int pc, int rc) {
-    return ((size_t)(pad_to(ic, 16) + pad_to(pc, 16) + pad_to(rc, 128) + pad_to(pc, 128)) * SW_LD + 32) * sizeof(float);
+static size_t li_fusion_lds_bytes(int ic, int pc, int rc, bool p_in_lds) {
+    return ((size_t)(pad_to(ic, 16) + (p_in_lds ? pad_to(pc, 16) : 0) + pad_to(rc, 128) + pad_to(pc, 128)) * SW_LD + 32) * sizeof(float);
+}
+// 1: everything staged in LDS; 2: the point features are read in place (needs pc % 16 == 0); 0: does not fit
+static int li_fusion_mode(int ic, int pc, int rc) {
+    if (li_fusion_lds_bytes(ic, pc, rc, true) <= 160 * 1024) return 1;
+    if (pc % 16 == 0 && li_fusion_lds_bytes(ic, pc, rc, false) <= 160 * 1024) return 2;
+    return 0;
 }
 
 }  // namespace jm
@@ -144,7 +158,7 @@ using namespace jm;
 extern "C" int jm_attention_fusion_supported(int b, int n, int ic, int pc, int rc, int oc) {
     if (b < 0 || n < 1 || ic < 1 || pc < 1 || rc < 1 || oc < 1) return 0;
     if (n % 32 || (long long)b * (n / 32) >= (1LL << 31)) return 0;
-    return li_fusion_lds_bytes(ic, pc, rc) <= 160 * 1024 ? 1 : 0;
+    return li_fusion_mode(ic, pc, rc) != 0 ? 1 : 0;
 }
 
 extern "C" int jm_attention_fusion_forward(int b, int n, int ic, int pc, int rc, int oc, const float* img_feats,
@@ -155,7 +169,7 @@ extern "C" int jm_attention_fusion_forward(int b, int n, int ic, int pc, int rc,
     JM_REQUIRE(b >= 0 && n >= 0, "attention_fusion: bad sizes");
     if (b == 0 || n == 0) return JM_OK;
     JM_REQUIRE(jm_attention_fusion_supported(b, n, ic, pc, rc, oc), "attention_fusion: unsupported shape (n %% 32 == 0, "
-               "pad16(ic) + pad16(pc) + pad128(rc) + pad128(pc) channels of a 32-point tile must fit the 160 KB LDS)");
+               "pad16(ic) + pad128(rc) + pad128(pc) channels of a 32-point tile must fit the 160 KB LDS)");
     JM_REQUIRE(img_feats && point_feats && w_fc1 && w_fc2 && b_fc12 && w_fc3 && w_img && b_img && w_fuse_point && w_fuse_img &&
                b_fuse && out, "attention_fusion: null pointer");
     JM_REQUIRE(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(w_fc1) | reinterpret_cast<uintptr_t>(w_fc2) |
@@ -169,7 +183,8 @@ extern "C" int jm_attention_fusion_forward(int b, int n, int ic, int pc, int rc,
     p.W1 = w_fc1; p.W2 = w_fc2; p.Wi = w_img; p.WfP = w_fuse_point; p.WfG = w_fuse_img;
     p.ba = b_fc12; p.bi = b_img; p.bf = b_fuse; p.w3 = w_fc3; p.b3 = b_fc3;
     p.out = out; p.tiles_per_frame = n / 32;
-    const size_t lds_bytes = li_fusion_lds_bytes(ic, pc, rc);
+    p.p_in_lds = li_fusion_mode(ic, pc, rc) == 1;
+    const size_t lds_bytes = li_fusion_lds_bytes(ic, pc, rc, p.p_in_lds != 0);
     (void)hipFuncSetAttribute((const void*)attention_fusion_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL(attention_fusion_kernel, dim3((unsigned)(b * (n / 32))), dim3(256), lds_bytes, (hipStream_t)stream, p);
     return check_launch("attention_fusion");

@@ -29,7 +29,7 @@ import torch.nn.functional as F
 from .ops import proposal as proposal_ops
 from .ops.affinity import make_affinity_mlp, pairwise_affinity
 from .ops.detections import DetectionCache, decode_rcnn_boxes, select_detections
-from .ops.fusion import PackedAttentionFusion, PackedImageFusion, feature_gather
+from .ops.fusion import PackedAttentionFusion, PackedImageFusion, bias_relu_, feature_gather
 from .ops.pointnet2 import pytorch_utils as pt_utils
 from .ops.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModule, PointnetSAModuleMSG
 from .ops.pointnet2.pyramid import FpsPyramid, side_stream
@@ -358,7 +358,7 @@ class DetectAffinityEngine(nn.Module):
         with torch.cuda.stream(img_stream):
             cur = image.contiguous(memory_format=torch.channels_last)
             for i, blk in enumerate(net.Img_Block):
-                cur = self._t(f"image_block_{i + 1}(MIOpen)", 0, lambda b=blk, c=cur: b(c))
+                cur = self._t(f"image_block_{i + 1}(MIOpen)", 0, lambda k=i, c=cur: self._image_block(k, c))
                 ev = torch.cuda.Event()
                 ev.record(img_stream)
                 cur.record_stream(main)
@@ -407,6 +407,20 @@ class DetectAffinityEngine(nn.Module):
             img_stream.wait_stream(main)     # image buffers are not recycled under the main stream's readers
         pyr.release()
         return out
+
+    def _image_block(self, i: int, x: torch.Tensor) -> torch.Tensor:
+        """BasicBlock (backbone.py:16-32) with the eval-mode BatchNorm folded into conv1: conv3x3 (MIOpen) ->
+        + bias, ReLU in one in-place pass -> conv3x3 stride 2 (MIOpen)"""
+        blk = self.rpn.backbone_net.Img_Block[i]
+
+        def make():
+            bn = blk.bn1
+            scale = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+            W = (blk.conv1.weight.detach() * scale[:, None, None, None]).contiguous(memory_format=torch.channels_last)
+            return W, (bn.bias.detach() - bn.running_mean.detach() * scale).contiguous()
+        W, b = self._wb(f"img_block{i}", make)
+        y = F.conv2d(x, W, None, stride=1, padding=1)
+        return blk.conv2(bias_relu_(y, b))
 
     def _image_fusion_map(self, img_maps: List[torch.Tensor]) -> torch.Tensor:
         """relu(bn(conv1x1(cat_i deconv_i(img_i)))) (backbone.py:187-193).  The 1x1 fusion convolution is linear,

@@ -162,3 +162,15 @@ class PackedImageFusion:
                                            L.dev(xy, _f32, "xy"), ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(base),
                                            ws_bytes, L.stream_ptr()), "image_fusion_gather")
         return out
+
+
+@torch.no_grad()
+def bias_relu_(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """x (B, C, H, W) channels-last, in place: relu(x + bias[c]) in ONE pass (csrc/elementwise.hip)"""
+    import ctypes
+    if not (x.is_cuda and x.dtype == _f32 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % 4 == 0):
+        return torch.relu_(x.add_(bias.view(1, -1, 1, 1)))
+    b = bias.detach().to(_f32).contiguous()
+    L.check(L.load().jm_bias_relu_channels_last(x.numel(), x.shape[1], ctypes.c_void_p(x.data_ptr()), L.dev(b, _f32, "bias"),
+                                                L.stream_ptr()), "bias_relu")
+    return x

@@ -149,8 +149,10 @@ def test_li_fusion_blocks_match_reference_forward():
         x = torch.from_numpy(gd["image"])
         maps = []
         for i, blk in enumerate(net.Img_Block):
+            folded = eng._image_block(i, x.contiguous(memory_format=torch.channels_last))   # BatchNorm folded into conv1
             x = blk(x.contiguous(memory_format=torch.channels_last))
             assert torch.allclose(x, torch.from_numpy(gd[f"img{i + 1}"]), atol=2e-5), i
+            assert torch.allclose(folded, torch.from_numpy(gd[f"img{i + 1}"]), atol=2e-5), i
             maps.append(torch.from_numpy(gd[f"img{i + 1}"]))
         fused = eng._image_fusion_map(maps)
         assert torch.allclose(fused, torch.from_numpy(gd["fused_map"]), atol=2e-5)

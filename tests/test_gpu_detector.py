@@ -360,6 +360,10 @@ def test_li_fusion_blocks_on_gpu_vs_reference_golden():
             close(got[..., :29], gd[f"fusion{i}_out"])
         from jmodt_amd.ops.fusion import feature_gather
         close(feature_gather(T(gd["fused_map"]), T(gd["xy"])), gd["gathered"], 1e-5)
+        x = T(gd["image"]).contiguous(memory_format=torch.channels_last)
+        for i in range(4):                                  # BasicBlock with folded BatchNorm + the one-pass bias/ReLU kernel
+            x = eng._image_block(i, x)
+            close(x, gd[f"img{i + 1}"])
 
 
 @pytest.mark.parametrize("full,B,N,H,W", [(False, 2, 1000, 32, 64), (False, 1, 37, 48, 160), (True, 1, 16384, 384, 1280)])
