@@ -242,6 +242,20 @@ int jm_feature_gather(int b, int c, int h, int w, int n, const float* fmap, int6
 int jm_feature_gather_grad(int b, int c, int h, int w, int n, const float* grad_out, const float* xy,
                            float* grad_fmap, int64_t sb, int64_t sc, int64_t sh, int64_t sw, jm_stream_t stream);
 
+/* The RCNN stage's per-point input MLP (jmodt/detection/modeling/rcnn.py:176-184): pts (R, S, K + C) pooled RoI
+ * points [K geometric channels = xyz, mask, depth | C RPN feature channels] ->
+ *   h1 = relu(W_up1 x_K + b);  h2 = relu(W_up2 h1 + b);  m = relu(W_merge [h2 | rpn] + b)          (xyz_up + merge_down)
+ * out (R, h_m, S).  With h_out > 0 the first set-abstraction layer (linear part, hoisted in front of its gather, see
+ * jm_sa_mlp_forward_pre) follows in the same launch: out = u = w_out_m m + w_out_x x_K + b_out, (R, h_out, S).
+ * One launch on 32-point tiles instead of 2 transposes + cat + 3 convolutions over (R, 128..256, S) tensors.
+ * All matrices / biases in the layout of jm_sa_mlp_pack(cout, cin, 0); w_merge split column-wise into its h2 and C
+ * parts; widths <= 128, S % 32 == 0, 3 <= K <= 16. */
+int jm_rcnn_lift_supported(int s, int k, int c, int h1, int h2, int hm, int ho);
+int jm_rcnn_lift_forward(int r, int s, int k, int c, int h1, int h2, int hm, int ho, const float* pts, const float* w_up1,
+                         const float* b_up1, const float* w_up2, const float* b_up2, const float* w_merge_h,
+                         const float* w_merge_f, const float* b_merge, const float* w_out_m, const float* w_out_x,
+                         const float* b_out, float* out, jm_stream_t stream);
+
 /* x = relu(x + bias[c]) in place on CHANNELS-LAST data (numel = pixels * channels, channels % 4 == 0): the one
  * element-wise pass of the image branch's BasicBlock (backbone.py:16-32) once its eval-mode BatchNorm is folded into
  * the first convolution (replaces a BatchNorm pass + a ReLU pass over up to 1 GB). */

@@ -30,10 +30,12 @@ from .ops import proposal as proposal_ops
 from .ops.affinity import make_affinity_mlp, pairwise_affinity
 from .ops.detections import DetectionCache, decode_rcnn_boxes, select_detections
 from .ops.fusion import PackedAttentionFusion, PackedImageFusion, bias_relu_, feature_gather
+from .ops.pointnet2 import fused, pointnet2_utils
 from .ops.pointnet2 import pytorch_utils as pt_utils
 from .ops.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModule, PointnetSAModuleMSG
 from .ops.pointnet2.pyramid import FpsPyramid, side_stream
 from .profile import prof
+from .ops.rcnn_lift import PackedRcnnLift
 from .ops.roipool3d.roipool3d_utils import roipool3d_canonical_gpu
 
 
@@ -269,6 +271,7 @@ class DetectAffinityEngine(nn.Module):
         self.overlap = True                # FPS pyramid + image branch on side streams
         self.last_fps_idx: List[torch.Tensor] = []
         self.sparse_image_fusion = True    # final image feature only under the bilinear taps (else dense deconvolutions)
+        self.fuse_rcnn_lift = True         # xyz_up + merge_down (+ hoisted first SA layer) as one kernel
         self.fuse_attention = True         # LI-Fusion attention block as one kernel where it fits (else rocBLAS GEMMs)
         self._prefetched = None
 
@@ -527,11 +530,37 @@ class DetectAffinityEngine(nn.Module):
             m = torch.addmm(bm, h, Wm[:, :c_up].t())
             m = torch.addmm(m, rows[:, k:], Wm[:, c_up:].t())  # merge_down on [xyz_feature | rpn_feature] without the cat
             return torch.relu_(m).view(R, S, -1).transpose(1, 2).contiguous()       # (R, C, S) for the SA kernels
-        flops = 2 * R * S * (sum(W.numel() for W, _ in up) + Wm.numel())
-        feats = self._t("rcnn_xyz_lift+merge(rocBLAS)", 0, lift, flops=flops)
         xyz = pts_input[:, :, 0:3].contiguous()
-        l_xyz, l_feats = xyz, feats
+        sa1 = net.SA_modules[0]
+        lifted = None
+        if self.fuse_rcnn_lift and pts_input.is_cuda and len(up) == 2 and sa1.fuse:
+            # one kernel for xyz_up + merge_down (+ the first SA layer hoisted in front of its gather)
+            def make():
+                g0 = sa1.groupers[0]
+                hoist = None
+                if isinstance(g0, pointnet2_utils.QueryAndGroup) and len(sa1.groupers) == 1 and g0.use_xyz and sa1.npoint:
+                    hoist = fused.hoistable_first_layer(sa1.mlps[0], sa1.npoint, g0.nsample, pts_input.device)
+                return PackedRcnnLift(up, (Wm, bm), hoist)
+            packed = self._wb("rcnn_lift", make)
+            if packed.supported(S):
+                lifted = packed
+        l_xyz, first = xyz, 0
+        if lifted is not None and lifted.ho:
+            u = lifted(pts_input)                                                      # (R, H1, S)
+            with prof.scope("rcnn_sa1"):
+                _, new_xyz = pointnet2_utils.farthest_point_sample_xyz(xyz, sa1.npoint)
+                g0 = sa1.groupers[0]
+                nb = pointnet2_utils.ball_query(g0.radius, g0.nsample, xyz, new_xyz)
+                l_feats = fused.sa_mlp_pre_from_u(u, new_xyz, nb, sa1.mlps[0])
+            l_xyz, first = new_xyz, 1
+        elif lifted is not None:
+            l_feats = lifted(pts_input)
+        else:
+            flops = 2 * R * S * (sum(W.numel() for W, _ in up) + Wm.numel())
+            l_feats = self._t("rcnn_xyz_lift+merge(rocBLAS)", 0, lift, flops=flops)
         for i, sa in enumerate(net.SA_modules):
+            if i < first:
+                continue
             with prof.scope(f"rcnn_sa{i + 1}"):
                 l_xyz, l_feats, _ = sa(l_xyz, l_feats)
         rcnn_cls, rcnn_reg = self._t("rcnn_heads(rocBLAS)", 0, lambda: (

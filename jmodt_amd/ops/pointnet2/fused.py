@@ -144,6 +144,36 @@ def _can_pre_project(mlp: nn.Sequential, features, idx, M: int, ns: int) -> bool
 
 
 @torch.no_grad()
+def sa_mlp_pre_from_u(u: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, mlp: nn.Sequential) -> torch.Tensor:
+    """layers 2..L + max-pool of a set-abstraction scale whose hoisted first layer u = W1 [xyz | f] + b1 (B, H1, N) was
+    computed by the producer of the features (ops/rcnn_lift.py): -> (B, mlp_out, M)"""
+    lib = L.load()
+    W1, b1, w1x, packed = _pre_layers(mlp, u.device)
+    B, H1, N = u.shape
+    M, ns = idx.shape[1], idx.shape[2]
+    widths = [H1] + [cout for _, _, cout, _ in packed]
+    nl = len(packed)
+    out = torch.empty((B, widths[-1], M), dtype=_f32, device=u.device)
+    warr = (ctypes.c_void_p * nl)(*[wp.data_ptr() for wp, _, _, _ in packed])
+    barr = (ctypes.c_void_p * nl)(*[bp.data_ptr() for _, bp, _, _ in packed])
+    widths_c = (ctypes.c_int * (nl + 1))(*widths)
+    L.check(lib.jm_sa_mlp_forward_pre(B, N, M, H1, ns, L.dev(u.contiguous(), _f32, "u"), L.dev(w1x, _f32, "w1x"),
+                                      L.dev(new_xyz.contiguous(), _f32, "new_xyz"), L.dev(idx, _i32, "idx"), nl, widths_c, warr,
+                                      barr, ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "sa_mlp_fused(pre)")
+    return out
+
+
+def hoistable_first_layer(mlp: nn.Sequential, npoint: int, nsample: int, device):
+    """(W1 (H1, 3 + C), b1) when the scale qualifies for the pre-projected kernel, else None"""
+    shapes = _layer_shapes(mlp)
+    if (not PRE_PROJECT or not shapes or len(shapes) < 2 or len(shapes) > 4 or shapes[0][0] % 16 or shapes[0][0] > 128
+            or any(c > 128 for c, _ in shapes[:-1]) or nsample not in (16, 32, 64) or (npoint * nsample) % 128):
+        return None
+    W1, b1, _, _ = _pre_layers(mlp, device)
+    return W1, b1
+
+
+@torch.no_grad()
 def _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp):
     """QueryAndGroup + SharedMLP + max-pool with the first layer hoisted in front of the gather: W1 [xyz_j - c_i | f_j] + b1
     = u_j - W1x c_i with u = W1 [xyz | f] + b1 per point (two small batched GEMMs accumulating into one tensor); the

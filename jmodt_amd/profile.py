@@ -102,6 +102,10 @@ ALGO: Dict[str, Callable] = {
     "jm_image_fusion_gather": lambda a: (
         _i(a, 0) * _i(a, 1) * 4 * 4 * sum(int(a[6][k]) for k in range(_i(a, 5))) + _i(a, 0) * _i(a, 1) * _i(a, 4) * 4,
         2 * _i(a, 0) * _i(a, 1) * 4 * 32 * sum(int(a[6][k]) for k in range(_i(a, 5))), {}),
+    "jm_rcnn_lift_forward": lambda a: (
+        _i(a, 0) * _i(a, 1) * 4 * (_i(a, 2) + _i(a, 3) + (_i(a, 7) or _i(a, 6))),
+        2 * _i(a, 0) * _i(a, 1) * (_i(a, 2) * _i(a, 4) + _i(a, 4) * _i(a, 5) + (_i(a, 5) + _i(a, 3)) * _i(a, 6)
+                                   + (_i(a, 6) + 3) * _i(a, 7)), {}),
     "jm_bias_relu_channels_last": lambda a: (8 * _i(a, 0), 0, {}),
     "jm_affinity_forward": _affinity,
     "jm_affinity_start_end": lambda a: (0, _mlp3_flops(_i(a, 0) + _i(a, 1), _mlp3(a[4])), {}),

@@ -403,3 +403,40 @@ def test_sparse_image_fusion_gather_vs_dense(full, B, N, H, W):
     assert torch.equal(got, again)                     # deterministic whatever order the phase sort produced
     out_of_canvas = (xy.abs() > 1.0 + 2.0 / (min(H, W) - 1) + 1e-3).any(dim=2)     # more than one pixel outside
     assert out_of_canvas.any() and (got.transpose(1, 2)[out_of_canvas].abs().max().item() == 0.0)
+
+
+def test_rcnn_lift_kernel_and_hoisted_first_layer(run):
+    """csrc/rcnn_lift.hip (xyz_up + merge_down + hoisted first SA layer in one launch) vs the rocBLAS route and vs the
+    kernel without hoisting, on the run's pooled RoI points; plus the full-size widths on random rows"""
+    eng = run["eng"]
+    pts = run["inter"]["pts_input"]
+    with torch.no_grad():
+        a = eng.rcnn_forward(pts)
+        assert eng._folded["rcnn_lift"].ho > 0
+        eng.fuse_rcnn_lift = False
+        try:
+            b = eng.rcnn_forward(pts)
+        finally:
+            eng.fuse_rcnn_lift = True
+    for k in ("rcnn_feat", "rcnn_cls", "rcnn_reg"):
+        close(a[k], b[k])
+    # full-size widths (5 -> 128 -> 128, merge 256 -> 128, hoisted 131 -> 128), 512 points per RoI
+    from jmodt_amd.ops.rcnn_lift import PackedRcnnLift
+    g = torch.Generator().manual_seed(3)
+    R, S, C = 9, 512, 128
+    mk = lambda o, i: (torch.randn(o, i, generator=g) * (2.0 / i) ** 0.5).to(DEV)   # noqa: E731
+    bias = lambda o: (torch.randn(o, generator=g) * 0.1).to(DEV)                    # noqa: E731
+    up = [(mk(128, 5), bias(128)), (mk(128, 128), bias(128))]
+    merge = (mk(128, 256), bias(128))
+    W1, b1 = mk(128, 131), bias(128)
+    x = torch.randn(R, S, 5 + C, generator=g).to(DEV)
+    with torch.no_grad():
+        rows = x.view(R * S, -1).double()
+        h = torch.relu(rows[:, :5] @ up[0][0].double().t() + up[0][1].double())
+        h = torch.relu(h @ up[1][0].double().t() + up[1][1].double())
+        m = torch.relu(torch.cat([h, rows[:, 5:]], 1) @ merge[0].double().t() + merge[1].double())
+        u = torch.cat([rows[:, :3], m], 1) @ W1.double().t() + b1.double()
+        got_m = PackedRcnnLift(up, merge)(x)
+        got_u = PackedRcnnLift(up, merge, (W1, b1))(x)
+    close(got_m, m.view(R, S, -1).transpose(1, 2))
+    close(got_u, u.view(R, S, -1).transpose(1, 2))
