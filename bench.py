@@ -90,7 +90,15 @@ def cpu_baseline_detect(frames=2):
     with torch.no_grad():
         chain.forward(xyz, img, xy)
     dt = time.perf_counter() - t0
-    return frames / dt, dt
+    # BASELINE configs[0] on its own: the link / start-end head on 64 cached proposal features, PyTorch-CPU
+    f64 = torch.relu(torch.randn(2, 64, cfg.rcnn_sa_mlps[-1][-1]))
+    with torch.no_grad():
+        chain.affinity(f64[0], f64[1])
+        t1 = time.perf_counter()
+        for _ in range(3):
+            chain.affinity(f64[0], f64[1])
+        aff64 = (time.perf_counter() - t1) / 3
+    return frames / dt, dt, chain.stage_seconds, aff64
 
 
 # ---------------------------------------------------------------------------------------------- sa
@@ -315,8 +323,12 @@ def pick_roofline(kernels, traffic_json):
     if "mfma_frac" in dom:
         return {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved_tflops"], "peak": MFMA_F32_PEAK_TF,
                 "unit": "TFLOP/s", "frac": dom["mfma_frac"], "traffic": traffic,
-                "basis": "algorithmic flops 2*rows*sum(c_in*c_out) of the fused MLP (SURVEY.md §8d), time = HIP events "
-                         "around the entry point on its launch stream inside the timed region (includes launch gaps)"}
+                "basis": "algorithmic flops 2*rows*sum(c_in*c_out) of the WHOLE set-abstraction MLP (SURVEY.md §8d: 831 GFLOP for "
+                         "RCNN SA1 per 1024 RoIs); time = HIP events around the entry point on its launch stream inside the "
+                         "timed region (includes launch gaps).  The first layer is hoisted in front of the gather (per-point "
+                         "GEMM elsewhere), so the kernel EXECUTES fewer flops than that: see executed_frac",
+                **({"executed_tflops": round(dom["executed_flops_per_step"] / (dom["ms_per_step"] * 1e-3) / 1e12, 2),
+                    "executed_frac": dom["executed_mfma_frac"]} if "executed_flops_per_step" in dom else {})}
     r = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": dom["hbm_frac"], "traffic": traffic, "measured_copy_ceiling_gbs": HBM_COPY_CEILING_GBS,
          "basis": "algorithmic bytes per SURVEY.md §8(d) (FPS: streaming-equivalent B*m*20n — latency/VALU-bound, "
@@ -463,8 +475,10 @@ def main():
         if not args.no_cpu_baseline and world == 1 and not args.tiny and args.workload in ("detect", "sa"):
             cores = torch.get_num_threads()
             try:
+                extra = {}
                 if args.workload == "detect":
-                    fps, dt = cpu_baseline_detect(2)
+                    fps, dt, stages, aff64 = cpu_baseline_detect(2)
+                    extra = {"stage_seconds": stages, "configs0_affinity_64x64_pytorch_cpu_ms": round(aff64 * 1e3, 2)}
                     sample = (f"2 full-size frames (one (prev, next) pair) through the chained CPU oracle in {dt:.1f} s: "
                               "oracle C restatement for the jmodt ops (the reference has no CPU code for them), the "
                               "same PyTorch-CPU operators the reference calls for conv / BN / Linear / grid_sample / "
@@ -474,7 +488,8 @@ def main():
                     sample = (f"one batch of {args.batch} frames of the same workload ({dt:.1f} s), oracle C restatement "
                               "with OpenMP over batch/centres (the reference has no CPU code for these ops)")
                     cores = os.cpu_count()
-                result["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample}
+                result["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample,
+                                          **extra}
             except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
                 result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": cores, "kind": "port", "sample": f"failed: {ex!r}"}
         print(json.dumps(result))

@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib as L
+from ...profile import prof
 
 _f32, _i32 = torch.float32, torch.int32
 
@@ -153,6 +154,7 @@ def sa_mlp_pre_from_u(u: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor,
     M, ns = idx.shape[1], idx.shape[2]
     widths = [H1] + [cout for _, _, cout, _ in packed]
     nl = len(packed)
+    prof.hoisted_flops(2 * B * M * ns * H1 * W1.shape[1])     # the first layer's per-row work this form avoids
     out = torch.empty((B, widths[-1], M), dtype=_f32, device=u.device)
     warr = (ctypes.c_void_p * nl)(*[wp.data_ptr() for wp, _, _, _ in packed])
     barr = (ctypes.c_void_p * nl)(*[bp.data_ptr() for _, bp, _, _ in packed])
@@ -188,6 +190,7 @@ def _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp):
     u = torch.baddbmm(u, W1[:, :3].expand(B, -1, -1), xyz.transpose(1, 2))            # (B, H1, N)
     widths = [H1] + [cout for _, _, cout, _ in packed]
     nl = len(packed)
+    prof.hoisted_flops(2 * B * M * ns * H1 * W1.shape[1])     # the first layer's per-row work this form avoids
     out = torch.empty((B, widths[-1], M), dtype=_f32, device=xyz.device)
     warr = (ctypes.c_void_p * nl)(*[wp.data_ptr() for wp, _, _, _ in packed])
     barr = (ctypes.c_void_p * nl)(*[bp.data_ptr() for _, bp, _, _ in packed])

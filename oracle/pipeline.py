@@ -215,17 +215,27 @@ class Chain:
 
     # ---- whole path (free running: every stage consumes the oracle's own previous stage) ---------------
     def forward(self, xyz: np.ndarray, image: np.ndarray, pts_xy: np.ndarray):
+        import time
         cfg = self.cfg
+        t = [time.perf_counter()]
         r = self.rpn(xyz, image, pts_xy)
+        t.append(time.perf_counter())
         rpn_cls, rpn_reg = _np(r["rpn_cls"]).astype(np.float32), _np(r["rpn_reg"]).astype(np.float32)
         rois, roi_scores = self.proposals(rpn_cls, rpn_reg, xyz)
+        t.append(time.perf_counter())
         pts_input, _ = self.roi_pool(xyz, rpn_cls, _np(r["backbone_features"]).astype(np.float32), rois)
+        t.append(time.perf_counter())
         out = self.rcnn(pts_input)
+        t.append(time.perf_counter())
         B, M = rois.shape[:2]
         boxes = orc.decode_rcnn_boxes(rois.reshape(-1, 7), _np(out["rcnn_reg"]).astype(np.float32), cfg.rcnn_loc_scope,
                                       cfg.rcnn_loc_bin_size, cfg.rcnn_num_head_bin, cfg.mean_size).reshape(B, M, 7)
         raw = _np(out["rcnn_cls"]).astype(np.float32).reshape(B, M)
         keep = orc.select_detections(boxes, raw, cfg.rcnn_score_thresh, cfg.rcnn_nms_thresh)
+        t.append(time.perf_counter())
         feats = out["rcnn_feat"].view(B, M, -1)
         aff = [self.affinity(feats[b - 1], feats[b]) for b in range(B)]
+        t.append(time.perf_counter())
+        self.stage_seconds = dict(zip(("backbone+rpn_heads", "proposal_layer", "roipool3d+canonical", "rcnn", "decode+detection_nms",
+                                       "pairwise_affinity"), (round(b - a, 4) for a, b in zip(t[:-1], t[1:]))))
         return dict(r, rois=rois, roi_scores_raw=roi_scores, pts_input=pts_input, pred_boxes3d=boxes, keep=keep, affinity=aff, **out)
