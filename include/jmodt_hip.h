@@ -318,6 +318,17 @@ int jm_affinity_forward(int p, int d, const float* pred_feat, const float* det_f
                         const jm_mlp3_t* se, float* link_raw, float* link_out, float* start, float* end, void* ws,
                         size_t ws_bytes, jm_stream_t stream);
 
+/* Batched forms: nb independent (P, D) problems stacked on the leading axis — pred_feat (nb, P, C), det_feat (nb, D, C) ->
+ * link_raw / link (nb, P, D), se_out (nb, D + P) = per problem [start logits (D) | end logits (P)].  The detector scores
+ * every frame of a batch against its predecessor (tracker.py:81-112 per frame pair): one GEMM chain over nb*P*D pair
+ * rows instead of nb chains. */
+size_t jm_affinity_batched_workspace_bytes(int nb, int p, int d, const jm_mlp3_t* link);
+int jm_affinity_forward_batched(int nb, int p, int d, const float* pred_feat, const float* det_feat, const jm_mlp3_t* link,
+                                float* link_raw, float* link_out, void* ws, size_t ws_bytes, jm_stream_t stream);
+size_t jm_affinity_start_end_batched_workspace_bytes(int nb, int p, int d, const jm_mlp3_t* se);
+int jm_affinity_start_end_batched(int nb, int p, int d, const float* pred_feat, const float* det_feat, const jm_mlp3_t* se,
+                                  float* se_out, void* ws, size_t ws_bytes, jm_stream_t stream);
+
 /* The same MLP on plain rows x (M,C) -> y (M): used for the start/end features and exposed for
  * callers that hold a materialised feature matrix (rcnn.py:272-285). */
 size_t jm_mlp3_workspace_bytes(int m, const jm_mlp3_t* mlp);

@@ -48,6 +48,8 @@ struct GemmParams {
     const float* pf;  // (P,K) and (D,K), row m -> (m / D, m % D)   [AMODE 1]
     const float* df;
     int D;
+    int PD;             // 0: one (P, D) problem.  P*D: a BATCH of problems stacked on the row axis, pf (nb*P, K), df (nb*D, K):
+                        // row m -> problem m / PD, pred row m / D (already batch-global), det row (m / PD) * D + m % D
     const float* W;     // (N,K) row-major (Conv1d weight (N,K,1))
     const float* bias;  // (N)
     float* H;           // (M,N) output, ReLU applied            [EMODE 0]
@@ -95,7 +97,8 @@ mlp_gemm_kernel(GemmGroup grp) {
             a2_ptr[i] = a_ptr[i];
         } else {
             const int mm = a_ok[i] ? m : 0;
-            const int pi = mm / p.D, di = mm - pi * p.D;
+            const int pi = mm / p.D;
+            const int di = mm - pi * p.D + (p.PD ? (mm / p.PD) * p.D : 0);
             a_ptr[i] = p.pf + (size_t)pi * p.K + skq[i];
             a2_ptr[i] = p.df + (size_t)di * p.K + skq[i];
         }
@@ -216,7 +219,8 @@ mlp_gemm_small_kernel(GemmParams p) {
     const int row = min(m0 + r, p.M - 1), col = min(n0 + r, p.N - 1);
     const float *a_ptr, *a2_ptr;
     if (pair_mode) {
-        const int pi = row / p.D, di = row - pi * p.D;
+        const int pi = row / p.D;
+        const int di = row - pi * p.D + (p.PD ? (row / p.PD) * p.D : 0);
         a_ptr = p.pf + (size_t)pi * p.K + 4 * h;
         a2_ptr = p.df + (size_t)di * p.K + 4 * h;
     } else {
@@ -284,6 +288,7 @@ __global__ void __launch_bounds__(256)
 se_feature_kernel(int P, int D, int C, const float* __restrict__ pf, const float* __restrict__ df,
                   float* __restrict__ feat) {
     const int row = blockIdx.x;
+    pf += (size_t)blockIdx.y * P * C; df += (size_t)blockIdx.y * D * C; feat += (size_t)blockIdx.y * (P + D) * C;   // problem
     for (int k = threadIdx.x; k < C; k += blockDim.x) {
         float acc = 0.f;
         if (row < D) {
@@ -306,6 +311,7 @@ __global__ void __launch_bounds__(256)
 softmax_stats_kernel(int P, int D, const float* __restrict__ S, float* __restrict__ stats) {
     __shared__ float red[4];
     const int blk = blockIdx.x;
+    S += (size_t)blockIdx.y * P * D; stats += (size_t)blockIdx.y * 2 * (P + D);   // problem
     const bool is_row = blk < P;
     const int len = is_row ? D : P;
     const size_t base = is_row ? (size_t)blk * D : (size_t)(blk - P);
@@ -333,6 +339,7 @@ dual_softmax_kernel(int P, int D, const float* __restrict__ S, const float* __re
                     float* __restrict__ A) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P * D) return;
+    S += (size_t)blockIdx.y * P * D; A += (size_t)blockIdx.y * P * D; stats += (size_t)blockIdx.y * 2 * (P + D);   // problem
     const int i = e / D, j = e - i * D;
     const float s = S[e];
     const float r = expf(s - stats[2 * i]) / stats[2 * i + 1];
@@ -357,6 +364,7 @@ struct MlpJob {
     const jm_mlp3_t* mlp;
     float* hidden;         // (M,H1) scratch
     float* y;              // (M) output
+    int PD = 0;            // batched pair mode: P * D (see GemmParams)
 };
 
 static int tiles_of(int M, int N) { return divup(M, BM) * divup(N, BN); }
@@ -369,7 +377,7 @@ static int run_mlps(const MlpJob* jobs, int njobs, hipStream_t s) {
         const MlpJob& jb = jobs[j];
         GemmParams& a = g1.p[j];
         a.M = jb.M; a.N = jb.mlp->h1; a.K = jb.mlp->c;
-        a.A = jb.x; a.pf = jb.x ? nullptr : jb.pf; a.df = jb.df; a.D = jb.D;
+        a.A = jb.x; a.pf = jb.x ? nullptr : jb.pf; a.df = jb.df; a.D = jb.D; a.PD = jb.PD;
         a.W = jb.mlp->w1; a.bias = jb.mlp->b1; a.H = jb.hidden;
         GemmParams& b = g2.p[j];
         b.M = jb.M; b.N = jb.mlp->h2; b.K = jb.mlp->h1;
@@ -435,6 +443,75 @@ extern "C" size_t jm_affinity_workspace_bytes(int p, int d, const jm_mlp3_t* lin
     if (se) b += align_up(r * se->c * sizeof(float), 256) + align_up(r * se->h1 * sizeof(float), 256) +
                  align_up(r * sizeof(float), 256);
     return b;
+}
+
+// ---------------------------------------------------------------- batched forms: nb independent (P, D) problems
+// (the detector scores every frame of a batch against its predecessor: 8 x 128^2 pair rows become ONE GEMM chain of
+// 131072 rows instead of 8 chains of 16384 — one launch per layer, full waves of workgroups, no per-call tails)
+extern "C" size_t jm_affinity_batched_workspace_bytes(int nb, int p, int d, const jm_mlp3_t* link) {
+    if (nb <= 0 || p <= 0 || d <= 0 || !link) return 0;
+    const size_t pd = (size_t)nb * p * d, r = (size_t)nb * ((size_t)p + d);
+    return align_up(pd * link->h1 * sizeof(float), 256) + align_up(pd * sizeof(float), 256) + align_up(2 * r * sizeof(float), 256);
+}
+
+extern "C" int jm_affinity_forward_batched(int nb, int p, int d, const float* pred_feat, const float* det_feat,
+                                           const jm_mlp3_t* link, float* link_raw, float* link_out, void* ws, size_t ws_bytes,
+                                           jm_stream_t stream) {
+    JM_REQUIRE(nb >= 0 && p >= 0 && d >= 0, "affinity_batched: bad sizes");
+    if (nb == 0 || p == 0 || d == 0) return JM_OK;
+    int rc = check_mlp(link, "affinity link_layer");
+    if (rc) return rc;
+    JM_REQUIRE(pred_feat && det_feat && ws && (link_raw || link_out), "affinity_batched: null pointer");
+    JM_REQUIRE(((reinterpret_cast<uintptr_t>(pred_feat) | reinterpret_cast<uintptr_t>(det_feat)) & 15u) == 0,
+               "affinity: features must be 16-byte aligned");
+    JM_REQUIRE((long long)nb * p * d < (1LL << 31) && nb <= 65535, "affinity_batched: too many pairs");
+    if (ws_bytes < jm_affinity_batched_workspace_bytes(nb, p, d, link)) { set_error("affinity_batched: workspace too small"); return JM_EWORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t pd = (size_t)nb * p * d, r = (size_t)nb * ((size_t)p + d);
+    char* w = (char*)ws;
+    float* hidden = (float*)w; w += align_up(pd * link->h1 * sizeof(float), 256);
+    float* sraw = (float*)w;   w += align_up(pd * sizeof(float), 256);
+    float* stats = (float*)w;
+    float* S = link_raw ? link_raw : sraw;
+    MlpJob lj{(int)pd, nullptr, pred_feat, det_feat, d, link, hidden, S};
+    lj.PD = p * d;
+    rc = run_mlps(&lj, 1, s);
+    if (rc) return rc;
+    if (link_out) {
+        hipLaunchKernelGGL(softmax_stats_kernel, dim3((unsigned)(p + d), (unsigned)nb), dim3(256), 0, s, p, d, S, stats);
+        hipLaunchKernelGGL(dual_softmax_kernel, dim3(divup(p * d, 256), (unsigned)nb), dim3(256), 0, s, p, d, S, stats, link_out);
+    }
+    (void)r;
+    return check_launch("affinity_batched");
+}
+
+extern "C" size_t jm_affinity_start_end_batched_workspace_bytes(int nb, int p, int d, const jm_mlp3_t* se) {
+    if (nb <= 0 || p <= 0 || d <= 0 || !se) return 0;
+    const size_t r = (size_t)nb * ((size_t)p + d);
+    return align_up(r * se->c * sizeof(float), 256) + align_up(r * se->h1 * sizeof(float), 256);
+}
+
+/* se_out (nb, D + P): per problem [start logits (D) | end logits (P)] */
+extern "C" int jm_affinity_start_end_batched(int nb, int p, int d, const float* pred_feat, const float* det_feat,
+                                             const jm_mlp3_t* se, float* se_out, void* ws, size_t ws_bytes,
+                                             jm_stream_t stream) {
+    JM_REQUIRE(nb >= 0 && p >= 0 && d >= 0 && nb <= 65535, "affinity start/end batched: bad sizes");
+    if (nb == 0 || p == 0 || d == 0) return JM_OK;
+    int rc = check_mlp(se, "affinity se_layer");
+    if (rc) return rc;
+    JM_REQUIRE(pred_feat && det_feat && se_out && ws, "affinity start/end batched: null pointer");
+    if (ws_bytes < jm_affinity_start_end_batched_workspace_bytes(nb, p, d, se)) { set_error("affinity start/end batched: workspace too small"); return JM_EWORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t r = (size_t)nb * ((size_t)p + d);
+    JM_REQUIRE(r < (1ULL << 31), "affinity start/end batched: too many rows");
+    char* w = (char*)ws;
+    float* feat = (float*)w;  w += align_up(r * se->c * sizeof(float), 256);
+    float* sehid = (float*)w;
+    hipLaunchKernelGGL(se_feature_kernel, dim3((unsigned)(p + d), (unsigned)nb), dim3(256), 0, s, p, d, se->c, pred_feat, det_feat, feat);
+    const MlpJob sj{(int)r, feat, nullptr, nullptr, 1, se, sehid, se_out};
+    rc = run_mlps(&sj, 1, s);
+    if (rc) return rc;
+    return check_launch("affinity start/end batched");
 }
 
 // workspace: [se feat (D+P,C)] [se hidden (D+P,H1)] [se logit (D+P)]

@@ -58,6 +58,7 @@ struct SaMlpParams {
     float* out;                      // (B, cout, M)
     int cout;
     int tiles_per_frame, total_tiles, xcd_frames;
+    int dbg;                         // tools build only (JM_SA_DBG): timing experiments, results are wrong when set
 };
 
 // packed layout: Wp[kt][n][khalf][kk] = W'[n][16 kt + 2 kk + khalf]   (kt < Kp/16, n < Np, khalf < 2, kk < 8)
@@ -188,7 +189,10 @@ __device__ __forceinline__ void sa_gather_role(const SaMlpParams& p, float* lds,
 #pragma unroll
         for (int grp = 0; grp < SM_GRP; ++grp) {
             if (g0 + grp < nfast) {
-                if (pre) {
+                if (pre && p.dbg == 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) Gt[2 * (grp * 8 + j) * SM_LDP] = g[grp * 8 + j];
+                } else if (pre) {
                     // channel (wave-uniform) -> its three xyz weights by scalar loads; value = relu(u_j - W1x . c_i)
                     const float* wv = p.w1x + ((size_t)(g0 + grp) * 16 + gk0) * 4;
 #pragma unroll
@@ -534,6 +538,7 @@ static int sa_mlp_narrow_launch(int b, int n, int m, int c, int nsample, const f
     JM_REQUIRE(total < (1LL << 31), "sa_mlp: too many tiles");
     p.total_tiles = (int)total;
     p.xcd_frames = b >= 16 ? 1 : 0;
+    p.dbg = tune_env("JM_SA_DBG", 0);
     const int grid = p.xcd_frames ? cus : (int)(total < cus ? total : cus);
     hipLaunchKernelGGL(sa_mlp_kernel, dim3((unsigned)grid), dim3(512), SM_LDS_BYTES, (hipStream_t)stream, p);
     return check_launch("sa_mlp");

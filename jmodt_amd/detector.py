@@ -27,7 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .ops import proposal as proposal_ops
-from .ops.affinity import make_affinity_mlp, pairwise_affinity
+from .ops.affinity import make_affinity_mlp, pairwise_affinity, pairwise_affinity_batched
 from .ops.detections import DetectionCache, decode_rcnn_boxes, select_detections
 from .ops.fusion import PackedAttentionFusion, PackedImageFusion, bias_relu_, feature_gather
 from .ops.pointnet2 import fused, pointnet2_utils
@@ -419,7 +419,7 @@ class DetectAffinityEngine(nn.Module):
         def make():
             bn = blk.bn1
             scale = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
-            W = (blk.conv1.weight.detach() * scale[:, None, None, None]).contiguous(memory_format=torch.channels_last)
+            W = (blk.conv1.weight.detach() * scale[:, None, None, None]).contiguous()   # same layout as the module's parameter
             return W, (bn.bias.detach() - bn.running_mean.detach() * scale).contiguous()
         W, b = self._wb(f"img_block{i}", make)
         y = F.conv2d(x, W, None, stride=1, padding=1)
@@ -595,6 +595,8 @@ class DetectAffinityEngine(nn.Module):
         feats = inter["rcnn_feat"].view(cache.boxes.shape[0], cache.boxes.shape[1], -1)
         B, M, C = feats.shape
         link, se = self.rcnn_net.link_layer, self.rcnn_net.se_layer
-        with prof.scope(f"affinity_{M}x{M}"):
-            aff = [pairwise_affinity(feats[b - 1], feats[b], link, se) for b in range(B)]
+        with prof.scope(f"affinity_{B}x{M}x{M}"):
+            # every frame against its predecessor, all B problems as one GEMM chain (jm_affinity_forward_batched)
+            A, start, end = pairwise_affinity_batched(torch.roll(feats, 1, 0), feats, link, se)
+            aff = [(A[b], start[b], end[b]) for b in range(B)]
         return cache, aff, inter

@@ -122,6 +122,52 @@ def pairwise_affinity(pred_features: torch.Tensor, det_features: torch.Tensor, l
 
 
 @torch.no_grad()
+def pairwise_affinity_batched(pred_features: torch.Tensor, det_features: torch.Tensor, link_model: nn.Sequential,
+                              se_model: Optional[nn.Sequential] = None, return_raw: bool = False,
+                              overlap_start_end: bool = True) -> Tuple[torch.Tensor, ...]:
+    """nb independent problems at once: pred_features (nb, P, C), det_features (nb, D, C) ->
+    link_scores (nb, P, D), start_logits (nb, D), end_logits (nb, P) (+ raw (nb, P, D)): `pairwise_affinity` for every
+    frame pair of a batch as ONE GEMM chain over nb*P*D pair rows (jm_affinity_forward_batched)"""
+    lib = L.load()
+    pf = pred_features.to(_f32).contiguous()
+    df = det_features.to(_f32).contiguous()
+    nb, P, _ = pf.shape
+    D = df.shape[1]
+    dev = pf.device
+    link, keep1 = _pack(link_model)
+    se, keep2 = _pack(se_model) if se_model is not None else (None, [])
+    A = torch.empty((nb, P, D), dtype=_f32, device=dev)
+    raw = torch.empty((nb, P, D), dtype=_f32, device=dev) if return_raw else None
+    se_out = torch.empty((nb, D + P), dtype=_f32, device=dev)
+    main = torch.cuda.current_stream(dev)
+    side = main
+    if se is not None:
+        se_p = ctypes.byref(se)
+        side = side_stream(dev, 2) if overlap_start_end else main
+        se_bytes = lib.jm_affinity_start_end_batched_workspace_bytes(nb, P, D, se_p)
+        se_ws = torch.empty((max(se_bytes, 16),), dtype=torch.uint8, device=dev)
+        if side is not main:
+            side.wait_stream(main)
+            for t in (pf, df, se_out, se_ws, *keep2):
+                t.record_stream(side)
+        with torch.cuda.stream(side):
+            L.check(lib.jm_affinity_start_end_batched(nb, P, D, L.dev(pf, _f32, "pred_features"), L.dev(df, _f32, "det_features"),
+                                                      se_p, ctypes.c_void_p(se_out.data_ptr()), ctypes.c_void_p(se_ws.data_ptr()),
+                                                      se_bytes, L.stream_ptr()), "pairwise_affinity_batched(start/end)")
+    link_p = ctypes.byref(link)
+    ws_bytes = lib.jm_affinity_batched_workspace_bytes(nb, P, D, link_p)
+    ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+    L.check(lib.jm_affinity_forward_batched(nb, P, D, L.dev(pf, _f32, "pred_features"), L.dev(df, _f32, "det_features"), link_p,
+                                            ctypes.c_void_p(raw.data_ptr()) if raw is not None else None,
+                                            ctypes.c_void_p(A.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws_bytes,
+                                            L.stream_ptr()), "pairwise_affinity_batched")
+    if side is not main:
+        main.wait_stream(side)
+    out = (A, se_out[:, :D], se_out[:, D:]) if se_model is not None else (A,)
+    return out + ((raw,) if return_raw else ())
+
+
+@torch.no_grad()
 def mlp3_forward(x: torch.Tensor, head: nn.Sequential) -> torch.Tensor:
     """the same head on materialised rows x (M, C) -> (M)   (e.g. rcnn.py:272-285 start/end features)"""
     lib = L.load()

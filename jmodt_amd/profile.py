@@ -108,6 +108,10 @@ ALGO: Dict[str, Callable] = {
                                    + (_i(a, 6) + 3) * _i(a, 7)), {}),
     "jm_bias_relu_channels_last": lambda a: (8 * _i(a, 0), 0, {}),
     "jm_affinity_forward": _affinity,
+    "jm_affinity_forward_batched": lambda a: (
+        _i(a, 0) * ((_i(a, 1) + _i(a, 2)) * _mlp3(a[5])[0] * 4 + 4 * _i(a, 1) * _i(a, 2)),
+        _mlp3_flops(_i(a, 0) * _i(a, 1) * _i(a, 2), _mlp3(a[5])), {}),
+    "jm_affinity_start_end_batched": lambda a: (0, _mlp3_flops(_i(a, 0) * (_i(a, 1) + _i(a, 2)), _mlp3(a[5])), {}),
     "jm_affinity_start_end": lambda a: (0, _mlp3_flops(_i(a, 0) + _i(a, 1), _mlp3(a[4])), {}),
     "jm_mlp3_forward": lambda a: (0, _mlp3_flops(_i(a, 0), _mlp3(a[2])), {}),
     "jm_association_cost": lambda a: ((_i(a, 0) + _i(a, 2)) * 28 + 4 * _i(a, 0) * _i(a, 2), 0, {}),

@@ -138,3 +138,96 @@ def test_training_affinity_and_finetune_step_on_gpu():
             assert (pd.detach().double().cpu() - p64.detach())[big].abs().max().item() < 2e-4
         moved = max(moved, (pd.detach().cpu() - p0).abs().max().item())
     assert moved > 5e-4
+
+
+# ------------------------------------------------------------------ contraction-proof decision fixtures
+# Index outputs depend on comparisons of float32 expressions whose rounding depends on whether the compiler contracts
+# a*b + c into an FMA (DESIGN.md §3 states the two conventions used).  These inputs make every compared quantity EXACT
+# in float32 under ANY contraction (small dyadic rationals), and put points / boxes exactly ON the decision boundary.
+def test_ball_query_points_exactly_at_the_radius_grid(oracle):
+    """coordinates on a 2^-3 grid, radius 0.5 (r^2 = 0.25 exact): points at distance exactly r are NOT neighbours
+    (strict <, ball_query_gpu.cu:33-35), points one grid step inside are"""
+    from jmodt_amd.ops.pointnet2.pointnet2_utils import ball_query
+    g = np.arange(-8, 9, dtype=np.float32) / 8.0
+    pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)       # 17^3 lattice
+    centres = np.array([[[0, 0, 0], [0.5, 0.5, 0.5], [-1, -1, -1], [0.125, -0.25, 0.375]]], np.float32)
+    for ns in (16, 64):
+        got = ball_query(0.5, ns, T(pts), T(centres)).cpu().numpy()
+        assert np.array_equal(got, oracle.ball_query(0.5, ns, pts, centres))
+    d2 = ((pts[0][None] - centres[0][:, None]) ** 2).sum(-1)                                           # exact
+    full = ball_query(0.5, 64, T(pts), T(centres)).cpu().numpy()[0]
+    for c in range(4):
+        inside = np.nonzero(d2[c] < 0.25)[0]
+        on_sphere = np.nonzero(d2[c] == 0.25)[0]
+        assert len(on_sphere) >= 6 or c == 2
+        hits = np.unique(full[c])
+        assert set(hits) <= set(inside) and not (set(hits) & set(on_sphere))
+        assert np.array_equal(np.sort(full[c][:min(64, len(inside))]), inside[:64])
+
+
+def test_roipool_points_exactly_on_box_faces_grid(oracle):
+    """axis-aligned boxes (ry = 0: cos = 1, sin = 0 exactly) with dyadic sizes on a lattice cloud: points exactly on a
+    face belong to the box (closed intervals, roipool3d_kernel.cu:14-28); the pooled index order is the point order"""
+    from jmodt_amd.ops.roipool3d.roipool3d_utils import roipool3d_gpu
+    g = np.arange(-8, 9, dtype=np.float32) / 4.0
+    pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)
+    feat = np.arange(pts.shape[1], dtype=np.float32).reshape(1, -1, 1)                                 # feature = point index
+    # [x, y(bottom), z, h, w, l, ry]; after the 0.25 enlargement every face lies ON lattice planes
+    boxes = np.array([[[0, 0.5, 0, 0.5, 0.5, 1.0, 0], [1, 1, -1, 1.5, 1.5, 0.5, 0], [-1.5, 0, 1.5, 0.0, 0.5, 0.5, 0]]], np.float32)
+    pooled, empty = roipool3d_gpu(T(pts), T(feat), T(boxes), 0.25, 64)
+    want, wempty = oracle.roipool3d(pts, feat, oracle.enlarge_box3d(boxes, 0.25), 64)
+    assert np.array_equal(pooled.cpu().numpy(), want) and np.array_equal(empty.cpu().numpy(), wempty)
+    e = oracle.enlarge_box3d(boxes, 0.25)[0]
+    for m in range(3):
+        cx, by, cz, h, w, l = e[m, :6]
+        inside = (np.abs(pts[0, :, 0] - cx) <= l / 2) & (np.abs(pts[0, :, 1] - (by - h / 2)) <= h / 2) & (np.abs(pts[0, :, 2] - cz) <= w / 2)
+        idx = np.nonzero(inside)[0]
+        on_face = (np.abs(pts[0, idx, 0] - cx) == l / 2) | (np.abs(pts[0, idx, 2] - cz) == w / 2)
+        assert on_face.any()
+        assert np.array_equal(pooled.cpu().numpy()[0, m, :min(64, len(idx)), 3], idx[:64].astype(np.float32))
+
+
+def test_nms_normal_iou_exactly_at_the_threshold(oracle):
+    """integer boxes whose axis-aligned IoU is exactly 1/2, 1/4, 3/4: suppression is strict (iou > thresh,
+    iou3d_kernel.cu:318-330), so a pair AT the threshold is kept, one ulp below the threshold value it is suppressed"""
+    from jmodt_amd.ops.iou3d.iou3d_utils import nms_normal_gpu
+    boxes = np.array([[0, 0, 2, 1, 0], [0, 0, 1, 1, 0],          # IoU 1/2 with box 0
+                      [10, 0, 14, 1, 0], [10, 0, 11, 1, 0],      # IoU 1/4
+                      [20, 0, 24, 1, 0], [20, 0, 23, 1, 0],      # IoU 3/4
+                      [30, 0, 31, 1, 0], [30, 0, 31, 1, 0]], np.float32)    # IoU 1
+    scores = np.array([0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3, 0.2], np.float32)
+    for thr, kept in ((0.5, [0, 1, 2, 3, 4, 6]), (0.25, [0, 2, 3, 4, 6]), (0.75, [0, 1, 2, 3, 4, 5, 6]),
+                      (float(np.nextafter(np.float32(0.5), np.float32(0))), [0, 2, 3, 4, 6])):
+        got = nms_normal_gpu(T(boxes), T(scores), thr).cpu().numpy()
+        assert np.array_equal(got, oracle.nms(boxes, scores, thr, normal=True))
+        assert got.tolist() == kept, (thr, got)
+
+
+@pytest.mark.parametrize("nb,P,D,C", [(8, 128, 128, 512), (3, 7, 5, 64), (2, 1, 33, 96), (1, 40, 40, 512)])
+def test_pairwise_affinity_batched_matches_per_problem(oracle, nb, P, D, C):
+    """jm_affinity_forward_batched / _start_end_batched (every frame pair of a batch as one GEMM chain) vs the
+    single-problem entry and vs the oracle"""
+    from jmodt_amd.ops.affinity import make_affinity_mlp, pairwise_affinity, pairwise_affinity_batched
+    torch.manual_seed(nb * P + D)
+    link, se = make_affinity_mlp(C, (C, C)).to(DEV).eval(), make_affinity_mlp(C, (C, C)).to(DEV).eval()
+    with torch.no_grad():
+        for m in list(link.modules()) + list(se.modules()):
+            if isinstance(m, torch.nn.Conv1d):
+                m.bias.normal_(0, 0.05)
+    pf = torch.relu(torch.randn(nb, P, C, device=DEV))
+    df = torch.relu(torch.randn(nb, D, C, device=DEV))
+    A, s, e, raw = pairwise_affinity_batched(pf, df, link, se, return_raw=True)
+    assert A.shape == (nb, P, D) and s.shape == (nb, D) and e.shape == (nb, P)
+
+    def w(h):
+        return tuple(a.detach().cpu().numpy().copy() for a in (
+            h[0].conv.weight[..., 0], h[0].conv.bias, h[2].conv.weight[..., 0], h[2].conv.bias,
+            h[3].conv.weight.reshape(-1), h[3].conv.bias))
+    for b in range(nb):
+        A1, s1, e1, raw1 = pairwise_affinity(pf[b], df[b], link, se, return_raw=True)
+        for got, one in ((A[b], A1), (s[b], s1), (e[b], e1), (raw[b], raw1)):
+            assert (got - one).abs().max().item() < 2e-5
+        if b < 2:
+            oA, os_, oe = oracle.affinity(pf[b].cpu().numpy(), df[b].cpu().numpy(), w(link), w(se))
+            assert np.abs(A[b].cpu().numpy() - oA).max() < 1e-4 and np.abs(s[b].cpu().numpy() - os_).max() < 1e-4
+            assert np.abs(e[b].cpu().numpy() - oe).max() < 1e-4

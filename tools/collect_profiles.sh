@@ -1,10 +1,10 @@
 #!/bin/bash
-# Run ON THE GPU BOX (through gpurun): rocprofv3 kernel-trace stats + the two HBM PMC passes for both
-# bench workloads.  The rocpd databases stay in /tmp (they exceed gpurun's 64 MiB copy-back limit);
-# only the text summaries land in gpurun_out/profiles/, from where they are copied into profiles/.
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
+# Run ON THE GPU BOX (through gpurun): rocprofv3 kernel-trace stats + PMC passes (one counter per pass, never combined
+# with other trace domains) for the bench workloads.  The rocpd databases stay in /tmp (they exceed gpurun's 64 MiB
+# copy-back limit); only the text summaries land in gpurun_out/profiles/, from where they are copied into profiles/.
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r02'
 set -u
-ROUND=${1:-r01}
+ROUND=${1:-r02}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/profiles
 mkdir -p "$OUT"
@@ -13,20 +13,22 @@ cd /tmp
 run() {   # tag, extra rocprof flags, summarize mode, bench args...
     local tag=$1 flags=$2 mode=$3; shift 3
     rm -rf /tmp/prof_$tag
-    timeout 600 rocprofv3 $flags --kernel-trace -d /tmp/prof_$tag -o $tag -- python "$REPO/bench.py" "$@" > /tmp/prof_$tag.log 2>&1
+    timeout 900 rocprofv3 $flags --kernel-trace -d /tmp/prof_$tag -o $tag -- python "$REPO/bench.py" "$@" > /tmp/prof_$tag.log 2>&1
     local db; db=$(find /tmp/prof_$tag -name '*.db' | head -1)
     if [ -z "$db" ]; then echo "no db for $tag"; tail -5 /tmp/prof_$tag.log; return; fi
     python "$REPO/profiles/summarize.py" $mode "$db" "$OUT/${ROUND}_$tag.txt" > /dev/null
     tail -1 /tmp/prof_$tag.log | cut -c1-300
 }
-run sa_kernel_stats   "--stats" ""      --steps 12 --warmup 3 --no-cpu-baseline
-run ops_kernel_stats  "--stats" ""      --workload ops --steps 7 --warmup 2 --no-cpu-baseline
-for c in FETCH_SIZE WRITE_SIZE; do
-    run sa_pmc_$c  "--pmc $c" "--pmc" --steps 3 --warmup 1 --no-cpu-baseline
-    run ops_pmc_$c "--pmc $c" "--pmc" --workload ops --steps 3 --warmup 1 --no-cpu-baseline
+# MIOpen tunes every new convolution shape on first use (seconds of naive_conv_* kernels on a fresh box): do that outside the profile
+timeout 600 python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /tmp/warm.log 2>&1
+run detect_kernel_stats "--stats" ""   --steps 7 --warmup 3 --no-cpu-baseline
+run sa_kernel_stats     "--stats" ""   --workload sa --steps 12 --warmup 3 --no-cpu-baseline
+run ops_kernel_stats    "--stats" ""   --workload ops --steps 7 --warmup 2 --no-cpu-baseline
+for c in FETCH_SIZE WRITE_SIZE MfmaUtil SQ_INSTS_VALU_MFMA_MOPS_F32; do
+    run detect_pmc_$c "--pmc $c" "--pmc" --steps 2 --warmup 1 --no-cpu-baseline
 done
-# matrix-core counters for the MFMA kernels (fused SA block, affinity GEMMs): one counter per pass
-for c in MfmaUtil SQ_INSTS_VALU_MFMA_MOPS_F32; do
+for c in FETCH_SIZE WRITE_SIZE; do
+    run sa_pmc_$c  "--pmc $c" "--pmc" --workload sa --steps 3 --warmup 1 --no-cpu-baseline
     run ops_pmc_$c "--pmc $c" "--pmc" --workload ops --steps 3 --warmup 1 --no-cpu-baseline
 done
 ls -la "$OUT"
