@@ -18,12 +18,17 @@ __host__ __device__ inline int pad_to(int v, int m) { return (v + m - 1) / m * m
 //   bp     : this lane's packed weights for k-tile 0 of the range; kt_stride floats per k-tile
 //   bpre   : in  = k-tile 0's B operand, already loaded by the previous stage;
 //            out = the first B operand of the NEXT stage (next_bp)
-template <bool TWO>
+//   SUBV   : the A operand is relu(A - V): vt0 / vt1 = this lane's rows of a per-centre table in LDS for its two
+//            32-row blocks, 16 floats per k-tile laid out [khalf][8] (see sa_mlp.hip, pre-projected first layer); the
+//            subtraction and the ReLU are VALU work of THIS wave, issued under its own MFMAs
+template <bool TWO, bool SUBV = false>
 __device__ __forceinline__ void mfma_ktiles(const float* __restrict__ A, int nkt, const float* __restrict__ bp,
                                             size_t kt_stride, int a_off, f32x16 (&acc)[2][2], float4 (&bpre)[4],
-                                            const float* __restrict__ next_bp) {
+                                            const float* __restrict__ next_bp, const float* __restrict__ vt0 = nullptr,
+                                            const float* __restrict__ vt1 = nullptr) {
     float4 bc[4], bn[4];
     float ac[16], an[16];
+    float4 vc[4], vn[4];      // SUBV: [block 0 lo, hi | block 1 lo, hi]
     auto loadB = [&](float4 (&b)[4], const float* q) {
         b[0] = *reinterpret_cast<const float4*>(q);
         b[1] = *reinterpret_cast<const float4*>(q + 4);
@@ -38,7 +43,13 @@ __device__ __forceinline__ void mfma_ktiles(const float* __restrict__ A, int nkt
             a[2 * kk + 1] = q[(2 * kk) * SM_LDP + 32];
         }
     };
-    auto mm = [&](const float (&a)[16], const float4 (&b)[4]) {
+    auto loadV = [&](float4 (&v)[4], int kt) {
+        if (SUBV) {
+            v[0] = *reinterpret_cast<const float4*>(vt0 + kt * 16); v[1] = *reinterpret_cast<const float4*>(vt0 + kt * 16 + 4);
+            v[2] = *reinterpret_cast<const float4*>(vt1 + kt * 16); v[3] = *reinterpret_cast<const float4*>(vt1 + kt * 16 + 4);
+        }
+    };
+    auto mm_raw = [&](const float (&a)[16], const float4 (&b)[4]) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             const float b0 = reinterpret_cast<const float*>(&b[0])[kk];
@@ -51,31 +62,46 @@ __device__ __forceinline__ void mfma_ktiles(const float* __restrict__ A, int nkt
             }
         }
     };
+    auto mm = [&](const float (&a)[16], const float4 (&b)[4], const float4 (&v)[4]) {
+        if (!SUBV) { mm_raw(a, b); return; }
+        float t[16];
+        const float v0[8] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
+        const float v1[8] = {v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            t[2 * kk] = fmaxf(a[2 * kk] - v0[kk], 0.f);
+            t[2 * kk + 1] = fmaxf(a[2 * kk + 1] - v1[kk], 0.f);
+        }
+        mm_raw(t, b);
+    };
     // sched_barrier(0): keep the prefetches where they are written — left alone, the scheduler sinks
     // them to their first use and the L2 latency lands on the MFMA pipe
 #pragma unroll
     for (int q = 0; q < 4; ++q) bc[q] = bpre[q];
     loadA(ac, 0);
+    loadV(vc, 0);
     int kt = 0;
     for (; kt + 2 <= nkt; kt += 2) {
         loadB(bn, bp + (size_t)(kt + 1) * kt_stride);
         loadA(an, kt + 1);
+        loadV(vn, kt + 1);
         __builtin_amdgcn_sched_barrier(0);
-        mm(ac, bc);
+        mm(ac, bc, vc);
         __builtin_amdgcn_sched_barrier(0);
         // the k-tile after next — or, on the last trip, the NEXT stage's first B operand;
         // unconditional loads on a selected address, no branchy waits
         const bool more = kt + 2 < nkt;
         loadB(bc, more ? bp + (size_t)(kt + 2) * kt_stride : next_bp);
         loadA(ac, more ? kt + 2 : kt);
+        loadV(vc, more ? kt + 2 : kt);
         __builtin_amdgcn_sched_barrier(0);
-        mm(an, bn);
+        mm(an, bn, vn);
         __builtin_amdgcn_sched_barrier(0);
     }
     if (kt < nkt) {            // odd tail: bc / ac hold k-tile nkt-1
         loadB(bpre, next_bp);
         __builtin_amdgcn_sched_barrier(0);
-        mm(ac, bc);
+        mm(ac, bc, vc);
     } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) bpre[q] = bc[q];

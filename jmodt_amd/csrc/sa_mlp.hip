@@ -40,6 +40,8 @@ constexpr int SM_KC = 144;   // channels per activation buffer: 3 + 128 (both RC
 constexpr int SM_GRP = SM_KC / 16;                     // gather groups (16 channels each) per chunk
 constexpr int SM_BUF = SM_KC * SM_LDP;                 // floats per activation buffer
 constexpr size_t SM_LDS_BYTES = 2 * (size_t)SM_BUF * sizeof(float);
+constexpr int SM_VT = 8 * 128;                         // pre-projected mode: per-centre table, <= 8 centres x <= 128 channels
+constexpr size_t SM_LDS_BYTES_PRE = SM_LDS_BYTES + SM_VT * sizeof(float);
 
 struct SaMlpParams {
     int N, M, C, ns;                 // points per frame, centres per frame, feature channels, nsample
@@ -58,7 +60,6 @@ struct SaMlpParams {
     float* out;                      // (B, cout, M)
     int cout;
     int tiles_per_frame, total_tiles, xcd_frames;
-    int dbg;                         // tools build only (JM_SA_DBG): timing experiments, results are wrong when set
 };
 
 // packed layout: Wp[kt][n][khalf][kk] = W'[n][16 kt + 2 kk + khalf]   (kt < Kp/16, n < Np, khalf < 2, kk < 8)
@@ -189,23 +190,8 @@ __device__ __forceinline__ void sa_gather_role(const SaMlpParams& p, float* lds,
 #pragma unroll
         for (int grp = 0; grp < SM_GRP; ++grp) {
             if (g0 + grp < nfast) {
-                if (pre && p.dbg == 1) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) Gt[2 * (grp * 8 + j) * SM_LDP] = g[grp * 8 + j];
-                } else if (pre) {
-                    // channel (wave-uniform) -> its three xyz weights by scalar loads; value = relu(u_j - W1x . c_i)
-                    const float* wv = p.w1x + ((size_t)(g0 + grp) * 16 + gk0) * 4;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float val = __builtin_fmaf(-wv[8 * j], t.cx, g[grp * 8 + j]);
-                        val = __builtin_fmaf(-wv[8 * j + 1], t.cy, val);
-                        val = __builtin_fmaf(-wv[8 * j + 2], t.cz, val);
-                        Gt[2 * (grp * 8 + j) * SM_LDP] = fmaxf(val, 0.f);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) Gt[2 * (grp * 8 + j) * SM_LDP] = g[grp * 8 + j];
-                }
+                for (int j = 0; j < 8; ++j) Gt[2 * (grp * 8 + j) * SM_LDP] = g[grp * 8 + j];
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -223,8 +209,26 @@ __device__ __forceinline__ void sa_gather_role(const SaMlpParams& p, float* lds,
         }
     };
 
+    // pre-projected mode: v[c][k] = W1x[k] . centre_c for the tile's 128 / ns centres, consumed by the MFMA waves as
+    // relu(u - v) on their A operand (jm_mfma.h, SUBV).  Layout [centre][k-tile][khalf][8] = what one lane reads per
+    // k-tile.  ONE table: the MFMA waves read it only during the first layer of a tile, which is complete at the first
+    // hidden epilogue's barrier; the table of the next tile is written after that barrier (host: >= 2 layers here).
+    float* vt = lds + 2 * SM_BUF;
+    auto write_table = [&](int i) {
+        int bi, row0;
+        sch.tile(i, bi, row0);
+        const int ncen = SM_BM / p.ns, c0 = row0 / p.ns;
+        for (int e = ltid; e < ncen * C; e += 256) {
+            const int c = e / C, k = e - c * C;
+            const float* cp = p.new_xyz + ((size_t)bi * p.M + c0 + c) * 3;
+            const float* wv = p.w1x + (size_t)k * 4;
+            const float val = __builtin_fmaf(wv[2], cp[2], __builtin_fmaf(wv[1], cp[1], wv[0] * cp[0]));
+            vt[(size_t)c * C + (k >> 4) * 16 + (k & 1) * 8 + ((k & 15) >> 1)] = val;
+        }
+    };
     SaRow ct = load_row(0);
     issue(ct, 0);
+    if (pre) write_table(0);
     store(ct, 0, lds);
     lds_barrier();                                                   // B0: chunk 0 of the first tile published
     int cur = 0;
@@ -244,6 +248,7 @@ __device__ __forceinline__ void sa_gather_role(const SaMlpParams& p, float* lds,
         } else {
             lds_barrier(); cur ^= 1;                                 // first hidden epilogue's barrier
             if (has_next) issue(nt, 0);
+            if (pre && has_next) write_table(it + 1);                // the MFMA waves are past this tile's first layer
             for (int l = 1; l < p.L - 1; ++l) { lds_barrier(); cur ^= 1; }   // the other hidden epilogues' barriers
         }
         if (has_next) {
@@ -300,10 +305,20 @@ __device__ __forceinline__ void sa_mfma_role(const SaMlpParams& p, float* lds, i
     };
     // ncols: valid (padded-to-16) columns from ncol0 on; a wave without columns idles but keeps the
     // preload chain going
-    auto run = [&](const float* A, int nkt, int l, int kt0, int ncol0, int ncols, const float* next_bp) {
+    // pre-projected mode: this lane's rows of the per-centre table (gather role: write_table) for its two 32-row blocks
+    const bool pre = p.w1x != nullptr;
+    const float* vtab = lds + 2 * SM_BUF;
+    const float* vt0 = vtab + (size_t)((wm * 64 + lr) / p.ns) * p.C + lk * 8;
+    const float* vt1 = vtab + (size_t)((wm * 64 + 32 + lr) / p.ns) * p.C + lk * 8;
+    auto run = [&](const float* A, int nkt, int l, int kt0, int ncol0, int ncols, const float* next_bp, bool subv = false) {
         if (ncols <= 0) { preload(next_bp); return; }
         const float* bp = wptr(l, kt0, ncol0);
         const size_t st = (size_t)NP(l) * 16;
+        if (subv) {      // A operand = relu(u - v): the hoisted first layer's centre term and activation
+            if (ncols > 32) mfma_ktiles<true, true>(A, nkt, bp, st, a_off, acc, bpre, next_bp, vt0 + kt0 * 16, vt1 + kt0 * 16);
+            else mfma_ktiles<false, true>(A, nkt, bp, st, a_off, acc, bpre, next_bp, vt0 + kt0 * 16, vt1 + kt0 * 16);
+            return;
+        }
         if (ncols > 32) mfma_ktiles<true>(A, nkt, bp, st, a_off, acc, bpre, next_bp);
         else mfma_ktiles<false>(A, nkt, bp, st, a_off, acc, bpre, next_bp);
     };
@@ -340,7 +355,7 @@ __device__ __forceinline__ void sa_mfma_role(const SaMlpParams& p, float* lds, i
                 const int kc = min(SM_KC, K0 - c * SM_KC);     // multiple of 16
                 const bool more = c + 1 < nchunks;
                 run(lds + cur * SM_BUF, kc / 16, 0, c * (SM_KC / 16), wn * 64, kp1 - wn * 64,
-                    more ? wptr(0, (c + 1) * (SM_KC / 16), wn * 64) : wptr(1, 0, wn * 64));
+                    more ? wptr(0, (c + 1) * (SM_KC / 16), wn * 64) : wptr(1, 0, wn * 64), pre);
                 if (more) { lds_barrier(); cur ^= 1; }
             }
             // the other buffer held chunk nchunks-2 (or the previous tile's last input): every wave left it
@@ -480,7 +495,7 @@ extern "C" int jm_sa_mlp_forward_pre(int b, int n, int m, int c, int nsample, co
     JM_REQUIRE(b >= 0 && n >= 1 && m >= 0 && c >= 16 && c % 16 == 0 && c <= 128, "sa_mlp_pre: C must be a multiple of 16, <= 128");
     if (b == 0 || m == 0) return JM_OK;
     JM_REQUIRE(u && w1x && new_xyz && idx && out && widths && weights && biases, "sa_mlp_pre: null pointer");
-    JM_REQUIRE(num_layers >= 1 && num_layers <= 3 && widths[0] == c, "sa_mlp_pre: widths[0] must equal C");
+    JM_REQUIRE(num_layers >= 2 && num_layers <= 3 && widths[0] == c, "sa_mlp_pre: 2 or 3 layers after the hoisted one, widths[0] == C");
     return sa_mlp_narrow_launch(b, n, m, c, nsample, nullptr, new_xyz, u, w1x, idx, num_layers, widths, weights, biases, out, stream);
 }
 
@@ -527,7 +542,8 @@ static int sa_mlp_narrow_launch(int b, int n, int m, int c, int nsample, const f
         p.np[l] = pad_to(widths[l + 1], 128);
     }
     p.out = out; p.cout = widths[num_layers];
-    (void)hipFuncSetAttribute((const void*)sa_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM_LDS_BYTES);
+    const size_t lds_bytes = pre ? SM_LDS_BYTES_PRE : SM_LDS_BYTES;
+    (void)hipFuncSetAttribute((const void*)sa_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM_LDS_BYTES_PRE);
     // persistent: one workgroup per CU (135 KB of LDS each), whole frames per XCD when there are enough of them
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
@@ -538,8 +554,7 @@ static int sa_mlp_narrow_launch(int b, int n, int m, int c, int nsample, const f
     JM_REQUIRE(total < (1LL << 31), "sa_mlp: too many tiles");
     p.total_tiles = (int)total;
     p.xcd_frames = b >= 16 ? 1 : 0;
-    p.dbg = tune_env("JM_SA_DBG", 0);
     const int grid = p.xcd_frames ? cus : (int)(total < cus ? total : cus);
-    hipLaunchKernelGGL(sa_mlp_kernel, dim3((unsigned)grid), dim3(512), SM_LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(sa_mlp_kernel, dim3((unsigned)grid), dim3(512), lds_bytes, (hipStream_t)stream, p);
     return check_launch("sa_mlp");
 }

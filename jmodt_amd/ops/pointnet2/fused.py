@@ -137,7 +137,7 @@ def _pre_layers(mlp: nn.Sequential, device):
 
 def _can_pre_project(mlp: nn.Sequential, features, idx, M: int, ns: int) -> bool:
     shapes = _layer_shapes(mlp)
-    if not PRE_PROJECT or features is None or idx is None or not shapes or len(shapes) < 2 or len(shapes) > 4:
+    if not PRE_PROJECT or features is None or idx is None or not shapes or len(shapes) < 3 or len(shapes) > 4:
         return False
     h1 = shapes[0][0]
     return (h1 % 16 == 0 and h1 <= 128 and all(c <= 128 for c, _ in shapes[:-1]) and ns in (16, 32, 64)
@@ -168,7 +168,7 @@ def sa_mlp_pre_from_u(u: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor,
 def hoistable_first_layer(mlp: nn.Sequential, npoint: int, nsample: int, device):
     """(W1 (H1, 3 + C), b1) when the scale qualifies for the pre-projected kernel, else None"""
     shapes = _layer_shapes(mlp)
-    if (not PRE_PROJECT or not shapes or len(shapes) < 2 or len(shapes) > 4 or shapes[0][0] % 16 or shapes[0][0] > 128
+    if (not PRE_PROJECT or not shapes or len(shapes) < 3 or len(shapes) > 4 or shapes[0][0] % 16 or shapes[0][0] > 128
             or any(c > 128 for c, _ in shapes[:-1]) or nsample not in (16, 32, 64) or (npoint * nsample) % 128):
         return None
     W1, b1, _, _ = _pre_layers(mlp, device)

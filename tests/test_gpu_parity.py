@@ -792,7 +792,7 @@ def test_dense_config_sizes_vs_oracle(oracle):
 @pytest.mark.parametrize("N,npoint,C,ns,mlp,extent", [(512, 128, 128, 64, [128, 128, 128, 128], 3.0),       # RCNN SA1
                                                       (128, 32, 128, 64, [128, 128, 128, 256], 3.0),       # RCNN SA2
                                                       (4096, 1024, 96, 32, [96, 64, 96, 128], 60.0),        # RPN SA2, KITTI-sized coordinates
-                                                      (600, 64, 40, 16, [40, 32, 72], 8.0)])                # 2 layers
+                                                      (600, 64, 40, 16, [40, 32, 72, 48], 8.0)])            # nsample 16: 8 centres per tile
 def test_fused_sa_pre_projected_first_layer(N, npoint, C, ns, mlp, extent):
     """the first layer hoisted in front of the gather (u = W1 [xyz | f] + b1 per point, relu(u_j - W1x c_i) formed in the
     kernel: jm_sa_mlp_forward_pre) vs the same kernel with the first layer evaluated per (centre, sample) row vs the

@@ -30,7 +30,7 @@ runs = ((ar // ns * 4 + ar % ns) % N).expand(R, -1, -1).contiguous()          # 
 one = torch.zeros_like(real)
 rand = torch.randint(0, N, (R, M, ns), device="cuda", dtype=torch.int32)
 fl = 2 * R * M * ns * (128 * 128 * 2)
-print("JM_SA_DBG =", os.environ.get("JM_SA_DBG"))
+
 for name, idx in (("ball_query", real), ("single", one)):
     ms = timeit(lambda: fused.sa_mlp_pre_from_u(u, new_xyz, idx, sa.mlps[0]))
     print(f"{name:12s} {ms:.3f} ms  executed {fl / ms / 1e9:.1f} TF", flush=True)
