@@ -133,18 +133,6 @@ int jm_sa_mlp_forward_pre(int b, int n, int m, int c, int nsample, const float* 
                           const int* idx, int num_layers, const int* widths, const float* const* weights,
                           const float* const* biases, float* out, jm_stream_t stream);
 
-/* Fused feature-propagation block (MI355X-native; replaces the body of PointnetFPModule.forward after three_nn,
- * pointnet2_modules.py:147-164: inverse-distance weights, three_interpolate, skip concatenation, 2-layer SharedMLP):
- *   out[b, :, i] = relu(W_2 relu(W_1 [sum_t w_t known[b, :, idx[b,i,t]] | skip[b, :, i]] + b_1) + b_2),
- *   w_t = (1 / (sqrt(dist2[b,i,t]) + 1e-8)) / sum_t(...)
- * dist2 / idx (B, n, 3) from jm_three_nn, known_feats (B, c2, m), skip_feats (B, c1, n) or NULL (c1 = 0) -> out (B, h2, n).
- * w0 (h1 x (c2 + c1)), w1 (h2 x h1) and the biases in the layout of jm_sa_mlp_pack(cout, cin, 0), eval-mode BatchNorm
- * folded; n % 32 == 0, h1, h2 <= 512.  Neither the interpolated (B, c2, n) nor the concatenated tensor is materialised. */
-int jm_fp_mlp_supported(int b, int n, int m, int c2, int c1, int h1, int h2);
-int jm_fp_mlp_forward(int b, int n, int m, int c2, int c1, int h1, int h2, const float* dist2, const int* idx,
-                      const float* known_feats, const float* skip_feats, const float* w0, const float* b0, const float* w1,
-                      const float* b1, float* out, jm_stream_t stream);
-
 /* ------------------------------------------------------------------ roipool3d_cuda -------- */
 
 /* forward / forward_slow (roipool3d/src/roipool3d.cpp:16-79, roipool3d_kernel.cu:31-237).

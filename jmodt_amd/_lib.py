@@ -49,8 +49,6 @@ SIGNATURES = {
     "jm_sa_mlp_pack": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "jm_sa_mlp_forward": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, ctypes.POINTER(_I), ctypes.POINTER(_P),
                                ctypes.POINTER(_P), _P, _P]),
-    "jm_fp_mlp_supported": (_I, [_I] * 7),
-    "jm_fp_mlp_forward": (_I, [_I] * 7 + [_P] * 10),
     "jm_sa_mlp_forward_pre": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, ctypes.POINTER(_I), ctypes.POINTER(_P),
                                    ctypes.POINTER(_P), _P, _P]),
     "jm_roipool3d_forward": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),

@@ -246,8 +246,14 @@ __device__ __forceinline__ void sa_gather_role(const SaMlpParams& p, float* lds,
         if (single) {
             if (has_next) issue(nt, 0);
         } else {
+            // one-chunk inputs (every RCNN level, and every pre-projected call): the gather registers are free for the
+            // whole first layer of this tile, so the next tile's loads are issued BEFORE the first hidden epilogue's
+            // barrier and have that layer's MFMA time to land; only the LDS stores are left for after the barrier (with
+            // two layers per tile the loads otherwise had to complete within the last layer's MFMAs)
+            const bool early = has_next && nchunks == 1;
+            if (early) issue(nt, 0);
             lds_barrier(); cur ^= 1;                                 // first hidden epilogue's barrier
-            if (has_next) issue(nt, 0);
+            if (has_next && !early) issue(nt, 0);
             if (pre && has_next) write_table(it + 1);                // the MFMA waves are past this tile's first layer
             for (int l = 1; l < p.L - 1; ++l) { lds_barrier(); cur ^= 1; }   // the other hidden epilogues' barriers
         }

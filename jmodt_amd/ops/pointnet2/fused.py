@@ -267,63 +267,3 @@ def shared_mlp_points(mlp: nn.Sequential, parts) -> Optional[torch.Tensor]:
     for W, b in layers[1:]:
         x = torch.relu_(torch.baddbmm(b[None, :, None], W.expand(B, -1, -1), x))
     return x
-
-
-_fp_cache = weakref.WeakKeyDictionary()      # module -> (signature, packed 2-layer MLP)
-FUSE_FP = True
-
-
-def _fp_layers(mlp: nn.Sequential, device):
-    tensors = list(mlp.parameters()) + list(mlp.buffers())
-    sig = tuple((t.data_ptr(), t._version) for t in tensors) + (str(device),)
-    hit = _fp_cache.get(mlp)
-    if hit is not None and hit[0] == sig:
-        return hit[1]
-    lib = L.load()
-    folded = fold_shared_mlp(mlp)
-    packed = None
-    if folded is not None and len(folded) == 2:
-        packed = []
-        for W, b in folded:
-            W = W.to(device=device, dtype=_f32).contiguous()
-            b = b.to(device=device, dtype=_f32).contiguous()
-            cout, cin = W.shape
-            wp = torch.empty((lib.jm_sa_mlp_packed_weight_elems(cout, cin, 0),), dtype=_f32, device=device)
-            bp = torch.empty((lib.jm_sa_mlp_packed_bias_elems(cout),), dtype=_f32, device=device)
-            L.check(lib.jm_sa_mlp_pack(cout, cin, 0, L.dev(W, _f32, "W"), L.dev(b, _f32, "b"), ctypes.c_void_p(wp.data_ptr()),
-                                       ctypes.c_void_p(bp.data_ptr()), L.stream_ptr()), "sa_mlp_pack")
-            packed.append((wp, bp, cout, cin))
-    _fp_cache[mlp] = (sig, packed)
-    return packed
-
-
-@torch.no_grad()
-def fp_mlp_fused(dist2: torch.Tensor, idx: torch.Tensor, known_feats: torch.Tensor, skip_feats: Optional[torch.Tensor],
-                 mlp: nn.Sequential) -> Optional[torch.Tensor]:
-    """PointnetFPModule.forward after three_nn as ONE kernel (csrc/fp_mlp.hip): inverse-distance weights, 3-tap
-    interpolation, skip concatenation and the 2-layer SharedMLP (BatchNorm folded).  dist2 / idx (B, n, 3) from
-    three_nn_dist2, known_feats (B, C2, m), skip_feats (B, C1, n) or None -> (B, mlp_out, n); None when the shape is not
-    covered (the caller then takes the operator-by-operator route)"""
-    if not FUSE_FP or not known_feats.is_cuda:
-        return None
-    lib = L.load()
-    B, n, _ = dist2.shape
-    c2, m = known_feats.shape[1], known_feats.shape[2]
-    c1 = 0 if skip_feats is None else skip_feats.shape[1]
-    shapes = _layer_shapes(mlp)
-    if not shapes or len(shapes) != 2 or shapes[0][1] != c2 + c1:
-        return None
-    h1, h2 = shapes[0][0], shapes[1][0]
-    if not lib.jm_fp_mlp_supported(B, n, m, c2, c1, h1, h2):
-        return None
-    packed = _fp_layers(mlp, known_feats.device)
-    if packed is None:
-        return None
-    kf = known_feats.to(_f32).contiguous()
-    sf = skip_feats.to(_f32).contiguous() if skip_feats is not None else None
-    out = torch.empty((B, h2, n), dtype=_f32, device=kf.device)
-    L.check(lib.jm_fp_mlp_forward(B, n, m, c2, c1, h1, h2, L.dev(dist2, _f32, "dist2"), L.dev(idx, _i32, "idx"),
-                                  L.dev(kf, _f32, "known_feats"), L.dev(sf, _f32, "skip_feats") if sf is not None else None,
-                                  L.dev(packed[0][0], _f32, "w0"), L.dev(packed[0][1], _f32, "b0"), L.dev(packed[1][0], _f32, "w1"),
-                                  L.dev(packed[1][1], _f32, "b1"), ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "fp_mlp_fused")
-    return out

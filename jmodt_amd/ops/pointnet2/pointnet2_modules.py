@@ -118,13 +118,6 @@ class PointnetFPModule(nn.Module):
                 known_feats: torch.Tensor) -> torch.Tensor:
         """unknown (B, n, 3), known (B, m, 3), unknow_feats (B, C1, n), known_feats (B, C2, m)
         -> (B, mlp[-1], n)"""
-        if (known is not None and not torch.is_grad_enabled() and not self.training and known_feats.is_cuda
-                and fused.FUSE_FP and known.shape[1] >= 3):
-            # inference: weights + interpolation + skip concatenation + MLP in one fp32-MFMA kernel (csrc/fp_mlp.hip)
-            d2, nn3 = pointnet2_utils.three_nn_dist2(unknown, known)
-            out = fused.fp_mlp_fused(d2, nn3, known_feats, unknow_feats, self.mlp)
-            if out is not None:
-                return out
         if known is None:
             # a single global feature vector: broadcast it to every fine point
             carried = known_feats.expand(known_feats.shape[0], known_feats.shape[1], unknown.shape[1])

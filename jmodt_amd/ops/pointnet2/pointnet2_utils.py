@@ -120,20 +120,6 @@ class _ThreeNN(Function):
 three_nn = _ThreeNN.apply
 
 
-@torch.no_grad()
-def three_nn_dist2(unknown: torch.Tensor, known: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """three_nn without the square root: (dist2 (B, N, 3) SQUARED distances exactly as the kernel writes them,
-    idx (B, N, 3)) — the operands of the fused feature-propagation block (fused.fp_mlp_fused)"""
-    _need(unknown, "unknown"); _need(known, "known")
-    B, N, _ = unknown.size()
-    m = known.size(1)
-    dist2 = torch.empty((B, N, 3), dtype=_f32, device=unknown.device)
-    idx = torch.empty((B, N, 3), dtype=_i32, device=unknown.device)
-    L.check(L.load().jm_three_nn(B, N, m, L.dev(unknown, _f32, "unknown"), L.dev(known, _f32, "known"),
-                                 L.dev(dist2, _f32, "dist2"), L.dev(idx, _i32, "idx"), L.stream_ptr()), "three_nn")
-    return dist2, idx
-
-
 class _ThreeInterpolate(Function):
     @staticmethod
     def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:

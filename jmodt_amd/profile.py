@@ -85,9 +85,6 @@ ALGO: Dict[str, Callable] = {
     "jm_three_nn": lambda a: (_i(a, 0) * (12 * _i(a, 1) + 12 * _i(a, 2) + 24 * _i(a, 1)), 0,
                               dict(evals=_i(a, 0) * _i(a, 1) * _i(a, 2))),
     "jm_three_interpolate": lambda a: (_i(a, 0) * (4 * _i(a, 1) * _i(a, 2) + 24 * _i(a, 3) + 4 * _i(a, 1) * _i(a, 3)), 0, {}),
-    "jm_fp_mlp_forward": lambda a: (
-        _i(a, 0) * (4 * _i(a, 3) * _i(a, 2) + 24 * _i(a, 1) + 4 * _i(a, 4) * _i(a, 1) + 4 * _i(a, 6) * _i(a, 1)),
-        2 * _i(a, 0) * _i(a, 1) * ((_i(a, 3) + _i(a, 4)) * _i(a, 5) + _i(a, 5) * _i(a, 6)), {}),
     "jm_sa_mlp_forward": _sa_mlp,
     "jm_sa_mlp_forward_pre": _sa_mlp_pre,
     "jm_roipool3d_forward": _roipool,

@@ -820,45 +820,3 @@ def test_fused_sa_pre_projected_first_layer(N, npoint, C, ns, mlp, extent):
     assert f_ref.abs().max().item() > 0.1
     assert (f_pre - f_ref).abs().max().item() <= 1e-4 * scale, (f_pre - f_ref).abs().max().item()
     assert (f_row - f_ref).abs().max().item() <= 1e-4 * scale
-
-
-@pytest.mark.parametrize("n,m,c2,c1,mlp", [(16384, 4096, 256, 0, [256, 128, 128]),       # RPN FP1 (finest level, no skip features)
-                                            (4096, 1024, 512, 96, [608, 256, 256]),       # FP2
-                                            (1024, 256, 512, 256, [768, 512, 512]),       # FP3
-                                            (256, 64, 1024, 512, [1536, 512, 512]),       # FP4
-                                            (96, 5, 7, 3, [10, 20, 9])])                   # odd widths, tiny coarse set
-def test_fused_fp_block_matches_operator_route(oracle, n, m, c2, c1, mlp):
-    """csrc/fp_mlp.hip (weights + 3-tap interpolation + skip concatenation + 2-layer MLP in one launch) vs the
-    operator-by-operator route (three_nn, three_interpolate, folded GEMMs) and vs the oracle's three_interpolate"""
-    from jmodt_amd.ops.pointnet2 import fused
-    from jmodt_amd.ops.pointnet2.pointnet2_modules import PointnetFPModule
-    torch.manual_seed(n + c2)
-    fp = PointnetFPModule(mlp=list(mlp), bn=True)
-    _randomise_bn(fp, 9)
-    fp = fp.to(DEV).eval()
-    B = 2
-    unknown = synth.dense_cloud(B, n, 51, extent=20.0)
-    known = np.ascontiguousarray(unknown[:, :: n // m][:, :m])
-    kf = torch.randn(B, c2, m, device=DEV)
-    sf = torch.randn(B, c1, n, device=DEV) if c1 else None
-    with torch.no_grad():
-        got = fp(T(unknown), T(known), sf, kf)
-        fused.FUSE_FP = False
-        try:
-            want = fp(T(unknown), T(known), sf, kf)
-        finally:
-            fused.FUSE_FP = True
-    assert got.shape == want.shape == (B, mlp[-1], n)
-    scale = max(want.abs().max().item(), 1.0)
-    assert want.abs().max().item() > 0.1 and (got - want).abs().max().item() <= 1e-4 * scale
-    # the interpolation inside the kernel = the oracle's (identity MLP impossible: check through a 1-layer-equivalent)
-    d2, idx = oracle.three_nn(unknown, known)
-    w = 1.0 / (np.sqrt(d2) + np.float32(1e-8))
-    w = (w / w.sum(2, keepdims=True)).astype(np.float32)
-    interp = oracle.three_interpolate(kf.cpu().numpy(), idx, w)
-    x = np.concatenate([interp, sf.cpu().numpy()], 1) if c1 else interp
-    layers = fused.fold_shared_mlp(fp.mlp)
-    h = x.astype(np.float64)
-    for W, b in layers:
-        h = np.maximum(np.einsum("oc,bcn->bon", W.double().cpu().numpy(), h) + b.double().cpu().numpy()[None, :, None], 0)
-    assert np.abs(got.cpu().numpy() - h).max() <= 1e-4 * scale
