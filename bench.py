@@ -191,14 +191,13 @@ def make_ops_inputs(B, seed, dev, small=False):
     d["roi_feat"] = torch.randn(R, 128, 512, generator=g).to(dev)
     d["rcnn_sa1"] = PointnetSAModule(mlp=[128, 128, 128, 128], npoint=128, radius=0.2, nsample=64, bn=False).to(dev).eval()
     d["link"], d["se"] = make_affinity_mlp().to(dev).eval(), make_affinity_mlp().to(dev).eval()
-    P = 32 if small else 128
-    d["pf"] = torch.from_numpy(synth.roi_features(P, 512, seed + 2)).to(dev)
-    d["df"] = torch.from_numpy(synth.roi_features(P, 512, seed + 3)).to(dev)
+    d["pf256"] = torch.from_numpy(synth.roi_features(256, 512, seed + 2)).to(dev)
+    d["df256"] = torch.from_numpy(synth.roi_features(256, 512, seed + 3)).to(dev)
     return d
 
 
 def ops_step(d):
-    from jmodt_amd.ops.affinity import pairwise_affinity
+    from jmodt_amd.ops.affinity import pairwise_affinity, pairwise_affinity_batched
     from jmodt_amd.ops.fusion import feature_gather
     from jmodt_amd.ops.iou3d.iou3d_utils import nms_normal_gpu
     from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
@@ -224,8 +223,12 @@ def ops_step(d):
     distance_based_proposal(d["rpn_scores"], d["rpn_props"], 9000, 100, 0.8, "normal")
     with torch.no_grad(), prof.scope("rcnn_sa1"):
         d["rcnn_sa1"](d["roi_xyz"], d["roi_feat"])
-    for b in range(B):
-        pairwise_affinity(d["pf"], d["df"], d["link"], d["se"])
+    for P in (64, 128, 256):        # the affinity head at BASELINE configs[0] / [2] / [4] sizes, one problem each
+        with prof.scope(f"affinity_{P}x{P}"):
+            pairwise_affinity(d["pf256"][:P], d["df256"][:P], d["link"], d["se"])
+    with prof.scope(f"affinity_batched_{B}x128x128"):
+        pairwise_affinity_batched(d["pf256"][:128].unsqueeze(0).expand(B, -1, -1), d["df256"][:128].unsqueeze(0).expand(B, -1, -1),
+                                  d["link"], d["se"])
 
 
 # ---------------------------------------------------------------------------------------------- dense
@@ -247,7 +250,7 @@ def make_dense_inputs(B, seed, dev, small=False):
 
 
 def dense_step(d):
-    from jmodt_amd.ops.affinity import pairwise_affinity
+    from jmodt_amd.ops.affinity import pairwise_affinity_batched
     from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
     from jmodt_amd.ops.roipool3d.roipool3d_utils import roipool3d_canonical_gpu
     xyz, m = d["xyz"], d["m"]
@@ -259,8 +262,7 @@ def dense_step(d):
         pu.grouping_operation(xyz_t, nb)
     pu.three_nn(xyz, new_xyz)
     roipool3d_canonical_gpu(xyz, d["feat130"], d["boxes"], 0.2, 512)
-    for b in range(B):
-        pairwise_affinity(d["pf"], d["df"], d["link"], d["se"])
+    pairwise_affinity_batched(d["pf"].unsqueeze(0).expand(B, -1, -1), d["df"].unsqueeze(0).expand(B, -1, -1), d["link"], d["se"])
 
 
 # ---------------------------------------------------------------------------------------------- train
@@ -286,13 +288,14 @@ def make_train_state(frames, seed, dev, tiny=False):
 def train_step(st, world):
     """one data-parallel finetune step: frozen composed detector forward (no grad) -> 512-d RoI features ->
     local forward/backward of the pairwise affinity losses -> ONE bucketed gradient all-reduce over RCCL -> Adam"""
-    from jmodt_amd.ops.affinity_train import finetune_step
+    from jmodt_amd.ops.affinity_train import finetune_step_static
     eng = st["engine"]
     with torch.no_grad():
         _, inter = eng.detect(st["xyz"], st["image"], st["pts_xy"], next_xyz=st["xyz"] if st.get("prefetch", True) else None)
     B = st["xyz"].shape[0]
     feats = inter["rcnn_feat"].view(B, -1, inter["rcnn_feat"].shape[1])[:, :st["rois_per_frame"]].contiguous()
-    return prof.region("finetune(fwd+bwd+allreduce+adam)", lambda: finetune_step(
+    # static-shape, sync-free: the host never waits for the device inside a step
+    return prof.region("finetune(fwd+bwd+allreduce+adam)", lambda: finetune_step_static(
         feats, st["tids"], eng.rcnn_net.link_layer, eng.rcnn_net.se_layer, st["opt"], world=world))
 
 

@@ -64,6 +64,12 @@ def _worker(rank, world, port, tmpdir):
     b, e = jdist.shard_frames(feats.shape[0], world, rank)
     loss = finetune_step(feats[b:e], tids[b:e], link, se, opt, world=world)
     torch.save({"loss": loss, "link": link.state_dict(), "se": se.state_dict()}, os.path.join(tmpdir, f"r{rank}.pt"))
+    # --- the same step in the static-shape, sync-free form (device-side counts, no .item())
+    from jmodt_amd.ops.affinity_train import finetune_step_static
+    link2, se2 = _make_heads()
+    opt2 = torch.optim.SGD(list(link2.parameters()) + list(se2.parameters()), lr=0.1)
+    loss2 = finetune_step_static(feats[b:e], tids[b:e], link2, se2, opt2, world=world)
+    torch.save({"loss": float(loss2), "link": link2.state_dict(), "se": se2.state_dict()}, os.path.join(tmpdir, f"s{rank}.pt"))
     tdist.barrier()
     tdist.destroy_process_group()
 
@@ -85,6 +91,43 @@ def test_dp_finetune_step_matches_single_process(tmp_path):
         for k, v in ref.items():
             assert torch.allclose(r0[name][k], v, atol=1e-6), (name, k)     # DP == single process
             assert torch.equal(r0[name][k], r1[name][k]), (name, k)         # replicas stay identical
+    s0, s1 = (torch.load(tmp_path / f"s{r}.pt") for r in range(world))     # static-shape form: same loss, same update
+    assert abs(s0["loss"] - loss1) < 1e-5 and abs(s1["loss"] - loss1) < 1e-5
+    for name, ref in (("link", link.state_dict()), ("se", se.state_dict())):
+        for k, v in ref.items():
+            assert torch.allclose(s0[name][k], v, atol=1e-6), (name, k)
+            assert torch.equal(s0[name][k], s1[name][k]), (name, k)
+
+
+def test_static_training_affinity_equals_the_looped_form():
+    """training_affinity_static (masks instead of torch.unique / a Python loop over frame pairs) gives the reference
+    form's loss and gradients exactly (float64), incl. a pair without foreground on one side and duplicate track ids"""
+    from jmodt_amd.ops.affinity import make_affinity_mlp
+    from jmodt_amd.ops.affinity_train import reid_loss, reid_loss_static, training_affinity, training_affinity_static
+    g = torch.Generator().manual_seed(5)
+    frames, R, C = 8, 16, 32
+    feats = torch.relu(torch.randn(frames, R, C, generator=g)).double()
+    tids = torch.randint(0, 5, (frames, R), generator=g).double()
+    tids[2] = 0                      # pair 1: no foreground in prev -> skipped
+    tids[5] = 3                      # pair 2: every next RoI on one track
+    torch.manual_seed(1)
+    link, se = make_affinity_mlp(C, (C, C)).double(), make_affinity_mlp(C, (C, C)).double()
+    params = list(link.parameters()) + list(se.parameters())
+    a = training_affinity(feats, tids, link, se)
+    la = reid_loss(a)
+    la.backward()
+    ga = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    b = training_affinity_static(feats, tids, link, se)
+    lb, counts = reid_loss_static(b)
+    lb.backward()
+    assert counts.tolist() == [a["gt_links"].numel(), a["gt_starts"].numel(), a["gt_ends"].numel()]
+    assert abs(la.item() - lb.item()) < 1e-12
+    assert max((x - p.grad).abs().max().item() for x, p in zip(ga, params)) < 1e-12
+    # the valid entries ARE the reference's matrices: same multiset of link scores / labels
+    assert torch.allclose(torch.sort(b["link"][b["valid"]])[0], torch.sort(a["rcnn_link"].view(-1))[0], atol=1e-12)
+    assert b["gt_links"][b["valid"]].sum().item() == a["gt_links"].sum().item()
 
 
 def test_training_affinity_matches_reference_shapes_and_labels():

@@ -138,6 +138,16 @@ def test_training_affinity_and_finetune_step_on_gpu():
             assert (pd.detach().double().cpu() - p64.detach())[big].abs().max().item() < 2e-4
         moved = max(moved, (pd.detach().cpu() - p0).abs().max().item())
     assert moved > 5e-4
+    # the static-shape, sync-free step (what bench.py --workload train runs): same loss, same update
+    from jmodt_amd.ops.affinity_train import finetune_step_static
+    slink, sse = copy.deepcopy(link).to(DEV).train(), copy.deepcopy(se).to(DEV).train()
+    sopt = torch.optim.Adam(list(slink.parameters()) + list(sse.parameters()), lr=1e-3)
+    sloss = finetune_step_static(feats.to(DEV), tids.to(DEV), slink, sse, sopt, world=1)
+    assert sloss.is_cuda and abs(sloss.item() - l64.item()) < 1e-5
+    for ps, p64 in zip(list(slink.parameters()) + list(sse.parameters()), list(link64.parameters()) + list(se64.parameters())):
+        big = p64.grad.abs() > 1e-7
+        if big.any():
+            assert (ps.detach().double().cpu() - p64.detach())[big].abs().max().item() < 2e-4
 
 
 # ------------------------------------------------------------------ contraction-proof decision fixtures
