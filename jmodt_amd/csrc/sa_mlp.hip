@@ -60,7 +60,16 @@ struct SaMlpParams {
     float* out;                      // (B, cout, M)
     int cout;
     int tiles_per_frame, total_tiles, xcd_frames;
+#ifdef JM_TOOLS_BUILD
+    long long* trace;                // tools build: shader-clock stamps of workgroup 0's first MFMA wave (tools/sa_trace.py)
+#endif
 };
+
+#ifdef JM_TOOLS_BUILD
+#define JM_SA_STAMP(k) do { if (p.trace && blockIdx.x == 0 && tid == 0 && it < 64) p.trace[it * 8 + (k)] = (long long)clock64(); } while (0)
+#else
+#define JM_SA_STAMP(k) do { } while (0)
+#endif
 
 // packed layout: Wp[kt][n][khalf][kk] = W'[n][16 kt + 2 kk + khalf]   (kt < Kp/16, n < Np, khalf < 2, kk < 8)
 // W' = W zero padded, except for the FIRST layer, whose input channels [xyz(3) | C features]
@@ -355,6 +364,7 @@ __device__ __forceinline__ void sa_mfma_role(const SaMlpParams& p, float* lds, i
         int bi, row0;
         sch.tile(it, bi, row0);
         int l = 0;
+        JM_SA_STAMP(0);
         if (!single) {
             // ---------------- layer 1: chunks of <= 128 input channels (the gather waves stay one chunk ahead)
             for (int c = 0; c < nchunks; ++c) {
@@ -366,9 +376,12 @@ __device__ __forceinline__ void sa_mfma_role(const SaMlpParams& p, float* lds, i
             }
             // the other buffer held chunk nchunks-2 (or the previous tile's last input): every wave left it
             // before the last barrier
+            JM_SA_STAMP(1);
             hidden_epilogue(0, lds + (cur ^ 1) * SM_BUF);
             init_acc(BS(1), wn * 64);                          // next layer's bias, set while waiting
+            JM_SA_STAMP(2);
             lds_barrier();
+            JM_SA_STAMP(3);
             cur ^= 1;
             // ---------------- hidden layers 2 .. L-1
             for (l = 1; l < L - 1; ++l) {
@@ -389,6 +402,7 @@ __device__ __forceinline__ void sa_mfma_role(const SaMlpParams& p, float* lds, i
                 const bool last_n = n0 + 128 >= npl;
                 run(A, nkt, l, 0, n0 + wn * 64, kpl1 - (n0 + wn * 64),
                     last_n ? wptr(0, 0, wn * 64) : wptr(l, 0, n0 + 128 + wn * 64));
+                JM_SA_STAMP(4);
                 // max over each centre's nsample rows, straight from the accumulator layout
                 // row(i, r, lk) = 32 i + (r & 3) + 8 (r >> 2) + 4 lk  within this wave's 64 rows
 #pragma unroll
@@ -435,7 +449,9 @@ __device__ __forceinline__ void sa_mfma_role(const SaMlpParams& p, float* lds, i
                 // next column tile of this layer, or the next tile's first layer
                 if (last_n) init_acc(bs0, wn * 64); else init_acc(bl, n0 + 128 + wn * 64);
             }
+            JM_SA_STAMP(5);
             if (has_next) { lds_barrier(); cur ^= 1; }         // the gather waves parked the next tile's chunk 0
+            JM_SA_STAMP(6);
         }
     }
 }
@@ -493,6 +509,10 @@ extern "C" int jm_sa_mlp_pack(int cout, int cin, int first_layer, const float* w
 static int sa_mlp_narrow_launch(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                                 const float* features, const float* w1x, const int* idx, int num_layers, const int* widths,
                                 const float* const* weights, const float* const* biases, float* out, jm_stream_t stream);
+#ifdef JM_TOOLS_BUILD
+static long long* g_sa_trace = nullptr;      // tools build only: the product library keeps no state
+extern "C" __attribute__((visibility("default"))) void jm_tools_set_sa_trace(long long* buf) { g_sa_trace = buf; }
+#endif
 
 /* pre-projected form (see the header): layers 2..L on relu(u[idx] - v[centre]) */
 extern "C" int jm_sa_mlp_forward_pre(int b, int n, int m, int c, int nsample, const float* u, const float* w1x,
@@ -560,6 +580,9 @@ static int sa_mlp_narrow_launch(int b, int n, int m, int c, int nsample, const f
     JM_REQUIRE(total < (1LL << 31), "sa_mlp: too many tiles");
     p.total_tiles = (int)total;
     p.xcd_frames = b >= 16 ? 1 : 0;
+#ifdef JM_TOOLS_BUILD
+    p.trace = g_sa_trace;
+#endif
     const int grid = p.xcd_frames ? cus : (int)(total < cus ? total : cus);
     hipLaunchKernelGGL(sa_mlp_kernel, dim3((unsigned)grid), dim3(512), lds_bytes, (hipStream_t)stream, p);
     return check_launch("sa_mlp");
