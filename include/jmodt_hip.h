@@ -329,6 +329,12 @@ size_t jm_affinity_start_end_batched_workspace_bytes(int nb, int p, int d, const
 int jm_affinity_start_end_batched(int nb, int p, int d, const float* pred_feat, const float* det_feat, const jm_mlp3_t* se,
                                   float* se_out, void* ws, size_t ws_bytes, jm_stream_t stream);
 
+/* One dense layer on plain rows: y (M, N) = act(x (M, K) w^T + b), w (N, K) row-major = a Conv1d(k=1) / Linear weight,
+ * relu != 0 applies ReLU.  For the small-M heads (RCNN cls_layer / reg_layer, rcnn.py:43-89: 1024 RoIs x 512): single-wave
+ * 32x32 fp32-MFMA tiles, one launch per layer instead of GEMM + bias + ReLU.  K % 8 == 0. */
+int jm_linear_rows(int m, int k, int n, const float* x, const float* w, const float* b, float* y, int relu,
+                   jm_stream_t stream);
+
 /* The same MLP on plain rows x (M,C) -> y (M): used for the start/end features and exposed for
  * callers that hold a materialised feature matrix (rcnn.py:272-285). */
 size_t jm_mlp3_workspace_bytes(int m, const jm_mlp3_t* mlp);

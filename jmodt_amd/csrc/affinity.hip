@@ -267,8 +267,8 @@ mlp_gemm_small_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int orow = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const float hval = fmaxf(acc[i] + bv, 0.f);
-        if (EMODE == 0) {
+        const float hval = EMODE == 2 ? acc[i] + bv : fmaxf(acc[i] + bv, 0.f);   // EMODE 2: plain linear layer
+        if (EMODE == 0 || EMODE == 2) {
             if (cok && orow < p.M) p.H[(size_t)orow * p.N + c] = hval;
         } else {
             const float v = half_sum_f32_dpp(hval * wv);
@@ -415,6 +415,23 @@ static int run_mlps(const MlpJob* jobs, int njobs, hipStream_t s) {
 }  // namespace jm
 
 using namespace jm;
+
+/* y (M, N) = act(x (M, K) W^T (N, K) + b): one dense layer on plain rows with the single-wave 32x32 MFMA tiles of the
+ * start/end head (the RCNN's classification / regression heads: a few hundred..thousand rows x 512 channels, where a
+ * library GEMM + bias + ReLU is three latency-bound launches) */
+extern "C" int jm_linear_rows(int m, int k, int n, const float* x, const float* w, const float* b, float* y, int relu,
+                              jm_stream_t stream) {
+    JM_REQUIRE(m >= 0 && k >= 8 && k % 8 == 0 && n >= 1, "linear_rows: K must be a positive multiple of 8");
+    if (m == 0) return JM_OK;
+    JM_REQUIRE(x && w && b && y, "linear_rows: null pointer");
+    JM_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u) == 0, "linear_rows: 16-byte alignment");
+    JM_REQUIRE(divup(m, 32) <= 65535, "linear_rows: too many rows");
+    GemmParams p{};
+    p.M = m; p.N = n; p.K = k; p.A = x; p.pf = nullptr; p.df = nullptr; p.D = 1; p.PD = 0; p.W = w; p.bias = b; p.H = y;
+    if (relu) hipLaunchKernelGGL((mlp_gemm_small_kernel<0>), dim3(divup(n, 32), divup(m, 32)), dim3(64), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((mlp_gemm_small_kernel<2>), dim3(divup(n, 32), divup(m, 32)), dim3(64), 0, (hipStream_t)stream, p);
+    return check_launch("linear_rows");
+}
 
 extern "C" size_t jm_mlp3_workspace_bytes(int m, const jm_mlp3_t* mlp) {
     if (m <= 0 || !mlp) return 0;

@@ -62,6 +62,7 @@ struct SaMlpParams {
     int tiles_per_frame, total_tiles, xcd_frames;
 #ifdef JM_TOOLS_BUILD
     long long* trace;                // tools build: shader-clock stamps of workgroup 0's first MFMA wave (tools/sa_trace.py)
+    int dbg;                         // tools build (JM_SA_DBG): 2 = gather role idles (timing experiment, wrong results)
 #endif
 };
 
@@ -162,6 +163,9 @@ __device__ __forceinline__ void sa_gather_role(const SaMlpParams& p, float* lds,
     // A whole feature group is the lean path: one scalar base pointer, 8 loads / 8 ds_writes and nothing per
     // element in between.  This matters: the wave shares its SIMD with an MFMA wave and gets few issue slots.
     auto issue = [&](const SaRow& t, int c) {
+#ifdef JM_TOOLS_BUILD
+        if (p.dbg == 2) return;
+#endif
         const float* xyz_b = p.xyz + (size_t)t.bi * p.N * 3;
         const float* feat_b = p.feat ? p.feat + (size_t)t.bi * C * p.N : xyz_b;   // never dereferenced when C == 0
         const unsigned off_f = (unsigned)t.gidx;
@@ -194,6 +198,9 @@ __device__ __forceinline__ void sa_gather_role(const SaMlpParams& p, float* lds,
         }
     };
     auto store = [&](const SaRow& t, int c, float* G) {   // centre subtraction / zero padding happen here
+#ifdef JM_TOOLS_BUILD
+        if (p.dbg == 2) return;
+#endif
         float* Gt = G + gk0 * SM_LDP + grow;                 // element i of this thread: + 2 i SM_LDP
         const int g0 = c * SM_GRP;
 #pragma unroll
@@ -582,6 +589,7 @@ static int sa_mlp_narrow_launch(int b, int n, int m, int c, int nsample, const f
     p.xcd_frames = b >= 16 ? 1 : 0;
 #ifdef JM_TOOLS_BUILD
     p.trace = g_sa_trace;
+    p.dbg = tune_env("JM_SA_DBG", 0);
 #endif
     const int grid = p.xcd_frames ? cus : (int)(total < cus ? total : cus);
     hipLaunchKernelGGL(sa_mlp_kernel, dim3((unsigned)grid), dim3(512), lds_bytes, (hipStream_t)stream, p);

@@ -27,7 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .ops import proposal as proposal_ops
-from .ops.affinity import make_affinity_mlp, pairwise_affinity, pairwise_affinity_batched
+from .ops.affinity import linear_rows, make_affinity_mlp, pairwise_affinity, pairwise_affinity_batched
 from .ops.detections import DetectionCache, decode_rcnn_boxes, select_detections
 from .ops.fusion import PackedAttentionFusion, PackedImageFusion, bias_relu_, feature_gather
 from .ops.pointnet2 import fused, pointnet2_utils
@@ -271,6 +271,7 @@ class DetectAffinityEngine(nn.Module):
         self.overlap = True                # FPS pyramid + image branch on side streams
         self.last_fps_idx: List[torch.Tensor] = []
         self.sparse_image_fusion = True    # final image feature only under the bilinear taps (else dense deconvolutions)
+        self.fuse_small_heads = True       # RCNN cls / reg heads: one MFMA launch per dense layer
         self.fuse_rcnn_lift = True         # xyz_up + merge_down (+ hoisted first SA layer) as one kernel
         self.fuse_attention = True         # LI-Fusion attention block as one kernel where it fits (else rocBLAS GEMMs)
         self._prefetched = None
@@ -316,6 +317,16 @@ class DetectAffinityEngine(nn.Module):
     def _head_forward(self, tag: str, head: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
         """a Conv1d head on (B, C, n): folded 1x1 convolutions as batched GEMMs"""
         units = [m for m in head if not isinstance(m, nn.Dropout)]
+        if x.is_cuda and x.dtype == torch.float32 and x.shape[2] == 1 and x.shape[1] % 8 == 0 and self.fuse_small_heads:
+            # (R, C, 1) inputs = plain rows: one MFMA launch per layer (jm_linear_rows) instead of GEMM + bias + ReLU
+            rows = x[:, :, 0]
+            for li, unit in enumerate(units):
+                W, b = self._wb(f"{tag}.{li}", lambda u=unit: _unit_wb(u))
+                if rows.shape[1] % 8:
+                    break
+                rows = linear_rows(rows, W, b, getattr(unit, "activation", None) is not None)
+            else:
+                return rows.unsqueeze(-1)
         for li, unit in enumerate(units):
             W, b = self._wb(f"{tag}.{li}", lambda u=unit: _unit_wb(u))
             x = torch.baddbmm(b[None, :, None], W.expand(x.shape[0], -1, -1), x)

@@ -179,3 +179,18 @@ def mlp3_forward(x: torch.Tensor, head: nn.Sequential) -> torch.Tensor:
     L.check(lib.jm_mlp3_forward(x.shape[0], L.dev(x, _f32, "x"), ctypes.byref(mlp), ctypes.c_void_p(y.data_ptr()),
                                 ctypes.c_void_p(ws.data_ptr()), ws_bytes, L.stream_ptr()), "mlp3_forward")
     return y
+
+
+@torch.no_grad()
+def linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu: bool) -> torch.Tensor:
+    """x (M, K) rows, weight (N, K), bias (N) -> act(x W^T + b) (M, N) as one launch (jm_linear_rows): the small-M dense
+    layers of the RCNN heads"""
+    x = x.to(_f32).contiguous()
+    W = weight.detach().to(_f32).contiguous()
+    b = bias.detach().to(_f32).contiguous()
+    M, K = x.shape
+    N = W.shape[0]
+    y = torch.empty((M, N), dtype=_f32, device=x.device)
+    L.check(L.load().jm_linear_rows(M, K, N, L.dev(x, _f32, "x"), L.dev(W, _f32, "weight"), L.dev(b, _f32, "bias"),
+                                    ctypes.c_void_p(y.data_ptr()), int(bool(relu)), L.stream_ptr()), "linear_rows")
+    return y

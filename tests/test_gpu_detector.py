@@ -440,3 +440,51 @@ def test_rcnn_lift_kernel_and_hoisted_first_layer(run):
         got_u = PackedRcnnLift(up, merge, (W1, b1))(x)
     close(got_m, m.view(R, S, -1).transpose(1, 2))
     close(got_u, u.view(R, S, -1).transpose(1, 2))
+
+
+@pytest.mark.parametrize("M,K,N,relu", [(1024, 512, 512, True), (1024, 512, 46, False), (1024, 512, 1, False), (37, 8, 33, True),
+                                        (1, 64, 5, False), (0, 64, 5, True), (100, 520, 70, True)])
+def test_linear_rows_vs_fp64(M, K, N, relu):
+    """jm_linear_rows (one dense layer on plain rows, the RCNN heads' launch) vs fp64 matmul"""
+    from jmodt_amd.ops.affinity import linear_rows
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) * (2.0 / K) ** 0.5).to(DEV)
+    b = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    got = linear_rows(x, W, b, relu)
+    want = x.double() @ W.double().t() + b.double()
+    if relu:
+        want = torch.relu(want)
+    assert got.shape == (M, N)
+    if M:
+        close(got, want)
+        if not relu:
+            assert (got < 0).any()
+    with pytest.raises(RuntimeError):
+        linear_rows(torch.randn(4, 12).to(DEV), torch.randn(3, 12).to(DEV), torch.randn(3).to(DEV), True)   # K % 8
+
+
+def test_rcnn_heads_one_launch_per_layer_vs_rocblas(run):
+    """the engine's RCNN cls / reg heads through jm_linear_rows vs the GEMM + bias + ReLU route"""
+    eng = run["eng"]
+    pts = run["inter"]["pts_input"]
+    from jmodt_amd.profile import prof
+    with torch.no_grad():
+        prof.reset()
+        prof.enabled = True
+        try:
+            a = eng.rcnn_forward(pts)
+            torch.cuda.synchronize()
+            names = set(prof.records)
+        finally:
+            prof.enabled = False
+            prof.reset()
+        eng.fuse_small_heads = False
+        try:
+            b = eng.rcnn_forward(pts)
+        finally:
+            eng.fuse_small_heads = True
+    for k in ("rcnn_cls", "rcnn_reg"):
+        close(a[k], b[k])
+        assert a[k].shape == b[k].shape
+    assert any("linear_rows" in n for n in names), names
