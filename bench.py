@@ -74,7 +74,8 @@ def detect_step(st):
     """one batch; the NEXT batch's cloud is announced so that its FPS pyramid runs under this batch's work (a
     streaming detector always knows its next batch; here it is the same resident synthetic batch).  Every step
     still launches exactly one FPS pyramid and one of everything else inside the timed region."""
-    return st["engine"](st["xyz"], st["image"], st["pts_xy"], next_xyz=st["xyz"] if st.get("prefetch", True) else None)
+    pf = st.get("prefetch", True)
+    return st["engine"](st["xyz"], st["image"], st["pts_xy"], next_xyz=st["xyz"] if pf else None, next_image=st["image"] if pf else None)
 
 
 def cpu_baseline_detect(frames=2):
@@ -291,7 +292,8 @@ def train_step(st, world):
     from jmodt_amd.ops.affinity_train import finetune_step_static
     eng = st["engine"]
     with torch.no_grad():
-        _, inter = eng.detect(st["xyz"], st["image"], st["pts_xy"], next_xyz=st["xyz"] if st.get("prefetch", True) else None)
+        pf = st.get("prefetch", True)
+        _, inter = eng.detect(st["xyz"], st["image"], st["pts_xy"], next_xyz=st["xyz"] if pf else None, next_image=st["image"] if pf else None)
     B = st["xyz"].shape[0]
     feats = inter["rcnn_feat"].view(B, -1, inter["rcnn_feat"].shape[1])[:, :st["rois_per_frame"]].contiguous()
     # static-shape, sync-free: the host never waits for the device inside a step
@@ -349,6 +351,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 8; train: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="FPS chain and image branch on the main stream")
+    ap.add_argument("--image-prefetch", choices=["early", "late", "off"], default="early",
+                    help="next batch's image pyramid: under this batch's backbone, after it, or not announced")
     ap.add_argument("--no-prefetch", action="store_true", help="do not start the next batch's FPS pyramid early")
     ap.add_argument("--tiny", action="store_true", help="smoke-sized shapes (tests only; the JSON says so)")
     ap.add_argument("--workload", default="detect", choices=list(WORKLOAD_TEXT))
@@ -390,6 +394,8 @@ def main():
         st = make_detect_state(args.batch, seed + 2, dev, tiny=args.tiny)
         st["engine"].overlap = not args.no_overlap
         st["prefetch"] = not args.no_prefetch
+        st["engine"].prefetch_image = args.image_prefetch != "off"
+        st["engine"].prefetch_image_late = args.image_prefetch == "late"
         step = lambda: detect_step(st)  # noqa: E731
     elif args.workload == "sa":
         xyz, feats = make_sa_inputs(args.batch, seed + 1, dev)
@@ -404,6 +410,8 @@ def main():
         train_st = make_train_state(args.batch, seed + 3, dev, tiny=args.tiny)
         train_st["engine"].overlap = not args.no_overlap
         train_st["prefetch"] = not args.no_prefetch
+        train_st["engine"].prefetch_image = args.image_prefetch != "off"
+        train_st["engine"].prefetch_image_late = args.image_prefetch == "late"
         step = lambda: train_step(train_st, world)  # noqa: E731
     for _ in range(args.warmup):
         step()

@@ -256,6 +256,20 @@ int jm_rcnn_lift_forward(int r, int s, int k, int c, int h1, int h2, int hm, int
                          const float* w_merge_f, const float* b_merge, const float* w_out_m, const float* w_out_x,
                          const float* b_out, float* out, jm_stream_t stream);
 
+/* A stack of 1..3 kernel-size-1 Conv1d layers (BatchNorm folded by the caller, optional ReLU each) on (B, C, n) tensors in
+ * one launch: the RPN heads (rpn.py:34-58), the feature-propagation SharedMLPs on cat[interpolated, skip]
+ * (pointnet2_modules.py:139-153) and the hoisted first set-abstraction layer u = W_f f + W_x xyz^T.  The first layer
+ * takes one or two operands that accumulate into the same output columns (x0 (B, c0, n) and x1 (B, c1, n), i.e. the
+ * channel concatenation without building it); xyz1 != 0: x1 is point-major coordinates (B, n, 3), c1 == 3.
+ * widths[l] = output channels of layer l; weights in the layout of jm_sa_mlp_pack(cout, cin, 0): w0a (widths[0] x c0),
+ * w0b (widths[0] x c1) or NULL, weights[1..] (weights[0] ignored), biases[0..]; relu[l] != 0 applies ReLU after layer l.
+ * out (B, widths[num_layers-1], n).  n % 32 == 0; operands whose width is not a multiple of 16 and the hidden
+ * activations of a 32-point tile must fit the 160 KB LDS (jm_conv1d_stack_supported). */
+int jm_conv1d_stack_supported(int b, int n, int c0, int c1, int xyz1, int num_layers, const int* widths);
+int jm_conv1d_stack_forward(int b, int n, int c0, const float* x0, int c1, const float* x1, int xyz1, int num_layers,
+                            const int* widths, const float* w0a, const float* w0b, const float* const* weights,
+                            const float* const* biases, const int* relu, float* out, jm_stream_t stream);
+
 /* x = relu(x + bias[c]) in place on CHANNELS-LAST data (numel = pixels * channels, channels % 4 == 0): the one
  * element-wise pass of the image branch's BasicBlock (backbone.py:16-32) once its eval-mode BatchNorm is folded into
  * the first convolution (replaces a BatchNorm pass + a ReLU pass over up to 1 GB). */

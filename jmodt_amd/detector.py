@@ -275,6 +275,9 @@ class DetectAffinityEngine(nn.Module):
         self.fuse_rcnn_lift = True         # xyz_up + merge_down (+ hoisted first SA layer) as one kernel
         self.fuse_attention = True         # LI-Fusion attention block as one kernel where it fits (else rocBLAS GEMMs)
         self._prefetched = None
+        self._prefetched_img = None
+        self.prefetch_image = True         # prefetch(xyz, image) also starts the next batch's image pyramid
+        self.prefetch_image_late = False   # ... after this batch's backbone (under proposals / RCNN) instead of under it
 
     # -- helpers -------------------------------------------------------------------------------------
     @staticmethod
@@ -334,15 +337,45 @@ class DetectAffinityEngine(nn.Module):
                 x = torch.relu_(x)
         return x
 
+    def _rpn_heads_stack(self, feats: torch.Tensor) -> Optional[torch.Tensor]:
+        """both RPN heads (rpn.py:34-58: Conv1d + BN + ReLU -> Conv1d each) as ONE two-layer stack: the first layers
+        stacked row-wise, the second layers block-diagonal (the zero blocks contribute exact zeros) -> (B, 1 + C, N)"""
+        if not (self.fuse_small_heads and feats.is_cuda and feats.dtype == torch.float32):
+            return None
+
+        def make():
+            heads = []
+            for tag, head in (("rpn_cls", self.rpn.rpn_cls_layer), ("rpn_reg", self.rpn.rpn_reg_layer)):
+                units = [m for m in head if not isinstance(m, nn.Dropout)]
+                if len(units) != 2 or getattr(units[0], "activation", None) is None or getattr(units[1], "activation", None) is not None:
+                    return False
+                heads.append([_unit_wb(u) for u in units])
+            (Wc0, bc0), (Wc1, bc1) = heads[0]
+            (Wr0, br0), (Wr1, br1) = heads[1]
+            hc, hr = Wc0.shape[0], Wr0.shape[0]
+            W1 = torch.zeros((Wc1.shape[0] + Wr1.shape[0], hc + hr), dtype=Wc0.dtype, device=Wc0.device)
+            W1[:Wc1.shape[0], :hc] = Wc1
+            W1[Wc1.shape[0]:, hc:] = Wr1
+            from .ops.conv1d import PackedConv1dStack
+            return PackedConv1dStack([(torch.cat([Wc0, Wr0], 0), torch.cat([bc0, br0], 0), True),
+                                      (W1, torch.cat([bc1, br1], 0), False)], Wc0.shape[1])
+        st = self._wb("rpn_heads.stack", make)
+        if st is False or not st.supported(feats.shape[0], feats.shape[2]):
+            return None
+        return st(feats)
+
     # -- stage 1: backbone + RPN heads -----------------------------------------------------------------
     @torch.no_grad()
-    def prefetch(self, xyz: torch.Tensor) -> None:
-        """announce the NEXT batch's cloud: its FPS pyramid (coordinates only, one workgroup per frame, ~6 ms of
+    def prefetch(self, xyz: torch.Tensor, image: Optional[torch.Tensor] = None) -> None:
+        """announce the NEXT batch: its FPS pyramid (coordinates only, one workgroup per frame, ~6 ms of
         latency-bound sampling) starts now on the side stream, under the current batch's set abstraction /
-        RCNN work, instead of at the head of the next call's critical path.  The next call must pass the same
-        tensor object."""
+        RCNN work, instead of at the head of the next call's critical path; with `image`, so does its image pyramid
+        (the four convolution blocks depend on the image alone, backbone.py:162-168), which then no longer holds the
+        point branch of the next call at every LI-Fusion level.  The next call must pass the same tensor objects."""
         if self.overlap:
             self._prefetched = (xyz, FpsPyramid(xyz, list(self.cfg.sa_npoints), overlap=True))
+            if image is not None and self.prefetch_image:
+                self._prefetched_img = (image, self._launch_image_branch(image))
 
     def _take_prefetched(self, xyz: torch.Tensor):
         hit, self._prefetched = self._prefetched, None
@@ -352,22 +385,20 @@ class DetectAffinityEngine(nn.Module):
             hit[1].release()
         return None
 
-    @torch.no_grad()
-    def backbone(self, xyz: torch.Tensor, image: torch.Tensor, pts_xy: torch.Tensor,
-                 next_xyz: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """xyz (B, N, 3), image (B, 3, H, W), pts_xy (B, N, 2) in [-1, 1] -> point features (B, 128, N)
-        (PointNet2MSG.forward, backbone.py:159-196)"""
-        cfg, net = self.cfg, self.rpn.backbone_net
-        dev = xyz.device
+    def _take_prefetched_image(self, image: torch.Tensor):
+        hit, self._prefetched_img = self._prefetched_img, None
+        return hit[1] if hit is not None and hit[0] is image else None
+
+    def _launch_image_branch(self, image: torch.Tensor) -> dict:
+        """stream I: the image pyramid, channels-last, on its side stream (ordered after the current stream's position:
+        the image is ready, and nothing this stream has queued so far still needs buffers the branch will recycle)"""
+        net = self.rpn.backbone_net
+        dev = image.device
         main = torch.cuda.current_stream(dev)
-        B, N, _ = xyz.shape
-        # --- stream F: the whole FPS chain (coordinates only); already running if this batch was announced ---
-        pyr = self._take_prefetched(xyz) or FpsPyramid(xyz, list(cfg.sa_npoints), overlap=self.overlap)
-        if next_xyz is not None:
-            self.prefetch(next_xyz)
-        # --- stream I: image pyramid, channels-last ---
         img_stream = side_stream(dev, 1) if self.overlap else main
         img_stream.wait_stream(main)
+        if img_stream is not main:
+            image.record_stream(img_stream)
         img_maps, img_events = [], []
         with torch.cuda.stream(img_stream):
             cur = image.contiguous(memory_format=torch.channels_last)
@@ -375,7 +406,6 @@ class DetectAffinityEngine(nn.Module):
                 cur = self._t(f"image_block_{i + 1}(MIOpen)", 0, lambda k=i, c=cur: self._image_block(k, c))
                 ev = torch.cuda.Event()
                 ev.record(img_stream)
-                cur.record_stream(main)
                 img_maps.append(cur)
                 img_events.append(ev)
             H, W = image.shape[2], image.shape[3]
@@ -388,9 +418,31 @@ class DetectAffinityEngine(nn.Module):
             fused_map = None
             if sparse is None:      # dense fall-back: the full-resolution fused map, gathered afterwards
                 fused_map = self._t("image_deconv+fusion_conv(MIOpen)", 0, lambda: self._image_fusion_map(img_maps))
-                fused_map.record_stream(main)
             fused_ev = torch.cuda.Event()
             fused_ev.record(img_stream)
+        return dict(maps=img_maps, events=img_events, sparse=sparse, fused_map=fused_map, fused_ev=fused_ev, H=H, W=W,
+                    stream=img_stream)
+
+    @torch.no_grad()
+    def backbone(self, xyz: torch.Tensor, image: torch.Tensor, pts_xy: torch.Tensor,
+                 next_xyz: Optional[torch.Tensor] = None, next_image: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """xyz (B, N, 3), image (B, 3, H, W), pts_xy (B, N, 2) in [-1, 1] -> point features (B, 128, N)
+        (PointNet2MSG.forward, backbone.py:159-196)"""
+        cfg, net = self.cfg, self.rpn.backbone_net
+        dev = xyz.device
+        main = torch.cuda.current_stream(dev)
+        B, N, _ = xyz.shape
+        # --- stream F: the whole FPS chain (coordinates only); already running if this batch was announced ---
+        pyr = self._take_prefetched(xyz) or FpsPyramid(xyz, list(cfg.sa_npoints), overlap=self.overlap)
+        # --- stream I: image pyramid; already running (or done) if this batch's image was announced ---
+        ib = self._take_prefetched_image(image) or self._launch_image_branch(image)
+        if next_xyz is not None:
+            self.prefetch(next_xyz, None if self.prefetch_image_late else next_image)
+        img_maps, img_events, sparse, fused_map, fused_ev = ib["maps"], ib["events"], ib["sparse"], ib["fused_map"], ib["fused_ev"]
+        H, W, img_stream = ib["H"], ib["W"], ib["stream"]
+        if img_stream is not main:      # allocated on the image stream, read by this one
+            for t in img_maps + ([fused_map] if fused_map is not None else []):
+                t.record_stream(main)
         # --- stream M: set abstraction + LI-Fusion per level ---
         l_xyz, l_feats, l_xy = [xyz], [None], [pts_xy]
         self.last_fps_idx = []
@@ -417,9 +469,9 @@ class DetectAffinityEngine(nn.Module):
             gathered = sparse(img_maps, pts_xy, H, W) if sparse is not None else feature_gather(fused_map, pts_xy)
             out = self._t("attention_fusion(rocBLAS)", 0, lambda: self._attention_fusion(
                 "fusion_final", net.final_fusion_img_point, l_feats[0], gathered))
-        if self.overlap:
-            img_stream.wait_stream(main)     # image buffers are not recycled under the main stream's readers
         pyr.release()
+        if next_image is not None and self.prefetch_image_late and self.prefetch_image and self.overlap:
+            self._prefetched_img = (next_image, self._launch_image_branch(next_image))    # ordered after this batch's backbone
         return out
 
     def _image_block(self, i: int, x: torch.Tensor) -> torch.Tensor:
@@ -430,11 +482,15 @@ class DetectAffinityEngine(nn.Module):
         def make():
             bn = blk.bn1
             scale = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
-            W = (blk.conv1.weight.detach() * scale[:, None, None, None]).contiguous()   # same layout as the module's parameter
-            return W, (bn.bias.detach() - bn.running_mean.detach() * scale).contiguous()
-        W, b = self._wb(f"img_block{i}", make)
+            # both weights in the activations' channels-last layout: an NCHW weight is re-laid-out by every call
+            # (0.25 ms per step over the four blocks)
+            W = (blk.conv1.weight.detach() * scale[:, None, None, None]).contiguous(memory_format=torch.channels_last)
+            W2 = blk.conv2.weight.detach().contiguous(memory_format=torch.channels_last)
+            b2 = blk.conv2.bias.detach() if blk.conv2.bias is not None else None
+            return W, (bn.bias.detach() - bn.running_mean.detach() * scale).contiguous(), W2, b2
+        W, b, W2, b2 = self._wb(f"img_block{i}", make)
         y = F.conv2d(x, W, None, stride=1, padding=1)
-        return blk.conv2(bias_relu_(y, b))
+        return F.conv2d(bias_relu_(y, b), W2, b2, stride=blk.conv2.stride, padding=blk.conv2.padding)
 
     def _image_fusion_map(self, img_maps: List[torch.Tensor]) -> torch.Tensor:
         """relu(bn(conv1x1(cat_i deconv_i(img_i)))) (backbone.py:187-193).  The 1x1 fusion convolution is linear,
@@ -483,10 +539,13 @@ class DetectAffinityEngine(nn.Module):
         return self._wb("img_fusion", make)
 
     @torch.no_grad()
-    def rpn_forward(self, xyz, image, pts_xy, next_xyz=None) -> Dict[str, torch.Tensor]:
+    def rpn_forward(self, xyz, image, pts_xy, next_xyz=None, next_image=None) -> Dict[str, torch.Tensor]:
         """RPN.forward (rpn.py:71-87): backbone features + objectness / box regression per point"""
-        feats = self.backbone(xyz, image, pts_xy, next_xyz)
+        feats = self.backbone(xyz, image, pts_xy, next_xyz, next_image)
         def heads():
+            both = self._rpn_heads_stack(feats)
+            if both is not None:                                   # (B, 1 + C, N): one launch for the two heads
+                return both[:, :1].transpose(1, 2).contiguous(), both[:, 1:].transpose(1, 2).contiguous()
             cls = self._head_forward("rpn_cls", self.rpn.rpn_cls_layer, feats).transpose(1, 2).contiguous()   # (B, N, 1)
             reg = self._head_forward("rpn_reg", self.rpn.rpn_reg_layer, feats).transpose(1, 2).contiguous()   # (B, N, C)
             return cls, reg
@@ -581,10 +640,10 @@ class DetectAffinityEngine(nn.Module):
 
     # -- the whole path ----------------------------------------------------------------------------------
     @torch.no_grad()
-    def detect(self, xyz, image, pts_xy, next_xyz=None) -> Tuple[DetectionCache, Dict[str, torch.Tensor]]:
+    def detect(self, xyz, image, pts_xy, next_xyz=None, next_image=None) -> Tuple[DetectionCache, Dict[str, torch.Tensor]]:
         """frames -> device-resident detections (boxes, scores, 512-d features, per-frame counts)"""
         cfg = self.cfg
-        rpn_out = self.rpn_forward(xyz, image, pts_xy, next_xyz)
+        rpn_out = self.rpn_forward(xyz, image, pts_xy, next_xyz, next_image)
         rois, roi_scores = self.proposals(rpn_out)
         pts_input = self.roi_pool(rpn_out, rois)
         out = self.rcnn_forward(pts_input)
@@ -598,11 +657,11 @@ class DetectAffinityEngine(nn.Module):
         return cache, inter
 
     @torch.no_grad()
-    def forward(self, xyz, image, pts_xy, next_xyz=None):
+    def forward(self, xyz, image, pts_xy, next_xyz=None, next_image=None):
         """detect + affinity of every frame against its predecessor in the batch (frame 0 against the last):
         returns (DetectionCache, [(A (M, M), start (M), end (M)) per frame]) with all M RoI slots as the
         affinity operands (fixed work per frame: P = D = M)."""
-        cache, inter = self.detect(xyz, image, pts_xy, next_xyz)
+        cache, inter = self.detect(xyz, image, pts_xy, next_xyz, next_image)
         feats = inter["rcnn_feat"].view(cache.boxes.shape[0], cache.boxes.shape[1], -1)
         B, M, C = feats.shape
         link, se = self.rcnn_net.link_layer, self.rcnn_net.se_layer

@@ -1,0 +1,63 @@
+"""Per-point Conv1d stacks on (B, C, n) tensors as one launch (csrc/conv1d_stack.hip).
+
+Replaces, on the composed inference path, the kernel-size-1 `Conv1d (+ BatchNorm1d) (+ ReLU)` chains of the RPN heads
+(jmodt/detection/modeling/rpn.py:34-58), the SharedMLP of the feature-propagation modules on cat[interpolated, skip]
+(jmodt/ops/pointnet2/pointnet2_modules.py:139-153) and the hoisted first set-abstraction layer of
+jmodt_amd/ops/pointnet2/fused.py — each of which is otherwise a batched GEMM + bias broadcast + ReLU pass per layer.
+"""
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import _lib as L
+from .fusion import _pack
+
+_f32 = torch.float32
+
+
+class PackedConv1dStack:
+    """layers: [(W (cout, cin), b (cout) or None, relu)] with BatchNorm already folded; the FIRST layer's input is the
+    channel concatenation [x0 (c0) | x1 (c1)] (c1 = 0: single operand); xyz1: x1 is point-major xyz (B, n, 3)."""
+
+    def __init__(self, layers: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], bool]], c0: int, c1: int = 0,
+                 xyz1: bool = False):
+        assert 1 <= len(layers) <= 3 and layers[0][0].shape[1] == c0 + c1
+        self.c0, self.c1, self.xyz1 = int(c0), int(c1), bool(xyz1)
+        self.widths = [int(W.shape[0]) for W, _, _ in layers]
+        self.relu = [int(bool(r)) for _, _, r in layers]
+        W0, b0, _ = layers[0]
+        dev = W0.device
+        zeros = lambda n: torch.zeros(n, dtype=_f32, device=dev)      # noqa: E731
+        self.w0a, self.b0 = _pack(W0[:, :c0], b0 if b0 is not None else zeros(W0.shape[0]))
+        self.w0b = _pack(W0[:, c0:], None)[0] if c1 else None
+        self.w, self.b = [self.w0a], [self.b0]
+        for W, b, _ in layers[1:]:
+            wp, bp = _pack(W, b if b is not None else zeros(W.shape[0]))
+            self.w.append(wp)
+            self.b.append(bp)
+        nl = len(layers)
+        self._widths_c = (ctypes.c_int * nl)(*self.widths)
+        self._relu_c = (ctypes.c_int * nl)(*self.relu)
+        self._w_c = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in self.w])
+        self._b_c = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in self.b])
+
+    def supported(self, B: int, n: int) -> bool:
+        return bool(L.load().jm_conv1d_stack_supported(B, n, self.c0, self.c1, int(self.xyz1), len(self.widths), self._widths_c))
+
+    @torch.no_grad()
+    def __call__(self, x0: torch.Tensor, x1: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x0 (B, c0, n), x1 (B, c1, n) — or (B, n, 3) with xyz1 — -> (B, widths[-1], n)"""
+        x0 = x0.to(_f32).contiguous()
+        B, c0, n = x0.shape
+        assert c0 == self.c0 and (x1 is None) == (self.c1 == 0)
+        if x1 is not None:
+            x1 = x1.to(_f32).contiguous()
+            assert tuple(x1.shape) == ((B, n, 3) if self.xyz1 else (B, self.c1, n))
+        out = torch.empty((B, self.widths[-1], n), dtype=_f32, device=x0.device)
+        L.check(L.load().jm_conv1d_stack_forward(
+            B, n, self.c0, L.dev(x0, _f32, "x0"), self.c1, L.dev(x1, _f32, "x1") if x1 is not None else None, int(self.xyz1),
+            len(self.widths), self._widths_c, L.dev(self.w0a, _f32, "w0a"),
+            L.dev(self.w0b, _f32, "w0b") if self.w0b is not None else None, self._w_c, self._b_c, self._relu_c,
+            ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "conv1d_stack")
+        return out

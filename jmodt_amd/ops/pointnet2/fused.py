@@ -104,6 +104,9 @@ def _packed_layers(mlp: nn.Sequential, device):
     return packed
 
 
+CONV1D_STACK = True       # per-point Conv1d chains (FP MLPs, hoisted first SA layer) as one launch (csrc/conv1d_stack.hip)
+STACK_MIN_TILES = 128     # below this many 32-point tiles the launch cannot fill the machine: library GEMMs
+_stack_cache = weakref.WeakKeyDictionary()    # module -> {operand widths: (folded layers it was packed from, PackedConv1dStack)}
 _pre_cache = weakref.WeakKeyDictionary()      # module -> (signature, (W1, b1, packed layers 2..L))
 PRE_PROJECT = True    # first layer as per-point / per-centre GEMMs in front of the kernel where that applies
 
@@ -130,7 +133,7 @@ def _pre_layers(mlp: nn.Sequential, device):
         packed.append((wp, bp, cout, cin))
     w1x = torch.zeros((W1.shape[0], 4), dtype=_f32, device=device)
     w1x[:, :3] = W1[:, :3]
-    val = (W1, b1, w1x, packed)
+    val = (W1, b1, w1x, packed, {})
     _pre_cache[mlp] = (sig, val)
     return val
 
@@ -149,7 +152,7 @@ def sa_mlp_pre_from_u(u: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor,
     """layers 2..L + max-pool of a set-abstraction scale whose hoisted first layer u = W1 [xyz | f] + b1 (B, H1, N) was
     computed by the producer of the features (ops/rcnn_lift.py): -> (B, mlp_out, M)"""
     lib = L.load()
-    W1, b1, w1x, packed = _pre_layers(mlp, u.device)
+    W1, b1, w1x, packed, _ = _pre_layers(mlp, u.device)
     B, H1, N = u.shape
     M, ns = idx.shape[1], idx.shape[2]
     widths = [H1] + [cout for _, _, cout, _ in packed]
@@ -171,7 +174,7 @@ def hoistable_first_layer(mlp: nn.Sequential, npoint: int, nsample: int, device)
     if (not PRE_PROJECT or not shapes or len(shapes) < 3 or len(shapes) > 4 or shapes[0][0] % 16 or shapes[0][0] > 128
             or any(c > 128 for c, _ in shapes[:-1]) or nsample not in (16, 32, 64) or (npoint * nsample) % 128):
         return None
-    W1, b1, _, _ = _pre_layers(mlp, device)
+    W1, b1, _, _, _ = _pre_layers(mlp, device)
     return W1, b1
 
 
@@ -181,13 +184,22 @@ def _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp):
     = u_j - W1x c_i with u = W1 [xyz | f] + b1 per point (two small batched GEMMs accumulating into one tensor); the
     kernel forms relu(u_j - W1x c_i) while gathering and runs layers 2..L (jm_sa_mlp_forward_pre)"""
     lib = L.load()
-    W1, b1, w1x, packed = _pre_layers(mlp, xyz.device)
+    W1, b1, w1x, packed, extra = _pre_layers(mlp, xyz.device)
     B, N, _ = xyz.shape
     M, ns = idx.shape[1], idx.shape[2]
     H1 = W1.shape[0]
     feats = features.to(_f32)
-    u = torch.baddbmm(b1[None, :, None], W1[:, 3:].expand(B, -1, -1), feats)
-    u = torch.baddbmm(u, W1[:, :3].expand(B, -1, -1), xyz.transpose(1, 2))            # (B, H1, N)
+    u = None
+    if CONV1D_STACK and N % 32 == 0:
+        st = extra.get("u_stack")
+        if st is None:
+            from ..conv1d import PackedConv1dStack
+            st = extra["u_stack"] = PackedConv1dStack([(torch.cat([W1[:, 3:], W1[:, :3]], dim=1), b1, False)], W1.shape[1] - 3, 3, True)
+        if st.supported(B, N):
+            u = st(feats, xyz)                                                        # (B, H1, N), one launch
+    if u is None:
+        u = torch.baddbmm(b1[None, :, None], W1[:, 3:].expand(B, -1, -1), feats)
+        u = u.baddbmm_(W1[:, :3].expand(B, -1, -1), xyz.transpose(1, 2))
     widths = [H1] + [cout for _, _, cout, _ in packed]
     nl = len(packed)
     prof.hoisted_flops(2 * B * M * ns * H1 * W1.shape[1])     # the first layer's per-row work this form avoids
@@ -257,6 +269,18 @@ def shared_mlp_points(mlp: nn.Sequential, parts) -> Optional[torch.Tensor]:
     if layers is None or sum(p.shape[1] for p in parts) != layers[0][0].shape[1]:
         return None
     B = parts[0].shape[0]
+    n = parts[0].shape[2]
+    if CONV1D_STACK and parts[0].is_cuda and len(parts) <= 2 and len(layers) <= 3 and B * (n // 32) >= STACK_MIN_TILES:
+        # the whole stack as one launch on 32-point tiles (csrc/conv1d_stack.hip)
+        per_mlp = _stack_cache.setdefault(mlp, {})
+        key = tuple(p.shape[1] for p in parts)
+        st = per_mlp.get(key)
+        if st is None or st[0] is not layers:
+            from ..conv1d import PackedConv1dStack
+            st = per_mlp[key] = (layers, PackedConv1dStack(
+                [(W, b, True) for W, b in layers], parts[0].shape[1], parts[1].shape[1] if len(parts) == 2 else 0))
+        if st[1].supported(B, n):
+            return st[1](*parts)
     W, b = layers[0]
     x, off = None, 0
     for part in parts:

@@ -64,6 +64,9 @@ class FpsPyramid:
         idx, new_xyz, ev = self._levels[k]
         cur = torch.cuda.current_stream(idx.device)
         if cur is not self._side and cur != self._side:
+            if cur != self._main:           # consumed on another stream than the one that announced the cloud
+                idx.record_stream(cur)
+                new_xyz.record_stream(cur)
             # how long the consumer is actually held up = the EXPOSED part of this level's sampling
             prof.stall(f"fps_exposed_wait_L{k + 1}", lambda: cur.wait_event(ev))
         return idx, new_xyz

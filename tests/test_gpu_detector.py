@@ -178,6 +178,28 @@ def test_next_batch_prefetch_gives_identical_results(run):
     assert eng._prefetched is None
 
 
+@pytest.mark.parametrize("late", [False, True])
+def test_next_image_prefetch_gives_identical_results(run, late):
+    """announcing the next batch's image starts its image pyramid on the side stream (under this batch's backbone, or
+    after it); results must not change, an announcement for a different image must be dropped"""
+    eng = run["eng"]
+    a, img, xy = T(run["xyz"]), T(run["img"]), T(run["xy"])
+    other = T(run["img"][:, :, ::-1].copy())
+    eng.prefetch_image_late = late
+    try:
+        with torch.no_grad():
+            eng(a, img, xy, next_xyz=a, next_image=img)
+            assert eng._prefetched_img is not None and eng._prefetched_img[0] is img
+            _, _, i1 = eng(a, img, xy, next_xyz=a, next_image=other)      # consumes the announced pyramid
+            _, _, i2 = eng(a, img, xy)                                   # `other` was announced, `img` arrives: dropped
+            torch.cuda.synchronize()
+    finally:
+        eng.prefetch_image_late = False
+    for k in ("backbone_features", "rois", "rcnn_feat"):
+        assert torch.equal(i1[k], run["inter"][k]) and torch.equal(i2[k], run["inter"][k]), k
+    assert eng._prefetched_img is None
+
+
 def test_unfused_sa_path_matches_fused(run):
     """the same engine with the fused SA kernel disabled (QueryAndGroup + GroupAll + torch convs) — a8 / a5"""
     eng = run["eng"]
@@ -488,3 +510,35 @@ def test_rcnn_heads_one_launch_per_layer_vs_rocblas(run):
         close(a[k], b[k])
         assert a[k].shape == b[k].shape
     assert any("linear_rows" in n for n in names), names
+
+
+@pytest.mark.parametrize("B,n,c0,c1,xyz1,widths,relus", [
+    (2, 4096, 128, 0, False, [128, 77], [True, False]),          # both RPN heads as one block-diagonal stack
+    (3, 1024, 96, 3, True, [64], [False]),                       # hoisted first SA layer: W_f f + W_x xyz^T
+    (2, 256, 512, 256, False, [512, 512], [True, True]),         # an FP module: cat[interpolated, skip] -> SharedMLP
+    (1, 64, 20, 7, False, [40, 24, 9], [True, True, False]),     # ragged widths, both operands staged, 3 layers
+    (2, 32, 16, 0, False, [5], [True]),
+    (1, 96, 259, 0, False, [300, 130], [True, True]),
+])
+def test_conv1d_stack_vs_fp64(B, n, c0, c1, xyz1, widths, relus):
+    """csrc/conv1d_stack.hip vs the same chain in fp64 torch"""
+    from jmodt_amd.ops.conv1d import PackedConv1dStack
+    g = torch.Generator().manual_seed(B * 1000 + n + c0)
+    cin = c0 + c1
+    layers, k = [], cin
+    for w, r in zip(widths, relus):
+        layers.append(((torch.randn(w, k, generator=g) * (2.0 / k) ** 0.5).to(DEV), (torch.randn(w, generator=g) * 0.2).to(DEV), r))
+        k = w
+    x0 = torch.randn(B, c0, n, generator=g).to(DEV)
+    x1 = (torch.randn(B, n, 3, generator=g) if xyz1 else torch.randn(B, c1, n, generator=g)).to(DEV) if c1 else None
+    st = PackedConv1dStack(layers, c0, c1, xyz1)
+    assert st.supported(B, n)
+    got = st(x0, x1)
+    h = x0.double() if x1 is None else torch.cat([x0.double(), (x1.transpose(1, 2) if xyz1 else x1).double()], dim=1)
+    for W, b, r in layers:
+        h = torch.einsum("oc,bcn->bon", W.double(), h) + b.double()[None, :, None]
+        if r:
+            h = torch.relu(h)
+    assert got.shape == h.shape
+    close(got, h)
+    assert not PackedConv1dStack(layers, c0, c1, xyz1).supported(B, n + 1)          # n % 32

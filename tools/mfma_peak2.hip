@@ -4,14 +4,14 @@
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int MODE>
-__global__ void __launch_bounds__(256) probe(const float* __restrict__ W, float* out, long long* clk, int iters) {
+template <int MODE, int THREADS = 256>
+__global__ void __launch_bounds__(THREADS) probe(const float* __restrict__ W, float* out, long long* clk, int iters) {
     __shared__ float A[128 * 132];
-    for (int i = threadIdx.x; i < 128 * 132; i += 256) A[i] = i * 1e-4f;
+    for (int i = threadIdx.x; i < 128 * 132; i += THREADS) A[i] = i * 1e-4f;
     __syncthreads();
     f32x16 acc[2][2];
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lk = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, lr = lane & 31, lk = lane >> 5;
     const int a_off = lk * 132 + (wave >> 1) * 64 + lr;
     const float* bp = W + ((size_t)(wave & 1) * 64 + lr) * 16 + lk * 8;
     float4 bc[4], bn[4];
@@ -25,7 +25,13 @@ __global__ void __launch_bounds__(256) probe(const float* __restrict__ W, float*
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) { a[2 * kk] = q[(2 * kk) * 132]; a[2 * kk + 1] = q[(2 * kk) * 132 + 32]; }
     };
-    auto mm = [&](const float (&a)[16], const float4 (&b)[4]) {
+    float vsub[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) vsub[q] = A[q * 132 + lane] * 1e-3f;
+    auto mm = [&](const float (&a0)[16], const float4 (&b)[4]) {
+        float a[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = (MODE & 16) ? fmaxf(a0[q] - vsub[q], 0.f) : a0[q];
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             const float b0 = reinterpret_cast<const float*>(&b[0])[kk], b1 = reinterpret_cast<const float*>(&b[2])[kk];
@@ -76,19 +82,23 @@ __global__ void __launch_bounds__(256) probe(const float* __restrict__ W, float*
     if (threadIdx.x == 0) { clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = w1 - w0; }
 }
 
-template <int MODE>
+template <int MODE, int THREADS = 256>
 void run(const char* what) {
     const int wgs = 256, iters = 4000;
     float *out, *W; long long* clk;
-    hipMalloc(&out, sizeof(float) * wgs * 256); hipMalloc(&clk, sizeof(long long) * 2 * wgs);
+    hipMalloc(&out, sizeof(float) * wgs * THREADS); hipMalloc(&clk, sizeof(long long) * 2 * wgs);
     hipMalloc(&W, sizeof(float) * 2048 * 16); hipMemset(W, 0, sizeof(float) * 2048 * 16);
-    hipLaunchKernelGGL(probe<MODE>, dim3(wgs), dim3(256), 0, 0, W, out, clk, 10);
+    hipLaunchKernelGGL((probe<MODE, THREADS>), dim3(wgs), dim3(THREADS), 0, 0, W, out, clk, 10);
     hipDeviceSynchronize();
-    hipLaunchKernelGGL(probe<MODE>, dim3(wgs), dim3(256), 0, 0, W, out, clk, iters);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((probe<MODE, THREADS>), dim3(wgs), dim3(THREADS), 0, 0, W, out, clk, iters);
+    hipEventRecord(e1);
     hipDeviceSynchronize();
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     std::vector<long long> h(2 * wgs);
     hipMemcpy(h.data(), clk, sizeof(long long) * 2 * wgs, hipMemcpyDeviceToHost);
-    printf("%-44s cycles/MFMA %.1f   clock %.0f MHz\n", what, (double)h[0] / (iters * 64.0), (double)h[0] / (h[1] / 100.0));
+    printf("%-52s %d waves/SIMD: cycles per MFMA per SIMD %.1f   clock %.0f MHz  %.1f TF\n", what, THREADS / 256, (double)h[0] / (iters * 64.0) / (THREADS / 256), (double)h[0] / (h[1] / 100.0), (double)wgs * (THREADS / 64) * iters * 64.0 * 4096 / (ms * 1e-3) / 1e12);
 }
 
 int main() {
@@ -98,5 +108,12 @@ int main() {
     run<3>("+ both");
     run<7>("+ both + barrier per 2 k-tiles");
     run<11>("+ both + stage boundary per 8 k-tiles");
+    run<19>("+ both + relu(a - v) VALU on the A operand");
+    run<27>("+ both + VALU + stage boundary");
+    run<0, 512>("mm only");
+    run<3, 512>("+ both feeds");
+    run<11, 512>("+ both + stage boundary per 8 k-tiles");
+    run<19, 512>("+ both + relu(a - v) VALU on the A operand");
+    run<27, 512>("+ both + VALU + stage boundary");
     return 0;
 }

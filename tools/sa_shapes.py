@@ -15,6 +15,8 @@ def timeit(fn, iters=10):
 cases = [  # name, B, N, C, npoint, radii, nsamples, mlps (config.py:75-82, 134-139)
     ("RPN SA1", 8, 16384, 0, 4096, [0.1, 0.5], [16, 32], [[0, 16, 16, 32], [0, 32, 32, 64]]),
     ("RPN SA2", 8, 4096, 96, 1024, [0.5, 1.0], [16, 32], [[96, 64, 64, 128], [96, 64, 96, 128]]),
+    ("RPN SA3", 8, 1024, 256, 256, [1.0, 2.0], [16, 32], [[256, 128, 196, 256], [256, 128, 196, 256]]),
+    ("RPN SA4", 8, 256, 512, 64, [2.0, 4.0], [16, 32], [[512, 256, 256, 512], [512, 256, 384, 512]]),
     ("RCNN SA1", 1024, 512, 128, 128, [0.2], [64], [[128, 128, 128, 128]]),
     ("RCNN SA2", 1024, 128, 128, 32, [0.4], [64], [[128, 128, 128, 256]]),
 ]

@@ -6,7 +6,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from jmodt_amd import _lib
 from jmodt_amd.csrc import build as _hip_build
-_lib.LIB_PATH = _hip_build.TOOLS_LIB
+_lib.LIB_PATH = os.environ.get("JM_TOOLS_LIB", _hip_build.TOOLS_LIB)
 from jmodt_amd.ops.pointnet2 import fused, pointnet2_utils as pu
 from jmodt_amd.ops.pointnet2.pointnet2_modules import PointnetSAModule
 
