@@ -270,6 +270,14 @@ int jm_conv1d_stack_forward(int b, int n, int c0, const float* x0, int c1, const
                             const int* widths, const float* w0a, const float* w0b, const float* const* weights,
                             const float* const* biases, const int* relu, float* out, jm_stream_t stream);
 
+/* The image branch's first layer in one pass: out = relu(conv3x3(image, padding 1, stride 1) + bias) for a THREE-channel
+ * image (backbone.py:16-32, Img_Block[0].conv1 + bn1 + relu with the eval-mode BatchNorm folded by the caller).
+ * image (B, 3, H, W) NCHW; weight_tap_major (27, cout) = weight (cout, 3, 3, 3) permuted to [c][dy][dx] x cout; bias (cout);
+ * out (B, H, W, cout) = a channels-last (B, cout, H, W) tensor.  The layer writes 1 GB at 384 x 1280 x 8 frames and has
+ * K = 27: one HBM-bound pass instead of convolution + bias/ReLU pass.  cout % 4 == 0 and <= 32, or 64, or 128. */
+int jm_conv3x3_rgb_bias_relu(int b, int h, int w, int cout, const float* image, const float* weight_tap_major,
+                             const float* bias, float* out_channels_last, jm_stream_t stream);
+
 /* x = relu(x + bias[c]) in place on CHANNELS-LAST data (numel = pixels * channels, channels % 4 == 0): the one
  * element-wise pass of the image branch's BasicBlock (backbone.py:16-32) once its eval-mode BatchNorm is folded into
  * the first convolution (replaces a BatchNorm pass + a ReLU pass over up to 1 GB). */

@@ -90,6 +90,7 @@ SIGNATURES = {
     "jm_affinity_start_end_batched": (_I, [_I, _I, _I, _P, _P, ctypes.POINTER(Mlp3), _P, _P, _Z, _P]),
     "jm_conv1d_stack_supported": (_I, [_I, _I, _I, _I, _I, _I, _P]),
     "jm_conv1d_stack_forward": (_I, [_I, _I, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "jm_conv3x3_rgb_bias_relu": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "jm_linear_rows": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "jm_mlp3_workspace_bytes": (_Z, [_I, ctypes.POINTER(Mlp3)]),
     "jm_mlp3_forward": (_I, [_I, _P, ctypes.POINTER(Mlp3), _P, _P, _Z, _P]),

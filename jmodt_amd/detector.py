@@ -29,7 +29,8 @@ import torch.nn.functional as F
 from .ops import proposal as proposal_ops
 from .ops.affinity import linear_rows, make_affinity_mlp, pairwise_affinity, pairwise_affinity_batched
 from .ops.detections import DetectionCache, decode_rcnn_boxes, select_detections
-from .ops.fusion import PackedAttentionFusion, PackedImageFusion, bias_relu_, feature_gather
+from .ops.fusion import (PackedAttentionFusion, PackedImageFusion, bias_relu_, conv3x3_rgb_bias_relu, feature_gather,
+                         pack_rgb_weight)
 from .ops.pointnet2 import fused, pointnet2_utils
 from .ops.pointnet2 import pytorch_utils as pt_utils
 from .ops.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModule, PointnetSAModuleMSG
@@ -271,6 +272,7 @@ class DetectAffinityEngine(nn.Module):
         self.overlap = True                # FPS pyramid + image branch on side streams
         self.last_fps_idx: List[torch.Tensor] = []
         self.sparse_image_fusion = True    # final image feature only under the bilinear taps (else dense deconvolutions)
+        self.fuse_rgb_conv = True          # image branch's first (3-channel) convolution + bias + ReLU as one pass
         self.fuse_small_heads = True       # RCNN cls / reg heads: one MFMA launch per dense layer
         self.fuse_rcnn_lift = True         # xyz_up + merge_down (+ hoisted first SA layer) as one kernel
         self.fuse_attention = True         # LI-Fusion attention block as one kernel where it fits (else rocBLAS GEMMs)
@@ -401,7 +403,7 @@ class DetectAffinityEngine(nn.Module):
             image.record_stream(img_stream)
         img_maps, img_events = [], []
         with torch.cuda.stream(img_stream):
-            cur = image.contiguous(memory_format=torch.channels_last)
+            cur = image if self.fuse_rgb_conv and image.is_cuda else image.contiguous(memory_format=torch.channels_last)
             for i, blk in enumerate(net.Img_Block):
                 cur = self._t(f"image_block_{i + 1}(MIOpen)", 0, lambda k=i, c=cur: self._image_block(k, c))
                 ev = torch.cuda.Event()
@@ -489,8 +491,15 @@ class DetectAffinityEngine(nn.Module):
             b2 = blk.conv2.bias.detach() if blk.conv2.bias is not None else None
             return W, (bn.bias.detach() - bn.running_mean.detach() * scale).contiguous(), W2, b2
         W, b, W2, b2 = self._wb(f"img_block{i}", make)
-        y = F.conv2d(x, W, None, stride=1, padding=1)
-        return F.conv2d(bias_relu_(y, b), W2, b2, stride=blk.conv2.stride, padding=blk.conv2.padding)
+        if (self.fuse_rgb_conv and x.is_cuda and x.dtype == torch.float32 and x.shape[1] == 3 and W.shape[0] % 4 == 0
+                and (W.shape[0] <= 32 or W.shape[0] in (64, 128)) and tuple(blk.conv1.kernel_size) == (3, 3) and tuple(blk.conv1.stride) == (1, 1)
+                and tuple(blk.conv1.padding) == (1, 1)):
+            # the 3-channel first layer writes 1 GB and has K = 27: convolution + bias + ReLU as one HBM-bound pass
+            wt = self._wb(f"img_block{i}.rgb", lambda: pack_rgb_weight(W))
+            y = conv3x3_rgb_bias_relu(x, W, b, wt)
+        else:
+            y = bias_relu_(F.conv2d(x, W, None, stride=1, padding=1), b)
+        return F.conv2d(y, W2, b2, stride=blk.conv2.stride, padding=blk.conv2.padding)
 
     def _image_fusion_map(self, img_maps: List[torch.Tensor]) -> torch.Tensor:
         """relu(bn(conv1x1(cat_i deconv_i(img_i)))) (backbone.py:187-193).  The 1x1 fusion convolution is linear,

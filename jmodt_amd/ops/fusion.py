@@ -174,3 +174,26 @@ def bias_relu_(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     L.check(L.load().jm_bias_relu_channels_last(x.numel(), x.shape[1], ctypes.c_void_p(x.data_ptr()), L.dev(b, _f32, "bias"),
                                                 L.stream_ptr()), "bias_relu")
     return x
+
+
+@torch.no_grad()
+def conv3x3_rgb_bias_relu(image: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, packed=None) -> torch.Tensor:
+    """image (B, 3, H, W) NCHW, weight (cout, 3, 3, 3), bias (cout) -> relu(conv3x3(image, padding 1) + bias) as a
+    channels-last (B, cout, H, W) tensor, one pass (csrc/conv_rgb.hip).  `packed` = the (27, cout) tap-major weight when
+    the caller caches it (`pack_rgb_weight`)."""
+    import ctypes
+    x = image.to(_f32).contiguous()
+    B, C, H, W = x.shape
+    assert C == 3 and tuple(weight.shape[1:]) == (3, 3, 3)
+    cout = weight.shape[0]
+    wt = packed if packed is not None else pack_rgb_weight(weight)
+    b = bias.detach().to(_f32).contiguous()
+    out = torch.empty((B, cout, H, W), dtype=_f32, device=x.device, memory_format=torch.channels_last)
+    L.check(L.load().jm_conv3x3_rgb_bias_relu(B, H, W, cout, L.dev(x, _f32, "image"), L.dev(wt, _f32, "weight"), L.dev(b, _f32, "bias"),
+                                              ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "conv3x3_rgb")
+    return out
+
+
+def pack_rgb_weight(weight: torch.Tensor) -> torch.Tensor:
+    """(cout, 3, 3, 3) -> (27, cout) tap-major, the layout jm_conv3x3_rgb_bias_relu reads with scalar loads"""
+    return weight.detach().to(_f32).permute(1, 2, 3, 0).reshape(27, weight.shape[0]).contiguous()

@@ -17,6 +17,7 @@ import sys
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from jmodt_amd import synth
 
@@ -542,3 +543,18 @@ def test_conv1d_stack_vs_fp64(B, n, c0, c1, xyz1, widths, relus):
     assert got.shape == h.shape
     close(got, h)
     assert not PackedConv1dStack(layers, c0, c1, xyz1).supported(B, n + 1)          # n % 32
+
+
+@pytest.mark.parametrize("B,H,W,cout", [(2, 48, 160, 64), (1, 5, 7, 16), (1, 33, 300, 64), (2, 8, 256, 4), (1, 384, 1280, 64)])
+def test_conv3x3_rgb_bias_relu_vs_torch(B, H, W, cout):
+    """csrc/conv_rgb.hip (3-channel 3x3 convolution + bias + ReLU, channels-last output) vs fp64 torch conv2d"""
+    from jmodt_amd.ops.fusion import conv3x3_rgb_bias_relu
+    g = torch.Generator().manual_seed(H * W + cout)
+    img = torch.rand(B, 3, H, W, generator=g).to(DEV)
+    Wt = (torch.randn(cout, 3, 3, 3, generator=g) * 0.3).to(DEV)
+    b = (torch.randn(cout, generator=g) * 0.2).to(DEV)
+    got = conv3x3_rgb_bias_relu(img, Wt, b)
+    want = torch.relu(F.conv2d(img.double(), Wt.double(), b.double(), padding=1))
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert (want > 0).any() and (want == 0).any()
+    close(got, want)
