@@ -250,11 +250,25 @@ int jm_feature_gather_grad(int b, int c, int h, int w, int n, const float* grad_
  * One launch on 32-point tiles instead of 2 transposes + cat + 3 convolutions over (R, 128..256, S) tensors.
  * All matrices / biases in the layout of jm_sa_mlp_pack(cout, cin, 0); w_merge split column-wise into its h2 and C
  * parts; widths <= 128, S % 32 == 0, 3 <= K <= 16. */
+/* out_point_major != 0: out is (R, S, h) instead of (R, h, S) — the layout jm_sa_mlp_pm_forward gathers. */
 int jm_rcnn_lift_supported(int s, int k, int c, int h1, int h2, int hm, int ho);
 int jm_rcnn_lift_forward(int r, int s, int k, int c, int h1, int h2, int hm, int ho, const float* pts, const float* w_up1,
                          const float* b_up1, const float* w_up2, const float* b_up2, const float* w_merge_h,
                          const float* w_merge_f, const float* b_merge, const float* w_out_m, const float* w_out_x,
-                         const float* b_out, float* out, jm_stream_t stream);
+                         const float* b_out, int out_point_major, float* out, jm_stream_t stream);
+
+/* The pre-projected set-abstraction block (jm_sa_mlp_forward_pre) for exactly TWO layers after the hoisted one, on a
+ * POINT-major u (B, N, C) (C = 32, 64 or 128; the producers jm_conv1d_stack_forward / jm_rcnn_lift_forward write that
+ * layout on request): two MFMA waves per SIMD, row-major activation tiles read with 16-byte LDS loads, hidden layer
+ * computed transposed (csrc/sa_mlp_pm.hip).  w_hidden (hidden x C) and w_out (cout x hidden) are packed by
+ * jm_sa_mlp_pack(cout, cin, 0) AFTER the caller permuted their columns within every 16-block to
+ * [0, 8, 1, 9, 2, 10, ...] (source column 16 kt + 8 (j & 1) + (j >> 1) at position 16 kt + j), which makes a lane's
+ * eight k-values contiguous in the activation row; biases zero padded as jm_sa_mlp_pack writes them.
+ * out (B, cout, M).  hidden <= 128, cout <= 256, nsample in {16, 32, 64}, M * nsample % 128 == 0. */
+int jm_sa_mlp_pm_supported(int b, int n, int m, int c, int nsample, int hidden, int cout);
+int jm_sa_mlp_pm_forward(int b, int n, int m, int c, int nsample, int hidden, int cout, const float* u_point_major,
+                         const float* w1x, const float* new_xyz, const int* idx, const float* w_hidden, const float* b_hidden,
+                         const float* w_out, const float* b_out, float* out, jm_stream_t stream);
 
 /* A stack of 1..3 kernel-size-1 Conv1d layers (BatchNorm folded by the caller, optional ReLU each) on (B, C, n) tensors in
  * one launch: the RPN heads (rpn.py:34-58), the feature-propagation SharedMLPs on cat[interpolated, skip]
@@ -263,12 +277,14 @@ int jm_rcnn_lift_forward(int r, int s, int k, int c, int h1, int h2, int hm, int
  * channel concatenation without building it); xyz1 != 0: x1 is point-major coordinates (B, n, 3), c1 == 3.
  * widths[l] = output channels of layer l; weights in the layout of jm_sa_mlp_pack(cout, cin, 0): w0a (widths[0] x c0),
  * w0b (widths[0] x c1) or NULL, weights[1..] (weights[0] ignored), biases[0..]; relu[l] != 0 applies ReLU after layer l.
- * out (B, widths[num_layers-1], n).  n % 32 == 0; operands whose width is not a multiple of 16 and the hidden
+ * out (B, widths[num_layers-1], n), or (B, n, widths[num_layers-1]) when out_point_major != 0 (the layout
+ * jm_sa_mlp_pm_forward gathers).  n % 32 == 0; operands whose width is not a multiple of 16 and the hidden
  * activations of a 32-point tile must fit the 160 KB LDS (jm_conv1d_stack_supported). */
 int jm_conv1d_stack_supported(int b, int n, int c0, int c1, int xyz1, int num_layers, const int* widths);
 int jm_conv1d_stack_forward(int b, int n, int c0, const float* x0, int c1, const float* x1, int xyz1, int num_layers,
                             const int* widths, const float* w0a, const float* w0b, const float* const* weights,
-                            const float* const* biases, const int* relu, float* out, jm_stream_t stream);
+                            const float* const* biases, const int* relu, int out_point_major, float* out,
+                            jm_stream_t stream);
 
 /* The image branch's first layer in one pass: out = relu(conv3x3(image, padding 1, stride 1) + bias) for a THREE-channel
  * image (backbone.py:16-32, Img_Block[0].conv1 + bn1 + relu with the eval-mode BatchNorm folded by the caller).

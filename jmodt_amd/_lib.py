@@ -70,7 +70,7 @@ SIGNATURES = {
     "jm_feature_gather": (_I, [_I, _I, _I, _I, _I, _P, _L, _L, _L, _L, _P, _P, _P]),
     "jm_feature_gather_grad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _L, _L, _L, _L, _P]),
     "jm_rcnn_lift_supported": (_I, [_I] * 7),
-    "jm_rcnn_lift_forward": (_I, [_I] * 8 + [_P] * 13),
+    "jm_rcnn_lift_forward": (_I, [_I] * 8 + [_P] * 11 + [_I] + [_P] * 2),
     "jm_bias_relu_channels_last": (_I, [ctypes.c_longlong, _I, _P, _P, _P]),
     "jm_image_fusion_gather_workspace_bytes": (_Z, [_I, _I]),
     "jm_image_fusion_packed_elems": (_Z, [_I, _I]),
@@ -89,8 +89,10 @@ SIGNATURES = {
     "jm_affinity_start_end_batched_workspace_bytes": (_Z, [_I, _I, _I, ctypes.POINTER(Mlp3)]),
     "jm_affinity_start_end_batched": (_I, [_I, _I, _I, _P, _P, ctypes.POINTER(Mlp3), _P, _P, _Z, _P]),
     "jm_conv1d_stack_supported": (_I, [_I, _I, _I, _I, _I, _I, _P]),
-    "jm_conv1d_stack_forward": (_I, [_I, _I, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "jm_conv1d_stack_forward": (_I, [_I, _I, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "jm_conv3x3_rgb_bias_relu": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "jm_sa_mlp_pm_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),
+    "jm_sa_mlp_pm_forward": (_I, [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "jm_linear_rows": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "jm_mlp3_workspace_bytes": (_Z, [_I, ctypes.POINTER(Mlp3)]),
     "jm_mlp3_forward": (_I, [_I, _P, ctypes.POINTER(Mlp3), _P, _P, _Z, _P]),

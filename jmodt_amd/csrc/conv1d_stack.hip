@@ -32,7 +32,8 @@ struct ConvStackParams {
     const float *W0a, *W0b, *W1, *W2; // packed weights: layer 0 per operand, layers 1, 2
     const float *b0, *b1, *b2;        // packed biases
     int r0, r1, r2;                   // ReLU after layer l
-    float* out;                       // (B, w_last, n)
+    float* out;                       // (B, w_last, n), or (B, n, w_last) with out_pm
+    int out_pm;
 };
 
 __global__ void __launch_bounds__(256)
@@ -116,13 +117,21 @@ conv1d_stack_kernel(ConvStackParams p) {
         };
     };
     float* const outp = p.out;
+    const int out_pm = p.out_pm;
     auto to_out = [=](int oc, int relu) {
         float* outb = outp + (size_t)bi_ * oc * n + row0;
+        float* outr = outp + ((size_t)bi_ * n + row0) * oc;          // point-major: row stride oc
         return [=](const f32x16& a, int cb) __attribute__((always_inline)) {
             const int col = cb * 32 + lr;
             if (col >= oc) return;
-            float* o = outb + (size_t)col * n + 4 * lk;
             const float lo = relu ? 0.f : -__builtin_inff();
+            if (out_pm) {                                           // 32 lanes = 32 consecutive channels of one point
+                float* o = outr + (size_t)(4 * lk) * oc + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * oc] = fmaxf(a[r], lo);
+                return;
+            }
+            float* o = outb + (size_t)col * n + 4 * lk;
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 float4 v;
@@ -176,7 +185,8 @@ extern "C" int jm_conv1d_stack_supported(int b, int n, int c0, int c1, int xyz1,
 
 extern "C" int jm_conv1d_stack_forward(int b, int n, int c0, const float* x0, int c1, const float* x1, int xyz1, int num_layers,
                                        const int* widths, const float* w0a, const float* w0b, const float* const* weights,
-                                       const float* const* biases, const int* relu, float* out, jm_stream_t stream) {
+                                       const float* const* biases, const int* relu, int out_point_major, float* out,
+                                       jm_stream_t stream) {
     JM_REQUIRE(b >= 0 && n >= 0, "conv1d_stack: bad sizes");
     if (b == 0 || n == 0) return JM_OK;
     JM_REQUIRE(jm_conv1d_stack_supported(b, n, c0, c1, xyz1, num_layers, widths),
@@ -196,7 +206,7 @@ extern "C" int jm_conv1d_stack_forward(int b, int n, int c0, const float* x0, in
     p.W0a = w0a; p.W0b = w0b;
     if (num_layers > 1) { p.w1 = widths[1]; p.np1 = pad_to(widths[1], 128); p.r1 = relu[1]; p.b1 = biases[1]; p.W1 = weights[1]; }
     if (num_layers > 2) { p.w2 = widths[2]; p.np2 = pad_to(widths[2], 128); p.r2 = relu[2]; p.b2 = biases[2]; p.W2 = weights[2]; }
-    p.out = out;
+    p.out = out; p.out_pm = out_point_major ? 1 : 0;
     (void)hipFuncSetAttribute((const void*)conv1d_stack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(conv1d_stack_kernel, dim3((unsigned)(b * (n / 32))), dim3(256), pl.lds_bytes, (hipStream_t)stream, p);
     return check_launch("conv1d_stack");

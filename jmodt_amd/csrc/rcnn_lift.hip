@@ -27,7 +27,8 @@ struct RcnnLiftParams {
     const float* pts;                  // (R, S, K + C)
     const float *Wu1, *Wu2, *WmH, *WmF, *WoM, *WoX;   // packed: (h1 x K), (h2 x h1), (hm x h2), (hm x C), (ho x hm), (ho x K)
     const float *bu1, *bu2, *bm, *bo;  // packed biases (128)
-    float* out;                        // (R, hm or ho, S)
+    float* out;                        // (R, hm or ho, S), or (R, S, hm or ho) with out_pm
+    int out_pm;
     int tiles_per_roi;
 };
 
@@ -105,7 +106,14 @@ rcnn_lift_kernel(RcnnLiftParams p) {
         relu_out = false;
     }
     const int col = wave * 32 + lr;
-    if (col < cout) {
+    if (col < cout && p.out_pm) {              // point-major rows: 32 lanes = 32 consecutive channels of one point
+        float* o = p.out + ((size_t)roi * S + s0 + 4 * lk) * cout + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[0][r];
+            o[(size_t)((r & 3) + 8 * (r >> 2)) * cout] = relu_out ? fmaxf(v, 0.f) : v;
+        }
+    } else if (col < cout) {
         float* o = p.out + ((size_t)roi * cout + col) * S + s0 + 4 * lk;
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
@@ -134,8 +142,8 @@ extern "C" int jm_rcnn_lift_supported(int s, int k, int c, int h1, int h2, int h
 extern "C" int jm_rcnn_lift_forward(int r, int s, int k, int c, int h1, int h2, int hm, int ho, const float* pts,
                                     const float* w_up1, const float* b_up1, const float* w_up2, const float* b_up2,
                                     const float* w_merge_h, const float* w_merge_f, const float* b_merge,
-                                    const float* w_out_m, const float* w_out_x, const float* b_out, float* out,
-                                    jm_stream_t stream) {
+                                    const float* w_out_m, const float* w_out_x, const float* b_out, int out_point_major,
+                                    float* out, jm_stream_t stream) {
     JM_REQUIRE(r >= 0, "rcnn_lift: bad size");
     if (r == 0) return JM_OK;
     JM_REQUIRE(jm_rcnn_lift_supported(s, k, c, h1, h2, hm, ho), "rcnn_lift: unsupported shape (S %% 32 == 0, 3 <= K <= 16, widths <= 128)");
@@ -146,7 +154,7 @@ extern "C" int jm_rcnn_lift_forward(int r, int s, int k, int c, int h1, int h2, 
     RcnnLiftParams p{};
     p.S = s; p.K = k; p.C = c; p.cp = pad_to(c, 16); p.h1 = h1; p.h2 = h2; p.hm = hm; p.ho = ho;
     p.pts = pts; p.Wu1 = w_up1; p.Wu2 = w_up2; p.WmH = w_merge_h; p.WmF = w_merge_f; p.WoM = w_out_m; p.WoX = w_out_x;
-    p.bu1 = b_up1; p.bu2 = b_up2; p.bm = b_merge; p.bo = b_out; p.out = out; p.tiles_per_roi = s / 32;
+    p.bu1 = b_up1; p.bu2 = b_up2; p.bm = b_merge; p.bo = b_out; p.out = out; p.out_pm = out_point_major ? 1 : 0; p.tiles_per_roi = s / 32;
     const size_t lds_bytes = ((size_t)(16 + p.cp) * RL_XLD + 2 * 128 * SW_LD) * sizeof(float);
     (void)hipFuncSetAttribute((const void*)rcnn_lift_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL(rcnn_lift_kernel, dim3((unsigned)((long long)r * (s / 32))), dim3(256), lds_bytes, (hipStream_t)stream, p);

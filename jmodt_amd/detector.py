@@ -625,12 +625,13 @@ class DetectAffinityEngine(nn.Module):
                 lifted = packed
         l_xyz, first = xyz, 0
         if lifted is not None and lifted.ho:
-            u = lifted(pts_input)                                                      # (R, H1, S)
+            g0 = sa1.groupers[0]
+            pm = fused.pm_plan(sa1.mlps[0], pts_input.device, R, S, sa1.npoint, g0.nsample) is not None
+            u = lifted(pts_input, point_major=pm)                                      # (R, H1, S), or (R, S, H1) for sa_mlp_pm
             with prof.scope("rcnn_sa1"):
                 _, new_xyz = pointnet2_utils.farthest_point_sample_xyz(xyz, sa1.npoint)
-                g0 = sa1.groupers[0]
                 nb = pointnet2_utils.ball_query(g0.radius, g0.nsample, xyz, new_xyz)
-                l_feats = fused.sa_mlp_pre_from_u(u, new_xyz, nb, sa1.mlps[0])
+                l_feats = fused.sa_mlp_pre_from_u(u, new_xyz, nb, sa1.mlps[0], point_major=pm)
             l_xyz, first = new_xyz, 1
         elif lifted is not None:
             l_feats = lifted(pts_input)

@@ -46,18 +46,19 @@ class PackedConv1dStack:
         return bool(L.load().jm_conv1d_stack_supported(B, n, self.c0, self.c1, int(self.xyz1), len(self.widths), self._widths_c))
 
     @torch.no_grad()
-    def __call__(self, x0: torch.Tensor, x1: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x0 (B, c0, n), x1 (B, c1, n) — or (B, n, 3) with xyz1 — -> (B, widths[-1], n)"""
+    def __call__(self, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, point_major: bool = False) -> torch.Tensor:
+        """x0 (B, c0, n), x1 (B, c1, n) — or (B, n, 3) with xyz1 — -> (B, widths[-1], n), or (B, n, widths[-1]) with
+        point_major (the set-abstraction kernels gather whole rows of that layout)"""
         x0 = x0.to(_f32).contiguous()
         B, c0, n = x0.shape
         assert c0 == self.c0 and (x1 is None) == (self.c1 == 0)
         if x1 is not None:
             x1 = x1.to(_f32).contiguous()
             assert tuple(x1.shape) == ((B, n, 3) if self.xyz1 else (B, self.c1, n))
-        out = torch.empty((B, self.widths[-1], n), dtype=_f32, device=x0.device)
+        out = torch.empty((B, n, self.widths[-1]) if point_major else (B, self.widths[-1], n), dtype=_f32, device=x0.device)
         L.check(L.load().jm_conv1d_stack_forward(
             B, n, self.c0, L.dev(x0, _f32, "x0"), self.c1, L.dev(x1, _f32, "x1") if x1 is not None else None, int(self.xyz1),
             len(self.widths), self._widths_c, L.dev(self.w0a, _f32, "w0a"),
             L.dev(self.w0b, _f32, "w0b") if self.w0b is not None else None, self._w_c, self._b_c, self._relu_c,
-            ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "conv1d_stack")
+            int(point_major), ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "conv1d_stack")
         return out

@@ -111,6 +111,63 @@ _pre_cache = weakref.WeakKeyDictionary()      # module -> (signature, (W1, b1, p
 PRE_PROJECT = True    # first layer as per-point / per-centre GEMMs in front of the kernel where that applies
 
 
+PM_KERNEL = True      # two-layer pre-projected scales on csrc/sa_mlp_pm.hip (point-major u, two MFMA waves per SIMD)
+
+
+def _pack_k8(W: torch.Tensor, b: torch.Tensor):
+    """jm_sa_mlp_pack of a (cout, cin) weight whose columns are first zero padded to a multiple of 16 and permuted within
+    every 16-block so that MFMA lane (k-half lk, step kk) reads column 16 kt + 8 lk + kk (csrc/sa_mlp_pm.hip)"""
+    lib = L.load()
+    cout, cin = W.shape
+    kp = (cin + 15) // 16 * 16
+    Wz = torch.zeros((cout, kp), dtype=_f32, device=W.device)
+    Wz[:, :cin] = W
+    j = torch.arange(kp, device=W.device)
+    perm = (j // 16) * 16 + 8 * (j % 2) + (j % 16) // 2
+    Wq = Wz[:, perm].contiguous()
+    wp = torch.empty((lib.jm_sa_mlp_packed_weight_elems(cout, kp, 0),), dtype=_f32, device=W.device)
+    bp = torch.empty((lib.jm_sa_mlp_packed_bias_elems(cout),), dtype=_f32, device=W.device)
+    L.check(lib.jm_sa_mlp_pack(cout, kp, 0, L.dev(Wq, _f32, "W"), L.dev(b.contiguous(), _f32, "b"), ctypes.c_void_p(wp.data_ptr()),
+                               ctypes.c_void_p(bp.data_ptr()), L.stream_ptr()), "sa_mlp_pack")
+    return wp, bp
+
+
+def _pm_layers(mlp: nn.Sequential, device, extra: dict):
+    """(w_hidden, b_hidden, w_out, b_out, hidden, cout) of a scale with exactly two layers after the hoisted one, else None"""
+    if "pm" not in extra:
+        folded = fold_shared_mlp(mlp)
+        if len(folded) != 3:
+            extra["pm"] = None
+        else:
+            (W2, b2), (W3, b3) = [(W.to(device=device, dtype=_f32), b.to(device=device, dtype=_f32)) for W, b in folded[1:]]
+            extra["pm"] = _pack_k8(W2, b2) + _pack_k8(W3, b3) + (W2.shape[0], W3.shape[0])
+    return extra["pm"]
+
+
+def _sa_mlp_pm(u_pm: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w1x: torch.Tensor, pm) -> torch.Tensor:
+    """u_pm (B, N, C) point-major -> (B, cout, M) through jm_sa_mlp_pm_forward"""
+    wh, bh, wo, bo, hidden, cout = pm
+    B, N, C = u_pm.shape
+    M, ns = idx.shape[1], idx.shape[2]
+    out = torch.empty((B, cout, M), dtype=_f32, device=u_pm.device)
+    L.check(L.load().jm_sa_mlp_pm_forward(B, N, M, C, ns, hidden, cout, L.dev(u_pm, _f32, "u"), L.dev(w1x, _f32, "w1x"),
+                                          L.dev(new_xyz.contiguous(), _f32, "new_xyz"), L.dev(idx, _i32, "idx"), L.dev(wh, _f32, "w_hidden"),
+                                          L.dev(bh, _f32, "b_hidden"), L.dev(wo, _f32, "w_out"), L.dev(bo, _f32, "b_out"),
+                                          ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "sa_mlp_pm")
+    return out
+
+
+def pm_plan(mlp: nn.Sequential, device, B: int, N: int, M: int, ns: int):
+    """the point-major kernel's packed layers when this scale runs on it (callers then produce u as (B, N, C)), else None"""
+    if not PM_KERNEL:
+        return None
+    W1, b1, w1x, packed, extra = _pre_layers(mlp, device)
+    pm = _pm_layers(mlp, device, extra)
+    if pm is None or not L.load().jm_sa_mlp_pm_supported(B, N, M, W1.shape[0], ns, pm[4], pm[5]):
+        return None
+    return pm
+
+
 def _pre_layers(mlp: nn.Sequential, device):
     """the pre-projected form's operands: (W1 (H1, 3 + C) folded, b1, W1x (H1, 4), [(wp, bp, cout, cin)] of layers 2..L)"""
     tensors = list(mlp.parameters()) + list(mlp.buffers())
@@ -148,13 +205,22 @@ def _can_pre_project(mlp: nn.Sequential, features, idx, M: int, ns: int) -> bool
 
 
 @torch.no_grad()
-def sa_mlp_pre_from_u(u: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, mlp: nn.Sequential) -> torch.Tensor:
-    """layers 2..L + max-pool of a set-abstraction scale whose hoisted first layer u = W1 [xyz | f] + b1 (B, H1, N) was
-    computed by the producer of the features (ops/rcnn_lift.py): -> (B, mlp_out, M)"""
+def sa_mlp_pre_from_u(u: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, mlp: nn.Sequential,
+                      point_major: bool = False) -> torch.Tensor:
+    """layers 2..L + max-pool of a set-abstraction scale whose hoisted first layer u = W1 [xyz | f] + b1 was computed by
+    the producer of the features (ops/rcnn_lift.py): u (B, H1, N), or (B, N, H1) with point_major (the layout
+    `pm_plan` asks for) -> (B, mlp_out, M)"""
     lib = L.load()
     W1, b1, w1x, packed, _ = _pre_layers(mlp, u.device)
-    B, H1, N = u.shape
     M, ns = idx.shape[1], idx.shape[2]
+    if point_major:
+        B, N, H1 = u.shape
+        pm = pm_plan(mlp, u.device, B, N, M, ns)
+        if pm is not None:
+            prof.hoisted_flops(2 * B * M * ns * H1 * W1.shape[1])
+            return _sa_mlp_pm(u.contiguous(), new_xyz, idx, w1x, pm)
+        u = u.transpose(1, 2).contiguous()
+    B, H1, N = u.shape
     widths = [H1] + [cout for _, _, cout, _ in packed]
     nl = len(packed)
     prof.hoisted_flops(2 * B * M * ns * H1 * W1.shape[1])     # the first layer's per-row work this form avoids
@@ -190,16 +256,23 @@ def _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp):
     H1 = W1.shape[0]
     feats = features.to(_f32)
     u = None
+    pm = pm_plan(mlp, xyz.device, B, N, M, ns)
     if CONV1D_STACK and N % 32 == 0:
         st = extra.get("u_stack")
         if st is None:
             from ..conv1d import PackedConv1dStack
             st = extra["u_stack"] = PackedConv1dStack([(torch.cat([W1[:, 3:], W1[:, :3]], dim=1), b1, False)], W1.shape[1] - 3, 3, True)
         if st.supported(B, N):
-            u = st(feats, xyz)                                                        # (B, H1, N), one launch
+            u = st(feats, xyz, point_major=pm is not None)                            # (B, H1, N) or (B, N, H1), one launch
+            if pm is not None:
+                prof.hoisted_flops(2 * B * M * ns * H1 * W1.shape[1])
+                return _sa_mlp_pm(u, new_xyz, idx, w1x, pm)
     if u is None:
         u = torch.baddbmm(b1[None, :, None], W1[:, 3:].expand(B, -1, -1), feats)
         u = u.baddbmm_(W1[:, :3].expand(B, -1, -1), xyz.transpose(1, 2))
+        if pm is not None:
+            prof.hoisted_flops(2 * B * M * ns * H1 * W1.shape[1])
+            return _sa_mlp_pm(u.transpose(1, 2).contiguous(), new_xyz, idx, w1x, pm)
     widths = [H1] + [cout for _, _, cout, _ in packed]
     nl = len(packed)
     prof.hoisted_flops(2 * B * M * ns * H1 * W1.shape[1])     # the first layer's per-row work this form avoids

@@ -40,16 +40,18 @@ class PackedRcnnLift:
         return bool(L.load().jm_rcnn_lift_supported(S, self.K, self.C, self.h1, self.h2, self.hm, self.ho))
 
     @torch.no_grad()
-    def __call__(self, pts_input: torch.Tensor) -> torch.Tensor:
-        """pts_input (R, S, K + C) contiguous -> (R, hm, S) merged features, or (R, ho, S) = u when a layer is hoisted"""
+    def __call__(self, pts_input: torch.Tensor, point_major: bool = False) -> torch.Tensor:
+        """pts_input (R, S, K + C) contiguous -> (R, hm, S) merged features, or (R, ho, S) = u when a layer is hoisted;
+        point_major: (R, S, h) instead (the layout the point-major set-abstraction kernel gathers)"""
         p = pts_input.to(_f32).contiguous()
         R, S, _ = p.shape
-        out = torch.empty((R, self.ho or self.hm, S), dtype=_f32, device=p.device)
+        h = self.ho or self.hm
+        out = torch.empty((R, S, h) if point_major else (R, h, S), dtype=_f32, device=p.device)
 
         def ptr(t):
             return L.dev(t, _f32, "w") if t is not None else None
         L.check(L.load().jm_rcnn_lift_forward(R, S, self.K, self.C, self.h1, self.h2, self.hm, self.ho, L.dev(p, _f32, "pts_input"),
                                               ptr(self.wu1), ptr(self.bu1), ptr(self.wu2), ptr(self.bu2), ptr(self.wmh),
-                                              ptr(self.wmf), ptr(self.bm), ptr(self.wom), ptr(self.wox), ptr(self.bo),
+                                              ptr(self.wmf), ptr(self.bm), ptr(self.wom), ptr(self.wox), ptr(self.bo), int(point_major),
                                               ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "rcnn_lift")
         return out

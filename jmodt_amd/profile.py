@@ -117,6 +117,9 @@ ALGO: Dict[str, Callable] = {
         4 * _i(a, 0) * _i(a, 1) * (_i(a, 2) + _i(a, 4) + int(a[8][_i(a, 7) - 1])),
         2 * _i(a, 0) * _i(a, 1) * sum(k * int(a[8][l]) for l, k in enumerate([_i(a, 2) + _i(a, 4)] + [int(a[8][j]) for j in range(_i(a, 7) - 1)])), {}),
     "jm_conv3x3_rgb_bias_relu": lambda a: (4 * _i(a, 0) * _i(a, 1) * _i(a, 2) * (3 + _i(a, 3)), 0, {}),
+    "jm_sa_mlp_pm_forward": lambda a: (
+        4 * _i(a, 0) * (_i(a, 2) * _i(a, 4) * (_i(a, 3) + 1) + _i(a, 2) * _i(a, 6)),
+        2 * _i(a, 0) * _i(a, 2) * _i(a, 4) * (_i(a, 3) * _i(a, 5) + _i(a, 5) * _i(a, 6)), {}),
     "jm_linear_rows": lambda a: (4 * (_i(a, 0) * (_i(a, 1) + _i(a, 2)) + _i(a, 1) * _i(a, 2)), 2 * _i(a, 0) * _i(a, 1) * _i(a, 2), {}),
     "jm_mlp3_forward": lambda a: (0, _mlp3_flops(_i(a, 0), _mlp3(a[2])), {}),
     "jm_association_cost": lambda a: ((_i(a, 0) + _i(a, 2)) * 28 + 4 * _i(a, 0) * _i(a, 2), 0, {}),

@@ -323,7 +323,7 @@ def test_bench_workloads_smoke(workload, extra):
     names = " ".join(k["kernel"] for k in r["kernels"])
     if workload in ("detect", "train"):
         for needle in ("fps_pyramid/L1/furthest_point_sampling_xyz", "rpn_sa1/", "li_fusion1/feature_gather", "three_nn",
-                       "three_interpolate", "proposal_layer/", "roipool3d_canonical", "rcnn_sa1/sa_mlp_forward",
+                       "three_interpolate", "proposal_layer/", "roipool3d_canonical", "rcnn_sa1/sa_mlp_",
                        "detections/decode_rcnn_boxes", "nms_batched"):
             assert needle in names, (needle, names)
     if workload == "detect":
@@ -461,6 +461,8 @@ def test_rcnn_lift_kernel_and_hoisted_first_layer(run):
         u = torch.cat([rows[:, :3], m], 1) @ W1.double().t() + b1.double()
         got_m = PackedRcnnLift(up, merge)(x)
         got_u = PackedRcnnLift(up, merge, (W1, b1))(x)
+        got_u_pm = PackedRcnnLift(up, merge, (W1, b1))(x, point_major=True)      # (R, S, h): the layout sa_mlp_pm gathers
+        assert got_u_pm.shape == (R, S, 128) and torch.equal(got_u_pm.transpose(1, 2), got_u)
     close(got_m, m.view(R, S, -1).transpose(1, 2))
     close(got_u, u.view(R, S, -1).transpose(1, 2))
 
@@ -542,6 +544,8 @@ def test_conv1d_stack_vs_fp64(B, n, c0, c1, xyz1, widths, relus):
             h = torch.relu(h)
     assert got.shape == h.shape
     close(got, h)
+    got_pm = st(x0, x1, point_major=True)
+    assert got_pm.shape == (B, n, widths[-1]) and torch.equal(got_pm.transpose(1, 2), got)
     assert not PackedConv1dStack(layers, c0, c1, xyz1).supported(B, n + 1)          # n % 32
 
 

@@ -792,9 +792,14 @@ def test_dense_config_sizes_vs_oracle(oracle):
 @pytest.mark.parametrize("N,npoint,C,ns,mlp,extent", [(512, 128, 128, 64, [128, 128, 128, 128], 3.0),       # RCNN SA1
                                                       (128, 32, 128, 64, [128, 128, 128, 256], 3.0),       # RCNN SA2
                                                       (4096, 1024, 96, 32, [96, 64, 96, 128], 60.0),        # RPN SA2, KITTI-sized coordinates
-                                                      (600, 64, 40, 16, [40, 32, 72, 48], 8.0)])            # nsample 16: 8 centres per tile
-def test_fused_sa_pre_projected_first_layer(N, npoint, C, ns, mlp, extent):
-    """the first layer hoisted in front of the gather (u = W1 [xyz | f] + b1 per point, relu(u_j - W1x c_i) formed in the
+                                                      (600, 64, 40, 16, [40, 32, 72, 48], 8.0),            # nsample 16: 8 centres per tile
+                                                      (256, 64, 64, 16, [64, 32, 32, 32], 6.0),            # one 32-column block per layer: half the MFMA waves skip it
+                                                      (256, 64, 61, 32, [61, 64, 80, 64], 6.0),            # hidden 80: 3 blocks, odd k-tile count
+                                                      (128, 64, 64, 16, [64, 32, 48, 64], 6.0)])
+@pytest.mark.parametrize("pm", [True, False])
+def test_fused_sa_pre_projected_first_layer(N, npoint, C, ns, mlp, extent, pm):
+    """pm: the two-layer point-major kernel (csrc/sa_mlp_pm.hip) or the k-major one (csrc/sa_mlp.hip).
+    The first layer hoisted in front of the gather (u = W1 [xyz | f] + b1 per point, relu(u_j - W1x c_i) formed in the
     kernel: jm_sa_mlp_forward_pre) vs the same kernel with the first layer evaluated per (centre, sample) row vs the
     un-fused module; coordinates up to the KITTI range (the subtraction u_j - W1x c_i cancels W1x-scaled coordinates)"""
     from jmodt_amd.ops.pointnet2 import fused
@@ -807,8 +812,20 @@ def test_fused_sa_pre_projected_first_layer(N, npoint, C, ns, mlp, extent):
     xyz = T(synth.dense_cloud(B, N, 29, extent=extent) + np.float32(extent))
     feats = torch.randn(B, C, N, device=DEV)
     assert fused._can_pre_project(sa.mlps[0], feats, torch.zeros(B, npoint, ns), npoint, ns)
+    from jmodt_amd.profile import prof
     with torch.no_grad():
-        nx, f_pre, _ = sa(xyz, feats)
+        fused.PM_KERNEL = pm
+        prof.reset()
+        prof.enabled = True
+        try:
+            nx, f_pre, _ = sa(xyz, feats)
+            torch.cuda.synchronize()
+            used = set(prof.records)
+        finally:
+            fused.PM_KERNEL = True
+            prof.enabled = False
+            prof.reset()
+        assert any("sa_mlp_pm_forward" in k for k in used) == pm and any("sa_mlp_forward_pre" in k for k in used) == (not pm), used
         fused.PRE_PROJECT = False
         try:
             _, f_row, _ = sa(xyz, feats)

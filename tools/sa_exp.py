@@ -30,6 +30,11 @@ tag = os.path.basename(_lib.LIB_PATH)
 ms = timeit(lambda: fused.sa_mlp_pre_from_u(u, new_xyz, idx, sa.mlps[0]))
 mf = R * M * ns / 128 / 256 * 512          # MFMAs per wave
 print(f"{tag:36s} hoisted {ms:.3f} ms = {ms * 1e-3 * 2.4e9 / mf:.1f} cycles@2.4GHz per MFMA (incl. epilogues)", flush=True)
+u_pm = u.transpose(1, 2).contiguous()
+ms = timeit(lambda: fused.sa_mlp_pre_from_u(u_pm, new_xyz, idx, sa.mlps[0], point_major=True))
+print(f"{tag:36s} point-major kernel {ms:.3f} ms = {ms * 1e-3 * 2.4e9 / mf:.1f} cycles@2.4GHz per MFMA-slot  ({2 * R * M * ns * 2 * 128 * 128 / ms / 1e9:.1f} TF executed)", flush=True)
+a = fused.sa_mlp_pre_from_u(u_pm, new_xyz, idx, sa.mlps[0], point_major=True); b = fused.sa_mlp_pre_from_u(u, new_xyz, idx, sa.mlps[0])
+print("   max |pm - k-major| =", (a - b).abs().max().item(), " max |out| =", b.abs().max().item())
 fused.PRE_PROJECT = False
 ms = timeit(lambda: fused.sa_mlp_fused(xyz, new_xyz, feats, idx, sa.mlps[0]))
 print(f"{tag:36s} row-wise {ms:.3f} ms = {ms * 1e-3 * 2.4e9 / (mf / 512 * 800):.1f} cycles@2.4GHz per MFMA", flush=True)

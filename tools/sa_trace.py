@@ -35,3 +35,19 @@ for label, fn in (("hoisted (pre) 128->128->128", lambda: fused.sa_mlp_pre_from_
     for k in range(6):
         print(f"   {names[k]:28s} {int(np.median(d[:, k])):7d}")
     print(f"   {'(stamp 6 -> next stamp 0)':28s} {int(np.median(t[1:, 0] - t[:-1, 6])):7d}")
+
+# ---- the point-major kernel (csrc/sa_mlp_pm.hip)
+raw.jm_tools_set_pm_trace.argtypes = [ctypes.c_void_p]
+u_pm = u.transpose(1, 2).contiguous()
+fn = lambda: fused.sa_mlp_pre_from_u(u_pm, new_xyz, idx, sa.mlps[0], point_major=True)
+fn(); torch.cuda.synchronize()
+trace.zero_()
+raw.jm_tools_set_pm_trace(ctypes.c_void_p(trace.data_ptr()))
+fn(); torch.cuda.synchronize()
+raw.jm_tools_set_pm_trace(None)
+t = trace.cpu().numpy().reshape(64, 8)[4:60]
+d = np.diff(t[:, :7], axis=1)
+print("point-major kernel, median cycles per tile:", int(np.median(np.diff(t[:, 0]))))
+for k, nm in enumerate(["hidden layer k-loop (incl. bias init)", "hidden epilogue (b128 stores)", "barrier 1 wait", "last layer k-loop", "max-pool partials", "barrier 2 wait"]):
+    print(f"   {nm:40s} {int(np.median(d[:, k])):7d}")
+print(f"   {'output phase + next tile set-up':40s} {int(np.median(t[1:, 0] - t[:-1, 6])):7d}")
