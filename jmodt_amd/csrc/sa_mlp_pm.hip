@@ -338,7 +338,11 @@ __global__ void __launch_bounds__(768)
 sa_mlp_pm_kernel(SaPmParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
-    if (tid < 512) { if (PM_DBG(32)) __builtin_amdgcn_s_setprio(3); pm_mfma_role(p, lds, tid); }
+    if (tid < 512) {
+        if (PM_DBG(32)) __builtin_amdgcn_s_setprio(3);
+        if (PM_DBG(64)) { if (tid >= 256) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1); }
+        pm_mfma_role(p, lds, tid);
+    }
     else if (p.C == 128) pm_gather_role<16>(p, lds, tid - 512);
     else if (p.C == 64) pm_gather_role<8>(p, lds, tid - 512);
     else pm_gather_role<4>(p, lds, tid - 512);

@@ -15,7 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # bench row (kernels[].kernel) -> (workload, kernel-name substring in the rocprof tables)
 MAP = {
     # default workload (detect): the largest-shape dispatch of each kernel = the row named here
-    "rcnn_sa1/sa_mlp_forward_pre": ("detect", "sa_mlp_kernel"),
+    "rcnn_sa1/sa_mlp_pm_forward": ("detect", "sa_mlp_pm_kernel"),
+    "conv3x3_rgb_bias_relu": ("detect", "conv3x3_rgb_kernel"),
+    "conv1d_stack_forward": ("detect", "conv1d_stack_kernel"),
     "fps_pyramid/L1/furthest_point_sampling_xyz": ("detect", "fps_regs2_kernel<16, 1024>"),
     "roipool3d_canonical": ("detect", "roipool3d_kernel"),
     "li_fusion_final/image_fusion_gather": ("detect", "if_gemm_kernel"),
