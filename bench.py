@@ -21,8 +21,9 @@ barrier + synchronize and the MAX over ranks is used.
 
 One JSON line on rank 0.  `kernels` lists every C-ABI entry point of the step with its algorithmic bytes /
 flops (jmodt_amd/profile.py: SURVEY.md §8(d) formulas evaluated on the call's own arguments) and its time from
-HIP events recorded on the launching stream inside the timed region, plus the caller-side torch spans
-(MIOpen / rocBLAS) and the exposed waits on the FPS / image side streams; `roofline` is the dominant jm
+HIP events recorded on the launching stream inside the timed region, plus caller-side spans (`name(MIOpen)` /
+`name(rocBLAS)` = library calls; `name(span)` = a stage that wraps jm entries listed on their own) and the exposed
+waits on the FPS / image side streams; `roofline` is the dominant jm
 entry; `cpu_baseline` is the chained CPU oracle (oracle/pipeline.py: the C restatement for the jmodt ops + the
 same PyTorch-CPU operators the reference calls for everything else) on a bounded sample.
 """

@@ -457,7 +457,7 @@ class DetectAffinityEngine(nn.Module):
             prof.stall(f"image_exposed_wait_L{i + 1}", lambda e=img_events[i]: main.wait_event(e))
             with prof.scope(f"li_fusion{i + 1}"):
                 gathered = feature_gather(img_maps[i], xy_i)
-                feats = self._t("attention_fusion(rocBLAS)", 0, lambda f=feats, g=gathered, k=i: self._attention_fusion(
+                feats = self._t("attention_fusion(span)", 0, lambda f=feats, g=gathered, k=i: self._attention_fusion(
                     f"fusion{k}", net.Fusion_Conv[k], f, g))
             l_xyz.append(new_xyz); l_feats.append(feats); l_xy.append(xy_i)
         # --- feature propagation, coarse to fine (backbone.py:182-185) ---
@@ -469,7 +469,7 @@ class DetectAffinityEngine(nn.Module):
         with prof.scope("li_fusion_final"):
             # sparse: the fused image feature evaluated only under the points' bilinear taps (csrc/image_fusion.hip)
             gathered = sparse(img_maps, pts_xy, H, W) if sparse is not None else feature_gather(fused_map, pts_xy)
-            out = self._t("attention_fusion(rocBLAS)", 0, lambda: self._attention_fusion(
+            out = self._t("attention_fusion(span)", 0, lambda: self._attention_fusion(
                 "fusion_final", net.final_fusion_img_point, l_feats[0], gathered))
         pyr.release()
         if next_image is not None and self.prefetch_image_late and self.prefetch_image and self.overlap:
@@ -558,7 +558,7 @@ class DetectAffinityEngine(nn.Module):
             cls = self._head_forward("rpn_cls", self.rpn.rpn_cls_layer, feats).transpose(1, 2).contiguous()   # (B, N, 1)
             reg = self._head_forward("rpn_reg", self.rpn.rpn_reg_layer, feats).transpose(1, 2).contiguous()   # (B, N, C)
             return cls, reg
-        rpn_cls, rpn_reg = self._t("rpn_heads(rocBLAS)", 0, heads)
+        rpn_cls, rpn_reg = self._t("rpn_heads(span)", 0, heads)
         return dict(rpn_cls=rpn_cls, rpn_reg=rpn_reg, backbone_xyz=xyz, backbone_features=feats)
 
     # -- stage 2: proposals + RoI pooling + RCNN ---------------------------------------------------------
@@ -643,7 +643,7 @@ class DetectAffinityEngine(nn.Module):
                 continue
             with prof.scope(f"rcnn_sa{i + 1}"):
                 l_xyz, l_feats, _ = sa(l_xyz, l_feats)
-        rcnn_cls, rcnn_reg = self._t("rcnn_heads(rocBLAS)", 0, lambda: (
+        rcnn_cls, rcnn_reg = self._t("rcnn_heads(span)", 0, lambda: (
             self._head_forward("rcnn_cls", net.cls_layer, l_feats).squeeze(-1),
             self._head_forward("rcnn_reg", net.reg_layer, l_feats).squeeze(-1)))
         return dict(rcnn_cls=rcnn_cls, rcnn_reg=rcnn_reg, rcnn_feat=l_feats)

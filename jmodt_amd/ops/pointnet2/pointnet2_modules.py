@@ -129,7 +129,7 @@ class PointnetFPModule(nn.Module):
         if not torch.is_grad_enabled() and not self.training and carried.is_cuda:
             # inference: one batched GEMM per layer (BatchNorm folded), skip concatenation never materialised
             parts = [carried] if unknow_feats is None else [carried, unknow_feats]
-            out = prof.region("fp_mlp(rocBLAS)", lambda: fused.shared_mlp_points(self.mlp, parts))
+            out = prof.region("fp_mlp(span)", lambda: fused.shared_mlp_points(self.mlp, parts))
             if out is not None:
                 return out
         stacked = carried if unknow_feats is None else torch.cat((carried, unknow_feats), dim=1)
