@@ -75,7 +75,7 @@ class _PointnetSAModuleBase(nn.Module):
             else:
                 grouped = grouper(xyz, new_xyz, features)
             pooled.append(prof.region("unfused_mlp+pool(MIOpen)", lambda g=grouped, f=mlp: self._pool(f(g))))
-        return new_xyz, torch.cat(pooled, dim=1), idx
+        return new_xyz, (pooled[0] if len(pooled) == 1 else torch.cat(pooled, dim=1)), idx     # one scale: no copy
 
 
 class PointnetSAModuleMSG(_PointnetSAModuleBase):

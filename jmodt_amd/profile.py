@@ -129,6 +129,9 @@ ALGO: Dict[str, Callable] = {
 }
 
 
+VALU_F32_PEAK_TF = 157.3      # fp32 vector peak (256 CUs x 4 SIMD x 2.4 GHz x 64 flops per cycle)
+
+
 class Profiler:
     def __init__(self):
         self.enabled = False
@@ -217,8 +220,12 @@ class Profiler:
                 row["executed_flops_per_step"] = int(xf)
                 row["executed_mfma_frac"] = round(xf / (ms * 1e-3) / 1e12 / mfma_peak_tf, 4) if ms > 0 else 0.0
             if "evals" in ex:
+                # pairwise point evaluations (distance + compare / select): the brute-force searches are VALU-bound, not
+                # HBM-bound — priced at 8 fp32 operations per evaluation (3 sub, 3 mul/fma, compare, select) against the
+                # vector peak (= the 157.3 TFLOP/s of MI355X_MICROARCH.md's fp32 row, 2 flops per lane-FMA)
                 ev = sum(r[4].get("evals", 0) for r in evs) / steps
                 row["evals_per_s"] = round(ev / (ms * 1e-3), 1) if ms > 0 else 0.0
+                row["valu_frac"] = round(8.0 * ev / (ms * 1e-3) / 1e12 / VALU_F32_PEAK_TF, 4) if ms > 0 else 0.0
             if "iterations" in ex:
                 it = sum(r[4]["iterations"] for r in evs) / steps
                 row["us_per_fps_iteration"] = round(ms * 1e3 / it, 4)
