@@ -650,19 +650,29 @@ class DetectAffinityEngine(nn.Module):
 
     # -- the whole path ----------------------------------------------------------------------------------
     @torch.no_grad()
-    def detect(self, xyz, image, pts_xy, next_xyz=None, next_image=None) -> Tuple[DetectionCache, Dict[str, torch.Tensor]]:
-        """frames -> device-resident detections (boxes, scores, 512-d features, per-frame counts)"""
-        cfg = self.cfg
+    def _trunk(self, xyz, image, pts_xy, next_xyz=None, next_image=None):
         rpn_out = self.rpn_forward(xyz, image, pts_xy, next_xyz, next_image)
         rois, roi_scores = self.proposals(rpn_out)
         pts_input = self.roi_pool(rpn_out, rois)
         out = self.rcnn_forward(pts_input)
+        return rpn_out, rois, roi_scores, pts_input, out
+
+    @torch.no_grad()
+    def _detections(self, rois, out) -> Tuple[DetectionCache, torch.Tensor]:
+        cfg = self.cfg
         B, M = rois.shape[:2]
         with prof.scope("detections"):
             boxes = decode_rcnn_boxes(rois.view(-1, 7), out["rcnn_reg"], cfg.rcnn_loc_scope, cfg.rcnn_loc_bin_size,
                                       cfg.rcnn_num_head_bin, cfg.mean_size).view(B, M, 7)
             feats = out["rcnn_feat"].view(B, M, -1)
             cache = select_detections(boxes, out["rcnn_cls"].view(B, M), feats, cfg.rcnn_score_thresh, cfg.rcnn_nms_thresh)
+        return cache, boxes
+
+    @torch.no_grad()
+    def detect(self, xyz, image, pts_xy, next_xyz=None, next_image=None) -> Tuple[DetectionCache, Dict[str, torch.Tensor]]:
+        """frames -> device-resident detections (boxes, scores, 512-d features, per-frame counts)"""
+        rpn_out, rois, roi_scores, pts_input, out = self._trunk(xyz, image, pts_xy, next_xyz, next_image)
+        cache, boxes = self._detections(rois, out)
         inter = dict(rpn_out, rois=rois, roi_scores_raw=roi_scores, pts_input=pts_input, pred_boxes3d=boxes, **out)
         return cache, inter
 
@@ -671,12 +681,31 @@ class DetectAffinityEngine(nn.Module):
         """detect + affinity of every frame against its predecessor in the batch (frame 0 against the last):
         returns (DetectionCache, [(A (M, M), start (M), end (M)) per frame]) with all M RoI slots as the
         affinity operands (fixed work per frame: P = D = M)."""
-        cache, inter = self.detect(xyz, image, pts_xy, next_xyz, next_image)
-        feats = inter["rcnn_feat"].view(cache.boxes.shape[0], cache.boxes.shape[1], -1)
-        B, M, C = feats.shape
+        rpn_out, rois, roi_scores, pts_input, out = self._trunk(xyz, image, pts_xy, next_xyz, next_image)
+        B, M = rois.shape[:2]
+        dev = rois.device
+        main = torch.cuda.current_stream(dev) if rois.is_cuda else None
+        # box decode + score filter + per-frame NMS + gathers (two dozen latency-bound launches) do not feed the affinity
+        # head (it takes all M RoI slots): they run on a side stream under the affinity GEMMs
+        side = side_stream(dev, 3) if (self.overlap and rois.is_cuda) else None
+        if side is not None:
+            side.wait_stream(main)
+            for t in (rois, out["rcnn_reg"], out["rcnn_cls"], out["rcnn_feat"]):
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                cache, boxes = self._detections(rois, out)
+        else:
+            cache, boxes = self._detections(rois, out)
+        feats = out["rcnn_feat"].view(B, M, -1)
+        C = feats.shape[2]
         link, se = self.rcnn_net.link_layer, self.rcnn_net.se_layer
         with prof.scope(f"affinity_{B}x{M}x{M}"):
             # every frame against its predecessor, all B problems as one GEMM chain (jm_affinity_forward_batched)
             A, start, end = pairwise_affinity_batched(torch.roll(feats, 1, 0), feats, link, se)
             aff = [(A[b], start[b], end[b]) for b in range(B)]
+        if side is not None:
+            main.wait_stream(side)
+            for t in (boxes, cache.boxes, cache.scores, cache.raw_scores, cache.feats, cache.count, cache.roi_index):
+                t.record_stream(main)
+        inter = dict(rpn_out, rois=rois, roi_scores_raw=roi_scores, pts_input=pts_input, pred_boxes3d=boxes, **out)
         return cache, aff, inter
