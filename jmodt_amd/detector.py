@@ -575,17 +575,28 @@ class DetectAffinityEngine(nn.Module):
                 loc_bin_size=cfg.rpn_loc_bin_size, num_head_bin=cfg.rpn_num_head_bin, anchor_size=cfg.mean_size)
 
     @torch.no_grad()
-    def roi_pool(self, rpn_out: Dict[str, torch.Tensor], rois: torch.Tensor) -> torch.Tensor:
-        """ProposalTargetLayer.forward in EVAL mode (proposal_target_layer.py:16-34,99-115): per-point
-        [mask, depth, rpn features] -> pooled (B*M, S, 3 + 2 + C) in each RoI's canonical frame"""
+    def pts_feature(self, rpn_out: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """per-point [mask, depth, rpn features] (B, N, 2 + C) of ProposalTargetLayer.forward in EVAL mode
+        (point_rcnn.py:42-44, proposal_target_layer.py:26): independent of the proposals"""
         cfg = self.cfg
         xyz, feats = rpn_out["backbone_xyz"], rpn_out["backbone_features"]
         B, N, _ = xyz.shape
         C = feats.shape[1]
-        pts_feature = torch.empty((B, N, 2 + C), dtype=torch.float32, device=xyz.device)
-        pts_feature[:, :, 0] = (torch.sigmoid(rpn_out["rpn_cls"][:, :, 0]) > cfg.rpn_score_thresh).float()   # point_rcnn.py:42-43
-        pts_feature[:, :, 1] = torch.norm(xyz, p=2, dim=2) / 70.0 - 0.5                                       # :44; ptl.py:26
-        pts_feature[:, :, 2:] = feats.transpose(1, 2)
+        pf = torch.empty((B, N, 2 + C), dtype=torch.float32, device=xyz.device)
+        pf[:, :, 0] = (torch.sigmoid(rpn_out["rpn_cls"][:, :, 0]) > cfg.rpn_score_thresh).float()   # point_rcnn.py:42-43
+        pf[:, :, 1] = torch.norm(xyz, p=2, dim=2) / 70.0 - 0.5                                       # :44; ptl.py:26
+        pf[:, :, 2:] = feats.transpose(1, 2)
+        return pf
+
+    def roi_pool(self, rpn_out: Dict[str, torch.Tensor], rois: torch.Tensor, pts_feature: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """ProposalTargetLayer.forward in EVAL mode (proposal_target_layer.py:16-34,99-115): per-point
+        [mask, depth, rpn features] -> pooled (B*M, S, 3 + 2 + C) in each RoI's canonical frame"""
+        cfg = self.cfg
+        xyz = rpn_out["backbone_xyz"]
+        B = xyz.shape[0]
+        if pts_feature is None:
+            pts_feature = self.pts_feature(rpn_out)
+        C = pts_feature.shape[2] - 2
         M, S = rois.shape[1], cfg.rcnn_num_points
         pooled, _ = roipool3d_canonical_gpu(xyz, pts_feature, rois, cfg.pool_extra_width, S)
         return pooled.view(B * M, S, 5 + C)
@@ -652,8 +663,21 @@ class DetectAffinityEngine(nn.Module):
     @torch.no_grad()
     def _trunk(self, xyz, image, pts_xy, next_xyz=None, next_image=None):
         rpn_out = self.rpn_forward(xyz, image, pts_xy, next_xyz, next_image)
+        pf = None
+        if self.overlap and xyz.is_cuda:
+            # the roipool input (mask, depth, transposed features: half a dozen element-wise passes) does not depend on the
+            # proposals: built on a side stream under the proposal layer's sort / decode / NMS chain
+            main, side = torch.cuda.current_stream(xyz.device), side_stream(xyz.device, 3)
+            side.wait_stream(main)
+            for t in (rpn_out["rpn_cls"], rpn_out["backbone_features"], xyz):
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                pf = self.pts_feature(rpn_out)
+            pf.record_stream(main)
         rois, roi_scores = self.proposals(rpn_out)
-        pts_input = self.roi_pool(rpn_out, rois)
+        if pf is not None:
+            main.wait_stream(side)
+        pts_input = self.roi_pool(rpn_out, rois, pf)
         out = self.rcnn_forward(pts_input)
         return rpn_out, rois, roi_scores, pts_input, out
 
