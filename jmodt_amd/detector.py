@@ -375,7 +375,7 @@ class DetectAffinityEngine(nn.Module):
         (the four convolution blocks depend on the image alone, backbone.py:162-168), which then no longer holds the
         point branch of the next call at every LI-Fusion level.  The next call must pass the same tensor objects."""
         if self.overlap:
-            self._prefetched = (xyz, FpsPyramid(xyz, list(self.cfg.sa_npoints), overlap=True))
+            self._prefetched = (xyz, FpsPyramid(xyz, list(self.cfg.sa_npoints), overlap=True, with_interp=True))
             if image is not None and self.prefetch_image:
                 self._prefetched_img = (image, self._launch_image_branch(image))
 
@@ -435,7 +435,7 @@ class DetectAffinityEngine(nn.Module):
         main = torch.cuda.current_stream(dev)
         B, N, _ = xyz.shape
         # --- stream F: the whole FPS chain (coordinates only); already running if this batch was announced ---
-        pyr = self._take_prefetched(xyz) or FpsPyramid(xyz, list(cfg.sa_npoints), overlap=self.overlap)
+        pyr = self._take_prefetched(xyz) or FpsPyramid(xyz, list(cfg.sa_npoints), overlap=self.overlap, with_interp=self.overlap)
         # --- stream I: image pyramid; already running (or done) if this batch's image was announced ---
         ib = self._take_prefetched_image(image) or self._launch_image_branch(image)
         if next_xyz is not None:
@@ -463,7 +463,8 @@ class DetectAffinityEngine(nn.Module):
         # --- feature propagation, coarse to fine (backbone.py:182-185) ---
         for i in range(-1, -(len(net.FP_modules) + 1), -1):
             with prof.scope(f"fp{len(net.FP_modules) + 1 + i}"):
-                l_feats[i - 1] = net.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i])
+                l_feats[i - 1] = net.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i],
+                                                   interp=pyr.interp(len(net.FP_modules) + i))
         # --- final image fusion on the full cloud (backbone.py:187-195) ---
         prof.stall("image_exposed_wait_final", lambda: main.wait_event(fused_ev))
         with prof.scope("li_fusion_final"):

@@ -115,10 +115,13 @@ class PointnetFPModule(nn.Module):
         self.mlp = pt_utils.SharedMLP(mlp, bn=bn, activation=activation)
 
     def forward(self, unknown: torch.Tensor, known: Optional[torch.Tensor], unknow_feats: Optional[torch.Tensor],
-                known_feats: torch.Tensor) -> torch.Tensor:
+                known_feats: torch.Tensor, interp=None) -> torch.Tensor:
         """unknown (B, n, 3), known (B, m, 3), unknow_feats (B, C1, n), known_feats (B, C2, m)
-        -> (B, mlp[-1], n)"""
-        if known is None:
+        -> (B, mlp[-1], n).  interp = (nn3, weights) when the caller has the neighbour search already
+        (ops/pointnet2/pyramid.py: it depends on coordinates only)"""
+        if interp is not None:
+            carried = pointnet2_utils.three_interpolate(known_feats, interp[0], interp[1])
+        elif known is None:
             # a single global feature vector: broadcast it to every fine point
             carried = known_feats.expand(known_feats.shape[0], known_feats.shape[1], unknown.shape[1])
         else:

@@ -38,7 +38,7 @@ _side_stream = side_stream   # round-1 name
 
 
 class FpsPyramid:
-    def __init__(self, xyz: torch.Tensor, npoints: List[int], overlap: bool = True):
+    def __init__(self, xyz: torch.Tensor, npoints: List[int], overlap: bool = True, with_interp: bool = False):
         main = torch.cuda.current_stream(xyz.device)
         side = side_stream(xyz.device) if overlap else main
         self._main, self._side, self._xyz = main, side, xyz   # xyz stays referenced until release()
@@ -58,6 +58,22 @@ class FpsPyramid:
                     new_xyz.record_stream(main)
                 self._levels.append((idx, new_xyz, ev))
                 cur = new_xyz
+            # the feature-propagation modules' neighbour search (three_nn + inverse-distance weights,
+            # pointnet2_modules.py:147-152) depends on coordinates only as well: level k-1 <- level k, behind the chain
+            self._interp: List[Tuple[torch.Tensor, torch.Tensor, torch.cuda.Event]] = []
+            if with_interp:
+                with prof.scope("fp_neighbours"):
+                    for k in range(len(npoints)):
+                        unknown = xyz if k == 0 else self._levels[k - 1][1]
+                        d3, nn3 = pointnet2_utils.three_nn(unknown, self._levels[k][1])
+                        inv = (d3 + 1e-8).reciprocal()
+                        w = inv / inv.sum(dim=2, keepdim=True)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        if side is not main:
+                            nn3.record_stream(main)
+                            w.record_stream(main)
+                        self._interp.append((nn3, w, ev))
 
     def level(self, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """(idx (B, m_k) int32, new_xyz (B, m_k, 3)) of level k, ordered after its FPS on the current stream"""
@@ -71,8 +87,22 @@ class FpsPyramid:
             prof.stall(f"fps_exposed_wait_L{k + 1}", lambda: cur.wait_event(ev))
         return idx, new_xyz
 
+    def interp(self, k: int):
+        """(nn3 (B, n_{k-1}, 3) int32, weights (B, n_{k-1}, 3)) interpolating level k's features onto level k-1's points
+        (level -1 = the input cloud), or None when the pyramid was built without them"""
+        if not self._interp:
+            return None
+        nn3, w, ev = self._interp[k]
+        cur = torch.cuda.current_stream(nn3.device)
+        if cur != self._side:
+            if cur != self._main:
+                nn3.record_stream(cur)
+                w.record_stream(cur)
+            cur.wait_event(ev)
+        return nn3, w
+
     def release(self):
         """the consumer is done with every level: order the side stream after it, drop the references"""
         if self._side is not self._main:
             self._side.wait_stream(torch.cuda.current_stream(self._xyz.device))
-        self._levels, self._xyz = [], None
+        self._levels, self._interp, self._xyz = [], [], None
