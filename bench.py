@@ -361,7 +361,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 8; train: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="FPS chain and image branch on the main stream")
-    ap.add_argument("--image-prefetch", choices=["early", "late", "off"], default="early",
+    ap.add_argument("--image-prefetch", choices=["early", "late", "off"], default="off",
                     help="next batch's image pyramid: under this batch's backbone, after it, or not announced")
     ap.add_argument("--no-prefetch", action="store_true", help="do not start the next batch's FPS pyramid early")
     ap.add_argument("--tiny", action="store_true", help="smoke-sized shapes (tests only; the JSON says so)")

@@ -391,7 +391,7 @@ class DetectAffinityEngine(nn.Module):
         hit, self._prefetched_img = self._prefetched_img, None
         return hit[1] if hit is not None and hit[0] is image else None
 
-    def _launch_image_branch(self, image: torch.Tensor) -> dict:
+    def _launch_image_branch(self, image: torch.Tensor, pts_xy: Optional[torch.Tensor] = None) -> dict:
         """stream I: the image pyramid, channels-last, on its side stream (ordered after the current stream's position:
         the image is ready, and nothing this stream has queued so far still needs buffers the branch will recycle)"""
         net = self.rpn.backbone_net
@@ -420,10 +420,18 @@ class DetectAffinityEngine(nn.Module):
             fused_map = None
             if sparse is None:      # dense fall-back: the full-resolution fused map, gathered afterwards
                 fused_map = self._t("image_deconv+fusion_conv(MIOpen)", 0, lambda: self._image_fusion_map(img_maps))
+            final = None
+            if sparse is not None and pts_xy is not None:
+                # the fused image feature under the points' bilinear taps needs the image pyramid and the pixel coordinates
+                # only: evaluated here, behind the pyramid, while the other stream is still in its last LI-Fusion / FP levels
+                if img_stream is not main:
+                    pts_xy.record_stream(img_stream)
+                with prof.scope("li_fusion_final"):
+                    final = sparse(img_maps, pts_xy, H, W)
             fused_ev = torch.cuda.Event()
             fused_ev.record(img_stream)
         return dict(maps=img_maps, events=img_events, sparse=sparse, fused_map=fused_map, fused_ev=fused_ev, H=H, W=W,
-                    stream=img_stream)
+                    stream=img_stream, final=final)
 
     @torch.no_grad()
     def backbone(self, xyz: torch.Tensor, image: torch.Tensor, pts_xy: torch.Tensor,
@@ -437,7 +445,7 @@ class DetectAffinityEngine(nn.Module):
         # --- stream F: the whole FPS chain (coordinates only); already running if this batch was announced ---
         pyr = self._take_prefetched(xyz) or FpsPyramid(xyz, list(cfg.sa_npoints), overlap=self.overlap, with_interp=self.overlap)
         # --- stream I: image pyramid; already running (or done) if this batch's image was announced ---
-        ib = self._take_prefetched_image(image) or self._launch_image_branch(image)
+        ib = self._take_prefetched_image(image) or self._launch_image_branch(image, pts_xy)
         if next_xyz is not None:
             self.prefetch(next_xyz, None if self.prefetch_image_late else next_image)
         img_maps, img_events, sparse, fused_map, fused_ev = ib["maps"], ib["events"], ib["sparse"], ib["fused_map"], ib["fused_ev"]
@@ -469,7 +477,12 @@ class DetectAffinityEngine(nn.Module):
         prof.stall("image_exposed_wait_final", lambda: main.wait_event(fused_ev))
         with prof.scope("li_fusion_final"):
             # sparse: the fused image feature evaluated only under the points' bilinear taps (csrc/image_fusion.hip)
-            gathered = sparse(img_maps, pts_xy, H, W) if sparse is not None else feature_gather(fused_map, pts_xy)
+            if ib["final"] is not None:
+                gathered = ib["final"]
+                if img_stream is not main:
+                    gathered.record_stream(main)
+            else:
+                gathered = sparse(img_maps, pts_xy, H, W) if sparse is not None else feature_gather(fused_map, pts_xy)
             out = self._t("attention_fusion(span)", 0, lambda: self._attention_fusion(
                 "fusion_final", net.final_fusion_img_point, l_feats[0], gathered))
         pyr.release()
