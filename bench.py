@@ -318,10 +318,16 @@ WORKLOAD_TEXT = {
 }
 
 
-def pick_roofline(kernels, traffic_json):
+def pick_roofline(kernels, traffic_json, full_table=True):
     """the dominant jm_* entry (caller-side torch spans and stream waits are listed but are not ours to price)"""
     own = [k for k in kernels if not k.get("stall") and ("algo_bytes_per_step" in k or "algo_flops_per_step" in k)
            and "(" not in k["kernel"]]
+    # the FPS chain on its side stream is not on the critical path when the consumer hardly ever waits for it (its exposed
+    # share is reported under `overlap`): the roofline kernel is then the largest entry of the main chain
+    chain = sum(k["ms_per_step"] for k in kernels if k["kernel"].startswith("fps_pyramid/"))
+    exposed = sum(k["ms_per_step"] for k in kernels if k.get("stall") and k["kernel"].startswith("fps_exposed"))
+    if full_table and chain > 0 and exposed < 0.1 * chain:
+        own = [k for k in own if not k["kernel"].startswith("fps_pyramid/")]
     if not own:
         return None
     dom = own[0]
@@ -423,14 +429,31 @@ def main():
         train_st["engine"].prefetch_image = args.image_prefetch != "off"
         train_st["engine"].prefetch_image_late = args.image_prefetch == "late"
         step = lambda: train_step(train_st, world)  # noqa: E731
-    for _ in range(args.warmup):
+    # Per-entry HIP events cost GPU time (two records per call: ~0.9 ms of the 21 ms composed step), so the timed region
+    # carries events around ONE entry only — the dominant jm kernel, picked from a fully instrumented warm-up step — and the
+    # per-entry table comes from fully instrumented steps AFTER the timed region.
+    for i in range(args.warmup):
+        last = i == args.warmup - 1
+        if last:
+            torch.cuda.synchronize()
+            prof.reset()
+            prof.only = None
+            prof.enabled = True
         step()
+        if last:
+            torch.cuda.synchronize()
+            prof.enabled = False
+    dom_key = None
+    if args.warmup >= 1:
+        dom = pick_roofline(prof.summary(1, HBM_PEAK_GBS, MFMA_F32_PEAK_TF), None)
+        dom_key = dom["kernel"] if dom else None
     torch.cuda.synchronize()
     gc.collect()
     gc.disable()   # a generation-2 collection in the middle of the timed region is a 30-40 ms host stall
     if dist is not None:
         dist.barrier()
     prof.reset()
+    prof.only = {dom_key} if dom_key else None
     prof.enabled = True
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -445,9 +468,24 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    timed_rows = prof.summary(args.steps, HBM_PEAK_GBS, MFMA_F32_PEAK_TF)
+    table_steps = args.steps
+    if dom_key:                                   # the per-entry table: fully instrumented steps, outside `value`
+        table_steps = max(1, min(5, args.steps))
+        prof.reset()
+        prof.only = None
+        prof.enabled = True
+        t1 = time.perf_counter()
+        for _ in range(table_steps):
+            step()
+        torch.cuda.synchronize()
+        table_ms = (time.perf_counter() - t1) / table_steps * 1e3
+        prof.enabled = False
+        if dist is not None:
+            dist.barrier()
 
     if rank == 0:
-        kernels = prof.summary(args.steps, HBM_PEAK_GBS, MFMA_F32_PEAK_TF)
+        kernels = prof.summary(table_steps, HBM_PEAK_GBS, MFMA_F32_PEAK_TF)
         # HBM bytes per launch from the committed rocprofv3 --pmc passes (collected separately, as the guide
         # prescribes; bench.py itself runs un-profiled)
         tj = None
@@ -462,6 +500,12 @@ def main():
                 if k["kernel"] in tj:
                     k["traffic_bytes_per_launch"] = tj[k["kernel"]]["bytes"]
         ms_step = elapsed / args.steps * 1e3
+        # the roofline kernel's time comes from the TIMED region (its own events only); bytes / flops per call are the same
+        roofline = pick_roofline(timed_rows, tj, full_table=False) if dom_key else pick_roofline(kernels, tj)
+        if roofline is not None and dom_key:
+            roofline["timing"] = (f"HIP events around this entry only, {args.steps} timed steps; the table `kernels` is from "
+                                  f"{table_steps} fully instrumented steps run after the timed region ({table_ms:.2f} ms per step "
+                                  f"with every entry timed vs {ms_step:.2f} ms)")
         exposed = sum(k["ms_per_step"] for k in kernels if k.get("stall") and k["kernel"].startswith("fps_exposed"))
         fps_total = sum(k["ms_per_step"] for k in kernels if k["kernel"].startswith("fps_pyramid/"))
         img_exposed = sum(k["ms_per_step"] for k in kernels if k.get("stall") and k["kernel"].startswith("image_exposed"))
@@ -484,13 +528,14 @@ def main():
                        "frames_per_gpu_per_step": args.batch,
                        "points": (65536 if args.workload == "dense" else 16384) if not args.tiny else "tiny",
                        "parallelism": f"dp{world} (gradient all-reduce)" if args.workload == "train" else f"replicas x{world}"},
-            "roofline": pick_roofline(kernels, tj),
+            "roofline": roofline,
             "overlap": {"side_streams": not args.no_overlap, "next_batch_fps_prefetch": not (args.no_prefetch or args.no_overlap),
                         "fps_chain_ms": round(fps_total, 4), "fps_exposed_ms": round(exposed, 4),
                         "fps_critical_path_share": round(exposed / ms_step, 4) if ms_step else None,
                         "image_branch_exposed_ms": round(img_exposed, 4),
                         "note": "exposed = time the main stream is held at its wait on the side stream (HIP events "
                                 "either side of the wait); chain = sum of the FPS entry points on the side stream"},
+            "kernels_from": (f"{table_steps} fully instrumented steps after the timed region" if dom_key else "the timed region"),
             "kernels": kernels,
         }
         if not args.no_cpu_baseline and world == 1 and not args.tiny and args.workload in ("detect", "sa"):
