@@ -379,6 +379,15 @@ class DetectAffinityEngine(nn.Module):
             if image is not None and self.prefetch_image:
                 self._prefetched_img = (image, self._launch_image_branch(image))
 
+    def _drop_kept(self):
+        kept, self._kept = getattr(self, "_kept", None), None
+        if kept is not None:
+            ib, pyr = kept
+            pyr.release()                                       # side stream ordered after this one, then dropped
+            cur = torch.cuda.current_stream(ib["maps"][0].device)
+            if ib["stream"] != cur:
+                ib["stream"].wait_stream(cur)                   # same for the image pyramid's blocks
+
     def _take_prefetched(self, xyz: torch.Tensor):
         hit, self._prefetched = self._prefetched, None
         if hit is not None and hit[0] is xyz:
@@ -442,6 +451,7 @@ class DetectAffinityEngine(nn.Module):
         dev = xyz.device
         main = torch.cuda.current_stream(dev)
         B, N, _ = xyz.shape
+        self._drop_kept()
         # --- stream F: the whole FPS chain (coordinates only); already running if this batch was announced ---
         pyr = self._take_prefetched(xyz) or FpsPyramid(xyz, list(cfg.sa_npoints), overlap=self.overlap, with_interp=self.overlap)
         # --- stream I: image pyramid; already running (or done) if this batch's image was announced ---
@@ -450,9 +460,8 @@ class DetectAffinityEngine(nn.Module):
             self.prefetch(next_xyz, None if self.prefetch_image_late else next_image)
         img_maps, img_events, sparse, fused_map, fused_ev = ib["maps"], ib["events"], ib["sparse"], ib["fused_map"], ib["fused_ev"]
         H, W, img_stream = ib["H"], ib["W"], ib["stream"]
-        if img_stream is not main:      # allocated on the image stream, read by this one
-            for t in img_maps + ([fused_map] if fused_map is not None else []):
-                t.record_stream(main)
+        # (allocated on the image stream, read by this one: kept referenced until the next call's _drop_kept / the next
+        # _launch_image_branch, which orders the image stream after this one — no record_stream, see pyramid.py)
         # --- stream M: set abstraction + LI-Fusion per level ---
         l_xyz, l_feats, l_xy = [xyz], [None], [pts_xy]
         self.last_fps_idx = []
@@ -479,13 +488,14 @@ class DetectAffinityEngine(nn.Module):
             # sparse: the fused image feature evaluated only under the points' bilinear taps (csrc/image_fusion.hip)
             if ib["final"] is not None:
                 gathered = ib["final"]
-                if img_stream is not main:
-                    gathered.record_stream(main)
             else:
                 gathered = sparse(img_maps, pts_xy, H, W) if sparse is not None else feature_gather(fused_map, pts_xy)
             out = self._t("attention_fusion(span)", 0, lambda: self._attention_fusion(
                 "fusion_final", net.final_fusion_img_point, l_feats[0], gathered))
-        pyr.release()
+        # the previous batch's pyramids are dropped at the START of the next call: their blocks were allocated on the side
+        # streams and record_stream-ed here, so freeing them makes the allocator record one event per block on THIS stream —
+        # a ~100 us train of markers in front of the RPN heads when done at this point
+        self._kept = (ib, pyr)
         if next_image is not None and self.prefetch_image_late and self.prefetch_image and self.overlap:
             self._prefetched_img = (next_image, self._launch_image_branch(next_image))    # ordered after this batch's backbone
         return out

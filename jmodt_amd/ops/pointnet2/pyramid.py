@@ -53,9 +53,10 @@ class FpsPyramid:
                     idx, new_xyz = pointnet2_utils.farthest_point_sample_xyz(cur, m)
                 ev = torch.cuda.Event()
                 ev.record(side)
-                if side is not main:     # handed to the main stream: keep the allocator from recycling them under it
-                    idx.record_stream(main)
-                    new_xyz.record_stream(main)
+                # handed to the announcing stream WITHOUT record_stream: the tensors stay referenced until release(), which
+                # orders the side stream after the consumer before dropping them — a record_stream would make the caching
+                # allocator record one event per block on the consumer's stream at that point (a train of markers in the
+                # middle of its kernel chain, ~100 us per pyramid: tools/timeline.sh)
                 self._levels.append((idx, new_xyz, ev))
                 cur = new_xyz
             # the feature-propagation modules' neighbour search (three_nn + inverse-distance weights,
@@ -70,9 +71,6 @@ class FpsPyramid:
                         w = inv / inv.sum(dim=2, keepdim=True)
                         ev = torch.cuda.Event()
                         ev.record(side)
-                        if side is not main:
-                            nn3.record_stream(main)
-                            w.record_stream(main)
                         self._interp.append((nn3, w, ev))
 
     def level(self, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
