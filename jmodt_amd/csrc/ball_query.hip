@@ -30,6 +30,7 @@ struct BqParams {
     int lds_hits_off[2];  // int offsets into dynamic LDS of the per-radius hit lists
     int lds_cnt_off[2];   // per-radius counts [NW][64]
     int chunk;            // points per wave slice (multiple of 8)
+    int b, gx;            // frames, centre blocks per frame; gx > 0: 1-D grid with whole frames per XCD (see the kernel)
 };
 
 // HT = unsigned short when n <= 65536 (halves the LDS per wave -> twice the waves per CU)
@@ -86,8 +87,18 @@ ball_query_kernel(BqParams p, const float* __restrict__ new_xyz, const float* __
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform -> scalar loads
     const int nw = blockDim.x >> 6;
-    const int bi = blockIdx.y;
-    const int c0 = blockIdx.x * 64;
+    // Workgroups are dealt to the 8 XCDs round-robin and every XCD has its own L2: with the frame in blockIdx.y the 64+
+    // workgroups of ONE frame land on all eight and each L2 pulls every cloud (32 MB of HBM fetches for 8.3 MB of
+    // compulsory bytes at B = 8 x 16384, round-1 counters).  1-D grid: workgroup g runs on XCD g % 8 and takes frame
+    // (g % 8) + 8 * (slot / gx), so a frame's cloud is streamed through one L2 only.
+    int bi = blockIdx.y, cblk = blockIdx.x;
+    if (p.gx > 0) {
+        const int slot = blockIdx.x >> 3;
+        bi = (blockIdx.x & 7) + 8 * (slot / p.gx);
+        cblk = slot % p.gx;
+        if (bi >= p.b) return;                                   // workgroup-uniform
+    }
+    const int c0 = cblk * 64;
     const int ci = c0 + lane;
     const bool active = ci < p.m;
     const float* cptr = new_xyz + ((size_t)bi * p.m + (active ? ci : 0)) * 3;
@@ -191,7 +202,12 @@ static int launch_ball_query(int b, int n, int m, int nr, const float* radius, c
     p.chunk = (divup(n, nw) + 7) / 8 * 8;
     const size_t lds_bytes = (size_t)off * esz;
     JM_REQUIRE(lds_bytes <= 160 * 1024, "ball_query: nsample too large for LDS (%zu B)", lds_bytes);
+    p.b = b; p.gx = 0;
     dim3 grid(divup(m, 64), b), block(64 * nw);
+    if (b >= 8 && (long long)divup(b, 8) * 8 * divup(m, 64) < (1LL << 31)) {   // whole frames per XCD
+        p.gx = divup(m, 64);
+        grid = dim3((unsigned)(divup(b, 8) * 8 * p.gx), 1);
+    }
 #define JM_BQ_LAUNCH(NRV, HTV)                                                                              \
     do {                                                                                                   \
         if (lds_bytes > 64 * 1024)                                                                         \
