@@ -562,3 +562,23 @@ def test_conv3x3_rgb_bias_relu_vs_torch(B, H, W, cout):
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     assert (want > 0).any() and (want == 0).any()
     close(got, want)
+
+
+def test_engine_stream_safety_soak(run):
+    """the same batch through 12 steps with every overlap / prefetch on and allocator churn on the main stream in
+    between: the pyramids are handed between streams without record_stream (ordered release), so a recycling race would
+    show up as a changed intermediate result"""
+    eng = run["eng"]
+    a, img, xy = T(run["xyz"]), T(run["img"]), T(run["xy"])
+    g = torch.Generator().manual_seed(5)
+    for i in range(12):
+        with torch.no_grad():
+            cache, aff, inter = eng(a, img, xy, next_xyz=a, next_image=img if i % 3 == 0 else None)
+        junk = [torch.empty(int(s), device=DEV).fill_(float(i)) for s in torch.randint(1 << 8, 1 << 20, (5,), generator=g).tolist()]
+        del junk
+        for k in ("backbone_features", "rois", "rcnn_feat", "pred_boxes3d"):
+            assert torch.equal(inter[k], run["inter"][k]), (i, k)
+        assert torch.equal(cache.count, run["cache"].count)
+    with torch.no_grad():
+        eng(a, img, xy)                                    # consume the last announcement
+    assert eng._prefetched is None and eng._prefetched_img is None

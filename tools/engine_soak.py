@@ -1,0 +1,33 @@
+"""stream-safety soak of the composed engine: the same resident batch through N steps with every overlap / prefetch on,
+interleaved with allocator churn on the main stream; every step's intermediate results must equal step 0's bit for bit
+(the affinity head's atomically accumulated sums to 1e-6)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+st = bench.make_detect_state(8, 1236, torch.device("cuda:0"))
+eng = st["engine"]
+keys = ("backbone_features", "rpn_cls", "rpn_reg", "rois", "pts_input", "rcnn_feat", "rcnn_cls", "rcnn_reg", "pred_boxes3d")
+ref = None
+bad = 0
+g = torch.Generator(device="cuda").manual_seed(1)
+for i in range(N):
+    with torch.no_grad():
+        cache, aff, inter = eng(st["xyz"], st["image"], st["pts_xy"], next_xyz=st["xyz"], next_image=st["image"] if i % 3 == 0 else None)
+    # allocator churn: blocks of many sizes allocated and dropped on the main stream between steps
+    junk = [torch.empty(int(s), device="cuda").fill_(float(i)) for s in torch.randint(1 << 10, 1 << 24, (6,), generator=g, device="cuda").tolist()]
+    cur = {k: inter[k].clone() for k in keys}
+    cur["count"] = cache.count.clone(); cur["boxes"] = cache.boxes.clone(); cur["A0"] = aff[0][0].clone()
+    del junk
+    if ref is None:
+        torch.cuda.synchronize(); ref = cur; continue
+    if i % 10 == 9 or i == N - 1:
+        torch.cuda.synchronize()
+    for k, v in cur.items():
+        same = (v - ref[k]).abs().max().item() < 1e-6 if k == "A0" else torch.equal(v, ref[k])
+        if not same:
+            bad += 1
+            print(f"step {i}: {k} differs (max |diff| {(v.float() - ref[k].float()).abs().max().item():.3e})", flush=True)
+torch.cuda.synchronize()
+print(f"{N} steps, {bad} mismatches", "ENGINE_SOAK_OK" if bad == 0 else "ENGINE_SOAK_FAILED")
