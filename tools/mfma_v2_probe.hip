@@ -11,7 +11,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SB() __builtin_amdgcn_sched_barrier(0)
 constexpr int S = 132;     // row stride (floats): S / 4 odd -> conflict-free b128 reads of 16 rows
 
-template <int MODE>        // bit 0: relu(a - v) on the first layer; bit 1: layer boundaries (epilogues + barriers)
+template <int MODE>        // bit 0: relu(a - v) on the first layer; bit 1: layer boundaries; bit 2: loads spread between the MFMAs
 __global__ void __launch_bounds__(512) probe(const float* __restrict__ W, float* out, int tiles) {
     __shared__ float X[2][128 * S];
     __shared__ float VT[4 * 128];
@@ -58,11 +58,26 @@ __global__ void __launch_bounds__(512) probe(const float* __restrict__ W, float*
                 }
             };
             loadA(a0, v0, 0); loadB(b0, 0);
+            auto spread = [&]() __attribute__((always_inline)) {     // 16 MFMAs, one load and one or two VALU after each of the first 8
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    else if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                }
+            };
             for (int kt = 0; kt < 8; kt += 2) {
                 loadA(a1, v1, kt + 1); loadB(b1, kt + 1);
-                SB(); mm(a0, v0, b0); SB();
+                if (!(MODE & 4)) SB();
+                mm(a0, v0, b0);
+                if (MODE & 4) spread();
+                SB();
                 loadA(a0, v0, (kt + 2) & 7); loadB(b0, kt + 2);
-                SB(); mm(a1, v1, b1); SB();
+                if (!(MODE & 4)) SB();
+                mm(a1, v1, b1);
+                if (MODE & 4) spread();
+                SB();
             }
             if (MODE & 2) {
                 if (layer == 0) {          // hidden epilogue: relu -> row-major tile of the next layer, 4 b128 per accumulator
@@ -122,5 +137,6 @@ int main() {
     run<1>("+ relu(a - v) on the first layer");
     run<2>("+ layer boundaries (b128 epilogue / max-pool + barrier)");
     run<3>("+ both (= the proposed kernel's MFMA side)");
+    run<7>("+ both, loads / VALU spread between the MFMAs (sched_group_barrier)");
     return 0;
 }
