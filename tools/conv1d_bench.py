@@ -21,6 +21,7 @@ cases = [  # name, B, n, c0, c1, xyz1, widths, relus
     ("FP1 256+? -> 128,128", 8, 16384, 256, 0, False, [128, 128], [True, True]),
     ("FP2 512+96 -> 256,256", 8, 4096, 512, 96, False, [256, 256], [True, True]),
     ("FP3 512+256 -> 512,512", 8, 1024, 512, 256, False, [512, 512], [True, True]),
+    ("FP4 1024+512 -> 512,512 (64 tiles)", 8, 256, 1024, 512, False, [512, 512], [True, True]),
 ]
 for name, B, n, c0, c1, xyz1, widths, relus in cases:
     layers, k = [], c0 + c1
