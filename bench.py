@@ -15,7 +15,10 @@ one batch of 8 frames through jmodt_amd.detector.DetectAffinityEngine.  value = 
   train   configs[3]: frozen detector forward + data-parallel finetune step of the link / start-end heads
           (one bucketed fp32 gradient all-reduce over RCCL)
 
-N > 1 is launched by torch.distributed.run, one rank per GPU; frames are independent, so every rank processes
+N > 1 runs one rank per GPU under torch.distributed.run — either launched that way by the caller (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment) or, from a plain shell (`python bench.py --gpus 8`), by bench.py re-executing
+itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (the process-per-GPU
+equivalent of the reference's nn.DataParallel, tools/train.py:86-88).  Frames are independent, so every rank processes
 its own batch with no data-path collective (weak scaling); the timed region is bracketed by
 barrier + synchronize and the MAX over ranks is used.
 
@@ -61,7 +64,7 @@ SA_LEVELS = [
 def make_detect_state(B, seed, dev, tiny=False):
     from jmodt_amd.detector import DetectAffinityEngine, DetectorConfig
     torch.manual_seed(seed)
-    cfg = DetectorConfig.tiny() if tiny else DetectorConfig()
+    cfg = DetectorConfig.tiny() if tiny else DetectorConfig.survey()
     eng = DetectAffinityEngine(cfg).to(dev)
     if tiny:
         xyz, img, xy = synth.frames(B, 2048, seed, H=96, W=320, native=(94, 310))
@@ -84,7 +87,7 @@ def cpu_baseline_detect(frames=2):
     from jmodt_amd.detector import DetectAffinityEngine, DetectorConfig
     from oracle.pipeline import Chain
     torch.manual_seed(99)
-    cfg = DetectorConfig()
+    cfg = DetectorConfig.survey()
     sd = DetectAffinityEngine(cfg).state_dict()
     xyz, img, xy = synth.frames(frames, 16384, 4321)
     chain = Chain(sd, cfg, torch.float32)
@@ -303,6 +306,24 @@ def train_step(st, world):
 
 
 # ---------------------------------------------------------------------------------------------- main
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` from a plain shell: the same command line under torch.distributed.run, one rank per GPU on
+    this node, rendezvous on 127.0.0.1 (the container hostname may not resolve) at a free port.  The child ranks print the
+    ONE JSON line (rank 0) straight to this process's stdout; returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if n_gpus == 1:
+        env["JM_BENCH_FORCE_DIST"] = "1"         # --launch on one GPU: still create the RCCL communicator, barrier, all-reduce
+    return subprocess.call(cmd, env=env)
+
+
 WORKLOAD_TEXT = {
     "detect": "BASELINE configs[2] + affinity: composed detect+affinity forward (LI-Fusion backbone 4xSA-MSG + 4xFP, RPN "
               "heads, proposal layer, roipool3d+canonical, RCNN 3xSA + heads, box decode, detection NMS, pairwise "
@@ -372,22 +393,34 @@ def main():
     ap.add_argument("--no-prefetch", action="store_true", help="do not start the next batch's FPS pyramid early")
     ap.add_argument("--tiny", action="store_true", help="smoke-sized shapes (tests only; the JSON says so)")
     ap.add_argument("--workload", default="detect", choices=list(WORKLOAD_TEXT))
+    ap.add_argument("--launch", action="store_true",
+                    help="re-execute under torch.distributed.run even for --gpus 1 (the N > 1 launch path incl. RCCL init / "
+                         "barrier / all-reduce on one GPU: what the GPU tier runs)")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 4 if args.workload == "train" else 8
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.launch):
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} inside a torch.distributed.run job of WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the jmodt ops have no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank}, the node has {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or os.environ.get("JM_BENCH_FORCE_DIST") == "1":   # (the env switch exercises the RCCL path on one GPU)
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:      # JM_BENCH_FORCE_DIST=1 from a plain shell: a world of one
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
         # stdout carries exactly one JSON line.  RCCL prints a version banner to fd 1 when the communicator is
         # created (NCCL_DEBUG=VERSION in this image), so fd 1 points at stderr while that happens.
         sys.stdout.flush()

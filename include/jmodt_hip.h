@@ -50,7 +50,9 @@ int jm_furthest_point_sampling(int b, int n, int m, const float* xyz, float* tem
 /* Same, with a caller-provided workspace: clouds of 16384 < n <= 131072 points (config 5: 65536) are then
  * split over ceil(n/16384) co-operating workgroups instead of being streamed from L2 by one.
  * ws: >= jm_fps_workspace_bytes(b, n) bytes (0 when no workspace is needed), 64-byte aligned.  Two such
- * launches must not run concurrently on one device (their workgroups wait for each other). */
+ * launches must not run concurrently on one device (their workgroups wait for each other).  A cloud whose
+ * workgroups could not exchange records for ~2 s (peers kept off the device) is not sampled: its whole index
+ * row is -1 (a valid row starts with index 0) and its new_xyz row NaN; the HIP context stays usable. */
 size_t jm_fps_workspace_bytes(int b, int n);
 /* sampling + the gather of the sampled coordinates that always follows it (pointnet2_modules.py:35-39):
  * additionally writes new_xyz (B, m, 3) = xyz[b, idx[b, j], :].  ws may be NULL when

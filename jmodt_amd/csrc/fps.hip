@@ -302,9 +302,11 @@ fps_coop_kernel(int n, int m, int G, int nclouds, const float* __restrict__ data
     __shared__ int vals[2][16];
     __shared__ FpsCand win[2];
     __shared__ int out_buf[FPS_OUT_CHUNK];
+    __shared__ int failed;
     const int T = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(T >> 6);
     const int lane = T & 63;
+    if (T == 0) failed = 0;
     // block -> (cloud, part): parts of one cloud are 8 block ids apart
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int cloud = xcd + 8 * (slot / G), g = slot % G;
@@ -386,9 +388,11 @@ fps_coop_kernel(int n, int m, int G, int nclouds, const float* __restrict__ data
                                  (unsigned)(w3 >> 32) == tag && (unsigned)(w4 >> 32) == tag;
                 if (__all(okk)) break;
                 // bounded (~seconds): a peer that never publishes (the host sizes every launch to be co-resident, so
-                // this means a broken device partition) must neither hang the GPU nor be papered over with stale
-                // records: abort the kernel — the error surfaces as a launch failure at the caller's next sync
-                if (++spins > (1 << 21)) __builtin_trap();
+                // this means a broken device partition, or a caller that overlapped the launch with work that keeps the
+                // peers off the machine for seconds) must neither hang the GPU, nor kill the HIP context, nor be papered
+                // over with stale records: every workgroup of the cloud gives up (its peers time out the same way) and
+                // the cloud's whole index row is written as -1 — a valid row always starts with index 0
+                if (++spins > (1 << 21)) { if (lane == 0) failed = 1; break; }
             }
             const int cv = lane < G ? (int)(unsigned)w0 : (int)0x80000000;
             const int ck = (int)(unsigned)w1;
@@ -409,10 +413,16 @@ fps_coop_kernel(int n, int m, int G, int nclouds, const float* __restrict__ data
             }
         }
         lds_barrier();                                                        // B
+        if (failed) break;                                                    // uniform: read behind the barrier
         const FpsCand c = win[it & 1];
         x1 = c.x; y1 = c.y; z1 = c.z;
     }
     __syncthreads();
+    if (failed) {                                  // exchange timed out: poison the row (jm_furthest_point_sampling*: idx[b][0] == -1)
+        if (g == 0)
+            for (int e = T; e < m; e += 1024) out[e] = -1;
+        return;
+    }
     if (g == 0) {
         const int done = ((m - 1) / FPS_OUT_CHUNK) * FPS_OUT_CHUNK;
         for (int e = T; e < m - done; e += 1024) out[done + e] = out_buf[e];
@@ -482,8 +492,10 @@ __global__ void fps_gather_xyz_kernel(int n, int m, long long total, const float
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
     const long long b = e / m;
-    const float* q = xyz + ((size_t)b * n + idx[e]) * 3;
+    const int i = idx[e];
     float* o = new_xyz + e * 3;
+    if (i < 0) { o[0] = o[1] = o[2] = __builtin_nanf(""); return; }   // a row the cooperative kernel gave up on (-1)
+    const float* q = xyz + ((size_t)b * n + i) * 3;
     o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
 }
 

@@ -486,8 +486,10 @@ using namespace jm;
 extern "C" int jm_sa_mlp_supported(int b, int n, int m, int c, int nsample, int group_all, int num_layers,
                                    const int* widths) {
     if (b < 0 || n < 1 || m < 0 || c < 0 || num_layers < 1 || !widths || widths[0] != 3 + c) return 0;
+    // every launch-time requirement of sa_mlp_narrow_launch: "supported" must imply that the launch succeeds
     bool narrow = !group_all && (nsample == 16 || nsample == 32 || nsample == 64) && ((long long)m * nsample) % SM_BM == 0 &&
-                  num_layers <= 4 && (num_layers > 1 || sa_first_kp(widths[0]) <= SM_KC);
+                  num_layers <= 4 && (num_layers > 1 || sa_first_kp(widths[0]) <= SM_KC) &&
+                  (long long)m * nsample / SM_BM * b < (1LL << 31) && widths[num_layers] >= 1;
     for (int l = 1; l < num_layers && narrow; ++l) narrow = widths[l] >= 1 && widths[l] <= 128;
     if (narrow) return 1;
     return sa_wide_unsupported(b, n, m, c, nsample, group_all, num_layers, widths) == nullptr ? 2 : 0;
@@ -557,7 +559,7 @@ static int sa_mlp_narrow_launch(int b, int n, int m, int c, int nsample, const f
     JM_REQUIRE(nsample == 16 || nsample == 32 || nsample == 64, "sa_mlp: nsample %d not in {16,32,64}", nsample);
     JM_REQUIRE(((long long)m * nsample) % SM_BM == 0, "sa_mlp: npoint*nsample = %lld is not a multiple of 128", (long long)m * nsample);
     JM_REQUIRE(num_layers >= 1 && num_layers <= 4, "sa_mlp: %d layers unsupported", num_layers);
-    JM_REQUIRE(b <= 65535, "sa_mlp: batch too large");
+    // (persistent kernel, grid = #CUs: the batch is bounded only by the 31-bit tile counter below)
     JM_REQUIRE(num_layers > 1 || (pre ? c : sa_first_kp(widths[0])) <= SM_KC, "sa_mlp: a single layer needs C <= 128");
     SaMlpParams p{};
     p.N = n; p.M = m; p.C = c; p.ns = nsample;

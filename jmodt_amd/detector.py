@@ -63,9 +63,10 @@ class DetectorConfig:
     deconv_reduce: Sequence[int] = (16, 16, 16, 16)
     deconv_kernels: Sequence[int] = (2, 4, 8, 16)
     img_features_channel: int = 128
-    # proposal layer, TEST mode (config.py:224-230); post_nms_top_n is 100 in the reference, SURVEY.md §8 uses 128
+    # proposal layer, TEST mode (config.py:204,213,224-230): 100 RoIs per frame as the reference's EVAL / TEST configuration;
+    # SURVEY.md §8 / BASELINE.json benchmark 128 per frame: DetectorConfig.survey()
     rpn_pre_nms_top_n: int = 9000
-    rpn_post_nms_top_n: int = 128
+    rpn_post_nms_top_n: int = 100
     rpn_nms_thresh: float = 0.8
     rpn_nms_type: str = "normal"          # :94
     # RCNN (config.py:100-139)
@@ -95,6 +96,12 @@ class DetectorConfig:
     @property
     def rcnn_reg_channels(self) -> int:  # rcnn.py:73-77 with LOC_Y_BY_BIN = False
         return int(self.rcnn_loc_scope / self.rcnn_loc_bin_size) * 2 * 4 + self.rcnn_num_head_bin * 2 + 3 + 1
+
+    @staticmethod
+    def survey() -> "DetectorConfig":
+        """the benchmarked configuration (BASELINE.json: 128 proposals per frame); everything else as
+        jmodt/config.py"""
+        return DetectorConfig(rpn_post_nms_top_n=128)
 
     @staticmethod
     def tiny() -> "DetectorConfig":
@@ -269,6 +276,8 @@ class DetectAffinityEngine(nn.Module):
         self.rcnn_net = RCNN(self.cfg, input_channels=self.cfg.fp_mlps[0][-1])
         self.eval()
         self._folded: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._folded_sig = None            # (data_ptr, _version) of every parameter / buffer the folded entries were made from
+        self._sig_tensors: Optional[List[torch.Tensor]] = None
         self.overlap = True                # FPS pyramid + image branch on side streams
         self.last_fps_idx: List[torch.Tensor] = []
         self.sparse_image_fusion = True    # final image feature only under the bilinear taps (else dense deconvolutions)
@@ -295,8 +304,27 @@ class DetectAffinityEngine(nn.Module):
         return hit
 
     def invalidate(self):
-        """drop folded weights (call after loading a checkpoint)"""
+        """drop folded weights (not needed after load_state_dict / optimizer steps / .to(): `_refresh` sees those)"""
         self._folded.clear()
+        self._folded_sig = None
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float(): the parameters' storage is replaced, folded copies live on the old device
+        self._folded.clear()
+        self._folded_sig = self._sig_tensors = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def _refresh(self):
+        """drop every folded / packed weight when ANY parameter or buffer of the engine changed since it was made: torch
+        bumps `_version` on every in-place update (load_state_dict, optimizer steps, manual copy_), `.to()` changes the
+        storage.  Same rule as the SA / FP module caches (ops/pointnet2/fused.py:_packed_layers); called at every public
+        entry (a few hundred attribute reads, ~0.1 ms of host time per batch)."""
+        if self._sig_tensors is None:
+            self._sig_tensors = list(self.parameters()) + list(self.buffers())
+        sig = tuple([(t.data_ptr(), t._version) for t in self._sig_tensors])
+        if sig != self._folded_sig:
+            self._folded.clear()
+            self._folded_sig = sig
 
     def _attention_fusion(self, tag: str, mod: AttentionFusion, point_feats: torch.Tensor, img_feats: torch.Tensor):
         """AttentionFusion.forward on (B, C, n) operands with the BatchNorms folded (backbone.py:44-81)"""
@@ -374,6 +402,7 @@ class DetectAffinityEngine(nn.Module):
         RCNN work, instead of at the head of the next call's critical path; with `image`, so does its image pyramid
         (the four convolution blocks depend on the image alone, backbone.py:162-168), which then no longer holds the
         point branch of the next call at every LI-Fusion level.  The next call must pass the same tensor objects."""
+        self._refresh()
         if self.overlap:
             self._prefetched = (xyz, FpsPyramid(xyz, list(self.cfg.sa_npoints), overlap=True, with_interp=True))
             if image is not None and self.prefetch_image:
@@ -451,6 +480,7 @@ class DetectAffinityEngine(nn.Module):
         dev = xyz.device
         main = torch.cuda.current_stream(dev)
         B, N, _ = xyz.shape
+        self._refresh()
         self._drop_kept()
         # --- stream F: the whole FPS chain (coordinates only); already running if this batch was announced ---
         pyr = self._take_prefetched(xyz) or FpsPyramid(xyz, list(cfg.sa_npoints), overlap=self.overlap, with_interp=self.overlap)
@@ -631,6 +661,7 @@ class DetectAffinityEngine(nn.Module):
         rcnn_cls (R, 1), rcnn_reg (R, 46), rcnn_feat (R, 512, 1)"""
         net = self.rcnn_net
         R, S, Cin = pts_input.shape
+        self._refresh()
         k = net.rcnn_input_channel
         rows = pts_input.view(R * S, Cin)
         up = [self._wb(f"xyz_up.{i}", lambda u=u: _unit_wb(u)) for i, u in enumerate(net.xyz_up_layer)]

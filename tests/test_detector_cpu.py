@@ -125,12 +125,56 @@ def test_state_dict_matches_reference_point_rcnn():
         assert mine[k] == shape, (k, mine[k], shape)
     assert sum(np.prod(s) for k, s in mine.items() if "running" not in k and "num_batches" not in k) == ref["num_parameters"]
     cfg = DetectorConfig()
-    rc = ref["config"]     # the engine's defaults are the reference's TEST-mode values (post-NMS budget: 100 there, 128 in SURVEY §8)
+    rc = ref["config"]     # the engine's defaults are the reference's TEST-mode values (post-NMS budget 100; SURVEY §8's 128 =
+    # DetectorConfig.survey())
     assert (cfg.rpn_pre_nms_top_n, cfg.rpn_nms_thresh, cfg.rcnn_score_thresh, cfg.rcnn_nms_thresh, cfg.rpn_score_thresh,
             cfg.pool_extra_width, cfg.rcnn_num_points) == (rc["RPN_PRE_NMS_TOP_N"], rc["RPN_NMS_THRESH"], rc["RCNN_SCORE_THRESH"],
                                                             rc["RCNN_NMS_THRESH"], rc["RPN_SCORE_THRESH"], rc["POOL_EXTRA_WIDTH"],
                                                             rc["RCNN_NUM_POINTS"])
-    assert rc["RPN_POST_NMS_TOP_N"] == 100
+    assert rc["RPN_POST_NMS_TOP_N"] == cfg.rpn_post_nms_top_n == 100
+    assert DetectorConfig.survey().rpn_post_nms_top_n == 128
+    import dataclasses
+    assert dataclasses.replace(DetectorConfig.survey(), rpn_post_nms_top_n=100) == cfg
+
+
+def test_folded_weights_follow_load_state_dict_and_inplace_updates(monkeypatch):
+    """the engine's folded / packed weights are keyed on every parameter's (data_ptr, _version): load_state_dict, an
+    optimizer-style in-place update or .to() after a first forward must never leave stale entries (no invalidate() call)"""
+    torch.manual_seed(1)
+    a = DetectAffinityEngine(DetectorConfig.tiny()).double()
+    torch.manual_seed(2)
+    b = DetectAffinityEngine(DetectorConfig.tiny()).double()
+    cfg = a.cfg
+    g = torch.Generator().manual_seed(5)
+    pts = torch.randn(3, cfg.rcnn_num_points, 5 + cfg.fp_mlps[0][-1], generator=g).double()
+    x = torch.randn(2, cfg.fp_mlps[0][-1], 40, generator=g).double()
+
+    class Stop(Exception):
+        pass
+
+    def lifted(e):
+        got = {}
+
+        def fake_sa(xyz, feats, *args, **kw):
+            got["feats"] = feats
+            raise Stop
+        monkeypatch.setattr(e.rcnn_net.SA_modules[0], "forward", fake_sa)
+        with pytest.raises(Stop):
+            e.rcnn_forward(pts)
+        return got["feats"]
+    fa, fb = lifted(a), lifted(b)
+    assert not torch.allclose(fa, fb) and "merge_down" in a._folded
+    a.load_state_dict(b.state_dict())                        # in-place copies: versions bump, no invalidate()
+    assert torch.equal(lifted(a), fb)
+    with torch.no_grad():                                    # an optimizer-style in-place step on one tensor
+        a.rcnn_net.merge_down_layer[0].conv.bias.add_(0.25)
+        b.rcnn_net.merge_down_layer[0].conv.bias.add_(0.25)
+    assert torch.equal(lifted(a), lifted(b))
+    h0 = a._head_forward("h", a.rpn.rpn_cls_layer, x)
+    a = a.float()                                            # _apply: storage replaced
+    assert not a._folded
+    assert a._head_forward("h", a.rpn.rpn_cls_layer, x.float()).dtype == torch.float32
+    assert torch.allclose(a._head_forward("h", a.rpn.rpn_cls_layer, x.float()).double(), h0, atol=1e-5)
 
 
 def test_li_fusion_blocks_match_reference_forward():

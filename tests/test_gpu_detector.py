@@ -50,10 +50,10 @@ def tiny_frames(B, N, seed):
     return xyz, img, xy
 
 
-def make_engine(seed=0):
+def make_engine(seed=0, cfg=None):
     from jmodt_amd.detector import DetectAffinityEngine, DetectorConfig
     torch.manual_seed(seed)
-    eng = DetectAffinityEngine(DetectorConfig.tiny())
+    eng = DetectAffinityEngine(cfg or DetectorConfig.tiny())
     g = torch.Generator().manual_seed(seed + 1)
     for m in eng.modules():     # non-trivial BatchNorm statistics, non-zero biases, larger head weights
         if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
@@ -147,6 +147,120 @@ def test_detections_and_affinity_teacher_forced(run, oracle):
         A, s, e = run["aff"][b]
         wA, ws, we = chain.affinity(f64[b - 1], f64[b])
         close(A, wA); close(s, ws); close(e, we)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the BENCHMARKED network: full widths (point_rcnn.py:24-70 with config.py:71-139 shapes: 16.7 M parameters, hidden
+# widths to 512), 16384-point frames on the 384x1280 canvas, 128 RoIs x 512 points — the configuration bench.py
+# times selects different kernels than DetectorConfig.tiny() (sa_mlp_pm C = 128, sa_mlp_wide hidden 512, rcnn_lift
+# with the hoisted layer, rocBLAS at LI-Fusion level 4, the 128-RoI affinity batch)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full_run():
+    from jmodt_amd.detector import DetectorConfig
+    from jmodt_amd.profile import prof
+    from oracle.pipeline import Chain
+    eng = make_engine(seed=5, cfg=DetectorConfig.survey()).to(DEV)
+    xyz, img, xy = synth.frames(2, 16384, 4321)
+    with torch.no_grad():
+        eng(T(xyz), T(img), T(xy))                         # warm-up: packs / folds every weight
+        prof.reset()
+        prof.enabled = True
+        try:
+            cache, aff, inter = eng(T(xyz), T(img), T(xy))
+            torch.cuda.synchronize()
+            taken = set(prof.records)
+        finally:
+            prof.enabled = False
+            prof.reset()
+    chain = Chain(eng.state_dict(), eng.cfg, torch.float64)
+    return dict(eng=eng, xyz=xyz, img=img, xy=xy, cache=cache, aff=aff, inter=inter, chain=chain, taken=taken)
+
+
+def test_full_width_kernel_selection(full_run):
+    """the entries the benchmarked configuration takes (from the profiler's records of the compared run itself)"""
+    taken, eng = full_run["taken"], full_run["eng"]
+    names = " ".join(sorted(taken))
+    for needle in ("rcnn_sa1/sa_mlp_pm_forward", "rcnn_sa2/sa_mlp_pm_forward", "rcnn_sa3/sa_mlp_forward", "rpn_sa2/sa_mlp_pm_forward",
+                   "rpn_sa3/sa_mlp_forward", "rpn_sa4/sa_mlp_forward", "rcnn_lift_forward", "conv1d_stack_forward",
+                   "li_fusion_final/image_fusion_gather", "li_fusion1/attention_fusion_forward", "li_fusion3/attention_fusion_forward",
+                   "li_fusion_final/attention_fusion_forward", "affinity_2x128x128/affinity_forward_batched", "linear_rows",
+                   "conv3x3_rgb_bias_relu", "proposal_layer/", "roipool3d_canonical", "detections/nms_batched",
+                   "fps_pyramid/L1/furthest_point_sampling_xyz", "three_nn", "three_interpolate"):
+        assert needle in names, (needle, names)
+    assert "li_fusion4/attention_fusion_forward" not in names          # 512 rows x 1024 channels: rocBLAS GEMMs
+    assert eng._folded["rcnn_lift"].ho == 128                           # lift kernel carries RCNN SA1's hoisted first layer
+    # the `wide` variant is what jm_sa_mlp_forward dispatches to at hidden widths > 128 / GroupAll
+    import ctypes
+    from jmodt_amd import _lib
+    lib = _lib.load()
+    for (b, n, m, c, ns, ga, widths) in ((2, 1024, 256, 256, 16, 0, [259, 128, 196, 256]), (2, 256, 64, 512, 32, 0, [515, 256, 384, 512]),
+                                         (256, 32, 1, 256, 32, 1, [259, 256, 256, 512])):
+        assert lib.jm_sa_mlp_supported(b, n, m, c, ns, ga, 3, (ctypes.c_int * 4)(*widths)) == 2, widths
+
+
+def test_full_width_backbone_and_rpn_heads_free_running(full_run):
+    want = full_run["chain"].rpn(full_run["xyz"], full_run["img"], full_run["xy"])
+    inter = full_run["inter"]
+    for lv, (got_idx, want_idx) in enumerate(zip(full_run["eng"].last_fps_idx, full_run["chain"].last["fps_idx"])):
+        assert np.array_equal(got_idx.cpu().numpy(), want_idx), f"FPS level {lv + 1}"
+    assert float(want["backbone_features"].abs().max()) > 0.5
+    close(inter["backbone_features"], want["backbone_features"])
+    close(inter["rpn_cls"], want["rpn_cls"])
+    close(inter["rpn_reg"], want["rpn_reg"])
+
+
+def test_full_width_proposals_roipool_rcnn_teacher_forced(full_run, oracle):
+    inter, chain, cfg = full_run["inter"], full_run["chain"], full_run["eng"].cfg
+    xyz = full_run["xyz"]
+    rpn_cls, rpn_reg = inter["rpn_cls"].cpu().numpy(), inter["rpn_reg"].cpu().numpy()
+    feats = inter["backbone_features"].cpu().numpy()
+    from jmodt_amd.ops.proposal import decode_rpn_proposals
+    dec = decode_rpn_proposals(T(xyz), inter["rpn_reg"], cfg.rpn_loc_scope, cfg.rpn_loc_bin_size,
+                               cfg.rpn_num_head_bin, cfg.mean_size).cpu().numpy()
+    close(dec, oracle.decode_rpn_proposals(xyz, rpn_reg, cfg.rpn_loc_scope, cfg.rpn_loc_bin_size, cfg.rpn_num_head_bin, cfg.mean_size))
+    wb, ws = oracle.proposal_select(rpn_cls[:, :, 0], dec, cfg.rpn_pre_nms_top_n, cfg.rpn_post_nms_top_n,
+                                    cfg.rpn_nms_thresh, cfg.rpn_nms_type)
+    rois = inter["rois"].cpu().numpy()
+    assert rois.shape == (2, 128, 7)
+    assert np.array_equal(rois, wb) and np.array_equal(inter["roi_scores_raw"].cpu().numpy(), ws)
+    assert (np.abs(rois).sum(-1) > 0).sum() >= 200         # the proposal layer fills (nearly) every RoI slot
+    want_pts, _ = chain.roi_pool(xyz, rpn_cls, feats, rois)
+    got_pts = inter["pts_input"].cpu().numpy()
+    assert got_pts.shape == (256, 512, 133)
+    assert np.array_equal(got_pts[..., 3], want_pts[..., 3]) and np.array_equal(got_pts[..., 5:], want_pts[..., 5:])
+    close(got_pts[..., 4], want_pts[..., 4], 1e-6)
+    close(got_pts[..., :3], want_pts[..., :3])
+    assert (np.abs(got_pts[..., 5:]).sum(axis=(1, 2)) > 0).mean() > 0.5
+    want = chain.rcnn(got_pts)                              # 256 RoIs x 512 points, un-fused, float64
+    close(inter["rcnn_feat"], want["rcnn_feat"])
+    close(inter["rcnn_cls"], want["rcnn_cls"])
+    close(inter["rcnn_reg"], want["rcnn_reg"])
+
+
+def test_full_width_detections_and_affinity_teacher_forced(full_run, oracle):
+    inter, chain, cfg, cache = full_run["inter"], full_run["chain"], full_run["eng"].cfg, full_run["cache"]
+    rois = inter["rois"].cpu().numpy()
+    B, M = rois.shape[:2]
+    reg = inter["rcnn_reg"].cpu().numpy()
+    boxes = inter["pred_boxes3d"].cpu().numpy()
+    close(boxes, oracle.decode_rcnn_boxes(rois.reshape(-1, 7), reg, cfg.rcnn_loc_scope, cfg.rcnn_loc_bin_size,
+                                          cfg.rcnn_num_head_bin, cfg.mean_size).reshape(B, M, 7))
+    raw = inter["rcnn_cls"].cpu().numpy().reshape(B, M)
+    keep = oracle.select_detections(boxes, raw, cfg.rcnn_score_thresh, cfg.rcnn_nms_thresh)
+    counts = cache.counts_host()
+    assert sum(counts) > 0
+    feats = inter["rcnn_feat"].view(B, M, -1).cpu().numpy()
+    for b in range(B):
+        assert counts[b] == len(keep[b])
+        assert np.array_equal(cache.roi_index[b, :counts[b]].cpu().numpy(), keep[b])
+        bx, sc, ft = cache.to_host(b)
+        assert np.array_equal(bx, boxes[b][keep[b]]) and np.array_equal(ft, feats[b][keep[b]])
+    f64 = torch.from_numpy(feats).double()
+    for b in range(B):                                      # 128 x 128 pairs x 512 channels per frame
+        A, s, e = full_run["aff"][b]
+        wA, ws_, we = chain.affinity(f64[b - 1], f64[b])
+        close(A, wA); close(s, ws_); close(e, we)
 
 
 def test_engine_without_side_streams_gives_identical_results(run):
@@ -332,6 +446,34 @@ def test_bench_workloads_smoke(workload, extra):
         assert "finetune" in names
 
 
+@pytest.mark.parametrize("extra", [["--workload", "train", "--tiny", "--launch"], ["--workload", "detect", "--tiny", "--launch"]])
+def test_bench_self_launch_under_torch_distributed_run(extra):
+    """`python bench.py --gpus N` from a plain shell re-executes itself under torch.distributed.run (the driver's N > 1
+    command line); --launch takes that path on ONE GPU: rendezvous on 127.0.0.1, RCCL communicator, barriers, the MAX
+    all-reduce of the timing and (train) the bucketed gradient all-reduce all run, and stdout is still exactly one JSON line"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["value"] > 0 and r["steps"] == 2
+    assert "dp1" in r["config"]["parallelism"] or "replicas x1" in r["config"]["parallelism"]
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """--gpus 2 on a one-GPU box: the self-launched job must fail loudly (no silent fallback to one GPU)"""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--tiny", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert "GPU(s)" in p.stderr
+
+
 @pytest.mark.parametrize("ic,pc,n,B", [(64, 96, 4096, 2), (128, 256, 1024, 3), (32, 128, 16384, 1), (8, 48, 64, 2), (20, 40, 96, 1)])
 def test_attention_fusion_kernel_vs_module(ic, pc, n, B):
     """csrc/li_fusion.hip against the parameter container's own forward (Linear / Conv1d / BatchNorm1d modules =
@@ -397,7 +539,7 @@ def test_sparse_image_fusion_gather_vs_dense(full, B, N, H, W):
     from jmodt_amd.detector import DetectAffinityEngine, DetectorConfig
     from jmodt_amd.ops.fusion import PackedImageFusion, feature_gather
     torch.manual_seed(7)
-    eng = DetectAffinityEngine(DetectorConfig() if full else DetectorConfig.tiny())
+    eng = DetectAffinityEngine(DetectorConfig.survey() if full else DetectorConfig.tiny())
     net = eng.rpn.backbone_net
     g = torch.Generator().manual_seed(8)
     with torch.no_grad():
