@@ -1,7 +1,10 @@
 """Turn rocprofv3 (ROCm 7.2, rocpd SQLite) output into the small text tables committed here.
 
-    python profiles/summarize.py <results.db> [out.txt]            per-kernel time stats
-    python profiles/summarize.py --pmc <results.db> [out.txt]      per-kernel PMC counter averages
+    python profiles/summarize.py <results.db> [out.txt]            per-kernel time stats, then the same per SHAPE:
+                                                                   one row per (kernel, grid, workgroup), so that a kernel
+                                                                   launched at several shapes in one workload (sa_mlp_pm:
+                                                                   RPN SA2 x2, RCNN SA1, SA2) has each shape's own average
+    python profiles/summarize.py --pmc <results.db> [out.txt]      per-kernel PMC counter averages (+ per shape)
 """
 import sqlite3
 import sys
@@ -21,10 +24,42 @@ def stats(db_path, out_path=None):
     lines = [f"{'kernel':<64} {'calls':>6} {'total_us':>12} {'avg_us':>11} {'min_us':>10} {'max_us':>10} {'pct':>6}"]
     for n, c, s, a, mn, mx in rows:
         lines.append(f"{short(n):<64} {c:>6} {s / 1e3:>12.1f} {a / 1e3:>11.2f} {mn / 1e3:>10.2f} {mx / 1e3:>10.2f} {100 * s / total:>6.2f}")
+    lines += ["", shape_table(cur, cols, name_col)]
     text = "\n".join(lines) + "\n"
     if out_path:
         open(out_path, "w").write(text)
     print(text)
+
+
+def _shape_cols(cols):
+    """the grid / workgroup columns of a rocpd view, whatever this ROCm calls them"""
+    def pick(*stems):
+        found = []
+        for axis in ("x", "y", "z"):
+            hit = [c for c in cols if any(c.lower() in (f"{st}_{axis}", f"{st}_size_{axis}", f"{st}{axis}") for st in stems)]
+            if not hit:
+                return None
+            found.append(hit[0])
+        return found
+    return pick("grid"), pick("workgroup", "block", "wg")
+
+
+def shape_table(cur, cols, name_col, top=70):
+    grid, wg = _shape_cols(cols)
+    if not grid or not wg:
+        return f"(no grid / workgroup columns in the kernels view: {cols})"
+    key = ", ".join([name_col] + grid + wg)
+    rows = cur.execute(f"select {key}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels "
+                       f"group by {key} order by sum(end-start) desc limit {top}").fetchall()
+    lines = [f"per dispatch shape (top {top} by total time; grid = work-items as rocprofv3 records them)",
+             f"{'kernel':<56} {'grid':>18} {'wg':>12} {'calls':>6} {'total_us':>12} {'avg_us':>11} {'min_us':>10} {'max_us':>10}"]
+    for r in rows:
+        n, g, w = r[0], r[1:4], r[4:7]
+        c, s, a, mn, mx = r[7:]
+        gs = "x".join(str(v) for v in g if v not in (1, None)) or "1"
+        ws = "x".join(str(v) for v in w if v not in (1, None)) or "1"
+        lines.append(f"{short(n)[-56:]:<56} {gs:>18} {ws:>12} {c:>6} {s / 1e3:>12.1f} {a / 1e3:>11.2f} {mn / 1e3:>10.2f} {mx / 1e3:>10.2f}")
+    return "\n".join(lines)
 
 
 def pmc(db_path, out_path=None):
@@ -44,6 +79,19 @@ def pmc(db_path, out_path=None):
     lines = [f"{'kernel':<64} {'counter':<14} {'dispatches':>10} {'avg':>16} {'min':>16} {'max':>16}"]
     for k, c, n, a, mn, mx in rows:
         lines.append(f"{short(k):<64} {c:<14} {n:>10} {a:>16.1f} {mn:>16.1f} {mx:>16.1f}")
+    grid, wg = _shape_cols(cols)
+    if grid and wg:
+        key = ", ".join([kcol[0]] + grid + wg + [ccol[0]])
+        rows = cur.execute(f"select {key}, count(*), avg({vcol[0]}), min({vcol[0]}), max({vcol[0]}) from counters_collection "
+                           f"group by {key} order by avg({vcol[0]}) desc limit 60").fetchall()
+        lines += ["", "per dispatch shape (top 60 by counter average)",
+                  f"{'kernel':<56} {'grid':>18} {'wg':>12} {'counter':<14} {'dispatches':>10} {'avg':>16} {'min':>16} {'max':>16}"]
+        for r in rows:
+            gs = "x".join(str(v) for v in r[1:4] if v not in (1, None)) or "1"
+            ws = "x".join(str(v) for v in r[4:7] if v not in (1, None)) or "1"
+            lines.append(f"{short(r[0])[-56:]:<56} {gs:>18} {ws:>12} {r[7]:<14} {r[8]:>10} {r[9]:>16.1f} {r[10]:>16.1f} {r[11]:>16.1f}")
+    else:
+        lines += ["", f"(no grid / workgroup columns in counters_collection: {cols})"]
     text = "\n".join(lines) + "\n"
     if out_path:
         open(out_path, "w").write(text)

@@ -2,9 +2,9 @@
 # Run ON THE GPU BOX (through gpurun): rocprofv3 kernel-trace stats + PMC passes (one counter per pass, never combined
 # with other trace domains) for the bench workloads.  The rocpd databases stay in /tmp (they exceed gpurun's 64 MiB
 # copy-back limit); only the text summaries land in gpurun_out/profiles/, from where they are copied into profiles/.
-#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r02'
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r03'
 set -u
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/profiles
 mkdir -p "$OUT"
