@@ -82,18 +82,41 @@ def detect_step(st):
     return st["engine"](st["xyz"], st["image"], st["pts_xy"], next_xyz=st["xyz"] if pf else None, next_image=st["image"] if pf else None)
 
 
-def cpu_baseline_detect(frames=2):
-    """the chained CPU oracle (float32, the reference's arithmetic) on `frames` full-size frames"""
+def _liven(eng, seed):
+    """non-trivial BatchNorm statistics / biases and head weights that produce a spread of scores and visible box
+    regression (the default initialisation gives every point the same objectness to ~1e-3: proposal selection would be
+    decided by rounding noise and a per-stage comparison with the CPU chain would stop at the first discrete decision)"""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in eng.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+        eng.rpn.rpn_cls_layer[2].conv.bias.zero_()
+        eng.rpn.rpn_cls_layer[2].conv.weight.mul_(8.0)
+        eng.rpn.rpn_reg_layer[2].conv.weight.copy_(torch.randn(eng.rpn.rpn_reg_layer[2].conv.weight.shape, generator=g) * 0.3)
+        eng.rcnn_net.reg_layer[-1].conv.weight.copy_(torch.randn(eng.rcnn_net.reg_layer[-1].conv.weight.shape, generator=g) * 0.3)
+        eng.rcnn_net.cls_layer[-1].conv.weight.mul_(6.0)
+
+
+def cpu_baseline_detect(frames=2, dev=None):
+    """the chained CPU oracle (float32, the reference's arithmetic) on `frames` full-size frames; with `dev`, the engine
+    then runs the SAME frames with the SAME weights on the GPU and every stage's output is compared with the chain's
+    (free running on both sides: stages behind a discrete decision are compared only when the decision was identical)"""
     from jmodt_amd.detector import DetectAffinityEngine, DetectorConfig
     from oracle.pipeline import Chain
     torch.manual_seed(99)
     cfg = DetectorConfig.survey()
-    sd = DetectAffinityEngine(cfg).state_dict()
+    eng = DetectAffinityEngine(cfg)
+    _liven(eng, 100)
+    sd = eng.state_dict()
     xyz, img, xy = synth.frames(frames, 16384, 4321)
     chain = Chain(sd, cfg, torch.float32)
     t0 = time.perf_counter()
     with torch.no_grad():
-        chain.forward(xyz, img, xy)
+        want = chain.forward(xyz, img, xy)
     dt = time.perf_counter() - t0
     # BASELINE configs[0] on its own: the link / start-end head on 64 cached proposal features, PyTorch-CPU
     f64 = torch.relu(torch.randn(2, 64, cfg.rcnn_sa_mlps[-1][-1]))
@@ -103,7 +126,38 @@ def cpu_baseline_detect(frames=2):
         for _ in range(3):
             chain.affinity(f64[0], f64[1])
         aff64 = (time.perf_counter() - t1) / 3
-    return frames / dt, dt, chain.stage_seconds, aff64
+    parity = None
+    if dev is not None:
+        eng = eng.to(dev)
+        with torch.no_grad():
+            cache, aff, inter = eng(torch.from_numpy(xyz).to(dev), torch.from_numpy(img).to(dev), torch.from_numpy(xy).to(dev))
+        torch.cuda.synchronize()
+
+        def err(got, ref):
+            got = got.detach().float().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+            ref = ref.detach().float().cpu().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
+            return {"max_abs_err": float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()), "max_abs_ref": float(np.abs(ref).max())}
+        parity = {"note": "GPU engine vs the float32 CPU chain, same weights and frames, both free running; float64 teacher-forced "
+                          "bars are in tests/test_gpu_detector.py::test_full_width_*",
+                  "fps_indices_identical": all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(eng.last_fps_idx, chain.last["fps_idx"])),
+                  "backbone_features": err(inter["backbone_features"], want["backbone_features"]),
+                  "rpn_cls": err(inter["rpn_cls"], want["rpn_cls"]), "rpn_reg": err(inter["rpn_reg"], want["rpn_reg"])}
+        same_rois = bool(np.array_equal(inter["rois"].cpu().numpy(), want["rois"]))
+        parity["rois_identical"] = same_rois
+        parity["rois_identical_rows"] = float((inter["rois"].cpu().numpy() == want["rois"]).all(-1).mean())
+        if same_rois:
+            B, M = want["rois"].shape[:2]
+            parity["roipool_pts_input"] = err(inter["pts_input"], want["pts_input"])
+            for k in ("rcnn_feat", "rcnn_cls", "rcnn_reg"):
+                parity[k] = err(inter[k], want[k])
+            parity["pred_boxes3d"] = err(inter["pred_boxes3d"], want["pred_boxes3d"])
+            counts = cache.counts_host()
+            parity["detection_keep_identical"] = all(
+                np.array_equal(cache.roi_index[b, :counts[b]].cpu().numpy(), want["keep"][b]) for b in range(B))
+            parity["affinity"] = {"max_abs_err": max(err(aff[b][0], want["affinity"][b][0])["max_abs_err"] for b in range(B)),
+                                  "start_end_max_abs_err": max(max(err(aff[b][1], want["affinity"][b][1])["max_abs_err"],
+                                                                   err(aff[b][2], want["affinity"][b][2])["max_abs_err"]) for b in range(B))}
+    return frames / dt, dt, chain.stage_seconds, aff64, parity
 
 
 # ---------------------------------------------------------------------------------------------- sa
@@ -285,7 +339,7 @@ def make_train_state(frames, seed, dev, tiny=False):
         p.requires_grad_(False)
     for p in list(link.parameters()) + list(se.parameters()):
         p.requires_grad_(True)
-    st["opt"] = torch.optim.Adam(list(link.parameters()) + list(se.parameters()), lr=2e-4, weight_decay=1e-2)
+    st["opt"] = torch.optim.Adam(list(link.parameters()) + list(se.parameters()), lr=2e-4, weight_decay=1e-2, fused=True)   # one launch
     st["rois_per_frame"] = rois_per_frame
     return st
 
@@ -378,6 +432,38 @@ def pick_roofline(kernels, traffic_json, full_table=True):
     if "us_per_fps_iteration" in dom:
         r["us_per_fps_iteration"] = dom["us_per_fps_iteration"]
     return r
+
+
+# bench row -> kernel-name needle in the committed rocprofv3 per-shape table (profiles/<round>_detect_kernel_stats.txt)
+ROCPROF_NEEDLE = {"rcnn_sa1/sa_mlp_pm_forward": "sa_mlp_pm_kernel", "affinity_8x128x128/affinity_forward_batched": "mlp_gemm_kernel"}
+
+
+def rocprof_average(kernel_row):
+    """average duration of the roofline kernel's LARGEST shape in the committed rocprofv3 --kernel-trace --stats summary of
+    this same command (bench.py itself runs un-profiled): the cross-check of the live HIP-event time"""
+    needle = ROCPROF_NEEDLE.get(kernel_row)
+    if not needle:
+        return None
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_detect_kernel_stats.txt")
+        try:
+            lines = open(path).read().splitlines()
+        except OSError:
+            continue
+        start = next((i for i, ln in enumerate(lines) if ln.startswith("per dispatch shape")), None)
+        best = None
+        for ln in (lines[start + 2:] if start is not None else lines[1:]):
+            if needle in ln:
+                f = ln.split()
+                try:
+                    calls, avg = (int(f[-5]), float(f[-3])) if start is not None else (int(f[-6]), float(f[-4]))
+                except (ValueError, IndexError):
+                    continue
+                if best is None or avg > best[1]:
+                    best = (calls, avg)
+        if best:
+            return {"avg_us": best[1], "calls": best[0], "source": os.path.relpath(path, ROOT) + (" (per-shape table)" if start is not None else " (all shapes of the kernel in one row)")}
+    return None
 
 
 def main():
@@ -517,12 +603,43 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # the same workload with one overlap mechanism off at a time (a few steps, after the timed region, outside `value`)
+    variants = {}
+    if args.workload == "detect" and args.steps >= 2:
+        eng = st["engine"]
+        n_var = max(2, min(5, args.steps))
+
+        def variant(prefetch, overlap):
+            keep = (st["prefetch"], eng.overlap)
+            st["prefetch"], eng.overlap = prefetch, overlap
+            try:
+                step(); step()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                for _ in range(n_var):
+                    step()
+                torch.cuda.synchronize()
+                return world * args.batch * n_var / (time.perf_counter() - t2)
+            finally:
+                st["prefetch"], eng.overlap = keep
+                step()                                  # consume / re-announce under the restored settings
+                torch.cuda.synchronize()
+        if st["prefetch"] and eng.overlap:
+            variants["no_prefetch_value"] = round(variant(False, True), 2)
+        if eng.overlap:
+            variants["no_overlap_value"] = round(variant(False, False), 2)
+        variants["variants_note"] = (f"{n_var} steps each after the timed region, this rank x world: no_prefetch = every batch's FPS pyramid "
+                                     "starts at the head of its OWN step (still on the side stream, nothing announced early); no_overlap = "
+                                     "FPS chain, image branch and detection glue all on the main stream")
+        if dist is not None:
+            dist.barrier()
+
     if rank == 0:
         kernels = prof.summary(table_steps, HBM_PEAK_GBS, MFMA_F32_PEAK_TF)
         # HBM bytes per launch from the committed rocprofv3 --pmc passes (collected separately, as the guide
         # prescribes; bench.py itself runs un-profiled)
         tj = None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")))
                 break
@@ -543,6 +660,20 @@ def main():
         fps_total = sum(k["ms_per_step"] for k in kernels if k["kernel"].startswith("fps_pyramid/"))
         img_exposed = sum(k["ms_per_step"] for k in kernels if k.get("stall") and k["kernel"].startswith("image_exposed"))
         frames = world * args.batch * args.steps
+        # all fp32 matrix-core work of one step (what each kernel EXECUTES: hoisted first layers excluded, MIOpen's 3x3
+        # convolutions included) over the step time
+        mfma_flops = sum(k.get("executed_flops_per_step", k.get("algo_flops_per_step", 0)) for k in kernels)
+        if roofline is not None and roofline.get("bound") == "mfma":
+            dom_row = next((k for k in timed_rows if k["kernel"] == roofline["kernel"]), None)
+            if dom_row:
+                roofline["avg_launch_ms"] = dom_row["ms_per_step"] / max(dom_row["launches_per_step"], 1)
+                roofline["max_launch_ms"] = dom_row["max_launch_ms"]
+            rp = rocprof_average(roofline["kernel"])
+            if rp:
+                ex = next((k.get("executed_flops_per_step", k.get("algo_flops_per_step")) for k in kernels if k["kernel"] == roofline["kernel"]), None)
+                if ex:
+                    rp["frac"] = round(ex / (rp["avg_us"] * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, 4)
+                roofline["rocprof"] = rp
         result = {
             "metric": METRIC,
             "value": round(frames / elapsed, 2),
@@ -562,6 +693,13 @@ def main():
                        "points": (65536 if args.workload == "dense" else 16384) if not args.tiny else "tiny",
                        "parallelism": f"dp{world} (gradient all-reduce)" if args.workload == "train" else f"replicas x{world}"},
             "roofline": roofline,
+            "step_mfma_frac": round(mfma_flops / (ms_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4) if ms_step else None,
+            "step_mfma_flops": int(mfma_flops),
+            **variants,
+            "affinity_operands": ("all RoI slots of every frame (P = D = proposals per frame: fixed work per frame, SURVEY.md §8d), not the "
+                                  "detection-NMS survivors: the head therefore does not wait for box decode / score filter / rotated NMS, "
+                                  "which run on a side stream under its GEMMs; DetectionCache.associate (tests) is the survivor-only form"
+                                  if args.workload == "detect" else None),
             "overlap": {"side_streams": not args.no_overlap, "next_batch_fps_prefetch": not (args.no_prefetch or args.no_overlap),
                         "fps_chain_ms": round(fps_total, 4), "fps_exposed_ms": round(exposed, 4),
                         "fps_critical_path_share": round(exposed / ms_step, 4) if ms_step else None,
@@ -576,8 +714,9 @@ def main():
             try:
                 extra = {}
                 if args.workload == "detect":
-                    fps, dt, stages, aff64 = cpu_baseline_detect(2)
-                    extra = {"stage_seconds": stages, "configs0_affinity_64x64_pytorch_cpu_ms": round(aff64 * 1e3, 2)}
+                    fps, dt, stages, aff64, parity = cpu_baseline_detect(2, dev)
+                    extra = {"stage_seconds": stages, "configs0_affinity_64x64_pytorch_cpu_ms": round(aff64 * 1e3, 2),
+                             "gpu_vs_chain": parity}
                     sample = (f"2 full-size frames (one (prev, next) pair) through the chained CPU oracle in {dt:.1f} s: "
                               "oracle C restatement for the jmodt ops (the reference has no CPU code for them), the "
                               "same PyTorch-CPU operators the reference calls for conv / BN / Linear / grid_sample / "

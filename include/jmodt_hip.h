@@ -381,6 +381,56 @@ size_t jm_mlp3_workspace_bytes(int m, const jm_mlp3_t* mlp);
 int jm_mlp3_forward(int m, const float* x, const jm_mlp3_t* mlp, float* y, void* ws, size_t ws_bytes,
                     jm_stream_t stream);
 
+/* ------------------------------------------------------------------ training-time affinity ---- */
+
+/* Gradients of one 3-layer head, same shapes as jm_mlp3_t's tensors: dw1 (h1, c), db1 (h1), dw2 (h2, h1), db2 (h2),
+ * dw3 (h2), db3 (1).  Written (not accumulated). */
+typedef struct {
+    float *dw1, *db1, *dw2, *db2, *dw3, *db3;
+} jm_mlp3_grad_t;
+
+/* Training-time pairwise affinity for `npairs` (prev, next) frame pairs of r RoI slots each, static shapes, no host
+ * synchronisation (jmodt/detection/modeling/rcnn.py:145-156,204-287; losses train_functions.py:282-329, L1 form).
+ *
+ * jm_affinity_train_prepare: feats (2*npairs, r, c) and tids (2*npairs, r) with frames interleaved prev, next, prev, ...
+ *   (rcnn.py:212-217; tid <= 0 = background) ->
+ *   pooled_prev / pooled_next (npairs*r, c)  mean feature of the foreground RoIs sharing the slot's track id
+ *                                            (get_unique_tid_feature, rcnn.py:145-156), zero for background slots
+ *   rep_prev / rep_next (npairs, r) i32      1 = the slot is the first foreground RoI of its id (one row of the reference's
+ *                                            unique-id tensors) and the pair has foreground on both sides (rcnn.py:230)
+ *   n_pair (npairs, 2) i32                   representatives per pair [prev, next]
+ *   gt_starts / gt_ends (npairs, r)          1 - column / row sums of the tid-equality matrix (rcnn.py:247-252)
+ *   counts (3) f32, DEVICE                   LOCAL element counts of the three loss means [links, starts, ends]; a
+ *                                            data-parallel caller all-reduces them before the step calls (the reference
+ *                                            takes its means over the gathered batch)
+ *   rep_ws: (2*npairs, r) i32 scratch.
+ * jm_affinity_train_link_step: link head forward on all npairs*r*r slot pairs (|prev_i - next_j| formed on the fly),
+ *   masked dual softmax, loss_part[f] = sum over valid entries |link - gt| (divide by counts[0] for the mean), and the
+ *   gradients of loss_weight * sum(loss_part) / max(counts[0], 1) w.r.t. the six tensors of `link`.
+ *   link_out / gt_links (npairs, r, r) optional (zero outside rep_prev x rep_next).
+ * jm_affinity_train_se_step: masked start / end feature means, se head, sigmoid + L1; se_logits (npairs, 2r) = per pair
+ *   [start logits of the next slots | end logits of the prev slots] (optional); loss_part (npairs, 2) = [sum |sigmoid(start) -
+ *   gt|, sum |sigmoid(end) - gt|]; gradients of loss_weight * (sum_start / max(counts[1], 1) + sum_end / max(counts[2], 1)).
+ * The two step calls are independent of each other (a caller may run them on two streams).  Gradients w.r.t. the RoI
+ * features are not produced (finetune: the detector is frozen, tools/train.py:96-107). */
+int jm_affinity_train_prepare(int npairs, int r, int c, const float* feats, const float* tids, float* pooled_prev,
+                              float* pooled_next, int* rep_ws, int* rep_prev, int* rep_next, int* n_pair, float* gt_starts,
+                              float* gt_ends, float* counts, jm_stream_t stream);
+/* loss[0] = link_weight * sum(link_loss_part) / max(counts[0], 1) + se_weight * (sum(se_loss_part[:, 0]) / max(counts[1], 1) +
+ * sum(se_loss_part[:, 1]) / max(counts[2], 1))   (train_functions.py:282-329: the three L1 means, weighted) */
+int jm_affinity_train_loss_value(int npairs, const float* link_loss_part, const float* se_loss_part, const float* counts,
+                                 float link_weight, float se_weight, float* loss, jm_stream_t stream);
+size_t jm_affinity_train_link_workspace_bytes(int npairs, int r, const jm_mlp3_t* link);
+int jm_affinity_train_link_step(int npairs, int r, const float* pooled_prev, const float* pooled_next, const int* rep_prev,
+                                const int* rep_next, const float* tids, const float* counts, float loss_weight,
+                                const jm_mlp3_t* link, float* link_out, float* gt_links, float* loss_part,
+                                const jm_mlp3_grad_t* grads, void* ws, size_t ws_bytes, jm_stream_t stream);
+size_t jm_affinity_train_se_workspace_bytes(int npairs, int r, const jm_mlp3_t* se);
+int jm_affinity_train_se_step(int npairs, int r, const float* pooled_prev, const float* pooled_next, const int* rep_prev,
+                              const int* rep_next, const int* n_pair, const float* gt_starts, const float* gt_ends,
+                              const float* counts, float loss_weight, const jm_mlp3_t* se, float* se_logits, float* loss_part,
+                              const jm_mlp3_grad_t* grads, void* ws, size_t ws_bytes, jm_stream_t stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -26,6 +26,11 @@ class Mlp3(ctypes.Structure):
                 ("b3", _P)]
 
 
+class Mlp3Grad(ctypes.Structure):
+    """jm_mlp3_grad_t"""
+    _fields_ = [("dw1", _P), ("db1", _P), ("dw2", _P), ("db2", _P), ("dw3", _P), ("db3", _P)]
+
+
 # name -> (restype, argtypes); mirrors include/jmodt_hip.h one to one
 SIGNATURES = {
     "jm_version": (_I, []),
@@ -96,6 +101,14 @@ SIGNATURES = {
     "jm_linear_rows": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "jm_mlp3_workspace_bytes": (_Z, [_I, ctypes.POINTER(Mlp3)]),
     "jm_mlp3_forward": (_I, [_I, _P, ctypes.POINTER(Mlp3), _P, _P, _Z, _P]),
+    "jm_affinity_train_prepare": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "jm_affinity_train_loss_value": (_I, [_I, _P, _P, _P, _F, _F, _P, _P]),
+    "jm_affinity_train_link_workspace_bytes": (_Z, [_I, _I, ctypes.POINTER(Mlp3)]),
+    "jm_affinity_train_link_step": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _F, ctypes.POINTER(Mlp3), _P, _P, _P,
+                                         ctypes.POINTER(Mlp3Grad), _P, _Z, _P]),
+    "jm_affinity_train_se_workspace_bytes": (_Z, [_I, _I, ctypes.POINTER(Mlp3)]),
+    "jm_affinity_train_se_step": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, ctypes.POINTER(Mlp3), _P, _P,
+                                       ctypes.POINTER(Mlp3Grad), _P, _Z, _P]),
 }
 
 _lib = None

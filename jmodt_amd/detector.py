@@ -320,7 +320,10 @@ class DetectAffinityEngine(nn.Module):
         storage.  Same rule as the SA / FP module caches (ops/pointnet2/fused.py:_packed_layers); called at every public
         entry (a few hundred attribute reads, ~0.1 ms of host time per batch)."""
         if self._sig_tensors is None:
-            self._sig_tensors = list(self.parameters()) + list(self.buffers())
+            # (the link / start-end heads are never folded: ops/affinity.py hands their live tensors to the kernels on every
+            # call, and the finetune step updates them every iteration — tools/train.py:96-107)
+            skip = {id(t) for head in (self.rcnn_net.link_layer, self.rcnn_net.se_layer) for t in head.parameters()}
+            self._sig_tensors = [t for t in list(self.parameters()) + list(self.buffers()) if id(t) not in skip]
         sig = tuple([(t.data_ptr(), t._version) for t in self._sig_tensors])
         if sig != self._folded_sig:
             self._folded.clear()
@@ -443,7 +446,12 @@ class DetectAffinityEngine(nn.Module):
         with torch.cuda.stream(img_stream):
             cur = image if self.fuse_rgb_conv and image.is_cuda else image.contiguous(memory_format=torch.channels_last)
             for i, blk in enumerate(net.Img_Block):
-                cur = self._t(f"image_block_{i + 1}(MIOpen)", 0, lambda k=i, c=cur: self._image_block(k, c))
+                # flops of the block's MIOpen convolutions (3x3 stride 1 cin -> cout at (h, w), 3x3 stride 2 cout -> cout);
+                # the 3-channel first layer of block 1 runs on the vector units (csrc/conv_rgb.hip) and is listed on its own
+                h, w, cin, cout = cur.shape[2], cur.shape[3], blk.conv1.in_channels, blk.conv1.out_channels
+                rgb = self.fuse_rgb_conv and image.is_cuda and cin == 3
+                fl = 2 * 9 * cur.shape[0] * ((0 if rgb else cin * cout * h * w) + cout * cout * ((h + 1) // 2) * ((w + 1) // 2))
+                cur = self._t(f"image_block_{i + 1}(MIOpen)", 0, lambda k=i, c=cur: self._image_block(k, c), flops=fl)
                 ev = torch.cuda.Event()
                 ev.record(img_stream)
                 img_maps.append(cur)

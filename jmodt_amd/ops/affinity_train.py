@@ -6,16 +6,26 @@ softmax, start/end features = cor.mean(0) / cor.mean(1) through the se head, gro
 matrix from track-id equality) and the re-id losses of
 jmodt/detection/modeling/train_functions.py:282-329 (L1 on links, L1 on sigmoid(start/end)).
 
-Forward+backward here go through torch autograd on the GPU (hipBLASLt GEMMs): the fused fp32-MFMA
-kernels of jmodt_amd/csrc/affinity.hip are forward-only so far (backward = DESIGN.md §7 "next").
+Three forms of the same computation:
+  * `training_affinity` / `reid_loss` / `finetune_step`: the reference's op sequence (Python loop over frame pairs,
+    torch.unique, data-dependent shapes) — the readable restatement, used by the tests as the bridge to the float64
+    statement-by-statement copy of rcnn.py;
+  * `training_affinity_static` / `reid_loss_static`: the static-shape, sync-free form in plain torch (masks instead of
+    torch.unique) — runs on CPU tensors, which is what the world-size-2 gloo tests of the data-parallel step use;
+  * `AffinityTrainState` / `affinity_train_loss` (GPU tensors): the static-shape form on the HAND-WRITTEN kernels of
+    jmodt_amd/csrc/affinity_train.hip — forward, losses and the backward of both heads as fp32-MFMA GEMM chains that never
+    materialise the |prev_i - next_j| pair tensor.  `finetune_step_static` takes this path for GPU tensors (no torch fallback
+    on the GPU: a missing library raises).
 The *inference* affinity (tracker.py:81-112) never comes through this module.
 """
-from typing import Dict, Tuple
+import ctypes
+from typing import Dict, Optional, Tuple
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import _lib as L
 from .. import dist as jdist
 
 
@@ -170,11 +180,189 @@ def reid_loss_static(out: Dict[str, torch.Tensor], counts: torch.Tensor = None, 
     return link_weight * l_link + se_weight * (l_start + l_end), local
 
 
+# ---------------------------------------------------------------------------------------------------------
+# the static-shape form on the HIP kernels (csrc/affinity_train.hip)
+# ---------------------------------------------------------------------------------------------------------
+_f32, _i32 = torch.float32, torch.int32
+
+
+def _head_tensors(head: nn.Sequential):
+    """the six parameter tensors of a link / se head in jm_mlp3_t order (w1, b1, w2, b2, w3, b3)"""
+    convs = [m for m in head.modules() if isinstance(m, nn.Conv1d)]
+    if len(convs) != 3 or any(isinstance(m, nn.BatchNorm1d) for m in head.modules()) or any(c.bias is None for c in convs):
+        raise NotImplementedError("affinity_train kernels support the reference head: 3 Conv1d(k=1) with bias, no BN")
+    for m in head.modules():
+        if isinstance(m, nn.Dropout) and m.p != 0 and head.training:
+            raise NotImplementedError("affinity_train kernels: dropout p > 0 in training mode")     # config.py:166-169: DP_RATIO 0
+    if convs[2].out_channels != 1 or any(c.kernel_size != (1,) for c in convs):
+        raise NotImplementedError("affinity_train kernels: kernel_size 1, last layer 1-wide")
+    return [convs[0].weight, convs[0].bias, convs[1].weight, convs[1].bias, convs[2].weight, convs[2].bias]
+
+
+def _mlp3(tensors):
+    ts = [t.detach() for t in tensors]
+    for t in ts:
+        L.dev(t, _f32, "affinity head parameter")
+    c, h1, h2 = ts[0].shape[1], ts[0].shape[0], ts[2].shape[0]
+    return L.Mlp3(c, h1, h2, *[ctypes.c_void_p(t.data_ptr()) for t in ts]), ts
+
+
+class AffinityTrainState:
+    """jm_affinity_train_prepare: pooled per-id features, representatives, targets and LOCAL loss-mean element counts of a
+    batch of interleaved (prev, next) frames: roi_features (2F, R, C), gt_tids (2F, R).  `counts` (3,) lives on the device;
+    a data-parallel step all-reduces it (SUM) before `affinity_train_loss`."""
+
+    def __init__(self, roi_features: torch.Tensor, gt_tids: torch.Tensor):
+        feats = roi_features.detach().to(_f32).contiguous()
+        tids = gt_tids.detach().to(_f32).contiguous()
+        if feats.dim() != 3 or tids.shape != feats.shape[:2] or feats.shape[0] % 2:
+            raise ValueError(f"roi_features (2F, R, C) and gt_tids (2F, R) expected, got {tuple(feats.shape)} / {tuple(tids.shape)}")
+        self.F, self.R, self.C = feats.shape[0] // 2, feats.shape[1], feats.shape[2]
+        dev, F_, R, C = feats.device, self.F, self.R, self.C
+        self.tids = tids
+        self.pooled_prev = torch.empty((F_ * R, C), dtype=_f32, device=dev)
+        self.pooled_next = torch.empty((F_ * R, C), dtype=_f32, device=dev)
+        self.rep_prev = torch.empty((F_, R), dtype=_i32, device=dev)
+        self.rep_next = torch.empty((F_, R), dtype=_i32, device=dev)
+        self.n_pair = torch.empty((F_, 2), dtype=_i32, device=dev)
+        self.gt_starts = torch.empty((F_, R), dtype=_f32, device=dev)
+        self.gt_ends = torch.empty((F_, R), dtype=_f32, device=dev)
+        self.counts = torch.empty((3,), dtype=_f32, device=dev)
+        rep_ws = torch.empty((2 * F_, R), dtype=_i32, device=dev)
+        L.check(L.load().jm_affinity_train_prepare(
+            F_, R, C, L.dev(feats, _f32, "roi_features"), L.dev(tids, _f32, "gt_tids"), L.dev(self.pooled_prev, _f32, "pooled_prev"),
+            L.dev(self.pooled_next, _f32, "pooled_next"), L.dev(rep_ws, _i32, "rep_ws"), L.dev(self.rep_prev, _i32, "rep_prev"),
+            L.dev(self.rep_next, _i32, "rep_next"), L.dev(self.n_pair, _i32, "n_pair"), L.dev(self.gt_starts, _f32, "gt_starts"),
+            L.dev(self.gt_ends, _f32, "gt_ends"), L.dev(self.counts, _f32, "counts"), L.stream_ptr()), "affinity_train_prepare")
+
+
+def _train_steps(st: AffinityTrainState, counts: torch.Tensor, link_t, se_t, link_weight: float, se_weight: float,
+                 want_outputs: bool):
+    """both heads' forward + loss + backward (link on the current stream, start/end on a side stream of the caller's):
+    returns (loss parts link (F,), se (F, 2), gradient tensors [6 link, 6 se], outputs dict or None)"""
+    from .pointnet2.pyramid import side_stream
+    lib = L.load()
+    dev = st.pooled_prev.device
+    F_, R = st.F, st.R
+    link, keep_l = _mlp3(link_t)
+    se, keep_s = _mlp3(se_t)
+    g_link = [torch.empty_like(t) for t in keep_l]
+    g_se = [torch.empty_like(t) for t in keep_s]
+    gl = L.Mlp3Grad(*[ctypes.c_void_p(t.data_ptr()) for t in g_link])
+    gs = L.Mlp3Grad(*[ctypes.c_void_p(t.data_ptr()) for t in g_se])
+    counts = counts.to(_f32).contiguous()
+    lp = torch.empty((F_,), dtype=_f32, device=dev)
+    sp = torch.empty((F_, 2), dtype=_f32, device=dev)
+    link_out = torch.empty((F_, R, R), dtype=_f32, device=dev) if want_outputs else None
+    gt_links = torch.empty((F_, R, R), dtype=_f32, device=dev) if want_outputs else None
+    se_logits = torch.empty((F_, 2 * R), dtype=_f32, device=dev) if want_outputs else None
+    main = torch.cuda.current_stream(dev)
+    side = side_stream(dev, 2)
+    se_bytes = lib.jm_affinity_train_se_workspace_bytes(F_, R, ctypes.byref(se))
+    se_ws = torch.empty((max(se_bytes, 16),), dtype=torch.uint8, device=dev)
+    side.wait_stream(main)
+    touched = [st.pooled_prev, st.pooled_next, st.rep_prev, st.rep_next, st.n_pair, st.gt_starts, st.gt_ends, counts, sp, se_ws,
+               *keep_s, *g_se] + ([se_logits] if want_outputs else [])
+    for t in touched:
+        t.record_stream(side)
+    with torch.cuda.stream(side):
+        L.check(lib.jm_affinity_train_se_step(
+            F_, R, L.dev(st.pooled_prev, _f32, "pooled_prev"), L.dev(st.pooled_next, _f32, "pooled_next"),
+            L.dev(st.rep_prev, _i32, "rep_prev"), L.dev(st.rep_next, _i32, "rep_next"), L.dev(st.n_pair, _i32, "n_pair"),
+            L.dev(st.gt_starts, _f32, "gt_starts"), L.dev(st.gt_ends, _f32, "gt_ends"), L.dev(counts, _f32, "counts"), float(se_weight),
+            ctypes.byref(se), L.dev(se_logits, _f32, "se_logits") if want_outputs else None, L.dev(sp, _f32, "loss_part"),
+            ctypes.byref(gs), ctypes.c_void_p(se_ws.data_ptr()), se_bytes, L.stream_ptr()), "affinity_train_se_step")
+    ws_bytes = lib.jm_affinity_train_link_workspace_bytes(F_, R, ctypes.byref(link))
+    ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+    L.check(lib.jm_affinity_train_link_step(
+        F_, R, L.dev(st.pooled_prev, _f32, "pooled_prev"), L.dev(st.pooled_next, _f32, "pooled_next"),
+        L.dev(st.rep_prev, _i32, "rep_prev"), L.dev(st.rep_next, _i32, "rep_next"), L.dev(st.tids, _f32, "gt_tids"),
+        L.dev(counts, _f32, "counts"), float(link_weight), ctypes.byref(link),
+        L.dev(link_out, _f32, "link_out") if want_outputs else None, L.dev(gt_links, _f32, "gt_links") if want_outputs else None,
+        L.dev(lp, _f32, "loss_part"), ctypes.byref(gl), ctypes.c_void_p(ws.data_ptr()), ws_bytes, L.stream_ptr()),
+        "affinity_train_link_step")
+    main.wait_stream(side)
+    outputs = None
+    if want_outputs:
+        rp, rn = st.rep_prev.bool(), st.rep_next.bool()
+        outputs = dict(link=link_out, gt_links=gt_links, valid=rp.unsqueeze(2) & rn.unsqueeze(1), start=se_logits[:, :R],
+                       gt_starts=st.gt_starts, start_valid=rn, end=se_logits[:, R:], gt_ends=st.gt_ends, end_valid=rp)
+    return lp, sp, g_link + g_se, outputs
+
+
+def _loss_from_parts(lp, sp, counts, link_weight, se_weight):
+    """the weighted sum of the three L1 means as a device scalar (one launch)"""
+    out = torch.empty((), dtype=_f32, device=lp.device)
+    counts = counts.to(_f32).contiguous()
+    L.check(L.load().jm_affinity_train_loss_value(lp.shape[0], L.dev(lp, _f32, "link_loss_part"), L.dev(sp, _f32, "se_loss_part"),
+                                                  L.dev(counts, _f32, "counts"), float(link_weight), float(se_weight),
+                                                  ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "affinity_train_loss_value")
+    return out
+
+
+class _AffinityTrainLoss(torch.autograd.Function):
+    """loss = link_weight * sum|link - gt| / counts[0] + se_weight * (sum|sig(start) - gt| / counts[1] + sum|sig(end) - gt| / counts[2])
+    with the gradients of the twelve head tensors computed by the kernels in the SAME pass (the backward GEMM chains run
+    right behind the forward ones); autograd's backward only scales them by the incoming gradient"""
+
+    @staticmethod
+    def forward(ctx, st, counts, link_weight, se_weight, *params):
+        lp, sp, grads, _ = _train_steps(st, counts, params[:6], params[6:], link_weight, se_weight, False)
+        ctx.grads = grads
+        return _loss_from_parts(lp, sp, counts, link_weight, se_weight)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None, None, None) + tuple(g * t for t in ctx.grads)
+
+
+def affinity_train_loss(st: AffinityTrainState, link_layer: nn.Module, se_layer: nn.Module, counts: Optional[torch.Tensor] = None,
+                        link_weight: float = 1.0, se_weight: float = 1.0) -> torch.Tensor:
+    """the re-id loss of train_functions.py:282-329 (L1 forms) of the prepared batch as a differentiable DEVICE scalar
+    (w.r.t. the parameters of the two heads; the RoI features are constants: the finetune step trains the heads only,
+    tools/train.py:96-107).  `counts` overrides the denominators (global element counts of a data-parallel step)."""
+    params = _head_tensors(link_layer) + _head_tensors(se_layer)
+    return _AffinityTrainLoss.apply(st, st.counts if counts is None else counts, float(link_weight), float(se_weight), *params)
+
+
+def training_affinity_hip(roi_features: torch.Tensor, gt_tids: torch.Tensor, link_layer: nn.Module, se_layer: nn.Module):
+    """`training_affinity_static`'s dictionary from the HIP kernels (+ 'loss', the local re-id loss), no gradients"""
+    st = AffinityTrainState(roi_features, gt_tids)
+    lp, sp, _, out = _train_steps(st, st.counts, _head_tensors(link_layer), _head_tensors(se_layer), 1.0, 1.0, True)
+    out["loss"] = _loss_from_parts(lp, sp, st.counts, 1.0, 1.0)
+    out["counts"] = st.counts
+    return out
+
+
+def _finetune_step_hip(roi_features, gt_tids, link_layer, se_layer, optimizer, world):
+    import torch.distributed as tdist
+    st = AffinityTrainState(roi_features, gt_tids)
+    counts = st.counts
+    if world > 1:
+        counts = counts.clone()
+        tdist.all_reduce(counts, op=tdist.ReduceOp.SUM)
+    params = _head_tensors(link_layer) + _head_tensors(se_layer)
+    lp, sp, grads, _ = _train_steps(st, counts, params[:6], params[6:], 1.0, 1.0, False)
+    optimizer.zero_grad(set_to_none=True)
+    for p, g in zip(params, grads):             # the kernels wrote d(loss)/d(param) of THIS rank's sums over the GLOBAL counts
+        p.grad = g
+    jdist.allreduce_gradients(params, world=world, average=False)
+    optimizer.step()
+    total = _loss_from_parts(lp, sp, counts, 1.0, 1.0)
+    if world > 1:
+        tdist.all_reduce(total, op=tdist.ReduceOp.SUM)
+    return total
+
+
 def finetune_step_static(roi_features: torch.Tensor, gt_tids: torch.Tensor, link_layer: nn.Module, se_layer: nn.Module,
                          optimizer: torch.optim.Optimizer, world: int = 1) -> torch.Tensor:
     """`finetune_step` without host synchronisation: static-shape forward/backward, the three global element counts
-    and the gradients all-reduced on the device (RCCL), Adam; returns the whole-batch loss as a DEVICE scalar"""
+    and the gradients all-reduced on the device (RCCL), Adam; returns the whole-batch loss as a DEVICE scalar.
+    GPU tensors: the hand-written kernels (csrc/affinity_train.hip); CPU tensors (the gloo tests of the data-parallel
+    logic): the plain-torch static form."""
     import torch.distributed as tdist
+    if roi_features.is_cuda:
+        return _finetune_step_hip(roi_features, gt_tids, link_layer, se_layer, optimizer, world)
     optimizer.zero_grad(set_to_none=True)
     out = training_affinity_static(roi_features, gt_tids, link_layer, se_layer)
     with torch.no_grad():

@@ -32,6 +32,11 @@ def _mlp3_flops(rows, dims):
     return rows * (2 * c * h1 + 2 * h1 * h2 + 2 * h2)
 
 
+def _train_flops(rows, dims):
+    c, h1, h2 = dims
+    return rows * (2 * c * h1 + 2 * h1 * h2 + 2 * h2) + rows * (2 * h2 * h1 + 2 * h2 * h1 + 2 * h1 * c)
+
+
 def _fps(a):
     b, n, m = _i(a, 0), _i(a, 1), _i(a, 2)
     # streaming-equivalent bytes (what the reference re-reads per iteration); the compulsory
@@ -122,6 +127,9 @@ ALGO: Dict[str, Callable] = {
         2 * _i(a, 0) * _i(a, 2) * _i(a, 4) * (_i(a, 3) * _i(a, 5) + _i(a, 5) * _i(a, 6)), {}),
     "jm_linear_rows": lambda a: (4 * (_i(a, 0) * (_i(a, 1) + _i(a, 2)) + _i(a, 1) * _i(a, 2)), 2 * _i(a, 0) * _i(a, 1) * _i(a, 2), {}),
     "jm_mlp3_forward": lambda a: (0, _mlp3_flops(_i(a, 0), _mlp3(a[2])), {}),
+    # a16: forward (3 layers) + backward (dH1, dW2, dW1) GEMMs of a head on M rows
+    "jm_affinity_train_link_step": lambda a: (0, _train_flops(_i(a, 0) * _i(a, 1) * _i(a, 1), _mlp3(a[9])), {}),
+    "jm_affinity_train_se_step": lambda a: (0, _train_flops(_i(a, 0) * 2 * _i(a, 1), _mlp3(a[11])), {}),
     "jm_association_cost": lambda a: ((_i(a, 0) + _i(a, 2)) * 28 + 4 * _i(a, 0) * _i(a, 2), 0, {}),
     "jm_boxes_overlap_bev": lambda a: ((_i(a, 0) + _i(a, 2)) * 20 + 4 * _i(a, 0) * _i(a, 2), 0, {}),
     "jm_boxes_iou_bev": lambda a: ((_i(a, 0) + _i(a, 2)) * 20 + 4 * _i(a, 0) * _i(a, 2), 0, {}),

@@ -150,6 +150,99 @@ def test_training_affinity_and_finetune_step_on_gpu():
             assert (ps.detach().double().cpu() - p64.detach())[big].abs().max().item() < 2e-4
 
 
+@pytest.mark.parametrize("frames,R,C,H,ntid", [(6, 64, 512, 512, 9), (4, 64, 512, 512, 30), (2, 48, 64, 64, 5), (8, 128, 128, 96, 40)])
+def test_training_affinity_hip_kernels_vs_float64_reference(frames, R, C, H, ntid):
+    """a16 on the matrix cores (csrc/affinity_train.hip): outputs, loss and the gradients of all twelve head tensors
+    against (i) the float64 statement-by-statement copy of rcnn.py:204-287 + train_functions.py:282-329 differentiated by
+    torch autograd on the CPU, (ii) the plain-torch static form.  Bars: 1e-4 on link / sigmoid outputs and the loss,
+    1e-4 x max|grad| per gradient tensor."""
+    import copy
+    from jmodt_amd.ops.affinity import make_affinity_mlp
+    from jmodt_amd.ops.affinity_train import (AffinityTrainState, affinity_train_loss, reid_loss_static, training_affinity_hip,
+                                              training_affinity_static)
+    g = torch.Generator().manual_seed(frames * R + C)
+    feats = torch.relu(torch.randn(frames, R, C, generator=g))
+    tids = torch.randint(0, ntid, (frames, R), generator=g).float()
+    if frames >= 6:
+        tids[2] = 0                                # a pair without foreground on one side is skipped (rcnn.py:230)
+    torch.manual_seed(3)
+    link, se = make_affinity_mlp(C, (H, H)), make_affinity_mlp(C, (H, H))
+    with torch.no_grad():
+        for m in list(link.modules()) + list(se.modules()):
+            if isinstance(m, torch.nn.Conv1d):
+                m.bias.normal_(0, 0.05)
+    link64, se64 = copy.deepcopy(link).double(), copy.deepcopy(se).double()
+    want = _reference_training_affinity(feats.double(), tids.double(), link64, se64)
+    l64 = _reid_loss_reference(want)
+    l64.backward()
+    dlink, dse = copy.deepcopy(link).to(DEV).train(), copy.deepcopy(se).to(DEV).train()
+    f_d, t_d = feats.to(DEV), tids.to(DEV)
+    out = training_affinity_hip(f_d, t_d, dlink, dse)
+    # (i) outputs: the reference's per-pair tensors are the slot matrices restricted to the representatives; its rows are
+    # ordered by ascending track id (torch.unique), ours by slot — compare as sorted multisets per pair via the static torch form
+    ref = training_affinity_static(f_d, t_d, dlink, dse)
+    for k in ("valid", "start_valid", "end_valid"):
+        assert torch.equal(out[k], ref[k]), k
+    v, sv, ev = ref["valid"], ref["start_valid"], ref["end_valid"]
+    assert int(v.sum()) == want["gt_links"].numel() and int(sv.sum()) == want["gt_starts"].numel()
+    assert torch.equal(out["gt_links"], ref["gt_links"]) and torch.equal(out["gt_starts"] * sv, ref["gt_starts"] * sv)
+    assert torch.equal(out["gt_ends"] * ev, ref["gt_ends"] * ev)
+    assert (out["link"] - ref["link"] * v).abs().max().item() < 1e-5
+    assert ((torch.sigmoid(out["start"]) - torch.sigmoid(ref["start"])) * sv).abs().max().item() < 1e-5
+    assert ((torch.sigmoid(out["end"]) - torch.sigmoid(ref["end"])) * ev).abs().max().item() < 1e-5
+    assert abs(out["loss"].item() - l64.item()) < 1e-5
+    assert abs(reid_loss_static(ref)[0].item() - l64.item()) < 1e-5
+    got_sorted = torch.sort(out["link"][v].double().cpu())[0]
+    assert (got_sorted - torch.sort(want["rcnn_link"].view(-1))[0]).abs().max().item() < 1e-4
+    # (ii) gradients through the autograd.Function
+    st = AffinityTrainState(f_d, t_d)
+    loss = affinity_train_loss(st, dlink, dse)
+    assert abs(loss.item() - l64.item()) < 1e-5
+    (2.0 * loss).backward()
+    names = ["w1", "b1", "w2", "b2", "w3", "b3"]
+    for head, (pd_list, p64_list) in (("link", (list(dlink.parameters()), list(link64.parameters()))),
+                                      ("se", (list(dse.parameters()), list(se64.parameters())))):
+        for nm, pd, p64 in zip(names, pd_list, p64_list):
+            gw = 2.0 * p64.grad
+            scale = max(gw.abs().max().item(), 1e-12)
+            err = (pd.grad.double().cpu() - gw).abs().max().item()
+            # (the link head's b3 gradient is ZERO mathematically: both softmaxes are invariant to a constant shift of the scores)
+            assert err <= 1e-4 * scale + 1e-7, (head, nm, err, scale)
+            assert gw.abs().max().item() > 0 or (head, nm) == ("link", "b3")
+    # determinism: the split-M partial sums are reduced in a fixed order
+    st2 = AffinityTrainState(f_d, t_d)
+    dlink.zero_grad(); dse.zero_grad()
+    (2.0 * affinity_train_loss(st2, dlink, dse)).backward()
+    again = [p.grad.clone() for p in list(dlink.parameters())[:1]]
+    dlink.zero_grad(); dse.zero_grad()
+    (2.0 * affinity_train_loss(AffinityTrainState(f_d, t_d), dlink, dse)).backward()
+    assert (list(dlink.parameters())[0].grad - again[0]).abs().max().item() <= 1e-6 * again[0].abs().max().item()
+
+
+def test_finetune_step_static_uses_the_hip_kernels():
+    """bench.py --workload train's step: on GPU tensors it is the hand-written kernels that run (profiler records)"""
+    from jmodt_amd.ops.affinity import make_affinity_mlp
+    from jmodt_amd.ops.affinity_train import finetune_step_static
+    from jmodt_amd.profile import prof
+    torch.manual_seed(0)
+    link, se = make_affinity_mlp().to(DEV).train(), make_affinity_mlp().to(DEV).train()
+    opt = torch.optim.Adam(list(link.parameters()) + list(se.parameters()), lr=1e-3)
+    g = torch.Generator().manual_seed(1)
+    feats = torch.relu(torch.randn(4, 64, 512, generator=g)).to(DEV)
+    tids = torch.randint(0, 13, (4, 64), generator=g).float().to(DEV)
+    before = [p.detach().clone() for p in link.parameters()]
+    prof.reset(); prof.enabled = True
+    try:
+        loss = finetune_step_static(feats, tids, link, se, opt, world=1)
+        torch.cuda.synchronize()
+        names = set(prof.records)
+    finally:
+        prof.enabled = False; prof.reset()
+    assert {"affinity_train_prepare", "affinity_train_link_step", "affinity_train_se_step"} <= names, names
+    assert loss.is_cuda and 0 < loss.item() < 3
+    assert all((a - b.detach()).abs().max().item() > 0 for a, b in zip(before, link.parameters()))
+
+
 # ------------------------------------------------------------------ contraction-proof decision fixtures
 # Index outputs depend on comparisons of float32 expressions whose rounding depends on whether the compiler contracts
 # a*b + c into an FMA (DESIGN.md §3 states the two conventions used).  These inputs make every compared quantity EXACT
