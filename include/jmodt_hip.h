@@ -80,6 +80,16 @@ int jm_ball_query(int b, int n, int m, float radius, int nsample, const float* n
  * (pointnet2_modules.py:46-47 calls ball_query once per radius on the same centres). */
 int jm_ball_query_dual(int b, int n, int m, float radius0, int nsample0, float radius1, int nsample1,
                        const float* new_xyz, const float* xyz, int* idx0, int* idx1, jm_stream_t stream);
+/* The same two searches through a per-frame hash grid (csrc/ball_query_grid.hip): identical output (the first nsample
+ * indices in ascending order, back-fill, untouched rows without a hit), but only the points of the <= 64 grid cells a
+ * ball can touch are evaluated instead of all n.  ws: >= jm_ball_query_workspace_bytes(b, n) bytes, 16-byte aligned
+ * (bucket table + the points sorted by bucket); the function returns 0 where the brute-force scan is used anyway
+ * (n < 2048 or n > 131072: the *_ws entries then forward to the entries above, as they do for ws == NULL). */
+size_t jm_ball_query_workspace_bytes(int b, int n);
+int jm_ball_query_ws(int b, int n, int m, float radius, int nsample, const float* new_xyz, const float* xyz, int* idx, void* ws,
+                     size_t ws_bytes, jm_stream_t stream);
+int jm_ball_query_dual_ws(int b, int n, int m, float radius0, int nsample0, float radius1, int nsample1, const float* new_xyz,
+                          const float* xyz, int* idx0, int* idx1, void* ws, size_t ws_bytes, jm_stream_t stream);
 
 /* group_points_wrapper / group_points_grad_wrapper (group_points.cpp:11-36,
  * group_points_gpu.cu:8-86).  points (B,C,N), idx (B,P,S) -> out (B,C,P,S). */
@@ -92,6 +102,15 @@ int jm_group_points_grad(int b, int c, int n, int npoints, int nsample, const fl
  * known (B,M,3) -> dist2 (B,N,3) SQUARED distances, idx (B,N,3) i32. */
 int jm_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2, int* idx,
                 jm_stream_t stream);
+/* The same search through a hash grid over the known points (csrc/three_nn_grid.hip): identical output (the three smallest
+ * (distance, index) pairs), a few dozen distance evaluations per unknown point instead of m.  ws: >=
+ * jm_three_nn_grid_workspace_bytes(b, n, m) bytes, 16-byte aligned (0: m outside [1024, 16384], no grid form).
+ * jm_three_nn_workspace_bytes is the POLICY: the same size where the walk is faster than the scan (n * m >= 2^27, measured),
+ * else 0; jm_three_nn_ws scans when ws == NULL and walks the grid whenever it is handed a workspace. */
+size_t jm_three_nn_workspace_bytes(int b, int n, int m);
+size_t jm_three_nn_grid_workspace_bytes(int b, int n, int m);
+int jm_three_nn_ws(int b, int n, int m, const float* unknown, const float* known, float* dist2, int* idx, void* ws,
+                   size_t ws_bytes, jm_stream_t stream);
 
 /* three_interpolate_wrapper / _grad_wrapper (interpolate.cpp:26-54, interpolate_gpu.cu:77-161).
  * points (B,C,M), idx/weight (B,N,3) -> out (B,C,N);  grad_points (B,C,M) pre-zeroed. */

@@ -43,9 +43,15 @@ SIGNATURES = {
     "jm_gather_points_grad": (_I, [_I, _I, _I, _I, _P, _P, _P, _P]),
     "jm_ball_query": (_I, [_I, _I, _I, _F, _I, _P, _P, _P, _P]),
     "jm_ball_query_dual": (_I, [_I, _I, _I, _F, _I, _F, _I, _P, _P, _P, _P, _P]),
+    "jm_ball_query_workspace_bytes": (_Z, [_I, _I]),
+    "jm_ball_query_ws": (_I, [_I, _I, _I, _F, _I, _P, _P, _P, _P, _Z, _P]),
+    "jm_ball_query_dual_ws": (_I, [_I, _I, _I, _F, _I, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "jm_group_points": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "jm_group_points_grad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "jm_three_nn": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
+    "jm_three_nn_workspace_bytes": (_Z, [_I, _I, _I]),
+    "jm_three_nn_grid_workspace_bytes": (_Z, [_I, _I, _I]),
+    "jm_three_nn_ws": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "jm_three_interpolate": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "jm_three_interpolate_grad": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "jm_sa_mlp_supported": (_I, [_I, _I, _I, _I, _I, _I, _I, ctypes.POINTER(_I)]),

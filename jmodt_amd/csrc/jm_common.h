@@ -164,6 +164,18 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return v;
 }
 
+// inclusive prefix sum over the 64 lanes with DPP row shifts + row broadcasts (no LDS crossbar round trips: a __shfl_up
+// tree is six dependent ds_bpermute latencies).  Lanes without a source read 0 (old = 0, bound_ctrl off).
+__device__ __forceinline__ int wave_incl_scan_i32_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2, 3
+    return v;
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
 // number of set bits of `mask` strictly below this lane

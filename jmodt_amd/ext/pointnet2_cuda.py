@@ -10,8 +10,11 @@ f32, i32 = torch.float32, torch.int32
 
 def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
     lib = L.load()
-    L.check(lib.jm_ball_query(b, n, m, float(radius), nsample, L.dev(new_xyz, f32, "new_xyz"), L.dev(xyz, f32, "xyz"),
-                              L.dev(idx, i32, "idx"), L.stream_ptr()), "ball_query_wrapper")
+    ws_bytes = lib.jm_ball_query_workspace_bytes(b, n)          # hash-grid search for n >= 2048 (same output)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=xyz.device) if ws_bytes else None
+    L.check(lib.jm_ball_query_ws(b, n, m, float(radius), nsample, L.dev(new_xyz, f32, "new_xyz"), L.dev(xyz, f32, "xyz"),
+                                 L.dev(idx, i32, "idx"), ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, ws_bytes,
+                                 L.stream_ptr()), "ball_query_wrapper")
     return 1
 
 
@@ -91,8 +94,11 @@ def farthest_point_sampling_wrapper(b, n, m, points, temp, idx, new_xyz=None):
 
 def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
     lib = L.load()
-    L.check(lib.jm_three_nn(b, n, m, L.dev(unknown, f32, "unknown"), L.dev(known, f32, "known"),
-                            L.dev(dist2, f32, "dist2"), L.dev(idx, i32, "idx"), L.stream_ptr()), "three_nn_wrapper")
+    ws_bytes = lib.jm_three_nn_workspace_bytes(b, n, m)         # hash-grid search for 1024 <= m <= 16384 (same output)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=unknown.device) if ws_bytes else None
+    L.check(lib.jm_three_nn_ws(b, n, m, L.dev(unknown, f32, "unknown"), L.dev(known, f32, "known"),
+                               L.dev(dist2, f32, "dist2"), L.dev(idx, i32, "idx"),
+                               ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, ws_bytes, L.stream_ptr()), "three_nn_wrapper")
 
 
 def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):

@@ -16,6 +16,8 @@ stream, and errors surface as Python exceptions instead of exit().
 """
 from typing import Optional, Tuple
 
+import ctypes
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -107,8 +109,12 @@ class _ThreeNN(Function):
         m = known.size(1)
         dist2 = torch.empty((B, N, 3), dtype=_f32, device=unknown.device)
         idx = torch.empty((B, N, 3), dtype=_i32, device=unknown.device)
-        L.check(L.load().jm_three_nn(B, N, m, L.dev(unknown, _f32, "unknown"), L.dev(known, _f32, "known"),
-                                     L.dev(dist2, _f32, "dist2"), L.dev(idx, _i32, "idx"), L.stream_ptr()), "three_nn")
+        lib = L.load()
+        ws_bytes = lib.jm_three_nn_workspace_bytes(B, N, m)       # hash grid over the known points where that pays (same output)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=unknown.device) if ws_bytes else None
+        L.check(lib.jm_three_nn_ws(B, N, m, L.dev(unknown, _f32, "unknown"), L.dev(known, _f32, "known"),
+                                   L.dev(dist2, _f32, "dist2"), L.dev(idx, _i32, "idx"),
+                                   ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, ws_bytes, L.stream_ptr()), "three_nn")
         ctx.mark_non_differentiable(idx)
         return torch.sqrt(dist2), idx
 
@@ -183,6 +189,15 @@ class _GroupingOperation(Function):
 grouping_operation = _GroupingOperation.apply
 
 
+def _ball_query_workspace(B: int, N: int, device):
+    """scratch of the hash-grid search (csrc/ball_query_grid.hip): bucket table + bucket-sorted points; (None, 0) where the
+    library scans all points anyway (small clouds)"""
+    nbytes = L.load().jm_ball_query_workspace_bytes(B, N)
+    if nbytes == 0:
+        return None, 0
+    return torch.empty((nbytes,), dtype=torch.uint8, device=device), nbytes
+
+
 class _BallQuery(Function):
     @staticmethod
     def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
@@ -191,8 +206,10 @@ class _BallQuery(Function):
         B, N, _ = xyz.size()
         npoint = new_xyz.size(1)
         idx = torch.zeros((B, npoint, nsample), dtype=_i32, device=xyz.device)
-        L.check(L.load().jm_ball_query(B, N, npoint, float(radius), nsample, L.dev(new_xyz, _f32, "new_xyz"),
-                                       L.dev(xyz, _f32, "xyz"), L.dev(idx, _i32, "idx"), L.stream_ptr()), "ball_query")
+        ws, ws_bytes = _ball_query_workspace(B, N, xyz.device)
+        L.check(L.load().jm_ball_query_ws(B, N, npoint, float(radius), nsample, L.dev(new_xyz, _f32, "new_xyz"),
+                                          L.dev(xyz, _f32, "xyz"), L.dev(idx, _i32, "idx"),
+                                          ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, ws_bytes, L.stream_ptr()), "ball_query")
         ctx.mark_non_differentiable(idx)
         return idx
 
@@ -213,9 +230,11 @@ def ball_query_dual(radius0: float, nsample0: int, radius1: float, nsample1: int
     npoint = new_xyz.size(1)
     idx0 = torch.zeros((B, npoint, nsample0), dtype=_i32, device=xyz.device)
     idx1 = torch.zeros((B, npoint, nsample1), dtype=_i32, device=xyz.device)
-    L.check(L.load().jm_ball_query_dual(B, N, npoint, float(radius0), nsample0, float(radius1), nsample1,
-                                        L.dev(new_xyz, _f32, "new_xyz"), L.dev(xyz, _f32, "xyz"),
-                                        L.dev(idx0, _i32, "idx0"), L.dev(idx1, _i32, "idx1"), L.stream_ptr()),
+    ws, ws_bytes = _ball_query_workspace(B, N, xyz.device)
+    L.check(L.load().jm_ball_query_dual_ws(B, N, npoint, float(radius0), nsample0, float(radius1), nsample1,
+                                           L.dev(new_xyz, _f32, "new_xyz"), L.dev(xyz, _f32, "xyz"),
+                                           L.dev(idx0, _i32, "idx0"), L.dev(idx1, _i32, "idx1"),
+                                           ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, ws_bytes, L.stream_ptr()),
             "ball_query_dual")
     return idx0, idx1
 

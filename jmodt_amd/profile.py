@@ -85,10 +85,17 @@ ALGO: Dict[str, Callable] = {
                                 dict(evals=_i(a, 0) * _i(a, 1) * _i(a, 2))),
     "jm_ball_query_dual": lambda a: (_i(a, 0) * (12 * _i(a, 1) + 12 * _i(a, 2) + 4 * _i(a, 2) * (_i(a, 4) + _i(a, 6))), 0,
                                      dict(evals=_i(a, 0) * _i(a, 1) * _i(a, 2))),
+    # grid search: same compulsory bytes; the number of evaluated candidates is data dependent (not known on the host)
+    "jm_ball_query_ws": lambda a: (_i(a, 0) * (12 * _i(a, 1) + 12 * _i(a, 2) + 4 * _i(a, 2) * _i(a, 4)), 0,
+                                   dict(brute_force_evals=_i(a, 0) * _i(a, 1) * _i(a, 2))),
+    "jm_ball_query_dual_ws": lambda a: (_i(a, 0) * (12 * _i(a, 1) + 12 * _i(a, 2) + 4 * _i(a, 2) * (_i(a, 4) + _i(a, 6))), 0,
+                                        dict(brute_force_evals=_i(a, 0) * _i(a, 1) * _i(a, 2))),
     "jm_group_points": lambda a: (_i(a, 0) * (4 * _i(a, 3) * _i(a, 4) + 4 * _i(a, 1) * _i(a, 2)
                                               + 4 * _i(a, 1) * _i(a, 3) * _i(a, 4)), 0, {}),
     "jm_three_nn": lambda a: (_i(a, 0) * (12 * _i(a, 1) + 12 * _i(a, 2) + 24 * _i(a, 1)), 0,
                               dict(evals=_i(a, 0) * _i(a, 1) * _i(a, 2))),
+    "jm_three_nn_ws": lambda a: (_i(a, 0) * (12 * _i(a, 1) + 12 * _i(a, 2) + 24 * _i(a, 1)), 0,
+                                 dict(brute_force_evals=_i(a, 0) * _i(a, 1) * _i(a, 2))),
     "jm_three_interpolate": lambda a: (_i(a, 0) * (4 * _i(a, 1) * _i(a, 2) + 24 * _i(a, 3) + 4 * _i(a, 1) * _i(a, 3)), 0, {}),
     "jm_sa_mlp_forward": _sa_mlp,
     "jm_sa_mlp_forward_pre": _sa_mlp_pre,

@@ -24,6 +24,37 @@ def cloud(B, N, seed, dup_frac=0.0, quantize=None):
     return pts
 
 
+def kitti_like_cloud(B, N, seed, dup_frac=0.1, n_objects=24):
+    """SURVEY.md §8(d)'s "KITTI-like" variant: point density ~ 1/z (log-uniform depth, what a spinning lidar sampled into a
+    fixed budget looks like), lateral position inside the camera frustum (|x| <= 0.85 z, the 1242-px image at fu = 721.5),
+    70 % of the points on the ground plane y ~ 1.65 m (camera height), the rest on vertical structure / `n_objects`
+    car-sized clusters (3.9 x 1.6 x 1.5 m boxes holding a few hundred points each near the sensor), cropped to the KITTI
+    range (config.py:34-36); + dup_frac duplicated indices (kitti_dataset.py:243-247)."""
+    rng = np.random.default_rng(seed)
+    pts = np.empty((B, N, 3), dtype=np.float32)
+    for b in range(B):
+        z = (2.5 * (70.4 / 2.5) ** rng.random(N)).astype(np.float32)                       # p(z) ~ 1/z on [2.5, 70.4]
+        x = (rng.uniform(-1, 1, N) * np.minimum(0.85 * z, 40.0)).astype(np.float32)
+        kind = rng.random(N)
+        y = np.where(kind < 0.7, 1.65 + rng.normal(0, 0.03, N), rng.uniform(-1.0, 1.65, N)).astype(np.float32)
+        # objects: a share of the points snapped into car-sized boxes standing on the ground, nearer objects get more points
+        oz = (4.0 * (60.0 / 4.0) ** rng.random(n_objects)).astype(np.float32)
+        ox = (rng.uniform(-0.7, 0.7, n_objects) * np.minimum(0.85 * oz, 35.0)).astype(np.float32)
+        w = 1.0 / oz
+        take = rng.random(N) < 0.18
+        which = rng.choice(n_objects, N, p=w / w.sum())
+        box = rng.uniform(-0.5, 0.5, (N, 3)).astype(np.float32) * np.array([1.6, 1.5, 3.9], np.float32)
+        x = np.where(take, ox[which] + box[:, 0], x)
+        y = np.where(take, 0.9 + box[:, 1], y)
+        z = np.where(take, oz[which] + box[:, 2], z)
+        pts[b] = np.stack([np.clip(x, -40, 40), np.clip(y, -1, 3), np.clip(z, 0, 70.4)], -1)
+        if dup_frac > 0:
+            nd = int(N * dup_frac)
+            dst = rng.choice(N, nd, replace=False)
+            pts[b, dst] = pts[b, rng.integers(0, N, nd)]
+    return pts
+
+
 def dense_cloud(B, N, seed, extent=4.0):
     """small-extent cloud so balls contain many points (exercises the >nsample truncation)."""
     rng = np.random.default_rng(seed)
@@ -128,7 +159,8 @@ def image(B, seed, H=384, W=1280, native=(375, 1242)):
     return img
 
 
-def frames(B, N, seed, H=384, W=1280, native=(375, 1242), dup_frac=0.1):
-    """(xyz (B,N,3), image (B,3,H,W), pts_xy (B,N,2)): one synthetic KITTI-shaped input batch"""
-    pts = cloud(B, N, seed, dup_frac=dup_frac)
+def frames(B, N, seed, H=384, W=1280, native=(375, 1242), dup_frac=0.1, kind="uniform"):
+    """(xyz (B,N,3), image (B,3,H,W), pts_xy (B,N,2)): one synthetic KITTI-shaped input batch; kind =
+    "uniform" (the crop filled uniformly) or "kitti" (density ~ 1/z, ground plane, object clusters)"""
+    pts = cloud(B, N, seed, dup_frac=dup_frac) if kind == "uniform" else kitti_like_cloud(B, N, seed, dup_frac=dup_frac)
     return pts, image(B, seed + 1, H, W, native), pts_xy(pts, W, H)

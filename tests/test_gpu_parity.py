@@ -837,3 +837,152 @@ def test_fused_sa_pre_projected_first_layer(N, npoint, C, ns, mlp, extent, pm):
     assert f_ref.abs().max().item() > 0.1
     assert (f_pre - f_ref).abs().max().item() <= 1e-4 * scale, (f_pre - f_ref).abs().max().item()
     assert (f_row - f_ref).abs().max().item() <= 1e-4 * scale
+
+
+# ------------------------------------------------------------------ hash-grid ball query (csrc/ball_query_grid.hip)
+def _bq_both(oracle, xyz, new_xyz, radii, nss):
+    """grid path (the ops' default for n >= 2048) and brute-force entry vs the oracle, single and dual"""
+    import ctypes
+    from jmodt_amd import _lib as L
+    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    want = [oracle.ball_query(r, ns, xyz, new_xyz) for r, ns in zip(radii, nss)]
+    tx, tn = T(xyz), T(new_xyz)
+    assert L.load().jm_ball_query_workspace_bytes(B, N) > 0
+    for r, ns, w in zip(radii, nss, want):
+        assert np.array_equal(pu.ball_query(r, ns, tx, tn).cpu().numpy(), w), (r, ns)
+        brute = torch.zeros((B, M, ns), dtype=torch.int32, device=DEV)
+        L.check(L.load().jm_ball_query(B, N, M, float(r), ns, L.dev(tn, torch.float32, "c"), L.dev(tx, torch.float32, "x"),
+                                       L.dev(brute, torch.int32, "i"), L.stream_ptr()), "bq")
+        assert np.array_equal(brute.cpu().numpy(), w)
+    if len(radii) == 2:
+        i0, i1 = pu.ball_query_dual(radii[0], nss[0], radii[1], nss[1], tx, tn)
+        assert np.array_equal(i0.cpu().numpy(), want[0]) and np.array_equal(i1.cpu().numpy(), want[1])
+    return want
+
+
+@pytest.mark.parametrize("kind", ["uniform", "kitti", "dense", "identical", "dup_heavy"])
+def test_ball_query_grid_vs_oracle(oracle, kind):
+    rng = np.random.default_rng(7)
+    B, N, M = 2, 8192, 1024
+    if kind == "uniform":
+        xyz = synth.cloud(B, N, 31, dup_frac=0.1)
+    elif kind == "kitti":
+        xyz = synth.kitti_like_cloud(B, N, 32)
+    elif kind == "dense":
+        xyz = synth.dense_cloud(B, N, 33, extent=3.0)              # hundreds of points per ball: truncation at nsample
+    elif kind == "identical":
+        xyz = np.full((B, N, 3), 0.25, np.float32)                 # every point in one bucket, every pair a hit
+        xyz[1, ::2] += 7.0
+    else:
+        xyz = synth.cloud(B, N, 34)
+        xyz[:, N // 4:] = xyz[:, rng.integers(0, N // 4, N - N // 4)]   # 4 copies of everything on average
+    pick = np.stack([rng.choice(N, M, replace=False) for _ in range(B)])
+    new_xyz = np.take_along_axis(xyz, pick[..., None], axis=1).copy()
+    new_xyz[:, -8:] += 300.0                                      # centres with no neighbour at all: rows stay at the caller's fill
+    new_xyz[0, -9] = np.nan
+    want = _bq_both(oracle, xyz, new_xyz, (0.1, 0.5), (16, 32))
+    assert (want[1][:, -8:] == 0).all()
+    if kind in ("dense", "identical"):
+        assert (np.diff(want[1][:, :M - 9], axis=2) > 0).all()     # full rows of distinct ascending indices (truncated, no back-fill)
+    _bq_both(oracle, xyz, new_xyz, (1.7,), (64,))
+
+
+def test_ball_query_grid_full_size_and_far_coordinates(oracle):
+    """B = 8 x 16384 -> 4096 (the level-1 call of the detector) on a slice, and a cloud 10^6 m from the origin (the padded
+    reach then spans more than 64 cells: those centres scan the frame's whole sorted array)"""
+    xyz = synth.kitti_like_cloud(8, 16384, 41)
+    idx = oracle.furthest_point_sample(xyz[:2], 4096)
+    new_xyz = np.take_along_axis(xyz[:2], idx[..., None].astype(np.int64), axis=1)
+    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
+    full_new = np.concatenate([new_xyz] * 4)
+    i0, i1 = pu.ball_query_dual(0.1, 16, 0.5, 32, T(xyz), T(full_new))
+    for b in range(2):
+        assert np.array_equal(i0[b].cpu().numpy(), oracle.ball_query(0.1, 16, xyz[b:b + 1], new_xyz[b:b + 1])[0])
+        assert np.array_equal(i1[b].cpu().numpy(), oracle.ball_query(0.5, 32, xyz[b:b + 1], new_xyz[b:b + 1])[0])
+    far = synth.cloud(1, 4096, 42) + np.float32(1.0e6)
+    cen = far[:, :300].copy()
+    _bq_both(oracle, far, cen, (2.0,), (16,))
+
+
+# ------------------------------------------------------------------ hash-grid 3-NN (csrc/three_nn_grid.hip)
+@pytest.mark.parametrize("kind", ["uniform", "kitti", "flat", "identical", "dup_heavy", "isolated"])
+def test_three_nn_grid_vs_oracle(oracle, kind):
+    """the grid walk (1024 <= m <= 16384) against the sequential scan: indices bit-exact incl. the earlier-index rule on
+    equal distances, squared distances exact"""
+    from jmodt_amd import _lib as L
+    from jmodt_amd.ext import pointnet2_cuda
+    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
+    rng = np.random.default_rng(3)
+    B, N, M = 2, 6000, 2048
+    if kind == "uniform":
+        unknown = synth.cloud(B, N, 51)
+    elif kind == "kitti":
+        unknown = synth.kitti_like_cloud(B, N, 52)
+    elif kind == "flat":
+        unknown = synth.cloud(B, N, 53); unknown[..., 1] = 1.5                    # a plane: the box has no volume
+    elif kind == "identical":
+        unknown = np.full((B, N, 3), 2.0, np.float32); unknown[:, ::3] += 1.0     # two locations: every distance tied
+    elif kind == "dup_heavy":
+        unknown = synth.cloud(B, N, 54); unknown[:, N // 8:] = unknown[:, rng.integers(0, N // 8, N - N // 8)]
+    else:
+        unknown = synth.kitti_like_cloud(B, N, 55); unknown[:, :40] += 500.0      # far outliers: the full-scan list
+        unknown[0, 41] = np.nan
+    pick = np.stack([np.sort(rng.choice(N, M, replace=False)) for _ in range(B)])
+    known = np.take_along_axis(unknown, pick[..., None], axis=1).copy()
+    if kind == "isolated":
+        known[:, :5] = unknown[:, :5]
+    want_d2, want_idx = oracle.three_nn(unknown, known)
+    ok = ~np.isnan(unknown).any(-1)
+    d2, ii = _three_nn_grid(unknown, known)
+    assert np.array_equal(ii[ok], want_idx[ok]) and np.array_equal(d2[ok], want_d2[ok])
+    dist, idx = pu.three_nn(T(unknown), T(known))                  # the op (scan at this size) and the shim agree too
+    assert np.array_equal(idx.cpu().numpy()[ok], want_idx[ok]) and np.array_equal(dist.cpu().numpy()[ok], np.sqrt(want_d2[ok]))
+    d2s = torch.zeros((B, N, 3), device=DEV); iis = torch.zeros((B, N, 3), dtype=torch.int32, device=DEV)
+    pointnet2_cuda.three_nn_wrapper(B, N, M, T(unknown), T(known), d2s, iis)
+    assert np.array_equal(iis.cpu().numpy()[ok], want_idx[ok]) and np.array_equal(d2s.cpu().numpy()[ok], want_d2[ok])
+
+
+def _three_nn_grid(unknown, known):
+    """jm_three_nn_ws with the grid workspace: the walk, whatever the size policy says"""
+    import ctypes
+    from jmodt_amd import _lib as L
+    B, N, _ = unknown.shape
+    M = known.shape[1]
+    lib = L.load()
+    nbytes = lib.jm_three_nn_grid_workspace_bytes(B, N, M)
+    assert nbytes > 0
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=DEV)
+    d2 = torch.zeros((B, N, 3), device=DEV)
+    ii = torch.zeros((B, N, 3), dtype=torch.int32, device=DEV)
+    tu, tk = T(unknown), T(known)
+    L.check(lib.jm_three_nn_ws(B, N, M, L.dev(tu, torch.float32, "u"), L.dev(tk, torch.float32, "k"), L.dev(d2, torch.float32, "d"),
+                               L.dev(ii, torch.int32, "i"), ctypes.c_void_p(ws.data_ptr()), nbytes, L.stream_ptr()), "three_nn_ws")
+    return d2.cpu().numpy(), ii.cpu().numpy()
+
+
+def test_three_nn_grid_fp1_shape(oracle):
+    """the last feature-propagation level of the detector: 16384 unknown points against their own 4096 FPS samples"""
+    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
+    xyz = synth.kitti_like_cloud(2, 16384, 61)
+    idx = oracle.furthest_point_sample(xyz, 4096)
+    known = np.take_along_axis(xyz, idx[..., None].astype(np.int64), axis=1)
+    want_d2, want_idx = oracle.three_nn(xyz, known)
+    d2, got = _three_nn_grid(xyz, known)
+    assert np.array_equal(got, want_idx) and np.array_equal(d2, want_d2)
+    dist, got = pu.three_nn(T(xyz), T(known))
+    assert np.array_equal(got.cpu().numpy(), want_idx)
+    assert np.array_equal(dist.cpu().numpy(), np.sqrt(want_d2))
+
+
+def test_three_nn_policy_takes_the_grid_for_the_dense_shape(oracle):
+    """65536 unknown x 4096 known (BASELINE configs[4]): the op's default path is the grid walk; a slice against the oracle"""
+    from jmodt_amd import _lib as L
+    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
+    assert L.load().jm_three_nn_workspace_bytes(1, 65536, 4096) > 0 and L.load().jm_three_nn_workspace_bytes(8, 16384, 4096) == 0
+    xyz = synth.kitti_like_cloud(1, 65536, 71)
+    known = xyz[:, ::16].copy()
+    dist, got = pu.three_nn(T(xyz), T(known))
+    want_d2, want_idx = oracle.three_nn(xyz[:, :3000], known)
+    assert np.array_equal(got.cpu().numpy()[:, :3000], want_idx) and np.array_equal(dist.cpu().numpy()[:, :3000], np.sqrt(want_d2))
