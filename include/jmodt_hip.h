@@ -400,6 +400,38 @@ size_t jm_mlp3_workspace_bytes(int m, const jm_mlp3_t* mlp);
 int jm_mlp3_forward(int m, const float* x, const jm_mlp3_t* mlp, float* y, void* ws, size_t ws_bytes,
                     jm_stream_t stream);
 
+/* ------------------------------------------------------------------ duplicate-aware set abstraction (exact) ---- */
+
+/* jm_roipool3d_canonical + pooled_cnt (B, M) i32: the number of distinct source points of every pooled slab (0: empty RoI;
+ * else rows cnt .. S-1 repeat rows 0 .. cnt-1 cyclically, roipool3d_kernel.cu:123-160). */
+int jm_roipool3d_canonical_cnt(int batch_size, int pts_num, int boxes_num, int feature_in_len, int sampled_pts_num,
+                               const float* xyz, const float* rois, float extra_width, const float* pts_feature,
+                               float* pooled_features, int* pooled_empty_flag, int* pooled_cnt, jm_stream_t stream);
+
+/* sa_mlp_pm_kernel (jm_sa_mlp_pm_forward) on a row set whose size lives in DEVICE memory: one frame of n points, capacity m
+ * (virtual) centres, tiles_dev[0] = number of 128-row tiles to run. */
+int jm_sa_mlp_pm_forward_dyn(int n, int m, int c, int nsample, int hidden, int cout, const float* u_point_major,
+                             const float* w1x, const float* new_xyz, const int* idx, const float* w_hidden, const float* b_hidden,
+                             const float* w_out, const float* b_out, float* out, const int* tiles_dev, jm_stream_t stream);
+
+/* Exact removal of repeated rows from a set-abstraction scale over r point sets of n points (csrc/sa_dedupe.hip): rows
+ * whose neighbour is a copy of an earlier neighbour of the same centre (cyclic roipool padding, ball-query back-fill) and
+ * centres that are copies of an earlier centre contribute nothing to the max-pool.
+ *   canon (r, n) i32        canon[k] = first point of which point k is an exact copy (canon_from_cnt: k % max(cnt, 1))
+ *   fps_idx (r, m), nb (r, m, nsample), new_xyz (r, m, 3)   the scale's sampling, neighbour lists and centres
+ * plan ->  rep (r, m)       first centre with the same canonical point (the next level's canon)
+ *          seg_start / seg_cnt (r, m)   the representative's segments in the virtual-centre arrays
+ *          vidx (cap, 16) i32 GLOBAL point indices (set * n + point), vxyz (cap, 3): a 16-sample problem over all sets;
+ *          cap = jm_sa_dedupe_capacity(r, m, nsample)
+ *          counters (4) i32, device: [virtual centres, tiles (-> jm_sa_mlp_pm_forward_dyn), virtual centres, -]
+ * combine: out (r, cout, m) = per centre the max over its representative's segments of out_virtual (cout, cap). */
+int jm_sa_dedupe_canon_from_cnt(int r, int n, const int* cnt, int* canon, jm_stream_t stream);
+long long jm_sa_dedupe_capacity(int r, int m, int nsample);
+int jm_sa_dedupe_plan(int r, int n, int m, int nsample, const int* canon, const int* fps_idx, const int* nb, const float* new_xyz,
+                      int* rep, int* seg_start, int* seg_cnt, int* vidx, float* vxyz, int* counters, jm_stream_t stream);
+int jm_sa_dedupe_combine(int r, int m, int cout, long long vmax, const float* out_virtual, const int* rep, const int* seg_start,
+                         const int* seg_cnt, float* out, jm_stream_t stream);
+
 /* ------------------------------------------------------------------ training-time affinity ---- */
 
 /* Gradients of one 3-layer head, same shapes as jm_mlp3_t's tensors: dw1 (h1, c), db1 (h1), dw2 (h2, h1), db2 (h2),

@@ -107,6 +107,12 @@ SIGNATURES = {
     "jm_linear_rows": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "jm_mlp3_workspace_bytes": (_Z, [_I, ctypes.POINTER(Mlp3)]),
     "jm_mlp3_forward": (_I, [_I, _P, ctypes.POINTER(Mlp3), _P, _P, _Z, _P]),
+    "jm_roipool3d_canonical_cnt": (_I, [_I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P]),
+    "jm_sa_mlp_pm_forward_dyn": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "jm_sa_dedupe_canon_from_cnt": (_I, [_I, _I, _P, _P, _P]),
+    "jm_sa_dedupe_capacity": (_L, [_I, _I, _I]),
+    "jm_sa_dedupe_plan": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "jm_sa_dedupe_combine": (_I, [_I, _I, _I, _L, _P, _P, _P, _P, _P, _P]),
     "jm_affinity_train_prepare": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "jm_affinity_train_loss_value": (_I, [_I, _P, _P, _P, _F, _F, _P, _P]),
     "jm_affinity_train_link_workspace_bytes": (_Z, [_I, _I, ctypes.POINTER(Mlp3)]),

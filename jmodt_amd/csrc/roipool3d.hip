@@ -73,7 +73,7 @@ template <bool VEC4, bool CANON>
 __global__ void __launch_bounds__(RP_T)
 roipool3d_kernel(int N, int M, int C, int S, const float* __restrict__ xyz, const float* __restrict__ boxes3d,
                  const float* __restrict__ pts_feature, float* __restrict__ pooled, int* __restrict__ empty_flag,
-                 int zero_empty, float e1, float e2) {
+                 int zero_empty, float e1, float e2, int* __restrict__ pooled_cnt) {
     extern __shared__ __attribute__((aligned(16))) int lds[];  // [S] indices, then [2][RP_W] wave totals
     int* sel = lds;
     int* wtot = lds + ((S + 3) & ~3);
@@ -147,6 +147,9 @@ roipool3d_kernel(int N, int M, int C, int S, const float* __restrict__ xyz, cons
     }
     __syncthreads();
     if (cnt > S) cnt = S;
+    // rows cnt .. S-1 of the slab are cyclic copies of rows 0 .. cnt-1 (row s = row s % cnt): callers that want to skip
+    // the redundant rows (ops/pointnet2/fused.py, sa_dedupe.hip) read the count here
+    if (pooled_cnt && tid == 0) pooled_cnt[(size_t)bi * M + mi] = cnt;
 
     float* dst = pooled + ((size_t)bi * M + mi) * S * (3 + C);
     const int RC = 3 + C;
@@ -242,7 +245,8 @@ using namespace jm;
 template <bool CANON>
 static int roipool3d_launch(int batch_size, int pts_num, int boxes_num, int feature_in_len, int sampled_pts_num,
                             const float* xyz, const float* boxes3d, const float* pts_feature, float* pooled_features,
-                            int* pooled_empty_flag, int zero_empty, float e1, float e2, jm_stream_t stream) {
+                            int* pooled_empty_flag, int zero_empty, float e1, float e2, jm_stream_t stream,
+                            int* pooled_cnt = nullptr) {
     JM_REQUIRE(batch_size >= 0 && pts_num >= 0 && boxes_num >= 0 && feature_in_len >= 0 && sampled_pts_num >= 1,
                "roipool3d: bad sizes");
     if (batch_size == 0 || boxes_num == 0) return JM_OK;
@@ -261,12 +265,12 @@ static int roipool3d_launch(int batch_size, int pts_num, int boxes_num, int feat
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)roipool3d_kernel<true, CANON>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((roipool3d_kernel<true, CANON>), grid, block, lds, (hipStream_t)stream, pts_num, boxes_num,
                            feature_in_len, sampled_pts_num, xyz, boxes3d, pts_feature, pooled_features,
-                           pooled_empty_flag, zero_empty, e1, e2);
+                           pooled_empty_flag, zero_empty, e1, e2, pooled_cnt);
     } else {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)roipool3d_kernel<false, CANON>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((roipool3d_kernel<false, CANON>), grid, block, lds, (hipStream_t)stream, pts_num, boxes_num,
                            feature_in_len, sampled_pts_num, xyz, boxes3d, pts_feature, pooled_features,
-                           pooled_empty_flag, zero_empty, e1, e2);
+                           pooled_empty_flag, zero_empty, e1, e2, pooled_cnt);
     }
     return check_launch("roipool3d");
 }
@@ -288,6 +292,18 @@ extern "C" int jm_roipool3d_canonical(int batch_size, int pts_num, int boxes_num
     const float e1 = extra_width, e2 = (float)((double)extra_width * 2.0);
     return roipool3d_launch<true>(batch_size, pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, rois,
                                   pts_feature, pooled_features, pooled_empty_flag, 1, e1, e2, stream);
+}
+
+/* jm_roipool3d_canonical + pooled_cnt (B, M) i32: the number of DISTINCT source points of every slab (0 = empty RoI,
+ * else rows cnt .. S-1 repeat rows 0 .. cnt-1 cyclically, roipool3d_kernel.cu:123-160) */
+extern "C" int jm_roipool3d_canonical_cnt(int batch_size, int pts_num, int boxes_num, int feature_in_len,
+                                          int sampled_pts_num, const float* xyz, const float* rois, float extra_width,
+                                          const float* pts_feature, float* pooled_features, int* pooled_empty_flag,
+                                          int* pooled_cnt, jm_stream_t stream) {
+    JM_REQUIRE(pooled_cnt || batch_size == 0 || boxes_num == 0, "roipool3d: null pooled_cnt");
+    const float e1 = extra_width, e2 = (float)((double)extra_width * 2.0);
+    return roipool3d_launch<true>(batch_size, pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, rois,
+                                  pts_feature, pooled_features, pooled_empty_flag, 1, e1, e2, stream, pooled_cnt);
 }
 
 // ---- host CPU entry points of the reference API (roipool3d.cpp:97-195); synchronous ----------

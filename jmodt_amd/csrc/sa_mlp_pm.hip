@@ -42,6 +42,8 @@ struct SaPmParams {
     float* out;                            // (B, cout, M)
     int S0, S1;                            // LDS row strides of the two tiles
     int tiles_per_frame, total_tiles, xcd_frames;
+    const int* total_dev;                  // non-null: the number of tiles is read from device memory (<= total_tiles; the
+                                           // duplicate-compacted form of sa_dedupe.hip, whose row count is data dependent)
 #ifdef JM_TOOLS_BUILD
     int dbg;                               // tools build (JM_PM_DBG): timing experiments, wrong results
     long long* trace;                      // tools build: shader-clock stamps of workgroup 0's first MFMA wave (tools/sa_trace.py)
@@ -61,12 +63,13 @@ struct PmSchedule {                        // = SaSchedule of sa_mlp.hip: whole 
     __device__ PmSchedule(const SaPmParams& p) {
         nwg = gridDim.x; tpf = p.tiles_per_frame; mode = p.xcd_frames;
         xcd = blockIdx.x & 7; slot = blockIdx.x >> 3; per = nwg >> 3;
+        const int total_tiles = p.total_dev ? min(*p.total_dev, p.total_tiles) : p.total_tiles;
         if (mode) {
-            const int nb = p.total_tiles / tpf;
+            const int nb = total_tiles / tpf;
             const int local_tiles = ((nb - xcd + 7) >> 3) * tpf;
             n_local = local_tiles > slot ? (local_tiles - slot + per - 1) / per : 0;
         } else {
-            n_local = p.total_tiles > (int)blockIdx.x ? (p.total_tiles - (int)blockIdx.x + nwg - 1) / nwg : 0;
+            n_local = total_tiles > (int)blockIdx.x ? (total_tiles - (int)blockIdx.x + nwg - 1) / nwg : 0;
         }
     }
     __device__ void tile(int i, int& bi, int& row0) const {
@@ -371,10 +374,10 @@ extern "C" int jm_sa_mlp_pm_supported(int b, int n, int m, int c, int nsample, i
     return sa_pm_lds_bytes(c, hidden) <= 160 * 1024 ? 1 : 0;
 }
 
-extern "C" int jm_sa_mlp_pm_forward(int b, int n, int m, int c, int nsample, int hidden, int cout, const float* u_point_major,
-                                    const float* w1x, const float* new_xyz, const int* idx, const float* w_hidden,
-                                    const float* b_hidden, const float* w_out, const float* b_out, float* out,
-                                    jm_stream_t stream) {
+static int sa_mlp_pm_launch(int b, int n, int m, int c, int nsample, int hidden, int cout, const float* u_point_major,
+                            const float* w1x, const float* new_xyz, const int* idx, const float* w_hidden,
+                            const float* b_hidden, const float* w_out, const float* b_out, float* out, const int* total_dev,
+                            jm_stream_t stream) {
     JM_REQUIRE(b >= 0 && m >= 0, "sa_mlp_pm: bad sizes");
     if (b == 0 || m == 0) return JM_OK;
     JM_REQUIRE(jm_sa_mlp_pm_supported(b, n, m, c, nsample, hidden, cout),
@@ -399,6 +402,8 @@ extern "C" int jm_sa_mlp_pm_forward(int b, int n, int m, int c, int nsample, int
     p.tiles_per_frame = (int)((long long)m * nsample / PM_BM);
     p.total_tiles = (int)((long long)p.tiles_per_frame * b);
     p.xcd_frames = b >= 16 ? 1 : 0;
+    p.total_dev = total_dev;
+    if (total_dev) p.xcd_frames = 0;
 #ifdef JM_TOOLS_BUILD
     p.dbg = tune_env("JM_PM_DBG", 0);
     p.trace = g_pm_trace;
@@ -407,4 +412,23 @@ extern "C" int jm_sa_mlp_pm_forward(int b, int n, int m, int c, int nsample, int
     const int grid = p.xcd_frames ? cus : (p.total_tiles < cus ? p.total_tiles : cus);
     hipLaunchKernelGGL(sa_mlp_pm_kernel, dim3((unsigned)grid), dim3(768), lds_bytes, (hipStream_t)stream, p);
     return check_launch("sa_mlp_pm");
+}
+
+extern "C" int jm_sa_mlp_pm_forward(int b, int n, int m, int c, int nsample, int hidden, int cout, const float* u_point_major,
+                                    const float* w1x, const float* new_xyz, const int* idx, const float* w_hidden,
+                                    const float* b_hidden, const float* w_out, const float* b_out, float* out,
+                                    jm_stream_t stream) {
+    return sa_mlp_pm_launch(b, n, m, c, nsample, hidden, cout, u_point_major, w1x, new_xyz, idx, w_hidden, b_hidden, w_out, b_out, out,
+                            nullptr, stream);
+}
+
+/* the same kernel on a row set whose size lives in device memory: frames = 1, m = the CAPACITY in (virtual) centres,
+ * tiles_dev[0] = the number of 128-row tiles to run (<= m * nsample / 128); outputs of centres beyond it are not written */
+extern "C" int jm_sa_mlp_pm_forward_dyn(int n, int m, int c, int nsample, int hidden, int cout, const float* u_point_major,
+                                        const float* w1x, const float* new_xyz, const int* idx, const float* w_hidden,
+                                        const float* b_hidden, const float* w_out, const float* b_out, float* out,
+                                        const int* tiles_dev, jm_stream_t stream) {
+    JM_REQUIRE(tiles_dev, "sa_mlp_pm_dyn: null tile count");
+    return sa_mlp_pm_launch(1, n, m, c, nsample, hidden, cout, u_point_major, w1x, new_xyz, idx, w_hidden, b_hidden, w_out, b_out, out,
+                            tiles_dev, stream);
 }

@@ -285,6 +285,7 @@ class DetectAffinityEngine(nn.Module):
         self.fuse_small_heads = True       # RCNN cls / reg heads: one MFMA launch per dense layer
         self.fuse_rcnn_lift = True         # xyz_up + merge_down (+ hoisted first SA layer) as one kernel
         self.fuse_attention = True         # LI-Fusion attention block as one kernel where it fits (else rocBLAS GEMMs)
+        self.dedupe_rcnn = True            # RCNN SA1 / SA2: skip (centre, sample) rows that are exact copies (bit-identical output)
         self._prefetched = None
         self._prefetched_img = None
         self.prefetch_image = True         # prefetch(xyz, image) also starts the next batch's image pyramid
@@ -660,7 +661,12 @@ class DetectAffinityEngine(nn.Module):
             pts_feature = self.pts_feature(rpn_out)
         C = pts_feature.shape[2] - 2
         M, S = rois.shape[1], cfg.rcnn_num_points
-        pooled, _ = roipool3d_canonical_gpu(xyz, pts_feature, rois, cfg.pool_extra_width, S)
+        if xyz.is_cuda and self.dedupe_rcnn:
+            # + the number of distinct points per RoI slab: rows count .. S-1 are cyclic copies (roipool3d_kernel.cu:123-160)
+            pooled, _, count = roipool3d_canonical_gpu(xyz, pts_feature, rois, cfg.pool_extra_width, S, return_count=True)
+            self._roi_count = (pooled, count.view(B * M))
+        else:
+            pooled, _ = roipool3d_canonical_gpu(xyz, pts_feature, rois, cfg.pool_extra_width, S)
         return pooled.view(B * M, S, 5 + C)
 
     @torch.no_grad()
@@ -670,6 +676,7 @@ class DetectAffinityEngine(nn.Module):
         net = self.rcnn_net
         R, S, Cin = pts_input.shape
         self._refresh()
+        fused.DedupeStats.last.clear()
         k = net.rcnn_input_channel
         rows = pts_input.view(R * S, Cin)
         up = [self._wb(f"xyz_up.{i}", lambda u=u: _unit_wb(u)) for i, u in enumerate(net.xyz_up_layer)]
@@ -702,11 +709,35 @@ class DetectAffinityEngine(nn.Module):
             g0 = sa1.groupers[0]
             pm = fused.pm_plan(sa1.mlps[0], pts_input.device, R, S, sa1.npoint, g0.nsample) is not None
             u = lifted(pts_input, point_major=pm)                                      # (R, H1, S), or (R, S, H1) for sa_mlp_pm
-            with prof.scope("rcnn_sa1"):
-                _, new_xyz = pointnet2_utils.farthest_point_sample_xyz(xyz, sa1.npoint)
-                nb = pointnet2_utils.ball_query(g0.radius, g0.nsample, xyz, new_xyz)
-                l_feats = fused.sa_mlp_pre_from_u(u, new_xyz, nb, sa1.mlps[0], point_major=pm)
-            l_xyz, first = new_xyz, 1
+            res = None
+            kept = getattr(self, "_roi_count", None)
+            count = kept[1] if kept is not None and kept[0].data_ptr() == pts_input.data_ptr() else None
+            if pm and self.dedupe_rcnn and fused.DEDUPE and count is not None:
+                # the pooled sets are full of exact copies (cyclic padding -> copied centres -> back-filled neighbour lists):
+                # only distinct rows go through the MFMA kernel (csrc/sa_dedupe.hip), the result is bit-identical
+                with prof.scope("rcnn_sa1"):
+                    res = fused.sa_scale_pm_dedupe(xyz, u, sa1.mlps[0], sa1.npoint, g0.radius, g0.nsample,
+                                                   fused.canon_from_count(count, S), "rcnn_sa1")
+            if res is not None:
+                l_xyz, l_feats, rep = res
+                first = 1
+                sa2 = net.SA_modules[1] if len(net.SA_modules) > 1 else None
+                g2 = sa2.groupers[0] if sa2 is not None and len(sa2.groupers) == 1 else None
+                if (g2 is not None and sa2.fuse and sa2.npoint and isinstance(g2, pointnet2_utils.QueryAndGroup) and g2.use_xyz
+                        and fused.hoistable_first_layer(sa2.mlps[0], sa2.npoint, g2.nsample, pts_input.device) is not None):
+                    with prof.scope("rcnn_sa2"):
+                        u2 = fused.hoisted_u_point_major(l_xyz, l_feats, sa2.mlps[0])
+                        res2 = None if u2 is None else fused.sa_scale_pm_dedupe(l_xyz, u2, sa2.mlps[0], sa2.npoint, g2.radius,
+                                                                                g2.nsample, rep, "rcnn_sa2")
+                    if res2 is not None:
+                        l_xyz, l_feats, _ = res2
+                        first = 2
+            else:
+                with prof.scope("rcnn_sa1"):
+                    _, new_xyz = pointnet2_utils.farthest_point_sample_xyz(xyz, sa1.npoint)
+                    nb = pointnet2_utils.ball_query(g0.radius, g0.nsample, xyz, new_xyz)
+                    l_feats = fused.sa_mlp_pre_from_u(u, new_xyz, nb, sa1.mlps[0], point_major=pm)
+                l_xyz, first = new_xyz, 1
         elif lifted is not None:
             l_feats = lifted(pts_input)
         else:

@@ -18,12 +18,20 @@ def forward(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag, zero_
     return 1
 
 
-def forward_canonical(xyz, rois, extra_width, pts_feature, pooled_features, pooled_empty_flag):
+def forward_canonical(xyz, rois, extra_width, pts_feature, pooled_features, pooled_empty_flag, pooled_count=None):
     """MI355X-native: pooling + the canonical transformation of proposal_target_layer.py:106-112 in one pass;
-    `rois` are the un-enlarged boxes"""
+    `rois` are the un-enlarged boxes; pooled_count (B, M) int32 (optional) receives the distinct points per slab"""
     lib = L.load()
     B, N = xyz.size(0), xyz.size(1)
     M, C, S = rois.size(1), pts_feature.size(2), pooled_features.size(2)
+    if pooled_count is not None:
+        L.check(lib.jm_roipool3d_canonical_cnt(B, N, M, C, S, L.dev(xyz, f32, "xyz"), L.dev(rois, f32, "rois"),
+                                               float(extra_width), L.dev(pts_feature, f32, "pts_feature"),
+                                               L.dev(pooled_features, f32, "pooled_features"),
+                                               L.dev(pooled_empty_flag, i32, "pooled_empty_flag"),
+                                               L.dev(pooled_count, i32, "pooled_count"), L.stream_ptr()),
+                "roipool3d.forward_canonical")
+        return 1
     L.check(lib.jm_roipool3d_canonical(B, N, M, C, S, L.dev(xyz, f32, "xyz"), L.dev(rois, f32, "rois"),
                                        float(extra_width), L.dev(pts_feature, f32, "pts_feature"),
                                        L.dev(pooled_features, f32, "pooled_features"),

@@ -157,6 +157,88 @@ def _sa_mlp_pm(u_pm: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w1x
     return out
 
 
+DEDUPE = True         # RCNN scales: skip (centre, sample) rows that are exact copies (csrc/sa_dedupe.hip), bit-identical output
+
+
+class DedupeStats:
+    """device-side record of the last duplicate-compacted scales: [(name, dense rows, counters tensor)]"""
+    last = []
+
+
+@torch.no_grad()
+def sa_scale_pm_dedupe(xyz: torch.Tensor, u_pm: torch.Tensor, mlp: nn.Sequential, npoint: int, radius: float, nsample: int,
+                       canon: torch.Tensor, name: str = ""):
+    """one QueryAndGroup + SharedMLP + max-pool scale on point sets with known exact copies, pre-projected form:
+    xyz (R, n, 3), u_pm (R, n, H1) point-major hoisted first layer, canon (R, n) int32 (canon[k] = first point of which point
+    k is an exact copy) -> (new_xyz (R, npoint, 3), features (R, mlp_out, npoint), rep (R, npoint) int32 = the next level's
+    canon), or None when the scale does not run on sa_mlp_pm_kernel.
+    Sampling and neighbour search are the ordinary ones (their outputs are what the reference computes); only the rows the
+    MFMA kernel executes are compacted: distinct canonical neighbours of distinct canonical centres, in segments of 16."""
+    from . import pointnet2_utils
+    lib = L.load()
+    R, n, H1 = u_pm.shape
+    dev = xyz.device
+    W1, b1, w1x, packed, extra = _pre_layers(mlp, dev)
+    pm = _pm_layers(mlp, dev, extra)
+    cap = int(lib.jm_sa_dedupe_capacity(R, npoint, nsample))
+    if (pm is None or n > 2048 or npoint > 256 or R * n >= 2 ** 31 or
+            not lib.jm_sa_mlp_pm_supported(1, R * n, cap, H1, 16, pm[4], pm[5])):
+        return None
+    wh, bh, wo, bo, hidden, cout = pm
+    fps_idx, new_xyz = pointnet2_utils.farthest_point_sample_xyz(xyz, npoint)
+    nb = pointnet2_utils.ball_query(radius, nsample, xyz, new_xyz)
+    rep = torch.empty((R, npoint), dtype=_i32, device=dev)
+    seg_start = torch.empty((R, npoint), dtype=_i32, device=dev)
+    seg_cnt = torch.empty((R, npoint), dtype=_i32, device=dev)
+    vidx = torch.empty((cap, 16), dtype=_i32, device=dev)
+    vxyz = torch.empty((cap, 3), dtype=_f32, device=dev)
+    counters = torch.empty((4,), dtype=_i32, device=dev)
+    L.check(lib.jm_sa_dedupe_plan(R, n, npoint, nsample, L.dev(canon, _i32, "canon"), L.dev(fps_idx, _i32, "fps_idx"),
+                                  L.dev(nb, _i32, "nb"), L.dev(new_xyz, _f32, "new_xyz"), L.dev(rep, _i32, "rep"),
+                                  L.dev(seg_start, _i32, "seg_start"), L.dev(seg_cnt, _i32, "seg_cnt"), L.dev(vidx, _i32, "vidx"),
+                                  L.dev(vxyz, _f32, "vxyz"), L.dev(counters, _i32, "counters"), L.stream_ptr()), "sa_dedupe_plan")
+    outv = torch.empty((cout, cap), dtype=_f32, device=dev)
+    prof.hoisted_flops(0)
+    L.check(lib.jm_sa_mlp_pm_forward_dyn(R * n, cap, H1, 16, hidden, cout, L.dev(u_pm.contiguous(), _f32, "u"), L.dev(w1x, _f32, "w1x"),
+                                         L.dev(vxyz, _f32, "vxyz"), L.dev(vidx, _i32, "vidx"), L.dev(wh, _f32, "w_hidden"),
+                                         L.dev(bh, _f32, "b_hidden"), L.dev(wo, _f32, "w_out"), L.dev(bo, _f32, "b_out"),
+                                         ctypes.c_void_p(outv.data_ptr()), ctypes.c_void_p(counters.data_ptr() + 4), L.stream_ptr()),
+            "sa_mlp_pm(dedupe)")
+    out = torch.empty((R, cout, npoint), dtype=_f32, device=dev)
+    L.check(lib.jm_sa_dedupe_combine(R, npoint, cout, cap, L.dev(outv, _f32, "outv"), L.dev(rep, _i32, "rep"),
+                                     L.dev(seg_start, _i32, "seg_start"), L.dev(seg_cnt, _i32, "seg_cnt"),
+                                     ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "sa_dedupe_combine")
+    DedupeStats.last.append((name, R * npoint * nsample, counters))
+    return new_xyz, out, rep
+
+
+@torch.no_grad()
+def canon_from_count(count: torch.Tensor, n: int) -> torch.Tensor:
+    """(R,) distinct points per cyclically padded set (roipool3d) -> canon (R, n) int32, canon[k] = k % max(count, 1)"""
+    count = count.reshape(-1).to(_i32).contiguous()
+    canon = torch.empty((count.shape[0], n), dtype=_i32, device=count.device)
+    L.check(L.load().jm_sa_dedupe_canon_from_cnt(count.shape[0], n, L.dev(count, _i32, "count"), L.dev(canon, _i32, "canon"),
+                                                 L.stream_ptr()), "sa_dedupe_canon_from_cnt")
+    return canon
+
+
+@torch.no_grad()
+def hoisted_u_point_major(xyz: torch.Tensor, features: torch.Tensor, mlp: nn.Sequential) -> Optional[torch.Tensor]:
+    """u = W1 [xyz | f] + b1 per point, point-major (B, N, H1): the hoisted first layer of a pre-projected scale as ONE launch
+    (csrc/conv1d_stack.hip), or None where that kernel does not take the shape"""
+    W1, b1, w1x, packed, extra = _pre_layers(mlp, xyz.device)
+    B, N, _ = xyz.shape
+    if not (CONV1D_STACK and N % 32 == 0):
+        return None
+    st = extra.get("u_stack")
+    if st is None:
+        from ..conv1d import PackedConv1dStack
+        st = extra["u_stack"] = PackedConv1dStack([(torch.cat([W1[:, 3:], W1[:, :3]], dim=1), b1, False)], W1.shape[1] - 3, 3, True)
+    if not st.supported(B, N):
+        return None
+    return st(features.to(_f32), xyz, point_major=True)
+
+
 def pm_plan(mlp: nn.Sequential, device, B: int, N: int, M: int, ns: int):
     """the point-major kernel's packed layers when this scale runs on it (callers then produce u as (B, N, C)), else None"""
     if not PM_KERNEL:

@@ -39,15 +39,21 @@ def roipool3d_gpu(pts, pts_feature, boxes3d, pool_extra_width, sampled_pt_num=51
     return pooled_features, pooled_empty_flag
 
 
-def roipool3d_canonical_gpu(pts, pts_feature, boxes3d, pool_extra_width, sampled_pt_num=512):
+def roipool3d_canonical_gpu(pts, pts_feature, boxes3d, pool_extra_width, sampled_pt_num=512, return_count=False):
     """roipool3d_gpu followed by the canonical transformation the RCNN stage always applies
     (jmodt/detection/layers/proposal_target_layer.py:100-112): pooled xyz minus the RoI centre, then rotated by
     the RoI heading — in ONE kernel instead of the pooling + two full passes over the (B, M, S, 3 + C) tensor
-    and a per-frame Python loop.  Returns (pooled (B, M, S, 3 + C), pooled_empty_flag (B, M) int32)."""
+    and a per-frame Python loop.  Returns (pooled (B, M, S, 3 + C), pooled_empty_flag (B, M) int32) [+ pooled_count (B, M)
+    int32 with return_count: the number of distinct source points per slab — rows count .. S-1 are cyclic copies]."""
     batch_size, boxes_num, feature_len = pts.shape[0], boxes3d.shape[1], pts_feature.shape[2]
     pooled = torch.empty((batch_size, boxes_num, sampled_pt_num, 3 + feature_len), dtype=torch.float32,
                          device=pts.device)
     empty = torch.empty((batch_size, boxes_num), dtype=torch.int32, device=pts.device)
+    if return_count:
+        count = torch.empty((batch_size, boxes_num), dtype=torch.int32, device=pts.device)
+        roipool3d_cuda.forward_canonical(pts.contiguous(), boxes3d.contiguous().float(), pool_extra_width,
+                                         pts_feature.contiguous(), pooled, empty, count)
+        return pooled, empty, count
     roipool3d_cuda.forward_canonical(pts.contiguous(), boxes3d.contiguous().float(), pool_extra_width,
                                      pts_feature.contiguous(), pooled, empty)
     return pooled, empty

@@ -132,6 +132,9 @@ ALGO: Dict[str, Callable] = {
     "jm_sa_mlp_pm_forward": lambda a: (
         4 * _i(a, 0) * (_i(a, 2) * _i(a, 4) * (_i(a, 3) + 1) + _i(a, 2) * _i(a, 6)),
         2 * _i(a, 0) * _i(a, 2) * _i(a, 4) * (_i(a, 3) * _i(a, 5) + _i(a, 5) * _i(a, 6)), {}),
+    # duplicate-compacted form: the row count lives in device memory (bench.py multiplies by the rows it reads back)
+    "jm_sa_mlp_pm_forward_dyn": lambda a: (0, 0, dict(flops_per_row=2 * (_i(a, 2) * _i(a, 4) + _i(a, 4) * _i(a, 5)),
+                                                      bytes_per_row=4 * (_i(a, 2) + 1))),
     "jm_linear_rows": lambda a: (4 * (_i(a, 0) * (_i(a, 1) + _i(a, 2)) + _i(a, 1) * _i(a, 2)), 2 * _i(a, 0) * _i(a, 1) * _i(a, 2), {}),
     "jm_mlp3_forward": lambda a: (0, _mlp3_flops(_i(a, 0), _mlp3(a[2])), {}),
     # a16: forward (3 layers) + backward (dH1, dW2, dW1) GEMMs of a head on M rows
@@ -246,6 +249,9 @@ class Profiler:
                 ev = sum(r[4].get("evals", 0) for r in evs) / steps
                 row["evals_per_s"] = round(ev / (ms * 1e-3), 1) if ms > 0 else 0.0
                 row["valu_frac"] = round(8.0 * ev / (ms * 1e-3) / 1e12 / VALU_F32_PEAK_TF, 4) if ms > 0 else 0.0
+            if "flops_per_row" in ex:
+                row["flops_per_row"] = ex["flops_per_row"]
+                row["bytes_per_row"] = ex["bytes_per_row"]
             if "iterations" in ex:
                 it = sum(r[4]["iterations"] for r in evs) / steps
                 row["us_per_fps_iteration"] = round(ms * 1e3 / it, 4)

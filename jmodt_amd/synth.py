@@ -55,6 +55,20 @@ def kitti_like_cloud(B, N, seed, dup_frac=0.1, n_objects=24):
     return pts
 
 
+def packed_cloud(B, N, seed, n_objects=16):
+    """worst case for the RCNN stage: ALL points inside `n_objects` car-sized boxes (N / n_objects >= 512 points each), so
+    every proposal holds at least 512 distinct points and roipool3d pads nothing"""
+    rng = np.random.default_rng(seed)
+    pts = np.empty((B, N, 3), dtype=np.float32)
+    for b in range(B):
+        oz = rng.uniform(6.0, 60.0, n_objects).astype(np.float32)
+        ox = (rng.uniform(-0.7, 0.7, n_objects) * np.minimum(0.85 * oz, 35.0)).astype(np.float32)
+        which = rng.integers(0, n_objects, N)
+        box = rng.uniform(-0.5, 0.5, (N, 3)).astype(np.float32) * np.array([1.6, 1.5, 3.9], np.float32)
+        pts[b] = np.stack([ox[which] + box[:, 0], 0.9 + box[:, 1], oz[which] + box[:, 2]], -1)
+    return pts
+
+
 def dense_cloud(B, N, seed, extent=4.0):
     """small-extent cloud so balls contain many points (exercises the >nsample truncation)."""
     rng = np.random.default_rng(seed)
@@ -161,6 +175,14 @@ def image(B, seed, H=384, W=1280, native=(375, 1242)):
 
 def frames(B, N, seed, H=384, W=1280, native=(375, 1242), dup_frac=0.1, kind="uniform"):
     """(xyz (B,N,3), image (B,3,H,W), pts_xy (B,N,2)): one synthetic KITTI-shaped input batch; kind =
-    "uniform" (the crop filled uniformly) or "kitti" (density ~ 1/z, ground plane, object clusters)"""
-    pts = cloud(B, N, seed, dup_frac=dup_frac) if kind == "uniform" else kitti_like_cloud(B, N, seed, dup_frac=dup_frac)
+    "uniform" (the crop filled uniformly), "kitti" (density ~ 1/z, ground plane, object clusters) or "packed" (every point in
+    one of 16 car-sized boxes: RoIs of >= 512 distinct points)"""
+    if kind == "uniform":
+        pts = cloud(B, N, seed, dup_frac=dup_frac)
+    elif kind == "kitti":
+        pts = kitti_like_cloud(B, N, seed, dup_frac=dup_frac)
+    elif kind == "packed":
+        pts = packed_cloud(B, N, seed)
+    else:
+        raise ValueError(kind)
     return pts, image(B, seed + 1, H, W, native), pts_xy(pts, W, H)
