@@ -277,6 +277,14 @@ int jm_rcnn_lift_forward(int r, int s, int k, int c, int h1, int h2, int hm, int
                          const float* b_up1, const float* w_up2, const float* b_up2, const float* w_merge_h,
                          const float* w_merge_f, const float* b_merge, const float* w_out_m, const float* w_out_x,
                          const float* b_out, int out_point_major, float* out, jm_stream_t stream);
+/* the same on slabs whose rows count[r] .. S-1 are cyclic copies of rows 0 .. count[r]-1 (jm_roipool3d_canonical_cnt): 32-point
+ * tiles holding only copies are skipped and their output rows are NOT written — for consumers that read canonical rows only
+ * (the duplicate-compacted set abstraction, jm_sa_dedupe_plan).  work: (1 + r * s / 32) i32 device scratch (list of live tiles) */
+int jm_rcnn_lift_forward_cnt(int r, int s, int k, int c, int h1, int h2, int hm, int ho, const float* pts, const float* w_up1,
+                             const float* b_up1, const float* w_up2, const float* b_up2, const float* w_merge_h,
+                             const float* w_merge_f, const float* b_merge, const float* w_out_m, const float* w_out_x,
+                             const float* b_out, int out_point_major, float* out, const int* count, int* work,
+                             jm_stream_t stream);
 
 /* The pre-projected set-abstraction block (jm_sa_mlp_forward_pre) for exactly TWO layers after the hoisted one, on a
  * POINT-major u (B, N, C) (C = 32, 64 or 128; the producers jm_conv1d_stack_forward / jm_rcnn_lift_forward write that

@@ -82,6 +82,7 @@ SIGNATURES = {
     "jm_feature_gather_grad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _L, _L, _L, _L, _P]),
     "jm_rcnn_lift_supported": (_I, [_I] * 7),
     "jm_rcnn_lift_forward": (_I, [_I] * 8 + [_P] * 11 + [_I] + [_P] * 2),
+    "jm_rcnn_lift_forward_cnt": (_I, [_I] * 8 + [_P] * 11 + [_I] + [_P] * 4),
     "jm_bias_relu_channels_last": (_I, [ctypes.c_longlong, _I, _P, _P, _P]),
     "jm_image_fusion_gather_workspace_bytes": (_Z, [_I, _I]),
     "jm_image_fusion_packed_elems": (_Z, [_I, _I]),

@@ -30,7 +30,34 @@ struct RcnnLiftParams {
     float* out;                        // (R, hm or ho, S), or (R, S, hm or ho) with out_pm
     int out_pm;
     int tiles_per_roi;
+    int total_tiles;                   // R * tiles_per_roi
+    const int* work;                   // optional work list (see rcnn_lift_worklist_kernel): [0] = number of tiles, [1..] = tile ids
 };
+
+// tiles (roi * tiles_per_roi + tile) that hold at least one DISTINCT point of their slab: first point < max(count[roi], 1).
+// One workgroup; work[0] = their number, work[1..] the ids in ascending order.
+__global__ void __launch_bounds__(1024)
+rcnn_lift_worklist_kernel(int R, int tiles_per_roi, const int* __restrict__ count, int* __restrict__ work) {
+    __shared__ int wave_tot[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < R; r0 += 1024) {
+        const int r = r0 + tid;
+        const int nt = r < R ? min(tiles_per_roi, (max(count[r], 1) + SW_BM - 1) / SW_BM) : 0;
+        const int incl = wave_incl_scan_i32_dpp(nt);
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int off = base_s + incl - nt;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        for (int t = 0; t < nt; ++t) work[1 + off + t] = r * tiles_per_roi + t;
+        __syncthreads();
+        if (tid == 1023) base_s = off + nt;
+        __syncthreads();
+    }
+    if (tid == 0) work[0] = base_s;
+}
 
 __global__ void __launch_bounds__(256)
 rcnn_lift_kernel(RcnnLiftParams p) {
@@ -44,8 +71,13 @@ rcnn_lift_kernel(RcnnLiftParams p) {
     float* XF = X5 + 16 * RL_XLD;                      // [cp][33]  RPN features
     float* H1 = XF + (size_t)cp * RL_XLD;              // [128][36]
     float* H2 = H1 + 128 * SW_LD;                      // [128][36]
-    const int roi = blockIdx.x / p.tiles_per_roi;
-    const int s0 = (blockIdx.x % p.tiles_per_roi) * SW_BM;
+    // persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ... (16384 workgroups of 58 KB LDS cost ~40 ns each just
+    // to be launched: 0.67 ms for this kernel's usual grid even when every one of them exits at once — measured)
+    const int n_tiles = p.work ? min(p.work[0], p.total_tiles) : p.total_tiles;
+    for (int wi = blockIdx.x; wi < n_tiles; wi += gridDim.x) {
+    const int tile_id = p.work ? p.work[1 + wi] : wi;
+    const int roi = tile_id / p.tiles_per_roi;
+    const int s0 = (tile_id % p.tiles_per_roi) * SW_BM;
     // ---- transposing stage-in of the contiguous 32 x RC block: element e -> (row e / RC, channel e % RC)
     {
         const float* src = p.pts + ((size_t)roi * S + s0) * RC;
@@ -123,6 +155,8 @@ rcnn_lift_kernel(RcnnLiftParams p) {
             *reinterpret_cast<float4*>(o + 8 * rq) = v;
         }
     }
+    lds_barrier();                                        // the tile's LDS operands are free for the next stage-in
+    }
 }
 
 }  // namespace jm
@@ -139,11 +173,11 @@ extern "C" int jm_rcnn_lift_supported(int s, int k, int c, int h1, int h2, int h
 
 /* all matrices in the layout of jm_sa_mlp_pack(cout, cin, first_layer = 0); w_out_m / w_out_x / b_out may be NULL (no
  * hoisted layer, h_out = 0): out = m (R, h_m, S); otherwise out = u (R, h_out, S) */
-extern "C" int jm_rcnn_lift_forward(int r, int s, int k, int c, int h1, int h2, int hm, int ho, const float* pts,
-                                    const float* w_up1, const float* b_up1, const float* w_up2, const float* b_up2,
-                                    const float* w_merge_h, const float* w_merge_f, const float* b_merge,
-                                    const float* w_out_m, const float* w_out_x, const float* b_out, int out_point_major,
-                                    float* out, jm_stream_t stream) {
+static int rcnn_lift_launch(int r, int s, int k, int c, int h1, int h2, int hm, int ho, const float* pts,
+                            const float* w_up1, const float* b_up1, const float* w_up2, const float* b_up2,
+                            const float* w_merge_h, const float* w_merge_f, const float* b_merge,
+                            const float* w_out_m, const float* w_out_x, const float* b_out, int out_point_major,
+                            float* out, const int* count, int* work, jm_stream_t stream) {
     JM_REQUIRE(r >= 0, "rcnn_lift: bad size");
     if (r == 0) return JM_OK;
     JM_REQUIRE(jm_rcnn_lift_supported(s, k, c, h1, h2, hm, ho), "rcnn_lift: unsupported shape (S %% 32 == 0, 3 <= K <= 16, widths <= 128)");
@@ -155,8 +189,39 @@ extern "C" int jm_rcnn_lift_forward(int r, int s, int k, int c, int h1, int h2, 
     p.S = s; p.K = k; p.C = c; p.cp = pad_to(c, 16); p.h1 = h1; p.h2 = h2; p.hm = hm; p.ho = ho;
     p.pts = pts; p.Wu1 = w_up1; p.Wu2 = w_up2; p.WmH = w_merge_h; p.WmF = w_merge_f; p.WoM = w_out_m; p.WoX = w_out_x;
     p.bu1 = b_up1; p.bu2 = b_up2; p.bm = b_merge; p.bo = b_out; p.out = out; p.out_pm = out_point_major ? 1 : 0; p.tiles_per_roi = s / 32;
+    p.total_tiles = (int)((long long)r * (s / 32));
+    p.work = count ? work : nullptr;
     const size_t lds_bytes = ((size_t)(16 + p.cp) * RL_XLD + 2 * 128 * SW_LD) * sizeof(float);
     (void)hipFuncSetAttribute((const void*)rcnn_lift_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(rcnn_lift_kernel, dim3((unsigned)((long long)r * (s / 32))), dim3(256), lds_bytes, (hipStream_t)stream, p);
+    if (count) hipLaunchKernelGGL(rcnn_lift_worklist_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, r, s / 32, count, work);
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    // every tile live: one workgroup each (measured 787 us; a persistent grid of 8 per CU takes 823 us).  With a work list the
+    // number of live tiles is unknown here: a persistent grid walks it (52 us at 11 distinct points per slab)
+    const int grid = (count && p.total_tiles > 8 * cus) ? 8 * cus : p.total_tiles;
+    hipLaunchKernelGGL(rcnn_lift_kernel, dim3((unsigned)grid), dim3(256), lds_bytes, (hipStream_t)stream, p);
     return check_launch("rcnn_lift");
+}
+
+extern "C" int jm_rcnn_lift_forward(int r, int s, int k, int c, int h1, int h2, int hm, int ho, const float* pts,
+                                    const float* w_up1, const float* b_up1, const float* w_up2, const float* b_up2,
+                                    const float* w_merge_h, const float* w_merge_f, const float* b_merge,
+                                    const float* w_out_m, const float* w_out_x, const float* b_out, int out_point_major,
+                                    float* out, jm_stream_t stream) {
+    return rcnn_lift_launch(r, s, k, c, h1, h2, hm, ho, pts, w_up1, b_up1, w_up2, b_up2, w_merge_h, w_merge_f, b_merge, w_out_m, w_out_x,
+                            b_out, out_point_major, out, nullptr, nullptr, stream);
+}
+
+/* the same on slabs whose rows count[r] .. S-1 are cyclic copies of rows 0 .. count[r]-1 (jm_roipool3d_canonical_cnt): 32-point
+ * tiles that hold only copies are skipped, their output rows are NOT written — for consumers that read canonical rows only
+ * (the duplicate-compacted set abstraction, csrc/sa_dedupe.hip).  work: (1 + r * s / 32) i32 scratch (the list of live tiles) */
+extern "C" int jm_rcnn_lift_forward_cnt(int r, int s, int k, int c, int h1, int h2, int hm, int ho, const float* pts,
+                                        const float* w_up1, const float* b_up1, const float* w_up2, const float* b_up2,
+                                        const float* w_merge_h, const float* w_merge_f, const float* b_merge,
+                                        const float* w_out_m, const float* w_out_x, const float* b_out, int out_point_major,
+                                        float* out, const int* count, int* work, jm_stream_t stream) {
+    JM_REQUIRE((count && work) || r == 0, "rcnn_lift: null count / work list");
+    return rcnn_lift_launch(r, s, k, c, h1, h2, hm, ho, pts, w_up1, b_up1, w_up2, b_up2, w_merge_h, w_merge_f, b_merge, w_out_m, w_out_x,
+                            b_out, out_point_major, out, count, work, stream);
 }

@@ -708,11 +708,14 @@ class DetectAffinityEngine(nn.Module):
         if lifted is not None and lifted.ho:
             g0 = sa1.groupers[0]
             pm = fused.pm_plan(sa1.mlps[0], pts_input.device, R, S, sa1.npoint, g0.nsample) is not None
-            u = lifted(pts_input, point_major=pm)                                      # (R, H1, S), or (R, S, H1) for sa_mlp_pm
-            res = None
             kept = getattr(self, "_roi_count", None)
             count = kept[1] if kept is not None and kept[0].data_ptr() == pts_input.data_ptr() else None
-            if pm and self.dedupe_rcnn and fused.DEDUPE and count is not None:
+            dedupe = (pm and self.dedupe_rcnn and count is not None
+                      and fused.dedupe_applies(sa1.mlps[0], pts_input.device, R, S, lifted.ho, sa1.npoint, g0.nsample))
+            # (with the compaction, only canonical rows of u are ever gathered: the lift skips 32-point tiles of pure copies)
+            u = lifted(pts_input, point_major=pm, count=count if dedupe else None)     # (R, H1, S), or (R, S, H1) for sa_mlp_pm
+            res = None
+            if dedupe:
                 # the pooled sets are full of exact copies (cyclic padding -> copied centres -> back-filled neighbour lists):
                 # only distinct rows go through the MFMA kernel (csrc/sa_dedupe.hip), the result is bit-identical
                 with prof.scope("rcnn_sa1"):
@@ -733,6 +736,8 @@ class DetectAffinityEngine(nn.Module):
                         l_xyz, l_feats, _ = res2
                         first = 2
             else:
+                if dedupe:                      # (cannot happen: dedupe_applies mirrors sa_scale_pm_dedupe) — rows were skipped
+                    u = lifted(pts_input, point_major=pm)
                 with prof.scope("rcnn_sa1"):
                     _, new_xyz = pointnet2_utils.farthest_point_sample_xyz(xyz, sa1.npoint)
                     nb = pointnet2_utils.ball_query(g0.radius, g0.nsample, xyz, new_xyz)

@@ -165,6 +165,16 @@ class DedupeStats:
     last = []
 
 
+def dedupe_applies(mlp: nn.Sequential, device, R: int, n: int, H1: int, npoint: int, nsample: int) -> bool:
+    """will sa_scale_pm_dedupe take this scale?  (callers that skip work for non-canonical rows decide on this)"""
+    lib = L.load()
+    W1, b1, w1x, packed, extra = _pre_layers(mlp, device)
+    pm = _pm_layers(mlp, device, extra)
+    cap = int(lib.jm_sa_dedupe_capacity(R, npoint, nsample))
+    return bool(DEDUPE and pm is not None and n <= 2048 and npoint <= 256 and R * n < 2 ** 31
+                and lib.jm_sa_mlp_pm_supported(1, R * n, cap, H1, 16, pm[4], pm[5]))
+
+
 @torch.no_grad()
 def sa_scale_pm_dedupe(xyz: torch.Tensor, u_pm: torch.Tensor, mlp: nn.Sequential, npoint: int, radius: float, nsample: int,
                        canon: torch.Tensor, name: str = ""):

@@ -40,9 +40,11 @@ class PackedRcnnLift:
         return bool(L.load().jm_rcnn_lift_supported(S, self.K, self.C, self.h1, self.h2, self.hm, self.ho))
 
     @torch.no_grad()
-    def __call__(self, pts_input: torch.Tensor, point_major: bool = False) -> torch.Tensor:
+    def __call__(self, pts_input: torch.Tensor, point_major: bool = False, count: Optional[torch.Tensor] = None) -> torch.Tensor:
         """pts_input (R, S, K + C) contiguous -> (R, hm, S) merged features, or (R, ho, S) = u when a layer is hoisted;
-        point_major: (R, S, h) instead (the layout the point-major set-abstraction kernel gathers)"""
+        point_major: (R, S, h) instead (the layout the point-major set-abstraction kernel gathers).
+        count (R,) int32: distinct points per slab (rows count .. S-1 are cyclic copies): 32-point tiles of pure copies are
+        skipped and their output rows stay UNINITIALISED — only for consumers that read canonical rows (fused.sa_scale_pm_dedupe)"""
         p = pts_input.to(_f32).contiguous()
         R, S, _ = p.shape
         h = self.ho or self.hm
@@ -50,6 +52,15 @@ class PackedRcnnLift:
 
         def ptr(t):
             return L.dev(t, _f32, "w") if t is not None else None
+        if count is not None:
+            work = torch.empty((1 + R * (S // 32),), dtype=torch.int32, device=p.device)
+            L.check(L.load().jm_rcnn_lift_forward_cnt(R, S, self.K, self.C, self.h1, self.h2, self.hm, self.ho, L.dev(p, _f32, "pts_input"),
+                                                      ptr(self.wu1), ptr(self.bu1), ptr(self.wu2), ptr(self.bu2), ptr(self.wmh),
+                                                      ptr(self.wmf), ptr(self.bm), ptr(self.wom), ptr(self.wox), ptr(self.bo),
+                                                      int(point_major), ctypes.c_void_p(out.data_ptr()),
+                                                      L.dev(count.contiguous(), torch.int32, "count"),
+                                                      L.dev(work, torch.int32, "work"), L.stream_ptr()), "rcnn_lift")
+            return out
         L.check(L.load().jm_rcnn_lift_forward(R, S, self.K, self.C, self.h1, self.h2, self.hm, self.ho, L.dev(p, _f32, "pts_input"),
                                               ptr(self.wu1), ptr(self.bu1), ptr(self.wu2), ptr(self.bu2), ptr(self.wmh),
                                               ptr(self.wmf), ptr(self.bm), ptr(self.wom), ptr(self.wox), ptr(self.bo), int(point_major),
