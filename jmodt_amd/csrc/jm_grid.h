@@ -24,6 +24,8 @@ __device__ __forceinline__ unsigned bg_bucket(int ix, int iy, int iz, unsigned t
 // and the scatter pass (n <= 1024 PPT; 0: re-read).  Bucket ORDER in the sorted array is "thread-major": thread t owns
 // buckets t, t + 1024, t + 2048, ... (conflict-free LDS columns); the table stores (start, end) per bucket, so the order
 // is private to this kernel.
+// hdr given without AUTO_H: 1 / cell edge = the inv_h ARGUMENT x hdr[frame].x (a second point set binned on the first one's
+// grid, or on a coarser one: 0.5 = cells of twice the edge, exactly the union of 2 x 2 x 2 cells of the first grid).
 // AUTO_H (needs PPT > 0): the cell edge is chosen from the frame's own bounding box — 1.5 x the point spacing of n points
 // spread over the box's volume, its largest face or its longest edge, whichever is largest (flat and line-like clouds
 // included) — and written with its reciprocal to hdr[frame] = {inv_h, h, 0, 0} for the query kernel.
@@ -41,6 +43,7 @@ bq_grid_build_kernel(int n, float inv_h, const float* __restrict__ xyz, uint2* _
     float4* so = sorted + (size_t)blockIdx.x * n;
     float px[PPT > 0 ? PPT : 1], py[PPT > 0 ? PPT : 1], pz[PPT > 0 ? PPT : 1];
     unsigned pb[PPT > 0 ? PPT : 1];
+    if (!AUTO_H && hdr) inv_h *= hdr[blockIdx.x].x;               // (inv_h argument = scale of the header's value: 0.5 -> cells twice as wide)
     if (PPT > 0) {                                   // all loads in flight at once (clamped index: no branch around a load)
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
@@ -77,7 +80,7 @@ bq_grid_build_kernel(int n, float inv_h, const float* __restrict__ xyz, uint2* _
         float s = cbrtf(ext[0] * ext[1] * ext[2] / fn);
         s = fmaxf(s, sqrtf(fmaxf(fmaxf(ext[0] * ext[1], ext[0] * ext[2]), ext[1] * ext[2]) / fn));
         s = fmaxf(s, fmaxf(fmaxf(ext[0], ext[1]), ext[2]) / fn);
-        float h = 1.5f * s;
+        float h = (inv_h > 0.f ? inv_h : 1.5f) * s;          // (AUTO_H: the inv_h argument carries the spacing factor, default 1.5)
         if (!(h > 0.f) || !(h < 1e30f)) h = 1.f;             // all points identical / non-finite coordinates: any edge works
         h = fmaxf(h, amax * 1e-5f);                          // keep cell coordinates well inside the int range
         inv_h = 1.f / h;

@@ -12,6 +12,13 @@
 //   ring 2: rho = 2 h for the lanes that could not stop.
 //   rest  : queries that still cannot stop (isolated points) are appended to a list; a second kernel scans ALL known
 //           points for them, one wave per query.
+// Two wave-cooperative forms were built, verified bit-exact and measured SLOWER than this lane walk (round 3, kept out):
+//   * one wave per bucket of unknown points, the shared neighbourhood's candidates through wave-uniform scalar loads:
+//     0.54-0.59 ms (two dependent s_load round trips per cell x 27 cells per group);
+//   * the same with the candidates staged 64 per load into a per-wave LDS list, coarse 2 x 2 x 2 grouping and the brute-force
+//     scan's "can anybody use this candidate" filter in front of the insertion: 0.23 ms at 16384 x 4096 (scan: 0.095),
+//     0.67 ms at 65536 x 4096 (this walk: 0.27, scan: 0.59) — ~13 useful lanes per fine-cell group, or ~500 candidates per
+//     coarse group, cost more than they save at these sizes.
 // Candidates arrive in cell order, not index order, and a bucket may be visited twice (two cells hashing to one bucket, ring
 // 2 re-walking ring 1): the insertion compares (d2, index) lexicographically and ignores a point that is already in the list,
 // which makes the result independent of visiting order and multiplicity — i.e. equal to the sequential scan's.
