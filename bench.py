@@ -627,17 +627,21 @@ def main():
         elapsed = float(t.item())
     timed_rows = prof.summary(args.steps, HBM_PEAK_GBS, MFMA_F32_PEAK_TF)
     table_steps = args.steps
+    bq_evals = {}
     if dom_key:                                   # the per-entry table: fully instrumented steps, outside `value`
+        from jmodt_amd.ops.pointnet2 import pointnet2_utils as _pu
         table_steps = max(1, min(5, args.steps))
         prof.reset()
         prof.only = None
         prof.enabled = True
+        _pu.BQ_EVALS.clear()
         t1 = time.perf_counter()
         for _ in range(table_steps):
             step()
         torch.cuda.synchronize()
         table_ms = (time.perf_counter() - t1) / table_steps * 1e3
         prof.enabled = False
+        bq_evals = _pu.ball_query_evals()          # distance evaluations the grid searches really did (device counters)
         if dist is not None:
             dist.barrier()
 
@@ -694,6 +698,18 @@ def main():
                     step(); step()
                     torch.cuda.synchronize()
         variants["clouds"] = clouds
+        # EXPERIMENTAL, never the headline: the link head's fp32 products as 3-term bf16 splits on the bf16 matrix pipe
+        # (csrc/affinity_x3.hip; error vs float64 at the level of the exact-fp32 kernel's: tests/test_gpu_surface.py)
+        eng.affinity_split_bf16 = True
+        try:
+            variants["experimental"] = {"split_bf16_affinity_value": round(variant(st["prefetch"], eng.overlap), 2),
+                                        "note": "same workload with ONLY the batched link head on jm_affinity_link_scores_x3 (six bf16 MFMA "
+                                                "products per fp32 product, fp32 accumulate); `value` and every other number of this "
+                                                "line are from the exact-fp32 kernels"}
+        finally:
+            eng.affinity_split_bf16 = False
+            step(); step()
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
@@ -713,6 +729,15 @@ def main():
                 if k["kernel"] in tj:
                     k["traffic_bytes_per_launch"] = tj[k["kernel"]]["bytes"]
         ms_step = elapsed / args.steps * 1e3
+        # the hash-grid ball queries: evaluations actually done (per step) next to the n * m of the scan they replace
+        for k in kernels:
+            scope = k["kernel"].rsplit("/", 1)[0] + "/ball_query" if "/" in k["kernel"] else "ball_query"
+            if "ball_query" in k["kernel"] and scope in bq_evals and k["ms_per_step"] > 0:
+                ev = bq_evals[scope][0] / table_steps
+                k["evals_per_step"] = int(ev)
+                k["evals_per_s"] = round(ev / (k["ms_per_step"] * 1e-3), 1)
+                if k.get("brute_force_evals_per_step"):
+                    k["evals_vs_brute_force"] = round(ev / k["brute_force_evals_per_step"], 5)
         # the compacted RCNN scales: executed rows were read back from the device after the timed region
         rows_now = (variants.get("clouds") or {}).get("uniform", {}).get("rcnn", {})
         for rows in (kernels, timed_rows):

@@ -86,6 +86,9 @@ int jm_ball_query_dual(int b, int n, int m, float radius0, int nsample0, float r
  * (bucket table + the points sorted by bucket); the function returns 0 where the brute-force scan is used anyway
  * (n < 2048 or n > 131072: the *_ws entries then forward to the entries above, as they do for ws == NULL). */
 size_t jm_ball_query_workspace_bytes(int b, int n);
+/* byte offset inside the workspace of 32 uint64 slots whose SUM is the number of (centre, candidate) distance evaluations of
+ * the last call that used it (0: no grid form) — the op's real work, for profiles */
+size_t jm_ball_query_evals_offset(int b, int n);
 int jm_ball_query_ws(int b, int n, int m, float radius, int nsample, const float* new_xyz, const float* xyz, int* idx, void* ws,
                      size_t ws_bytes, jm_stream_t stream);
 int jm_ball_query_dual_ws(int b, int n, int m, float radius0, int nsample0, float radius1, int nsample1, const float* new_xyz,
@@ -395,6 +398,18 @@ int jm_affinity_forward_batched(int nb, int p, int d, const float* pred_feat, co
 size_t jm_affinity_start_end_batched_workspace_bytes(int nb, int p, int d, const jm_mlp3_t* se);
 int jm_affinity_start_end_batched(int nb, int p, int d, const float* pred_feat, const float* det_feat, const jm_mlp3_t* se,
                                   float* se_out, void* ws, size_t ws_bytes, jm_stream_t stream);
+
+/* the dual softmax of jm_affinity_forward_batched on its own: link = (softmax(S, dim 2) + softmax(S, dim 1)) / 2;
+ * stats: 2 * nb * (P + D) floats of scratch */
+int jm_affinity_dual_softmax_batched(int nb, int p, int d, const float* link_raw, float* link_out, float* stats,
+                                     jm_stream_t stream);
+
+/* EXPERIMENTAL, opt-in (csrc/affinity_x3.hip): the raw link scores S (nb, P, D) with every fp32 product evaluated on the
+ * bf16 matrix pipe as a 3-term split (six bf16 products per fp32 product, fp32 accumulate): same error against fp64 as the
+ * exact-fp32 kernels (tests assert it), 2.5 x the matrix-pipe rate.  Not used by any default path. */
+size_t jm_affinity_x3_workspace_bytes(int nb, int p, int d, const jm_mlp3_t* link);
+int jm_affinity_link_scores_x3(int nb, int p, int d, const float* pred_feat, const float* det_feat, const jm_mlp3_t* link,
+                               float* link_raw, void* ws, size_t ws_bytes, jm_stream_t stream);
 
 /* One dense layer on plain rows: y (M, N) = act(x (M, K) w^T + b), w (N, K) row-major = a Conv1d(k=1) / Linear weight,
  * relu != 0 applies ReLU.  For the small-M heads (RCNN cls_layer / reg_layer, rcnn.py:43-89: 1024 RoIs x 512): single-wave

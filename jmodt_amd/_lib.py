@@ -44,6 +44,7 @@ SIGNATURES = {
     "jm_ball_query": (_I, [_I, _I, _I, _F, _I, _P, _P, _P, _P]),
     "jm_ball_query_dual": (_I, [_I, _I, _I, _F, _I, _F, _I, _P, _P, _P, _P, _P]),
     "jm_ball_query_workspace_bytes": (_Z, [_I, _I]),
+    "jm_ball_query_evals_offset": (_Z, [_I, _I]),
     "jm_ball_query_ws": (_I, [_I, _I, _I, _F, _I, _P, _P, _P, _P, _Z, _P]),
     "jm_ball_query_dual_ws": (_I, [_I, _I, _I, _F, _I, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "jm_group_points": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
@@ -105,6 +106,9 @@ SIGNATURES = {
     "jm_conv3x3_rgb_bias_relu": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "jm_sa_mlp_pm_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "jm_sa_mlp_pm_forward": (_I, [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "jm_affinity_dual_softmax_batched": (_I, [_I, _I, _I, _P, _P, _P, _P]),
+    "jm_affinity_x3_workspace_bytes": (_Z, [_I, _I, _I, ctypes.POINTER(Mlp3)]),
+    "jm_affinity_link_scores_x3": (_I, [_I, _I, _I, _P, _P, ctypes.POINTER(Mlp3), _P, _P, _Z, _P]),
     "jm_linear_rows": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "jm_mlp3_workspace_bytes": (_Z, [_I, ctypes.POINTER(Mlp3)]),
     "jm_mlp3_forward": (_I, [_I, _P, ctypes.POINTER(Mlp3), _P, _P, _Z, _P]),

@@ -502,6 +502,18 @@ extern "C" int jm_affinity_forward_batched(int nb, int p, int d, const float* pr
     return check_launch("affinity_batched");
 }
 
+/* the dual softmax alone: link (nb, P, D) = (softmax(S, dim 2) + softmax(S, dim 1)) / 2 of raw scores S; stats: 2 * nb * (P + D) floats */
+extern "C" int jm_affinity_dual_softmax_batched(int nb, int p, int d, const float* link_raw, float* link_out, float* stats,
+                                                jm_stream_t stream) {
+    JM_REQUIRE(nb >= 0 && p >= 0 && d >= 0 && nb <= 65535, "affinity dual softmax: bad sizes");
+    if (nb == 0 || p == 0 || d == 0) return JM_OK;
+    JM_REQUIRE(link_raw && link_out && stats, "affinity dual softmax: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(softmax_stats_kernel, dim3((unsigned)(p + d), (unsigned)nb), dim3(256), 0, s, p, d, link_raw, stats);
+    hipLaunchKernelGGL(dual_softmax_kernel, dim3(divup(p * d, 256), (unsigned)nb), dim3(256), 0, s, p, d, link_raw, stats, link_out);
+    return check_launch("affinity dual softmax");
+}
+
 extern "C" size_t jm_affinity_start_end_batched_workspace_bytes(int nb, int p, int d, const jm_mlp3_t* se) {
     if (nb <= 0 || p <= 0 || d <= 0 || !se) return 0;
     const size_t r = (size_t)nb * ((size_t)p + d);

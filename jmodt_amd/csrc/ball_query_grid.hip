@@ -34,6 +34,7 @@ struct BgParams {
     float r[2], r2[2];
     int ns[2];
     int* idx[2];
+    unsigned long long* evals;   // distance evaluations of the launch (one atomic per wave): the op's real work, for the profile
 };
 
 constexpr int BG_WAVES = 4;
@@ -105,6 +106,7 @@ bq_grid_query_kernel(BgParams p, const float* __restrict__ new_xyz, const uint2*
     };
 
     BgCells nxt = lookup(0);
+    int evaluated = 0;
     for (int ci = 0; ci < nc; ++ci) {
         const BgCells cur = nxt;
         if (ci + 1 < nc) nxt = lookup(ci + 1);                          // its table loads fly under this centre's work
@@ -114,6 +116,7 @@ bq_grid_query_kernel(BgParams p, const float* __restrict__ new_xyz, const uint2*
         const int excl = incl - cur.cnt;
         const int total = __builtin_amdgcn_readlane(incl, 63);
         const int rel = cur.start - excl;                // candidate t of this lane's range lives at sorted[rel + t]
+        evaluated += total;
         for (int t0 = 0; t0 < total; t0 += 64) {
             const int t = t0 + lane;
             const bool valid = t < total;
@@ -212,6 +215,7 @@ bq_grid_query_kernel(BgParams p, const float* __restrict__ new_xyz, const uint2*
             }
         }
     }
+    if (p.evals && lane == 0) atomicAdd(p.evals + (blockIdx.x & 31), (unsigned long long)evaluated);   // 32 slots: no hot address
 }
 
 static int bg_words(int n) { return divup(divup(n, 32), 256) * 256; }
@@ -233,6 +237,9 @@ static int launch_ball_query_grid(int b, int n, int m, int nr, const float* radi
     const int T = bg_table_size(n);
     uint2* tbl = reinterpret_cast<uint2*>(ws);
     float4* sorted = reinterpret_cast<float4*>(reinterpret_cast<char*>(ws) + align_up((size_t)b * BG_T_MAX * sizeof(uint2), 256));
+    unsigned long long* evals = reinterpret_cast<unsigned long long*>(
+        reinterpret_cast<char*>(sorted) + align_up((size_t)b * n * sizeof(float4), 256));      // last 256 bytes of the workspace
+    (void)hipMemsetAsync(evals, 0, 32 * sizeof(unsigned long long), s);
 #define JM_BG_BUILD(TPT, PPT)                                                                                                   \
     do {                                                                                                                       \
         (void)hipFuncSetAttribute((const void*)bq_grid_build_kernel<TPT, PPT>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
@@ -247,6 +254,7 @@ static int launch_ball_query_grid(int b, int n, int m, int nr, const float* radi
 #undef JM_BG_BUILD
     BgParams p{};
     p.n = n; p.m = m; p.b = b; p.inv_h = 1.f / h; p.T = T;
+    p.evals = evals;
     p.words = bg_words(n);
     p.cpw = 1;                                   // centres per wave: as few as keeps >= ~2048 workgroups in the launch
     while (p.cpw < BG_CPW && (long long)b * m / (BG_WAVES * p.cpw * 2) >= 2048) p.cpw *= 2;
@@ -274,6 +282,14 @@ static int launch_ball_query_grid(int b, int n, int m, int nr, const float* radi
 using namespace jm;
 
 extern "C" size_t jm_ball_query_workspace_bytes(int b, int n) {
+    if (b < 1 || !bg_applies(n)) return 0;
+    return align_up((size_t)b * BG_T_MAX * sizeof(uint2), 256) + align_up((size_t)b * n * sizeof(float4), 256) + 256;
+}
+
+/* byte offset of the launch's distance-evaluation counters (32 x uint64, to be summed) inside the workspace: the number of
+ * (centre, candidate) pairs the last call on that workspace evaluated, readable after the stream has finished (bench.py
+ * reports it as evals/s) */
+extern "C" size_t jm_ball_query_evals_offset(int b, int n) {
     if (b < 1 || !bg_applies(n)) return 0;
     return align_up((size_t)b * BG_T_MAX * sizeof(uint2), 256) + align_up((size_t)b * n * sizeof(float4), 256);
 }

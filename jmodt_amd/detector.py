@@ -285,6 +285,7 @@ class DetectAffinityEngine(nn.Module):
         self.fuse_small_heads = True       # RCNN cls / reg heads: one MFMA launch per dense layer
         self.fuse_rcnn_lift = True         # xyz_up + merge_down (+ hoisted first SA layer) as one kernel
         self.fuse_attention = True         # LI-Fusion attention block as one kernel where it fits (else rocBLAS GEMMs)
+        self.affinity_split_bf16 = False   # EXPERIMENTAL (csrc/affinity_x3.hip): link-head products as 3-term bf16 splits
         self.dedupe_rcnn = True            # RCNN SA1 / SA2: skip (centre, sample) rows that are exact copies (bit-identical output)
         self._prefetched = None
         self._prefetched_img = None
@@ -824,7 +825,7 @@ class DetectAffinityEngine(nn.Module):
         link, se = self.rcnn_net.link_layer, self.rcnn_net.se_layer
         with prof.scope(f"affinity_{B}x{M}x{M}"):
             # every frame against its predecessor, all B problems as one GEMM chain (jm_affinity_forward_batched)
-            A, start, end = pairwise_affinity_batched(torch.roll(feats, 1, 0), feats, link, se)
+            A, start, end = pairwise_affinity_batched(torch.roll(feats, 1, 0), feats, link, se, split_bf16=self.affinity_split_bf16)
             aff = [(A[b], start[b], end[b]) for b in range(B)]
         if side is not None:
             main.wait_stream(side)

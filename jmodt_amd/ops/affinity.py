@@ -124,7 +124,7 @@ def pairwise_affinity(pred_features: torch.Tensor, det_features: torch.Tensor, l
 @torch.no_grad()
 def pairwise_affinity_batched(pred_features: torch.Tensor, det_features: torch.Tensor, link_model: nn.Sequential,
                               se_model: Optional[nn.Sequential] = None, return_raw: bool = False,
-                              overlap_start_end: bool = True) -> Tuple[torch.Tensor, ...]:
+                              overlap_start_end: bool = True, split_bf16: bool = False) -> Tuple[torch.Tensor, ...]:
     """nb independent problems at once: pred_features (nb, P, C), det_features (nb, D, C) ->
     link_scores (nb, P, D), start_logits (nb, D), end_logits (nb, P) (+ raw (nb, P, D)): `pairwise_affinity` for every
     frame pair of a batch as ONE GEMM chain over nb*P*D pair rows (jm_affinity_forward_batched)"""
@@ -155,6 +155,21 @@ def pairwise_affinity_batched(pred_features: torch.Tensor, det_features: torch.T
                                                       se_p, ctypes.c_void_p(se_out.data_ptr()), ctypes.c_void_p(se_ws.data_ptr()),
                                                       se_bytes, L.stream_ptr()), "pairwise_affinity_batched(start/end)")
     link_p = ctypes.byref(link)
+    if split_bf16:
+        # EXPERIMENTAL (csrc/affinity_x3.hip): the link head's products on the bf16 matrix pipe as 3-term splits
+        raw = torch.empty((nb, P, D), dtype=_f32, device=dev)
+        xb = lib.jm_affinity_x3_workspace_bytes(nb, P, D, link_p)
+        xws = torch.empty((max(xb, 16),), dtype=torch.uint8, device=dev)
+        L.check(lib.jm_affinity_link_scores_x3(nb, P, D, L.dev(pf, _f32, "pred_features"), L.dev(df, _f32, "det_features"), link_p,
+                                               ctypes.c_void_p(raw.data_ptr()), ctypes.c_void_p(xws.data_ptr()), xb, L.stream_ptr()),
+                "pairwise_affinity_batched(x3)")
+        stats = torch.empty((2 * nb * (P + D),), dtype=_f32, device=dev)
+        L.check(lib.jm_affinity_dual_softmax_batched(nb, P, D, L.dev(raw, _f32, "raw"), ctypes.c_void_p(A.data_ptr()),
+                                                     ctypes.c_void_p(stats.data_ptr()), L.stream_ptr()), "pairwise_affinity_batched(softmax)")
+        if side is not main:
+            main.wait_stream(side)
+        out = (A, se_out[:, :D], se_out[:, D:]) if se_model is not None else (A,)
+        return out + ((raw,) if return_raw else ())
     ws_bytes = lib.jm_affinity_batched_workspace_bytes(nb, P, D, link_p)
     ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
     L.check(lib.jm_affinity_forward_batched(nb, P, D, L.dev(pf, _f32, "pred_features"), L.dev(df, _f32, "det_features"), link_p,

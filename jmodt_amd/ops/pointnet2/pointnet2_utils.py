@@ -23,6 +23,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from ... import _lib as L
+from ...profile import prof
 from ...ext import pointnet2_cuda
 
 _f32, _i32 = torch.float32, torch.int32
@@ -195,7 +196,25 @@ def _ball_query_workspace(B: int, N: int, device):
     nbytes = L.load().jm_ball_query_workspace_bytes(B, N)
     if nbytes == 0:
         return None, 0
-    return torch.empty((nbytes,), dtype=torch.uint8, device=device), nbytes
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    if prof.enabled and prof.only is None:      # the launch counts its distance evaluations at the end of the workspace: kept for bench.py to read
+        BQ_EVALS.append((prof._key("ball_query"), ws, L.load().jm_ball_query_evals_offset(B, N), B * N))
+    return ws, nbytes
+
+
+BQ_EVALS = []     # (profile scope, workspace, counter offset, B * N) of the grid searches launched while the profiler was on
+
+
+def ball_query_evals():
+    """{profile scope: (distance evaluations, launches)} of the recorded grid searches; clears the record (synchronises)"""
+    torch.cuda.synchronize()
+    out = {}
+    for key, ws, off, _ in BQ_EVALS:
+        n = int(ws[off:off + 256].view(torch.int64).sum().item())
+        e, c = out.get(key, (0, 0))
+        out[key] = (e + n, c + 1)
+    BQ_EVALS.clear()
+    return out
 
 
 class _BallQuery(Function):

@@ -249,6 +249,8 @@ class Profiler:
                 ev = sum(r[4].get("evals", 0) for r in evs) / steps
                 row["evals_per_s"] = round(ev / (ms * 1e-3), 1) if ms > 0 else 0.0
                 row["valu_frac"] = round(8.0 * ev / (ms * 1e-3) / 1e12 / VALU_F32_PEAK_TF, 4) if ms > 0 else 0.0
+            if "brute_force_evals" in ex:
+                row["brute_force_evals_per_step"] = int(sum(r[4].get("brute_force_evals", 0) for r in evs) / steps)
             if "flops_per_row" in ex:
                 row["flops_per_row"] = ex["flops_per_row"]
                 row["bytes_per_row"] = ex["bytes_per_row"]
@@ -277,7 +279,8 @@ class LibProxy:
         if hit is not None:
             return hit
         fn = getattr(object.__getattribute__(self, "_cdll"), sym)
-        if not sym.startswith("jm_") or sym.endswith("_bytes") or sym.endswith("_elems") or sym.endswith("_supported") or sym in (
+        if (not sym.startswith("jm_") or sym.endswith("_bytes") or sym.endswith("_elems") or sym.endswith("_supported")
+                or sym.endswith("_offset") or sym.endswith("_capacity")) or sym in (
                 "jm_version", "jm_last_error", "jm_sa_mlp_pack", "jm_image_fusion_pack", "jm_pts_in_boxes3d_cpu", "jm_roipool3d_cpu"):
             cache[sym] = fn
             return fn

@@ -334,3 +334,36 @@ def test_pairwise_affinity_batched_matches_per_problem(oracle, nb, P, D, C):
             oA, os_, oe = oracle.affinity(pf[b].cpu().numpy(), df[b].cpu().numpy(), w(link), w(se))
             assert np.abs(A[b].cpu().numpy() - oA).max() < 1e-4 and np.abs(s[b].cpu().numpy() - os_).max() < 1e-4
             assert np.abs(e[b].cpu().numpy() - oe).max() < 1e-4
+
+
+# ------------------------------------------------------------------ EXPERIMENTAL split-bf16 affinity (csrc/affinity_x3.hip)
+@pytest.mark.parametrize("nb,P,D,C", [(8, 128, 128, 512), (2, 64, 64, 512), (1, 37, 50, 64)])
+def test_affinity_split_bf16_error_not_above_exact_fp32(nb, P, D, C):
+    """opt-in path only: every fp32 product as six bf16 products (3-term splits).  Its error against a float64 evaluation must
+    be AT THE LEVEL of the exact-fp32 MFMA kernel's (both ~1e-6 on O(1) scores, i.e. fp32 rounding of a 512-term sum: the two
+    maxima differ by a few per cent either way, which is noise of the maximum, so the bar is 1.25 x), and the final affinity stays
+    within the 1e-4 bar with a 10 x margin."""
+    from jmodt_amd.ops.affinity import make_affinity_mlp, pairwise_affinity_batched
+    torch.manual_seed(nb * P + C)
+    link = make_affinity_mlp(C, (C, C)).to(DEV).eval()
+    with torch.no_grad():
+        for m in link.modules():
+            if isinstance(m, torch.nn.Conv1d):
+                m.bias.normal_(0, 0.05)
+    g = torch.Generator().manual_seed(3)
+    pf = torch.relu(torch.randn(nb, P, C, generator=g)).to(DEV)
+    df = torch.relu(torch.randn(nb, D, C, generator=g)).to(DEV)
+    A32, raw32 = pairwise_affinity_batched(pf, df, link, None, return_raw=True)
+    Ax3, rawx3 = pairwise_affinity_batched(pf, df, link, None, return_raw=True, split_bf16=True)
+    w = [t.detach().double() for t in (link[0].conv.weight[..., 0], link[0].conv.bias, link[2].conv.weight[..., 0], link[2].conv.bias,
+                                       link[3].conv.weight.reshape(-1), link[3].conv.bias)]
+    cor = (pf.double().unsqueeze(2) - df.double().unsqueeze(1)).abs()                       # (nb, P, D, C)
+    h = torch.relu(cor @ w[0].t() + w[1])
+    h = torch.relu(h @ w[2].t() + w[3])
+    want = h @ w[4] + w[5]
+    e32 = (raw32.double() - want).abs().max().item()
+    ex3 = (rawx3.double() - want).abs().max().item()
+    print(f"raw link scores, max |err| vs float64: exact fp32 MFMA {e32:.3e}, split bf16 (6 products) {ex3:.3e}, |S|max {want.abs().max().item():.2f}")
+    assert ex3 <= max(e32 * 1.25, 1e-6), (ex3, e32)
+    wantA = (torch.softmax(want, 2) + torch.softmax(want, 1)) / 2
+    assert (Ax3.double() - wantA).abs().max().item() < 1e-5 and (A32.double() - wantA).abs().max().item() < 1e-5
