@@ -10,7 +10,10 @@
 //   * operands held as three bf16 PLANES: weights are split once per call (split_planes_kernel), the pair rows |p_i - d_j| are
 //     split while they are staged (layer 1), and layer 1's epilogue writes the hidden activations directly as planes, so
 //     layer 2 stages plain 8-byte copies;
-//   * LDS tiles row-major [plane][row][16 k + 8 pad] bf16: a lane's eight k of a 32 x 32 x 16 operand are one ds_read_b128.
+//   * A tiles in LDS, row-major [plane][row][16 k + 8 pad] bf16: a lane's eight k of a 32 x 32 x 16 operand are one
+//     ds_read_b128; the WEIGHT planes are packed once per call in MFMA fragment order (pack_planes_frag_kernel) and read
+//     straight from L2 into registers one k-tile ahead — no B tile in LDS (37 KB per workgroup instead of 72: four
+//     workgroups per CU), no B staging instructions.
 // The dual softmax and the start / end head are affinity.hip's.
 #include "jm_common.h"
 
@@ -20,7 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
-constexpr int XM = 128, XN = 128, XK = 16, XLD = 24;     // rows, columns, k per tile; LDS row stride in bf16 (48 B: conflict-free b128)
+constexpr int XM = 128, XN = 128, XK = 32, XLD = 40;     // rows, columns, k per tile (two MFMA k-steps per barrier); LDS row stride in bf16 (80 B)
 
 __device__ __forceinline__ u16 bf16_rne(float x) {
     unsigned u = __float_as_uint(x);
@@ -46,12 +49,27 @@ __global__ void split_planes_kernel(long long total, const float* __restrict__ s
     dst[e] = a; dst[total + e] = b; dst[2 * total + e] = c;
 }
 
+// weights W (N, K) fp32 -> three bf16 planes in fragment order: [plane][k-tile][32-column block][lane][8] with
+// lane (lr, lk) holding W[32 cb + lr][16 kt + 8 lk .. + 7]: a wave's B operand of one MFMA is 1 KB contiguous
+__global__ void pack_planes_frag_kernel(int N, int K, const float* __restrict__ W, u16* __restrict__ dst) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // one (n, k) element
+    if (e >= (long long)N * K) return;
+    const int n = (int)(e / K), k = (int)(e - (long long)n * K);
+    u16 h[3];
+    split3(W[e], h[0], h[1], h[2]);
+    const int kt = k >> 4, lk = (k >> 3) & 1, t = k & 7, cb = n >> 5, lr = n & 31;
+    const size_t plane = (size_t)N * K;
+    const size_t at = ((((size_t)kt * (N >> 5) + cb) * 64) + lk * 32 + lr) * 8 + t;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) dst[q * plane + at] = h[q];
+}
+
 struct X3Params {
     int M, N, K;
     const float *pf, *df;      // layer 1: pair rows (see GemmParams of affinity.hip): row m -> (m / D, m % D + (m / PD) * D)
     int D, PD;
     const u16* Ap;             // layer 2: A planes (3, M, K)
-    const u16* Bp;             // weight planes (3, N, K)
+    const u16* Bp;             // weight planes in fragment order (pack_planes_frag_kernel)
     const float* bias;         // (N)
     u16* Hp;                   // layer 1 out: relu(acc + bias) as planes (3, M, N)
     const float* w3;           // layer 2: projection
@@ -61,24 +79,24 @@ struct X3Params {
 template <int LAYER>
 __global__ void __launch_bounds__(256)
 mlp_gemm_x3_kernel(X3Params p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];        // 72 KB: above the static limit
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];        // 2 x 3 x 128 x 40 bf16 = 60 KB
     typedef u16 (*Tile)[3][XM][XLD];
     Tile As = reinterpret_cast<Tile>(lds_raw);
-    Tile Bs = reinterpret_cast<Tile>(lds_raw + sizeof(u16) * 2 * 3 * XM * XLD);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (p.N + XN - 1) / XN;
     const int m0 = ((int)blockIdx.x / ntn) * XM, n0 = ((int)blockIdx.x % ntn) * XN;
     const size_t planeA = (size_t)p.M * p.K, planeB = (size_t)p.N * p.K;
-    // staging: 128 rows x 16 k per operand per k-tile = 512 groups of 4 k: two per thread
-    int srow[2], skq[2];
-    const float *a_ptr[2], *a2_ptr[2];
-    const u16 *ap_ptr[2], *bp_ptr[2];
+    // staging: 128 rows x 32 k per k-tile = 1024 groups of 4 k: four per thread
+    constexpr int NST = XM * XK / 4 / 256;
+    int srow[NST], skq[NST];
+    const float *a_ptr[NST], *a2_ptr[NST];
+    const u16* ap_ptr[NST];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NST; ++i) {
         const int f = tid + 256 * i;
-        srow[i] = f >> 2; skq[i] = (f & 3) * 4;
-        const int m = min(m0 + srow[i], p.M - 1), n = min(n0 + srow[i], p.N - 1);
+        srow[i] = f / (XK / 4); skq[i] = (f % (XK / 4)) * 4;
+        const int m = min(m0 + srow[i], p.M - 1);
         if (LAYER == 1) {
             const int pi = m / p.D, di = m - pi * p.D + (m / p.PD) * p.D;
             a_ptr[i] = p.pf + (size_t)pi * p.K + skq[i];
@@ -86,13 +104,12 @@ mlp_gemm_x3_kernel(X3Params p) {
         } else {
             ap_ptr[i] = p.Ap + (size_t)m * p.K + skq[i];
         }
-        bp_ptr[i] = p.Bp + (size_t)n * p.K + skq[i];
     }
-    float4 rv[2], ru[2];
-    uint2 ra[2][3], rb[2][3];
+    float4 rv[NST], ru[NST];
+    uint2 ra[NST][3];
     auto g_load = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NST; ++i) {
             if (LAYER == 1) {
                 rv[i] = *reinterpret_cast<const float4*>(a_ptr[i] + k0);
                 ru[i] = *reinterpret_cast<const float4*>(a2_ptr[i] + k0);
@@ -100,13 +117,11 @@ mlp_gemm_x3_kernel(X3Params p) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) ra[i][q] = *reinterpret_cast<const uint2*>(ap_ptr[i] + q * planeA + k0);
             }
-#pragma unroll
-            for (int q = 0; q < 3; ++q) rb[i][q] = *reinterpret_cast<const uint2*>(bp_ptr[i] + q * planeB + k0);
         }
     };
     auto s_store = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NST; ++i) {
             if (LAYER == 1) {
                 const float v[4] = {fabsf(rv[i].x - ru[i].x), fabsf(rv[i].y - ru[i].y), fabsf(rv[i].z - ru[i].z), fabsf(rv[i].w - ru[i].w)};
                 u16 h[3][4];
@@ -120,8 +135,17 @@ mlp_gemm_x3_kernel(X3Params p) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(&As[buf][q][srow[i]][skq[i]]) = ra[i][q];
             }
+        }
+    };
+    // this wave's B fragments of 16-k step ks: column blocks (n0 + wn * 64) / 32 + j, planes q (clamped block: loads stay unconditional)
+    const int ncb = p.N >> 5;
+    const int cb0 = min((n0 + wn * 64) >> 5, ncb - 1), cb1 = min(cb0 + 1, ncb - 1);
+    auto b_load = [&](int ks, bf16x8 (&b)[2][3]) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(&Bs[buf][q][srow[i]][skq[i]]) = rb[i][q];
+        for (int q = 0; q < 3; ++q) {
+            const u16* base = p.Bp + q * planeB + ((size_t)ks * ncb * 64 + lane) * 8;
+            b[0][q] = *reinterpret_cast<const bf16x8*>(base + (size_t)cb0 * 512);
+            b[1][q] = *reinterpret_cast<const bf16x8*>(base + (size_t)cb1 * 512);
         }
     };
     f32x16 acc[2][2];
@@ -131,35 +155,43 @@ mlp_gemm_x3_kernel(X3Params p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int nkt = p.K / XK;
+    const int nkt = p.K / XK, nks = p.K / 16;
     const int lr = lane & 31, lk = lane >> 5;
+    // six products per fp32 product, smallest terms first; the four accumulators interleaved (no back-to-back dependent MFMAs)
+    auto mm = [&](const bf16x8 (&a)[2][3], const bf16x8 (&b)[2][3]) {
+        constexpr int QA[6] = {0, 1, 2, 0, 1, 0}, QB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][QA[t]], b[j][QB[t]], acc[i][j], 0, 0, 0);
+    };
+    auto a_load = [&](int buf, int half, bf16x8 (&a)[2][3]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(&As[buf][q][wm * 64 + i * 32 + lr][half * 16 + lk * 8]);
+    };
+    bf16x8 b0[2][3], b1[2][3];
     g_load(0);
+    b_load(0, b0);
     s_store(0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         g_load(min(kt + 1, nkt - 1) * XK);
+        b_load(min(2 * kt + 1, nks - 1), b1);
+        bf16x8 a0[2][3], a1[2][3];
+        a_load(buf, 0, a0);
+        a_load(buf, 1, a1);
         __builtin_amdgcn_sched_barrier(0);
-        bf16x8 a[2][3], b[2][3];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                a[i][q] = *reinterpret_cast<const bf16x8*>(&As[buf][q][wm * 64 + i * 32 + lr][lk * 8]);
-                b[i][q] = *reinterpret_cast<const bf16x8*>(&Bs[buf][q][wn * 64 + i * 32 + lr][lk * 8]);
-            }
-        // smallest terms first: (1,3) (2,2) (3,1), then (1,2) (2,1), then (1,1)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-            }
+        mm(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        b_load(min(2 * kt + 2, nks - 1), b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < nkt) s_store(buf ^ 1);
         __syncthreads();
@@ -227,8 +259,8 @@ extern "C" int jm_affinity_link_scores_x3(int nb, int p, int d, const float* pre
     JM_REQUIRE(nb >= 0 && p >= 0 && d >= 0, "affinity_x3: bad sizes");
     if (nb == 0 || p == 0 || d == 0) return JM_OK;
     JM_REQUIRE(link && link->w1 && link->b1 && link->w2 && link->b2 && link->w3 && link->b3, "affinity_x3: null weights");
-    JM_REQUIRE(link->c % 16 == 0 && link->h1 % 16 == 0 && link->h2 >= 1 && link->c >= 16 && link->h1 >= 16,
-               "affinity_x3: channel sizes must be multiples of 16");
+    JM_REQUIRE(link->c % 32 == 0 && link->h1 % 32 == 0 && link->h2 % 32 == 0 && link->c >= 32,
+               "affinity_x3: channel sizes must be multiples of 32");
     JM_REQUIRE(pred_feat && det_feat && link_raw && ws, "affinity_x3: null pointer");
     JM_REQUIRE(((reinterpret_cast<uintptr_t>(pred_feat) | reinterpret_cast<uintptr_t>(det_feat) | reinterpret_cast<uintptr_t>(ws)) & 15u) == 0,
                "affinity_x3: 16-byte alignment");
@@ -241,12 +273,12 @@ extern "C" int jm_affinity_link_scores_x3(int nb, int p, int d, const float* pre
     u16* W1p = (u16*)w; w += align_up(3 * (size_t)link->h1 * link->c * sizeof(u16), 256);
     u16* W2p = (u16*)w;
     const long long t1 = (long long)link->h1 * link->c, t2 = (long long)link->h2 * link->h1;
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, t1, link->w1, W1p);
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, t2, link->w2, W2p);
+    hipLaunchKernelGGL(pack_planes_frag_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, link->h1, link->c, link->w1, W1p);
+    hipLaunchKernelGGL(pack_planes_frag_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, s, link->h2, link->h1, link->w2, W2p);
     X3Params a{};
     a.M = M; a.N = link->h1; a.K = link->c; a.pf = pred_feat; a.df = det_feat; a.D = d; a.PD = p * d;
     a.Bp = W1p; a.bias = link->b1; a.Hp = Hp;
-    const size_t lds = sizeof(u16) * 2 * 3 * (XM + XN) * XLD;
+    const size_t lds = sizeof(u16) * 2 * 3 * XM * XLD;
     (void)hipFuncSetAttribute((const void*)mlp_gemm_x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)mlp_gemm_x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((mlp_gemm_x3_kernel<1>), dim3((unsigned)(divup(M, XM) * divup(a.N, XN))), dim3(256), lds, s, a);

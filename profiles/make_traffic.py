@@ -15,7 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # bench row (kernels[].kernel) -> (workload, kernel-name substring in the rocprof tables)
 MAP = {
     # default workload (detect): the largest-shape dispatch of each kernel = the row named here
-    "rcnn_sa1/sa_mlp_pm_forward": ("detect", "sa_mlp_pm_kernel"),
+    "rcnn_sa1/sa_mlp_pm_forward": ("detect", "sa_mlp_pm_kernel"),          # largest dispatch = the DENSE RCNN SA1 (bench variant)
+    "affinity_8x128x128/affinity_forward_batched": ("detect", ["mlp_gemm_kernel<0", "mlp_gemm_kernel<1"]),   # the entry's two GEMMs
+    "rpn_sa1/ball_query_dual_ws": ("detect", ["bq_grid_build_kernel<16", "bq_grid_query_kernel<2>"]),
+    "rcnn_lift_forward_cnt": ("detect", "rcnn_lift_kernel"),
     "conv3x3_rgb_bias_relu": ("detect", "conv3x3_rgb_kernel"),
     "conv1d_stack_forward": ("detect", "conv1d_stack_kernel"),
     "fps_pyramid/L1/furthest_point_sampling_xyz": ("detect", "fps_regs2_kernel<16, 1024>"),
@@ -31,7 +34,7 @@ MAP = {
     "rpn_sa4/sa_mlp_forward": ("detect", "sa_mlp_wide_kernel"),
     # sa workload (configs[1])
     "fps_pyramid/L2/furthest_point_sampling_xyz": ("sa", "fps_regs2_kernel<4, 1024>"),
-    "L1/ball_query_dual": ("sa", "ball_query_kernel<2,"),
+    "L1/ball_query_dual_ws": ("sa", ["bq_grid_build_kernel<16", "bq_grid_query_kernel<2>"]),
     "L2/feat/group_points": ("sa", "group_points_kernel<true>"),
     # ops workload
     "roipool3d_forward": ("ops", "roipool3d_kernel"),
@@ -44,6 +47,11 @@ MAP = {
 
 
 def column(path, needle, col):
+    """the avg / min / max field (col 0 / 1 / 2) of the first row naming `needle` (the per-name table comes first); a LIST of
+    needles = the kernels one entry launches: their sum"""
+    if isinstance(needle, (list, tuple)):
+        vals = [column(path, n, col) for n in needle]
+        return None if any(v is None for v in vals) else sum(vals)
     for line in open(path):
         if needle in line:
             return float(line.split()[-3 + col])   # avg, min, max are the last three fields
@@ -64,7 +72,8 @@ def main(rnd):
             continue
         if f is None or w is None:
             continue
-        out[name] = {"kernel": needle, "fetch_kib": f, "write_kib": w, "bytes": int((2 * f + w) * 1024)}
+        out[name] = {"kernel": needle if isinstance(needle, str) else " + ".join(needle), "fetch_kib": f, "write_kib": w,
+                     "bytes": int((2 * f + w) * 1024)}
     json.dump(out, open(os.path.join(HERE, f"{rnd}_traffic.json"), "w"), indent=1)
     for k, v in out.items():
         if isinstance(v, dict):
@@ -72,4 +81,4 @@ def main(rnd):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r02")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r03")
