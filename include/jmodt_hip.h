@@ -93,6 +93,13 @@ int jm_ball_query_ws(int b, int n, int m, float radius, int nsample, const float
                      size_t ws_bytes, jm_stream_t stream);
 int jm_ball_query_dual_ws(int b, int n, int m, float radius0, int nsample0, float radius1, int nsample1, const float* new_xyz,
                           const float* xyz, int* idx0, int* idx1, void* ws, size_t ws_bytes, jm_stream_t stream);
+/* The two steps of the *_ws entries on their own.  The BUILD depends on the points and the cell radius only — a caller can run
+ * it early / on another stream (ops/pointnet2/pyramid.py: every level's grid is built on the FPS side stream) and leave only
+ * the query on its critical path.  cell_radius: the largest radius the grid will be searched with (any positive value gives
+ * correct results; the same value must be passed to the query).  radius1 <= 0 or idx1 == NULL: one radius. */
+int jm_ball_query_grid_build(int b, int n, float cell_radius, const float* xyz, void* ws, size_t ws_bytes, jm_stream_t stream);
+int jm_ball_query_grid_query(int b, int n, int m, float cell_radius, float radius0, int nsample0, float radius1, int nsample1,
+                             const float* new_xyz, int* idx0, int* idx1, void* ws, size_t ws_bytes, jm_stream_t stream);
 
 /* group_points_wrapper / group_points_grad_wrapper (group_points.cpp:11-36,
  * group_points_gpu.cu:8-86).  points (B,C,N), idx (B,P,S) -> out (B,C,P,S). */

@@ -47,6 +47,8 @@ SIGNATURES = {
     "jm_ball_query_evals_offset": (_Z, [_I, _I]),
     "jm_ball_query_ws": (_I, [_I, _I, _I, _F, _I, _P, _P, _P, _P, _Z, _P]),
     "jm_ball_query_dual_ws": (_I, [_I, _I, _I, _F, _I, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    "jm_ball_query_grid_build": (_I, [_I, _I, _F, _P, _P, _Z, _P]),
+    "jm_ball_query_grid_query": (_I, [_I, _I, _I, _F, _F, _I, _F, _I, _P, _P, _P, _P, _Z, _P]),
     "jm_group_points": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "jm_group_points_grad": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "jm_three_nn": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),

@@ -49,7 +49,8 @@ struct TGemm {
     int D, PD, ldp;            // m -> pi = m / D, di = m % D + (m / PD) * D
     const float* bias;         // E_RELU*: (N)
     const float* w3;           // E_RELU_PROJ: (N)
-    float* score;              // E_RELU_PROJ: (M), pre-filled with b3
+    float* score;              // E_RELU_PROJ: (slots, M) partial projections, slot = the 64- (small kernel: 32-) column group;
+                               // train_score_sum_kernel adds them in slot order (no float atomics: bit-reproducible)
     const float* mask;         // E_MASK: (M, N), out = acc where mask > 0 else 0 (may alias out)
     float* out; int ldo;       // (M, N); E_PARTIAL: out + split * M * ldo
 };
@@ -226,7 +227,7 @@ train_gemm_kernel(TGemm p) {
             for (int r = 0; r < 16; ++r) {
                 const float v = half_sum_f32_dpp(part[r]);
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (lr == 31 && row < p.M) unsafeAtomicAdd(p.score + row, v);
+                if (lr == 31 && row < p.M) p.score[(size_t)((n0 >> 6) + wn) * p.M + row] = v;
             }
         }
     }
@@ -298,7 +299,7 @@ train_gemm_small_kernel(TGemm p) {
         if (ok) p.out[(size_t)orow * p.ldo + c] = v;
         if (EM == E_RELU_PROJ) {
             const float t = half_sum_f32_dpp(v * wv);
-            if (r == 31 && orow < p.M) unsafeAtomicAdd(p.score + orow, t);
+            if (r == 31 && orow < p.M) p.score[(size_t)blockIdx.x * p.M + orow] = t;
         }
     }
 }
@@ -310,9 +311,14 @@ static void launch_tgemm_small(const TGemm& p, hipStream_t s) {
     hipLaunchKernelGGL((train_gemm_small_kernel<BM_, EM>), dim3((unsigned)divup(p.N, 32), (unsigned)divup(p.M, 32)), dim3(64), 0, s, p);
 }
 
-__global__ void train_fill_kernel(int n, const float* __restrict__ value, float* __restrict__ dst) {
+// y[m] = b3 + sum over the column-group slots of the projection partials, in slot order
+__global__ void train_score_sum_kernel(int n, int slots, const float* __restrict__ part, const float* __restrict__ b3,
+                                       float* __restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = value[0];
+    if (i >= n) return;
+    float v = b3[0];
+    for (int k = 0; k < slots; ++k) v += part[(size_t)k * n + i];
+    dst[i] = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -681,7 +687,7 @@ static int split_rows(int M, int tiles) {
 }
 
 struct TrainWs {      // carved out of the caller's workspace
-    float *h1, *h2, *y, *dy, *p_dw3, *p_db2, *p_db3, *p_db1, *p_dw2, *p_dw1;
+    float *h1, *h2, *y, *ypart, *dy, *p_dw3, *p_db2, *p_db3, *p_db1, *p_dw2, *p_dw1;
     int chunks, chunk1, chunk2, splits1, splits2;
     size_t bytes;
 };
@@ -698,6 +704,7 @@ static TrainWs carve(int M, const jm_mlp3_t* mlp, void* ws) {
     w.h1 = take((size_t)M * mlp->h1);
     w.h2 = take((size_t)M * mlp->h2);
     w.y = take(M);
+    w.ypart = take((size_t)M * divup(mlp->h2, 32));
     w.dy = take(M);
     w.p_dw3 = take((size_t)w.chunks * mlp->h2);
     w.p_db2 = take((size_t)w.chunks * mlp->h2);
@@ -720,12 +727,13 @@ static int mlp_train_forward(int M, const float* x, const float* pf, const float
     if (small) launch_tgemm_small<B_ROWS, E_RELU>(a, s);
     else if (x) launch_tgemm<A_ROWS, B_ROWS, E_RELU>(a, s);
     else launch_tgemm<A_PAIR, B_ROWS, E_RELU>(a, s);
-    hipLaunchKernelGGL(train_fill_kernel, dim3(divup(M, 256)), dim3(256), 0, s, M, mlp->b3, w.y);
     TGemm b{};
     b.M = M; b.N = mlp->h2; b.K = mlp->h1; b.kchunk = mlp->h1;
-    b.A = w.h1; b.lda = mlp->h1; b.B = mlp->w2; b.ldb = mlp->h1; b.bias = mlp->b2; b.w3 = mlp->w3; b.score = w.y;
+    b.A = w.h1; b.lda = mlp->h1; b.B = mlp->w2; b.ldb = mlp->h1; b.bias = mlp->b2; b.w3 = mlp->w3; b.score = w.ypart;
     b.out = w.h2; b.ldo = mlp->h2;
     if (small) launch_tgemm_small<B_ROWS, E_RELU_PROJ>(b, s); else launch_tgemm<A_ROWS, B_ROWS, E_RELU_PROJ>(b, s);
+    const int slots = small ? divup(mlp->h2, 32) : 2 * divup(mlp->h2, TBN);
+    hipLaunchKernelGGL(train_score_sum_kernel, dim3(divup(M, 256)), dim3(256), 0, s, M, slots, w.ypart, mlp->b3, w.y);
     return check_launch("affinity_train forward");
 }
 

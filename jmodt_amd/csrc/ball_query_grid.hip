@@ -229,32 +229,46 @@ static int bg_table_size(int n) {
     return t;
 }
 
-static int launch_ball_query_grid(int b, int n, int m, int nr, const float* radius, const int* nsample, const float* new_xyz,
-                                  const float* xyz, int* const* idx, void* ws, hipStream_t s) {
-    float rmax = radius[0];
-    for (int r = 1; r < nr; ++r) rmax = fmaxf(rmax, radius[r]);
-    const float h = rmax * 1.01f;
+struct BgWs { uint2* tbl; float4* sorted; unsigned long long* evals; };
+
+static BgWs bg_carve(int b, int n, void* ws) {
+    BgWs w;
+    w.tbl = reinterpret_cast<uint2*>(ws);
+    w.sorted = reinterpret_cast<float4*>(reinterpret_cast<char*>(ws) + align_up((size_t)b * BG_T_MAX * sizeof(uint2), 256));
+    w.evals = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(w.sorted) + align_up((size_t)b * n * sizeof(float4), 256));
+    return w;
+}
+
+// step 1: bin the frames' points (depends on xyz and the cell radius only — not on the centres)
+static int bg_build(int b, int n, float cell_radius, const float* xyz, void* ws, hipStream_t s) {
+    const float h = cell_radius * 1.01f;
     const int T = bg_table_size(n);
-    uint2* tbl = reinterpret_cast<uint2*>(ws);
-    float4* sorted = reinterpret_cast<float4*>(reinterpret_cast<char*>(ws) + align_up((size_t)b * BG_T_MAX * sizeof(uint2), 256));
-    unsigned long long* evals = reinterpret_cast<unsigned long long*>(
-        reinterpret_cast<char*>(sorted) + align_up((size_t)b * n * sizeof(float4), 256));      // last 256 bytes of the workspace
-    (void)hipMemsetAsync(evals, 0, 32 * sizeof(unsigned long long), s);
+    const BgWs w = bg_carve(b, n, ws);
 #define JM_BG_BUILD(TPT, PPT)                                                                                                   \
     do {                                                                                                                       \
         (void)hipFuncSetAttribute((const void*)bq_grid_build_kernel<TPT, PPT>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                   1024 * TPT * 4);                                                                             \
         hipLaunchKernelGGL((bq_grid_build_kernel<TPT, PPT>), dim3((unsigned)b), dim3(1024), 1024 * TPT * 4, s, n, 1.f / h, xyz, \
-                           tbl, sorted);                                                                                       \
+                           w.tbl, w.sorted);                                                                                   \
     } while (0)
     if (T == 4096) JM_BG_BUILD(4, 16);              // n <= 4096
     else if (T == 8192) JM_BG_BUILD(8, 16);
     else if (T == 16384) JM_BG_BUILD(16, 16);       // n <= 16384
     else JM_BG_BUILD(32, 0);
 #undef JM_BG_BUILD
+    return check_launch("ball_query(grid build)");
+}
+
+// step 2: the searches on a grid built with `cell_radius` (any positive value is CORRECT: the cell range of a ball is computed
+// from the ball's own radius; a cell radius close to the largest search radius is the fast one)
+static int bg_query(int b, int n, int m, float cell_radius, int nr, const float* radius, const int* nsample, const float* new_xyz,
+                    int* const* idx, void* ws, hipStream_t s) {
+    const float h = cell_radius * 1.01f;
+    const BgWs w = bg_carve(b, n, ws);
+    (void)hipMemsetAsync(w.evals, 0, 32 * sizeof(unsigned long long), s);
     BgParams p{};
-    p.n = n; p.m = m; p.b = b; p.inv_h = 1.f / h; p.T = T;
-    p.evals = evals;
+    p.n = n; p.m = m; p.b = b; p.inv_h = 1.f / h; p.T = bg_table_size(n);
+    p.evals = w.evals;
     p.words = bg_words(n);
     p.cpw = 1;                                   // centres per wave: as few as keeps >= ~2048 workgroups in the launch
     while (p.cpw < BG_CPW && (long long)b * m / (BG_WAVES * p.cpw * 2) >= 2048) p.cpw *= 2;
@@ -269,12 +283,20 @@ static int launch_ball_query_grid(int b, int n, int m, int nr, const float* radi
     JM_REQUIRE(groups < (1LL << 31), "ball_query: too many centres");
     if (nr == 1) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)bq_grid_query_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((bq_grid_query_kernel<1>), dim3((unsigned)groups), dim3(64 * BG_WAVES), lds, s, p, new_xyz, tbl, sorted);
+        hipLaunchKernelGGL((bq_grid_query_kernel<1>), dim3((unsigned)groups), dim3(64 * BG_WAVES), lds, s, p, new_xyz, w.tbl, w.sorted);
     } else {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)bq_grid_query_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((bq_grid_query_kernel<2>), dim3((unsigned)groups), dim3(64 * BG_WAVES), lds, s, p, new_xyz, tbl, sorted);
+        hipLaunchKernelGGL((bq_grid_query_kernel<2>), dim3((unsigned)groups), dim3(64 * BG_WAVES), lds, s, p, new_xyz, w.tbl, w.sorted);
     }
     return check_launch("ball_query(grid)");
+}
+
+static int launch_ball_query_grid(int b, int n, int m, int nr, const float* radius, const int* nsample, const float* new_xyz,
+                                  const float* xyz, int* const* idx, void* ws, hipStream_t s) {
+    float rmax = radius[0];
+    for (int r = 1; r < nr; ++r) rmax = fmaxf(rmax, radius[r]);
+    const int rc = bg_build(b, n, rmax, xyz, ws, s);
+    return rc ? rc : bg_query(b, n, m, rmax, nr, radius, nsample, new_xyz, idx, ws, s);
 }
 
 }  // namespace jm
@@ -320,4 +342,32 @@ extern "C" int jm_ball_query_dual_ws(int b, int n, int m, float radius0, int nsa
     const int ns[2] = {nsample0, nsample1};
     int* idxs[2] = {idx0, idx1};
     return launch_ball_query_grid(b, n, m, 2, rad, ns, new_xyz, xyz, idxs, ws, (hipStream_t)stream);
+}
+
+/* the two steps of the *_ws entries on their own: the BUILD depends on the points and the cell radius only, so a caller can run
+ * it early / on another stream (ops/pointnet2/pyramid.py builds every level's grid on the FPS side stream, behind the sampling
+ * that produces the level's points) and leave only the query on the critical path.  cell_radius: the largest radius the grid
+ * will be searched with (any positive value gives correct results).  radius1 <= 0 or idx1 == NULL: one radius. */
+extern "C" int jm_ball_query_grid_build(int b, int n, float cell_radius, const float* xyz, void* ws, size_t ws_bytes, jm_stream_t stream) {
+    const size_t need = jm_ball_query_workspace_bytes(b, n);
+    JM_REQUIRE(need > 0 && bg_radius_ok(cell_radius), "ball_query_grid_build: no grid form for n = %d / radius %g", n, (double)cell_radius);
+    JM_REQUIRE(xyz && ws && (reinterpret_cast<uintptr_t>(ws) & 15u) == 0, "ball_query_grid_build: null / unaligned pointer");
+    if (ws_bytes < need) { set_error("ball_query_grid_build: workspace %zu < %zu bytes", ws_bytes, need); return JM_EWORKSPACE; }
+    return bg_build(b, n, cell_radius, xyz, ws, (hipStream_t)stream);
+}
+
+extern "C" int jm_ball_query_grid_query(int b, int n, int m, float cell_radius, float radius0, int nsample0, float radius1, int nsample1,
+                                        const float* new_xyz, int* idx0, int* idx1, void* ws, size_t ws_bytes, jm_stream_t stream) {
+    const size_t need = jm_ball_query_workspace_bytes(b, n);
+    JM_REQUIRE(need > 0 && bg_radius_ok(cell_radius) && bg_radius_ok(radius0), "ball_query_grid_query: no grid form for these arguments");
+    if (m == 0) return JM_OK;
+    const int nr = (idx1 && radius1 > 0.f) ? 2 : 1;
+    JM_REQUIRE(nr == 1 || bg_radius_ok(radius1), "ball_query_grid_query: bad second radius");
+    JM_REQUIRE(m >= 0 && nsample0 >= 1 && nsample0 <= 1024 && (nr == 1 || (nsample1 >= 1 && nsample1 <= 1024)), "ball_query_grid_query: bad sizes");
+    JM_REQUIRE(new_xyz && idx0 && ws && (reinterpret_cast<uintptr_t>(ws) & 15u) == 0, "ball_query_grid_query: null / unaligned pointer");
+    if (ws_bytes < need) { set_error("ball_query_grid_query: workspace %zu < %zu bytes", ws_bytes, need); return JM_EWORKSPACE; }
+    const float rad[2] = {radius0, radius1};
+    const int ns[2] = {nsample0, nsample1};
+    int* idxs[2] = {idx0, idx1};
+    return bg_query(b, n, m, cell_radius, nr, rad, ns, new_xyz, idxs, ws, (hipStream_t)stream);
 }

@@ -409,9 +409,14 @@ class DetectAffinityEngine(nn.Module):
         point branch of the next call at every LI-Fusion level.  The next call must pass the same tensor objects."""
         self._refresh()
         if self.overlap:
-            self._prefetched = (xyz, FpsPyramid(xyz, list(self.cfg.sa_npoints), overlap=True, with_interp=True))
+            self._prefetched = (xyz, FpsPyramid(xyz, list(self.cfg.sa_npoints), overlap=True, with_interp=True,
+                                                grid_radii=self._grid_radii()))
             if image is not None and self.prefetch_image:
                 self._prefetched_img = (image, self._launch_image_branch(image))
+
+    def _grid_radii(self):
+        """largest ball-query radius per RPN SA level: the pyramid builds the levels' neighbour-search grids on its side stream"""
+        return [max(r) for r in self.cfg.sa_radius]
 
     def _drop_kept(self):
         kept, self._kept = getattr(self, "_kept", None), None
@@ -493,7 +498,8 @@ class DetectAffinityEngine(nn.Module):
         self._refresh()
         self._drop_kept()
         # --- stream F: the whole FPS chain (coordinates only); already running if this batch was announced ---
-        pyr = self._take_prefetched(xyz) or FpsPyramid(xyz, list(cfg.sa_npoints), overlap=self.overlap, with_interp=self.overlap)
+        pyr = self._take_prefetched(xyz) or FpsPyramid(xyz, list(cfg.sa_npoints), overlap=self.overlap, with_interp=self.overlap,
+                                                       grid_radii=self._grid_radii())
         # --- stream I: image pyramid; already running (or done) if this batch's image was announced ---
         ib = self._take_prefetched_image(image) or self._launch_image_branch(image, pts_xy)
         if next_xyz is not None:
@@ -509,7 +515,7 @@ class DetectAffinityEngine(nn.Module):
             idx, new_xyz = pyr.level(i)
             self.last_fps_idx.append(idx)
             with prof.scope(f"rpn_sa{i + 1}"):
-                _, feats, _ = sa(l_xyz[i], l_feats[i], new_xyz=new_xyz)
+                _, feats, _ = sa(l_xyz[i], l_feats[i], new_xyz=new_xyz, grid=pyr.grid(i))
             xy_i = torch.gather(l_xy[i], 1, idx.long().unsqueeze(-1).expand(-1, -1, 2))       # backbone.py:170-171
             prof.stall(f"image_exposed_wait_L{i + 1}", lambda e=img_events[i]: main.wait_event(e))
             with prof.scope(f"li_fusion{i + 1}"):

@@ -38,9 +38,10 @@ class _PointnetSAModuleBase(nn.Module):
         raise NotImplementedError(self.pool_method)
 
     def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor] = None,
-                new_xyz: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+                new_xyz: Optional[torch.Tensor] = None, grid=None) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
         """xyz (B, N, 3), features (B, C, N) -> new_xyz (B, npoint, 3),
-        new_features (B, sum_k mlps[k][-1], npoint), idx (B, npoint) or None"""
+        new_features (B, sum_k mlps[k][-1], npoint), idx (B, npoint) or None.
+        grid: (MI355X-native, optional) a pointnet2_utils.BallQueryGrid of xyz built ahead of this call"""
         idx = None
         if new_xyz is None and self.npoint is not None:
             if xyz.requires_grad:   # (never in the reference pipeline; keeps the autograd path available)
@@ -54,7 +55,7 @@ class _PointnetSAModuleBase(nn.Module):
         if (len(self.groupers) == 2 and new_xyz is not None
                 and all(isinstance(g, pointnet2_utils.QueryAndGroup) for g in self.groupers)):
             g0, g1 = self.groupers
-            neigh = list(pointnet2_utils.ball_query_dual(g0.radius, g0.nsample, g1.radius, g1.nsample, xyz, new_xyz))
+            neigh = list(pointnet2_utils.ball_query_dual(g0.radius, g0.nsample, g1.radius, g1.nsample, xyz, new_xyz, grid=grid))
 
         pooled = []
         for grouper, mlp, nb in zip(self.groupers, self.mlps, neigh):

@@ -202,6 +202,39 @@ def _ball_query_workspace(B: int, N: int, device):
     return ws, nbytes
 
 
+class BallQueryGrid:
+    """the hash grid of a cloud, built ahead of the searches (jm_ball_query_grid_build): the build needs the points and the
+    largest search radius only — e.g. on the FPS side stream, while the centres are still being sampled (pyramid.py).  None of
+    it is needed for correctness: `ball_query(..., grid=None)` builds its own."""
+
+    def __init__(self, xyz: torch.Tensor, cell_radius: float):
+        _need(xyz, "xyz")
+        self.B, self.N = xyz.shape[0], xyz.shape[1]
+        self.cell_radius = float(cell_radius)
+        lib = L.load()
+        self.nbytes = lib.jm_ball_query_workspace_bytes(self.B, self.N)
+        self.ws = None
+        if self.nbytes and self.cell_radius > 0:
+            self.ws = torch.empty((self.nbytes,), dtype=torch.uint8, device=xyz.device)
+            L.check(lib.jm_ball_query_grid_build(self.B, self.N, self.cell_radius, L.dev(xyz, _f32, "xyz"),
+                                                 ctypes.c_void_p(self.ws.data_ptr()), self.nbytes, L.stream_ptr()), "ball_query_grid_build")
+
+    def matches(self, xyz: torch.Tensor) -> bool:
+        return self.ws is not None and xyz.shape[0] == self.B and xyz.shape[1] == self.N
+
+    def query(self, new_xyz, r0, ns0, r1=0.0, ns1=0):
+        B, npoint = new_xyz.shape[0], new_xyz.shape[1]
+        idx0 = torch.zeros((B, npoint, ns0), dtype=_i32, device=new_xyz.device)
+        idx1 = torch.zeros((B, npoint, ns1), dtype=_i32, device=new_xyz.device) if ns1 else None
+        if prof.enabled and prof.only is None:
+            BQ_EVALS.append((prof._key("ball_query"), self.ws, L.load().jm_ball_query_evals_offset(self.B, self.N), self.B * self.N))
+        L.check(L.load().jm_ball_query_grid_query(B, self.N, npoint, self.cell_radius, float(r0), ns0, float(r1), ns1,
+                                                  L.dev(new_xyz, _f32, "new_xyz"), L.dev(idx0, _i32, "idx0"),
+                                                  L.dev(idx1, _i32, "idx1") if idx1 is not None else None,
+                                                  ctypes.c_void_p(self.ws.data_ptr()), self.nbytes, L.stream_ptr()), "ball_query_grid_query")
+        return idx0, idx1
+
+
 BQ_EVALS = []     # (profile scope, workspace, counter offset, B * N) of the grid searches launched while the profiler was on
 
 
@@ -241,10 +274,12 @@ ball_query = _BallQuery.apply
 
 
 def ball_query_dual(radius0: float, nsample0: int, radius1: float, nsample1: int, xyz: torch.Tensor,
-                    new_xyz: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+                    new_xyz: torch.Tensor, grid: Optional["BallQueryGrid"] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """both MSG radii of an SA level in one pass over xyz (no reference counterpart; results are
-    identical to two ball_query calls)"""
+    identical to two ball_query calls).  grid: a BallQueryGrid of xyz built ahead (only its query then runs here)"""
     _need(new_xyz, "new_xyz"); _need(xyz, "xyz")
+    if grid is not None and grid.matches(xyz) and radius0 > 0 and radius1 > 0:
+        return grid.query(new_xyz, radius0, nsample0, radius1, nsample1)
     B, N, _ = xyz.size()
     npoint = new_xyz.size(1)
     idx0 = torch.zeros((B, npoint, nsample0), dtype=_i32, device=xyz.device)

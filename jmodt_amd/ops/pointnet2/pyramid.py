@@ -15,7 +15,7 @@ compete for the machine.
 
 `PointnetSAModuleMSG.forward` already takes `new_xyz` (pointnet2_modules.py:24-33).
 """
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -38,7 +38,11 @@ _side_stream = side_stream   # round-1 name
 
 
 class FpsPyramid:
-    def __init__(self, xyz: torch.Tensor, npoints: List[int], overlap: bool = True, with_interp: bool = False):
+    def __init__(self, xyz: torch.Tensor, npoints: List[int], overlap: bool = True, with_interp: bool = False,
+                 grid_radii: Optional[List[float]] = None):
+        """grid_radii[k] (optional): the largest ball-query radius of level k — the level's neighbour-search grid
+        (pointnet2_utils.BallQueryGrid over the level's INPUT points) is then built here, on the side stream, ahead of the
+        sampling that produces the level's centres; `grid(k)` hands it out"""
         main = torch.cuda.current_stream(xyz.device)
         side = side_stream(xyz.device) if overlap else main
         self._main, self._side, self._xyz = main, side, xyz   # xyz stays referenced until release()
@@ -46,10 +50,16 @@ class FpsPyramid:
         if side is not main:
             xyz.record_stream(side)      # allocated on the main stream, read by the side stream
         self._levels: List[Tuple[torch.Tensor, torch.Tensor, torch.cuda.Event]] = []
+        self._grids: List[Optional[pointnet2_utils.BallQueryGrid]] = []
         with torch.cuda.stream(side), prof.scope("fps_pyramid"):
             cur = xyz
             for k, m in enumerate(npoints):
                 with prof.scope(f"L{k + 1}"):
+                    g = None
+                    if grid_radii is not None and k < len(grid_radii) and grid_radii[k]:
+                        g = pointnet2_utils.BallQueryGrid(cur, grid_radii[k])      # (points + radius only: in front of the sampling)
+                        g = g if g.ws is not None else None
+                    self._grids.append(g)
                     idx, new_xyz = pointnet2_utils.farthest_point_sample_xyz(cur, m)
                 ev = torch.cuda.Event()
                 ev.record(side)
@@ -85,6 +95,11 @@ class FpsPyramid:
             prof.stall(f"fps_exposed_wait_L{k + 1}", lambda: cur.wait_event(ev))
         return idx, new_xyz
 
+    def grid(self, k: int):
+        """the BallQueryGrid over level k's input points (None: not requested / the scan is used at that size); ordered like
+        level(k): call it after level(k)"""
+        return self._grids[k] if k < len(self._grids) else None
+
     def interp(self, k: int):
         """(nn3 (B, n_{k-1}, 3) int32, weights (B, n_{k-1}, 3)) interpolating level k's features onto level k-1's points
         (level -1 = the input cloud), or None when the pyramid was built without them"""
@@ -103,4 +118,4 @@ class FpsPyramid:
         """the consumer is done with every level: order the side stream after it, drop the references"""
         if self._side is not self._main:
             self._side.wait_stream(torch.cuda.current_stream(self._xyz.device))
-        self._levels, self._interp, self._xyz = [], [], None
+        self._levels, self._interp, self._xyz, self._grids = [], [], None, []

@@ -906,6 +906,32 @@ def test_ball_query_grid_full_size_and_far_coordinates(oracle):
     _bq_both(oracle, far, cen, (2.0,), (16,))
 
 
+def test_ball_query_prebuilt_grid_on_side_stream(oracle):
+    """jm_ball_query_grid_build on a side stream, jm_ball_query_grid_query later on the main stream (the FpsPyramid use):
+    same indices as the oracle; a grid reused for two different centre sets; a grid of the wrong cloud is refused"""
+    import torch
+    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
+    xyz = synth.kitti_like_cloud(2, 16384, 43)
+    rng = np.random.default_rng(5)
+    side = torch.cuda.Stream()
+    txyz = T(xyz)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        grid = pu.BallQueryGrid(txyz, 0.5)
+        ev = torch.cuda.Event(); ev.record()
+    assert grid.ws is not None
+    torch.cuda.current_stream().wait_event(ev)
+    for seed in (0, 1):
+        pick = np.stack([rng.choice(16384, 512, replace=False) for _ in range(2)])
+        cen = np.take_along_axis(xyz, pick[..., None], axis=1).copy()
+        i0, i1 = pu.ball_query_dual(0.1, 16, 0.5, 32, txyz, T(cen), grid=grid)
+        assert np.array_equal(i0.cpu().numpy(), oracle.ball_query(0.1, 16, xyz, cen))
+        assert np.array_equal(i1.cpu().numpy(), oracle.ball_query(0.5, 32, xyz, cen))
+    assert not grid.matches(txyz[:, :4096])
+    small = pu.BallQueryGrid(txyz[:, :1024].contiguous(), 0.5)      # below the grid's size range: no workspace, callers scan
+    assert small.ws is None
+
+
 # ------------------------------------------------------------------ hash-grid 3-NN (csrc/three_nn_grid.hip)
 @pytest.mark.parametrize("kind", ["uniform", "kitti", "flat", "identical", "dup_heavy", "isolated"])
 def test_three_nn_grid_vs_oracle(oracle, kind):
