@@ -19,6 +19,7 @@ The parameter containers keep the reference's attribute names (`rpn.backbone_net
 float32 (the reference's arithmetic; `dtype` of bench.py).  Eval mode only: BatchNorm is folded into the
 neighbouring 1x1 convolution where that removes a pass over a tensor.
 """
+import contextlib
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -282,6 +283,9 @@ class DetectAffinityEngine(nn.Module):
         self.last_fps_idx: List[torch.Tensor] = []
         self.sparse_image_fusion = True    # final image feature only under the bilinear taps (else dense deconvolutions)
         self.fuse_rgb_conv = True          # image branch's first (3-channel) convolution + bias + ReLU as one pass
+        self.conv_find = True              # MIOpen picks each image convolution's kernel by measurement on first use (find
+                                           # mode, scoped to those calls): 6.03 vs 6.34 ms over the seven 3x3 convolutions
+                                           # (tools/miopen_find_probe.py); costs 1-3 s per new shape, once per process
         self.fuse_small_heads = True       # RCNN cls / reg heads: one MFMA launch per dense layer
         self.fuse_rcnn_lift = True         # xyz_up + merge_down (+ hoisted first SA layer) as one kernel
         self.fuse_attention = True         # LI-Fusion attention block as one kernel where it fits (else rocBLAS GEMMs)
@@ -546,6 +550,16 @@ class DetectAffinityEngine(nn.Module):
             self._prefetched_img = (next_image, self._launch_image_branch(next_image))    # ordered after this batch's backbone
         return out
 
+    @contextlib.contextmanager
+    def _miopen_find(self):
+        """torch.backends.cudnn.benchmark (= MIOpen find mode on ROCm) for the convolutions issued inside, nothing else"""
+        prev = torch.backends.cudnn.benchmark
+        torch.backends.cudnn.benchmark = bool(self.conv_find) or prev
+        try:
+            yield
+        finally:
+            torch.backends.cudnn.benchmark = prev
+
     def _image_block(self, i: int, x: torch.Tensor) -> torch.Tensor:
         """BasicBlock (backbone.py:16-32) with the eval-mode BatchNorm folded into conv1: conv3x3 (MIOpen) ->
         + bias, ReLU in one in-place pass -> conv3x3 stride 2 (MIOpen)"""
@@ -568,8 +582,11 @@ class DetectAffinityEngine(nn.Module):
             wt = self._wb(f"img_block{i}.rgb", lambda: pack_rgb_weight(W))
             y = conv3x3_rgb_bias_relu(x, W, b, wt)
         else:
-            y = bias_relu_(F.conv2d(x, W, None, stride=1, padding=1), b)
-        return F.conv2d(y, W2, b2, stride=blk.conv2.stride, padding=blk.conv2.padding)
+            with self._miopen_find():
+                y = F.conv2d(x, W, None, stride=1, padding=1)
+            y = bias_relu_(y, b)
+        with self._miopen_find():
+            return F.conv2d(y, W2, b2, stride=blk.conv2.stride, padding=blk.conv2.padding)
 
     def _image_fusion_map(self, img_maps: List[torch.Tensor]) -> torch.Tensor:
         """relu(bn(conv1x1(cat_i deconv_i(img_i)))) (backbone.py:187-193).  The 1x1 fusion convolution is linear,

@@ -25,12 +25,23 @@ from . import pointnet2_utils
 _side = {}
 
 
+def _side_priority(slot: int) -> int:
+    """JM_SIDE_PRIO="slot:priority,..." (experiments: tools/stream_prio_probe.py); default 0 everywhere"""
+    import os
+    for item in os.environ.get("JM_SIDE_PRIO", "").split(","):
+        if ":" in item:
+            k, v = item.split(":")
+            if int(k) == slot:
+                return int(v)
+    return 0
+
+
 def side_stream(device, slot: int = 0) -> torch.cuda.Stream:
     """a per-(device, slot) auxiliary stream, created once (slot 0: FPS chain, slot 1: image branch)"""
     d = torch.device(device)
     key = (d.index if d.index is not None else torch.cuda.current_device(), slot)
     if key not in _side:
-        _side[key] = torch.cuda.Stream(device=key[0])
+        _side[key] = torch.cuda.Stream(device=key[0], priority=_side_priority(slot))
     return _side[key]
 
 

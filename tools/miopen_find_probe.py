@@ -3,13 +3,16 @@ Run in a FRESH process per setting (the find results are cached per process and 
 import os, sys, time
 import torch, torch.nn.functional as F
 mode = sys.argv[1] if len(sys.argv) > 1 else "default"
-torch.backends.cudnn.benchmark = mode != "default"
+layout = sys.argv[2] if len(sys.argv) > 2 else "nhwc"
+fmt = torch.channels_last if layout == "nhwc" else torch.contiguous_format
+torch.backends.cudnn.benchmark = mode not in ("default", "deterministic")
+torch.backends.cudnn.deterministic = mode.startswith("deterministic")   # MIOpen: excludes the split-K (atomic add) solvers
 shapes = [(64, 64, 384, 1280, 2), (64, 128, 192, 640, 1), (128, 128, 192, 640, 2), (128, 256, 96, 320, 1), (256, 256, 96, 320, 2),
           (256, 512, 48, 160, 1), (512, 512, 48, 160, 2)]
 tot = 0.0
 for cin, cout, H, W, s in shapes:
-    x = torch.randn(8, cin, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
-    w = torch.randn(cout, cin, 3, 3, device="cuda").contiguous(memory_format=torch.channels_last)
+    x = torch.randn(8, cin, H, W, device="cuda").contiguous(memory_format=fmt)
+    w = torch.randn(cout, cin, 3, 3, device="cuda").contiguous(memory_format=fmt)
     t0 = time.time()
     for _ in range(3): F.conv2d(x, w, None, stride=s, padding=1)
     torch.cuda.synchronize(); setup = time.time() - t0
@@ -20,5 +23,5 @@ for cin, cout, H, W, s in shapes:
     ms = e0.elapsed_time(e1) / 10
     fl = 2 * 8 * (H // s) * (W // s) * 9 * cin * cout
     tot += ms
-    print(f"{mode:10s} {cin:4d}->{cout:4d} @{H}x{W} s{s}: {ms:.3f} ms  {fl / ms / 1e9:6.1f} TF  (first calls {setup:.1f} s)", flush=True)
+    print(f"{mode:10s} {layout} {cin:4d}->{cout:4d} @{H}x{W} s{s}: {ms:.3f} ms  {fl / ms / 1e9:6.1f} TF  (first calls {setup:.1f} s)", flush=True)
 print(f"{mode:10s} total {tot:.3f} ms")
