@@ -54,7 +54,7 @@ struct GemmParams {
     const float* bias;  // (N)
     float* H;           // (M,N) output, ReLU applied            [EMODE 0]
     const float* w3;    // (N)                                    [EMODE 1]
-    float* score;       // (M) pre-filled with b3, accumulated    [EMODE 1]
+    float* score;       // (slots, M) projection partials, slot = 64-column group (single-wave kernel: 32)   [EMODE 1]
 };
 
 // Up to two independent problems per launch (grouped GEMM): the link head's P*D pair rows and
@@ -197,7 +197,7 @@ mlp_gemm_kernel(GemmGroup grp) {
             for (int r = 0; r < 16; ++r) {
                 const float v = half_sum_f32_dpp(part[r]);   // sum over the 32 columns of this lane half
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (lr == 31 && row < p.M) unsafeAtomicAdd(p.score + row, v);
+                if (lr == 31 && row < p.M) p.score[(size_t)((n0 >> 6) + wn) * p.M + row] = v;
             }
         }
     }
@@ -272,14 +272,19 @@ mlp_gemm_small_kernel(GemmParams p) {
             if (cok && orow < p.M) p.H[(size_t)orow * p.N + c] = hval;
         } else {
             const float v = half_sum_f32_dpp(hval * wv);
-            if (r == 31 && orow < p.M) unsafeAtomicAdd(p.score + orow, v);
+            if (r == 31 && orow < p.M) p.score[(size_t)blockIdx.x * p.M + orow] = v;
         }
     }
 }
 
-__global__ void fill_kernel(int n, const float* __restrict__ value, float* __restrict__ dst) {
+// y[m] = b3 + sum of the projection partials in slot order
+__global__ void score_sum_kernel(int n, int slots, const float* __restrict__ part, const float* __restrict__ b3,
+                                 float* __restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = value[0];
+    if (i >= n) return;
+    float v = b3[0];
+    for (int k = 0; k < slots; ++k) v += part[(size_t)k * n + i];
+    dst[i] = v;
 }
 
 // rows [0,D): mean_i |p_i - d_j| (start features, tracker.py:106 / rcnn.py:254);
@@ -356,20 +361,30 @@ static int check_mlp(const jm_mlp3_t* m, const char* who) {
     return JM_OK;
 }
 
+// projection partials of the last layer: one slot per 32 output columns of layer 2 (the single-wave kernel's tile; the
+// 128-column tiles use two slots each), summed in slot order by score_sum_kernel — no float atomics, bit-reproducible scores
+static int proj_slots(const jm_mlp3_t* mlp) { return divup(mlp->h2, 32); }
+static size_t hidden_bytes(size_t m, const jm_mlp3_t* mlp) {
+    return align_up(m * mlp->h1 * sizeof(float), 256) + align_up(m * proj_slots(mlp) * sizeof(float), 256);
+}
+static float* proj_part(float* hidden, size_t m, const jm_mlp3_t* mlp) {
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(hidden) + align_up(m * mlp->h1 * sizeof(float), 256));
+}
+
 struct MlpJob {
     int M;                 // rows
     const float* x;        // plain rows (M,C), or nullptr for pair rows
     const float *pf, *df;  // pair mode
     int D;
     const jm_mlp3_t* mlp;
-    float* hidden;         // (M,H1) scratch
+    float* hidden;         // hidden_bytes(M, mlp) of scratch: (M,H1) activations, then the projection partials
     float* y;              // (M) output
     int PD = 0;            // batched pair mode: P * D (see GemmParams)
 };
 
 static int tiles_of(int M, int N) { return divup(M, BM) * divup(N, BN); }
 
-// run the 3-layer MLP for up to two jobs: 1 launch per layer (grouped) + 1 fill launch
+// run the 3-layer MLP for up to two jobs: 1 launch per layer (grouped) + 1 launch per job summing the projection partials
 static int run_mlps(const MlpJob* jobs, int njobs, hipStream_t s) {
     GemmGroup g1{}, g2{};
     int t1 = 0, t2 = 0;
@@ -381,7 +396,7 @@ static int run_mlps(const MlpJob* jobs, int njobs, hipStream_t s) {
         a.W = jb.mlp->w1; a.bias = jb.mlp->b1; a.H = jb.hidden;
         GemmParams& b = g2.p[j];
         b.M = jb.M; b.N = jb.mlp->h2; b.K = jb.mlp->h1;
-        b.A = jb.hidden; b.pf = nullptr; b.W = jb.mlp->w2; b.bias = jb.mlp->b2; b.w3 = jb.mlp->w3; b.score = jb.y;
+        b.A = jb.hidden; b.pf = nullptr; b.W = jb.mlp->w2; b.bias = jb.mlp->b2; b.w3 = jb.mlp->w3; b.score = proj_part(jb.hidden, (size_t)jb.M, jb.mlp);
         if (j == 0) { g1.tiles0 = tiles_of(a.M, a.N); g2.tiles0 = tiles_of(b.M, b.N); }
         t1 += tiles_of(a.M, a.N);
         t2 += tiles_of(b.M, b.N);
@@ -391,8 +406,9 @@ static int run_mlps(const MlpJob* jobs, int njobs, hipStream_t s) {
         const GemmParams& a = g1.p[0];
         const GemmParams& b = g2.p[0];
         hipLaunchKernelGGL((mlp_gemm_small_kernel<0>), dim3(divup(a.N, 32), divup(a.M, 32)), dim3(64), 0, s, a);
-        hipLaunchKernelGGL(fill_kernel, dim3(divup(jobs[0].M, 256)), dim3(256), 0, s, jobs[0].M, jobs[0].mlp->b3, jobs[0].y);
         hipLaunchKernelGGL((mlp_gemm_small_kernel<1>), dim3(divup(b.N, 32), divup(b.M, 32)), dim3(64), 0, s, b);
+        hipLaunchKernelGGL(score_sum_kernel, dim3(divup(jobs[0].M, 256)), dim3(256), 0, s, jobs[0].M, divup(b.N, 32), b.score,
+                           jobs[0].mlp->b3, jobs[0].y);
         return check_launch("affinity mlp (small)");
     }
     static const int bk = tune_env("JM_GEMM_BK", 16);
@@ -405,10 +421,11 @@ static int run_mlps(const MlpJob* jobs, int njobs, hipStream_t s) {
         else hipLaunchKernelGGL((mlp_gemm_kernel<E, 16, false>), dim3(T), dim3(256), 0, s, G);                      \
     } while (0)
     JM_GEMM_LAUNCH(0, t1, g1);
-    for (int j = 0; j < njobs; ++j)
-        hipLaunchKernelGGL(fill_kernel, dim3(divup(jobs[j].M, 256)), dim3(256), 0, s, jobs[j].M, jobs[j].mlp->b3, jobs[j].y);
     JM_GEMM_LAUNCH(1, t2, g2);
 #undef JM_GEMM_LAUNCH
+    for (int j = 0; j < njobs; ++j)
+        hipLaunchKernelGGL(score_sum_kernel, dim3(divup(jobs[j].M, 256)), dim3(256), 0, s, jobs[j].M, 2 * divup(g2.p[j].N, BN),
+                           g2.p[j].score, jobs[j].mlp->b3, jobs[j].y);
     return check_launch("affinity mlp");
 }
 
@@ -435,7 +452,7 @@ extern "C" int jm_linear_rows(int m, int k, int n, const float* x, const float* 
 
 extern "C" size_t jm_mlp3_workspace_bytes(int m, const jm_mlp3_t* mlp) {
     if (m <= 0 || !mlp) return 0;
-    return align_up((size_t)m * mlp->h1 * sizeof(float), 256);
+    return hidden_bytes((size_t)m, mlp);
 }
 
 extern "C" int jm_mlp3_forward(int m, const float* x, const jm_mlp3_t* mlp, float* y, void* ws, size_t ws_bytes,
@@ -455,9 +472,9 @@ extern "C" int jm_mlp3_forward(int m, const float* x, const jm_mlp3_t* mlp, floa
 extern "C" size_t jm_affinity_workspace_bytes(int p, int d, const jm_mlp3_t* link, const jm_mlp3_t* se) {
     if (p <= 0 || d <= 0 || !link) return 0;
     const size_t pd = (size_t)p * d, r = (size_t)p + d;
-    size_t b = align_up(pd * link->h1 * sizeof(float), 256) + align_up(pd * sizeof(float), 256) +
+    size_t b = hidden_bytes(pd, link) + align_up(pd * sizeof(float), 256) +
                align_up(2 * r * sizeof(float), 256);
-    if (se) b += align_up(r * se->c * sizeof(float), 256) + align_up(r * se->h1 * sizeof(float), 256) +
+    if (se) b += align_up(r * se->c * sizeof(float), 256) + hidden_bytes(r, se) +
                  align_up(r * sizeof(float), 256);
     return b;
 }
@@ -468,7 +485,7 @@ extern "C" size_t jm_affinity_workspace_bytes(int p, int d, const jm_mlp3_t* lin
 extern "C" size_t jm_affinity_batched_workspace_bytes(int nb, int p, int d, const jm_mlp3_t* link) {
     if (nb <= 0 || p <= 0 || d <= 0 || !link) return 0;
     const size_t pd = (size_t)nb * p * d, r = (size_t)nb * ((size_t)p + d);
-    return align_up(pd * link->h1 * sizeof(float), 256) + align_up(pd * sizeof(float), 256) + align_up(2 * r * sizeof(float), 256);
+    return hidden_bytes(pd, link) + align_up(pd * sizeof(float), 256) + align_up(2 * r * sizeof(float), 256);
 }
 
 extern "C" int jm_affinity_forward_batched(int nb, int p, int d, const float* pred_feat, const float* det_feat,
@@ -486,7 +503,7 @@ extern "C" int jm_affinity_forward_batched(int nb, int p, int d, const float* pr
     hipStream_t s = (hipStream_t)stream;
     const size_t pd = (size_t)nb * p * d, r = (size_t)nb * ((size_t)p + d);
     char* w = (char*)ws;
-    float* hidden = (float*)w; w += align_up(pd * link->h1 * sizeof(float), 256);
+    float* hidden = (float*)w; w += hidden_bytes(pd, link);
     float* sraw = (float*)w;   w += align_up(pd * sizeof(float), 256);
     float* stats = (float*)w;
     float* S = link_raw ? link_raw : sraw;
@@ -517,7 +534,7 @@ extern "C" int jm_affinity_dual_softmax_batched(int nb, int p, int d, const floa
 extern "C" size_t jm_affinity_start_end_batched_workspace_bytes(int nb, int p, int d, const jm_mlp3_t* se) {
     if (nb <= 0 || p <= 0 || d <= 0 || !se) return 0;
     const size_t r = (size_t)nb * ((size_t)p + d);
-    return align_up(r * se->c * sizeof(float), 256) + align_up(r * se->h1 * sizeof(float), 256);
+    return align_up(r * se->c * sizeof(float), 256) + hidden_bytes(r, se);
 }
 
 /* se_out (nb, D + P): per problem [start logits (D) | end logits (P)] */
@@ -547,7 +564,7 @@ extern "C" int jm_affinity_start_end_batched(int nb, int p, int d, const float* 
 extern "C" size_t jm_affinity_start_end_workspace_bytes(int p, int d, const jm_mlp3_t* se) {
     if (p <= 0 || d <= 0 || !se) return 0;
     const size_t r = (size_t)p + d;
-    return align_up(r * se->c * sizeof(float), 256) + align_up(r * se->h1 * sizeof(float), 256) + align_up(r * sizeof(float), 256);
+    return align_up(r * se->c * sizeof(float), 256) + hidden_bytes(r, se) + align_up(r * sizeof(float), 256);
 }
 
 extern "C" int jm_affinity_start_end(int p, int d, const float* pred_feat, const float* det_feat, const jm_mlp3_t* se,
@@ -564,7 +581,7 @@ extern "C" int jm_affinity_start_end(int p, int d, const float* pred_feat, const
     const size_t r = (size_t)p + d;
     char* w = (char*)ws;
     float* feat = (float*)w;    w += align_up(r * se->c * sizeof(float), 256);
-    float* sehid = (float*)w;   w += align_up(r * se->h1 * sizeof(float), 256);
+    float* sehid = (float*)w;   w += hidden_bytes(r, se);
     float* logit = (float*)w;
     const bool contiguous_out = (end == start + d);   // caller gave one (D+P) buffer: write logits in place
     hipLaunchKernelGGL(se_feature_kernel, dim3((unsigned)r), dim3(256), 0, s, p, d, se->c, pred_feat, det_feat, feat);
@@ -596,7 +613,7 @@ extern "C" int jm_affinity_forward(int p, int d, const float* pred_feat, const f
     hipStream_t s = (hipStream_t)stream;
     const size_t pd = (size_t)p * d, r = (size_t)p + d;
     char* w = (char*)ws;
-    float* hidden = (float*)w; w += align_up(pd * link->h1 * sizeof(float), 256);
+    float* hidden = (float*)w; w += hidden_bytes(pd, link);
     float* sraw = (float*)w;   w += align_up(pd * sizeof(float), 256);
     float* stats = (float*)w;  w += align_up(2 * r * sizeof(float), 256);
     float* S = link_raw ? link_raw : sraw;

@@ -336,6 +336,13 @@ def test_pairwise_affinity_batched_matches_per_problem(oracle, nb, P, D, C):
             oA, os_, oe = oracle.affinity(pf[b].cpu().numpy(), df[b].cpu().numpy(), w(link), w(se))
             assert np.abs(A[b].cpu().numpy() - oA).max() < 1e-4 and np.abs(s[b].cpu().numpy() - os_).max() < 1e-4
             assert np.abs(e[b].cpu().numpy() - oe).max() < 1e-4
+    # bit-reproducible: the projection partials are summed in slot order (no float atomics)
+    for _ in range(3):
+        A2, s2, e2, raw2 = pairwise_affinity_batched(pf, df, link, se, return_raw=True)
+        assert torch.equal(raw2, raw) and torch.equal(A2, A) and torch.equal(s2, s) and torch.equal(e2, e)
+    A3, s3, e3, raw3 = pairwise_affinity(pf[0], df[0], link, se, return_raw=True)
+    A4, s4, e4, raw4 = pairwise_affinity(pf[0], df[0], link, se, return_raw=True)
+    assert torch.equal(raw3, raw4) and torch.equal(A3, A4) and torch.equal(s3, s4) and torch.equal(e3, e4)
 
 
 # ------------------------------------------------------------------ EXPERIMENTAL split-bf16 affinity (csrc/affinity_x3.hip)
