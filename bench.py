@@ -628,6 +628,7 @@ def main():
     timed_rows = prof.summary(args.steps, HBM_PEAK_GBS, MFMA_F32_PEAK_TF)
     table_steps = args.steps
     bq_evals = {}
+    nms_evals = (0, 0, 0)
     if dom_key:                                   # the per-entry table: fully instrumented steps, outside `value`
         from jmodt_amd.ops.pointnet2 import pointnet2_utils as _pu
         table_steps = max(1, min(5, args.steps))
@@ -635,6 +636,8 @@ def main():
         prof.only = None
         prof.enabled = True
         _pu.BQ_EVALS.clear()
+        from jmodt_amd.ops import proposal as _pp
+        _pp.NMS_EVALS.clear()
         t1 = time.perf_counter()
         for _ in range(table_steps):
             step()
@@ -642,6 +645,7 @@ def main():
         table_ms = (time.perf_counter() - t1) / table_steps * 1e3
         prof.enabled = False
         bq_evals = _pu.ball_query_evals()          # distance evaluations the grid searches really did (device counters)
+        nms_evals = _pp.nms_evals()                # IoU evaluations of the RPN's lazy first-K NMS vs its full pair masks
         if dist is not None:
             dist.barrier()
 
@@ -732,6 +736,10 @@ def main():
         # the hash-grid ball queries: evaluations actually done (per step) next to the n * m of the scan they replace
         for k in kernels:
             scope = k["kernel"].rsplit("/", 1)[0] + "/ball_query" if "/" in k["kernel"] else "ball_query"
+            if k["kernel"].endswith("proposal_select") and nms_evals[2]:
+                k["iou_evals_per_step"] = int(nms_evals[0] / table_steps)
+                k["pair_mask_evals_per_step"] = int(nms_evals[1] / table_steps)
+                k["evals_vs_pair_mask"] = round(nms_evals[0] / max(nms_evals[1], 1), 6)
             if "ball_query" in k["kernel"] and scope in bq_evals and k["ms_per_step"] > 0:
                 ev = bq_evals[scope][0] / table_steps
                 k["evals_per_step"] = int(ev)

@@ -224,6 +224,13 @@ int jm_nms(int boxes_num, const float* boxes, float nms_overlap_thresh, int norm
 int jm_nms_batched(int num_problems, int max_boxes, const int* counts, const float* boxes,
                    float nms_overlap_thresh, int normal, int64_t* keep, int* num_keep, void* ws, size_t ws_bytes,
                    jm_stream_t stream);
+/* The first `first_k` entries of jm_nms_batched's keep lists with the axis-aligned IoU (nms_normal_gpu), without the pair
+ * mask: callers that truncate the keep list (proposal_layer.py:103-117 `keep_idx[:post_nms_top_n]`) only need each box's
+ * IoU with the boxes KEPT before it.  keep (P, max_boxes) int64 — entries [0, num_keep[p]) are written —, num_keep (P)
+ * int32 = min(first_k, survivors); first_k <= 2048; no workspace.  Bit-identical to the truncated jm_nms_batched result. */
+int jm_nms_normal_first_k_batched(int num_problems, int max_boxes, const int* counts, const float* boxes,
+                                  float nms_overlap_thresh, int first_k, int64_t* keep, int* num_keep,
+                                  jm_stream_t stream);
 /* RPN proposal selection for a whole batch (ProposalLayer.forward after the decode,
  * proposal_layer.py:34-144): scores (B,N), proposals (B,N,7) [x, y_bottom, z, h, w, l, ry], order (B,N) =
  * indices of the scores in descending order.  distance_based != 0: depth bands (0,40] / (40,80] with the
@@ -231,6 +238,9 @@ int jm_nms_batched(int num_problems, int max_boxes, const int* counts, const flo
  * distance_based == 0: one problem per frame (:119-144; the reference uses rotated NMS there).
  * out_boxes (B, post_nms_top_n, 7), out_scores (B, post_nms_top_n), zero padded.  No host round trip. */
 size_t jm_proposal_select_workspace_bytes(int b, int distance_based, int pre_nms_top_n);
+/* byte offset inside that workspace of (K * b) uint64 counters: IoU evaluations the lazy NMS of the last jm_proposal_select
+ * call did per (frame, band) problem (the pair mask would do pre^2 / 2) */
+size_t jm_proposal_select_evals_offset(int b, int distance_based, int pre_nms_top_n);
 int jm_proposal_select(int b, int n, const float* scores, const float* proposals, const int64_t* order,
                        int distance_based, int pre_nms_top_n, int post_nms_top_n, float nms_thresh, int nms_normal,
                        float* out_boxes, float* out_scores, void* ws, size_t ws_bytes, jm_stream_t stream);

@@ -75,7 +75,9 @@ SIGNATURES = {
     "jm_nms_workspace_bytes": (_Z, [_I]),
     "jm_nms": (_I, [_I, _P, _F, _I, _P, _P, _P, _Z, _P]),
     "jm_nms_batched": (_I, [_I, _I, _P, _P, _F, _I, _P, _P, _P, _Z, _P]),
+    "jm_nms_normal_first_k_batched": (_I, [_I, _I, _P, _P, _F, _I, _P, _P, _P]),
     "jm_proposal_select_workspace_bytes": (_Z, [_I, _I, _I]),
+    "jm_proposal_select_evals_offset": (_Z, [_I, _I, _I]),
     "jm_proposal_select": (_I, [_I, _I, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _Z, _P]),
     "jm_decode_rpn_proposals": (_I, [ctypes.c_longlong, _I, _P, _P, _F, _F, _I, ctypes.POINTER(_F), _I, _P, _P]),
     "jm_decode_rcnn_boxes": (_I, [ctypes.c_longlong, _I, _P, _P, _F, _F, _I, ctypes.POINTER(_F), _I, _P, _P]),

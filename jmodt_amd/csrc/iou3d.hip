@@ -409,6 +409,100 @@ nms_reduce_kernel(int nmax, const int* __restrict__ counts, int stride_cb,
     if (tid == 0) *num_keep = count;
 }
 
+// ------------------------------------------------------------------ NMS, first K survivors only (axis-aligned IoU)
+// The RPN keeps at most post_nms_top_n boxes per depth band (proposal_layer.py:103-117: `keep_idx[:post_nms]`), i.e. only the
+// FIRST K entries of the keep list are ever read — and the greedy rule (iou3d.cpp:98-114: box i survives iff no KEPT box
+// before it overlaps it by more than the threshold) needs, for box i, its IoU with the kept boxes only.  So instead of the
+// n^2/2 pair mask (19.8 M evaluations for 6300 boxes) + reduce, one workgroup per problem walks the score order in chunks:
+//   phase A (all waves)      every candidate of the chunk against the boxes kept before the chunk (LDS broadcast reads);
+//   phase B (wave by wave)   the candidates that are still alive against the boxes kept earlier IN this chunk, then the wave
+//                            resolves its own 64 in order: lowest alive lane is kept, published to LDS, the rest test
+//                            against it (one ~300-cycle step per KEPT box, <= K of them in total);
+// and stops at K survivors.  Evaluations: <= n * K (560 k at n = 6300, K = 89), typically a few thousand.  The IoU is
+// nms_mask_kernel's own expression with the same operand order (kept box first), so the keep list is the first K entries of
+// the mask + reduce result bit for bit (tests/test_gpu_parity.py::test_nms_first_k_*).
+constexpr int NFK_W = 8, NFK_T = NFK_W * 64, NFK_CAP = 2048;
+
+__global__ void __launch_bounds__(NFK_T)
+nms_first_k_kernel(int nmax, const int* __restrict__ counts, float thresh, const float* __restrict__ boxes_all, int group,
+                   int cap0, int cap1, long long* __restrict__ keep_all, int* __restrict__ num_keep_all,
+                   unsigned long long* __restrict__ evals_all) {
+    __shared__ float4 kb[NFK_CAP];        // x1, y1, x2, y2 of the kept boxes (iou_normal ignores ry)
+    __shared__ int nk_hist[NFK_W + 1];    // kept count after wave w's turn (slot w + 1); one slot per turn: no reuse race
+    const int prob = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = counts ? min(counts[prob], nmax) : nmax;
+    const int cap = min(min((prob % group) ? cap1 : cap0, n), NFK_CAP);
+    const float* boxes = boxes_all + (size_t)prob * nmax * 5;
+    long long* keep = keep_all + (size_t)prob * nmax;
+    unsigned int tests = 0;
+    int nk = 0;   // uniform
+    if (n > 0 && cap > 0) {
+        for (int base = 0; base < n; base += NFK_T) {
+            const int c = base + tid;
+            const float* src = boxes + (size_t)min(c, n - 1) * 5;
+            const float me[4] = {src[0], src[1], src[2], src[3]};
+            bool alive = c < n;
+            const int K0 = nk;
+            for (int k = 0; k < K0; ++k) {                                   // phase A
+                if (__ballot(alive) == 0ULL) break;
+                const float4 q4 = kb[k];
+                const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+                tests += alive ? 1u : 0u;
+                if (alive && iou_normal(q, me) > thresh) alive = false;
+            }
+            for (int w = 0; w < NFK_W; ++w) {                                // phase B
+                if (wave == w) {
+                    int cur = w == 0 ? K0 : nk_hist[w];
+                    for (int k = K0; k < cur; ++k) {
+                        if (__ballot(alive) == 0ULL) break;
+                        const float4 q4 = kb[k];
+                        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+                        tests += alive ? 1u : 0u;
+                        if (alive && iou_normal(q, me) > thresh) alive = false;
+                    }
+                    unsigned long long am = __ballot(alive);
+                    while (am != 0ULL && cur < cap) {
+                        const int j = (int)__ffsll((long long)am) - 1;
+                        am &= am - 1ULL;
+                        if (lane == j) {
+                            kb[cur] = make_float4(me[0], me[1], me[2], me[3]);
+                            keep[cur] = c;
+                        }
+                        const float4 q4 = kb[cur];                           // same wave: LDS executes in order
+                        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+                        const bool mine = (am >> lane) & 1ULL;
+                        tests += mine ? 1u : 0u;
+                        am &= ~__ballot(mine && iou_normal(q, me) > thresh);
+                        ++cur;
+                    }
+                    if (lane == 0) nk_hist[w + 1] = cur;
+                }
+                __syncthreads();
+                nk = nk_hist[w + 1];
+                if (nk >= cap) break;                                        // uniform
+            }
+            if (nk >= cap) break;
+        }
+    }
+    if (tid == 0) num_keep_all[prob] = nk;
+    if (evals_all) {
+        const unsigned long long tot = (unsigned long long)wave_sum_u32(tests);
+        if (lane == 0 && tot) atomicAdd(evals_all + prob, tot);
+    }
+}
+
+int launch_nms_first_k(int nprob, int nmax, const int* counts, const float* boxes, float thresh, int group, int cap0, int cap1,
+                       int64_t* keep, int* num_keep, unsigned long long* evals, hipStream_t s) {
+    JM_REQUIRE(group >= 1 && cap0 >= 0 && cap1 >= 0 && cap0 <= NFK_CAP && cap1 <= NFK_CAP,
+               "nms_first_k: at most %d survivors per problem", NFK_CAP);
+    if (evals) (void)hipMemsetAsync(evals, 0, sizeof(unsigned long long) * nprob, s);
+    hipLaunchKernelGGL(nms_first_k_kernel, dim3(nprob), dim3(NFK_T), 0, s, nmax, counts, thresh, boxes, group, cap0, cap1,
+                       (long long*)keep, num_keep, evals);
+    return check_launch("nms_first_k");
+}
+int nms_first_k_capacity() { return NFK_CAP; }
+
 }  // namespace jm
 
 using namespace jm;
@@ -555,6 +649,22 @@ int launch_nms_batched(int nprob, int nmax, const int* counts, const float* boxe
     return launch_nms_reduce(nprob, nmax, counts, (const unsigned long long*)mask_ws, keep, num_keep, s);
 }
 }  // namespace jm
+
+extern "C" int jm_nms_normal_first_k_batched(int num_problems, int max_boxes, const int* counts, const float* boxes,
+                                            float nms_overlap_thresh, int first_k, int64_t* keep, int* num_keep,
+                                            jm_stream_t stream) {
+    JM_REQUIRE(num_problems >= 0 && max_boxes >= 0 && first_k >= 0, "nms_normal_first_k: bad sizes");
+    if (num_problems == 0) return JM_OK;
+    JM_REQUIRE(num_keep, "nms_normal_first_k: null num_keep");
+    if (max_boxes == 0 || first_k == 0) {
+        (void)hipMemsetAsync(num_keep, 0, sizeof(int) * num_problems, (hipStream_t)stream);
+        return check_launch("nms_normal_first_k(memset)");
+    }
+    JM_REQUIRE(boxes && keep, "nms_normal_first_k: null pointer");
+    JM_REQUIRE(num_problems <= 65535 * 32768, "nms_normal_first_k: too many problems");
+    return launch_nms_first_k(num_problems, max_boxes, counts, boxes, nms_overlap_thresh, 1, first_k, first_k, keep, num_keep,
+                              nullptr, (hipStream_t)stream);
+}
 
 extern "C" int jm_nms_batched(int num_problems, int max_boxes, const int* counts, const float* boxes,
                               float nms_overlap_thresh, int normal, int64_t* keep, int* num_keep, void* ws,

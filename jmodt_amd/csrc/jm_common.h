@@ -114,6 +114,25 @@ __device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
         : "+v"(v));
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+// integer sum over the 64 lanes (same DPP pattern), wave-uniform result
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
     const unsigned lo = wave_or_u32((unsigned)v), hi = wave_or_u32((unsigned)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;

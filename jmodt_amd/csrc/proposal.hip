@@ -8,7 +8,9 @@
 //   proposal_compact_kernel  one workgroup per frame: walks the score order once, ranks the members of
 //                            each band with wave ballots + prefix popcounts, writes the BEV boxes of the
 //                            selected ones straight into the padded NMS problem buffers
-//   nms_mask / nms_reduce    (iou3d.hip) all 2 B problems at once, counts read on the device
+//   nms_first_k              (iou3d.hip) all 2 B problems at once, counts read on the device; only the first post-NMS-budget
+//                            survivors of a band are ever used, so the greedy rule is evaluated lazily against the kept
+//                            boxes only (axis-aligned IoU; the rotated form keeps the full mask + reduce)
 //   proposal_stitch_kernel   kept boxes of band 0 then band 1, post budgets, zero padding
 #include "jm_common.h"
 #include "../../include/jm_detmath.h"
@@ -17,6 +19,9 @@ namespace jm {
 
 int launch_nms_batched(int nprob, int nmax, const int* counts, const float* boxes, float thresh, int normal,
                        int64_t* keep, int* num_keep, void* mask_ws, hipStream_t s);   // iou3d.hip
+int launch_nms_first_k(int nprob, int nmax, const int* counts, const float* boxes, float thresh, int group, int cap0, int cap1,
+                       int64_t* keep, int* num_keep, unsigned long long* evals, hipStream_t s);   // iou3d.hip
+int nms_first_k_capacity();
 
 constexpr int PC_T = 1024, PC_W = PC_T / 64;
 
@@ -130,7 +135,8 @@ __global__ void proposal_stitch_kernel(int n, int K, int pmax, int post1, int po
 }
 
 struct ProposalWs {
-    float* bev; int* src; int* counts; int64_t* keep; int* num_keep; void* mask; size_t total;
+    float* bev; int* src; int* counts; int64_t* keep; int* num_keep; unsigned long long* evals; void* mask; size_t total;
+    size_t evals_off;
 };
 
 static ProposalWs carve(void* ws, int b, int K, int pmax) {
@@ -143,6 +149,8 @@ static ProposalWs carve(void* ws, int b, int K, int pmax) {
     w.counts = (int*)take(P * sizeof(int));
     w.keep = (int64_t*)take(P * pmax * sizeof(int64_t));
     w.num_keep = (int*)take(P * sizeof(int));
+    w.evals_off = off;
+    w.evals = (unsigned long long*)take(P * sizeof(unsigned long long));   // IoU evaluations of the lazy NMS, per problem
     w.mask = take(P * jm_nms_workspace_bytes(pmax));
     w.total = off;
     return w;
@@ -158,6 +166,14 @@ extern "C" size_t jm_proposal_select_workspace_bytes(int b, int distance_based, 
     const int pre2 = distance_based ? pre_nms_top_n - pre1 : 0;
     const int pmax = pre1 > pre2 ? pre1 : pre2;
     return carve(nullptr, b, distance_based ? 2 : 1, pmax < 1 ? 1 : pmax).total;
+}
+
+extern "C" size_t jm_proposal_select_evals_offset(int b, int distance_based, int pre_nms_top_n) {
+    if (b < 1 || pre_nms_top_n < 1) return 0;
+    const int pre1 = distance_based ? (int)(pre_nms_top_n * 0.7) : pre_nms_top_n;
+    const int pre2 = distance_based ? pre_nms_top_n - pre1 : 0;
+    const int pmax = pre1 > pre2 ? pre1 : pre2;
+    return carve(nullptr, b, distance_based ? 2 : 1, pmax < 1 ? 1 : pmax).evals_off;
 }
 
 extern "C" int jm_proposal_select(int b, int n, const float* scores, const float* proposals, const int64_t* order,
@@ -184,7 +200,10 @@ extern "C" int jm_proposal_select(int b, int n, const float* scores, const float
                        40.0f, 80.0f, pmax, proposals, (const long long*)order, w.bev, w.src, w.counts);
     int rc = check_launch("proposal_compact");
     if (rc) return rc;
-    rc = launch_nms_batched(b * K, pmax, w.counts, w.bev, nms_thresh, nms_normal, w.keep, w.num_keep, w.mask, s);
+    if (nms_normal && post1 <= nms_first_k_capacity() && post2 <= nms_first_k_capacity())
+        rc = launch_nms_first_k(b * K, pmax, w.counts, w.bev, nms_thresh, K, post1, post2, w.keep, w.num_keep, w.evals, s);
+    else
+        rc = launch_nms_batched(b * K, pmax, w.counts, w.bev, nms_thresh, nms_normal, w.keep, w.num_keep, w.mask, s);
     if (rc) return rc;
     const int post = post1 + post2;
     hipLaunchKernelGGL(proposal_stitch_kernel, dim3(divup(post, 128), b), dim3(128), 0, s, n, K, pmax, post1, post2, scores,

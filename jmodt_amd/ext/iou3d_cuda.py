@@ -55,6 +55,20 @@ def nms_batched_device(boxes, counts, thresh, normal):
     return keep, num[:nprob]
 
 
+def nms_normal_first_k_device(boxes, counts, thresh, first_k):
+    """the first `first_k` survivors of P axis-aligned NMS problems without the pair mask (jm_nms_normal_first_k_batched):
+    boxes (P, Nmax, 5) score-sorted per problem, counts (P) int32 device -> keep (P, Nmax) int64 (first num_keep[p] entries
+    valid), num_keep (P) int32 = min(first_k, survivors); nothing syncs, no workspace."""
+    lib = L.load()
+    nprob, nmax = boxes.size(0), boxes.size(1)
+    keep = torch.empty((nprob, max(nmax, 1)), dtype=torch.int64, device=boxes.device)
+    num = torch.empty((max(nprob, 1),), dtype=torch.int32, device=boxes.device)
+    L.check(lib.jm_nms_normal_first_k_batched(nprob, nmax, L.dev(counts, torch.int32, "counts"), L.dev(boxes, f32, "boxes"),
+                                              float(thresh), int(first_k), ctypes.c_void_p(keep.data_ptr()),
+                                              ctypes.c_void_p(num.data_ptr()), L.stream_ptr()), "nms_normal_first_k_batched")
+    return keep, num[:nprob]
+
+
 def _nms_to_cpu_keep(boxes, keep, thresh, normal):
     if keep.is_cuda or keep.dtype != torch.int64 or not keep.is_contiguous():
         raise RuntimeError("keep must be a contiguous CPU int64 tensor (iou3d.cpp:76-82)")

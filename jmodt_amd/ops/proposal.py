@@ -27,6 +27,22 @@ from .. import _lib as L
 _f32 = torch.float32
 
 
+NMS_EVALS = []    # (workspace, counter offset, problems, pre-NMS pair count of the full mask) while the profiler is on
+
+
+def nms_evals():
+    """(IoU evaluations the lazy first-K NMS did, evaluations of the full pair masks, calls) of the recorded
+    jm_proposal_select calls; clears the record (synchronises)"""
+    torch.cuda.synchronize()
+    done = full = 0
+    for ws, off, nprob, tri in NMS_EVALS:
+        done += int(ws[off:off + 8 * nprob].view(torch.int64).sum().item())
+        full += tri
+    calls = len(NMS_EVALS)
+    NMS_EVALS.clear()
+    return done, full, calls
+
+
 def _select(scores, proposals, distance_based, pre, post, thresh, normal):
     lib = L.load()
     B, N = scores.shape
@@ -44,6 +60,12 @@ def _select(scores, proposals, distance_based, pre, post, thresh, normal):
                                    float(thresh), int(normal), ctypes.c_void_p(out_boxes.data_ptr()),
                                    ctypes.c_void_p(out_scores.data_ptr()), ctypes.c_void_p(base), ws_bytes,
                                    L.stream_ptr()), "proposal_select")
+    from ..profile import prof
+    if prof.enabled and prof.only is None and normal:
+        off = base - ws.data_ptr() + lib.jm_proposal_select_evals_offset(B, int(distance_based), pre)
+        pre1 = int(pre * 0.7) if distance_based else pre
+        tri = B * (pre1 * (pre1 - 1) // 2 + (pre - pre1) * (pre - pre1 - 1) // 2)      # upper bound: bands filled to their budgets
+        NMS_EVALS.append((ws, off, B * (2 if distance_based else 1), tri))
     return out_boxes, out_scores
 
 

@@ -697,6 +697,42 @@ def test_nms_batched_matches_single_problem_oracle(oracle, normal):
         assert np.array_equal(keep[p, :num[p]], want), p
 
 
+@pytest.mark.parametrize("first_k", [1, 39, 89, 512, 2048])
+@pytest.mark.parametrize("kind,thresh", [("clustered", 0.6), ("clustered", 0.85), ("piled", 0.3), ("sparse", 0.8)])
+def test_nms_first_k_equals_truncated_mask_reduce(oracle, kind, thresh, first_k):
+    """jm_nms_normal_first_k_batched (lazy greedy: each box against the boxes KEPT before it, stops at K) == the first K
+    entries of jm_nms_batched's keep lists, ragged problems incl. empty / 1 / chunk-boundary sizes / 6300 boxes;
+    `piled`: hundreds of near-copies per object (a handful of survivors out of thousands: the walk visits every box)"""
+    from jmodt_amd.ext import iou3d_cuda
+    counts = [6300, 0, 1, 64, 65, 512, 513, 2700, 1025]
+    nmax = 6300
+    boxes = np.zeros((len(counts), nmax, 5), np.float32)
+    rng = np.random.default_rng(int(thresh * 100) + first_k)
+    for p, c in enumerate(counts):
+        if kind == "clustered":
+            b, s = synth.bev_boxes(max(c, 1), 70 + p)
+        elif kind == "piled":
+            b, s = synth.bev_boxes(max(c, 1), 80 + p, jitter_clusters=False)
+            b[:, :4] += rng.normal(0, 0.05, (len(b), 1)).astype(np.float32)
+            b = b[rng.integers(0, max(1, len(b) // 40), len(b))] + rng.normal(0, 0.02, (len(b), 5)).astype(np.float32)
+        else:
+            b, s = synth.bev_boxes(max(c, 1), 90 + p, extent=2000.0)
+        boxes[p, :c] = b[np.argsort(-s, kind="stable")][:c]
+        boxes[p, c:] = np.nan
+    tb, tc = T(boxes), T(np.array(counts, np.int32))
+    full_keep, full_num = iou3d_cuda.nms_batched_device(tb, tc, thresh, 1)
+    keep, num = iou3d_cuda.nms_normal_first_k_device(tb, tc, thresh, first_k)
+    full_keep, full_num, keep, num = (a.cpu().numpy() for a in (full_keep, full_num, keep, num))
+    for p, c in enumerate(counts):
+        k = min(first_k, int(full_num[p]))
+        assert num[p] == k, (p, num[p], k)
+        assert np.array_equal(keep[p, :k], full_keep[p, :k]), p
+    if first_k == 89:      # the oracle itself on the small problems
+        for p in (2, 3, 4, 5, 6):
+            want = oracle.nms_sorted(boxes[p, :counts[p]], thresh, 1)[:first_k]
+            assert np.array_equal(keep[p, :num[p]], want)
+
+
 @pytest.mark.parametrize("B,N,pre,post,thresh,nms_type,kw", [
     (4, 16384, 9000, 100, 0.8, "normal", dict(empty_far=(1,), empty_near=(2,))),   # TEST config (config.py:226-230)
     (2, 16384, 9000, 512, 0.85, "normal", {}),                                    # TRAIN config (config.py:201-205)
