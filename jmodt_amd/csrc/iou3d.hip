@@ -444,23 +444,34 @@ nms_first_k_kernel(int nmax, const int* __restrict__ counts, float thresh, const
             const float me[4] = {src[0], src[1], src[2], src[3]};
             bool alive = c < n;
             const int K0 = nk;
-            for (int k = 0; k < K0; ++k) {                                   // phase A
-                if (__ballot(alive) == 0ULL) break;
-                const float4 q4 = kb[k];
-                const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-                tests += alive ? 1u : 0u;
-                if (alive && iou_normal(q, me) > thresh) alive = false;
-            }
+            // candidate `me` against kept boxes [k0, k1): four per step with independent IoUs (a single wave has nothing else to
+            // hide the dependent-issue latency with), one wave-wide "anyone left?" check per step
+            auto pretest = [&](int k0, int k1) {
+                int k = k0;
+                for (; k + 4 <= k1; k += 4) {
+                    if (__ballot(alive) == 0ULL) return;
+                    bool hit = false;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float4 q4 = kb[k + u];
+                        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+                        hit |= iou_normal(q, me) > thresh;
+                    }
+                    tests += alive ? 4u : 0u;
+                    alive = alive && !hit;
+                }
+                for (; k < k1; ++k) {
+                    const float4 q4 = kb[k];
+                    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+                    tests += alive ? 1u : 0u;
+                    alive = alive && !(iou_normal(q, me) > thresh);
+                }
+            };
+            pretest(0, K0);                                                  // phase A
             for (int w = 0; w < NFK_W; ++w) {                                // phase B
                 if (wave == w) {
                     int cur = w == 0 ? K0 : nk_hist[w];
-                    for (int k = K0; k < cur; ++k) {
-                        if (__ballot(alive) == 0ULL) break;
-                        const float4 q4 = kb[k];
-                        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-                        tests += alive ? 1u : 0u;
-                        if (alive && iou_normal(q, me) > thresh) alive = false;
-                    }
+                    pretest(K0, cur);
                     unsigned long long am = __ballot(alive);
                     while (am != 0ULL && cur < cap) {
                         const int j = (int)__ffsll((long long)am) - 1;
@@ -469,8 +480,11 @@ nms_first_k_kernel(int nmax, const int* __restrict__ counts, float thresh, const
                             kb[cur] = make_float4(me[0], me[1], me[2], me[3]);
                             keep[cur] = c;
                         }
-                        const float4 q4 = kb[cur];                           // same wave: LDS executes in order
-                        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+                        // box j to every lane through the scalar registers (v_readlane with a uniform index): no LDS round trip
+                        const float q[4] = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(me[0]), j)),
+                                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(me[1]), j)),
+                                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(me[2]), j)),
+                                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(me[3]), j))};
                         const bool mine = (am >> lane) & 1ULL;
                         tests += mine ? 1u : 0u;
                         am &= ~__ballot(mine && iou_normal(q, me) > thresh);

@@ -200,7 +200,9 @@ extern "C" int jm_proposal_select(int b, int n, const float* scores, const float
                        40.0f, 80.0f, pmax, proposals, (const long long*)order, w.bev, w.src, w.counts);
     int rc = check_launch("proposal_compact");
     if (rc) return rc;
-    if (nms_normal && post1 <= nms_first_k_capacity() && post2 <= nms_first_k_capacity())
+    // measured (tools/nms_first_k_bench.py, 16 problems of 6300 / 2700 boxes): budgets of 89 -> 25-95 us, 358 -> 65-335 us
+    // across many-/few-survivor box clouds, against 322-343 us for the pair mask + reduce; beyond ~500 the n * K walk loses
+    if (nms_normal && post1 <= 512 && post2 <= 512 && post1 <= nms_first_k_capacity() && post2 <= nms_first_k_capacity())
         rc = launch_nms_first_k(b * K, pmax, w.counts, w.bev, nms_thresh, K, post1, post2, w.keep, w.num_keep, w.evals, s);
     else
         rc = launch_nms_batched(b * K, pmax, w.counts, w.bev, nms_thresh, nms_normal, w.keep, w.num_keep, w.mask, s);
