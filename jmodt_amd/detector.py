@@ -694,7 +694,7 @@ class DetectAffinityEngine(nn.Module):
         return pooled.view(B * M, S, 5 + C)
 
     @torch.no_grad()
-    def rcnn_forward(self, pts_input: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def rcnn_forward(self, pts_input: torch.Tensor, heads: bool = True) -> Dict[str, torch.Tensor]:
         """RCNN.forward in EVAL mode (rcnn.py:158-202,288-289): pts_input (R, S, 5 + C) ->
         rcnn_cls (R, 1), rcnn_reg (R, 46), rcnn_feat (R, 512, 1)"""
         net = self.rcnn_net
@@ -777,14 +777,24 @@ class DetectAffinityEngine(nn.Module):
                 continue
             with prof.scope(f"rcnn_sa{i + 1}"):
                 l_xyz, l_feats, _ = sa(l_xyz, l_feats)
+        out = dict(rcnn_feat=l_feats)
+        if heads:
+            out.update(self.rcnn_heads(l_feats))
+        return out
+
+    @torch.no_grad()
+    def rcnn_heads(self, l_feats: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """classification / regression heads on the RoI features (rcnn.py:186-200).  Only the detections consume them — the
+        affinity head takes the features themselves — so `forward` runs them on the detections' side stream"""
+        net = self.rcnn_net
         rcnn_cls, rcnn_reg = self._t("rcnn_heads(span)", 0, lambda: (
             self._head_forward("rcnn_cls", net.cls_layer, l_feats).squeeze(-1),
             self._head_forward("rcnn_reg", net.reg_layer, l_feats).squeeze(-1)))
-        return dict(rcnn_cls=rcnn_cls, rcnn_reg=rcnn_reg, rcnn_feat=l_feats)
+        return dict(rcnn_cls=rcnn_cls, rcnn_reg=rcnn_reg)
 
     # -- the whole path ----------------------------------------------------------------------------------
     @torch.no_grad()
-    def _trunk(self, xyz, image, pts_xy, next_xyz=None, next_image=None):
+    def _trunk(self, xyz, image, pts_xy, next_xyz=None, next_image=None, heads: bool = True):
         rpn_out = self.rpn_forward(xyz, image, pts_xy, next_xyz, next_image)
         pf = None
         if self.overlap and xyz.is_cuda:
@@ -801,7 +811,7 @@ class DetectAffinityEngine(nn.Module):
         if pf is not None:
             main.wait_stream(side)
         pts_input = self.roi_pool(rpn_out, rois, pf)
-        out = self.rcnn_forward(pts_input)
+        out = self.rcnn_forward(pts_input, heads=heads)
         return rpn_out, rois, roi_scores, pts_input, out
 
     @torch.no_grad()
@@ -828,18 +838,21 @@ class DetectAffinityEngine(nn.Module):
         """detect + affinity of every frame against its predecessor in the batch (frame 0 against the last):
         returns (DetectionCache, [(A (M, M), start (M), end (M)) per frame]) with all M RoI slots as the
         affinity operands (fixed work per frame: P = D = M)."""
-        rpn_out, rois, roi_scores, pts_input, out = self._trunk(xyz, image, pts_xy, next_xyz, next_image)
+        overlap = self.overlap and xyz.is_cuda
+        rpn_out, rois, roi_scores, pts_input, out = self._trunk(xyz, image, pts_xy, next_xyz, next_image, heads=not overlap)
         B, M = rois.shape[:2]
         dev = rois.device
         main = torch.cuda.current_stream(dev) if rois.is_cuda else None
-        # box decode + score filter + per-frame NMS + gathers (two dozen latency-bound launches) do not feed the affinity
-        # head (it takes all M RoI slots): they run on a side stream under the affinity GEMMs
-        side = side_stream(dev, 3) if (self.overlap and rois.is_cuda) else None
+        # the RCNN's classification / regression heads, box decode + score filter + per-frame NMS + gathers (two dozen
+        # latency-bound launches) do not feed the affinity head (it takes the features of all M RoI slots): they run on a side
+        # stream under the affinity GEMMs
+        side = side_stream(dev, 3) if overlap else None
         if side is not None:
             side.wait_stream(main)
-            for t in (rois, out["rcnn_reg"], out["rcnn_cls"], out["rcnn_feat"]):
+            for t in (rois, out["rcnn_feat"]):
                 t.record_stream(side)
             with torch.cuda.stream(side):
+                out.update(self.rcnn_heads(out["rcnn_feat"]))
                 cache, boxes = self._detections(rois, out)
         else:
             cache, boxes = self._detections(rois, out)
@@ -852,7 +865,8 @@ class DetectAffinityEngine(nn.Module):
             aff = [(A[b], start[b], end[b]) for b in range(B)]
         if side is not None:
             main.wait_stream(side)
-            for t in (boxes, cache.boxes, cache.scores, cache.raw_scores, cache.feats, cache.count, cache.roi_index):
+            for t in (boxes, cache.boxes, cache.scores, cache.raw_scores, cache.feats, cache.count, cache.roi_index,
+                      out["rcnn_cls"], out["rcnn_reg"]):
                 t.record_stream(main)
         inter = dict(rpn_out, rois=rois, roi_scores_raw=roi_scores, pts_input=pts_input, pred_boxes3d=boxes, **out)
         return cache, aff, inter
