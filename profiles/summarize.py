@@ -11,7 +11,26 @@ import sys
 
 
 def short(name):
-    return name.split("(")[0][-64:]
+    """jm:: kernels keep their (short) template arguments; library kernels with page-long template lists (composable_kernel
+    convolutions picked by MIOpen's find mode) become `prefix<..>#hash` instead of the meaningless last 64 characters"""
+    base = name.split("(")[0]
+    if base.startswith("_Z") and len(base) > 64:        # a mangled symbol: spell out its leading nested name
+        import re
+        import zlib
+        parts, rest = [], base[3:] if base.startswith("_ZN") else base[2:]
+        while True:
+            m = re.match(r"(\d+)", rest)
+            if not m:
+                break
+            n = int(m.group(1))
+            parts.append(rest[len(m.group(1)):len(m.group(1)) + n])
+            rest = rest[len(m.group(1)) + n:]
+        return f"{'::'.join(parts)[-52:]}<..>#{zlib.crc32(base.encode()) & 0xffff:04x}"
+    if len(base) > 64 and "<" in base and "jm::" not in base:
+        import zlib
+        head = base.split("<")[0].split(" ")[-1]
+        return f"{head[-44:]}<..>#{zlib.crc32(base.encode()) & 0xffff:04x}"
+    return base[-64:]
 
 
 def stats(db_path, out_path=None):
@@ -20,10 +39,16 @@ def stats(db_path, out_path=None):
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
     rows = cur.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
                        f"from kernels group by {name_col} order by sum(end-start) desc").fetchall()
+    # MIOpen's find mode times every applicable solver once per process and shape, its reference kernel included
+    # (naive_conv_*: ~0.15 s each): start-up probes, not part of any step — listed at the end, outside the percentages
+    probes = [r for r in rows if r[0].startswith("naive_conv")]
+    rows = [r for r in rows if not r[0].startswith("naive_conv")]
     total = sum(r[2] for r in rows) or 1
     lines = [f"{'kernel':<64} {'calls':>6} {'total_us':>12} {'avg_us':>11} {'min_us':>10} {'max_us':>10} {'pct':>6}"]
     for n, c, s, a, mn, mx in rows:
         lines.append(f"{short(n):<64} {c:>6} {s / 1e3:>12.1f} {a / 1e3:>11.2f} {mn / 1e3:>10.2f} {mx / 1e3:>10.2f} {100 * s / total:>6.2f}")
+    for n, c, s, a, mn, mx in probes:
+        lines.append(f"(start-up probe of MIOpen find mode, not in pct) {short(n)[-40:]}: {c} calls, {s / 1e3:.1f} us")
     lines += ["", shape_table(cur, cols, name_col)]
     text = "\n".join(lines) + "\n"
     if out_path:
@@ -50,7 +75,7 @@ def shape_table(cur, cols, name_col, top=70):
         return f"(no grid / workgroup columns in the kernels view: {cols})"
     key = ", ".join([name_col] + grid + wg)
     rows = cur.execute(f"select {key}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels "
-                       f"group by {key} order by sum(end-start) desc limit {top}").fetchall()
+                       f"where {name_col} not like 'naive_conv%' group by {key} order by sum(end-start) desc limit {top}").fetchall()
     lines = [f"per dispatch shape (top {top} by total time; grid = work-items as rocprofv3 records them)",
              f"{'kernel':<56} {'grid':>18} {'wg':>12} {'calls':>6} {'total_us':>12} {'avg_us':>11} {'min_us':>10} {'max_us':>10}"]
     for r in rows:

@@ -9,6 +9,9 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/profiles
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# MIOpen's find mode (the engine scopes it to the image convolutions) also times its reference kernel, 0.15 s per call and
+# shape, at start-up: keep those probes out of the traces
+export MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD=0
 cd /tmp
 run() {   # tag, extra rocprof flags, summarize mode, bench args...
     local tag=$1 flags=$2 mode=$3; shift 3
