@@ -29,7 +29,11 @@
 //    19 k of MFMA work, so the MFMA waves waited for it;
 //  * the same tiling as here with packed weights from L2 and A staged 64 deep (1 barrier per 4 k-tiles):
 //    270 / 893 us.
-//  MfmaUtil of this kernel: 54-56 % (profiles/r01_ops_pmc_MfmaUtil.txt).
+//  * (round 3) the sa_mlp_pm.hip recipe on this tiling — operand tiles ROW-major in LDS ([row][BK + 4]), one ds_write_b128
+//    per staged float4 and one ds_read_b128 per four MFMA steps, with 8 waves (32 x 64 each, two per SIMD) or 4 waves
+//    (64 x 64), BK 16 or 32: bit-correct, all four slower at 8 x 128^2 / 8 x 256^2 pairs: 1332 / 4926 us (8 waves, BK 16),
+//    1530 / 5843 (4 waves), 1423 / 5368 and 1577 / 6016 (BK 32) against 1266 / 4630 us for this kernel.
+//  MfmaUtil of this kernel: 54-56 % (profiles/r01_ops_pmc_MfmaUtil.txt); 72-73 % in the batched form (r02).
 #include <stdlib.h>
 
 
