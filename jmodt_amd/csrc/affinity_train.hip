@@ -56,7 +56,7 @@ struct TGemm {
 };
 
 template <int AM, int BM_, int EM>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 registers: 4 workgroups per CU
 train_gemm_kernel(TGemm p) {
     __shared__ __attribute__((aligned(16))) float As[2][TBK][TLDP];
     __shared__ __attribute__((aligned(16))) float Bs[2][TBK][TLDP];
