@@ -137,7 +137,9 @@ int jm_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out,
  * conv weight (widths[l+1], widths[l]) and bias with eval-mode BatchNorm folded in, in the device layout
  * produced by jm_sa_mlp_pack (k-tile-major, so that one lane's MFMA B operand for a 16-deep k-tile is 8
  * consecutive floats; zero padded to pad16(widths[l]) x pad128(widths[l+1])).
- * Two kernels behind one entry (jm_sa_mlp_supported tells which): the persistent wave-specialised one
+ * Three kernels behind one entry (jm_sa_mlp_supported tells which; returns 3: the xyz-only scales [3,16,16,32] x 16 samples
+ * and [3,32,32,64] x 32 samples of the first backbone level, config.py:75-82, on the vector pipe — sa_xyz.hip):
+ * the persistent wave-specialised one
  * (returns 1: nsample in {16,32,64}, M*nsample % 128 == 0, hidden widths <= 128, <= 4 layers) and the wide one
  * (returns 2: 2-3 layers of up to 512 channels, nsample in {16,32}, B*M*nsample % 32 == 0), which also covers
  * GroupAll (pointnet2_utils.py:267-290): idx == NULL and new_xyz == NULL, M == 1, nsample == N — the group is the

@@ -12,6 +12,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int SM_BM = 128, SM_LDP = SM_BM + 4;   // rows per tile, padded row stride of the k-major LDS tiles
 
 __host__ __device__ inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+// padded contraction length of a FIRST set-abstraction layer in jm_sa_mlp_pack's layout: whole 16-channel groups of features,
+// xyz in a group of its own (sa_mlp.hip)
+__host__ __device__ inline int sa_first_kp(int cin) { return pad_to(cin - 3, 16) + 16; }
+// layers small enough for the vector-pipe kernel of sa_xyz.hip get a second, k-major copy [cin][cout] behind the MFMA layout
+__host__ __device__ inline int sa_kmajor_elems(int cout, int cin) { return (cout <= 64 && cin <= 64 && cout % 16 == 0) ? cin * cout : 0; }
 
 // acc += A(128 rows x 16 nkt, LDS k-major) x W-tile; this wave owns rows wm*64.., columns of bp (+32 if TWO)
 //   A      : LDS buffer [k][SM_LDP]

@@ -77,12 +77,12 @@ struct SaMlpParams {
 // (QueryAndGroup's cat order, pointnet2_utils.py:258-262) are reordered to
 //     [C features | zeros to pad16(C) | xyz(3) | zeros to +16]
 // so that the gather works in whole 16-channel groups of plain feature rows, with xyz in a group of its own.
-__host__ __device__ inline int sa_first_kp(int cin) { return pad_to(cin - 3, 16) + 16; }
 
 __global__ void sa_mlp_pack_kernel(int cout, int cin, int Kp, int Np, int first, const float* __restrict__ w,
                                    const float* __restrict__ b, float* __restrict__ wp, float* __restrict__ bp) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < Np) bp[e] = (e < cout && b) ? b[e] : 0.f;
+    if (e < sa_kmajor_elems(cout, cin)) wp[(size_t)Kp * Np + e] = w[(size_t)(e % cout) * cin + e / cout];   // [k][n]: k = e / cout
     if (e >= Kp * Np) return;
     const int kk = e & 7, kh = (e >> 3) & 1, n = (e >> 4) % Np, kt = (e >> 4) / Np;
     const int k = 16 * kt + 2 * kk + kh;
@@ -479,6 +479,9 @@ int sa_mlp_wide_launch(int b, int n, int m, int c, int nsample, const float* xyz
                        const float* features, const int* idx, int L, const int* widths, const float* const* weights,
                        const float* const* biases, float* out, hipStream_t s);                     // sa_mlp_wide.hip
 const char* sa_wide_unsupported(long long b, int n, int m, int c, int nsample, int group_all, int L, const int* widths);
+bool sa_xyz_valu_supported(int m, int c, int nsample, int num_layers, const int* widths);                          // sa_xyz.hip
+int sa_xyz_valu_launch(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* idx,
+                       const int* widths, const float* const* weights, const float* const* biases, float* out, hipStream_t s);
 }
 
 using namespace jm;
@@ -491,13 +494,14 @@ extern "C" int jm_sa_mlp_supported(int b, int n, int m, int c, int nsample, int 
                   num_layers <= 4 && (num_layers > 1 || sa_first_kp(widths[0]) <= SM_KC) &&
                   (long long)m * nsample / SM_BM * b < (1LL << 31) && widths[num_layers] >= 1;
     for (int l = 1; l < num_layers && narrow; ++l) narrow = widths[l] >= 1 && widths[l] <= 128;
+    if (narrow && !group_all && sa_xyz_valu_supported(m, c, nsample, num_layers, widths)) return 3;   // xyz-only scale: sa_xyz.hip
     if (narrow) return 1;
     return sa_wide_unsupported(b, n, m, c, nsample, group_all, num_layers, widths) == nullptr ? 2 : 0;
 }
 
 extern "C" size_t jm_sa_mlp_packed_weight_elems(int cout, int cin, int first_layer) {
     if (cout < 1 || cin < 1 || (first_layer && cin < 3)) return 0;
-    return (size_t)(first_layer ? sa_first_kp(cin) : pad_to(cin, 16)) * pad_to(cout, 128);
+    return (size_t)(first_layer ? sa_first_kp(cin) : pad_to(cin, 16)) * pad_to(cout, 128) + sa_kmajor_elems(cout, cin);
 }
 
 extern "C" size_t jm_sa_mlp_packed_bias_elems(int cout) { return cout < 1 ? 0 : (size_t)pad_to(cout, 128); }
@@ -548,6 +552,8 @@ extern "C" int jm_sa_mlp_forward(int b, int n, int m, int c, int nsample, const 
                                   out, (hipStream_t)stream);
     JM_REQUIRE(idx && new_xyz, "sa_mlp: GroupAll (idx == NULL) needs a shape of the wide variant");
     JM_REQUIRE(widths[0] == 3 + c, "sa_mlp: widths[0] = %d != 3 + C = %d", widths[0], 3 + c);
+    if (sa_xyz_valu_supported(m, c, nsample, num_layers, widths))        // xyz-only scales: the vector pipe (sa_xyz.hip)
+        return sa_xyz_valu_launch(b, n, m, nsample, xyz, new_xyz, idx, widths, weights, biases, out, (hipStream_t)stream);
     return sa_mlp_narrow_launch(b, n, m, c, nsample, xyz, new_xyz, features, nullptr, idx, num_layers, widths, weights, biases,
                                 out, stream);
 }

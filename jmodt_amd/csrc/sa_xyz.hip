@@ -1,0 +1,200 @@
+// sa_xyz.hip — the xyz-only set-abstraction scale (first level of the RPN backbone, config.py:75-82:
+// SharedMLP [3, 16, 16, 32] over 16 samples and [3, 32, 32, 64] over 32 samples of 4096 centres per frame) on the VECTOR
+// pipe (gfx950).
+//
+// _PointnetSAModuleBase.forward (jmodt/ops/pointnet2/pointnet2_modules.py:41-52) with QueryAndGroup(use_xyz=True) and no
+// input features: rows = (centre, sample), row input = xyz[idx] - centre (pointnet2_utils.py:259-262), three
+// 1x1 conv + folded BN + ReLU layers, max over the samples.  7.5 GFLOP for 1.57 M rows at batch 8.
+//
+// Why not the matrix cores: fp32 MFMA and packed fp32 VALU (v_pk_fma_f32) have the SAME peak on this chip (157 TFLOP/s), and
+// with contraction lengths of 3, 16 and 32 the MFMA route pays for its operand layout instead of computing: the general
+// kernel (sa_mlp_kernel: gather waves -> LDS tiles -> 32x32x2 MFMAs with K padded to 16, 256 registers, 44 of them
+// spilled) takes 0.19 ms per scale = 0.12 of the peak.  Here a LANE owns a row: the three layers are straight-line
+// v_pk_fma_f32 on registers (two output channels per instruction, the input broadcast into both halves), the weights are
+// wave-uniform and come through the SCALAR cache straight into the SGPR operand of the FMA (s_load_dwordx4.. of the k-major
+// copy jm_sa_mlp_pack appends to small layers; as vector registers from LDS they push hipcc into thousands of spills: the
+// weights of a fully unrolled layer do not fit next to its accumulators), the max over a centre's 16 / 32 samples is 4 / 5
+// DPP max steps per channel
+// inside the wave, and the (centre, channel) maxima leave through an LDS tile as 256-byte row segments of the (B, C, M)
+// output.  No gather stage, no barrier in the row loop.
+#include "jm_mfma.h"
+#include <type_traits>
+
+namespace jm {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct SaXyzParams {
+    int N, M, ns;                  // points per frame, centres per frame, samples per centre (16 or 32)
+    const float* xyz;              // (B, N, 3)
+    const float* new_xyz;          // (B, M, 3)
+    const int* idx;                // (B, M, ns)
+    const float *w0, *w1, *w2;     // k-major tables [cin][cout] (jm_sa_mlp_pack appends them behind the MFMA layout)
+    const float *b0, *b1, *b2;     // biases, zero padded
+    float* out;                    // (B, C3, M)
+};
+
+// max over the 16 lanes of each DPP row (result in every lane of the row) of FOUR values at once: the four independent
+// chains fill each other's two wait states between a VALU write and a DPP read of the same register (one chain alone
+// spends as many s_nops as max instructions).  NS == 32: ... and of each pair of rows, valid in the ODD rows (lanes 16-31,
+// 48-63): row_bcast:15 hands lane 15 of the previous row to rows 1 and 3.
+#define JM_DPP4(ctrl)                                               \
+    "v_max_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_max_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_max_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_max_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
+template <int NS>
+__device__ __forceinline__ void samples_max4(float& a, float& b, float& c, float& d) {
+    asm volatile("s_nop 1\n\t" JM_DPP4("quad_perm:[1,0,3,2]") JM_DPP4("quad_perm:[2,3,0,1]") JM_DPP4("row_half_mirror")
+                 JM_DPP4("row_mirror") "s_nop 0"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if (NS == 32)
+        asm volatile("s_nop 1\n\t"
+                     "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "v_max_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "v_max_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "v_max_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "s_nop 1"
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+#undef JM_DPP4
+
+// ROWS rows per lane (rows tid, tid + T, ...: other centres of the same workgroup) share every weight load: the weights are
+// the scalar cache's traffic — 12.7 KB per wave and pass at [32, 32, 64] —, and with one row per lane the kernel waits for
+// them (0.225 ms); two rows halve that traffic per FMA.
+template <int H1, int H2, int C3, int NS, int ROWS>
+__global__ void __launch_bounds__(1024 / ROWS)
+sa_xyz_valu_kernel(SaXyzParams p) {
+    constexpr int T = 1024 / ROWS, CPW = 1024 / NS;       // threads, centres per workgroup (1024 rows)
+    __shared__ __attribute__((aligned(16))) float tile[C3][CPW + 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const float* __restrict__ W0t = p.w0; const float* __restrict__ W1t = p.w1; const float* __restrict__ W2t = p.w2;
+    const float* __restrict__ B0 = p.b0; const float* __restrict__ B1 = p.b1; const float* __restrict__ B2 = p.b2;
+
+    f32x2 din[ROWS][2];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const long long row = (long long)blockIdx.x * 1024 + r * T + tid;   // (frame, centre, sample) flattened; M * NS % 1024 == 0
+        const int per_frame = p.M * NS;
+        const int bi = (int)(row / per_frame), rr = (int)(row - (long long)bi * per_frame);
+        const int centre = rr / NS;
+        const int k = p.idx[row];
+        const float* q = p.xyz + ((size_t)bi * p.N + k) * 3;
+        const float* c = p.new_xyz + ((size_t)bi * p.M + centre) * 3;
+        din[r][0] = (f32x2){q[0] - c[0], q[1] - c[1]};
+        din[r][1] = (f32x2){q[2] - c[2], 0.f};
+    }
+
+    // One layer for a chunk of 16 output channels: acc[r][8] (pairs) += in[r][kk] * Wt[kk][n0 .. n0 + 15] over kk < KIN; the
+    // addresses are uniform, so the weights are scalar loads into SGPRs (the SGPR operand of v_pk_fma_f32)
+    auto chunk16 = [&](auto KIN_, auto IN_, const f32x2 (*in)[decltype(IN_)::value], bool relu_in, const float* Wt, int ldw,
+                       const float* bias, int n0, f32x2 (&acc)[ROWS][8]) __attribute__((always_inline)) {
+        constexpr int KIN = decltype(KIN_)::value;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int n = 0; n < 8; ++n) acc[r][n] = (f32x2){bias[n0 + 2 * n], bias[n0 + 2 * n + 1]};
+#pragma unroll
+        for (int kk = 0; kk < KIN; ++kk) {
+            float4 wc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wc[j] = *reinterpret_cast<const float4*>(&Wt[kk * ldw + n0 + 4 * j]);
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                float a = (kk & 1) ? in[r][kk >> 1].y : in[r][kk >> 1].x;
+                if (relu_in) a = fmaxf(a, 0.f);
+                const f32x2 pp = {a, a};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[r][2 * j] = __builtin_elementwise_fma(pp, (f32x2){wc[j].x, wc[j].y}, acc[r][2 * j]);
+                    acc[r][2 * j + 1] = __builtin_elementwise_fma(pp, (f32x2){wc[j].z, wc[j].w}, acc[r][2 * j + 1]);
+                }
+            }
+        }
+    };
+    f32x2 h1[ROWS][H1 / 2], h2[ROWS][H2 / 2];
+#pragma unroll
+    for (int ch = 0; ch < H1 / 16; ++ch) {
+        f32x2 acc[ROWS][8];
+        chunk16(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{}, din, false, W0t, H1, B0, ch * 16, acc);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int n = 0; n < 8; ++n) h1[r][ch * 8 + n] = acc[r][n];
+    }
+#pragma unroll
+    for (int ch = 0; ch < H2 / 16; ++ch) {
+        f32x2 acc[ROWS][8];
+        chunk16(std::integral_constant<int, H1>{}, std::integral_constant<int, H1 / 2>{}, h1, true, W1t, H2, B1, ch * 16, acc);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int n = 0; n < 8; ++n) h2[r][ch * 8 + n] = acc[r][n];
+    }
+    // last layer chunk by chunk: the 16 channels of a chunk are reduced over the centre's samples (max and ReLU commute:
+    // pointnet2_modules.py:48-52 applies the ReLU first) and parked in the workgroup's (channel, centre) tile at once
+    const bool writer = NS == 16 ? (lane & 15) == 0 : (lane & 31) == 16;
+#pragma unroll
+    for (int ch = 0; ch < C3 / 16; ++ch) {
+        f32x2 acc[ROWS][8];
+        chunk16(std::integral_constant<int, H2>{}, std::integral_constant<int, H2 / 2>{}, h2, true, W2t, C3, B2, ch * 16, acc);
+        // all accumulator pairs are complete HERE: without this fence hipcc orders the layer by consumer — one accumulator
+        // through all k, then its reduction, then the next — which needs every weight of the chunk live at once (the SGPRs
+        // spill through v_writelane: 1276 registers)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+            asm volatile("" : "+v"(acc[r][0]), "+v"(acc[r][1]), "+v"(acc[r][2]), "+v"(acc[r][3]), "+v"(acc[r][4]), "+v"(acc[r][5]),
+                              "+v"(acc[r][6]), "+v"(acc[r][7]));
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int cl = (r * T + tid) / NS;                         // centre within the workgroup
+#pragma unroll
+            for (int n = 0; n < 8; n += 2) {                           // channels 2n .. 2n + 3 of the chunk
+                float v0 = acc[r][n].x, v1 = acc[r][n].y, v2 = acc[r][n + 1].x, v3 = acc[r][n + 1].y;
+                samples_max4<NS>(v0, v1, v2, v3);
+                if (writer) {
+                    tile[ch * 16 + 2 * n + 0][cl] = fmaxf(v0, 0.f); tile[ch * 16 + 2 * n + 1][cl] = fmaxf(v1, 0.f);
+                    tile[ch * 16 + 2 * n + 2][cl] = fmaxf(v2, 0.f); tile[ch * 16 + 2 * n + 3][cl] = fmaxf(v3, 0.f);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const long long crow0 = (long long)blockIdx.x * CPW;               // first (frame, centre) of the workgroup: one frame
+    const int ob = (int)(crow0 / p.M), om = (int)(crow0 - (long long)ob * p.M);      // (CPW divides M)
+    for (int e = tid; e < C3 * CPW; e += T) {
+        const int n = e / CPW, j = e - n * CPW;
+        p.out[((size_t)ob * C3 + n) * p.M + om + j] = tile[n][j];
+    }
+}
+
+// widths[1..3] of the two scales this file instantiates; anything else stays on the matrix-core kernels
+bool sa_xyz_valu_supported(int m, int c, int nsample, int num_layers, const int* widths) {
+    if (c != 0 || num_layers != 3) return false;
+    const bool a = nsample == 16 && widths[1] == 16 && widths[2] == 16 && widths[3] == 32;
+    const bool b = nsample == 32 && widths[1] == 32 && widths[2] == 32 && widths[3] == 64;
+    return (a || b) && m % (1024 / nsample) == 0;
+}
+
+int sa_xyz_valu_launch(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* idx,
+                       const int* widths, const float* const* weights, const float* const* biases, float* out, hipStream_t s) {
+    SaXyzParams p{};
+    p.N = n; p.M = m; p.ns = nsample; p.xyz = xyz; p.new_xyz = new_xyz; p.idx = idx;
+    // the k-major copies behind the MFMA layouts (sa_mlp_pack_kernel): Kp x Np floats in
+    p.w0 = weights[0] + (size_t)sa_first_kp(3) * pad_to(widths[1], 128);
+    p.w1 = weights[1] + (size_t)pad_to(widths[1], 16) * pad_to(widths[2], 128);
+    p.w2 = weights[2] + (size_t)pad_to(widths[2], 16) * pad_to(widths[3], 128);
+    p.b0 = biases[0]; p.b1 = biases[1]; p.b2 = biases[2];
+    p.out = out;
+    const long long rows = (long long)b * m * nsample;
+    JM_REQUIRE(rows / 1024 < (1LL << 31), "sa_xyz: too many rows");
+    const dim3 grid((unsigned)(rows / 1024));
+    static const int rpl = tune_env("JM_SA_XYZ_ROWS", 2);       // rows per lane
+    if (nsample == 16 && rpl == 1) hipLaunchKernelGGL((sa_xyz_valu_kernel<16, 16, 32, 16, 1>), grid, dim3(1024), 0, s, p);
+    else if (nsample == 16) hipLaunchKernelGGL((sa_xyz_valu_kernel<16, 16, 32, 16, 2>), grid, dim3(512), 0, s, p);
+    else if (rpl == 1) hipLaunchKernelGGL((sa_xyz_valu_kernel<32, 32, 64, 32, 1>), grid, dim3(1024), 0, s, p);
+    else hipLaunchKernelGGL((sa_xyz_valu_kernel<32, 32, 64, 32, 2>), grid, dim3(512), 0, s, p);
+    return check_launch("sa_xyz_valu");
+}
+
+}  // namespace jm

@@ -531,6 +531,40 @@ def test_fused_sa_block_repacks_after_weight_update():
     assert (b - c).abs().max().item() <= 1e-4 * max(c.abs().max().item(), 1.0)
 
 
+def test_xyz_only_scales_take_the_vector_pipe_kernel(oracle):
+    """RPN level 1 (no input features, [3,16,16,32] x 16 and [3,32,32,64] x 32): jm_sa_mlp_supported says 3 = sa_xyz.hip; its
+    output against a float64 evaluation of the same folded layers on the oracle's own neighbour lists"""
+    import ctypes
+    from jmodt_amd import _lib as L
+    from jmodt_amd.ops.pointnet2 import fused
+    from jmodt_amd.ops.pointnet2.pointnet2_modules import PointnetSAModuleMSG
+    lib = L.load()
+    for ns, w in ((16, [3, 16, 16, 32]), (32, [3, 32, 32, 64])):
+        assert lib.jm_sa_mlp_supported(8, 16384, 4096, 0, ns, 0, 3, (ctypes.c_int * 4)(*w)) == 3
+    assert lib.jm_sa_mlp_supported(8, 16384, 4096, 0, 16, 0, 3, (ctypes.c_int * 4)(3, 16, 24, 32)) == 1     # other widths: MFMA kernel
+    assert lib.jm_sa_mlp_supported(2, 2048, 72, 0, 32, 0, 3, (ctypes.c_int * 4)(3, 32, 32, 64)) == 1         # centres not a multiple of 32
+    torch.manual_seed(11)
+    sa = PointnetSAModuleMSG(npoint=1024, radii=[0.1, 0.5], nsamples=[16, 32], mlps=[[0, 16, 16, 32], [0, 32, 32, 64]], bn=True)
+    _randomise_bn(sa, 9)
+    sa = sa.to(DEV).eval()
+    xyz = synth.kitti_like_cloud(2, 8192, 23)
+    with torch.no_grad():
+        new_xyz, feats, _ = sa(T(xyz))
+    new_np = new_xyz.cpu().numpy()
+    off = 0
+    for g, mlp, ns, r in zip(sa.groupers, sa.mlps, (16, 32), (0.1, 0.5)):
+        idx = oracle.ball_query(r, ns, xyz, new_np).astype(np.int64)                  # (B, M, ns)
+        rel = np.take_along_axis(xyz[:, None], idx[..., None], axis=2) - new_np[:, :, None, :]   # (B, M, ns, 3)
+        h = torch.from_numpy(rel).double()
+        for W, b in fused.fold_shared_mlp(mlp):
+            h = torch.relu(h @ W.double().cpu().t() + b.double().cpu())
+        want = h.max(dim=2)[0].permute(0, 2, 1)                                       # (B, C, M)
+        got = feats[:, off:off + want.shape[1]].double().cpu()
+        off += want.shape[1]
+        assert (got - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+        assert want.abs().max().item() > 0.05
+
+
 def test_fused_sa_block_is_used_and_falls_back():
     from jmodt_amd.ops.pointnet2 import fused
     from jmodt_amd.ops.pointnet2.pointnet2_modules import PointnetSAModuleMSG
