@@ -61,7 +61,9 @@ __device__ __forceinline__ void samples_max4(float& a, float& b, float& c, float
 
 // ROWS rows per lane (rows tid, tid + T, ...: other centres of the same workgroup) share every weight load: the weights are
 // the scalar cache's traffic — 12.7 KB per wave and pass at [32, 32, 64] —, and with one row per lane the kernel waits for
-// them (0.225 ms); two rows halve that traffic per FMA.
+// them (0.225 ms); two rows halve that traffic per FMA (0.144 ms at 256 registers, two waves per SIMD).  Sharing the weights
+// in the last layer only (two thirds of the FMAs) with the first two layers row by row, to fit 128 registers and four waves
+// per SIMD: hipcc still wants 256 registers, and capped at 128 it spills 115 of them — 0.355 ms.
 template <int H1, int H2, int C3, int NS, int ROWS>
 __global__ void __launch_bounds__(1024 / ROWS)
 sa_xyz_valu_kernel(SaXyzParams p) {
@@ -189,10 +191,7 @@ int sa_xyz_valu_launch(int b, int n, int m, int nsample, const float* xyz, const
     const long long rows = (long long)b * m * nsample;
     JM_REQUIRE(rows / 1024 < (1LL << 31), "sa_xyz: too many rows");
     const dim3 grid((unsigned)(rows / 1024));
-    static const int rpl = tune_env("JM_SA_XYZ_ROWS", 2);       // rows per lane
-    if (nsample == 16 && rpl == 1) hipLaunchKernelGGL((sa_xyz_valu_kernel<16, 16, 32, 16, 1>), grid, dim3(1024), 0, s, p);
-    else if (nsample == 16) hipLaunchKernelGGL((sa_xyz_valu_kernel<16, 16, 32, 16, 2>), grid, dim3(512), 0, s, p);
-    else if (rpl == 1) hipLaunchKernelGGL((sa_xyz_valu_kernel<32, 32, 64, 32, 1>), grid, dim3(1024), 0, s, p);
+    if (nsample == 16) hipLaunchKernelGGL((sa_xyz_valu_kernel<16, 16, 32, 16, 2>), grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL((sa_xyz_valu_kernel<32, 32, 64, 32, 2>), grid, dim3(512), 0, s, p);
     return check_launch("sa_xyz_valu");
 }
