@@ -61,20 +61,23 @@ SA_LEVELS = [
 
 
 # ---------------------------------------------------------------------------------------------- detect
-def detect_inputs(B, seed, dev, tiny=False, kind="uniform"):
+def detect_inputs(B, seed, dev, tiny=False, kind="uniform", points=16384):
     if tiny:
         xyz, img, xy = synth.frames(B, 2048, seed, H=96, W=320, native=(94, 310), kind=kind)
     else:
-        xyz, img, xy = synth.frames(B, 16384, seed, kind=kind)
+        xyz, img, xy = synth.frames(B, points, seed, kind=kind)
     return dict(xyz=torch.from_numpy(xyz).to(dev), image=torch.from_numpy(img).to(dev), pts_xy=torch.from_numpy(xy).to(dev))
 
 
-def make_detect_state(B, seed, dev, tiny=False, kind="uniform"):
+def make_detect_state(B, seed, dev, tiny=False, kind="uniform", points=16384, rois=None):
+    import dataclasses
     from jmodt_amd.detector import DetectAffinityEngine, DetectorConfig
     torch.manual_seed(seed)
     cfg = DetectorConfig.tiny() if tiny else DetectorConfig.survey()
+    if rois and not tiny:
+        cfg = dataclasses.replace(cfg, rpn_post_nms_top_n=rois)
     eng = DetectAffinityEngine(cfg).to(dev)
-    return dict(engine=eng, **detect_inputs(B, seed, dev, tiny, kind))
+    return dict(engine=eng, **detect_inputs(B, seed, dev, tiny, kind, points))
 
 
 def _with_headline(clouds, value):
@@ -408,6 +411,8 @@ WORKLOAD_TEXT = {
            "pts x 133), RPN nms_normal (6300 boxes), proposal selection, fused RCNN SA1, 128x128 affinity, per frame",
     "train": "BASELINE configs[3]: frozen composed detector forward + data-parallel finetune step of the link / "
              "start-end heads (64 RoIs x 512-d per frame, pairwise affinity losses, bucketed fp32 gradient all-reduce, Adam)",
+    "dense_detect": "BASELINE configs[4], composed: the SAME detect+affinity forward as `detect` on 65536-pt frames (co-operative "
+                    "FPS, hash-grid ball query / 3-NN at the first level), 256 proposals/frame, 256x256 affinity per frame pair",
     "dense": "supplementary, BASELINE configs[4] shapes: 65536-pt clouds (co-operative FPS -> 4096, dual ball query, "
              "grouping, 3-NN), roipool3d+canonical for 256 RoIs, 256x256 affinity per frame",
 }
@@ -576,6 +581,11 @@ def main():
     elif args.workload == "ops":
         ops_in = make_ops_inputs(args.batch, seed + 2, dev, small=args.tiny)
         step = lambda: ops_step(ops_in)  # noqa: E731
+    elif args.workload == "dense_detect":
+        st = make_detect_state(args.batch, seed + 4, dev, tiny=args.tiny, points=65536, rois=256)
+        st["engine"].overlap = not args.no_overlap
+        st["prefetch"] = not args.no_prefetch
+        step = lambda: detect_step(st)  # noqa: E731
     elif args.workload == "dense":
         dense_in = make_dense_inputs(args.batch, seed + 4, dev, small=args.tiny)
         step = lambda: dense_step(dense_in)  # noqa: E731
@@ -800,7 +810,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOAD_TEXT[args.workload] + (" [TINY smoke shapes: not a benchmark]" if args.tiny else ""),
                        "frames_per_gpu_per_step": args.batch,
-                       "points": (65536 if args.workload == "dense" else 16384) if not args.tiny else "tiny",
+                       "points": (65536 if args.workload in ("dense", "dense_detect") else 16384) if not args.tiny else "tiny",
                        "parallelism": f"dp{world} (gradient all-reduce)" if args.workload == "train" else f"replicas x{world}"},
             "roofline": roofline,
             "roofline_selection": "the jm entry with the largest speed-of-light time (executed flops / 157.3 TF, algorithmic bytes / 8 TB/s) "
@@ -812,7 +822,7 @@ def main():
             "affinity_operands": ("all RoI slots of every frame (P = D = proposals per frame: fixed work per frame, SURVEY.md §8d), not the "
                                   "detection-NMS survivors: the head therefore does not wait for box decode / score filter / rotated NMS, "
                                   "which run on a side stream under its GEMMs; DetectionCache.associate (tests) is the survivor-only form"
-                                  if args.workload == "detect" else None),
+                                  if args.workload in ("detect", "dense_detect") else None),
             "overlap": {"side_streams": not args.no_overlap, "next_batch_fps_prefetch": not (args.no_prefetch or args.no_overlap),
                         "fps_chain_ms": round(fps_total, 4), "fps_exposed_ms": round(exposed, 4),
                         "fps_critical_path_share": round(exposed / ms_step, 4) if ms_step else None,
