@@ -1,0 +1,215 @@
+"""Golden vectors for the reference's PYTHON layer around its CUDA extensions (tests/golden/glue_ref.npz).  Run in the
+authoring container, where /root/reference exists:
+
+    python tests/golden/make_golden_glue.py
+
+What is executed is the reference's own Python, imported from /root/reference:
+  * jmodt/ops/pointnet2/pointnet2_utils.py — every autograd.Function's forward (and the three backward passes), QueryAndGroup,
+    GroupAll;
+  * jmodt/ops/pointnet2/pointnet2_modules.py — PointnetSAModuleMSG (two scales), PointnetSAModule (GroupAll), PointnetFPModule
+    forward with seeded weights / BatchNorm statistics in eval mode;
+  * jmodt/ops/iou3d/iou3d_utils.py — boxes_iou_bev, boxes_iou3d_gpu (the height / volume arithmetic around the BEV overlap),
+    nms_gpu, nms_normal_gpu (score order, keep gathering);
+  * jmodt/ops/roipool3d/roipool3d_utils.py — roipool3d_gpu (box enlargement + call).
+The CUDA extension modules those files call cannot exist here (no nvcc, no GPU).  Their fifteen entry points are bound,
+under the extension modules' names and with the argument orders of pointnet2_api.cpp:10-24 / iou3d.cpp:170-175 /
+roipool3d.cpp:198-203, to this repository's CPU oracle (oracle/jmodt_oracle.c), and the `torch.cuda.*Tensor` constructors /
+`.cuda()` the wrappers hard-code produce CPU tensors while the script runs.  So the fixture pins everything the reference does
+in PYTHON — argument orders, output allocation and zero-fill conventions, transposes and concatenation order, the sqrt of
+three_nn, the inverse-distance weights, BatchNorm / ReLU / max-pool composition, 3-D IoU arithmetic, the NMS score order — to
+the reference's own code; the extension kernels themselves stay pinned by the oracle (parity unpinned by the reference for
+those, as DESIGN.md §3 says).  Only data is stored: seeded inputs, parameters, expected outputs.  No reference source text.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from jmodt_amd import synth  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+import make_golden_model as mgm  # noqa: E402  (easydict stand-in, reference path)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _put(dst, arr):
+    dst.copy_(torch.from_numpy(np.ascontiguousarray(arr)).to(dst.dtype).view_as(dst))
+
+
+def bind_extensions():
+    """the three extension modules, entry point by entry point, on the CPU oracle"""
+    p2 = types.ModuleType("jmodt.ops.pointnet2.pointnet2_cuda")
+    p2.ball_query_wrapper = lambda b, n, m, radius, nsample, new_xyz, xyz, idx: (
+        _put(idx, orc.ball_query(radius, nsample, _np(xyz), _np(new_xyz))), 1)[1]
+    p2.group_points_wrapper = lambda b, c, n, npoints, nsample, points, idx, out: (
+        _put(out, orc.grouping_operation(_np(points), _np(idx))), 1)[1]
+    p2.group_points_grad_wrapper = lambda b, c, n, npoints, nsample, grad_out, idx, grad_points: (
+        _put(grad_points, orc.grouping_operation_grad(_np(grad_out), _np(idx), n)), 1)[1]
+    p2.gather_points_wrapper = lambda b, c, n, npoints, points, idx, out: (
+        _put(out, orc.gather_operation(_np(points), _np(idx))), 1)[1]
+    p2.gather_points_grad_wrapper = lambda b, c, n, npoints, grad_out, idx, grad_points: (
+        _put(grad_points, orc.gather_operation_grad(_np(grad_out), _np(idx), n)), 1)[1]
+    p2.farthest_point_sampling_wrapper = lambda b, n, m, points, temp, idx: (
+        _put(idx, orc.furthest_point_sample(_np(points), m)), 1)[1]
+
+    def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
+        d2, i = orc.three_nn(_np(unknown), _np(known))
+        _put(dist2, d2); _put(idx, i)
+    p2.three_nn_wrapper = three_nn_wrapper
+    p2.three_interpolate_wrapper = lambda b, c, m, n, points, idx, weight, out: _put(
+        out, orc.three_interpolate(_np(points), _np(idx), _np(weight)))
+    p2.three_interpolate_grad_wrapper = lambda b, c, n, m, grad_out, idx, weight, grad_points: _put(
+        grad_points, orc.three_interpolate_grad(_np(grad_out), _np(idx), _np(weight), m))
+
+    iou = types.ModuleType("jmodt.ops.iou3d.iou3d_cuda")
+    iou.boxes_overlap_bev_gpu = lambda a, b, out: (_put(out, orc.boxes_overlap_bev(_np(a), _np(b))), 1)[1]
+    iou.boxes_iou_bev_gpu = lambda a, b, out: (_put(out, orc.boxes_iou_bev(_np(a), _np(b))), 1)[1]
+
+    def _nms(normal):
+        def f(boxes, keep, thresh):
+            k = orc.nms_sorted(_np(boxes), thresh, normal)
+            keep[:len(k)] = torch.from_numpy(np.asarray(k, np.int64))
+            return len(k)
+        return f
+    iou.nms_gpu, iou.nms_normal_gpu = _nms(0), _nms(1)
+
+    roi = types.ModuleType("jmodt.ops.roipool3d.roipool3d_cuda")
+
+    def forward(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag):
+        pooled, empty = orc.roipool3d(_np(xyz), _np(pts_feature), _np(boxes3d), pooled_features.shape[2])
+        _put(pooled_features, pooled); _put(pooled_empty_flag, empty)
+        return 1
+    roi.forward = forward
+    return {m.__name__: m for m in (p2, iou, roi)}
+
+
+def import_reference_with_oracle_extensions():
+    if not os.path.isdir(os.path.join(mgm.REFERENCE, "jmodt")):
+        raise SystemExit("needs /root/reference")
+    sys.modules["easydict"] = types.SimpleNamespace(EasyDict=mgm._AttrDict)
+    for name, mod in bind_extensions().items():
+        sys.modules[name] = mod
+    sys.path.insert(0, mgm.REFERENCE)
+    import jmodt.ops.iou3d as a, jmodt.ops.pointnet2 as b, jmodt.ops.roipool3d as c   # namespace packages
+    a.iou3d_cuda = sys.modules["jmodt.ops.iou3d.iou3d_cuda"]
+    b.pointnet2_cuda = sys.modules["jmodt.ops.pointnet2.pointnet2_cuda"]
+    c.roipool3d_cuda = sys.modules["jmodt.ops.roipool3d.roipool3d_cuda"]
+    # the wrappers hard-code device constructors (pointnet2_utils.py:25-26,55,94-95,128,172,218; iou3d_utils.py:15,33,65-88;
+    # roipool3d_utils.py:22-24): CPU tensors while this script runs
+    torch.cuda.FloatTensor, torch.cuda.IntTensor, torch.cuda.LongTensor = torch.FloatTensor, torch.IntTensor, torch.LongTensor
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+
+def randomise_bn(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in module.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            with torch.no_grad():
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.2)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.3)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+
+
+def state(prefix, module):
+    return {f"{prefix}.{k}": _np(v) for k, v in module.state_dict().items() if v.dtype.is_floating_point}
+
+
+def main():
+    import_reference_with_oracle_extensions()
+    from jmodt.ops.iou3d import iou3d_utils
+    from jmodt.ops.pointnet2 import pointnet2_modules as ref_mod
+    from jmodt.ops.pointnet2 import pointnet2_utils as ref_pu
+    from jmodt.ops.roipool3d import roipool3d_utils
+    out = {}
+    rng = np.random.default_rng(71)
+    T = torch.from_numpy
+
+    # ---- the operator layer: every Function forward, the three backward passes
+    xyz = synth.dense_cloud(2, 600, 72, extent=4.0)
+    feats = rng.normal(size=(2, 7, 600)).astype(np.float32)
+    fps = ref_pu.farthest_point_sample(T(xyz), 96)
+    new_xyz = ref_pu.gather_operation(T(xyz).transpose(1, 2).contiguous(), fps).transpose(1, 2).contiguous()
+    bq = ref_pu.ball_query(0.9, 16, T(xyz), new_xyz)
+    f = T(feats).clone().requires_grad_(True)
+    grouped = ref_pu.grouping_operation(f, bq)
+    gw = T(rng.normal(size=tuple(grouped.shape)).astype(np.float32))
+    (grouped * gw).sum().backward()
+    qg = ref_pu.QueryAndGroup(0.9, 16, use_xyz=True)(T(xyz), new_xyz, T(feats))
+    qg_nofeat = ref_pu.QueryAndGroup(0.9, 16, use_xyz=True)(T(xyz), new_xyz, None)
+    qg_noxyz = ref_pu.QueryAndGroup(0.9, 16, use_xyz=False)(T(xyz), new_xyz, T(feats))
+    ga = ref_pu.GroupAll(use_xyz=True)(T(xyz), None, T(feats))
+    dist, nn_idx = ref_pu.three_nn(T(xyz), new_xyz)
+    w = 1.0 / (dist + 1e-8)
+    w = w / w.sum(dim=2, keepdim=True)
+    kf = T(rng.normal(size=(2, 5, 96)).astype(np.float32)).requires_grad_(True)
+    interp = ref_pu.three_interpolate(kf, nn_idx, w)
+    iw = T(rng.normal(size=tuple(interp.shape)).astype(np.float32))
+    (interp * iw).sum().backward()
+    gsrc = T(feats).clone().requires_grad_(True)
+    gathered = ref_pu.gather_operation(gsrc, fps)
+    gg = T(rng.normal(size=tuple(gathered.shape)).astype(np.float32))
+    (gathered * gg).sum().backward()
+    out.update(op_xyz=xyz, op_feats=feats, op_fps=_np(fps), op_new_xyz=_np(new_xyz), op_ball=_np(bq), op_grouped=_np(grouped),
+               op_group_w=_np(gw), op_group_grad=_np(f.grad), op_qg=_np(qg), op_qg_nofeat=_np(qg_nofeat), op_qg_noxyz=_np(qg_noxyz),
+               op_group_all=_np(ga), op_nn_dist=_np(dist), op_nn_idx=_np(nn_idx), op_known_feats=_np(kf), op_interp=_np(interp),
+               op_interp_w=_np(iw), op_interp_grad=_np(kf.grad), op_gathered=_np(gathered), op_gather_w=_np(gg),
+               op_gather_grad=_np(gsrc.grad))
+
+    # ---- the module layer (eval mode, seeded weights and BatchNorm statistics)
+    torch.manual_seed(73)
+    sa = ref_mod.PointnetSAModuleMSG(npoint=64, radii=[0.8, 1.6], nsamples=[16, 32], mlps=[[7, 16, 16, 32], [7, 16, 24, 48]],
+                                     use_xyz=True, bn=True).eval()
+    randomise_bn(sa, 74)
+    with torch.no_grad():
+        sa_xyz, sa_feat = sa(T(xyz), T(feats))[:2]
+    torch.manual_seed(75)
+    sa_all = ref_mod.PointnetSAModule(mlp=[32 + 48, 64, 96], use_xyz=True, bn=True).eval()
+    randomise_bn(sa_all, 76)
+    with torch.no_grad():
+        all_feat = sa_all(sa_xyz, sa_feat)[1]
+    torch.manual_seed(77)
+    fp = ref_mod.PointnetFPModule(mlp=[80 + 7, 40, 24], bn=True).eval()
+    randomise_bn(fp, 78)
+    with torch.no_grad():
+        fp_feat = fp(T(xyz), sa_xyz, T(feats), sa_feat)
+    out.update(mod_sa_xyz=_np(sa_xyz), mod_sa_feat=_np(sa_feat), mod_all_feat=_np(all_feat), mod_fp_feat=_np(fp_feat),
+               **state("sa", sa), **state("sa_all", sa_all), **state("fp", fp))
+
+    # ---- iou3d_utils
+    pts = synth.dense_cloud(1, 256, 79, extent=12.0)
+    a3 = synth.proposals(pts, 40, 80)[0]
+    b3 = synth.proposals(pts, 30, 81)[0]
+    b3[:10] = a3[:10] + rng.normal(0, 0.15, (10, 7)).astype(np.float32)          # overlapping pairs
+    from jmodt.utils import kitti_utils
+    a_bev, b_bev = kitti_utils.boxes3d_to_bev_torch(T(a3)), kitti_utils.boxes3d_to_bev_torch(T(b3))
+    iou_bev = iou3d_utils.boxes_iou_bev(a_bev, b_bev)
+    iou_3d = iou3d_utils.boxes_iou3d_gpu(T(a3), T(b3))
+    nb, ns = synth.bev_boxes(300, 82)
+    keep_rot = iou3d_utils.nms_gpu(T(nb), T(ns), 0.3)
+    keep_nrm = iou3d_utils.nms_normal_gpu(T(nb), T(ns), 0.5)
+    out.update(iou_a=a3, iou_b=b3, iou_bev=_np(iou_bev), iou_3d=_np(iou_3d), nms_boxes=nb, nms_scores=ns, nms_keep_rot=_np(keep_rot),
+               nms_keep_normal=_np(keep_nrm))
+
+    # ---- roipool3d_gpu (box enlargement + extension call)
+    rp = synth.dense_cloud(2, 2048, 83, extent=14.0)
+    rp[..., 1] = rp[..., 1] / 7.0
+    rboxes = synth.proposals(rp, 12, 84)
+    rfeat = rng.normal(size=(2, 2048, 5)).astype(np.float32)
+    pooled, empty = roipool3d_utils.roipool3d_gpu(T(rp), T(rfeat), T(rboxes), 0.2, sampled_pt_num=64)
+    out.update(roi_pts=rp, roi_feat=rfeat, roi_boxes=rboxes, roi_pooled=_np(pooled), roi_empty=_np(empty))
+
+    mgm.save("glue_ref.npz", source="reference python layer over the CPU oracle's extension entry points", **out)
+
+
+if __name__ == "__main__":
+    main()

@@ -106,3 +106,88 @@ def test_roipool3d_forward_and_forward_slow_shims(fn, oracle):
     wp, we = oracle.roipool3d(xyz, feats, boxes, s)
     assert np.array_equal(pooled.cpu().numpy(), wp) and np.array_equal(empty.cpu().numpy(), we)
     assert we[0, 0] == 1 and we.sum() < b * m
+
+
+# ------------------------------------------------------------------ the reference's PYTHON layer (tests/golden/glue_ref.npz)
+def test_operator_and_module_layer_against_the_references_python_layer():
+    """jmodt_amd.ops.{pointnet2, iou3d, roipool3d} — same function / class names and call forms as the reference's files —
+    against glue_ref.npz: the outputs of the REFERENCE's own pointnet2_utils.py / pointnet2_modules.py / iou3d_utils.py /
+    roipool3d_utils.py executed in the authoring container over the CPU oracle's extension entry points
+    (tests/golden/make_golden_glue.py).  Pins argument orders, zero-fill / back-fill conventions, QueryAndGroup's
+    concatenation order, GroupAll, three_nn's sqrt, the interpolation weights, the eval-mode module composition (also on the
+    fused kernels), the 3-D IoU arithmetic, the NMS score order and the box enlargement of roipool3d_gpu to the reference's code."""
+    import os
+    from jmodt_amd.ops.iou3d import iou3d_utils
+    from jmodt_amd.ops.pointnet2 import pointnet2_modules as mods
+    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
+    from jmodt_amd.ops.roipool3d import roipool3d_utils
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glue_ref.npz"))
+    G = lambda k: torch.from_numpy(g[k]).to(DEV)      # noqa: E731
+
+    def close(got, key, tol=1e-4):
+        want = g[key]
+        got = got.detach().cpu().numpy()
+        assert got.shape == want.shape, (key, got.shape, want.shape)
+        assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max()), (key, np.abs(got - want).max())
+
+    # ---- operator layer
+    xyz, feats = G("op_xyz"), G("op_feats")
+    fps = pu.farthest_point_sample(xyz, 96)
+    assert np.array_equal(fps.cpu().numpy(), g["op_fps"])
+    new_xyz = pu.gather_operation(xyz.transpose(1, 2).contiguous(), fps).transpose(1, 2).contiguous()
+    assert np.array_equal(new_xyz.cpu().numpy(), g["op_new_xyz"])
+    bq = pu.ball_query(0.9, 16, xyz, new_xyz)
+    assert np.array_equal(bq.cpu().numpy(), g["op_ball"])
+    f = feats.clone().requires_grad_(True)
+    grouped = pu.grouping_operation(f, bq)
+    assert np.array_equal(grouped.detach().cpu().numpy(), g["op_grouped"])
+    (grouped * G("op_group_w")).sum().backward()
+    close(f.grad, "op_group_grad", 1e-5)
+    assert np.array_equal(pu.QueryAndGroup(0.9, 16, use_xyz=True)(xyz, new_xyz, feats).cpu().numpy(), g["op_qg"])
+    assert np.array_equal(pu.QueryAndGroup(0.9, 16, use_xyz=True)(xyz, new_xyz, None).cpu().numpy(), g["op_qg_nofeat"])
+    assert np.array_equal(pu.QueryAndGroup(0.9, 16, use_xyz=False)(xyz, new_xyz, feats).cpu().numpy(), g["op_qg_noxyz"])
+    assert np.array_equal(pu.GroupAll(use_xyz=True)(xyz, None, feats).cpu().numpy(), g["op_group_all"])
+    dist, nn_idx = pu.three_nn(xyz, new_xyz)
+    assert np.array_equal(nn_idx.cpu().numpy(), g["op_nn_idx"])
+    close(dist, "op_nn_dist", 1e-6)
+    w = 1.0 / (dist + 1e-8)
+    w = w / w.sum(dim=2, keepdim=True)
+    kf = G("op_known_feats").requires_grad_(True)
+    interp = pu.three_interpolate(kf, nn_idx, w)
+    close(interp, "op_interp", 1e-5)
+    (interp * G("op_interp_w")).sum().backward()
+    close(kf.grad, "op_interp_grad", 1e-5)
+    gs = feats.clone().requires_grad_(True)
+    gathered = pu.gather_operation(gs, fps)
+    assert np.array_equal(gathered.detach().cpu().numpy(), g["op_gathered"])
+    (gathered * G("op_gather_w")).sum().backward()
+    close(gs.grad, "op_gather_grad", 1e-5)
+
+    # ---- module layer: the reference's state dicts load as they are (same parameter names)
+    def load(module, prefix):
+        sd = {k[len(prefix) + 1:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix + ".")}
+        missing, unexpected = module.load_state_dict(sd, strict=False)
+        assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+        return module.to(DEV).eval()
+    sa = load(mods.PointnetSAModuleMSG(npoint=64, radii=[0.8, 1.6], nsamples=[16, 32], mlps=[[7, 16, 16, 32], [7, 16, 24, 48]],
+                                       use_xyz=True, bn=True), "sa")
+    sa_all = load(mods.PointnetSAModule(mlp=[32 + 48, 64, 96], use_xyz=True, bn=True), "sa_all")
+    fp = load(mods.PointnetFPModule(mlp=[80 + 7, 40, 24], bn=True), "fp")
+    for fuse in (True, False):                          # the fused kernels and the operator route
+        for m in (sa, sa_all):
+            m.fuse = fuse
+        with torch.no_grad():
+            sx, sf = sa(xyz, feats)[:2]
+            af = sa_all(sx, sf)[1]
+            ff = fp(xyz, sx, feats, sf)
+        assert np.array_equal(sx.cpu().numpy(), g["mod_sa_xyz"])
+        close(sf, "mod_sa_feat"); close(af, "mod_all_feat"); close(ff, "mod_fp_feat")
+
+    # ---- iou3d_utils / roipool3d_utils
+    a3, b3 = G("iou_a"), G("iou_b")
+    close(iou3d_utils.boxes_iou_bev(iou3d_utils.boxes3d_to_bev_torch(a3), iou3d_utils.boxes3d_to_bev_torch(b3)), "iou_bev", 1e-5)
+    close(iou3d_utils.boxes_iou3d_gpu(a3, b3), "iou_3d", 1e-5)
+    assert np.array_equal(iou3d_utils.nms_gpu(G("nms_boxes"), G("nms_scores"), 0.3).cpu().numpy(), g["nms_keep_rot"])
+    assert np.array_equal(iou3d_utils.nms_normal_gpu(G("nms_boxes"), G("nms_scores"), 0.5).cpu().numpy(), g["nms_keep_normal"])
+    pooled, empty = roipool3d_utils.roipool3d_gpu(G("roi_pts"), G("roi_feat"), G("roi_boxes"), 0.2, sampled_pt_num=64)
+    assert np.array_equal(pooled.cpu().numpy(), g["roi_pooled"]) and np.array_equal(empty.cpu().numpy(), g["roi_empty"])

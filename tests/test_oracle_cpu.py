@@ -460,3 +460,46 @@ def test_box_decoders_vs_reference_decode_bbox_target(oracle):
         assert np.abs(got - gd[f"{tag}_proposals"]).max() < 2e-5, tag
         got = oracle.decode_rcnn_boxes(gd[f"{tag}_rois"], gd[f"{tag}_rcnn_reg"], cs, cb, int(ch), gd["mean_size"], avg)
         assert np.abs(got - gd[f"{tag}_boxes"]).max() < 2e-5, tag
+
+
+# ------------------------------------------------------------------ the reference's PYTHON layer (tests/golden/glue_ref.npz)
+def _glue():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glue_ref.npz"))
+
+
+def test_oracle_compositions_match_reference_python_layer(oracle):
+    """glue_ref.npz = the reference's own pointnet2_utils / iou3d_utils / roipool3d_utils executed over the oracle's extension
+    entry points (tests/golden/make_golden_glue.py).  The oracle-level COMPOSITIONS the GPU tests use as expected values must
+    reproduce them: 3-D IoU arithmetic, NMS score order + keep gathering, box enlargement + roipool, three_nn's sqrt"""
+    g = _glue()
+    assert np.allclose(oracle.boxes_iou3d(g["iou_a"], g["iou_b"]), g["iou_3d"], rtol=0, atol=1e-6)
+    assert (g["iou_3d"] > 0.3).sum() >= 5
+    assert np.array_equal(oracle.boxes_iou_bev(oracle.boxes3d_to_bev(g["iou_a"]), oracle.boxes3d_to_bev(g["iou_b"])), g["iou_bev"])
+    assert np.array_equal(oracle.nms(g["nms_boxes"], g["nms_scores"], 0.3, normal=False), g["nms_keep_rot"])
+    assert np.array_equal(oracle.nms(g["nms_boxes"], g["nms_scores"], 0.5, normal=True), g["nms_keep_normal"])
+    assert 20 < len(g["nms_keep_rot"]) < 300
+    pooled, empty = oracle.roipool3d(g["roi_pts"], g["roi_feat"], np.stack([oracle.enlarge_box3d(b, 0.2) for b in g["roi_boxes"]]), 64)
+    assert np.array_equal(pooled, g["roi_pooled"]) and np.array_equal(empty, g["roi_empty"])
+    d2, idx = oracle.three_nn(g["op_xyz"], g["op_new_xyz"])
+    assert np.array_equal(idx, g["op_nn_idx"]) and np.allclose(np.sqrt(d2), g["op_nn_dist"], rtol=2e-7, atol=0)   # (torch.sqrt: <= 1 ulp)
+
+
+def test_chained_oracle_modules_match_reference_modules():
+    """oracle/pipeline.Chain's set-abstraction (MSG and GroupAll) and feature-propagation restatements — what the composed
+    GPU tests compare the engine with — against the reference's PointnetSAModuleMSG / PointnetSAModule / PointnetFPModule
+    forward (eval mode, seeded weights) from glue_ref.npz"""
+    import torch
+    from oracle.pipeline import Chain
+    g = _glue()
+    sd = {k: torch.from_numpy(g[k]) for k in g.files if k.split(".")[0] in ("sa", "sa_all", "fp")}
+    for dtype, tol in ((torch.float32, 2e-5), (torch.float64, 2e-5)):
+        ch = Chain(sd, None, dtype)
+        feats = torch.from_numpy(g["op_feats"]).to(dtype)
+        new_xyz, f, idx = ch.sa_module("sa", g["op_xyz"], feats, 64, [0.8, 1.6], [16, 32])
+        assert np.array_equal(new_xyz, g["mod_sa_xyz"])
+        assert f.shape == (2, 80, 64) and (f.float().numpy() - g["mod_sa_feat"]).__abs__().max() <= tol * max(1.0, np.abs(g["mod_sa_feat"]).max())
+        _, fa, _ = ch.sa_module("sa_all", new_xyz, torch.from_numpy(g["mod_sa_feat"]).to(dtype), None, [None], [None])
+        assert fa.shape == (2, 96, 1) and (fa.float().numpy() - g["mod_all_feat"]).__abs__().max() <= tol * max(1.0, np.abs(g["mod_all_feat"]).max())
+        fp = ch.fp_module("fp", g["op_xyz"], new_xyz, feats, torch.from_numpy(g["mod_sa_feat"]).to(dtype))
+        assert fp.shape == (2, 24, 600) and (fp.float().numpy() - g["mod_fp_feat"]).__abs__().max() <= tol * max(1.0, np.abs(g["mod_fp_feat"]).max())
+    assert np.abs(g["mod_sa_feat"]).max() > 0.1 and np.abs(g["mod_fp_feat"]).max() > 0.1
