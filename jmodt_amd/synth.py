@@ -186,3 +186,26 @@ def frames(B, N, seed, H=384, W=1280, native=(375, 1242), dup_frac=0.1, kind="un
     else:
         raise ValueError(kind)
     return pts, image(B, seed + 1, H, W, native), pts_xy(pts, W, H)
+
+
+def seeded_state(shapes, seed):
+    """{key: float32 array} for a model state dict given as {key: shape}: a deterministic fill that depends on the sorted keys
+    and shapes only, so that two implementations with the same parameter names (the reference's PointRCNN and the engine
+    here) get identical weights from a seed instead of from a stored state dict.  Conv / Linear weights ~ N(0, 2 / fan_in),
+    1-d tensors: BatchNorm scale and running variance in [0.5, 1.5), running means N(0, 0.3^2), every bias N(0, 0.1^2)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for k in sorted(shapes):
+        shp = tuple(int(v) for v in shapes[k])
+        if k.endswith("num_batches_tracked"):
+            continue
+        if len(shp) >= 2:
+            fan_in = int(np.prod(shp[1:]))
+            out[k] = (rng.standard_normal(shp) * np.sqrt(2.0 / max(fan_in, 1))).astype(np.float32)
+        elif k.endswith("running_var") or (k.endswith("weight")):
+            out[k] = (rng.random(shp) + 0.5).astype(np.float32)
+        elif k.endswith("running_mean"):
+            out[k] = (rng.standard_normal(shp) * 0.3).astype(np.float32)
+        else:
+            out[k] = (rng.standard_normal(shp) * 0.1).astype(np.float32)
+    return out

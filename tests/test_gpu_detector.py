@@ -730,3 +730,43 @@ def test_engine_stream_safety_soak(run):
     with torch.no_grad():
         eng(a, img, xy)                                    # consume the last announcement
     assert eng._prefetched is None and eng._prefetched_img is None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the reference's COMPLETE forward (tests/golden/forward_ref.npz: PointRCNN.forward in TEST mode, executed in the
+# authoring container over the CPU oracle's extension entry points, tests/golden/make_golden_forward.py)
+# ------------------------------------------------------------------------------------------------------------------
+def test_engine_matches_the_references_complete_forward():
+    """DetectAffinityEngine with the SAME weights (same parameter names: strict load) on the same frames: backbone + LI-Fusion +
+    RPN heads free running; proposal layer, RoI pooling + canonical transform and the RCNN teacher-forced on the reference's own
+    intermediate outputs; fused and un-fused, with and without the duplicate compaction"""
+    from jmodt_amd.detector import DetectAffinityEngine
+    from tests.test_oracle_cpu import reference_forward_fixture
+    cfg, sd, g = reference_forward_fixture()
+    eng = DetectAffinityEngine(cfg)
+    own = eng.state_dict()
+    extra = {k: v for k, v in own.items() if k not in sd}                      # (the engine's BatchNorm counters)
+    assert all(k.endswith("num_batches_tracked") for k in extra) and not [k for k in sd if k not in own]
+    eng.load_state_dict({**extra, **sd}, strict=True)
+    eng = eng.to(DEV).eval()
+    xyz, img, xy = T(g["xyz"]), T(g["img"]), T(g["pts_xy"])
+    ref_rpn = dict(backbone_xyz=xyz, backbone_features=T(g["out.backbone_features"]), rpn_cls=T(g["out.rpn_cls"]), rpn_reg=T(g["out.rpn_reg"]))
+    for fuse, dedupe in ((True, True), (True, False), (False, False)):
+        for m_ in eng.modules():
+            if hasattr(m_, "fuse"):
+                m_.fuse = fuse
+        eng.dedupe_rcnn = dedupe
+        with torch.no_grad():
+            cache, aff, inter = eng(xyz, img, xy)
+            close(inter["backbone_features"], g["out.backbone_features"])
+            close(inter["rpn_cls"], g["out.rpn_cls"]); close(inter["rpn_reg"], g["out.rpn_reg"])
+            rois, scores = eng.proposals(ref_rpn)
+            close(rois, g["out.rois"]); close(scores, g["out.roi_scores_raw"], 1e-6)
+            pts = eng.roi_pool(ref_rpn, T(g["out.rois"]))
+            got = pts.cpu().numpy()
+            assert np.array_equal(got[..., 3], g["out.pts_input_geom"][..., 3])
+            close(got[..., :3], g["out.pts_input_geom"][..., :3]); close(got[..., 4], g["out.pts_input_geom"][..., 4], 1e-6)
+            close(got.astype(np.float64).sum(axis=(1, 2)), g["out.pts_input_sum"], 1e-6)
+            out = eng.rcnn_forward(pts)
+            close(out["rcnn_feat"], g["out.rcnn_feat"]); close(out["rcnn_cls"], g["out.rcnn_cls"]); close(out["rcnn_reg"], g["out.rcnn_reg"])
+    assert 0 < g["out.pts_input_geom"][..., 3].mean() < 1 and np.abs(g["out.rcnn_feat"]).max() > 1.0
