@@ -18,6 +18,14 @@ the reference does with PyTorch (convolutions, BatchNorm, Linear, grid_sample, s
 PyTorch CPU operators here, un-fused and un-folded, in `dtype` (float32 = the reference's arithmetic and the
 cpu_baseline leg; float64 = a tighter checker for the GPU path).  Weights come from a state_dict with the
 reference's parameter names.
+
+PINNED against the reference itself: tests/golden/forward_ref.npz holds the outputs of the reference's own
+PointRCNN.forward (TEST mode) executed in the authoring container over oracle.py's extension entry points
+(tests/golden/make_golden_forward.py); tests/test_oracle_cpu.py::test_chained_oracle_matches_the_references_complete_forward
+checks backbone + RPN heads, proposal layer, RoI pooling + canonical transform and the RCNN of this file against it, and
+glue_ref.npz does the same for sa_module / fp_module alone.  The detection post-processing and the inference affinity are
+pinned by decode_ref.npz / affinity_ref.npz.  What no fixture can pin here are the CUDA kernels inside oracle.py's
+restatements (the reference has no CPU code for them): "parity unpinned" for those, as oracle/jmodt_oracle.c says.
 """
 from typing import Dict, List, Optional
 
