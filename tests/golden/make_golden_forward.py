@@ -50,9 +50,8 @@ def L(x):
     return [L(v) for v in x] if isinstance(x, (tuple, list)) else x
 
 
-def main():
-    glue.import_reference_with_oracle_extensions()
-    from jmodt.config import cfg
+def apply_mini(cfg):
+    """write the reduced configuration into the reference's cfg (before any model is constructed)"""
     m = MINI
     cfg.RPN.SA_CONFIG.NPOINTS, cfg.RPN.SA_CONFIG.RADIUS = L(m["sa_npoints"]), L(m["sa_radius"])
     cfg.RPN.SA_CONFIG.NSAMPLE, cfg.RPN.SA_CONFIG.MLPS = L(m["sa_nsample"]), L(m["sa_mlps"])
@@ -65,6 +64,13 @@ def main():
     cfg.RCNN.SA_CONFIG.NSAMPLE, cfg.RCNN.SA_CONFIG.MLPS = L(m["rcnn_sa_nsample"]), L(m["rcnn_sa_mlps"])
     cfg.RCNN.CLS_FC, cfg.RCNN.REG_FC = L(m["rcnn_cls_fc"]), L(m["rcnn_reg_fc"])
     cfg.REID.LINK_FC, cfg.REID.SE_FC = L(m["link_fc"]), L(m["se_fc"])
+
+
+def main():
+    glue.import_reference_with_oracle_extensions()
+    from jmodt.config import cfg
+    m = MINI
+    apply_mini(cfg)
     from jmodt.detection.modeling.point_rcnn import PointRCNN
 
     model = PointRCNN(num_classes=2, use_xyz=True, mode="TEST").eval()

@@ -376,3 +376,33 @@ def test_affinity_split_bf16_error_not_above_exact_fp32(nb, P, D, C):
     assert ex3 <= max(e32 * 1.25, 1e-6), (ex3, e32)
     wantA = (torch.softmax(want, 2) + torch.softmax(want, 1)) / 2
     assert (Ax3.double() - wantA).abs().max().item() < 1e-5 and (A32.double() - wantA).abs().max().item() < 1e-5
+
+
+def test_training_affinity_hip_kernels_vs_the_references_train_forward_and_loss():
+    """a16 on the matrix cores against train_ref.npz — the reference's own PointRCNN.forward in TRAIN mode, its re-id loss
+    (get_rcnn_loss under FINETUNE) and the gradients its autograd produced (tests/golden/make_golden_train.py): per-pair link
+    scores as multisets (the reference orders a pair's rows by track id, the static form by RoI slot), start / end
+    probabilities, the loss and all twelve gradient tensors"""
+    from jmodt_amd.ops.affinity_train import AffinityTrainState, affinity_train_loss, training_affinity_hip
+    from tests.test_oracle_cpu import reference_train_fixture
+    g, link, se = reference_train_fixture()
+    link, se = link.to(DEV).train(), se.to(DEV).train()
+    feats, tids = torch.from_numpy(g["roi_feat"]).to(DEV), torch.from_numpy(g["gt_tids"]).to(DEV)
+    w_link, w_se = float(g["weights"][0]), float(g["weights"][1])
+    out = training_affinity_hip(feats, tids, link, se)
+    v, sv, ev = out["valid"], out["start_valid"], out["end_valid"]
+    assert int(v.sum()) == g["rcnn_link"].size and int(sv.sum()) == g["gt_starts"].size and int(ev.sum()) == g["gt_ends"].size
+    assert (torch.sort(out["link"][v].cpu())[0] - torch.sort(torch.from_numpy(g["rcnn_link"]).view(-1))[0]).abs().max().item() < 1e-5
+    assert (torch.sort(torch.sigmoid(out["start"][sv]).cpu())[0]
+            - torch.sort(torch.sigmoid(torch.from_numpy(g["rcnn_start"]).view(-1)))[0]).abs().max().item() < 1e-5
+    assert (torch.sort(torch.sigmoid(out["end"][ev]).cpu())[0]
+            - torch.sort(torch.sigmoid(torch.from_numpy(g["rcnn_end"]).view(-1)))[0]).abs().max().item() < 1e-5
+    assert int(out["gt_links"][v].sum()) == int(g["gt_links"].sum())
+    loss = affinity_train_loss(AffinityTrainState(feats, tids), link, se, link_weight=w_link, se_weight=w_se)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    loss.backward()
+    for head, mod in (("link_layer", link), ("se_layer", se)):
+        for k, p_ in mod.named_parameters():
+            want = g[f"grad.rcnn_net.{head}.{k}"]
+            got = p_.grad.cpu().numpy()
+            assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-12) + 1e-7, (head, k)

@@ -560,3 +560,52 @@ def test_chained_oracle_matches_the_references_complete_forward(oracle):
 
 def _np64(t):
     return (t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)).astype(np.float64)
+
+
+# ------------------------------------------------------------------ the reference's TRAINING affinity + re-id loss (train_ref.npz)
+def reference_train_fixture():
+    """(npz, link_layer, se_layer with the reference's weights) of train_ref.npz: the reference's PointRCNN.forward in TRAIN mode +
+    get_rcnn_loss (FINETUNE) + autograd, run by tests/golden/make_golden_train.py"""
+    import json
+    import torch
+    from jmodt_amd.ops.affinity import make_affinity_mlp
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_ref.npz"))
+    sd = synth.seeded_state(json.loads(str(g["keys"])), int(g["seed"]))
+    C = g["roi_feat"].shape[2]
+    heads = []
+    for h in ("link_layer", "se_layer"):
+        m = make_affinity_mlp(C, tuple(json.loads(str(g["config"]))["link_fc" if h == "link_layer" else "se_fc"]))
+        pre = f"rcnn_net.{h}."
+        m.load_state_dict({k[len(pre):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith(pre)}, strict=True)
+        heads.append(m)
+    return g, heads[0], heads[1]
+
+
+def test_training_affinity_restatements_match_the_references_train_forward_and_loss():
+    """ops/affinity_train.py on CPU — the looped restatement (rcnn.py:204-287) and the static-shape form the HIP kernels
+    implement — against the reference's own TRAIN-mode forward outputs, its re-id loss (get_rcnn_loss under FINETUNE) and the
+    gradients autograd gave the reference for the twelve head tensors"""
+    import torch
+    from jmodt_amd.ops.affinity_train import reid_loss, reid_loss_static, training_affinity, training_affinity_static
+    g, link, se = reference_train_fixture()
+    feats, tids = torch.from_numpy(g["roi_feat"]), torch.from_numpy(g["gt_tids"])
+    w_link, w_se = float(g["weights"][0]), float(g["weights"][1])
+    out = training_affinity(feats, tids, link, se)                    # same row order as the reference (torch.unique per pair)
+    for k in ("rcnn_link", "rcnn_start", "rcnn_end", "gt_links", "gt_starts", "gt_ends"):
+        _close(out[k].reshape(g[k].shape), g[k], 1e-5)
+    loss = reid_loss(out, w_link, w_se)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 and g["rcnn_link"].shape[0] >= 40 and g["gt_links"].sum() >= 4
+    params = list(link.parameters()) + list(se.parameters())
+    names = [f"rcnn_net.link_layer.{k}" for k, _ in link.named_parameters()] + [f"rcnn_net.se_layer.{k}" for k, _ in se.named_parameters()]
+    for p_, got in zip(names, torch.autograd.grad(loss, params, allow_unused=True)):
+        want = g["grad." + p_]
+        got = torch.zeros_like(torch.from_numpy(want)) if got is None else got
+        assert np.abs(got.numpy() - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-12) + 1e-8, p_
+    st = training_affinity_static(feats, tids, link, se)
+    ls, counts = reid_loss_static(st, None, w_link, w_se)
+    assert abs(ls.item() - float(g["loss"])) < 1e-5
+    assert counts.tolist() == [g["gt_links"].size, g["gt_starts"].size, g["gt_ends"].size]
+    for p_, got in zip(names, torch.autograd.grad(ls, params, allow_unused=True)):
+        want = g["grad." + p_]
+        got = torch.zeros_like(torch.from_numpy(want)) if got is None else got
+        assert np.abs(got.numpy() - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-12) + 1e-8, p_
