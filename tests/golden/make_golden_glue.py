@@ -10,7 +10,9 @@ What is executed is the reference's own Python, imported from /root/reference:
     forward with seeded weights / BatchNorm statistics in eval mode;
   * jmodt/ops/iou3d/iou3d_utils.py — boxes_iou_bev, boxes_iou3d_gpu (the height / volume arithmetic around the BEV overlap),
     nms_gpu, nms_normal_gpu (score order, keep gathering);
-  * jmodt/ops/roipool3d/roipool3d_utils.py — roipool3d_gpu (box enlargement + call).
+  * jmodt/ops/roipool3d/roipool3d_utils.py — roipool3d_gpu (box enlargement + call);
+  * jmodt/tracking/data_association.py — boxes_dist_gpu and the boxes_iou3d_gpu it imports (the two geometric terms of the
+    tracker's cost matrix).
 The CUDA extension modules those files call cannot exist here (no nvcc, no GPU).  Their fifteen entry points are bound,
 under the extension modules' names and with the argument orders of pointnet2_api.cpp:10-24 / iou3d.cpp:170-175 /
 roipool3d.cpp:198-203, to this repository's CPU oracle (oracle/jmodt_oracle.c), and the `torch.cuda.*Tensor` constructors /
@@ -207,6 +209,20 @@ def main():
     rfeat = rng.normal(size=(2, 2048, 5)).astype(np.float32)
     pooled, empty = roipool3d_utils.roipool3d_gpu(T(rp), T(rfeat), T(rboxes), 0.2, sampled_pt_num=64)
     out.update(roi_pts=rp, roi_feat=rfeat, roi_boxes=rboxes, roi_pooled=_np(pooled), roi_empty=_np(empty))
+
+    # ---- tracker cost-matrix terms (jmodt/tracking/data_association.py:10-28 boxes_dist_gpu, :42-44 the weighted sum's operands).
+    # The module imports `ortools` (absent here) for its MIP solver: an empty module is registered under that name, none of
+    # its functions is called.
+    for name in ("ortools", "ortools.linear_solver", "ortools.linear_solver.pywraplp"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["ortools.linear_solver"].pywraplp = sys.modules["ortools.linear_solver.pywraplp"]
+    from jmodt.tracking import data_association
+    pred = synth.proposals(pts, 20, 85)[0]
+    det = synth.proposals(pts, 17, 86)[0]
+    det[:8] = pred[:8] + rng.normal(0, 0.2, (8, 7)).astype(np.float32)             # tracked objects: overlapping pairs
+    a_iou = data_association.boxes_iou3d_gpu(T(pred), T(det))
+    a_dist = data_association.boxes_dist_gpu(T(pred), T(det))
+    out.update(assoc_pred=pred, assoc_det=det, assoc_iou=_np(a_iou), assoc_dist=_np(a_dist))
 
     mgm.save("glue_ref.npz", source="reference python layer over the CPU oracle's extension entry points", **out)
 

@@ -189,5 +189,12 @@ def test_operator_and_module_layer_against_the_references_python_layer():
     close(iou3d_utils.boxes_iou3d_gpu(a3, b3), "iou_3d", 1e-5)
     assert np.array_equal(iou3d_utils.nms_gpu(G("nms_boxes"), G("nms_scores"), 0.3).cpu().numpy(), g["nms_keep_rot"])
     assert np.array_equal(iou3d_utils.nms_normal_gpu(G("nms_boxes"), G("nms_scores"), 0.5).cpu().numpy(), g["nms_keep_normal"])
+    # tracker cost-matrix terms (jmodt/tracking/data_association.py:10-28 boxes_dist_gpu, :42-44)
+    from jmodt_amd.ops.association import association_cost, boxes_dist_gpu
+    close(boxes_dist_gpu(G("assoc_pred"), G("assoc_det")), "assoc_dist", 1e-5)
+    link = torch.linspace(0, 1, g["assoc_iou"].size, device=DEV).view(*g["assoc_iou"].shape)
+    cost, iou, dist = association_cost(G("assoc_pred"), G("assoc_det"), link, 0.5, 0.3, 0.2, return_parts=True)
+    close(iou, "assoc_iou", 1e-5); close(dist, "assoc_dist", 1e-5)
+    assert (cost.cpu().numpy() - (link.cpu().numpy() * 0.5 + g["assoc_iou"] * 0.3 + g["assoc_dist"] * 0.2)).__abs__().max() < 1e-5
     pooled, empty = roipool3d_utils.roipool3d_gpu(G("roi_pts"), G("roi_feat"), G("roi_boxes"), 0.2, sampled_pt_num=64)
     assert np.array_equal(pooled.cpu().numpy(), g["roi_pooled"]) and np.array_equal(empty.cpu().numpy(), g["roi_empty"])

@@ -480,6 +480,12 @@ def test_oracle_compositions_match_reference_python_layer(oracle):
     assert 20 < len(g["nms_keep_rot"]) < 300
     pooled, empty = oracle.roipool3d(g["roi_pts"], g["roi_feat"], np.stack([oracle.enlarge_box3d(b, 0.2) for b in g["roi_boxes"]]), 64)
     assert np.array_equal(pooled, g["roi_pooled"]) and np.array_equal(empty, g["roi_empty"])
+    # tracker cost-matrix terms (data_association.py:10-28,42-44)
+    assert np.abs(oracle.boxes_dist(g["assoc_pred"], g["assoc_det"]) - g["assoc_dist"]).max() < 1e-5
+    assert np.abs(oracle.boxes_iou3d(g["assoc_pred"], g["assoc_det"]) - g["assoc_iou"]).max() < 1e-6 and (g["assoc_iou"] > 0.2).sum() >= 4
+    link = np.linspace(0, 1, g["assoc_iou"].size, dtype=np.float32).reshape(g["assoc_iou"].shape)
+    assert np.abs(oracle.association_cost(g["assoc_pred"], g["assoc_det"], link, 0.5, 0.3, 0.2)
+                  - (link * 0.5 + g["assoc_iou"] * 0.3 + g["assoc_dist"] * 0.2)).max() < 1e-5
     d2, idx = oracle.three_nn(g["op_xyz"], g["op_new_xyz"])
     assert np.array_equal(idx, g["op_nn_idx"]) and np.allclose(np.sqrt(d2), g["op_nn_dist"], rtol=2e-7, atol=0)   # (torch.sqrt: <= 1 ulp)
 
