@@ -155,3 +155,71 @@ def test_fused_sa_and_feature_gather_outputs_stay_in_bounds():
     L.check(lib.jm_feature_gather(2, 6, 11, 13, 101, L.dev(fm, torch.float32, "fm"), *[int(s) for s in fm.stride()],
                                   L.dev(xy, torch.float32, "xy"), ctypes.c_void_p(g.view.data_ptr()), L.stream_ptr()), "fg")
     assert g.intact()
+
+
+def test_round3_entries_stay_in_bounds_and_refuse_bad_arguments():
+    """jm_nms_normal_first_k_batched, jm_ball_query_grid_build / _query, the vector-pipe set-abstraction scale (sa_xyz.hip) through
+    jm_sa_mlp_forward: outputs and workspaces inside guarded allocations; capacity / workspace violations return an error"""
+    from jmodt_amd import _lib as L
+    from jmodt_amd.ops.pointnet2 import fused, pointnet2_utils as pu
+    from jmodt_amd.ops.pointnet2.pointnet2_modules import PointnetSAModuleMSG
+    lib = L.load()
+    f32, i32 = torch.float32, torch.int32
+    # ---- first-K NMS: ragged problems, K below / above the survivor counts
+    counts = [1001, 0, 65, 513]
+    nmax = 1001
+    boxes = np.zeros((len(counts), nmax, 5), np.float32)
+    for p, c in enumerate(counts):
+        if c:
+            b, s = synth.bev_boxes(c, 40 + p)
+            boxes[p, :c] = b[np.argsort(-s, kind="stable")]
+    tb, tc = T(boxes), T(np.array(counts, np.int32))
+    for k in (7, 600):
+        keep, num = Guard((len(counts), nmax), torch.int64, fill=-1), Guard((len(counts),), i32)
+        L.check(lib.jm_nms_normal_first_k_batched(len(counts), nmax, L.dev(tc, i32, "counts"), L.dev(tb, f32, "boxes"), 0.7, k,
+                                                  ctypes.c_void_p(keep.view.data_ptr()), ctypes.c_void_p(num.view.data_ptr()),
+                                                  L.stream_ptr()), "first_k")
+        assert keep.intact() and num.intact()
+        n = num.view.cpu().numpy()
+        assert n[1] == 0 and (n <= k).all() and n[0] == min(k, n[0])
+        for p in range(len(counts)):
+            assert (keep.view[p, n[p]:] == -1).all()            # nothing written behind the kept entries
+    assert lib.jm_nms_normal_first_k_batched(1, nmax, L.dev(tc, i32, "counts"), L.dev(tb, f32, "boxes"), 0.7, 4096,
+                                             ctypes.c_void_p(keep.view.data_ptr()), ctypes.c_void_p(num.view.data_ptr()),
+                                             L.stream_ptr()) != 0 and b"2048" in lib.jm_last_error()
+    # ---- hash-grid ball query in two calls: guarded workspace and index outputs, short workspace refused
+    B, N, M = 3, 2500, 333
+    xyz = T(synth.kitti_like_cloud(B, N, 9))
+    cen = xyz[:, :M].contiguous()
+    wsb = lib.jm_ball_query_workspace_bytes(B, N)
+    assert wsb > 0
+    if PAD % 64 == 0:
+        ws = Guard((wsb // 4,), i32)
+    else:       # the workspace must be 256-byte aligned (header): the misaligning variant keeps it in a plain allocation
+        ws = type("Plain", (), {"view": torch.empty((wsb // 4,), dtype=i32, device=DEV), "intact": lambda self: True})()
+    i0, i1 = Guard((B, M, 16), i32, fill=0), Guard((B, M, 32), i32, fill=0)
+    L.check(lib.jm_ball_query_grid_build(B, N, 0.8, L.dev(xyz, f32, "xyz"), ctypes.c_void_p(ws.view.data_ptr()), wsb, L.stream_ptr()), "build")
+    L.check(lib.jm_ball_query_grid_query(B, N, M, 0.8, 0.4, 16, 0.8, 32, L.dev(cen, f32, "c"), ctypes.c_void_p(i0.view.data_ptr()),
+                                         ctypes.c_void_p(i1.view.data_ptr()), ctypes.c_void_p(ws.view.data_ptr()), wsb, L.stream_ptr()), "query")
+    assert ws.intact() and i0.intact() and i1.intact()
+    assert torch.equal(i0.view, pu.ball_query(0.4, 16, xyz, cen)) and torch.equal(i1.view, pu.ball_query(0.8, 32, xyz, cen))
+    assert lib.jm_ball_query_grid_build(B, N, 0.8, L.dev(xyz, f32, "xyz"), ctypes.c_void_p(ws.view.data_ptr()), wsb // 2, L.stream_ptr()) != 0
+    # ---- xyz-only scale on the vector pipe (npoint a multiple of 64 / 32: jm_sa_mlp_supported == 3)
+    torch.manual_seed(1)
+    sa = PointnetSAModuleMSG(npoint=192, radii=[0.5, 1.0], nsamples=[16, 32], mlps=[[0, 16, 16, 32], [0, 32, 32, 64]], bn=True).to(DEV).eval()
+    pts = T(synth.dense_cloud(2, 1500, 6, extent=5.0))
+    with torch.no_grad():
+        idx = pu.farthest_point_sample(pts, 192)
+        new_xyz = pu.gather_operation(pts.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+        for k, (r, ns, cout) in enumerate(((0.5, 16, 32), (1.0, 32, 64))):
+            nb = pu.ball_query(r, ns, pts, new_xyz)
+            layers = fused._packed_layers(sa.mlps[k], pts.device)
+            widths = (ctypes.c_int * 4)(3, *[l[2] for l in layers])
+            assert lib.jm_sa_mlp_supported(2, 1500, 192, 0, ns, 0, 3, widths) == 3
+            out = Guard((2, cout, 192), f32)
+            warr = (ctypes.c_void_p * 3)(*[l[0].data_ptr() for l in layers])
+            barr = (ctypes.c_void_p * 3)(*[l[1].data_ptr() for l in layers])
+            L.check(lib.jm_sa_mlp_forward(2, 1500, 192, 0, ns, L.dev(pts, f32, "xyz"), L.dev(new_xyz, f32, "c"), None,
+                                          L.dev(nb, i32, "i"), 3, widths, warr, barr, ctypes.c_void_p(out.view.data_ptr()),
+                                          L.stream_ptr()), "sa_xyz")
+            assert out.intact() and torch.isfinite(out.view).all() and out.view.abs().max() > 0
