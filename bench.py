@@ -139,12 +139,15 @@ def cpu_baseline_detect(frames=2, dev=None):
     dt = time.perf_counter() - t0
     # BASELINE configs[0] on its own: the link / start-end head on 64 cached proposal features, PyTorch-CPU
     f64 = torch.relu(torch.randn(2, 64, cfg.rcnn_sa_mlps[-1][-1]))
-    with torch.no_grad():
-        chain.affinity(f64[0], f64[1])
-        t1 = time.perf_counter()
+    with torch.no_grad():                                   # 3 warm-up passes, median of 10
         for _ in range(3):
             chain.affinity(f64[0], f64[1])
-        aff64 = (time.perf_counter() - t1) / 3
+        ts = []
+        for _ in range(10):
+            t1 = time.perf_counter()
+            chain.affinity(f64[0], f64[1])
+            ts.append(time.perf_counter() - t1)
+        aff64 = sorted(ts)[len(ts) // 2]
     parity = None
     if dev is not None:
         eng = eng.to(dev)
@@ -838,7 +841,7 @@ def main():
                 extra = {}
                 if args.workload == "detect":
                     fps, dt, stages, aff64, parity = cpu_baseline_detect(2, dev)
-                    extra = {"stage_seconds": stages, "configs0_affinity_64x64_pytorch_cpu_ms": round(aff64 * 1e3, 2),
+                    extra = {"stage_seconds": stages, "configs0_affinity_64x64_pytorch_cpu_ms": round(aff64 * 1e3, 2),   # median of 10 after 3 warm-ups
                              "gpu_vs_chain": parity}
                     sample = (f"2 full-size frames (one (prev, next) pair) through the chained CPU oracle in {dt:.1f} s: "
                               "oracle C restatement for the jmodt ops (the reference has no CPU code for them), the "
