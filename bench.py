@@ -553,15 +553,28 @@ def main():
             with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
                 sk.bind(("127.0.0.1", 0))
                 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
+        # Two process groups.  CONTROL plane (the barriers around the timed region, the MAX of the elapsed times): gloo — it
+        # needs no GPU resources.  DATA plane: RCCL, created ONLY for the workload that has a collective on its path (train: the
+        # gradient all-reduce); the inference workloads are replicas without any exchange, and a live RCCL
+        # communicator costs them throughput for nothing: with it, the same single-GPU step measures 572 instead of 609
+        # frames/s (detect) and 380 instead of 505 (train) — per-kernel times unchanged, more gaps between the launches of the
+        # engine's five streams (measured with JM_BENCH_FORCE_DIST=1; GPU_MAX_HW_QUEUES and the NCCL_* / RCCL_* channel knobs do
+        # not bring it back).  The training step pays that price because it needs the collective.
         # stdout carries exactly one JSON line.  RCCL prints a version banner to fd 1 when the communicator is
         # created (NCCL_DEBUG=VERSION in this image), so fd 1 points at stderr while that happens.
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=dev)
-            dist.barrier()                       # creates the communicator (and prints the banner) now
-            torch.cuda.synchronize()
+            if args.workload == "train":
+                dist.init_process_group("nccl", device_id=dev)
+                ctl = dist.new_group(backend="gloo")
+                dist.barrier()                   # creates the communicator (and prints the banner) now
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group("gloo")
+                ctl = dist.group.WORLD
+            dist.barrier(group=ctl)
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
@@ -621,7 +634,7 @@ def main():
     gc.collect()
     gc.disable()   # a generation-2 collection in the middle of the timed region is a 30-40 ms host stall
     if dist is not None:
-        dist.barrier()
+        dist.barrier(group=ctl)
     prof.reset()
     prof.only = {dom_key} if dom_key else None
     prof.enabled = True
@@ -634,9 +647,9 @@ def main():
     elapsed = time.perf_counter() - t0
     prof.enabled = False
     if dist is not None:
-        dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier(group=ctl)
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
         elapsed = float(t.item())
     timed_rows = prof.summary(args.steps, HBM_PEAK_GBS, MFMA_F32_PEAK_TF)
     table_steps = args.steps
@@ -660,7 +673,7 @@ def main():
         bq_evals = _pu.ball_query_evals()          # distance evaluations the grid searches really did (device counters)
         nms_evals = _pp.nms_evals()                # IoU evaluations of the RPN's lazy first-K NMS vs its full pair masks
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=ctl)
 
     # the same workload with one overlap mechanism off at a time (a few steps, after the timed region, outside `value`)
     variants = {}
@@ -728,7 +741,7 @@ def main():
             step(); step()
             torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=ctl)
 
     if rank == 0:
         kernels = prof.summary(table_steps, HBM_PEAK_GBS, MFMA_F32_PEAK_TF)
@@ -814,7 +827,11 @@ def main():
             "config": {"workload": WORKLOAD_TEXT[args.workload] + (" [TINY smoke shapes: not a benchmark]" if args.tiny else ""),
                        "frames_per_gpu_per_step": args.batch,
                        "points": (65536 if args.workload in ("dense", "dense_detect") else 16384) if not args.tiny else "tiny",
-                       "parallelism": f"dp{world} (gradient all-reduce)" if args.workload == "train" else f"replicas x{world}"},
+                       "parallelism": f"dp{world} (gradient all-reduce)" if args.workload == "train" else f"replicas x{world}",
+                       "process_groups": (None if dist is None else
+                                          ("data plane RCCL (gradient all-reduce), control plane gloo (barriers, max over ranks)"
+                                           if args.workload == "train" else
+                                           "no data-path collective (replicas): control plane gloo (barriers, max over ranks), no RCCL communicator"))},
             "roofline": roofline,
             "roofline_selection": "the jm entry with the largest speed-of-light time (executed flops / 157.3 TF, algorithmic bytes / 8 TB/s) "
                                   "of the main chain; measured times of small kernels include waits behind the other stream's convolutions",
@@ -832,6 +849,12 @@ def main():
                         "image_branch_exposed_ms": round(img_exposed, 4),
                         "note": "exposed = time the main stream is held at its wait on the side stream (HIP events "
                                 "either side of the wait); chain = sum of the FPS entry points on the side stream"},
+            "grad_allreduce": ({"world": world, "bytes_per_step": next((k.get("algo_bytes_per_step") for k in kernels
+                                                                         if k["kernel"].endswith("grad_allreduce(RCCL)")), None),
+                                "ms_per_step": next((k["ms_per_step"] for k in kernels if k["kernel"].endswith("grad_allreduce(RCCL)")), None),
+                                "note": "one flat fp32 all-reduce of the link / start-end heads' gradients per step (RCCL; HIP events on the "
+                                        "launching stream around the collective and its wait); world 1: no collective is issued"}
+                               if args.workload == "train" else None),
             "kernels_from": (f"{table_steps} fully instrumented steps after the timed region" if dom_key else "the timed region"),
             "kernels": kernels,
         }

@@ -346,7 +346,11 @@ def _finetune_step_hip(roi_features, gt_tids, link_layer, se_layer, optimizer, w
     optimizer.zero_grad(set_to_none=True)
     for p, g in zip(params, grads):             # the kernels wrote d(loss)/d(param) of THIS rank's sums over the GLOBAL counts
         p.grad = g
-    jdist.allreduce_gradients(params, world=world, average=False)
+    # ONE flat fp32 all-reduce of the twelve head tensors (4.2 MB at 512-wide heads) over RCCL; timed on this stream when the
+    # profiler is on (BASELINE.md §3 config 4 asks for the all-reduce time next to frames/s)
+    from ..profile import prof
+    prof.region("grad_allreduce(RCCL)", lambda: jdist.allreduce_gradients(params, world=world, average=False),
+                algo_bytes=sum(p.numel() for p in params) * 4)
     optimizer.step()
     total = _loss_from_parts(lp, sp, counts, 1.0, 1.0)
     if world > 1:
