@@ -532,6 +532,11 @@ def main():
     if args.batch is None:
         args.batch = 4 if args.workload == "train" else 8
 
+    if args.workload == "train":
+        # HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The RCCL communicator of the training
+        # step takes some of them, and the engine's four streams then serialise: 381 frames/s per GPU instead of 497-505
+        # (measured on one GPU, communicator alive; 6 or more queues restore it).  Read by the HIP runtime at initialisation.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.launch):
         sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -74,7 +74,7 @@ def _pack(head: nn.Sequential):
 @torch.no_grad()
 def pairwise_affinity(pred_features: torch.Tensor, det_features: torch.Tensor, link_model: nn.Sequential,
                       se_model: Optional[nn.Sequential] = None, return_raw: bool = False,
-                      overlap_start_end: bool = True) -> Tuple[torch.Tensor, ...]:
+                      overlap_start_end: bool = False) -> Tuple[torch.Tensor, ...]:
     """pred_features (P, C), det_features (D, C) ->
         link_scores (P, D)  dual-softmax affinity             (tracker.py:86-89)
         start_logits (D), end_logits (P)  raw se outputs      (tracker.py:105-110 applies
@@ -94,8 +94,11 @@ def pairwise_affinity(pred_features: torch.Tensor, det_features: torch.Tensor, l
     link_p = ctypes.byref(link)
     main = torch.cuda.current_stream(dev)
     if se is not None:
-        # the start/end head is a short latency-bound chain ((P+D) rows): it runs on a side stream owned HERE, under
-        # the link head's GEMMs (fork / join with stream waits; the library itself keeps no streams)
+        # the start/end head is a short latency-bound chain ((P+D) rows).  overlap_start_end runs it on a side stream owned
+        # HERE, under the link head's GEMMs; OFF by default: inside the composed engine that fork / join costs far more than the
+        # 0.1 ms it hides once every stream really has a hardware queue of its own (GPU_MAX_HW_QUEUES = 8: 513 frames/s with the
+        # fork, 625 without; at the default of 4 queues the side stream happened to share the main stream's queue: 609 / 631).
+        # (fork / join with stream waits; the library itself keeps no streams)
         se_p = ctypes.byref(se)
         side = side_stream(dev, 2) if overlap_start_end else main
         se_bytes = lib.jm_affinity_start_end_workspace_bytes(P, D, se_p)
@@ -124,7 +127,7 @@ def pairwise_affinity(pred_features: torch.Tensor, det_features: torch.Tensor, l
 @torch.no_grad()
 def pairwise_affinity_batched(pred_features: torch.Tensor, det_features: torch.Tensor, link_model: nn.Sequential,
                               se_model: Optional[nn.Sequential] = None, return_raw: bool = False,
-                              overlap_start_end: bool = True, split_bf16: bool = False) -> Tuple[torch.Tensor, ...]:
+                              overlap_start_end: bool = False, split_bf16: bool = False) -> Tuple[torch.Tensor, ...]:
     """nb independent problems at once: pred_features (nb, P, C), det_features (nb, D, C) ->
     link_scores (nb, P, D), start_logits (nb, D), end_logits (nb, P) (+ raw (nb, P, D)): `pairwise_affinity` for every
     frame pair of a batch as ONE GEMM chain over nb*P*D pair rows (jm_affinity_forward_batched)"""

@@ -236,6 +236,9 @@ class AffinityTrainState:
             L.dev(self.gt_ends, _f32, "gt_ends"), L.dev(self.counts, _f32, "counts"), L.stream_ptr()), "affinity_train_prepare")
 
 
+OVERLAP_SE = False
+
+
 def _train_steps(st: AffinityTrainState, counts: torch.Tensor, link_t, se_t, link_weight: float, se_weight: float,
                  want_outputs: bool):
     """both heads' forward + loss + backward (link on the current stream, start/end on a side stream of the caller's):
@@ -257,14 +260,18 @@ def _train_steps(st: AffinityTrainState, counts: torch.Tensor, link_t, se_t, lin
     gt_links = torch.empty((F_, R, R), dtype=_f32, device=dev) if want_outputs else None
     se_logits = torch.empty((F_, 2 * R), dtype=_f32, device=dev) if want_outputs else None
     main = torch.cuda.current_stream(dev)
-    side = side_stream(dev, 2)
+    # OVERLAP_SE: the start / end head on a side stream under the link head's chain.  Off: measured inside the training step,
+    # the fork / join (two stream waits + ~20 record_stream marks per step) costs more than the 0.25 ms chain it hides as soon as
+    # the streams have hardware queues of their own (GPU_MAX_HW_QUEUES = 8, needed next to RCCL: 320 vs ~500 frames/s)
+    side = side_stream(dev, 2) if OVERLAP_SE else main
     se_bytes = lib.jm_affinity_train_se_workspace_bytes(F_, R, ctypes.byref(se))
     se_ws = torch.empty((max(se_bytes, 16),), dtype=torch.uint8, device=dev)
-    side.wait_stream(main)
-    touched = [st.pooled_prev, st.pooled_next, st.rep_prev, st.rep_next, st.n_pair, st.gt_starts, st.gt_ends, counts, sp, se_ws,
-               *keep_s, *g_se] + ([se_logits] if want_outputs else [])
-    for t in touched:
-        t.record_stream(side)
+    if side is not main:
+        side.wait_stream(main)
+        touched = [st.pooled_prev, st.pooled_next, st.rep_prev, st.rep_next, st.n_pair, st.gt_starts, st.gt_ends, counts, sp, se_ws,
+                   *keep_s, *g_se] + ([se_logits] if want_outputs else [])
+        for t in touched:
+            t.record_stream(side)
     with torch.cuda.stream(side):
         L.check(lib.jm_affinity_train_se_step(
             F_, R, L.dev(st.pooled_prev, _f32, "pooled_prev"), L.dev(st.pooled_next, _f32, "pooled_next"),
@@ -281,7 +288,8 @@ def _train_steps(st: AffinityTrainState, counts: torch.Tensor, link_t, se_t, lin
         L.dev(link_out, _f32, "link_out") if want_outputs else None, L.dev(gt_links, _f32, "gt_links") if want_outputs else None,
         L.dev(lp, _f32, "loss_part"), ctypes.byref(gl), ctypes.c_void_p(ws.data_ptr()), ws_bytes, L.stream_ptr()),
         "affinity_train_link_step")
-    main.wait_stream(side)
+    if side is not main:
+        main.wait_stream(side)
     outputs = None
     if want_outputs:
         rp, rn = st.rep_prev.bool(), st.rep_next.bool()
