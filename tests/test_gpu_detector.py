@@ -155,17 +155,20 @@ def test_detections_and_affinity_teacher_forced(run, oracle):
 # times selects different kernels than DetectorConfig.tiny() (sa_mlp_pm C = 128, sa_mlp_wide hidden 512, rcnn_lift
 # with the hoisted layer, rocBLAS at LI-Fusion level 4, the 128-RoI affinity batch)
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module", params=["configs2", "configs4"])
+@pytest.fixture(scope="module", params=["configs2", "configs4", "reference100"])
 def full_run(request):
     """configs2: the headline workload's shapes (16384 points, 128 RoIs per frame); configs4: BASELINE configs[4] through the
     SAME composed engine (65536 points per frame: co-operative FPS, hash-grid ball query and 3-NN at the first level;
-    256 RoIs, 256 x 256 affinity)"""
+    256 RoIs, 256 x 256 affinity); reference100: DetectorConfig() = the reference's own TEST configuration, 100 RoIs per frame
+    (config.py:204,213: RoI counts and affinity sizes that are no multiple of any tile)"""
     import dataclasses
     from jmodt_amd.detector import DetectorConfig
     from jmodt_amd.profile import prof
     from oracle.pipeline import Chain
     dense = request.param == "configs4"
     cfg = dataclasses.replace(DetectorConfig.survey(), rpn_post_nms_top_n=256) if dense else DetectorConfig.survey()
+    if request.param == "reference100":
+        cfg = DetectorConfig()
     eng = make_engine(seed=5, cfg=cfg).to(DEV)
     xyz, img, xy = synth.frames(2, 65536 if dense else 16384, 4321)
     with torch.no_grad():
