@@ -147,18 +147,21 @@ fps_regs_kernel(int n, int m, int bs, int bs_log2, int R, int J, int recipJ, con
 //   phase 1 (all waves)   distance update with a value-only running max (8 VALU per point:
 //                         3 sub, mul, 2 fma, min, max), wave max by DPP, publish ONE dword;
 //   barrier A
-//   phase 2 (all waves)   reduce the <=16 wave maxima -> winning wave (lowest index among ties);
+//   phase 2 (all waves)   reduce the <=16 wave maxima -> winning wave (lowest index among ties): one ds_max_u64 per wave on a
+//                         (value, 15 - wave) key before barrier A and one broadcast read after it (ATOM; the 16-word
+//                         exchange + a second DPP reduction in every wave measured 0.5 - 4 % slower per iteration);
 //   phase 3 (winner only) find the lane (first = highest priority) and the register slot (first
 //                         slot equal to the max), fetch its coordinates by wave-uniform register
 //                         indexing, publish {k, x, y, z};
 //   barrier B
 //   all waves read the 16-byte winner record.
 // Two barriers instead of one, but ~2.5x fewer issued instructions per iteration.
-template <int PTS, int MAXBT>
+template <int PTS, int MAXBT, bool ATOM = false>
 __global__ void __launch_bounds__(MAXBT)
 fps_regs2_kernel(int n, int m, int bs, int bs_log2, int R, int J, int recipJ, const float* __restrict__ dataset,
                  float* __restrict__ temp, int* __restrict__ idxs) {
     __shared__ int vals[2][16];
+    __shared__ unsigned long long amax[2];   // ATOM: max over the waves of (value bits << 32 | 15 - wave) by ds_max_u64
     __shared__ FpsCand win[2];
     __shared__ int out_buf[FPS_OUT_CHUNK];
     const int T = threadIdx.x;
@@ -182,7 +185,7 @@ fps_regs2_kernel(int n, int m, int bs, int bs_log2, int R, int J, int recipJ, co
         tm[i] = ok ? (tp ? tp[k] : 1e10f) : -1.f;
     }
     float x1 = ds[0], y1 = ds[1], z1 = ds[2];
-    if (T == 0) out_buf[0] = 0;
+    if (T == 0) { out_buf[0] = 0; amax[0] = 0ULL; amax[1] = 0ULL; }
     __syncthreads();
 
     for (int it = 1; it < m; ++it) {
@@ -218,13 +221,26 @@ fps_regs2_kernel(int n, int m, int bs, int bs_log2, int R, int J, int recipJ, co
         }
         const int bits = __float_as_int(best);
         const int wmax = wave_max_i32(bits);
-        if (lane == 0) vals[it & 1][wave] = wmax;
-        lds_barrier();                                                        // A
-        const int v = lane < nwaves ? vals[it & 1][lane] : (int)0x80000000;
-        const int gmax = wave_max_i32(v);
-        const unsigned long long weq = __ballot(v == gmax);
-        const int ww = (int)__ffsll((long long)weq) - 1;
+        int gmax, ww;
+        if constexpr (ATOM) {
+            // one LDS atomic per wave instead of 16 words + a second DPP reduction in every wave: the key orders by value,
+            // then by LOWER wave index (ties); values are >= 0 or -1.0f, whose bit patterns order like unsigned after the flip
+            const unsigned key_hi = (unsigned)wmax ^ 0x80000000u;             // signed-int order -> unsigned order
+            if (lane == 0) atomicMax(&amax[it & 1], ((unsigned long long)key_hi << 32) | (unsigned)(15 - wave));
+            lds_barrier();                                                    // A
+            const unsigned long long k = amax[it & 1];
+            gmax = (int)((unsigned)(k >> 32) ^ 0x80000000u);
+            ww = 15 - (int)(k & 15ULL);
+        } else {
+            if (lane == 0) vals[it & 1][wave] = wmax;
+            lds_barrier();                                                    // A
+            const int v = lane < nwaves ? vals[it & 1][lane] : (int)0x80000000;
+            gmax = wave_max_i32(v);
+            const unsigned long long weq = __ballot(v == gmax);
+            ww = (int)__ffsll((long long)weq) - 1;
+        }
         if (wave == ww) {   // wave-uniform: exactly one wave extracts the winner
+            if (ATOM && lane == 0) amax[(it + 1) & 1] = 0ULL;                 // every wave has read it (before barrier B of it - 1)
             const unsigned long long eq = __ballot(bits == gmax);
             const int wl = (int)__ffsll((long long)eq) - 1;
             // (a scalar-unit variant — one ballot per slot, then bit tests of the winner lane — measured
@@ -615,9 +631,12 @@ static int fps_impl(int b, int n, int m, const float* xyz, float* temp, int* idx
     // multi-wave workgroups use the two-barrier kernel (one wave extracts the winner)
     static const int force_v1 = tune_env("JM_FPS_V1", 0);
     const bool v2 = block > 64 && !force_v1;
+    static const int atom = tune_env("JM_FPS_ATOM", 1);   // cross-wave arg-max through ds_max_u64 (-0.5 .. -4 % per iteration, bit-exact)
 #define JM_FPS_LAUNCH(P, MB)                                                                                    \
     do {                                                                                                        \
-        if (v2) hipLaunchKernelGGL((fps_regs2_kernel<P, MB>), dim3(b), dim3(block), 0, s, n, m, bs, bs_log2, R, \
+        if (v2 && atom) hipLaunchKernelGGL((fps_regs2_kernel<P, MB, true>), dim3(b), dim3(block), 0, s, n, m, bs, bs_log2, R, \
+                                   J, recipJ, xyz, temp, idx);                                                  \
+        else if (v2) hipLaunchKernelGGL((fps_regs2_kernel<P, MB>), dim3(b), dim3(block), 0, s, n, m, bs, bs_log2, R, \
                                    J, recipJ, xyz, temp, idx);                                                  \
         else hipLaunchKernelGGL((fps_regs_kernel<P, MB>), dim3(b), dim3(block), 0, s, n, m, bs, bs_log2, R, J,  \
                                 recipJ, xyz, temp, idx);                                                        \
