@@ -802,8 +802,9 @@ class DetectAffinityEngine(nn.Module):
             # proposals: built on a side stream under the proposal layer's sort / decode / NMS chain
             main, side = torch.cuda.current_stream(xyz.device), side_stream(xyz.device, 3)
             side.wait_stream(main)
-            for t in (rpn_out["rpn_cls"], rpn_out["backbone_features"], xyz):
-                t.record_stream(side)
+            # (inputs allocated on this stream, read by the side stream: no record_stream — this stream waits for the side
+            # stream below, before any of them can be freed, so their blocks cannot be recycled under the side stream's reads;
+            # a record_stream makes the allocator record and poll one event per tensor when it is freed)
             with torch.cuda.stream(side):
                 pf = self.pts_feature(rpn_out)
             pf.record_stream(main)
@@ -848,9 +849,7 @@ class DetectAffinityEngine(nn.Module):
         # stream under the affinity GEMMs
         side = side_stream(dev, 3) if overlap else None
         if side is not None:
-            side.wait_stream(main)
-            for t in (rois, out["rcnn_feat"]):
-                t.record_stream(side)
+            side.wait_stream(main)                      # (inputs: no record_stream, see _trunk — joined below before they can be freed)
             with torch.cuda.stream(side):
                 out.update(self.rcnn_heads(out["rcnn_feat"]))
                 cache, boxes = self._detections(rois, out)
