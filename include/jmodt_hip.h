@@ -504,8 +504,12 @@ typedef struct {
  * jm_affinity_train_se_step: masked start / end feature means, se head, sigmoid + L1; se_logits (npairs, 2r) = per pair
  *   [start logits of the next slots | end logits of the prev slots] (optional); loss_part (npairs, 2) = [sum |sigmoid(start) -
  *   gt|, sum |sigmoid(end) - gt|]; gradients of loss_weight * (sum_start / max(counts[1], 1) + sum_end / max(counts[2], 1)).
- * The two step calls are independent of each other (a caller may run them on two streams).  Gradients w.r.t. the RoI
- * features are not produced (finetune: the detector is frozen, tools/train.py:96-107). */
+ * The two step calls are independent of each other (a caller may run them on two streams).
+ * Gradients w.r.t. the RoI features (joint training; the finetune step of tools/train.py:96-107 freezes the detector and
+ * passes dx = NULL): dx (rows, c) of a step receives d(loss)/d(its input rows) — the (npairs * r * r) pair rows |p_i - d_j|
+ * of the link head, the (npairs * 2r) start / end feature rows of the se head —, and jm_affinity_train_feature_grad carries
+ * both through |.|, the masked means and the per-track-id mean pooling to dfeat (2 npairs, r, c) = d(loss)/d(feats);
+ * dpooled_ws: 2 * npairs * r * c floats of scratch; dx_se may be NULL (link loss only). */
 int jm_affinity_train_prepare(int npairs, int r, int c, const float* feats, const float* tids, float* pooled_prev,
                               float* pooled_next, int* rep_ws, int* rep_prev, int* rep_next, int* n_pair, float* gt_starts,
                               float* gt_ends, float* counts, jm_stream_t stream);
@@ -517,12 +521,16 @@ size_t jm_affinity_train_link_workspace_bytes(int npairs, int r, const jm_mlp3_t
 int jm_affinity_train_link_step(int npairs, int r, const float* pooled_prev, const float* pooled_next, const int* rep_prev,
                                 const int* rep_next, const float* tids, const float* counts, float loss_weight,
                                 const jm_mlp3_t* link, float* link_out, float* gt_links, float* loss_part,
-                                const jm_mlp3_grad_t* grads, void* ws, size_t ws_bytes, jm_stream_t stream);
+                                const jm_mlp3_grad_t* grads, float* dx, void* ws, size_t ws_bytes, jm_stream_t stream);
 size_t jm_affinity_train_se_workspace_bytes(int npairs, int r, const jm_mlp3_t* se);
 int jm_affinity_train_se_step(int npairs, int r, const float* pooled_prev, const float* pooled_next, const int* rep_prev,
                               const int* rep_next, const int* n_pair, const float* gt_starts, const float* gt_ends,
                               const float* counts, float loss_weight, const jm_mlp3_t* se, float* se_logits, float* loss_part,
-                              const jm_mlp3_grad_t* grads, void* ws, size_t ws_bytes, jm_stream_t stream);
+                              const jm_mlp3_grad_t* grads, float* dx, void* ws, size_t ws_bytes, jm_stream_t stream);
+int jm_affinity_train_feature_grad(int npairs, int r, int c, const float* tids, const float* pooled_prev,
+                                   const float* pooled_next, const int* rep_prev, const int* rep_next, const int* n_pair,
+                                   const float* dx_link, const float* dx_se, float* dpooled_ws, float* dfeat,
+                                   jm_stream_t stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -126,10 +126,11 @@ SIGNATURES = {
     "jm_affinity_train_loss_value": (_I, [_I, _P, _P, _P, _F, _F, _P, _P]),
     "jm_affinity_train_link_workspace_bytes": (_Z, [_I, _I, ctypes.POINTER(Mlp3)]),
     "jm_affinity_train_link_step": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _F, ctypes.POINTER(Mlp3), _P, _P, _P,
-                                         ctypes.POINTER(Mlp3Grad), _P, _Z, _P]),
+                                         ctypes.POINTER(Mlp3Grad), _P, _P, _Z, _P]),
     "jm_affinity_train_se_workspace_bytes": (_Z, [_I, _I, ctypes.POINTER(Mlp3)]),
     "jm_affinity_train_se_step": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, ctypes.POINTER(Mlp3), _P, _P,
-                                       ctypes.POINTER(Mlp3Grad), _P, _Z, _P]),
+                                       ctypes.POINTER(Mlp3Grad), _P, _P, _Z, _P]),
+    "jm_affinity_train_feature_grad": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

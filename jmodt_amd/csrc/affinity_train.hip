@@ -739,7 +739,7 @@ static int mlp_train_forward(int M, const float* x, const float* pf, const float
 
 // backward given dy (M) in w.dy; destroys w.h1 / w.h2 (they become dH1 / dH2)
 static int mlp_train_backward(int M, const float* x, const float* pf, const float* df, int D, int PD, const jm_mlp3_t* mlp,
-                              const TrainWs& w, const jm_mlp3_grad_t* g, hipStream_t s) {
+                              const TrainWs& w, const jm_mlp3_grad_t* g, float* dx, hipStream_t s) {
     const int c = mlp->c, h1 = mlp->h1, h2 = mlp->h2;
     hipLaunchKernelGGL(mlp_bwd_prep_kernel, dim3(w.chunks, divup(h2, CW)), dim3(CW), 0, s, M, h2, w.h2, w.dy, mlp->w3, w.p_dw3, w.p_db2, w.p_db3);
     // dW2 (h2, h1) = dH2^T H1: contraction over the M rows, both operands k-major in place
@@ -753,6 +753,14 @@ static int mlp_train_backward(int M, const float* x, const float* pf, const floa
     n1.A = w.h2; n1.lda = h2; n1.B = mlp->w2; n1.ldb = h1; n1.mask = w.h1; n1.out = w.h1; n1.ldo = h1;
     if (x && M <= SMALL_M && h2 % 8 == 0) launch_tgemm_small<B_KMAJOR, E_MASK>(n1, s); else launch_tgemm<A_ROWS, B_KMAJOR, E_MASK>(n1, s);
     hipLaunchKernelGGL(colsum_kernel, dim3(w.chunks, divup(h1, CW)), dim3(CW), 0, s, M, h1, w.h1, w.p_db1);
+    if (dx) {
+        // d(loss)/d(input rows) (M, c) = dH1 W1: W1 (h1, c) is k-major for this product as it lies (joint training: the rows
+        // are |p_i - d_j| or the start / end features; jm_affinity_train_feature_grad carries it on to the RoI features)
+        TGemm nx{};
+        nx.M = M; nx.N = c; nx.K = h1; nx.kchunk = h1;            // one split: E_PARTIAL stores the plain product
+        nx.A = w.h1; nx.lda = h1; nx.B = mlp->w1; nx.ldb = c; nx.out = dx; nx.ldo = c;
+        launch_tgemm<A_ROWS, B_KMAJOR, E_PARTIAL>(nx, s);
+    }
     // dW1 (h1, c) = dH1^T X, X = plain rows or |p_i - d_j| regenerated per tile
     TGemm t1{};
     t1.M = h1; t1.N = c; t1.K = M; t1.kchunk = w.chunk1;
@@ -774,6 +782,73 @@ static int mlp_train_backward(int M, const float* x, const float* pf, const floa
     j.first_block[6] = blocks;
     hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks), dim3(256), 0, s, j);
     return check_launch("affinity_train backward");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// d(loss)/d(pooled features) from d(loss)/d(pair rows) of the link head (dxl: (F, R, R, C), zero on invalid pairs) and
+// d(loss)/d(start / end features) of the se head (dxs: (F, 2R, C): rows [0, R) start feature of next slot j = mean over the
+// prev representatives of |p_i - d_j|, rows [R, 2R) end feature of prev slot i = mean over the next representatives):
+//   G[i][j][c] = sign(p_i - d_j) * (dxl[i][j][c] + [rep_prev[i] && rep_next[j]] * (dxs_start[j][c] / n_prev + dxs_end[i][c] / n_next))
+//   dP[i] = sum_j G[i][j],  dD[j] = -sum_i G[i][j]       (|.|' = sign, 0 at 0 as torch.abs)
+// One thread per (slot, channel) walks the other side in index order: deterministic.  blockIdx.y: 0 = prev slots, 1 = next slots.
+__global__ void __launch_bounds__(256)
+train_dpooled_kernel(int R, int C, const float* __restrict__ pp, const float* __restrict__ pn, const int* __restrict__ rep_prev,
+                     const int* __restrict__ rep_next, const int* __restrict__ n_pair, const float* __restrict__ dxl,
+                     const float* __restrict__ dxs, float* __restrict__ dpp, float* __restrict__ dpn) {
+    const int f = blockIdx.x / R, k = blockIdx.x % R;
+    const bool prev = blockIdx.y == 0;
+    const int* rp = rep_prev + (size_t)f * R;
+    const int* rn = rep_next + (size_t)f * R;
+    const float inv_p = 1.f / (float)max(n_pair[2 * f], 1), inv_n = 1.f / (float)max(n_pair[2 * f + 1], 1);
+    const float* P = pp + (size_t)f * R * C;
+    const float* D = pn + (size_t)f * R * C;
+    const float* XL = dxl + (size_t)f * R * R * C;
+    const float* XS = dxs ? dxs + (size_t)f * 2 * R * C : nullptr;
+    float* dst = (prev ? dpp : dpn) + ((size_t)f * R + k) * C;
+    const bool me_rep = prev ? rp[k] != 0 : rn[k] != 0;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        if (me_rep) {                                        // non-representative slots take part in nothing
+            const float mine = prev ? P[(size_t)k * C + c] : D[(size_t)k * C + c];
+            for (int q = 0; q < R; ++q) {
+                const bool other_rep = prev ? rn[q] != 0 : rp[q] != 0;
+                if (!other_rep) continue;
+                const int i = prev ? k : q, j = prev ? q : k;
+                const float other = prev ? D[(size_t)q * C + c] : P[(size_t)q * C + c];
+                const float diff = prev ? mine - other : other - mine;            // p_i - d_j
+                const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+                float gsum = XL[((size_t)i * R + j) * C + c];
+                if (XS) gsum += XS[(size_t)j * C + c] * inv_p + XS[(size_t)(R + i) * C + c] * inv_n;
+                acc += sg * gsum;
+            }
+            if (!prev) acc = -acc;
+        }
+        dst[c] = acc;
+    }
+}
+
+// ... and on to the RoI features through the mean pooling of get_unique_tid_feature: every foreground RoI k of a frame gets
+// d(pooled)[representative of its track id] / (RoIs with that id); frames interleaved (prev, next, ...) as in train_pool_kernel
+__global__ void __launch_bounds__(128)
+train_dfeat_kernel(int R, int C, const float* __restrict__ tids, const float* __restrict__ dpp, const float* __restrict__ dpn,
+                   float* __restrict__ dfeat) {
+    __shared__ int rep_s, cnt_s;
+    const int f = blockIdx.x / R, k = blockIdx.x % R;
+    const float* t = tids + (size_t)f * R;
+    const float tk = t[k];
+    if (threadIdx.x == 0) {
+        int rep = -1, cnt = 0;
+        if (tk > 0.f)
+            for (int q = 0; q < R; ++q)
+                if (t[q] == tk) { if (rep < 0) rep = q; ++cnt; }
+        rep_s = rep; cnt_s = cnt;
+    }
+    __syncthreads();
+    const int rep = rep_s;
+    const float inv = cnt_s > 0 ? 1.f / (float)cnt_s : 0.f;
+    const float* src = ((f & 1) ? dpn : dpp) + ((size_t)(f >> 1) * R + max(rep, 0)) * C;
+    float* dst = dfeat + ((size_t)f * R + k) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) dst[c] = rep >= 0 ? src[c] * inv : 0.f;
 }
 
 }  // namespace jm
@@ -819,7 +894,7 @@ extern "C" size_t jm_affinity_train_se_workspace_bytes(int npairs, int r, const 
 extern "C" int jm_affinity_train_link_step(int npairs, int r, const float* pooled_prev, const float* pooled_next,
                                            const int* rep_prev, const int* rep_next, const float* tids, const float* counts,
                                            float loss_weight, const jm_mlp3_t* link, float* link_out, float* gt_links,
-                                           float* loss_part, const jm_mlp3_grad_t* grads, void* ws, size_t ws_bytes,
+                                           float* loss_part, const jm_mlp3_grad_t* grads, float* dx, void* ws, size_t ws_bytes,
                                            jm_stream_t stream) {
     JM_REQUIRE(npairs >= 0 && r >= 1 && r <= 128, "affinity_train_link: bad sizes (pairs=%d R=%d; R <= 128)", npairs, r);
     if (npairs == 0) return JM_OK;
@@ -842,13 +917,13 @@ extern "C" int jm_affinity_train_link_step(int npairs, int r, const float* poole
         (void)hipFuncSetAttribute((const void*)train_link_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(train_link_loss_kernel, dim3((unsigned)npairs), dim3(1024), lds, s, r, w.y, rep_prev, rep_next, tids, counts,
                        loss_weight, link_out, gt_links, w.dy, loss_part);
-    return mlp_train_backward(M, nullptr, pooled_prev, pooled_next, r, r * r, link, w, grads, s);
+    return mlp_train_backward(M, nullptr, pooled_prev, pooled_next, r, r * r, link, w, grads, dx, s);
 }
 
 extern "C" int jm_affinity_train_se_step(int npairs, int r, const float* pooled_prev, const float* pooled_next,
                                          const int* rep_prev, const int* rep_next, const int* n_pair, const float* gt_starts,
                                          const float* gt_ends, const float* counts, float loss_weight, const jm_mlp3_t* se,
-                                         float* se_logits, float* loss_part, const jm_mlp3_grad_t* grads, void* ws,
+                                         float* se_logits, float* loss_part, const jm_mlp3_grad_t* grads, float* dx, void* ws,
                                          size_t ws_bytes, jm_stream_t stream) {
     JM_REQUIRE(npairs >= 0 && r >= 1 && r <= 256, "affinity_train_se: bad sizes (pairs=%d R=%d)", npairs, r);
     if (npairs == 0) return JM_OK;
@@ -871,5 +946,22 @@ extern "C" int jm_affinity_train_se_step(int npairs, int r, const float* pooled_
     if (se_logits) (void)hipMemcpyAsync(se_logits, w.y, (size_t)M * sizeof(float), hipMemcpyDeviceToDevice, s);
     hipLaunchKernelGGL(train_se_loss_kernel, dim3((unsigned)npairs), dim3(256), 0, s, r, w.y, rep_prev, rep_next, gt_starts, gt_ends,
                        counts, loss_weight, w.dy, loss_part);
-    return mlp_train_backward(M, feat, nullptr, nullptr, 1, 1, se, w, grads, s);
+    return mlp_train_backward(M, feat, nullptr, nullptr, 1, 1, se, w, grads, dx, s);
+}
+
+extern "C" int jm_affinity_train_feature_grad(int npairs, int r, int c, const float* tids, const float* pooled_prev,
+                                              const float* pooled_next, const int* rep_prev, const int* rep_next, const int* n_pair,
+                                              const float* dx_link, const float* dx_se, float* dpooled_ws, float* dfeat,
+                                              jm_stream_t stream) {
+    JM_REQUIRE(npairs >= 0 && r >= 1 && r <= 256 && c >= 1, "affinity_train_feature_grad: bad sizes");
+    if (npairs == 0) return JM_OK;
+    JM_REQUIRE(tids && pooled_prev && pooled_next && rep_prev && rep_next && n_pair && dx_link && dpooled_ws && dfeat,
+               "affinity_train_feature_grad: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    float* dpp = dpooled_ws;
+    float* dpn = dpooled_ws + (size_t)npairs * r * c;
+    hipLaunchKernelGGL(train_dpooled_kernel, dim3((unsigned)(npairs * r), 2), dim3(256), 0, s, r, c, pooled_prev, pooled_next, rep_prev,
+                       rep_next, n_pair, dx_link, dx_se, dpp, dpn);
+    hipLaunchKernelGGL(train_dfeat_kernel, dim3((unsigned)(2 * npairs * r)), dim3(128), 0, s, r, c, tids, dpp, dpn, dfeat);
+    return check_launch("affinity_train_feature_grad");
 }

@@ -219,6 +219,7 @@ class AffinityTrainState:
             raise ValueError(f"roi_features (2F, R, C) and gt_tids (2F, R) expected, got {tuple(feats.shape)} / {tuple(tids.shape)}")
         self.F, self.R, self.C = feats.shape[0] // 2, feats.shape[1], feats.shape[2]
         dev, F_, R, C = feats.device, self.F, self.R, self.C
+        self.roi_features = roi_features      # as given: when it requires grad, affinity_train_loss sends d(loss)/d(features) back
         self.tids = tids
         self.pooled_prev = torch.empty((F_ * R, C), dtype=_f32, device=dev)
         self.pooled_next = torch.empty((F_ * R, C), dtype=_f32, device=dev)
@@ -240,9 +241,9 @@ OVERLAP_SE = False
 
 
 def _train_steps(st: AffinityTrainState, counts: torch.Tensor, link_t, se_t, link_weight: float, se_weight: float,
-                 want_outputs: bool):
-    """both heads' forward + loss + backward (link on the current stream, start/end on a side stream of the caller's):
-    returns (loss parts link (F,), se (F, 2), gradient tensors [6 link, 6 se], outputs dict or None)"""
+                 want_outputs: bool, want_dfeat: bool = False):
+    """both heads' forward + loss + backward: returns (loss parts link (F,), se (F, 2), gradient tensors [6 link, 6 se],
+    outputs dict or None); want_dfeat: + d(loss)/d(RoI features) (2F, R, C) as a fifth value (joint training)"""
     from .pointnet2.pyramid import side_stream
     lib = L.load()
     dev = st.pooled_prev.device
@@ -259,6 +260,9 @@ def _train_steps(st: AffinityTrainState, counts: torch.Tensor, link_t, se_t, lin
     link_out = torch.empty((F_, R, R), dtype=_f32, device=dev) if want_outputs else None
     gt_links = torch.empty((F_, R, R), dtype=_f32, device=dev) if want_outputs else None
     se_logits = torch.empty((F_, 2 * R), dtype=_f32, device=dev) if want_outputs else None
+    C = st.pooled_prev.shape[-1]
+    dx_link = torch.empty((F_ * R * R, C), dtype=_f32, device=dev) if want_dfeat else None
+    dx_se = torch.empty((F_ * 2 * R, C), dtype=_f32, device=dev) if want_dfeat else None
     main = torch.cuda.current_stream(dev)
     # OVERLAP_SE: the start / end head on a side stream under the link head's chain.  Off: measured inside the training step,
     # the fork / join (two stream waits + ~20 record_stream marks per step) costs more than the 0.25 ms chain it hides as soon as
@@ -278,7 +282,8 @@ def _train_steps(st: AffinityTrainState, counts: torch.Tensor, link_t, se_t, lin
             L.dev(st.rep_prev, _i32, "rep_prev"), L.dev(st.rep_next, _i32, "rep_next"), L.dev(st.n_pair, _i32, "n_pair"),
             L.dev(st.gt_starts, _f32, "gt_starts"), L.dev(st.gt_ends, _f32, "gt_ends"), L.dev(counts, _f32, "counts"), float(se_weight),
             ctypes.byref(se), L.dev(se_logits, _f32, "se_logits") if want_outputs else None, L.dev(sp, _f32, "loss_part"),
-            ctypes.byref(gs), ctypes.c_void_p(se_ws.data_ptr()), se_bytes, L.stream_ptr()), "affinity_train_se_step")
+            ctypes.byref(gs), L.dev(dx_se, _f32, "dx_se") if want_dfeat else None, ctypes.c_void_p(se_ws.data_ptr()), se_bytes,
+            L.stream_ptr()), "affinity_train_se_step")
     ws_bytes = lib.jm_affinity_train_link_workspace_bytes(F_, R, ctypes.byref(link))
     ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
     L.check(lib.jm_affinity_train_link_step(
@@ -286,8 +291,8 @@ def _train_steps(st: AffinityTrainState, counts: torch.Tensor, link_t, se_t, lin
         L.dev(st.rep_prev, _i32, "rep_prev"), L.dev(st.rep_next, _i32, "rep_next"), L.dev(st.tids, _f32, "gt_tids"),
         L.dev(counts, _f32, "counts"), float(link_weight), ctypes.byref(link),
         L.dev(link_out, _f32, "link_out") if want_outputs else None, L.dev(gt_links, _f32, "gt_links") if want_outputs else None,
-        L.dev(lp, _f32, "loss_part"), ctypes.byref(gl), ctypes.c_void_p(ws.data_ptr()), ws_bytes, L.stream_ptr()),
-        "affinity_train_link_step")
+        L.dev(lp, _f32, "loss_part"), ctypes.byref(gl), L.dev(dx_link, _f32, "dx_link") if want_dfeat else None,
+        ctypes.c_void_p(ws.data_ptr()), ws_bytes, L.stream_ptr()), "affinity_train_link_step")
     if side is not main:
         main.wait_stream(side)
     outputs = None
@@ -295,7 +300,17 @@ def _train_steps(st: AffinityTrainState, counts: torch.Tensor, link_t, se_t, lin
         rp, rn = st.rep_prev.bool(), st.rep_next.bool()
         outputs = dict(link=link_out, gt_links=gt_links, valid=rp.unsqueeze(2) & rn.unsqueeze(1), start=se_logits[:, :R],
                        gt_starts=st.gt_starts, start_valid=rn, end=se_logits[:, R:], gt_ends=st.gt_ends, end_valid=rp)
-    return lp, sp, g_link + g_se, outputs
+    if not want_dfeat:
+        return lp, sp, g_link + g_se, outputs
+    # through |p - d|, the masked start / end means and the per-track-id mean pooling, back to the RoI features
+    dfeat = torch.empty((2 * F_, R, C), dtype=_f32, device=dev)
+    dpooled = torch.empty((2, F_, R, C), dtype=_f32, device=dev)
+    L.check(lib.jm_affinity_train_feature_grad(
+        F_, R, C, L.dev(st.tids, _f32, "gt_tids"), L.dev(st.pooled_prev, _f32, "pooled_prev"), L.dev(st.pooled_next, _f32, "pooled_next"),
+        L.dev(st.rep_prev, _i32, "rep_prev"), L.dev(st.rep_next, _i32, "rep_next"), L.dev(st.n_pair, _i32, "n_pair"),
+        L.dev(dx_link, _f32, "dx_link"), L.dev(dx_se, _f32, "dx_se"), ctypes.c_void_p(dpooled.data_ptr()),
+        ctypes.c_void_p(dfeat.data_ptr()), L.stream_ptr()), "affinity_train_feature_grad")
+    return lp, sp, g_link + g_se, outputs, dfeat
 
 
 def _loss_from_parts(lp, sp, counts, link_weight, se_weight):
@@ -314,23 +329,27 @@ class _AffinityTrainLoss(torch.autograd.Function):
     right behind the forward ones); autograd's backward only scales them by the incoming gradient"""
 
     @staticmethod
-    def forward(ctx, st, counts, link_weight, se_weight, *params):
-        lp, sp, grads, _ = _train_steps(st, counts, params[:6], params[6:], link_weight, se_weight, False)
-        ctx.grads = grads
-        return _loss_from_parts(lp, sp, counts, link_weight, se_weight)
+    def forward(ctx, st, counts, link_weight, se_weight, feats, *params):
+        want_dfeat = feats is not None and feats.requires_grad
+        res = _train_steps(st, counts, params[:6], params[6:], link_weight, se_weight, False, want_dfeat)
+        ctx.grads = res[2]
+        ctx.dfeat = res[4].view_as(feats) if want_dfeat else None
+        return _loss_from_parts(res[0], res[1], counts, link_weight, se_weight)
 
     @staticmethod
     def backward(ctx, g):
-        return (None, None, None, None) + tuple(g * t for t in ctx.grads)
+        return (None, None, None, None, g * ctx.dfeat if ctx.dfeat is not None else None) + tuple(g * t for t in ctx.grads)
 
 
 def affinity_train_loss(st: AffinityTrainState, link_layer: nn.Module, se_layer: nn.Module, counts: Optional[torch.Tensor] = None,
                         link_weight: float = 1.0, se_weight: float = 1.0) -> torch.Tensor:
-    """the re-id loss of train_functions.py:282-329 (L1 forms) of the prepared batch as a differentiable DEVICE scalar
-    (w.r.t. the parameters of the two heads; the RoI features are constants: the finetune step trains the heads only,
-    tools/train.py:96-107).  `counts` overrides the denominators (global element counts of a data-parallel step)."""
+    """the re-id loss of train_functions.py:282-329 (L1 forms) of the prepared batch as a differentiable DEVICE scalar w.r.t.
+    the parameters of the two heads and — when the `roi_features` the state was built from require grad (joint training; the
+    finetune step of tools/train.py:96-107 trains the heads only) — w.r.t. those features.  `counts` overrides the
+    denominators (global element counts of a data-parallel step)."""
     params = _head_tensors(link_layer) + _head_tensors(se_layer)
-    return _AffinityTrainLoss.apply(st, st.counts if counts is None else counts, float(link_weight), float(se_weight), *params)
+    return _AffinityTrainLoss.apply(st, st.counts if counts is None else counts, float(link_weight), float(se_weight),
+                                    st.roi_features, *params)
 
 
 def training_affinity_hip(roi_features: torch.Tensor, gt_tids: torch.Tensor, link_layer: nn.Module, se_layer: nn.Module):

@@ -17,7 +17,7 @@ make_golden_glue.py; configuration = make_golden_forward.py's reduced one (+ 32 
 synth.seeded_state + the same two head adjustments; numpy / torch RNGs seeded (the RoI sampling draws from them).
 Stored: the RoI features the heads saw (output of the last RCNN set-abstraction level) with the sampled RoIs' track ids — the
 INPUTS of the affinity —, the reference's link / start / end outputs and ground-truth vectors, the three loss terms, the loss
-and its gradients.  No reference source text.
+and its gradients (head tensors and RoI features).  No reference source text.
 """
 import json
 import os
@@ -87,7 +87,8 @@ def main():
         tb = {}
         loss = cells["get_rcnn_loss"](model, ret, tb)
         heads = {f"rcnn_net.{h}.{k}": v for h in ("link_layer", "se_layer") for k, v in getattr(model.rcnn_net, h).named_parameters()}
-        grads = torch.autograd.grad(loss, list(heads.values()))
+        grads = torch.autograd.grad(loss, list(heads.values()) + [feats["f"]])
+        grads, g_feat = grads[:-1], grads[-1]
     finally:
         torch.Tensor.get_device = get_device
     roi_feat = feats["f"].detach().squeeze(-1).view(B, R, -1).numpy()
@@ -98,6 +99,7 @@ def main():
                loss_terms=np.array([tb.get("rcnn_loss_link_mean", 0.0), tb.get("rcnn_loss_start_mean", 0.0), tb.get("rcnn_loss_end_mean", 0.0)]),
                weights=np.array([cfg.TRAIN.LINK_TRAIN_WEIGHT, cfg.TRAIN.SE_TRAIN_WEIGHT], np.float64))
     out.update({f"grad.{k}": g.numpy() for k, g in zip(heads, grads)})
+    out["grad.roi_feat"] = g_feat.squeeze(-1).view(B, R, -1).numpy()          # d(loss) / d(RoI features): what joint training sends back
     fg = (out["gt_tids"] > 0).sum(axis=1)
     print("foreground RoIs per frame", fg.tolist(), "| link entries", out["rcnn_link"].shape, "| loss", out["loss"], out["loss_terms"],
           "| gt_links positives", int(out["gt_links"].sum()))

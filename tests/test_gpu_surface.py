@@ -172,7 +172,8 @@ def test_training_affinity_hip_kernels_vs_float64_reference(frames, R, C, H, nti
             if isinstance(m, torch.nn.Conv1d):
                 m.bias.normal_(0, 0.05)
     link64, se64 = copy.deepcopy(link).double(), copy.deepcopy(se).double()
-    want = _reference_training_affinity(feats.double(), tids.double(), link64, se64)
+    f64 = feats.double().requires_grad_(True)
+    want = _reference_training_affinity(f64, tids.double(), link64, se64)
     l64 = _reid_loss_reference(want)
     l64.backward()
     dlink, dse = copy.deepcopy(link).to(DEV).train(), copy.deepcopy(se).to(DEV).train()
@@ -195,10 +196,13 @@ def test_training_affinity_hip_kernels_vs_float64_reference(frames, R, C, H, nti
     got_sorted = torch.sort(out["link"][v].double().cpu())[0]
     assert (got_sorted - torch.sort(want["rcnn_link"].view(-1))[0]).abs().max().item() < 1e-4
     # (ii) gradients through the autograd.Function
-    st = AffinityTrainState(f_d, t_d)
+    f_g = f_d.clone().requires_grad_(True)          # (joint training: the features' gradient comes back as well)
+    st = AffinityTrainState(f_g, t_d)
     loss = affinity_train_loss(st, dlink, dse)
     assert abs(loss.item() - l64.item()) < 1e-5
     (2.0 * loss).backward()
+    gf = 2.0 * f64.grad
+    assert (f_g.grad.double().cpu() - gf).abs().max().item() <= 1e-4 * gf.abs().max().item() + 1e-9 and gf.abs().max().item() > 0
     names = ["w1", "b1", "w2", "b2", "w3", "b3"]
     for head, (pd_list, p64_list) in (("link", (list(dlink.parameters()), list(link64.parameters()))),
                                       ("se", (list(dse.parameters()), list(se64.parameters())))):
@@ -398,9 +402,13 @@ def test_training_affinity_hip_kernels_vs_the_references_train_forward_and_loss(
     assert (torch.sort(torch.sigmoid(out["end"][ev]).cpu())[0]
             - torch.sort(torch.sigmoid(torch.from_numpy(g["rcnn_end"]).view(-1)))[0]).abs().max().item() < 1e-5
     assert int(out["gt_links"][v].sum()) == int(g["gt_links"].sum())
+    feats.requires_grad_(True)                     # joint training: d(loss)/d(RoI features) comes back too
     loss = affinity_train_loss(AffinityTrainState(feats, tids), link, se, link_weight=w_link, se_weight=w_se)
     assert abs(loss.item() - float(g["loss"])) < 1e-5
     loss.backward()
+    want = g["grad.roi_feat"]
+    assert np.abs(feats.grad.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max() + 1e-9 and np.abs(want).max() > 1e-3
+    assert (feats.grad[torch.from_numpy(g["gt_tids"]).to(DEV) <= 0] == 0).all()          # background RoIs get none
     for head, mod in (("link_layer", link), ("se_layer", se)):
         for k, p_ in mod.named_parameters():
             want = g[f"grad.rcnn_net.{head}.{k}"]

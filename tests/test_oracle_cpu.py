@@ -594,15 +594,17 @@ def test_training_affinity_restatements_match_the_references_train_forward_and_l
     import torch
     from jmodt_amd.ops.affinity_train import reid_loss, reid_loss_static, training_affinity, training_affinity_static
     g, link, se = reference_train_fixture()
-    feats, tids = torch.from_numpy(g["roi_feat"]), torch.from_numpy(g["gt_tids"])
+    feats, tids = torch.from_numpy(g["roi_feat"]).requires_grad_(True), torch.from_numpy(g["gt_tids"])
     w_link, w_se = float(g["weights"][0]), float(g["weights"][1])
     out = training_affinity(feats, tids, link, se)                    # same row order as the reference (torch.unique per pair)
     for k in ("rcnn_link", "rcnn_start", "rcnn_end", "gt_links", "gt_starts", "gt_ends"):
-        _close(out[k].reshape(g[k].shape), g[k], 1e-5)
+        _close(out[k].detach().reshape(g[k].shape), g[k], 1e-5)
     loss = reid_loss(out, w_link, w_se)
     assert abs(loss.item() - float(g["loss"])) < 1e-5 and g["rcnn_link"].shape[0] >= 40 and g["gt_links"].sum() >= 4
-    params = list(link.parameters()) + list(se.parameters())
-    names = [f"rcnn_net.link_layer.{k}" for k, _ in link.named_parameters()] + [f"rcnn_net.se_layer.{k}" for k, _ in se.named_parameters()]
+    params = list(link.parameters()) + list(se.parameters()) + [feats]
+    names = ([f"rcnn_net.link_layer.{k}" for k, _ in link.named_parameters()] + [f"rcnn_net.se_layer.{k}" for k, _ in se.named_parameters()]
+             + ["roi_feat"])                                          # ... and d(loss)/d(RoI features): what joint training sends back
+    assert np.abs(g["grad.roi_feat"]).max() > 1e-3
     for p_, got in zip(names, torch.autograd.grad(loss, params, allow_unused=True)):
         want = g["grad." + p_]
         got = torch.zeros_like(torch.from_numpy(want)) if got is None else got
