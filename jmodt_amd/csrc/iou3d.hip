@@ -675,7 +675,6 @@ extern "C" int jm_nms_normal_first_k_batched(int num_problems, int max_boxes, co
         return check_launch("nms_normal_first_k(memset)");
     }
     JM_REQUIRE(boxes && keep, "nms_normal_first_k: null pointer");
-    JM_REQUIRE(num_problems <= 65535 * 32768, "nms_normal_first_k: too many problems");
     return launch_nms_first_k(num_problems, max_boxes, counts, boxes, nms_overlap_thresh, 1, first_k, first_k, keep, num_keep,
                               nullptr, (hipStream_t)stream);
 }
