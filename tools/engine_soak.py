@@ -8,6 +8,10 @@ import bench
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 st = bench.make_detect_state(8, 1236, torch.device("cuda:0"))
 eng = st["engine"]
+# MIOpen's find mode picks split-K (atomic) kernels for most of the image convolutions: 1e-7 run to run in the backbone features,
+# enough to flip a proposal between near-tied scores of the random-init heads — not a race.  The soak compares bit for bit, so
+# it runs on MIOpen's default kernels (only blocks 3 / 4 then differ, at 7e-9)
+eng.conv_find = False
 keys = ("backbone_features", "rpn_cls", "rpn_reg", "rois", "pts_input", "rcnn_feat", "rcnn_cls", "rcnn_reg", "pred_boxes3d")
 ref = None
 bad = 0
