@@ -50,10 +50,14 @@ def tiny_frames(B, N, seed):
     return xyz, img, xy
 
 
-def make_engine(seed=0, cfg=None):
+def make_engine(seed=0, cfg=None, conv_find=False):
+    """conv_find off by default HERE: several tests compare two forwards bit for bit, and the kernels MIOpen's find mode picks
+    for the image convolutions are split-K (atomic adds: 1e-7 run to run); the full-width fixtures, whose comparisons carry a
+    tolerance, run with the engine's default (on)"""
     from jmodt_amd.detector import DetectAffinityEngine, DetectorConfig
     torch.manual_seed(seed)
     eng = DetectAffinityEngine(cfg or DetectorConfig.tiny())
+    eng.conv_find = conv_find
     g = torch.Generator().manual_seed(seed + 1)
     for m in eng.modules():     # non-trivial BatchNorm statistics, non-zero biases, larger head weights
         if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
@@ -169,7 +173,7 @@ def full_run(request):
     cfg = dataclasses.replace(DetectorConfig.survey(), rpn_post_nms_top_n=256) if dense else DetectorConfig.survey()
     if request.param == "reference100":
         cfg = DetectorConfig()
-    eng = make_engine(seed=5, cfg=cfg).to(DEV)
+    eng = make_engine(seed=5, cfg=cfg, conv_find=True).to(DEV)
     xyz, img, xy = synth.frames(2, 65536 if dense else 16384, 4321)
     with torch.no_grad():
         eng(T(xyz), T(img), T(xy))                         # warm-up: packs / folds every weight
