@@ -66,7 +66,13 @@ def main():
             [p_ for p_ in model.rpn.rpn_reg_layer.parameters() if p_.dim() > 1][-1].mul_(0.02)
             [p_ for p_ in model.rpn.rpn_reg_layer.parameters() if p_.dim() == 1][-1].mul_(0.02)
             rpn_out = model.rpn(inp)
-            rois, _ = model.rpn.proposal_layer(rpn_out["rpn_cls"][:, :, 0], rpn_out["rpn_reg"], rpn_out["backbone_xyz"])
+            rois, roi_scores = model.rpn.proposal_layer(rpn_out["rpn_cls"][:, :, 0], rpn_out["rpn_reg"], rpn_out["backbone_xyz"])
+        # ProposalLayer with the TRAIN budgets (config.py:189-205: NMS threshold 0.85, 300 -> 48 here): frame 0's inputs and result
+        prop = dict(prop_xyz=xyz[:1], prop_cls=rpn_out["rpn_cls"][:1, :, 0].numpy(), prop_reg=rpn_out["rpn_reg"][:1].numpy(),
+                    prop_rois=rois[:1].numpy(), prop_scores=roi_scores[:1].numpy(),
+                    prop_params=np.array([cfg.TRAIN.RPN_PRE_NMS_TOP_N, cfg.TRAIN.RPN_POST_NMS_TOP_N, cfg.TRAIN.RPN_NMS_THRESH], np.float64))
+        with torch.no_grad():
+            pass
         # ground truth: a few of the proposals themselves (IoU 1 with at least one RoI), track ids shared between the frames of a pair
         G = 6
         gt_boxes = np.zeros((B, G, 7), np.float32)
@@ -98,6 +104,7 @@ def main():
                gt_ends=ret["gt_ends"].numpy(), loss=np.float64(loss.item()),
                loss_terms=np.array([tb.get("rcnn_loss_link_mean", 0.0), tb.get("rcnn_loss_start_mean", 0.0), tb.get("rcnn_loss_end_mean", 0.0)]),
                weights=np.array([cfg.TRAIN.LINK_TRAIN_WEIGHT, cfg.TRAIN.SE_TRAIN_WEIGHT], np.float64))
+    out.update(prop)
     out.update({f"grad.{k}": g.numpy() for k, g in zip(heads, grads)})
     out["grad.roi_feat"] = g_feat.squeeze(-1).view(B, R, -1).numpy()          # d(loss) / d(RoI features): what joint training sends back
     fg = (out["gt_tids"] > 0).sum(axis=1)

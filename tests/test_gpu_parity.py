@@ -804,6 +804,18 @@ def test_decode_rpn_proposals_and_whole_proposal_layer(oracle, avg_by_bin):
     assert np.array_equal(sc.cpu().numpy(), ws) and np.array_equal(boxes.cpu().numpy(), wb)
 
 
+def test_proposal_layer_train_budgets_vs_the_references_own_proposal_layer():
+    """proposal_layer on the GPU with the TRAIN budgets / threshold against the reference's ProposalLayer output stored in
+    train_ref.npz (tests/golden/make_golden_train.py)"""
+    import os
+    from jmodt_amd.ops.proposal import proposal_layer
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_ref.npz"))
+    pre, post, thr = int(g["prop_params"][0]), int(g["prop_params"][1]), float(g["prop_params"][2])
+    boxes, sc = proposal_layer(T(g["prop_cls"]), T(g["prop_reg"]), T(g["prop_xyz"]), pre_nms_top_n=pre, post_nms_top_n=post, nms_thresh=thr)
+    assert np.abs(boxes.cpu().numpy() - g["prop_rois"]).max() < 1e-4 * max(1.0, np.abs(g["prop_rois"]).max())
+    assert np.abs(sc.cpu().numpy() - g["prop_scores"]).max() < 1e-6
+
+
 def test_proposal_select_score_based(oracle):
     from jmodt_amd.ops.proposal import score_based_proposal
     scores, props = synth.rpn_output(3, 4096, seed=77)

@@ -617,3 +617,14 @@ def test_training_affinity_restatements_match_the_references_train_forward_and_l
         want = g["grad." + p_]
         got = torch.zeros_like(torch.from_numpy(want)) if got is None else got
         assert np.abs(got.numpy() - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-12) + 1e-8, p_
+
+
+def test_proposal_layer_train_budgets_match_the_reference(oracle):
+    """ProposalLayer with the TRAIN-mode budgets and threshold (train_ref.npz: frame 0 of the reference's TRAIN forward): the
+    oracle's decode + distance-band selection reproduce the reference's RoIs and scores"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_ref.npz"))
+    pre, post, thr = int(g["prop_params"][0]), int(g["prop_params"][1]), float(g["prop_params"][2])
+    dec = oracle.decode_rpn_proposals(g["prop_xyz"], g["prop_reg"])
+    rois, scores = oracle.proposal_select(g["prop_cls"], dec, pre, post, thr, "normal")
+    _close(rois, g["prop_rois"]); _close(scores, g["prop_scores"], 1e-6)
+    assert (np.abs(g["prop_rois"]).sum(-1) > 0).sum() >= 40
