@@ -414,3 +414,25 @@ def test_training_affinity_hip_kernels_vs_the_references_train_forward_and_loss(
             want = g[f"grad.rcnn_net.{head}.{k}"]
             got = p_.grad.cpu().numpy()
             assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-12) + 1e-7, (head, k)
+
+
+def test_inference_affinity_and_cost_vs_the_references_tracker_update():
+    """a15 + f1 on the GPU against tracker_ref.npz: the arguments the reference's own Tracker.update (tracker.py:50-112) built
+    for its solver — dual-softmax link scores, w_se * sigmoid(start / end), class scores — and the solver's cost matrix"""
+    from jmodt_amd.ops.affinity import pairwise_affinity
+    from jmodt_amd.ops.association import association_cost
+    from tests.test_oracle_cpu import reference_train_fixture
+    g, link, se = reference_train_fixture("tracker_ref.npz", "pred_feat")
+    link, se = link.to(DEV).eval(), se.to(DEV).eval()
+    w_cls, w_app, w_iou, w_dis, w_se = (float(v) for v in g["weights"])
+    P, D = g["pred_feat"].shape[0], g["det_feat"].shape[0]
+    G = lambda k: torch.from_numpy(g[k]).to(DEV)       # noqa: E731
+    A, start, end = pairwise_affinity(G("pred_feat"), G("det_feat"), link, se)
+    assert (A.cpu() - torch.from_numpy(g["solver.link"])).abs().max().item() < 1e-5
+    new = torch.cat([torch.zeros(P), (w_se * torch.sigmoid(start)).cpu()])
+    endv = torch.cat([(w_se * torch.sigmoid(end)).cpu(), torch.zeros(D)])
+    assert (new.double() - torch.from_numpy(g["solver.new"])).abs().max().item() < 1e-5
+    assert (endv.double() - torch.from_numpy(g["solver.end"])).abs().max().item() < 1e-5
+    cost, iou, dist = association_cost(G("pred_boxes"), G("det_boxes"), A, w_app, w_iou, w_dis, return_parts=True)
+    for got, key in ((cost, "solver.cost"), (iou, "solver.iou"), (dist, "solver.dis")):
+        assert (got.cpu() - torch.from_numpy(g[key])).abs().max().item() < 2e-5, key

@@ -569,15 +569,15 @@ def _np64(t):
 
 
 # ------------------------------------------------------------------ the reference's TRAINING affinity + re-id loss (train_ref.npz)
-def reference_train_fixture():
+def reference_train_fixture(name="train_ref.npz", feat_key="roi_feat"):
     """(npz, link_layer, se_layer with the reference's weights) of train_ref.npz: the reference's PointRCNN.forward in TRAIN mode +
-    get_rcnn_loss (FINETUNE) + autograd, run by tests/golden/make_golden_train.py"""
+    get_rcnn_loss (FINETUNE) + autograd, run by tests/golden/make_golden_train.py (also serves tracker_ref.npz: same heads)"""
     import json
     import torch
     from jmodt_amd.ops.affinity import make_affinity_mlp
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_ref.npz"))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
     sd = synth.seeded_state(json.loads(str(g["keys"])), int(g["seed"]))
-    C = g["roi_feat"].shape[2]
+    C = g[feat_key].shape[-1]
     heads = []
     for h in ("link_layer", "se_layer"):
         m = make_affinity_mlp(C, tuple(json.loads(str(g["config"]))["link_fc" if h == "link_layer" else "se_fc"]))
@@ -628,3 +628,26 @@ def test_proposal_layer_train_budgets_match_the_reference(oracle):
     rois, scores = oracle.proposal_select(g["prop_cls"], dec, pre, post, thr, "normal")
     _close(rois, g["prop_rois"]); _close(scores, g["prop_scores"], 1e-6)
     assert (np.abs(g["prop_rois"]).sum(-1) > 0).sum() >= 40
+
+
+# ------------------------------------------------------------------ the reference's Tracker.update (tests/golden/tracker_ref.npz)
+def _head_weights(h):
+    return tuple(a.detach().cpu().numpy().copy() for a in (
+        h[0].conv.weight[..., 0], h[0].conv.bias, h[2].conv.weight[..., 0], h[2].conv.bias, h[3].conv.weight.reshape(-1), h[3].conv.bias))
+
+
+def test_oracle_affinity_and_cost_match_the_references_tracker_update(oracle):
+    """tracker_ref.npz = every argument the reference's Tracker.update (tracker.py:50-112) hands to its assignment solver for a
+    frame with nine tracks and eleven detections, and the solver's cost matrix (data_association.py:42-44), recorded by
+    tests/golden/make_golden_tracker.py.  The oracle's inference affinity (a15) and association cost (f1) reproduce them."""
+    g, link, se = reference_train_fixture("tracker_ref.npz", "pred_feat")
+    w_cls, w_app, w_iou, w_dis, w_se = (float(v) for v in g["weights"])
+    P, D = g["pred_feat"].shape[0], g["det_feat"].shape[0]
+    A, start, end = oracle.affinity(g["pred_feat"], g["det_feat"], _head_weights(link), _head_weights(se))
+    sig = lambda z: 1.0 / (1.0 + np.exp(-z.astype(np.float64)))      # noqa: E731
+    assert np.abs(A - g["solver.link"]).max() < 1e-5
+    assert np.abs(np.concatenate([np.zeros(P), w_se * sig(start)]) - g["solver.new"]).max() < 1e-5
+    assert np.abs(np.concatenate([w_se * sig(end), np.zeros(D)]) - g["solver.end"]).max() < 1e-5
+    assert np.abs(w_cls * (np.concatenate([g["pred_scores"], g["det_scores"]]) - 1) - g["solver.cls"]).max() < 1e-6
+    assert np.abs(oracle.association_cost(g["pred_boxes"], g["det_boxes"], g["solver.link"], w_app, w_iou, w_dis) - g["solver.cost"]).max() < 1e-5
+    assert (g["solver.iou"] > 0.3).sum() >= 5 and g["solver.link"].max() > 0.15
