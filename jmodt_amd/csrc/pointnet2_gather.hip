@@ -57,7 +57,9 @@ group_points_kernel(int c, int n, int q_total, const float* __restrict__ points,
             const float* src = points + ((size_t)bi * c + ci) * n;
             float4 v;
             v.x = src[i4.x]; v.y = src[i4.y]; v.z = src[i4.z]; v.w = src[i4.w];
-            *reinterpret_cast<float4*>(out + ((size_t)bi * c + ci) * q_total + q) = v;
+            // streaming store: the grouped tensor (100 MB at level 2) is written once and read once, much later
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(out + ((size_t)bi * c + ci) * q_total + q));
         }
     } else {
         const int q = blockIdx.x * blockDim.x + threadIdx.x;
