@@ -345,6 +345,18 @@ int jm_conv1d_stack_forward(int b, int n, int c0, const float* x0, int c1, const
 int jm_conv3x3_rgb_bias_relu(int b, int h, int w, int cout, const float* image, const float* weight_tap_major,
                              const float* bias, float* out_channels_last, jm_stream_t stream);
 
+/* The image branch's stride-1 3x3 convolutions with their folded BatchNorm bias and ReLU in one kernel, as a fused Winograd
+ * F(2x2, 3x3) (backbone.py:16-32: BasicBlock.conv1 + bn1 + relu of Img_Block[1..3]; 2.25x fewer multiplications than the
+ * direct form, fp32 throughout, transformed tensors never leave the CU — csrc/conv_wino.hip).
+ * x (B, H, W, cin) and out (B, H, W, cout) = channels-last (B, C, H, W) tensors; padding 1, stride 1; cin % 8 == 0,
+ * cout % 64 == 0 (jm_conv3x3_wino_supported).  `packed` = jm_conv3x3_wino_pack of the (cout, cin, 3, 3) weight
+ * (16 * cin * cout floats: U = G g G^T in MFMA operand order, made once per weight); bias (cout) or NULL; relu != 0 applies it. */
+size_t jm_conv3x3_wino_packed_elems(int cin, int cout);
+int jm_conv3x3_wino_supported(int cin, int cout);
+int jm_conv3x3_wino_pack(int cin, int cout, const float* weight, float* packed, jm_stream_t stream);
+int jm_conv3x3_wino_bias_relu(int b, int h, int w, int cin, int cout, const float* x_channels_last, const float* packed,
+                              const float* bias, int relu, float* out_channels_last, jm_stream_t stream);
+
 /* x = relu(x + bias[c]) in place on CHANNELS-LAST data (numel = pixels * channels, channels % 4 == 0): the one
  * element-wise pass of the image branch's BasicBlock (backbone.py:16-32) once its eval-mode BatchNorm is folded into
  * the first convolution (replaces a BatchNorm pass + a ReLU pass over up to 1 GB). */

@@ -6,6 +6,8 @@ bilinear, zero padding.  The feature map is consumed through its strides, so a
 `torch.channels_last` map (what MIOpen prefers for the image branch's convolutions anyway) is
 gathered with 16-byte tap reads and without a layout copy.
 """
+from typing import Optional
+
 import torch
 from torch.autograd import Function
 
@@ -191,6 +193,41 @@ def conv3x3_rgb_bias_relu(image: torch.Tensor, weight: torch.Tensor, bias: torch
     out = torch.empty((B, cout, H, W), dtype=_f32, device=x.device, memory_format=torch.channels_last)
     L.check(L.load().jm_conv3x3_rgb_bias_relu(B, H, W, cout, L.dev(x, _f32, "image"), L.dev(wt, _f32, "weight"), L.dev(b, _f32, "bias"),
                                               ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "conv3x3_rgb")
+    return out
+
+
+def wino_supported(cin: int, cout: int) -> bool:
+    return bool(L.load().jm_conv3x3_wino_supported(int(cin), int(cout)))
+
+
+@torch.no_grad()
+def pack_wino_weight(weight: torch.Tensor) -> torch.Tensor:
+    """(cout, cin, 3, 3) -> the 16 * cin * cout floats jm_conv3x3_wino_bias_relu streams: U = G g G^T per (cin, cout) pair in
+    MFMA operand order (csrc/conv_wino.hip); made once per weight"""
+    import ctypes
+    w = weight.detach().to(_f32).contiguous()
+    cout, cin = w.shape[0], w.shape[1]
+    assert tuple(w.shape[2:]) == (3, 3)
+    lib = L.load()
+    packed = torch.empty(lib.jm_conv3x3_wino_packed_elems(cin, cout), dtype=_f32, device=w.device)
+    L.check(lib.jm_conv3x3_wino_pack(cin, cout, L.dev(w, _f32, "weight"), ctypes.c_void_p(packed.data_ptr()), L.stream_ptr()),
+            "conv3x3_wino_pack")
+    return packed
+
+
+@torch.no_grad()
+def conv3x3_wino_bias_relu(x: torch.Tensor, packed: torch.Tensor, bias: Optional[torch.Tensor], cout: int, relu: bool = True) -> torch.Tensor:
+    """x (B, cin, H, W) channels-last, packed = pack_wino_weight(weight (cout, cin, 3, 3)) -> relu(conv3x3(x, padding 1) + bias)
+    as a channels-last (B, cout, H, W) tensor: fused Winograd F(2x2, 3x3), fp32 (csrc/conv_wino.hip)"""
+    import ctypes
+    assert x.is_cuda and x.dtype == _f32 and x.is_contiguous(memory_format=torch.channels_last)
+    B, cin, H, W = x.shape
+    assert packed.numel() == 16 * cin * cout
+    b = bias.detach().to(_f32).contiguous() if bias is not None else None
+    out = torch.empty((B, cout, H, W), dtype=_f32, device=x.device, memory_format=torch.channels_last)
+    L.check(L.load().jm_conv3x3_wino_bias_relu(B, H, W, cin, cout, ctypes.c_void_p(x.data_ptr()), L.dev(packed, _f32, "packed"),
+                                               L.dev(b, _f32, "bias") if b is not None else None, int(relu),
+                                               ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "conv3x3_wino")
     return out
 
 

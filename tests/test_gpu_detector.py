@@ -719,6 +719,27 @@ def test_conv3x3_rgb_bias_relu_vs_torch(B, H, W, cout):
     close(got, want)
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W,bias,relu", [
+    (2, 64, 128, 48, 160, True, True), (1, 8, 64, 5, 7, True, True), (1, 16, 64, 33, 31, False, True), (2, 128, 256, 24, 80, True, False),
+    (1, 256, 512, 12, 40, True, True), (3, 24, 192, 9, 18, True, True), (1, 64, 128, 192, 640, True, True)])
+def test_conv3x3_wino_bias_relu_vs_torch(B, cin, cout, H, W, bias, relu):
+    """csrc/conv_wino.hip (fused Winograd F(2x2, 3x3) + bias + ReLU, channels-last, fp32) vs fp64 torch conv2d: odd sizes (partial
+    tiles and patches), one-chunk K, no bias / no ReLU, the three image-branch widths"""
+    from jmodt_amd.ops.fusion import conv3x3_wino_bias_relu, pack_wino_weight, wino_supported
+    assert wino_supported(cin, cout) and not wino_supported(cin + 4, cout) and not wino_supported(cin, cout + 16)
+    g = torch.Generator().manual_seed(H * W + cout + cin)
+    x = (torch.randn(B, cin, H, W, generator=g) + 0.2).to(DEV).contiguous(memory_format=torch.channels_last)
+    Wt = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(DEV)
+    b = (torch.randn(cout, generator=g) * 0.2).to(DEV) if bias else None
+    got = conv3x3_wino_bias_relu(x, pack_wino_weight(Wt), b, cout, relu=relu)
+    want = F.conv2d(x.double(), Wt.double(), b.double() if bias else None, padding=1)
+    want = torch.relu(want) if relu else want
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert (want > 0).any() and ((want == 0).any() if relu else (want < 0).any())
+    close(got, want)
+    assert (got.double() - want).abs().max().item() <= 2e-6 * want.abs().max().item()      # what the direct fp32 form achieves too
+
+
 def test_engine_stream_safety_soak(run):
     """the same batch through 12 steps with every overlap / prefetch on and allocator churn on the main stream in
     between: the pyramids are handed between streams without record_stream (ordered release), so a recycling race would
