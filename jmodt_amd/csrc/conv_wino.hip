@@ -64,8 +64,11 @@ wino_pack_kernel(int cin, int cout, const float* __restrict__ w, float* __restri
     reinterpret_cast<f32x4*>(up)[i] = (f32x4){o[0], o[1], o[2], o[3]};
 }
 
+// EXP (tools build only, JM_WN_EXP): ablations for tools/conv_wino_bench.py — bit 0: no input path (raw loads + transform),
+// bit 1: no weight stream, bit 2: no LDS operand reads.  0 in the product library.
+template <int EXP>
 __global__ void __launch_bounds__(256, 2)
-conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_y, unsigned total_work, unsigned x_bytes,
+conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_y, int npatches, int group, unsigned total_work, unsigned x_bytes,
                     const float* __restrict__ x, const float* __restrict__ up, const float* __restrict__ bias,
                     float* __restrict__ y, int relu) {
     __shared__ __attribute__((aligned(16))) float V[2 * WN_VBUF];
@@ -73,9 +76,14 @@ conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned work = blockIdx.x;
     if ((total_work & 7u) == 0) work = (work & 7u) * (total_work >> 3) + (work >> 3);   // an XCD walks a contiguous range
+    // `group` patches share one 64-channel block of U before the next block starts: the workgroups resident on an XCD stream
+    // the same 16 * cin * 64 floats (L2-resident) instead of cycling through all of U (8 MB at 256 -> 512: above the 4 MB L2)
     const int nblocks = cout / WN_TN;
-    const int nb = (int)(work % (unsigned)nblocks);
-    int patch = (int)(work / (unsigned)nblocks);
+    const unsigned per_group = (unsigned)group * (unsigned)nblocks;
+    const unsigned grp = work / per_group, rem = work - grp * per_group;
+    const unsigned gsize = min((unsigned)group, (unsigned)npatches - grp * (unsigned)group);
+    const int nb = (int)(rem / gsize);
+    int patch = (int)(grp * (unsigned)group + rem % gsize);
     const int px = patch % patches_x; patch /= patches_x;
     const int py = patch % patches_y;
     const int b = patch / patches_y;
@@ -115,10 +123,12 @@ conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_
     auto load_raw = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, roff[i], c * (WN_KC * 4), 0));
+            if (!(EXP & 1) && (!(EXP & 16) || c == 0)) d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, roff[i], c * (WN_KC * 4), 0));
     };
-    auto transform = [&](float* Vb) __attribute__((always_inline)) {
-        float t[16];
+    // B^T d B in two passes: columns (d -> t, 16 adds) and rows (t -> the 16 positions, 16 adds + 16 LDS writes); the row pass is
+    // issued one row per MFMA stage so that the vector work sits in the shadow of the matrix pipe
+    float t[16];
+    auto transform_cols = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             t[0 + j] = d[0 + j] - d[8 + j];
@@ -126,44 +136,64 @@ conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_
             t[8 + j] = d[8 + j] - d[4 + j];
             t[12 + j] = d[4 + j] - d[12 + j];
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            Vb[(i * 4 + 0) * 256 + wslot] = t[i * 4 + 0] - t[i * 4 + 2];
-            Vb[(i * 4 + 1) * 256 + wslot] = t[i * 4 + 1] + t[i * 4 + 2];
-            Vb[(i * 4 + 2) * 256 + wslot] = t[i * 4 + 2] - t[i * 4 + 1];
-            Vb[(i * 4 + 3) * 256 + wslot] = t[i * 4 + 1] - t[i * 4 + 3];
-        }
+    };
+    auto transform_row = [&](float* Vb, int i) __attribute__((always_inline)) {
+        if (EXP & 1) return;
+        if ((EXP & 32) && i < 4) { if (i == 0) Vb[wslot] = t[0] + t[5] + t[10] + t[15]; return; }
+        Vb[(i * 4 + 0) * 256 + wslot] = t[i * 4 + 0] - t[i * 4 + 2];
+        Vb[(i * 4 + 1) * 256 + wslot] = t[i * 4 + 1] + t[i * 4 + 2];
+        Vb[(i * 4 + 2) * 256 + wslot] = t[i * 4 + 2] - t[i * 4 + 1];
+        Vb[(i * 4 + 3) * 256 + wslot] = t[i * 4 + 1] - t[i * 4 + 3];
     };
     auto load_b = [&](f32x4 (&bf)[4], int kstep) __attribute__((always_inline)) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bf[g] = __builtin_nontemporal_load(ub + (size_t)kstep * 256 + g * 64);
+        for (int g = 0; g < 4; ++g)
+            if (!(EXP & 2) || kstep == 0) bf[g] = (EXP & 8) ? __builtin_nontemporal_load(ub + (size_t)kstep * 256 + g * 64) : ub[(size_t)kstep * 256 + g * 64];
     };
-    auto mma = [&](const float* Vb, int ks, const f32x4 (&bf)[4]) __attribute__((always_inline)) {
+    // one stage = 4 positions = 8 MFMAs; its A fragments (8 LDS reads) are fetched one stage ahead
+    float af[2][8];
+    auto load_a = [&](const float* Vb, int stage) __attribute__((always_inline)) {
+        const int ks = stage >> 2, g = stage & 3;
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const float a0 = Vb[p * 256 + aoff[ks][0]], a1 = Vb[p * 256 + aoff[ks][1]];
-            const float bv = bf[p >> 2][p & 3];
-            acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[p][0], 0, 0, 0);
-            acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[p][1], 0, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+            if (EXP & 4) { af[stage & 1][2 * q] = af[stage & 1][2 * q + 1] = (float)(q + stage); continue; }
+            af[stage & 1][2 * q] = Vb[(g * 4 + q) * 256 + aoff[ks][0]];
+            af[stage & 1][2 * q + 1] = Vb[(g * 4 + q) * 256 + aoff[ks][1]];
+        }
+    };
+    auto mma = [&](int stage, const f32x4& bf) __attribute__((always_inline)) {
+        const int g = stage & 3;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc[g * 4 + q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[stage & 1][2 * q], bf[q], acc[g * 4 + q][0], 0, 0, 0);
+            acc[g * 4 + q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[stage & 1][2 * q + 1], bf[q], acc[g * 4 + q][1], 0, 0, 0);
         }
     };
 
     f32x4 b0[4], b1[4];
     load_raw(0);
     load_b(b0, 0);
-    transform(V);
+    transform_cols();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) transform_row(V, i);
     if (nch > 1) load_raw(1);
     __syncthreads();
     for (int c = 0; c < nch; ++c) {
         const float* Vc = V + (c & 1) * WN_VBUF;
+        float* Vn = V + ((c + 1) & 1) * WN_VBUF;
+        const bool more = c + 1 < nch;
+        load_a(Vc, 0);
         load_b(b1, 2 * c + 1);
-        mma(Vc, 0, b0);
-        if (c + 1 < nch) load_b(b0, 2 * c + 2);
-        mma(Vc, 1, b1);
-        if (c + 1 < nch) {
-            transform(V + ((c + 1) & 1) * WN_VBUF);
-            if (c + 2 < nch) load_raw(c + 2);
+        if (more) transform_cols();
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            if (st < 7) load_a(Vc, st + 1);
+            if (st == 4 && more) load_b(b0, 2 * c + 2);
+            mma(st, st < 4 ? b0[st & 3] : b1[st & 3]);
+            if (st >= 4 && more) transform_row(Vn, st - 4);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (c + 2 < nch) load_raw(c + 2);
         __syncthreads();
     }
 
@@ -227,7 +257,23 @@ extern "C" int jm_conv3x3_wino_bias_relu(int b, int h, int w, int cin, int cout,
     const int tx = divup(w, 2), ty = divup(h, 2), pxs = divup(tx, 8), pys = divup(ty, 4);
     const unsigned long long total = (unsigned long long)b * pxs * pys * (cout / WN_TN);
     JM_REQUIRE(total < 0x7FFFFFFFull, "conv3x3_wino: grid limit");
-    hipLaunchKernelGGL(conv3x3_wino_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, h, w, cin, cout, pxs, pys,
-                       (unsigned)total, (unsigned)xb, x_channels_last, packed, bias, out_channels_last, relu);
+    const int npatches = b * pxs * pys, group = tune_env("JM_WN_G", 16);
+#define WN_LAUNCH(E) hipLaunchKernelGGL(conv3x3_wino_kernel<E>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, h, w, cin, cout, pxs, pys, npatches, group, \
+                                        (unsigned)total, (unsigned)xb, x_channels_last, packed, bias, out_channels_last, relu)
+#ifdef JM_TOOLS_BUILD
+    switch (tune_env("JM_WN_EXP", 0)) {
+        case 1: WN_LAUNCH(1); break;
+        case 2: WN_LAUNCH(2); break;
+        case 3: WN_LAUNCH(3); break;
+        case 4: WN_LAUNCH(4); break;
+        case 7: WN_LAUNCH(7); break;
+        case 8: WN_LAUNCH(8); break;
+        case 16: WN_LAUNCH(16); break;
+        case 32: WN_LAUNCH(32); break;
+        default: WN_LAUNCH(0);
+    }
+#else
+    WN_LAUNCH(0);
+#endif
     return check_launch("conv3x3_wino");
 }
