@@ -348,7 +348,7 @@ int jm_conv3x3_rgb_bias_relu(int b, int h, int w, int cout, const float* image, 
 /* The image branch's stride-1 3x3 convolutions with their folded BatchNorm bias and ReLU in one kernel, as a fused Winograd
  * F(2x2, 3x3) (backbone.py:16-32: BasicBlock.conv1 + bn1 + relu of Img_Block[1..3]; 2.25x fewer multiplications than the
  * direct form, fp32 throughout, transformed tensors never leave the CU — csrc/conv_wino.hip).
- * x (B, H, W, cin) and out (B, H, W, cout) = channels-last (B, C, H, W) tensors; padding 1, stride 1; cin % 8 == 0,
+ * x (B, H, W, cin) and out (B, H, W, cout) = channels-last (B, C, H, W) tensors; padding 1, stride 1; cin % 16 == 0,
  * cout % 64 == 0 (jm_conv3x3_wino_supported).  `packed` = jm_conv3x3_wino_pack of the (cout, cin, 3, 3) weight
  * (16 * cin * cout floats: U = G g G^T in MFMA operand order, made once per weight); bias (cout) or NULL; relu != 0 applies it. */
 size_t jm_conv3x3_wino_packed_elems(int cin, int cout);

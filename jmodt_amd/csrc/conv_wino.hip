@@ -4,7 +4,7 @@
 // backbone.py:16-32: BasicBlock.conv1 + bn1 + relu of Img_Block[1..3] (64 -> 128 at 192 x 640, 128 -> 256 at 96 x 320,
 // 256 -> 512 at 48 x 160; eval-mode BatchNorm folded into weight and bias by the caller): 3 x 145 GFLOP = 60 % of the image
 // branch's arithmetic, which is half of the detect step.  As a direct convolution the fp32 MFMA pipe bounds each layer at
-// 0.92 ms (157.3 TF); the library's implicit GEMM runs at 0.66-0.81 of that plus a bias/ReLU pass over the output.
+// 0.92 ms (157.3 TF); the library's implicit GEMM runs at 0.78-0.81 of that (1.14-1.19 ms) plus a bias/ReLU pass over the output.
 // Winograd's minimal filtering needs 16 products per 2x2 output tile and (cin, cout) pair instead of 36: 64.4 GFLOP of
 // MFMA work per layer, bound 0.41 ms.  Un-fused (transform kernels + 16 GEMMs + inverse transform) the transformed
 // tensors move 6.7 GB per layer and lose to the direct form; here they never leave the CU:
@@ -12,26 +12,37 @@
 //     every wave owns ALL 16 transform positions of 32 tiles x 16 channels: 16 x 2 accumulator blocks of
 //     v_mfma_f32_16x16x4_f32 (128 registers) — the inverse transform A^T M A is then lane-local arithmetic on the
 //     accumulators, no exchange;
-//   * the input transform B^T d B is done by the workgroup's 256 threads, one (tile, channel) each per 8-channel chunk:
-//     16 buffer loads (out-of-image taps read 0 through the buffer descriptor's range check — no masks), 32 adds, 16 LDS
-//     writes into a double-buffered V[16][8][32] (16 KB per buffer; bank = tile + 16 (k & 1) + 4 (k >> 1): writes and
-//     MFMA operand reads both conflict-free), one barrier per chunk;
-//   * the transformed weights U = G g G^T are packed once, in MFMA B-operand order ([16-channel block][k-step][position
-//     group][lane][4]), and stream from L2 straight into registers as fully coalesced 1 KB wave loads, one k-step ahead:
-//     no LDS for the weights (16 positions x 16 channels per wave have no reuse inside the workgroup).
-// Per 2 k-steps a wave issues 64 MFMAs, 64 ds_read_b32, 8 global_load_dwordx4 and its share of the transform.
+//   * the input transform B^T d B is done by the workgroup's 256 threads, one (tile, channel PAIR) each per 16-channel chunk:
+//     16 buffer_load_dwordx2 (out-of-image taps read 0 through the buffer descriptor's range check — no masks), 32 packed
+//     adds, 16 ds_write_b64 into a double-buffered V[16 positions][8 pairs][32 tiles][2] (32 KB per buffer), one barrier per
+//     chunk.  The k order inside a chunk is permuted so that the two channels of a pair are the SAME lane's operand in two
+//     consecutive MFMA k-steps (k-step 2j + e, lane quarter q <-> channel 2 (4 j + q) + e): one ds_read_b64 feeds two MFMAs.
+//     tile' = tile + 16 (pair & 1) + 4 (pair >> 1) mod 32 keeps the 64-bit writes (16-lane groups) and reads (32-lane groups)
+//     both free of bank conflicts;
+//   * the transformed weights U = G g G^T are packed once, in MFMA B-operand order with the same k permutation ([16-channel
+//     block][k-step][position group][lane][4]), and stream from L2 / L1 straight into registers as fully coalesced 1 KB wave
+//     loads, three stages ahead: no LDS for the weights (the two workgroups resident on a CU share them through L1: the
+//     default cache policy measured 10-20 % faster than non-temporal loads);
+//   * work order: an XCD walks a contiguous range, inside it `group` patches share one 64-channel block of U before the next
+//     block starts.
+// Measured (tools/conv_wino_bench.py, batch 8): see DESIGN.md §4; error vs float64 3-6e-7 of the output range, the direct
+// fp32 form 7e-7-1.4e-6.
 #include "jm_common.h"
 
 namespace jm {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int WN_KC = 8;                     // input channels per chunk = two k-steps of the 16x16x4 MFMA
-constexpr int WN_TILES = 32;                 // 4 x 8 output tiles of 2 x 2 pixels per workgroup
+constexpr int WN_KC = 16;                    // input channels per chunk = four k-steps of the 16x16x4 MFMA
 constexpr int WN_TN = 64;                    // output channels per workgroup (16 per wave)
-constexpr int WN_VBUF = 16 * WN_KC * WN_TILES;   // floats per V buffer
+constexpr int WN_ABUF = 2;                   // A-operand stage buffers (2: fetched one stage ahead; 254 registers, no spills)
+constexpr int WN_POS = 8 * 32 * 2;           // floats per transform position in a V buffer: [pair][tile'][2]
+constexpr int WN_VBUF = 16 * WN_POS;         // floats per V buffer (32 KB)
 
-__device__ __forceinline__ int wn_voff(int k, int tile) { return k * 32 + ((tile + 16 * (k & 1) + 4 * (k >> 1)) & 31); }
+// channel (of a 16-channel chunk) that lane quarter kq multiplies in k-step ks of the chunk
+__host__ __device__ constexpr int wn_channel(int ks, int kq) { return 2 * (4 * (ks >> 1) + kq) + (ks & 1); }
+__device__ __forceinline__ int wn_slot(int pair, int tile) { return (pair * 32 + ((tile + 16 * (pair & 1) + 4 * (pair >> 1)) & 31)) * 2; }
 
 // U[p][q] = sum_ab G[p][a] g[a][b] G[q][b], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; one thread per packed float4
 __global__ void __launch_bounds__(256)
@@ -43,7 +54,7 @@ wino_pack_kernel(int cin, int cout, const float* __restrict__ w, float* __restri
     const int lane = (int)(i & 63), pg = (int)((i >> 6) & 3);
     const long long r = i >> 8;
     const int kstep = (int)(r % ksteps), nblk = (int)(r / ksteps);
-    const int ci = 4 * kstep + (lane >> 4), co = 16 * nblk + (lane & 15);
+    const int ci = WN_KC * (kstep >> 2) + wn_channel(kstep & 3, lane >> 4), co = 16 * nblk + (lane & 15);
     const float* g = w + ((size_t)co * cin + ci) * 9;
     double gg[3][3];
 #pragma unroll
@@ -64,9 +75,6 @@ wino_pack_kernel(int cin, int cout, const float* __restrict__ w, float* __restri
     reinterpret_cast<f32x4*>(up)[i] = (f32x4){o[0], o[1], o[2], o[3]};
 }
 
-// EXP (tools build only, JM_WN_EXP): ablations for tools/conv_wino_bench.py — bit 0: no input path (raw loads + transform),
-// bit 1: no weight stream, bit 2: no LDS operand reads.  0 in the product library.
-template <int EXP>
 __global__ void __launch_bounds__(256, 2)
 conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_y, int npatches, int group, unsigned total_work, unsigned x_bytes,
                     const float* __restrict__ x, const float* __restrict__ up, const float* __restrict__ bias,
@@ -76,8 +84,6 @@ conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned work = blockIdx.x;
     if ((total_work & 7u) == 0) work = (work & 7u) * (total_work >> 3) + (work >> 3);   // an XCD walks a contiguous range
-    // `group` patches share one 64-channel block of U before the next block starts: the workgroups resident on an XCD stream
-    // the same 16 * cin * 64 floats (L2-resident) instead of cycling through all of U (8 MB at 256 -> 512: above the 4 MB L2)
     const int nblocks = cout / WN_TN;
     const unsigned per_group = (unsigned)group * (unsigned)nblocks;
     const unsigned grp = work / per_group, rem = work - grp * per_group;
@@ -88,30 +94,29 @@ conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_
     const int py = patch % patches_y;
     const int b = patch / patches_y;
 
-    // ---- input-transform role: one (tile, channel of the chunk) per thread ----
-    const int kk = tid & 7, ttile = tid >> 3;
-    unsigned roff[16];
+    // ---- input-transform role: one (tile, channel pair of the chunk) per thread.  Lane bits: [1:0] pair >> 1, [3:2] tile & 3,
+    //      [4] pair & 1, [5] tile bit 2; wave = tile >> 3 (one row of 8 tiles): a 16-lane group writes 32 distinct banks ----
+    const int tpair = 2 * (lane & 3) + ((lane >> 4) & 1), ttile = wave * 8 + ((lane >> 5) & 1) * 4 + ((lane >> 2) & 3);
+    unsigned rrow[4], rcol[4];                 // byte offsets of the 4 rows / 4 columns of the tile's input window; 0xFFFFFF00 = outside
     {
         const int oy = (py * 4 + (ttile >> 3)) * 2 - 1, ox = (px * 8 + (ttile & 7)) * 2 - 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int iy = oy + i, ix = ox + j;
-                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-                roff[i * 4 + j] = ok ? (unsigned)((((size_t)b * H + iy) * W + ix) * cin + kk) * 4u : 0xFFFFFF00u;
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int iy = oy + i, ix = ox + i;
+            rrow[i] = (iy >= 0 && iy < H) ? (unsigned)(((size_t)b * H + iy) * W) * (unsigned)cin * 4u + (unsigned)tpair * 8u : 0xFFFFFF00u;
+            rcol[i] = (ix >= 0 && ix < W) ? (unsigned)ix * (unsigned)cin * 4u : 0xFFFFFF00u;
+        }
     }
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)x_bytes, 0x00020000);
-    const int wslot = wn_voff(kk, ttile);
+    const int wslot = wn_slot(tpair, ttile);
 
     // ---- MFMA role ----
     const int m = lane & 15, kq = lane >> 4;
-    int aoff[2][2];
+    int aoff[2][2];                            // [j = k-step pair of the chunk][a = tile half]: float offset of the lane's 64-bit operand
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int a = 0; a < 2; ++a) aoff[ks][a] = wn_voff(4 * ks + kq, 16 * a + m);
+        for (int a = 0; a < 2; ++a) aoff[j][a] = wn_slot(4 * j + kq, 16 * a + m);
     const int ksteps = cin >> 2, nch = cin / WN_KC;
     const f32x4* ub = reinterpret_cast<const f32x4*>(up) + ((size_t)(nb * 4 + wave) * ksteps) * 256 + lane;
 
@@ -119,81 +124,87 @@ conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_
 #pragma unroll
     for (int p = 0; p < 16; ++p) acc[p][0] = acc[p][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float d[16];
+    f32x2 d[16];
     auto load_raw = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (!(EXP & 1) && (!(EXP & 16) || c == 0)) d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, roff[i], c * (WN_KC * 4), 0));
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // saturating sum: either part outside the image keeps the offset above the buffer's size
+                const unsigned off = (rrow[i] | rcol[j]) >= 0xFFFFFF00u ? 0xFFFFFF00u : rrow[i] + rcol[j];
+                d[i * 4 + j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, off, c * (WN_KC * 4), 0));
+            }
     };
-    // B^T d B in two passes: columns (d -> t, 16 adds) and rows (t -> the 16 positions, 16 adds + 16 LDS writes); the row pass is
-    // issued one row per MFMA stage so that the vector work sits in the shadow of the matrix pipe
-    float t[16];
+    // B^T d B in two passes: columns (in place, 16 packed adds) and rows (16 packed adds + 16 LDS writes); the row pass is issued
+    // one row per MFMA stage so that the vector work sits in the shadow of the matrix pipe
     auto transform_cols = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            t[0 + j] = d[0 + j] - d[8 + j];
-            t[4 + j] = d[4 + j] + d[8 + j];
-            t[8 + j] = d[8 + j] - d[4 + j];
-            t[12 + j] = d[4 + j] - d[12 + j];
+            const f32x2 t0 = d[0 + j] - d[8 + j], t1 = d[4 + j] + d[8 + j], t2 = d[8 + j] - d[4 + j], t3 = d[4 + j] - d[12 + j];
+            d[0 + j] = t0; d[4 + j] = t1; d[8 + j] = t2; d[12 + j] = t3;
         }
     };
     auto transform_row = [&](float* Vb, int i) __attribute__((always_inline)) {
-        if (EXP & 1) return;
-        if ((EXP & 32) && i < 4) { if (i == 0) Vb[wslot] = t[0] + t[5] + t[10] + t[15]; return; }
-        Vb[(i * 4 + 0) * 256 + wslot] = t[i * 4 + 0] - t[i * 4 + 2];
-        Vb[(i * 4 + 1) * 256 + wslot] = t[i * 4 + 1] + t[i * 4 + 2];
-        Vb[(i * 4 + 2) * 256 + wslot] = t[i * 4 + 2] - t[i * 4 + 1];
-        Vb[(i * 4 + 3) * 256 + wslot] = t[i * 4 + 1] - t[i * 4 + 3];
+        f32x2* o = reinterpret_cast<f32x2*>(Vb + wslot);
+        o[(i * 4 + 0) * (WN_POS / 2)] = d[i * 4 + 0] - d[i * 4 + 2];
+        o[(i * 4 + 1) * (WN_POS / 2)] = d[i * 4 + 1] + d[i * 4 + 2];
+        o[(i * 4 + 2) * (WN_POS / 2)] = d[i * 4 + 2] - d[i * 4 + 1];
+        o[(i * 4 + 3) * (WN_POS / 2)] = d[i * 4 + 1] - d[i * 4 + 3];
     };
-    auto load_b = [&](f32x4 (&bf)[4], int kstep) __attribute__((always_inline)) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            if (!(EXP & 2) || kstep == 0) bf[g] = (EXP & 8) ? __builtin_nontemporal_load(ub + (size_t)kstep * 256 + g * 64) : ub[(size_t)kstep * 256 + g * 64];
+    // one stage = 4 positions x 2 k-steps = 16 MFMAs: its A operands are 8 ds_read_b64 (one stage ahead), its B operands two 1 KB
+    // wave loads (ring of 4: three stages ahead)
+    f32x4 bq[4][2];
+    f32x2 af[WN_ABUF][8];
+    auto load_b = [&](int slot, int stage_global) __attribute__((always_inline)) {   // stage_global = 8 * chunk + 4 * j + g; slot = g (static)
+        const size_t ks0 = (size_t)(stage_global >> 2) * 2;                   // first k-step of the pair
+        bq[slot][0] = ub[ks0 * 256 + (stage_global & 3) * 64];
+        bq[slot][1] = ub[(ks0 + 1) * 256 + (stage_global & 3) * 64];
     };
-    // one stage = 4 positions = 8 MFMAs; its A fragments (8 LDS reads) are fetched one stage ahead
-    float af[2][8];
     auto load_a = [&](const float* Vb, int stage) __attribute__((always_inline)) {
-        const int ks = stage >> 2, g = stage & 3;
+        const int j = stage >> 2, g = stage & 3;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (EXP & 4) { af[stage & 1][2 * q] = af[stage & 1][2 * q + 1] = (float)(q + stage); continue; }
-            af[stage & 1][2 * q] = Vb[(g * 4 + q) * 256 + aoff[ks][0]];
-            af[stage & 1][2 * q + 1] = Vb[(g * 4 + q) * 256 + aoff[ks][1]];
+            af[stage % WN_ABUF][2 * q] = *reinterpret_cast<const f32x2*>(Vb + (g * 4 + q) * WN_POS + aoff[j][0]);
+            af[stage % WN_ABUF][2 * q + 1] = *reinterpret_cast<const f32x2*>(Vb + (g * 4 + q) * WN_POS + aoff[j][1]);
         }
     };
-    auto mma = [&](int stage, const f32x4& bf) __attribute__((always_inline)) {
+    auto mma = [&](int stage) __attribute__((always_inline)) {
         const int g = stage & 3;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            acc[g * 4 + q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[stage & 1][2 * q], bf[q], acc[g * 4 + q][0], 0, 0, 0);
-            acc[g * 4 + q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[stage & 1][2 * q + 1], bf[q], acc[g * 4 + q][1], 0, 0, 0);
-        }
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float bv = bq[stage & 3][e][q];
+                acc[g * 4 + q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[stage % WN_ABUF][2 * q][e], bv, acc[g * 4 + q][0], 0, 0, 0);
+                acc[g * 4 + q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[stage % WN_ABUF][2 * q + 1][e], bv, acc[g * 4 + q][1], 0, 0, 0);
+            }
     };
 
-    f32x4 b0[4], b1[4];
+    // the k-loop body is branch-free (indices clamped instead: the last chunks re-load valid data and transform into the buffer
+    // nobody reads any more): with conditional loads hipcc's s_waitcnt placement falls back to vmcnt(0..1) and the prefetch is lost
+    const int last_stage = nch * 8 - 1;
     load_raw(0);
-    load_b(b0, 0);
+    load_b(0, 0); load_b(1, min(1, last_stage)); load_b(2, min(2, last_stage));
     transform_cols();
 #pragma unroll
     for (int i = 0; i < 4; ++i) transform_row(V, i);
-    if (nch > 1) load_raw(1);
+    load_raw(min(1, nch - 1));
     __syncthreads();
     for (int c = 0; c < nch; ++c) {
         const float* Vc = V + (c & 1) * WN_VBUF;
         float* Vn = V + ((c + 1) & 1) * WN_VBUF;
-        const bool more = c + 1 < nch;
-        load_a(Vc, 0);
-        load_b(b1, 2 * c + 1);
-        if (more) transform_cols();
+        if (WN_ABUF == 2) load_a(Vc, 0);
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
-            if (st < 7) load_a(Vc, st + 1);
-            if (st == 4 && more) load_b(b0, 2 * c + 2);
-            mma(st, st < 4 ? b0[st & 3] : b1[st & 3]);
-            if (st >= 4 && more) transform_row(Vn, st - 4);
+            if (WN_ABUF == 1) load_a(Vc, st);
+            else if (st < 7) load_a(Vc, st + 1);
+            load_b((st + 3) & 3, min(c * 8 + st + 3, last_stage));
+            mma(st);
+            if (st == 3) transform_cols();       // the next chunk's window was requested four stages ago (end of the previous iteration)
+            if (st >= 4) transform_row(Vn, st - 4);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (c + 2 < nch) load_raw(c + 2);
+        load_raw(min(c + 2, nch - 1));
         __syncthreads();
     }
 
@@ -236,7 +247,7 @@ extern "C" size_t jm_conv3x3_wino_packed_elems(int cin, int cout) { return (size
 extern "C" int jm_conv3x3_wino_supported(int cin, int cout) { return cin >= WN_KC && cin % WN_KC == 0 && cout >= WN_TN && cout % WN_TN == 0; }
 
 extern "C" int jm_conv3x3_wino_pack(int cin, int cout, const float* weight, float* packed, jm_stream_t stream) {
-    JM_REQUIRE(jm_conv3x3_wino_supported(cin, cout), "conv3x3_wino_pack: cin %% 8 == 0 and cout %% 64 == 0");
+    JM_REQUIRE(jm_conv3x3_wino_supported(cin, cout), "conv3x3_wino_pack: cin %% 16 == 0 and cout %% 64 == 0");
     JM_REQUIRE(weight && packed, "conv3x3_wino_pack: null pointer");
     JM_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15u) == 0, "conv3x3_wino_pack: 16-byte alignment");
     const long long total = (long long)(cout >> 4) * (cin >> 2) * 256;
@@ -248,7 +259,7 @@ extern "C" int jm_conv3x3_wino_bias_relu(int b, int h, int w, int cin, int cout,
                                          const float* packed, const float* bias, int relu, float* out_channels_last,
                                          jm_stream_t stream) {
     JM_REQUIRE(b >= 0 && h >= 0 && w >= 0, "conv3x3_wino: negative size");
-    JM_REQUIRE(jm_conv3x3_wino_supported(cin, cout), "conv3x3_wino: cin %% 8 == 0 and cout %% 64 == 0");
+    JM_REQUIRE(jm_conv3x3_wino_supported(cin, cout), "conv3x3_wino: cin %% 16 == 0 and cout %% 64 == 0");
     if (b == 0 || h == 0 || w == 0) return JM_OK;
     JM_REQUIRE(x_channels_last && packed && out_channels_last, "conv3x3_wino: null pointer");
     JM_REQUIRE(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(x_channels_last)) & 15u) == 0, "conv3x3_wino: 16-byte alignment");
@@ -258,22 +269,7 @@ extern "C" int jm_conv3x3_wino_bias_relu(int b, int h, int w, int cin, int cout,
     const unsigned long long total = (unsigned long long)b * pxs * pys * (cout / WN_TN);
     JM_REQUIRE(total < 0x7FFFFFFFull, "conv3x3_wino: grid limit");
     const int npatches = b * pxs * pys, group = tune_env("JM_WN_G", 16);
-#define WN_LAUNCH(E) hipLaunchKernelGGL(conv3x3_wino_kernel<E>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, h, w, cin, cout, pxs, pys, npatches, group, \
-                                        (unsigned)total, (unsigned)xb, x_channels_last, packed, bias, out_channels_last, relu)
-#ifdef JM_TOOLS_BUILD
-    switch (tune_env("JM_WN_EXP", 0)) {
-        case 1: WN_LAUNCH(1); break;
-        case 2: WN_LAUNCH(2); break;
-        case 3: WN_LAUNCH(3); break;
-        case 4: WN_LAUNCH(4); break;
-        case 7: WN_LAUNCH(7); break;
-        case 8: WN_LAUNCH(8); break;
-        case 16: WN_LAUNCH(16); break;
-        case 32: WN_LAUNCH(32); break;
-        default: WN_LAUNCH(0);
-    }
-#else
-    WN_LAUNCH(0);
-#endif
+    hipLaunchKernelGGL(conv3x3_wino_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, h, w, cin, cout, pxs, pys, npatches, group,
+                       (unsigned)total, (unsigned)xb, x_channels_last, packed, bias, out_channels_last, relu);
     return check_launch("conv3x3_wino");
 }

@@ -564,7 +564,7 @@ class DetectAffinityEngine(nn.Module):
             torch.backends.cudnn.benchmark = prev
 
     def _wino_ok(self, conv: nn.Conv2d, x: torch.Tensor) -> bool:
-        """3x3 / stride 1 / padding 1 on a channels-last fp32 device tensor with cin % 8 == 0, cout % 64 == 0"""
+        """3x3 / stride 1 / padding 1 on a channels-last fp32 device tensor with cin % 16 == 0, cout % 64 == 0"""
         return bool(self.wino_conv and x.is_cuda and x.dtype == torch.float32 and tuple(conv.kernel_size) == (3, 3)
                     and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1) and conv.groups == 1
                     and tuple(conv.dilation) == (1, 1) and x.shape[1] == conv.in_channels

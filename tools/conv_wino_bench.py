@@ -6,7 +6,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from jmodt_amd import _lib
 from jmodt_amd.csrc import build as _hip_build
-if os.environ.get("JM_WN_EXP"):          # ablation switches live in the tools build only
+if os.environ.get("JM_WN_G"):            # patches per channel-block group: a switch of the tools build only
     _lib.LIB_PATH = _hip_build.TOOLS_LIB
 from jmodt_amd.ops.fusion import bias_relu_, conv3x3_wino_bias_relu, pack_wino_weight
 
@@ -36,10 +36,6 @@ for cin, cout, H, W in ((64, 128, 192, 640), (128, 256, 96, 320), (256, 512, 48,
     e_w = (y[:1].double() - r64).abs().max().item() / scale
     e_m = (ref[:1].double() - r64).abs().max().item() / scale
     t_w = timeit(lambda: conv3x3_wino_bias_relu(x, packed, b, cout))
-    if os.environ.get("JM_WN_EXP"):
-        fl = 2 * 9 * cin * cout * H * W * B
-        print(f"EXP {os.environ['JM_WN_EXP']} {cin}->{cout}: {t_w:.3f} ms ({fl / 2.25 / t_w / 1e9:.1f} TF MFMA)", flush=True)
-        continue
     t_m = timeit(lambda: bias_relu_(F.conv2d(x, wcl, None, padding=1), b))
     t_c = timeit(lambda: F.conv2d(x, wcl, None, padding=1))
     fl = 2 * 9 * cin * cout * H * W * B
