@@ -75,6 +75,15 @@ wino_pack_kernel(int cin, int cout, const float* __restrict__ w, float* __restri
     reinterpret_cast<f32x4*>(up)[i] = (f32x4){o[0], o[1], o[2], o[3]};
 }
 
+#ifdef JM_TOOLS_BUILD
+// tools/wino_trace.py: shader-clock stamps of every stage of sampled workgroups (LDS during the run, dumped at the end)
+__device__ unsigned long long* g_wn_trace = nullptr;
+constexpr int WN_TR = 11 * 16 + 4;           // stamps per wave: (top + 8 stages + loads + barrier) x up to 16 chunks + 4 marks
+#define WN_STAMP(i) (tr[(i)] = __builtin_readcyclecounter())
+#else
+#define WN_STAMP(i) ((void)0)
+#endif
+
 __global__ void __launch_bounds__(256, 2)
 conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_y, int npatches, int group, unsigned total_work, unsigned x_bytes,
                     const float* __restrict__ x, const float* __restrict__ up, const float* __restrict__ bias,
@@ -82,6 +91,11 @@ conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_
     __shared__ __attribute__((aligned(16))) float V[2 * WN_VBUF];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef JM_TOOLS_BUILD
+    __shared__ unsigned long long trace[4 * WN_TR];
+    unsigned long long* tr = trace + wave * WN_TR;
+    WN_STAMP(WN_TR - 4);
+#endif
     unsigned work = blockIdx.x;
     if ((total_work & 7u) == 0) work = (work & 7u) * (total_work >> 3) + (work >> 3);   // an XCD walks a contiguous range
     const int nblocks = cout / WN_TN;
@@ -190,10 +204,12 @@ conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_
     for (int i = 0; i < 4; ++i) transform_row(V, i);
     load_raw(min(1, nch - 1));
     __syncthreads();
+    WN_STAMP(WN_TR - 3);
     for (int c = 0; c < nch; ++c) {
         const float* Vc = V + (c & 1) * WN_VBUF;
         float* Vn = V + ((c + 1) & 1) * WN_VBUF;
         if (WN_ABUF == 2) load_a(Vc, 0);
+        WN_STAMP((c & 15) * 11);
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
             if (WN_ABUF == 1) load_a(Vc, st);
@@ -202,10 +218,13 @@ conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_
             mma(st);
             if (st == 3) transform_cols();       // the next chunk's window was requested four stages ago (end of the previous iteration)
             if (st >= 4) transform_row(Vn, st - 4);
+            WN_STAMP((c & 15) * 11 + 1 + st);
             __builtin_amdgcn_sched_barrier(0);
         }
         load_raw(min(c + 2, nch - 1));
+        WN_STAMP((c & 15) * 11 + 9);
         __syncthreads();
+        WN_STAMP((c & 15) * 11 + 10);
     }
 
     // ---- inverse transform Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]), bias, ReLU, store ----
@@ -236,11 +255,27 @@ conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_
                 }
             }
         }
+#ifdef JM_TOOLS_BUILD
+    WN_STAMP(WN_TR - 2);
+    if (g_wn_trace && blockIdx.x % 509 == 100) {          // a few dozen workgroups spread over the grid
+        __syncthreads();
+        unsigned long long* dst = g_wn_trace + (size_t)(blockIdx.x / 509) * (4 * WN_TR + 4);
+        for (int i = tid; i < 4 * WN_TR; i += 256) dst[i] = trace[i];
+        if (tid == 0) { dst[4 * WN_TR] = blockIdx.x; dst[4 * WN_TR + 1] = nch; dst[4 * WN_TR + 2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); }
+    }
+#endif
 }
 
 }  // namespace jm
 
 using namespace jm;
+
+#ifdef JM_TOOLS_BUILD
+extern "C" __attribute__((visibility("default"))) int jm_tools_wino_trace(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wn_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+extern "C" __attribute__((visibility("default"))) int jm_tools_wino_trace_stride(void) { return 4 * WN_TR + 4; }
+#endif
 
 extern "C" size_t jm_conv3x3_wino_packed_elems(int cin, int cout) { return (size_t)16 * (size_t)cin * (size_t)cout; }
 
