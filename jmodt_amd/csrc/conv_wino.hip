@@ -27,6 +27,8 @@
 //     block starts.
 // Measured (tools/conv_wino_bench.py, batch 8): see DESIGN.md §4; error vs float64 3-6e-7 of the output range, the direct
 // fp32 form 7e-7-1.4e-6.
+#include <algorithm>
+
 #include "jm_common.h"
 
 namespace jm {
@@ -36,7 +38,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WN_KC = 16;                    // input channels per chunk = four k-steps of the 16x16x4 MFMA
 constexpr int WN_TN = 64;                    // output channels per workgroup (16 per wave)
-constexpr int WN_ABUF = 2;                   // A-operand stage buffers (2: fetched one stage ahead; 254 registers, no spills)
+constexpr int WN_ABUF = 1;                   // A-operand stage buffers (2 = fetched one stage ahead: +2 %, but 16 registers the spread window loads need)
 constexpr int WN_POS = 8 * 32 * 2;           // floats per transform position in a V buffer: [pair][tile'][2]
 constexpr int WN_VBUF = 16 * WN_POS;         // floats per V buffer (32 KB)
 
@@ -96,23 +98,35 @@ conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_
     unsigned long long* tr = trace + wave * WN_TR;
     WN_STAMP(WN_TR - 4);
 #endif
-    unsigned work = blockIdx.x;
-    if ((total_work & 7u) == 0) work = (work & 7u) * (total_work >> 3) + (work >> 3);   // an XCD walks a contiguous range
+    // ---- PERSISTENT walk: the grid is two workgroups per CU; a workgroup takes every (grid / 8)-th work item of its XCD's
+    //      contiguous range.  Work item = (patch, 64-channel block), channel-block-major inside groups of `group` patches: the
+    //      workgroups resident on an XCD stream the same few slices of U (L2-resident) instead of cycling through all of it. ----
+    unsigned item, item_end, item_step;
+    {
+        const unsigned nwg = gridDim.x, bid = blockIdx.x;
+        if ((total_work & 7u) == 0 && (nwg & 7u) == 0) {
+            const unsigned n8 = total_work >> 3;
+            item = (bid & 7u) * n8 + (bid >> 3); item_end = ((bid & 7u) + 1) * n8; item_step = nwg >> 3;
+        } else { item = bid; item_end = total_work; item_step = nwg; }
+    }
+    if (item >= item_end) return;
     const int nblocks = cout / WN_TN;
     const unsigned per_group = (unsigned)group * (unsigned)nblocks;
-    const unsigned grp = work / per_group, rem = work - grp * per_group;
-    const unsigned gsize = min((unsigned)group, (unsigned)npatches - grp * (unsigned)group);
-    const int nb = (int)(rem / gsize);
-    int patch = (int)(grp * (unsigned)group + rem % gsize);
-    const int px = patch % patches_x; patch /= patches_x;
-    const int py = patch % patches_y;
-    const int b = patch / patches_y;
+    auto decode = [&](unsigned work, int& b, int& py, int& px, int& nb) __attribute__((always_inline)) {
+        const unsigned grp = work / per_group, rem = work - grp * per_group;
+        const unsigned gsize = min((unsigned)group, (unsigned)npatches - grp * (unsigned)group);
+        nb = (int)(rem / gsize);
+        int patch = (int)(grp * (unsigned)group + rem % gsize);
+        px = patch % patches_x; patch /= patches_x;
+        py = patch % patches_y;
+        b = patch / patches_y;
+    };
 
     // ---- input-transform role: one (tile, channel pair of the chunk) per thread.  Lane bits: [1:0] pair >> 1, [3:2] tile & 3,
     //      [4] pair & 1, [5] tile bit 2; wave = tile >> 3 (one row of 8 tiles): a 16-lane group writes 32 distinct banks ----
     const int tpair = 2 * (lane & 3) + ((lane >> 4) & 1), ttile = wave * 8 + ((lane >> 5) & 1) * 4 + ((lane >> 2) & 3);
     unsigned rrow[4], rcol[4];                 // byte offsets of the 4 rows / 4 columns of the tile's input window; 0xFFFFFF00 = outside
-    {
+    auto window = [&](int b, int py, int px) __attribute__((always_inline)) {
         const int oy = (py * 4 + (ttile >> 3)) * 2 - 1, ox = (px * 8 + (ttile & 7)) * 2 - 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -120,7 +134,7 @@ conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_
             rrow[i] = (iy >= 0 && iy < H) ? (unsigned)(((size_t)b * H + iy) * W) * (unsigned)cin * 4u + (unsigned)tpair * 8u : 0xFFFFFF00u;
             rcol[i] = (ix >= 0 && ix < W) ? (unsigned)ix * (unsigned)cin * 4u : 0xFFFFFF00u;
         }
-    }
+    };
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)x_bytes, 0x00020000);
     const int wslot = wn_slot(tpair, ttile);
 
@@ -131,23 +145,24 @@ conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int a = 0; a < 2; ++a) aoff[j][a] = wn_slot(4 * j + kq, 16 * a + m);
-    const int ksteps = cin >> 2, nch = cin / WN_KC;
-    const f32x4* ub = reinterpret_cast<const f32x4*>(up) + ((size_t)(nb * 4 + wave) * ksteps) * 256 + lane;
+    const int ksteps = cin >> 2, nch = cin / WN_KC, nst = nch * 8;
+    auto wptr = [&](int nb) __attribute__((always_inline)) {
+        return reinterpret_cast<const f32x4*>(up) + ((size_t)(nb * 4 + wave) * ksteps) * 256;   // wave-uniform: SGPR base, the lane part is the load's VGPR offset
+    };
 
     f32x4 acc[16][2];
-#pragma unroll
-    for (int p = 0; p < 16; ++p) acc[p][0] = acc[p][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     f32x2 d[16];
+    auto load_raw_row = [&](int i, int c) __attribute__((always_inline)) {      // window row i of chunk c: 4 x buffer_load_dwordx2
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // saturating sum: either part outside the image keeps the offset above the buffer's size
+            const unsigned off = (rrow[i] | rcol[j]) >= 0xFFFFFF00u ? 0xFFFFFF00u : rrow[i] + rcol[j];
+            d[i * 4 + j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, off, c * (WN_KC * 4), 0));
+        }
+    };
     auto load_raw = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // saturating sum: either part outside the image keeps the offset above the buffer's size
-                const unsigned off = (rrow[i] | rcol[j]) >= 0xFFFFFF00u ? 0xFFFFFF00u : rrow[i] + rcol[j];
-                d[i * 4 + j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, off, c * (WN_KC * 4), 0));
-            }
+        for (int i = 0; i < 4; ++i) load_raw_row(i, c);
     };
     // B^T d B in two passes: columns (in place, 16 packed adds) and rows (16 packed adds + 16 LDS writes); the row pass is issued
     // one row per MFMA stage so that the vector work sits in the shadow of the matrix pipe
@@ -169,10 +184,10 @@ conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_
     // wave loads (ring of 4: three stages ahead)
     f32x4 bq[4][2];
     f32x2 af[WN_ABUF][8];
-    auto load_b = [&](int slot, int stage_global) __attribute__((always_inline)) {   // stage_global = 8 * chunk + 4 * j + g; slot = g (static)
-        const size_t ks0 = (size_t)(stage_global >> 2) * 2;                   // first k-step of the pair
-        bq[slot][0] = ub[ks0 * 256 + (stage_global & 3) * 64];
-        bq[slot][1] = ub[(ks0 + 1) * 256 + (stage_global & 3) * 64];
+    auto load_b = [&](int slot, const f32x4* base, int stage) __attribute__((always_inline)) {   // stage = 8 * chunk + 4 * j + g of ITS item
+        const size_t ks0 = (size_t)(stage >> 2) * 2;                          // first k-step of the pair
+        bq[slot][0] = base[ks0 * 256 + (stage & 3) * 64 + lane];
+        bq[slot][1] = base[(ks0 + 1) * 256 + (stage & 3) * 64 + lane];
     };
     auto load_a = [&](const float* Vb, int stage) __attribute__((always_inline)) {
         const int j = stage >> 2, g = stage & 3;
@@ -194,72 +209,130 @@ conv3x3_wino_kernel(int H, int W, int cin, int cout, int patches_x, int patches_
             }
     };
 
-    // the k-loop body is branch-free (indices clamped instead: the last chunks re-load valid data and transform into the buffer
-    // nobody reads any more): with conditional loads hipcc's s_waitcnt placement falls back to vmcnt(0..1) and the prefetch is lost
-    const int last_stage = nch * 8 - 1;
-    load_raw(0);
-    load_b(0, 0); load_b(1, min(1, last_stage)); load_b(2, min(2, last_stage));
+    // ---- the chunk pipeline runs ACROSS work items: while item n's last chunks are multiplied, the windows of item n + 1's first
+    //      two chunks are requested / transformed and its first weight stages are in flight, so only the very first item of a
+    //      workgroup has a prologue; between items there is just the inverse transform + store of the finished accumulators.
+    //      Cursors: (cb, cpy, cpx, cnb) = the item being multiplied; (ld_item, ld_c) = the chunk whose window is requested next;
+    //      ub / ub_next = the weight slices of this / the next item.  All loop bodies are branch-free around the loads (indices
+    //      and pointers selected, not branched on): with conditional loads hipcc's s_waitcnt placement falls back to vmcnt(0..1) ----
+    int cb, cpy, cpx, cnb;
+    decode(item, cb, cpy, cpx, cnb);
+    window(cb, cpy, cpx);
+    unsigned ld_item = item;
+    int ld_c = 0;
+    auto advance_window = [&]() __attribute__((always_inline)) {   // ALU only inside the branch: the pending-load state is the same on both paths
+        if (++ld_c == nch) {
+            ld_c = 0;
+            if (ld_item + item_step < item_end) {
+                ld_item += item_step;
+                int b2, py2, px2, nb2;
+                decode(ld_item, b2, py2, px2, nb2);
+                window(b2, py2, px2);
+            }                                                      // past the last item: the same windows again (never used)
+        }
+    };
+    const f32x4* ub = wptr(cnb);
+    const f32x4* ub_next = ub;
+    auto next_weights = [&]() __attribute__((always_inline)) {
+        if (item + item_step < item_end) {
+            int b2, py2, px2, nb2;
+            decode(item + item_step, b2, py2, px2, nb2);
+            ub_next = wptr(nb2);
+        }
+    };
+    next_weights();
+    float sb[16];
+    auto load_bias = [&]() __attribute__((always_inline)) {
+        const float* bp = bias + cnb * WN_TN + wave * 16;          // wave-uniform: s_load_dwordx16
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sb[k] = bias ? bp[k] : 0.f;
+    };
+    load_bias();
+    load_raw(ld_c); advance_window();
+    load_b(0, ub, 0); load_b(1, ub, 1); load_b(2, ub, 2);
     transform_cols();
 #pragma unroll
     for (int i = 0; i < 4; ++i) transform_row(V, i);
-    load_raw(min(1, nch - 1));
+    load_raw(ld_c); advance_window();
     __syncthreads();
-    WN_STAMP(WN_TR - 3);
-    for (int c = 0; c < nch; ++c) {
-        const float* Vc = V + (c & 1) * WN_VBUF;
-        float* Vn = V + ((c + 1) & 1) * WN_VBUF;
-        if (WN_ABUF == 2) load_a(Vc, 0);
-        WN_STAMP((c & 15) * 11);
+    int par = 0;
+    for (;;) {
 #pragma unroll
-        for (int st = 0; st < 8; ++st) {
-            if (WN_ABUF == 1) load_a(Vc, st);
-            else if (st < 7) load_a(Vc, st + 1);
-            load_b((st + 3) & 3, min(c * 8 + st + 3, last_stage));
-            mma(st);
-            if (st == 3) transform_cols();       // the next chunk's window was requested four stages ago (end of the previous iteration)
-            if (st >= 4) transform_row(Vn, st - 4);
-            WN_STAMP((c & 15) * 11 + 1 + st);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        load_raw(min(c + 2, nch - 1));
-        WN_STAMP((c & 15) * 11 + 9);
-        __syncthreads();
-        WN_STAMP((c & 15) * 11 + 10);
-    }
-
-    // ---- inverse transform Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]), bias, ReLU, store ----
-    const int co = nb * WN_TN + wave * 16 + m;
-    const float bv = bias ? bias[co] : 0.f;
+        for (int p = 0; p < 16; ++p) acc[p][0] = acc[p][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < nch; ++c) {
+            const float* Vc = V + par * WN_VBUF;
+            float* Vn = V + (par ^ 1) * WN_VBUF;
+            if (WN_ABUF == 2) load_a(Vc, 0);
+            WN_STAMP((c & 15) * 11);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int tile = 16 * a + 4 * kq + i;
-            const int oy = (py * 4 + (tile >> 3)) * 2, ox = (px * 8 + (tile & 7)) * 2;
-            float r0[4], r1[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                r0[q] = acc[0 + q][a][i] + acc[4 + q][a][i] + acc[8 + q][a][i];
-                r1[q] = acc[4 + q][a][i] - acc[8 + q][a][i] - acc[12 + q][a][i];
+            for (int st = 0; st < 8; ++st) {
+                if (WN_ABUF == 1) load_a(Vc, st);
+                else if (st < 7) load_a(Vc, st + 1);
+                {
+                    const int s = c * 8 + st + 3;
+                    const bool over = s >= nst;                   // the next item's first stages
+                    load_b((st + 3) & 3, over ? ub_next : ub, over ? s - nst : s);
+                }
+                mma(st);
+                if (st == 3) transform_cols();   // the next chunk's window was requested during stages 4-7 of the previous iteration
+                if (st >= 4) {
+                    transform_row(Vn, st - 4);   // frees d[4 i .. 4 i + 3] ...
+                    load_raw_row(st - 4, ld_c);  // ... for row i of the window after next: 4 loads per stage, under this stage's MFMAs
+                }                                // (all 16 at the end of the chunk cost 1250 cycles of issue in front of the barrier)
+                WN_STAMP((c & 15) * 11 + 1 + st);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            float o00 = r0[0] + r0[1] + r0[2] + bv, o01 = r0[1] - r0[2] - r0[3] + bv;
-            float o10 = r1[0] + r1[1] + r1[2] + bv, o11 = r1[1] - r1[2] - r1[3] + bv;
-            if (relu) { o00 = fmaxf(o00, 0.f); o01 = fmaxf(o01, 0.f); o10 = fmaxf(o10, 0.f); o11 = fmaxf(o11, 0.f); }
-            if (oy < H && ox < W) {
-                float* o = y + (((size_t)b * H + oy) * W + ox) * cout + co;
-                o[0] = o00;
-                if (ox + 1 < W) o[cout] = o01;
-                if (oy + 1 < H) {
-                    o[(size_t)W * cout] = o10;
-                    if (ox + 1 < W) o[(size_t)W * cout + cout] = o11;
+            advance_window();
+            WN_STAMP((c & 15) * 11 + 9);
+            __syncthreads();
+            WN_STAMP((c & 15) * 11 + 10);
+            par ^= 1;
+        }
+
+        // ---- inverse transform Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]), bias, ReLU, store ----
+        WN_STAMP(WN_TR - 3);
+        const int co = cnb * WN_TN + wave * 16 + m;
+        float bv = 0.f;                         // the wave's 16 biases were fetched through the scalar cache when the item started: a vector
+#pragma unroll                                  // load here would wait (in-order vmcnt) for every window / weight load in flight for the next item
+        for (int k = 0; k < 16; ++k) bv = (m == k) ? sb[k] : bv;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int tile = 16 * a + 4 * kq + i;
+                const int oy = (cpy * 4 + (tile >> 3)) * 2, ox = (cpx * 8 + (tile & 7)) * 2;
+                float r0[4], r1[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    r0[q] = acc[0 + q][a][i] + acc[4 + q][a][i] + acc[8 + q][a][i];
+                    r1[q] = acc[4 + q][a][i] - acc[8 + q][a][i] - acc[12 + q][a][i];
+                }
+                float o00 = r0[0] + r0[1] + r0[2] + bv, o01 = r0[1] - r0[2] - r0[3] + bv;
+                float o10 = r1[0] + r1[1] + r1[2] + bv, o11 = r1[1] - r1[2] - r1[3] + bv;
+                if (relu) { o00 = fmaxf(o00, 0.f); o01 = fmaxf(o01, 0.f); o10 = fmaxf(o10, 0.f); o11 = fmaxf(o11, 0.f); }
+                if (oy < H && ox < W) {
+                    float* o = y + (((size_t)cb * H + oy) * W + ox) * cout + co;
+                    o[0] = o00;
+                    if (ox + 1 < W) o[cout] = o01;
+                    if (oy + 1 < H) {
+                        o[(size_t)W * cout] = o10;
+                        if (ox + 1 < W) o[(size_t)W * cout + cout] = o11;
+                    }
                 }
             }
-        }
+        WN_STAMP(WN_TR - 2);
+        item += item_step;
+        if (item >= item_end) break;
+        decode(item, cb, cpy, cpx, cnb);
+        ub = ub_next;
+        next_weights();
+        load_bias();
+    }
 #ifdef JM_TOOLS_BUILD
-    WN_STAMP(WN_TR - 2);
-    if (g_wn_trace && blockIdx.x % 509 == 100) {          // a few dozen workgroups spread over the grid
+    WN_STAMP(WN_TR - 1);
+    if (g_wn_trace && blockIdx.x % 61 == 10) {            // eight workgroups spread over the grid (their LAST item's stamps)
         __syncthreads();
-        unsigned long long* dst = g_wn_trace + (size_t)(blockIdx.x / 509) * (4 * WN_TR + 4);
+        unsigned long long* dst = g_wn_trace + (size_t)(blockIdx.x / 61) * (4 * WN_TR + 4);
         for (int i = tid; i < 4 * WN_TR; i += 256) dst[i] = trace[i];
         if (tid == 0) { dst[4 * WN_TR] = blockIdx.x; dst[4 * WN_TR + 1] = nch; dst[4 * WN_TR + 2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); }
     }
@@ -304,7 +377,8 @@ extern "C" int jm_conv3x3_wino_bias_relu(int b, int h, int w, int cin, int cout,
     const unsigned long long total = (unsigned long long)b * pxs * pys * (cout / WN_TN);
     JM_REQUIRE(total < 0x7FFFFFFFull, "conv3x3_wino: grid limit");
     const int npatches = b * pxs * pys, group = tune_env("JM_WN_G", 16);
-    hipLaunchKernelGGL(conv3x3_wino_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, h, w, cin, cout, pxs, pys, npatches, group,
+    const unsigned grid = (unsigned)std::min<unsigned long long>(total, 2ull * 256ull * (unsigned)tune_env("JM_WN_WGS", 1));
+    hipLaunchKernelGGL(conv3x3_wino_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, w, cin, cout, pxs, pys, npatches, group,
                        (unsigned)total, (unsigned)xb, x_channels_last, packed, bias, out_channels_last, relu);
     return check_launch("conv3x3_wino");
 }

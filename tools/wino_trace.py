@@ -20,7 +20,7 @@ for cin, cout, H, W in ((64, 128, 192, 640), (128, 256, 96, 320), (256, 512, 48,
     packed = pack_wino_weight(w)
     for _ in range(3): conv3x3_wino_bias_relu(x, packed, b, cout)
     nwg = 8 * (H // 8) * (W // 16) * (cout // 64)
-    ns = nwg // 509 + 1
+    ns = 512 // 61 + 1
     buf = torch.zeros(ns * stride, dtype=torch.int64, device="cuda")
     raw.jm_tools_wino_trace(ctypes.c_void_p(buf.data_ptr()))
     conv3x3_wino_bias_relu(x, packed, b, cout)
@@ -30,14 +30,15 @@ for cin, cout, H, W in ((64, 128, 192, 640), (128, 256, 96, 320), (256, 512, 48,
     t = t[t[:, 4 * TR + 1] > 0]
     nch = int(t[0, 4 * TR + 1])
     tr = t[:, :4 * TR].reshape(-1, 4, TR).astype(np.float64)
-    start, loop0, end = tr[:, :, TR - 4], tr[:, :, TR - 3], tr[:, :, TR - 2]
+    start, ep0, ep1, fin = tr[:, :, TR - 4], tr[:, :, TR - 3], tr[:, :, TR - 2], tr[:, :, TR - 1]
     ch = tr[:, :, :11 * min(nch, 16)].reshape(len(tr), 4, -1, 11)
     stages = np.diff(ch[..., :9], axis=-1)                  # 8 stage durations
     loads = ch[..., 9] - ch[..., 8]
     barrier = ch[..., 10] - ch[..., 9]
     chunk = ch[..., 10] - ch[..., 0]
     print(f"{cin}->{cout}: {len(tr)} workgroups sampled, {nch} chunks; cycles (mean over workgroups, waves, chunks)")
-    print(f"  prologue {np.mean(loop0 - start):8.0f}   k-loop {np.mean(ch[:, :, -1, 10] - loop0):8.0f}   epilogue {np.mean(end - ch[:, :, -1, 10]):8.0f}   total {np.mean(end - start):8.0f}")
+    items = nwg / 512
+    print(f"  last item of a workgroup: k-loop {np.mean(ch[:, :, -1, 10] - ch[:, :, 0, 0]):8.0f}   epilogue {np.mean(ep1 - ep0):8.0f}   whole workgroup {np.mean(fin - start):9.0f} = {np.mean(fin - start) / items:8.0f} per item ({items:.0f} items)")
     print("  stage    " + " ".join(f"{v:7.0f}" for v in stages.mean(axis=(0, 1, 2))) + f"   window loads {loads.mean():6.0f}  barrier {barrier.mean():6.0f}  chunk {chunk.mean():7.0f} (128 MFMAs = 4096 pipe cycles)")
     print("  by chunk " + " ".join(f"{v:7.0f}" for v in chunk.mean(axis=(0, 1))))
     print("  p10/p50/p90 of a stage: " + " ".join(f"{np.percentile(stages, q):7.0f}" for q in (10, 50, 90)), flush=True)
