@@ -421,10 +421,32 @@ WORKLOAD_TEXT = {
 }
 
 
+# the image branch's own kernels: not a SURVEY.md §8 row (the reference calls nn.Conv2d there); priced in `image_branch_kernel`
+IMAGE_BRANCH_ENTRIES = ("conv3x3_rgb_bias_relu", "conv3x3_wino_bias_relu", "bias_relu_channels_last")
+
+
+def image_branch_kernel(kernels):
+    """the fused Winograd convolution (csrc/conv_wino.hip), the largest kernel of the image branch, on both bases"""
+    k = next((k for k in kernels if k["kernel"].split("/")[-1] == "conv3x3_wino_bias_relu"), None)
+    if k is None or not k.get("ms_per_step"):
+        return None
+    return {"kernel": k["kernel"], "bound": "mfma", "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+            "ms_per_step": k["ms_per_step"], "launches_per_step": k["launches_per_step"],
+            "achieved": round(k["executed_flops_per_step"] / (k["ms_per_step"] * 1e-3) / 1e12, 2), "frac": k.get("executed_mfma_frac"),
+            "basis": "flops the kernel EXECUTES on the matrix cores: 16 products per 2x2 output tile and (cin, cout) pair "
+                     "(Winograd F(2x2, 3x3)); HIP events around the entry on the image stream while the main chain's kernels share "
+                     "the machine (isolated: tools/conv_wino_bench.py, DESIGN.md §4)",
+            "direct_form": {"tflops": k.get("achieved_tflops"), "frac_of_peak": k.get("mfma_frac"),
+                            "basis": "2 * 9 * cin * cout flops per output pixel, what a direct / implicit-GEMM convolution executes: "
+                                     "can exceed the peak because 20 of 36 products are never formed"},
+            "note": "not a SURVEY.md §8 row (the reference calls nn.Conv2d): listed because it is the largest hand-written kernel of the "
+                    "step; `roofline` stays on the §8 path"}
+
+
 def pick_roofline(kernels, traffic_json, full_table=True):
     """the dominant jm_* entry (caller-side torch spans and stream waits are listed but are not ours to price)"""
     own = [k for k in kernels if not k.get("stall") and ("algo_bytes_per_step" in k or "algo_flops_per_step" in k)
-           and "(" not in k["kernel"]]
+           and "(" not in k["kernel"] and k["kernel"].split("/")[-1] not in IMAGE_BRANCH_ENTRIES]
     # the FPS chain on its side stream is not on the critical path when the consumer hardly ever waits for it (its exposed
     # share is reported under `overlap`): the roofline kernel is then the largest entry of the main chain
     chain = sum(k["ms_per_step"] for k in kernels if k["kernel"].startswith("fps_pyramid/"))
@@ -842,8 +864,10 @@ def main():
                                            if args.workload == "train" else
                                            "no data-path collective (replicas): control plane gloo (barriers, max over ranks), no RCCL communicator"))},
             "roofline": roofline,
-            "roofline_selection": "the jm entry with the largest speed-of-light time (executed flops / 157.3 TF, algorithmic bytes / 8 TB/s) "
-                                  "of the main chain; measured times of small kernels include waits behind the other stream's convolutions",
+            "roofline_selection": "the jm entry of the SURVEY.md §8 path with the largest speed-of-light time (executed flops / 157.3 TF, "
+                                  "algorithmic bytes / 8 TB/s) of the main chain; measured times of small kernels include waits behind the "
+                                  "other stream's convolutions; the image branch's own convolution kernel is priced in `image_branch_kernel`",
+            "image_branch_kernel": image_branch_kernel(kernels),
             "step_mfma_frac": round(mfma_flops / (ms_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4) if ms_step else None,
             "step_mfma_flops": int(mfma_flops),
             **{k: v for k, v in variants.items() if k != "clouds"},

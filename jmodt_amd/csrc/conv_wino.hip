@@ -23,8 +23,15 @@
 //     block][k-step][position group][lane][4]), and stream from L2 / L1 straight into registers as fully coalesced 1 KB wave
 //     loads, three stages ahead: no LDS for the weights (the two workgroups resident on a CU share them through L1: the
 //     default cache policy measured 10-20 % faster than non-temporal loads);
-//   * work order: an XCD walks a contiguous range, inside it `group` patches share one 64-channel block of U before the next
-//     block starts.
+//   * PERSISTENT grid (two workgroups per CU, 246 registers): an XCD walks a contiguous range of (patch, 64-channel block)
+//     items, channel-block-major inside groups of `group` patches, and the chunk pipeline runs ACROSS items: the windows and
+//     the first weight stages of item n + 1 are in flight under the last chunks and the epilogue of item n; the window loads
+//     are issued four per stage right behind the transform row that frees their registers.
+// What bounds it (tools/wino_trace.py: shader-clock stamps per stage; tools/wino_pmc.sh): a wave needs ~8 k cycles per chunk
+// for 4096 cycles of MFMA work — the vector-memory instructions cost their TA time wherever they are placed (16 weight + 16
+// window loads per chunk and wave; TA busy 42-50 %) — and two waves per SIMD (the 128 accumulator registers) overlap that only
+// partly: matrix pipe busy 58-69 %.  Halving the instruction count (8- vs 16-channel chunks), deeper operand prefetch and
+// removing the per-item prologue each moved the time by 0-3 %; removing a feed (ablation) moves it by 10-25 %.
 // Measured (tools/conv_wino_bench.py, batch 8): see DESIGN.md §4; error vs float64 3-6e-7 of the output range, the direct
 // fp32 form 7e-7-1.4e-6.
 #include <algorithm>
