@@ -223,3 +223,38 @@ def test_round3_entries_stay_in_bounds_and_refuse_bad_arguments():
                                           L.dev(nb, i32, "i"), 3, widths, warr, barr, ctypes.c_void_p(out.view.data_ptr()),
                                           L.stream_ptr()), "sa_xyz")
             assert out.intact() and torch.isfinite(out.view).all() and out.view.abs().max() > 0
+
+
+def test_conv3x3_wino_stays_in_bounds_and_refuses_bad_arguments():
+    """jm_conv3x3_wino_pack / jm_conv3x3_wino_bias_relu: odd image sizes (partial 2x2 tiles and partial 8x16 patches at both
+    borders), output and packed weight inside guarded allocations; unsupported widths, null pointers and a misaligned packed
+    weight return an error"""
+    import torch.nn.functional as F
+    from jmodt_amd import _lib as L
+    lib = L.load()
+    f32 = torch.float32
+    g = torch.Generator().manual_seed(11)
+    for B, cin, cout, H, W in ((2, 16, 64, 7, 19), (1, 32, 128, 9, 33), (1, 16, 64, 1, 1)):
+        x = torch.randn(B, cin, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).to(DEV)
+        b = torch.randn(cout, generator=g).to(DEV)
+        if PAD % 4 == 0:
+            packed = Guard((16 * cin * cout,), f32)
+        else:   # the packed weight must be 16-byte aligned (header): the misaligning variant keeps it in a plain allocation
+            packed = type("Plain", (), {"view": torch.empty((16 * cin * cout,), dtype=f32, device=DEV), "intact": lambda self: True})()
+        assert lib.jm_conv3x3_wino_packed_elems(cin, cout) == 16 * cin * cout
+        L.check(lib.jm_conv3x3_wino_pack(cin, cout, L.dev(w, f32, "w"), ctypes.c_void_p(packed.view.data_ptr()), L.stream_ptr()), "pack")
+        out = Guard((B, H, W, cout), f32)
+        L.check(lib.jm_conv3x3_wino_bias_relu(B, H, W, cin, cout, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(packed.view.data_ptr()),
+                                              L.dev(b, f32, "b"), 1, ctypes.c_void_p(out.view.data_ptr()), L.stream_ptr()), "wino")
+        assert packed.intact() and out.intact()
+        want = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)).permute(0, 2, 3, 1)
+        assert (out.view.double() - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+    px, po = ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.view.data_ptr())
+    pk = ctypes.c_void_p(packed.view.data_ptr())
+    assert lib.jm_conv3x3_wino_supported(24, 64) == 0 and lib.jm_conv3x3_wino_supported(16, 96) == 0 and lib.jm_conv3x3_wino_supported(16, 64) == 1
+    assert lib.jm_conv3x3_wino_bias_relu(1, 4, 4, 24, 64, px, pk, None, 1, po, L.stream_ptr()) != 0
+    assert lib.jm_conv3x3_wino_bias_relu(1, 4, 4, 16, 64, None, pk, None, 1, po, L.stream_ptr()) != 0
+    assert lib.jm_conv3x3_wino_bias_relu(1, 4, 4, 16, 64, px, ctypes.c_void_p(packed.view.data_ptr() + 4), None, 1, po, L.stream_ptr()) != 0
+    assert lib.jm_conv3x3_wino_bias_relu(0, 4, 4, 16, 64, None, None, None, 1, None, L.stream_ptr()) == 0      # empty batch: nothing to do
+    assert lib.jm_conv3x3_wino_pack(16, 64, None, pk, L.stream_ptr()) != 0
