@@ -31,7 +31,8 @@
 // for 4096 cycles of MFMA work — the vector-memory instructions cost their TA time wherever they are placed (16 weight + 16
 // window loads per chunk and wave; TA busy 42-50 %) — and two waves per SIMD (the 128 accumulator registers) overlap that only
 // partly: matrix pipe busy 58-69 %.  Halving the instruction count (8- vs 16-channel chunks), deeper operand prefetch and
-// removing the per-item prologue each moved the time by 0-3 %; removing a feed (ablation) moves it by 10-25 %.
+// removing the per-item prologue each moved the time by 0-3 %; s_setprio around the MFMA groups (either way) costs 5 %;
+// removing a feed (ablation) moves it by 10-25 %.
 // Measured (tools/conv_wino_bench.py, batch 8): see DESIGN.md §4; error vs float64 3-6e-7 of the output range, the direct
 // fp32 form 7e-7-1.4e-6.
 #include <algorithm>
