@@ -740,6 +740,41 @@ def test_conv3x3_wino_bias_relu_vs_torch(B, cin, cout, H, W, bias, relu):
     assert (got.double() - want).abs().max().item() <= 2e-6 * want.abs().max().item()      # what the direct fp32 form achieves too
 
 
+def test_image_branch_with_and_without_the_winograd_kernels():
+    """the engine's image pyramid at the benchmarked width (64 / 128 / 256 / 512 channels, BatchNorm folded): stride-1 convolutions on
+    conv_wino.hip vs the same blocks on MIOpen + bias/ReLU pass, and vs the module's own eval-mode forward in float64"""
+    from jmodt_amd.detector import DetectorConfig
+    eng = make_engine(3, DetectorConfig.survey()).to(DEV).eval()
+    img = torch.rand(2, 3, 96, 160, generator=torch.Generator().manual_seed(4)).to(DEV)
+
+    def pyramid():
+        cur, outs = img, []
+        with torch.no_grad():
+            for i in range(4):
+                cur = eng._image_block(i, cur)
+                outs.append(cur)
+        return outs
+    eng.wino_conv = True
+    assert eng._wino_ok(eng.rpn.backbone_net.Img_Block[1].conv1, pyramid()[0])          # the kernel really is the one that runs
+    got = pyramid()
+    assert any(k.endswith(".wino") for k in eng._folded)
+    eng.wino_conv = False
+    eng.invalidate()
+    lib = pyramid()
+    assert not any(k.endswith(".wino") for k in eng._folded)
+    blocks64 = [b.double() for b in eng.rpn.backbone_net.Img_Block]
+    cur, want = img.double(), []
+    with torch.no_grad():
+        for b in blocks64:
+            cur = b(cur)
+            want.append(cur)
+    eng.float()
+    for g, l, w in zip(got, lib, want):
+        close(g, w)
+        close(l, w)
+        close(g, l)
+
+
 def test_engine_stream_safety_soak(run):
     """the same batch through 12 steps with every overlap / prefetch on and allocator churn on the main stream in
     between: the pyramids are handed between streams without record_stream (ordered release), so a recycling race would
