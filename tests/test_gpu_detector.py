@@ -159,12 +159,13 @@ def test_detections_and_affinity_teacher_forced(run, oracle):
 # times selects different kernels than DetectorConfig.tiny() (sa_mlp_pm C = 128, sa_mlp_wide hidden 512, rcnn_lift
 # with the hoisted layer, rocBLAS at LI-Fusion level 4, the 128-RoI affinity batch)
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module", params=["configs2", "configs4", "reference100"])
+@pytest.fixture(scope="module", params=["configs2", "configs4", "reference100", "kitti"])
 def full_run(request):
     """configs2: the headline workload's shapes (16384 points, 128 RoIs per frame); configs4: BASELINE configs[4] through the
     SAME composed engine (65536 points per frame: co-operative FPS, hash-grid ball query and 3-NN at the first level;
     256 RoIs, 256 x 256 affinity); reference100: DetectorConfig() = the reference's own TEST configuration, 100 RoIs per frame
-    (config.py:204,213: RoI counts and affinity sizes that are no multiple of any tile)"""
+    (config.py:204,213: RoI counts and affinity sizes that are no multiple of any tile); kitti: the headline shapes on the KITTI-like
+    cloud (density ~ 1/z, ground plane + object clusters: RoIs with hundreds of distinct points, other compaction patterns)"""
     import dataclasses
     from jmodt_amd.detector import DetectorConfig
     from jmodt_amd.profile import prof
@@ -174,7 +175,7 @@ def full_run(request):
     if request.param == "reference100":
         cfg = DetectorConfig()
     eng = make_engine(seed=5, cfg=cfg, conv_find=True).to(DEV)
-    xyz, img, xy = synth.frames(2, 65536 if dense else 16384, 4321)
+    xyz, img, xy = synth.frames(2, 65536 if dense else 16384, 4321, kind="kitti" if request.param == "kitti" else "uniform")
     with torch.no_grad():
         eng(T(xyz), T(img), T(xy))                         # warm-up: packs / folds every weight
         prof.reset()
@@ -198,7 +199,7 @@ def test_full_width_kernel_selection(full_run):
                    "rpn_sa3/sa_mlp_forward", "rpn_sa4/sa_mlp_forward", "rcnn_lift_forward", "conv1d_stack_forward",
                    "li_fusion_final/image_fusion_gather", "li_fusion1/attention_fusion_forward", "li_fusion3/attention_fusion_forward",
                    "li_fusion_final/attention_fusion_forward", f"affinity_2x{eng.cfg.rpn_post_nms_top_n}x{eng.cfg.rpn_post_nms_top_n}/affinity_forward_batched", "linear_rows",
-                   "conv3x3_rgb_bias_relu", "proposal_layer/", "roipool3d_canonical", "detections/nms_batched",
+                   "conv3x3_rgb_bias_relu", "conv3x3_wino_bias_relu", "proposal_layer/", "roipool3d_canonical", "detections/nms_batched",
                    "fps_pyramid/L1/furthest_point_sampling_xyz", "three_nn", "three_interpolate"):
         assert needle in names, (needle, names)
     assert "li_fusion4/attention_fusion_forward" not in names          # 512 rows x 1024 channels: rocBLAS GEMMs
