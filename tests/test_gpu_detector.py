@@ -159,13 +159,14 @@ def test_detections_and_affinity_teacher_forced(run, oracle):
 # times selects different kernels than DetectorConfig.tiny() (sa_mlp_pm C = 128, sa_mlp_wide hidden 512, rcnn_lift
 # with the hoisted layer, rocBLAS at LI-Fusion level 4, the 128-RoI affinity batch)
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module", params=["configs2", "configs4", "reference100", "kitti"])
+@pytest.fixture(scope="module", params=["configs2", "configs4", "reference100", "kitti", "packed"])
 def full_run(request):
     """configs2: the headline workload's shapes (16384 points, 128 RoIs per frame); configs4: BASELINE configs[4] through the
     SAME composed engine (65536 points per frame: co-operative FPS, hash-grid ball query and 3-NN at the first level;
     256 RoIs, 256 x 256 affinity); reference100: DetectorConfig() = the reference's own TEST configuration, 100 RoIs per frame
     (config.py:204,213: RoI counts and affinity sizes that are no multiple of any tile); kitti: the headline shapes on the KITTI-like
-    cloud (density ~ 1/z, ground plane + object clusters: RoIs with hundreds of distinct points, other compaction patterns)"""
+    cloud (density ~ 1/z, ground plane + object clusters: RoIs with hundreds of distinct points, other compaction patterns); packed: every
+    point inside one of 16 car-sized boxes (RoIs of >= 512 distinct points: nothing to compact, dense neighbourhoods everywhere)"""
     import dataclasses
     from jmodt_amd.detector import DetectorConfig
     from jmodt_amd.profile import prof
@@ -175,7 +176,7 @@ def full_run(request):
     if request.param == "reference100":
         cfg = DetectorConfig()
     eng = make_engine(seed=5, cfg=cfg, conv_find=True).to(DEV)
-    xyz, img, xy = synth.frames(2, 65536 if dense else 16384, 4321, kind="kitti" if request.param == "kitti" else "uniform")
+    xyz, img, xy = synth.frames(2, 65536 if dense else 16384, 4321, kind=request.param if request.param in ("kitti", "packed") else "uniform")
     with torch.no_grad():
         eng(T(xyz), T(img), T(xy))                         # warm-up: packs / folds every weight
         prof.reset()
