@@ -345,6 +345,13 @@ int jm_conv1d_stack_forward(int b, int n, int c0, const float* x0, int c1, const
 int jm_conv3x3_rgb_bias_relu(int b, int h, int w, int cout, const float* image, const float* weight_tap_major,
                              const float* bias, float* out_channels_last, jm_stream_t stream);
 
+/* order (b, n) int64 = the indices that sort each row of scores (b, n) in DESCENDING order, equal scores in index order:
+ * torch.sort(scores, dim=1, descending=True, stable=True)[1] of proposal_layer.py:45 (the score order in front of the distance
+ * bands and the NMS walk) as one workgroup per row in LDS instead of a 14-kernel merge sort.  n <= 16384
+ * (jm_argsort_desc_supported); -0.0 orders as +0.0; NaNs by bit pattern (+NaN above +inf, -NaN below -inf), as torch.sort on this platform. */
+int jm_argsort_desc_supported(int n);
+int jm_argsort_desc_stable(int b, int n, const float* scores, long long* order, jm_stream_t stream);
+
 /* The image branch's stride-1 3x3 convolutions with their folded BatchNorm bias and ReLU in one kernel, as a fused Winograd
  * F(2x2, 3x3) (backbone.py:16-32: BasicBlock.conv1 + bn1 + relu of Img_Block[1..3]; 2.25x fewer multiplications than the
  * direct form, fp32 throughout, transformed tensors never leave the CU — csrc/conv_wino.hip).

@@ -108,6 +108,8 @@ SIGNATURES = {
     "jm_conv1d_stack_supported": (_I, [_I, _I, _I, _I, _I, _I, _P]),
     "jm_conv1d_stack_forward": (_I, [_I, _I, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "jm_conv3x3_rgb_bias_relu": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "jm_argsort_desc_supported": (_I, [_I]),
+    "jm_argsort_desc_stable": (_I, [_I, _I, _P, _P, _P]),
     "jm_conv3x3_wino_packed_elems": (_Z, [_I, _I]),
     "jm_conv3x3_wino_supported": (_I, [_I, _I]),
     "jm_conv3x3_wino_pack": (_I, [_I, _I, _P, _P, _P]),

@@ -43,13 +43,25 @@ def nms_evals():
     return done, full, calls
 
 
+def argsort_desc_stable(scores: torch.Tensor) -> torch.Tensor:
+    """(B, N) float32 -> (B, N) int64 = torch.sort(scores, dim=1, descending=True, stable=True)[1]: one workgroup per row in LDS
+    (csrc/sort.hip) for N <= 16384, the library sort above that"""
+    lib = L.load()
+    B, N = scores.shape
+    if not (scores.is_cuda and scores.dtype == _f32 and scores.is_contiguous() and lib.jm_argsort_desc_supported(N)):
+        return torch.sort(scores, dim=1, descending=True, stable=True)[1].contiguous()
+    order = torch.empty((B, N), dtype=torch.int64, device=scores.device)
+    L.check(lib.jm_argsort_desc_stable(B, N, L.dev(scores, _f32, "scores"), ctypes.c_void_p(order.data_ptr()), L.stream_ptr()), "argsort_desc")
+    return order
+
+
 def _select(scores, proposals, distance_based, pre, post, thresh, normal):
     lib = L.load()
     B, N = scores.shape
     scores = scores.contiguous().to(_f32)
     proposals = proposals.contiguous().to(_f32)
     # stable, so equal scores keep their index order (the reference's torch.sort leaves that unspecified)
-    order = torch.sort(scores, dim=1, descending=True, stable=True)[1].contiguous()
+    order = argsort_desc_stable(scores)
     out_boxes = torch.empty((B, post, 7), dtype=_f32, device=scores.device)
     out_scores = torch.empty((B, post), dtype=_f32, device=scores.device)
     ws_bytes = lib.jm_proposal_select_workspace_bytes(B, int(distance_based), pre)

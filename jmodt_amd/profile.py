@@ -128,6 +128,7 @@ ALGO: Dict[str, Callable] = {
     "jm_conv1d_stack_forward": lambda a: (
         4 * _i(a, 0) * _i(a, 1) * (_i(a, 2) + _i(a, 4) + int(a[8][_i(a, 7) - 1])),
         2 * _i(a, 0) * _i(a, 1) * sum(k * int(a[8][l]) for l, k in enumerate([_i(a, 2) + _i(a, 4)] + [int(a[8][j]) for j in range(_i(a, 7) - 1)])), {}),
+    "jm_argsort_desc_stable": lambda a: (12 * _i(a, 0) * _i(a, 1), 0, {}),
     "jm_conv3x3_rgb_bias_relu": lambda a: (4 * _i(a, 0) * _i(a, 1) * _i(a, 2) * (3 + _i(a, 3)), 0, {}),
     # algorithmic = the direct form's 2 * 9 * cin * cout per pixel; executed on the matrix cores = 16 / 36 of it (F(2x2, 3x3))
     "jm_conv3x3_wino_bias_relu": lambda a: (

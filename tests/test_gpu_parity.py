@@ -1094,3 +1094,22 @@ def test_three_nn_policy_takes_the_grid_for_the_dense_shape(oracle):
     dist, got = pu.three_nn(T(xyz), T(known))
     want_d2, want_idx = oracle.three_nn(xyz[:, :3000], known)
     assert np.array_equal(got.cpu().numpy()[:, :3000], want_idx) and np.array_equal(dist.cpu().numpy()[:, :3000], np.sqrt(want_d2))
+
+
+@pytest.mark.parametrize("B,N", [(1, 1), (3, 5), (2, 1000), (2, 1024), (2, 1025), (8, 4096), (3, 5000), (2, 8192), (8, 16384), (2, 16383)])
+def test_argsort_desc_stable_equals_torch_sort(B, N):
+    """csrc/sort.hip (LDS radix argsort, one workgroup per row) == torch.sort(descending=True, stable=True)[1] bit for bit: random
+    scores, heavily tied scores (8 distinct values), +-0.0, +-inf and NaN in one row"""
+    from jmodt_amd.ops.proposal import argsort_desc_stable
+    g = torch.Generator().manual_seed(N * 7 + B)
+    rows = [torch.randn(B, N, generator=g), torch.randint(0, 8, (B, N), generator=g).float() - 3.5,
+            torch.randn(B, N, generator=g).round(decimals=1)]
+    special = torch.randn(B, N, generator=g)
+    vals = torch.tensor([0.0, -0.0, float("inf"), float("-inf"), float("nan"), -float("nan"), 1e-45, -1e-45])
+    special[:, torch.randperm(N, generator=g)[:min(N, 64)]] = vals[torch.randint(0, 8, (min(N, 64),), generator=g)]
+    rows.append(special)
+    for sc in rows:
+        sc = sc.to(DEV).contiguous()
+        got = argsort_desc_stable(sc)
+        want = torch.sort(sc, dim=1, descending=True, stable=True)[1]
+        assert got.dtype == torch.int64 and torch.equal(got, want)

@@ -33,5 +33,5 @@ for r in rows:
     by[r[2]][0] += r[0]; by[r[2]][1] += r[1]
 for k, v in sorted(by.items(), key=lambda kv: -kv[1][0]):
     print(f"   {k:32s} {v[0]:9.1f} us  x{v[1]:5.1f}")
-for r in rows[8:110]:
+for r in rows[:110]:
     print(f"{r[0]:9.1f} us  x{r[1]:4.1f}  {r[2]:28s} {r[3]:90s} {r[4]}")
