@@ -321,6 +321,19 @@ int jm_sa_mlp_pm_forward(int b, int n, int m, int c, int nsample, int hidden, in
                          const float* w1x, const float* new_xyz, const int* idx, const float* w_hidden, const float* b_hidden,
                          const float* w_out, const float* b_out, float* out, jm_stream_t stream);
 
+/* jm_sa_mlp_forward / _forward_pre / _pm_forward writing frame b's (cout, M) block at out + b * out_frame_stride floats
+ * (0 = cout * M; otherwise >= cout * M): a channel slice of a wider (B, Ctot, M) tensor, i.e. the concatenation of an MSG
+ * module's scales (pointnet2_modules.py:54: torch.cat(new_features_list, dim=1)) without the copy. */
+int jm_sa_mlp_forward_into(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
+                      const float* features, const int* idx, int num_layers, const int* widths,
+                      const float* const* weights, const float* const* biases, float* out, size_t out_frame_stride, jm_stream_t stream);
+int jm_sa_mlp_forward_pre_into(int b, int n, int m, int c, int nsample, const float* u, const float* w1x, const float* new_xyz,
+                          const int* idx, int num_layers, const int* widths, const float* const* weights,
+                          const float* const* biases, float* out, size_t out_frame_stride, jm_stream_t stream);
+int jm_sa_mlp_pm_forward_into(int b, int n, int m, int c, int nsample, int hidden, int cout, const float* u_point_major,
+                         const float* w1x, const float* new_xyz, const int* idx, const float* w_hidden, const float* b_hidden,
+                         const float* w_out, const float* b_out, float* out, size_t out_frame_stride, jm_stream_t stream);
+
 /* A stack of 1..3 kernel-size-1 Conv1d layers (BatchNorm folded by the caller, optional ReLU each) on (B, C, n) tensors in
  * one launch: the RPN heads (rpn.py:34-58), the feature-propagation SharedMLPs on cat[interpolated, skip]
  * (pointnet2_modules.py:139-153) and the hoisted first set-abstraction layer u = W_f f + W_x xyz^T.  The first layer

@@ -65,6 +65,11 @@ SIGNATURES = {
                                ctypes.POINTER(_P), _P, _P]),
     "jm_sa_mlp_forward_pre": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, ctypes.POINTER(_I), ctypes.POINTER(_P),
                                    ctypes.POINTER(_P), _P, _P]),
+    "jm_sa_mlp_forward_into": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, ctypes.POINTER(_I), ctypes.POINTER(_P),
+                                    ctypes.POINTER(_P), _P, _Z, _P]),
+    "jm_sa_mlp_forward_pre_into": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, ctypes.POINTER(_I), ctypes.POINTER(_P),
+                                        ctypes.POINTER(_P), _P, _Z, _P]),
+    "jm_sa_mlp_pm_forward_into": (_I, [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "jm_roipool3d_forward": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "jm_roipool3d_canonical": (_I, [_I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P]),
     "jm_pts_in_boxes3d_cpu": (_I, [_I, _I, _P, _P, _P]),

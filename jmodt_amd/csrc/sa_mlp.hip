@@ -57,8 +57,9 @@ struct SaMlpParams {
     int np[4];                       // np[l] = pad128(width_{l+1}): packed rows of layer l
     const float* W[4];               // packed weights of layer l (see jm_sa_mlp_pack)
     const float* bias[4];            // (np[l]) zero padded
-    float* out;                      // (B, cout, M)
-    int cout;
+    float* out;                      // (B, cout, M); frame b starts at out + b * obs (obs = cout * M unless the caller writes into
+    int cout;                        // a channel slice of a wider (B, Ctot, M) tensor: an MSG module's concatenation)
+    size_t obs;
     int tiles_per_frame, total_tiles, xcd_frames;
 #ifdef JM_TOOLS_BUILD
     long long* trace;                // tools build: shader-clock stamps of workgroup 0's first MFMA wave (tools/sa_trace.py)
@@ -449,7 +450,7 @@ __device__ __forceinline__ void sa_mfma_role(const SaMlpParams& p, float* lds, i
                             float t = fmaxf(v[c], __shfl_xor(v[c], 32));   // the other lane half holds the rows + 4
                             const int m = (row0 + wm * 64) / p.ns + c;
                             if (lk == 0 && col < p.cout)
-                                p.out[((size_t)bi * p.cout + col) * p.M + m] = fmaxf(t, 0.f);
+                                p.out[(size_t)bi * p.obs + (size_t)col * p.M + m] = fmaxf(t, 0.f);
                         }
                     }
                 }
@@ -477,11 +478,11 @@ sa_mlp_kernel(SaMlpParams p) {
 namespace jm {
 int sa_mlp_wide_launch(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                        const float* features, const int* idx, int L, const int* widths, const float* const* weights,
-                       const float* const* biases, float* out, hipStream_t s);                     // sa_mlp_wide.hip
+                       const float* const* biases, float* out, size_t obs, hipStream_t s);         // sa_mlp_wide.hip
 const char* sa_wide_unsupported(long long b, int n, int m, int c, int nsample, int group_all, int L, const int* widths);
 bool sa_xyz_valu_supported(int m, int c, int nsample, int num_layers, const int* widths);                          // sa_xyz.hip
 int sa_xyz_valu_launch(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* idx,
-                       const int* widths, const float* const* weights, const float* const* biases, float* out, hipStream_t s);
+                       const int* widths, const float* const* weights, const float* const* biases, float* out, size_t obs, hipStream_t s);
 }
 
 using namespace jm;
@@ -521,46 +522,68 @@ extern "C" int jm_sa_mlp_pack(int cout, int cin, int first_layer, const float* w
  * weights[l] / biases[l]: packed by jm_sa_mlp_pack(widths[l+1], widths[l], l == 0, ...). */
 static int sa_mlp_narrow_launch(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                                 const float* features, const float* w1x, const int* idx, int num_layers, const int* widths,
-                                const float* const* weights, const float* const* biases, float* out, jm_stream_t stream);
+                                const float* const* weights, const float* const* biases, float* out, size_t obs, jm_stream_t stream);
 #ifdef JM_TOOLS_BUILD
 static long long* g_sa_trace = nullptr;      // tools build only: the product library keeps no state
 extern "C" __attribute__((visibility("default"))) void jm_tools_set_sa_trace(long long* buf) { g_sa_trace = buf; }
 #endif
 
 /* pre-projected form (see the header): layers 2..L on relu(u[idx] - v[centre]) */
-extern "C" int jm_sa_mlp_forward_pre(int b, int n, int m, int c, int nsample, const float* u, const float* w1x,
-                                     const float* new_xyz, const int* idx, int num_layers, const int* widths,
-                                     const float* const* weights, const float* const* biases, float* out, jm_stream_t stream) {
+static int check_out_stride(size_t obs, int m, int cout) {
+    JM_REQUIRE(obs == 0 || obs >= (size_t)cout * (size_t)m, "sa_mlp: output frame stride below cout * npoint");
+    return JM_OK;
+}
+
+extern "C" int jm_sa_mlp_forward_pre_into(int b, int n, int m, int c, int nsample, const float* u, const float* w1x,
+                                          const float* new_xyz, const int* idx, int num_layers, const int* widths,
+                                          const float* const* weights, const float* const* biases, float* out,
+                                          size_t out_frame_stride, jm_stream_t stream) {
     JM_REQUIRE(b >= 0 && n >= 1 && m >= 0 && c >= 16 && c % 16 == 0 && c <= 128, "sa_mlp_pre: C must be a multiple of 16, <= 128");
     if (b == 0 || m == 0) return JM_OK;
     JM_REQUIRE(u && w1x && new_xyz && idx && out && widths && weights && biases, "sa_mlp_pre: null pointer");
     JM_REQUIRE(num_layers >= 2 && num_layers <= 3 && widths[0] == c, "sa_mlp_pre: 2 or 3 layers after the hoisted one, widths[0] == C");
-    return sa_mlp_narrow_launch(b, n, m, c, nsample, nullptr, new_xyz, u, w1x, idx, num_layers, widths, weights, biases, out, stream);
+    if (int rc = check_out_stride(out_frame_stride, m, widths[num_layers])) return rc;
+    return sa_mlp_narrow_launch(b, n, m, c, nsample, nullptr, new_xyz, u, w1x, idx, num_layers, widths, weights, biases, out,
+                                out_frame_stride, stream);
+}
+
+extern "C" int jm_sa_mlp_forward_pre(int b, int n, int m, int c, int nsample, const float* u, const float* w1x,
+                                     const float* new_xyz, const int* idx, int num_layers, const int* widths,
+                                     const float* const* weights, const float* const* biases, float* out, jm_stream_t stream) {
+    return jm_sa_mlp_forward_pre_into(b, n, m, c, nsample, u, w1x, new_xyz, idx, num_layers, widths, weights, biases, out, 0, stream);
 }
 
 extern "C" int jm_sa_mlp_forward(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                                  const float* features, const int* idx, int num_layers, const int* widths,
                                  const float* const* weights, const float* const* biases, float* out,
                                  jm_stream_t stream) {
+    return jm_sa_mlp_forward_into(b, n, m, c, nsample, xyz, new_xyz, features, idx, num_layers, widths, weights, biases, out, 0, stream);
+}
+
+extern "C" int jm_sa_mlp_forward_into(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
+                                      const float* features, const int* idx, int num_layers, const int* widths,
+                                      const float* const* weights, const float* const* biases, float* out,
+                                      size_t out_frame_stride, jm_stream_t stream) {
     JM_REQUIRE(b >= 0 && n >= 1 && m >= 0 && c >= 0, "sa_mlp: bad sizes");
     if (b == 0 || m == 0) return JM_OK;
     JM_REQUIRE(xyz && out && widths && weights && biases && (features || c == 0), "sa_mlp: null pointer");
     JM_REQUIRE((idx == nullptr) == (new_xyz == nullptr), "sa_mlp: idx and new_xyz are both given or both NULL (GroupAll)");
     JM_REQUIRE(num_layers >= 1 && widths[0] == 3 + c, "sa_mlp: widths[0] = %d != 3 + C = %d", widths[0], 3 + c);
+    if (int rc = check_out_stride(out_frame_stride, idx ? m : 1, widths[num_layers])) return rc;
     if (jm_sa_mlp_supported(b, n, m, c, nsample, idx == nullptr, num_layers, widths) == 2)   // wide / GroupAll variant
         return sa_mlp_wide_launch(b, n, m, c, nsample, xyz, new_xyz, features, idx, num_layers, widths, weights, biases,
-                                  out, (hipStream_t)stream);
+                                  out, out_frame_stride, (hipStream_t)stream);
     JM_REQUIRE(idx && new_xyz, "sa_mlp: GroupAll (idx == NULL) needs a shape of the wide variant");
     JM_REQUIRE(widths[0] == 3 + c, "sa_mlp: widths[0] = %d != 3 + C = %d", widths[0], 3 + c);
     if (sa_xyz_valu_supported(m, c, nsample, num_layers, widths))        // xyz-only scales: the vector pipe (sa_xyz.hip)
-        return sa_xyz_valu_launch(b, n, m, nsample, xyz, new_xyz, idx, widths, weights, biases, out, (hipStream_t)stream);
+        return sa_xyz_valu_launch(b, n, m, nsample, xyz, new_xyz, idx, widths, weights, biases, out, out_frame_stride, (hipStream_t)stream);
     return sa_mlp_narrow_launch(b, n, m, c, nsample, xyz, new_xyz, features, nullptr, idx, num_layers, widths, weights, biases,
-                                out, stream);
+                                out, out_frame_stride, stream);
 }
 
 static int sa_mlp_narrow_launch(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                                 const float* features, const float* w1x, const int* idx, int num_layers, const int* widths,
-                                const float* const* weights, const float* const* biases, float* out, jm_stream_t stream) {
+                                const float* const* weights, const float* const* biases, float* out, size_t obs, jm_stream_t stream) {
     const bool pre = w1x != nullptr;
     JM_REQUIRE(nsample == 16 || nsample == 32 || nsample == 64, "sa_mlp: nsample %d not in {16,32,64}", nsample);
     JM_REQUIRE(((long long)m * nsample) % SM_BM == 0, "sa_mlp: npoint*nsample = %lld is not a multiple of 128", (long long)m * nsample);
@@ -583,6 +606,7 @@ static int sa_mlp_narrow_launch(int b, int n, int m, int c, int nsample, const f
         p.np[l] = pad_to(widths[l + 1], 128);
     }
     p.out = out; p.cout = widths[num_layers];
+    p.obs = obs ? obs : (size_t)p.cout * (size_t)m;
     const size_t lds_bytes = pre ? SM_LDS_BYTES_PRE : SM_LDS_BYTES;
     (void)hipFuncSetAttribute((const void*)sa_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM_LDS_BYTES_PRE);
     // persistent: one workgroup per CU (135 KB of LDS each), whole frames per XCD when there are enough of them

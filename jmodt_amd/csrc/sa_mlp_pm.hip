@@ -39,7 +39,8 @@ struct SaPmParams {
     int np1, np2;                          // pad128(H), pad128(cout): rows of the packed weights
     const float *W1, *W2;                  // packed (H x C), (cout x H), k order [16 kt + 8 lk + kk]
     const float *b1, *b2;                  // biases zero padded to np1 / np2
-    float* out;                            // (B, cout, M)
+    float* out;                            // (B, cout, M), frame stride obs
+    size_t obs;
     int S0, S1;                            // LDS row strides of the two tiles
     int tiles_per_frame, total_tiles, xcd_frames;
     const int* total_dev;                  // non-null: the number of tiles is read from device memory (<= total_tiles; the
@@ -265,7 +266,7 @@ __device__ __forceinline__ void pm_mfma_role(const SaPmParams& p, float* lds, in
         // ---------------- max over each centre's nsample rows (nsample / 16 half blocks x 2 lane halves), + bias, ReLU (both
         // commute with max)
         {
-            float* ob = p.out + (size_t)bi * cout * p.M + row0 / ns;
+            float* ob = p.out + (size_t)bi * p.obs + row0 / ns;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int e = tid + 512 * q;
@@ -376,9 +377,10 @@ extern "C" int jm_sa_mlp_pm_supported(int b, int n, int m, int c, int nsample, i
 
 static int sa_mlp_pm_launch(int b, int n, int m, int c, int nsample, int hidden, int cout, const float* u_point_major,
                             const float* w1x, const float* new_xyz, const int* idx, const float* w_hidden,
-                            const float* b_hidden, const float* w_out, const float* b_out, float* out, const int* total_dev,
+                            const float* b_hidden, const float* w_out, const float* b_out, float* out, size_t obs, const int* total_dev,
                             jm_stream_t stream) {
     JM_REQUIRE(b >= 0 && m >= 0, "sa_mlp_pm: bad sizes");
+    JM_REQUIRE(obs == 0 || obs >= (size_t)cout * (size_t)m, "sa_mlp_pm: output frame stride below cout * npoint");
     if (b == 0 || m == 0) return JM_OK;
     JM_REQUIRE(jm_sa_mlp_pm_supported(b, n, m, c, nsample, hidden, cout),
                "sa_mlp_pm: unsupported shape (C in {32,64,128}, nsample in {16,32,64}, npoint*nsample %% 128 == 0, hidden <= 128, out <= 256)");
@@ -392,6 +394,7 @@ static int sa_mlp_pm_launch(int b, int n, int m, int c, int nsample, int hidden,
     p.cout = cout; p.nblk2 = pad_to(cout, 32) / 32;
     p.np1 = pad_to(hidden, 128); p.np2 = pad_to(cout, 128);
     p.W1 = w_hidden; p.W2 = w_out; p.b1 = b_hidden; p.b2 = b_out; p.out = out;
+    p.obs = obs ? obs : (size_t)cout * (size_t)m;
     p.S0 = c + 4; p.S1 = pad_to(hidden, 32) + 4;
     const size_t lds_bytes = sa_pm_lds_bytes(c, hidden);
     (void)hipFuncSetAttribute((const void*)sa_mlp_pm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -419,7 +422,16 @@ extern "C" int jm_sa_mlp_pm_forward(int b, int n, int m, int c, int nsample, int
                                     const float* b_hidden, const float* w_out, const float* b_out, float* out,
                                     jm_stream_t stream) {
     return sa_mlp_pm_launch(b, n, m, c, nsample, hidden, cout, u_point_major, w1x, new_xyz, idx, w_hidden, b_hidden, w_out, b_out, out,
-                            nullptr, stream);
+                            0, nullptr, stream);
+}
+
+/* the same with frame b's output at out + b * out_frame_stride floats (>= cout * m): a channel slice of a wider (B, Ctot, M) tensor */
+extern "C" int jm_sa_mlp_pm_forward_into(int b, int n, int m, int c, int nsample, int hidden, int cout, const float* u_point_major,
+                                         const float* w1x, const float* new_xyz, const int* idx, const float* w_hidden,
+                                         const float* b_hidden, const float* w_out, const float* b_out, float* out,
+                                         size_t out_frame_stride, jm_stream_t stream) {
+    return sa_mlp_pm_launch(b, n, m, c, nsample, hidden, cout, u_point_major, w1x, new_xyz, idx, w_hidden, b_hidden, w_out, b_out, out,
+                            out_frame_stride, nullptr, stream);
 }
 
 /* the same kernel on a row set whose size lives in device memory: frames = 1, m = the CAPACITY in (virtual) centres,
@@ -430,5 +442,5 @@ extern "C" int jm_sa_mlp_pm_forward_dyn(int n, int m, int c, int nsample, int hi
                                         const int* tiles_dev, jm_stream_t stream) {
     JM_REQUIRE(tiles_dev, "sa_mlp_pm_dyn: null tile count");
     return sa_mlp_pm_launch(1, n, m, c, nsample, hidden, cout, u_point_major, w1x, new_xyz, idx, w_hidden, b_hidden, w_out, b_out, out,
-                            tiles_dev, stream);
+                            0, tiles_dev, stream);
 }

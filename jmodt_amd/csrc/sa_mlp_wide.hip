@@ -39,8 +39,9 @@ struct SaWideParams {
     int np[3];               // pad128(width_{l+1}): packed rows of layer l
     const float* W[3];
     const float* bias[3];
-    float* out;              // (B, cout, M)
+    float* out;              // (B, cout, M), frame stride obs
     int cout;
+    size_t obs;
     int rows_per_frame;
 };
 
@@ -128,11 +129,11 @@ sa_mlp_wide_kernel(SaWideParams p) {
         t1 = fmaxf(t1, __shfl_xor(t1, 32));
         if (lk == 0 && col < cout) {
             if (ns == 32) {
-                outp[((size_t)(G0 / Mu) * cout + col) * Mu + (G0 % Mu)] = fmaxf(fmaxf(t0, t1), 0.f);
+                outp[(size_t)(G0 / Mu) * p.obs + (size_t)col * Mu + (G0 % Mu)] = fmaxf(fmaxf(t0, t1), 0.f);
             } else {
                 const unsigned Gb = G0 + 1;
-                outp[((size_t)(G0 / Mu) * cout + col) * Mu + (G0 % Mu)] = fmaxf(t0, 0.f);
-                outp[((size_t)(Gb / Mu) * cout + col) * Mu + (Gb % Mu)] = fmaxf(t1, 0.f);
+                outp[(size_t)(G0 / Mu) * p.obs + (size_t)col * Mu + (G0 % Mu)] = fmaxf(t0, 0.f);
+                outp[(size_t)(Gb / Mu) * p.obs + (size_t)col * Mu + (Gb % Mu)] = fmaxf(t1, 0.f);
             }
         }
     };
@@ -207,7 +208,7 @@ const char* sa_wide_unsupported(long long b, int n, int m, int c, int nsample, i
 
 int sa_mlp_wide_launch(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                        const float* features, const int* idx, int L, const int* widths, const float* const* weights,
-                       const float* const* biases, float* out, hipStream_t s) {
+                       const float* const* biases, float* out, size_t obs, hipStream_t s) {
     const char* why = sa_wide_unsupported(b, n, m, c, nsample, idx == nullptr, L, widths);
     JM_REQUIRE(why == nullptr, "sa_mlp (wide): unsupported shape, needs %s", why);
     SaWideParams p{};
@@ -222,6 +223,7 @@ int sa_mlp_wide_launch(int b, int n, int m, int c, int nsample, const float* xyz
         p.np[l] = pad_to(widths[l + 1], 128);
     }
     p.out = out; p.cout = widths[L];
+    p.obs = obs ? obs : (size_t)p.cout * (size_t)(idx ? m : 1);
     JM_REQUIRE((long long)b * m * nsample < (1LL << 31), "sa_mlp: too many rows");
     p.rows_per_frame = m * nsample;
     const long long tiles = (long long)b * m * nsample / SW_BM;

@@ -31,7 +31,8 @@ struct SaXyzParams {
     const int* idx;                // (B, M, ns)
     const float *w0, *w1, *w2;     // k-major tables [cin][cout] (jm_sa_mlp_pack appends them behind the MFMA layout)
     const float *b0, *b1, *b2;     // biases, zero padded
-    float* out;                    // (B, C3, M)
+    float* out;                    // (B, C3, M), frame stride obs
+    size_t obs;
 };
 
 // max over the 16 lanes of each DPP row (result in every lane of the row) of FOUR values at once: the four independent
@@ -166,7 +167,7 @@ sa_xyz_valu_kernel(SaXyzParams p) {
     const int ob = (int)(crow0 / p.M), om = (int)(crow0 - (long long)ob * p.M);      // (CPW divides M)
     for (int e = tid; e < C3 * CPW; e += T) {
         const int n = e / CPW, j = e - n * CPW;
-        p.out[((size_t)ob * C3 + n) * p.M + om + j] = tile[n][j];
+        p.out[(size_t)ob * p.obs + (size_t)n * p.M + om + j] = tile[n][j];
     }
 }
 
@@ -179,7 +180,7 @@ bool sa_xyz_valu_supported(int m, int c, int nsample, int num_layers, const int*
 }
 
 int sa_xyz_valu_launch(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* idx,
-                       const int* widths, const float* const* weights, const float* const* biases, float* out, hipStream_t s) {
+                       const int* widths, const float* const* weights, const float* const* biases, float* out, size_t obs, hipStream_t s) {
     SaXyzParams p{};
     p.N = n; p.M = m; p.ns = nsample; p.xyz = xyz; p.new_xyz = new_xyz; p.idx = idx;
     // the k-major copies behind the MFMA layouts (sa_mlp_pack_kernel): Kp x Np floats in
@@ -188,6 +189,7 @@ int sa_xyz_valu_launch(int b, int n, int m, int nsample, const float* xyz, const
     p.w2 = weights[2] + (size_t)pad_to(widths[2], 16) * pad_to(widths[3], 128);
     p.b0 = biases[0]; p.b1 = biases[1]; p.b2 = biases[2];
     p.out = out;
+    p.obs = obs ? obs : (size_t)widths[3] * (size_t)m;
     const long long rows = (long long)b * m * nsample;
     JM_REQUIRE(rows / 1024 < (1LL << 31), "sa_xyz: too many rows");
     const dim3 grid((unsigned)(rows / 1024));

@@ -132,6 +132,27 @@ def _pack_k8(W: torch.Tensor, b: torch.Tensor):
     return wp, bp
 
 
+def out_width(mlp: nn.Sequential) -> int:
+    """output channels of a SharedMLP (its last convolution's width)"""
+    w = None
+    for m in mlp.modules():
+        if isinstance(m, (nn.Conv2d, nn.Conv1d)):
+            w = m.out_channels
+    if w is None:
+        raise ValueError("SharedMLP without a convolution")
+    return int(w)
+
+
+def _out_slot(out: Optional[torch.Tensor], B: int, cout: int, M: int, device):
+    """(tensor, frame stride in floats): `out` = a (B, cout, M) view whose channel rows are contiguous (a channel slice of a wider
+    (B, Ctot, M) tensor: the MSG concatenation written in place), or None for a fresh tensor"""
+    if out is None:
+        return torch.empty((B, cout, M), dtype=_f32, device=device), 0
+    assert out.dtype == _f32 and tuple(out.shape) == (B, cout, M) and out.stride(2) == 1 and (out.stride(1) == M or cout == 1) \
+        and (B == 1 or out.stride(0) >= cout * M), (out.shape, out.stride())
+    return out, (out.stride(0) if B > 1 else cout * M)
+
+
 def _pm_layers(mlp: nn.Sequential, device, extra: dict):
     """(w_hidden, b_hidden, w_out, b_out, hidden, cout) of a scale with exactly two layers after the hoisted one, else None"""
     if "pm" not in extra:
@@ -144,16 +165,16 @@ def _pm_layers(mlp: nn.Sequential, device, extra: dict):
     return extra["pm"]
 
 
-def _sa_mlp_pm(u_pm: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w1x: torch.Tensor, pm) -> torch.Tensor:
+def _sa_mlp_pm(u_pm: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w1x: torch.Tensor, pm, out=None) -> torch.Tensor:
     """u_pm (B, N, C) point-major -> (B, cout, M) through jm_sa_mlp_pm_forward"""
     wh, bh, wo, bo, hidden, cout = pm
     B, N, C = u_pm.shape
     M, ns = idx.shape[1], idx.shape[2]
-    out = torch.empty((B, cout, M), dtype=_f32, device=u_pm.device)
-    L.check(L.load().jm_sa_mlp_pm_forward(B, N, M, C, ns, hidden, cout, L.dev(u_pm, _f32, "u"), L.dev(w1x, _f32, "w1x"),
-                                          L.dev(new_xyz.contiguous(), _f32, "new_xyz"), L.dev(idx, _i32, "idx"), L.dev(wh, _f32, "w_hidden"),
-                                          L.dev(bh, _f32, "b_hidden"), L.dev(wo, _f32, "w_out"), L.dev(bo, _f32, "b_out"),
-                                          ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "sa_mlp_pm")
+    out, stride = _out_slot(out, B, cout, M, u_pm.device)
+    L.check(L.load().jm_sa_mlp_pm_forward_into(B, N, M, C, ns, hidden, cout, L.dev(u_pm, _f32, "u"), L.dev(w1x, _f32, "w1x"),
+                                               L.dev(new_xyz.contiguous(), _f32, "new_xyz"), L.dev(idx, _i32, "idx"), L.dev(wh, _f32, "w_hidden"),
+                                               L.dev(bh, _f32, "b_hidden"), L.dev(wo, _f32, "w_out"), L.dev(bo, _f32, "b_out"),
+                                               ctypes.c_void_p(out.data_ptr()), stride, L.stream_ptr()), "sa_mlp_pm")
     return out
 
 
@@ -337,7 +358,7 @@ def hoistable_first_layer(mlp: nn.Sequential, npoint: int, nsample: int, device)
 
 
 @torch.no_grad()
-def _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp):
+def _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp, out=None):
     """QueryAndGroup + SharedMLP + max-pool with the first layer hoisted in front of the gather: W1 [xyz_j - c_i | f_j] + b1
     = u_j - W1x c_i with u = W1 [xyz | f] + b1 per point (two small batched GEMMs accumulating into one tensor); the
     kernel forms relu(u_j - W1x c_i) while gathering and runs layers 2..L (jm_sa_mlp_forward_pre)"""
@@ -358,34 +379,35 @@ def _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp):
             u = st(feats, xyz, point_major=pm is not None)                            # (B, H1, N) or (B, N, H1), one launch
             if pm is not None:
                 prof.hoisted_flops(2 * B * M * ns * H1 * W1.shape[1])
-                return _sa_mlp_pm(u, new_xyz, idx, w1x, pm)
+                return _sa_mlp_pm(u, new_xyz, idx, w1x, pm, out)
     if u is None:
         u = torch.baddbmm(b1[None, :, None], W1[:, 3:].expand(B, -1, -1), feats)
         u = u.baddbmm_(W1[:, :3].expand(B, -1, -1), xyz.transpose(1, 2))
         if pm is not None:
             prof.hoisted_flops(2 * B * M * ns * H1 * W1.shape[1])
-            return _sa_mlp_pm(u.transpose(1, 2).contiguous(), new_xyz, idx, w1x, pm)
+            return _sa_mlp_pm(u.transpose(1, 2).contiguous(), new_xyz, idx, w1x, pm, out)
     widths = [H1] + [cout for _, _, cout, _ in packed]
     nl = len(packed)
     prof.hoisted_flops(2 * B * M * ns * H1 * W1.shape[1])     # the first layer's per-row work this form avoids
-    out = torch.empty((B, widths[-1], M), dtype=_f32, device=xyz.device)
+    out, stride = _out_slot(out, B, widths[-1], M, xyz.device)
     warr = (ctypes.c_void_p * nl)(*[wp.data_ptr() for wp, _, _, _ in packed])
     barr = (ctypes.c_void_p * nl)(*[bp.data_ptr() for _, bp, _, _ in packed])
     widths_c = (ctypes.c_int * (nl + 1))(*widths)
-    L.check(lib.jm_sa_mlp_forward_pre(B, N, M, H1, ns, L.dev(u.contiguous(), _f32, "u"), L.dev(w1x, _f32, "w1x"),
-                                      L.dev(new_xyz.contiguous(), _f32, "new_xyz"), L.dev(idx, _i32, "idx"), nl, widths_c, warr,
-                                      barr, ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "sa_mlp_fused(pre)")
+    L.check(lib.jm_sa_mlp_forward_pre_into(B, N, M, H1, ns, L.dev(u.contiguous(), _f32, "u"), L.dev(w1x, _f32, "w1x"),
+                                           L.dev(new_xyz.contiguous(), _f32, "new_xyz"), L.dev(idx, _i32, "idx"), nl, widths_c, warr,
+                                           barr, ctypes.c_void_p(out.data_ptr()), stride, L.stream_ptr()), "sa_mlp_fused(pre)")
     return out
 
 
 @torch.no_grad()
 def sa_mlp_fused(xyz: torch.Tensor, new_xyz: Optional[torch.Tensor], features: Optional[torch.Tensor],
-                 idx: Optional[torch.Tensor], mlp: nn.Sequential) -> torch.Tensor:
+                 idx: Optional[torch.Tensor], mlp: nn.Sequential, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """xyz (B,N,3), new_xyz (B,M,3), features (B,C,N) or None, idx (B,M,ns) int32 -> (B, mlp_out, M);
-    idx = new_xyz = None: GroupAll (one group of all N points per frame, xyz not re-centred) -> (B, mlp_out, 1)"""
+    idx = new_xyz = None: GroupAll (one group of all N points per frame, xyz not re-centred) -> (B, mlp_out, 1).
+    out: optional (B, mlp_out, M) view to write into — a channel slice of a wider tensor (the MSG concatenation in place)"""
     lib = L.load()
     if idx is not None and _can_pre_project(mlp, features, idx, idx.shape[1], idx.shape[2]):
-        return _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp)
+        return _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp, out)
     layers = _packed_layers(mlp, xyz.device)
     B, N, _ = xyz.shape
     M, ns = (idx.shape[1], idx.shape[2]) if idx is not None else (1, N)
@@ -394,16 +416,16 @@ def sa_mlp_fused(xyz: torch.Tensor, new_xyz: Optional[torch.Tensor], features: O
     if layers[0][3] != widths[0]:
         raise ValueError(f"SharedMLP expects {layers[0][3]} input channels, got 3 + {C}")
     nl = len(layers)
-    out = torch.empty((B, widths[-1], M), dtype=_f32, device=xyz.device)
+    out, stride = _out_slot(out, B, widths[-1], M, xyz.device)
     feats = features.to(_f32).contiguous() if features is not None else None
     warr = (ctypes.c_void_p * nl)(*[wp.data_ptr() for wp, _, _, _ in layers])
     barr = (ctypes.c_void_p * nl)(*[bp.data_ptr() for _, bp, _, _ in layers])
     widths_c = (ctypes.c_int * (nl + 1))(*widths)
-    L.check(lib.jm_sa_mlp_forward(B, N, M, C, ns, L.dev(xyz.contiguous(), _f32, "xyz"),
-                                  L.dev(new_xyz.contiguous(), _f32, "new_xyz") if new_xyz is not None else None,
-                                  L.dev(feats, _f32, "features") if feats is not None else None,
-                                  L.dev(idx, _i32, "idx") if idx is not None else None, nl, widths_c, warr, barr,
-                                  ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "sa_mlp_fused")
+    L.check(lib.jm_sa_mlp_forward_into(B, N, M, C, ns, L.dev(xyz.contiguous(), _f32, "xyz"),
+                                       L.dev(new_xyz.contiguous(), _f32, "new_xyz") if new_xyz is not None else None,
+                                       L.dev(feats, _f32, "features") if feats is not None else None,
+                                       L.dev(idx, _i32, "idx") if idx is not None else None, nl, widths_c, warr, barr,
+                                       ctypes.c_void_p(out.data_ptr()), stride, L.stream_ptr()), "sa_mlp_fused")
     return out
 
 

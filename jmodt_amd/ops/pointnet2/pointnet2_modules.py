@@ -58,14 +58,25 @@ class _PointnetSAModuleBase(nn.Module):
             neigh = list(pointnet2_utils.ball_query_dual(g0.radius, g0.nsample, g1.radius, g1.nsample, xyz, new_xyz, grid=grid))
 
         pooled = []
+        # multi-scale grouping: the fused scales write straight into their channel slice of the concatenated result
+        # (pointnet2_modules.py:54 of the reference: torch.cat(new_features_list, dim=1) — here no copy)
+        full, c_off = None, 0
+        if (len(self.groupers) > 1 and new_xyz is not None and xyz.is_cuda and not torch.is_grad_enabled()):
+            full = torch.empty((xyz.shape[0], sum(fused.out_width(m) for m in self.mlps), new_xyz.shape[1]),
+                               dtype=torch.float32, device=xyz.device)
         for grouper, mlp, nb in zip(self.groupers, self.mlps, neigh):
+            slot = None
+            if full is not None:
+                w = fused.out_width(mlp)
+                slot = full[:, c_off:c_off + w]
+                c_off += w
             eligible = self.fuse and self.pool_method == "max_pool" and grouper.use_xyz and not torch.is_grad_enabled()
             if (eligible and isinstance(grouper, pointnet2_utils.QueryAndGroup)
                     and fused.can_fuse(mlp, new_xyz.shape[1], grouper.nsample, self.training, xyz.shape[0], xyz.shape[1])):
                 # eval / no-grad: group + MLP + max-pool in one fp32-MFMA kernel, nothing materialised
                 if nb is None:
                     nb = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
-                pooled.append(fused.sa_mlp_fused(xyz, new_xyz, features, nb, mlp))
+                pooled.append(fused.sa_mlp_fused(xyz, new_xyz, features, nb, mlp, out=slot))
                 continue
             if (eligible and isinstance(grouper, pointnet2_utils.GroupAll)
                     and fused.can_fuse(mlp, 1, xyz.shape[1], self.training, xyz.shape[0], xyz.shape[1], group_all=True)):
@@ -76,7 +87,20 @@ class _PointnetSAModuleBase(nn.Module):
             else:
                 grouped = grouper(xyz, new_xyz, features)
             pooled.append(prof.region("unfused_mlp+pool(MIOpen)", lambda g=grouped, f=mlp: self._pool(f(g))))
+        if full is not None:
+            for t, (c0, c1) in zip(pooled, self._slices(pooled)):
+                if t.data_ptr() != full[:, c0:c1].data_ptr():     # a scale that took another route: copy its block in
+                    full[:, c0:c1].copy_(t)
+            return new_xyz, full, idx
         return new_xyz, (pooled[0] if len(pooled) == 1 else torch.cat(pooled, dim=1)), idx     # one scale: no copy
+
+    @staticmethod
+    def _slices(pooled):
+        c, out = 0, []
+        for t in pooled:
+            out.append((c, c + t.shape[1]))
+            c += t.shape[1]
+        return out
 
 
 class PointnetSAModuleMSG(_PointnetSAModuleBase):

@@ -188,6 +188,8 @@ class Profiler:
 
     def call(self, sym: str, fn, args):
         """a jm_* entry point under the profiler"""
+        if sym.endswith("_into"):        # the same operator writing into a channel slice: listed under the operator's name
+            sym = sym[:-5]
         if self.only is not None and self._key(sym[3:]) not in self.only:
             self._hoisted = 0
             return fn(*args)

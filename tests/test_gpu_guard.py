@@ -258,3 +258,59 @@ def test_conv3x3_wino_stays_in_bounds_and_refuses_bad_arguments():
     assert lib.jm_conv3x3_wino_bias_relu(1, 4, 4, 16, 64, px, ctypes.c_void_p(packed.view.data_ptr() + 4), None, 1, po, L.stream_ptr()) != 0
     assert lib.jm_conv3x3_wino_bias_relu(0, 4, 4, 16, 64, None, None, None, 1, None, L.stream_ptr()) == 0      # empty batch: nothing to do
     assert lib.jm_conv3x3_wino_pack(16, 64, None, pk, L.stream_ptr()) != 0
+
+
+def test_sa_outputs_written_into_a_channel_slice_leave_the_rest_alone():
+    """jm_sa_mlp_forward_into / _pre_into / _pm_forward_into (the MSG concatenation written in place): the scale's (cout, M) blocks land
+    in their channel slice of a wider guarded tensor — equal to the stand-alone call bit for bit — and every other channel and the
+    margins keep the sentinel; a frame stride below cout * M is refused"""
+    from jmodt_amd import _lib as L
+    from jmodt_amd.ops.pointnet2 import fused, pointnet2_utils as pu
+    from jmodt_amd.ops.pointnet2.pointnet2_modules import PointnetSAModuleMSG
+    torch.manual_seed(2)
+    cases = [  # (C, npoint, nsamples, mlps): xyz-only vector-pipe scales, pre-projected narrow / pm scales, wide scales
+        (0, 192, [16, 32], [[0, 16, 16, 32], [0, 32, 32, 64]]),
+        (32, 128, [16, 32], [[32, 32, 32, 64], [32, 64, 64, 128]]),
+        (64, 64, [16, 32], [[64, 128, 160, 256], [64, 128, 192, 256]]),
+    ]
+    for C, npoint, nsamples, mlps in cases:
+        sa = PointnetSAModuleMSG(npoint=npoint, radii=[0.6, 1.2], nsamples=nsamples, mlps=[list(m) for m in mlps], bn=True).to(DEV).eval()
+        B, N = 3, 1536
+        pts = T(synth.dense_cloud(B, N, 6 + C, extent=5.0))
+        feats = torch.randn(B, C, N, device=DEV) if C else None
+        with torch.no_grad():
+            idx = pu.farthest_point_sample(pts, npoint)
+            new_xyz = pu.gather_operation(pts.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+            widths = [fused.out_width(m) for m in sa.mlps]
+            wide = Guard((B, sum(widths) + 5, npoint), torch.float32)          # 5 channels nobody writes, between and behind the slices
+            c0 = 2
+            for k, (r, ns) in enumerate(zip([0.6, 1.2], nsamples)):
+                nb = pu.ball_query(r, ns, pts, new_xyz)
+                assert fused.can_fuse(sa.mlps[k], npoint, ns, False, B, N)
+                alone = fused.sa_mlp_fused(pts, new_xyz, feats, nb, sa.mlps[k])
+                slot = wide.view[:, c0:c0 + widths[k]]
+                got = fused.sa_mlp_fused(pts, new_xyz, feats, nb, sa.mlps[k], out=slot)
+                assert got.data_ptr() == slot.data_ptr() and torch.equal(slot, alone)
+                c0 += widths[k] + 1
+            s = SENT[torch.float32]
+            mask = torch.ones(sum(widths) + 5, dtype=torch.bool)
+            c0 = 2
+            for w in widths:
+                mask[c0:c0 + w] = False
+                c0 += w + 1
+            assert wide.intact() and bool((wide.view[:, mask.to(DEV)] == s).all())
+            # the module itself: concatenation in place == concatenation of the stand-alone results
+            _, full, _ = sa(pts, feats, new_xyz=new_xyz)
+            want = torch.cat([fused.sa_mlp_fused(pts, new_xyz, feats, pu.ball_query(r, ns, pts, new_xyz), m)
+                              for r, ns, m in zip([0.6, 1.2], nsamples, sa.mlps)], dim=1)
+            assert full.is_contiguous() and torch.equal(full, want)
+    lib = L.load()
+    layers = fused._packed_layers(sa.mlps[0], pts.device)
+    nl = len(layers)
+    wc = (ctypes.c_int * (nl + 1))(3 + C, *[l[2] for l in layers])
+    warr = (ctypes.c_void_p * nl)(*[l[0].data_ptr() for l in layers])
+    barr = (ctypes.c_void_p * nl)(*[l[1].data_ptr() for l in layers])
+    nb = pu.ball_query(0.6, nsamples[0], pts, new_xyz)
+    assert lib.jm_sa_mlp_forward_into(B, N, npoint, C, nsamples[0], L.dev(pts, torch.float32, "x"), L.dev(new_xyz, torch.float32, "c"),
+                                      L.dev(feats, torch.float32, "f"), L.dev(nb, torch.int32, "i"), nl, wc, warr, barr,
+                                      ctypes.c_void_p(wide.view.data_ptr()), widths[0] * npoint - 1, L.stream_ptr()) != 0
