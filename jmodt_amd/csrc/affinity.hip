@@ -33,6 +33,9 @@
 //    per staged float4 and one ds_read_b128 per four MFMA steps, with 8 waves (32 x 64 each, two per SIMD) or 4 waves
 //    (64 x 64), BK 16 or 32: bit-correct, all four slower at 8 x 128^2 / 8 x 256^2 pairs: 1332 / 4926 us (8 waves, BK 16),
 //    1530 / 5843 (4 waves), 1423 / 5368 and 1577 / 6016 (BK 32) against 1266 / 4630 us for this kernel.
+//  * (round 3) the B operand (weights) NOT staged through LDS: packed once per call in MFMA operand order and streamed from L1 / L2
+//    straight into operand registers half a k-tile ahead (the route conv_wino.hip takes): 112 registers, half the LDS traffic and
+//    ds_reads, bit-identical — and 2-3 % slower (1270-1284 / 4647-4676 us against 1242-1261 / 4505-4521 us).
 //  MfmaUtil of this kernel: 54-56 % (profiles/r01_ops_pmc_MfmaUtil.txt); 72-73 % in the batched form (r02).
 #include <stdlib.h>
 
