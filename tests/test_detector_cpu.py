@@ -218,3 +218,24 @@ def test_unique_tid_feature_matches_reference():
     gd = load_golden("tid_feature_ref.npz")
     u, f = get_unique_tid_feature(torch.from_numpy(gd["tid"]), torch.from_numpy(gd["feat"]))
     assert np.array_equal(u.numpy(), gd["unique_tid"]) and np.allclose(f.numpy(), gd["unique_feat"], atol=1e-6)
+
+
+def test_msg_concatenation_slots_and_widths():
+    """host logic of the in-place MSG concatenation (ops/pointnet2/fused.py): output widths of the SharedMLPs, the contract of a
+    channel-slice output view (frame stride handed to jm_sa_mlp_*_into) and what is refused"""
+    from jmodt_amd.ops.pointnet2 import fused
+    from jmodt_amd.ops.pointnet2.pointnet2_modules import PointnetSAModuleMSG
+    sa = PointnetSAModuleMSG(npoint=64, radii=[0.5, 1.0], nsamples=[16, 32], mlps=[[6, 16, 16, 32], [6, 32, 32, 64]], bn=True)
+    assert [fused.out_width(m) for m in sa.mlps] == [32, 64]
+    B, M = 3, 64
+    full = torch.empty(B, 32 + 64, M)
+    a, sa_ = fused._out_slot(full[:, :32], B, 32, M, full.device)
+    b, sb = fused._out_slot(full[:, 32:], B, 64, M, full.device)
+    assert sa_ == sb == 96 * M and a.data_ptr() == full.data_ptr() and b.data_ptr() == full[:, 32:].data_ptr()
+    fresh, s0 = fused._out_slot(None, B, 32, M, full.device)
+    assert s0 == 0 and fresh.shape == (B, 32, M) and fresh.is_contiguous()
+    one, s1 = fused._out_slot(torch.empty(1, 32, M), 1, 32, M, full.device)
+    assert s1 == 32 * M
+    for bad in (full[:, :32].transpose(1, 2), torch.empty(B, 32, M, dtype=torch.float64), full[:, :33], full[:, :32, ::2]):
+        with pytest.raises(AssertionError):
+            fused._out_slot(bad, B, 32, M if bad.shape[-1] == M else bad.shape[-1], full.device)
