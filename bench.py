@@ -22,7 +22,8 @@ equivalent of the reference's nn.DataParallel, tools/train.py:86-88).  Frames ar
 its own batch with no data-path collective (weak scaling); the timed region is bracketed by
 barrier + synchronize and the MAX over ranks is used.
 
-One JSON line on rank 0.  `kernels` lists every C-ABI entry point of the step with its algorithmic bytes /
+One COMPACT JSON line (<= 4 KB) on rank 0's stdout: the contract's keys, `roofline`, `roofline_by_time`, `cpu_baseline`, the
+per-cloud values; the FULL record goes to bench_out/<workload>.json (--full-out).  There, `kernels` lists every C-ABI entry point of the step with its algorithmic bytes /
 flops (jmodt_amd/profile.py: SURVEY.md §8(d) formulas evaluated on the call's own arguments) and its time from
 HIP events recorded on the launching stream inside the timed region, plus caller-side spans (`name(MIOpen)` /
 `name(rocBLAS)` = library calls; `name(span)` = a stage that wraps jm entries listed on their own) and the exposed
@@ -445,14 +446,9 @@ def image_branch_kernel(kernels):
 
 def pick_roofline(kernels, traffic_json, full_table=True):
     """the dominant jm_* entry (caller-side torch spans and stream waits are listed but are not ours to price)"""
-    own = [k for k in kernels if not k.get("stall") and ("algo_bytes_per_step" in k or "algo_flops_per_step" in k)
-           and "(" not in k["kernel"] and k["kernel"].split("/")[-1] not in IMAGE_BRANCH_ENTRIES]
     # the FPS chain on its side stream is not on the critical path when the consumer hardly ever waits for it (its exposed
     # share is reported under `overlap`): the roofline kernel is then the largest entry of the main chain
-    chain = sum(k["ms_per_step"] for k in kernels if k["kernel"].startswith("fps_pyramid/"))
-    exposed = sum(k["ms_per_step"] for k in kernels if k.get("stall") and k["kernel"].startswith("fps_exposed"))
-    if full_table and chain > 0 and exposed < 0.1 * chain:
-        own = [k for k in own if not k["kernel"].startswith("fps_pyramid/")]
+    own = own_rows(kernels, full_table and fps_hidden(kernels))
     if not own:
         return None
     # dominant = the entry that would take longest AT THE ROOFLINE (executed flops / MFMA peak, algorithmic bytes / HBM peak):
@@ -490,6 +486,123 @@ def pick_roofline(kernels, traffic_json, full_table=True):
     if "us_per_fps_iteration" in dom:
         r["us_per_fps_iteration"] = dom["us_per_fps_iteration"]
     return r
+
+
+def own_rows(kernels, hide_fps):
+    """the jm entries of the SURVEY.md §8 path (no stalls, no caller-side spans, no image-branch kernels); `hide_fps`: the FPS
+    chain runs on its side stream and the consumer hardly ever waits for it, so it is not part of the main chain"""
+    own = [k for k in kernels if not k.get("stall") and ("algo_bytes_per_step" in k or "algo_flops_per_step" in k)
+           and "(" not in k["kernel"] and k["kernel"].split("/")[-1] not in IMAGE_BRANCH_ENTRIES]
+    if hide_fps:
+        own = [k for k in own if not k["kernel"].startswith("fps_pyramid/")]
+    return own
+
+
+def fps_hidden(kernels):
+    chain = sum(k["ms_per_step"] for k in kernels if k["kernel"].startswith("fps_pyramid/"))
+    exposed = sum(k["ms_per_step"] for k in kernels if k.get("stall") and k["kernel"].startswith("fps_exposed"))
+    return chain > 0 and exposed < 0.1 * chain
+
+
+def roofline_by_time(kernels, ms_step):
+    """the OTHER reading of "dominant kernel": the jm entry with the largest measured time per step on the chain the step waits
+    for (HIP events, fully instrumented steps), with its own fraction of the roofline that bounds it.  Next to `roofline` (largest
+    speed-of-light time) it shows where the time is as opposed to where the work is."""
+    own = own_rows(kernels, fps_hidden(kernels))
+    if not own:
+        return None
+    k = max(own, key=lambda r: r["ms_per_step"])
+    r = {"kernel": k["kernel"], "ms_per_step": k["ms_per_step"], "launches_per_step": k["launches_per_step"],
+         "share_of_step": round(k["ms_per_step"] / ms_step, 4) if ms_step else None}
+    if "us_per_fps_iteration" in k:
+        r.update(bound="latency (sequential arg-max chain; cloud register-resident)", us_per_fps_iteration=k["us_per_fps_iteration"],
+                 evals_per_s=k.get("evals_per_s"), valu_frac=k.get("valu_frac"),
+                 hbm_frac_on_compulsory_bytes=k.get("hbm_frac"))
+    elif "mfma_frac" in k:
+        ex = "executed_mfma_frac" in k
+        tf = (k["executed_flops_per_step"] / (k["ms_per_step"] * 1e-3) / 1e12) if ex and k["ms_per_step"] > 0 else k.get("achieved_tflops")
+        r.update(bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                 frac=k["executed_mfma_frac"] if ex else k["mfma_frac"])
+    elif "evals_per_s" in k:
+        r.update(bound="valu (pairwise evaluations)", evals_per_s=k["evals_per_s"], valu_frac=k.get("valu_frac"),
+                 hbm_frac_on_compulsory_bytes=k.get("hbm_frac"))
+    else:
+        r.update(bound="hbm", achieved=k["achieved_gbs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=k["hbm_frac"])
+    if k.get("traffic_bytes_per_launch"):
+        r["traffic"] = k["traffic_bytes_per_launch"]
+    return r
+
+
+def fps_summary(kernels, ms_step):
+    """the FPS chain as a top-level figure: its largest level's time per iteration and the chain's share of the step"""
+    rows = [k for k in kernels if "us_per_fps_iteration" in k and k["kernel"].startswith("fps_pyramid/")]
+    if not rows:
+        return None
+    big = max(rows, key=lambda r: r["ms_per_step"])
+    chain = sum(k["ms_per_step"] for k in kernels if k["kernel"].startswith("fps_pyramid/"))
+    exposed = sum(k["ms_per_step"] for k in kernels if k.get("stall") and k["kernel"].startswith("fps_exposed"))
+    return {"kernel": big["kernel"], "us_per_fps_iteration": big["us_per_fps_iteration"], "ms_per_step": big["ms_per_step"],
+            "chain_ms_per_step": round(chain, 4), "chain_share_of_step": round(chain / ms_step, 4) if ms_step else None,
+            "exposed_ms_per_step": round(exposed, 4), "hidden_by_prefetch": fps_hidden(kernels)}
+
+
+COMPACT_LIMIT = 4096     # bytes: the driver records the TAIL of stdout; round 3's 24 KB line could not be parsed from it
+
+
+def _short(v, n):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 1] + "\u2026"
+
+
+def compact_line(full, full_path):
+    """the ONE stdout line: the contract's keys + roofline / roofline_by_time / cpu_baseline / the per-cloud values, at most
+    COMPACT_LIMIT bytes.  Everything else (kernel table, variants' notes, per-stage parity against the CPU chain) is in the
+    full record at `full_record`."""
+    def sub(d, keys, n=160):
+        return None if d is None else {k: _short(d[k], n) for k in keys if k in d and d[k] is not None}
+    c = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "host_enqueue_ms_per_step",
+                              "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    c["config"] = sub(full["config"], ("workload", "frames_per_gpu_per_step", "points", "parallelism", "process_groups"), 400)
+    rf = full.get("roofline")
+    if rf is not None:
+        r = sub(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "max_launch_ms",
+                     "us_per_fps_iteration", "measured_copy_ceiling_gbs"))
+        r.setdefault("traffic", None)
+        if "avg_launch_ms" in r:
+            r["avg_launch_ms"], r["max_launch_ms"] = round(r["avg_launch_ms"], 5), round(r["max_launch_ms"], 5)
+        if rf.get("rocprof"):
+            r["rocprof"] = sub(rf["rocprof"], ("avg_us", "frac", "source"), 80)
+        c["roofline"] = r
+    else:
+        c["roofline"] = None
+    c["roofline_by_time"] = full.get("roofline_by_time")
+    if full.get("fps") is not None:
+        c["fps"] = full["fps"]
+    cb = full.get("cpu_baseline")
+    if cb is not None:
+        c["cpu_baseline"] = sub(cb, ("value", "unit", "cores", "kind", "sample", "configs0_affinity_64x64_pytorch_cpu_ms"), 330)
+    cl = full.get("clouds")
+    if isinstance(cl, dict) and "uniform" in cl:
+        c["clouds"] = {k: v.get("value") for k, v in cl.items() if isinstance(v, dict)}
+        if cl["uniform"].get("value_dense_rcnn_kernels") is not None:
+            c["clouds"]["uniform_dense_rcnn_kernels"] = cl["uniform"]["value_dense_rcnn_kernels"]
+    for k in ("no_prefetch_value", "no_overlap_value", "step_mfma_frac"):
+        if full.get(k) is not None:
+            c[k] = full[k]
+    if full.get("overlap"):
+        c["overlap"] = sub(full["overlap"], ("side_streams", "next_batch_fps_prefetch", "fps_chain_ms", "fps_exposed_ms", "image_branch_exposed_ms"))
+    if full.get("grad_allreduce"):
+        c["grad_allreduce"] = sub(full["grad_allreduce"], ("world", "issued", "bytes_per_step", "ms_per_step", "mode"))
+    if full.get("image_branch_kernel"):
+        c["image_branch_kernel"] = sub(full["image_branch_kernel"], ("kernel", "achieved", "frac", "ms_per_step"))
+    c["full_record"] = full_path
+    line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    for drop in ("image_branch_kernel", "overlap", "fps", "step_mfma_frac", "no_overlap_value"):   # never reached at today's sizes
+        if len(line.encode()) <= COMPACT_LIMIT:
+            break
+        c.pop(drop, None)
+        line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    assert len(line.encode()) <= COMPACT_LIMIT, len(line)
+    return line
 
 
 # bench row -> kernel-name needles in the committed rocprofv3 per-shape table (profiles/<round>_detect_kernel_stats.txt): the
@@ -550,6 +663,9 @@ def main():
     ap.add_argument("--cloud", default="uniform", choices=["uniform", "kitti", "packed"],
                     help="detect only: the synthetic cloud the whole line (value, kernel table) is measured on; the default line "
                          "always carries all three values under `clouds`")
+    ap.add_argument("--full-out", default=None,
+                    help="where the FULL record (kernel table, variants, parity block) is written; default bench_out/<workload>.json. "
+                         "stdout carries one compact line of at most 4 KB")
     ap.add_argument("--launch", action="store_true",
                     help="re-execute under torch.distributed.run even for --gpus 1 (the N > 1 launch path incl. RCCL init / "
                          "barrier / all-reduce on one GPU: what the GPU tier runs)")
@@ -871,6 +987,8 @@ def main():
             "roofline_selection": "the jm entry of the SURVEY.md §8 path with the largest speed-of-light time (executed flops / 157.3 TF, "
                                   "algorithmic bytes / 8 TB/s) of the main chain; measured times of small kernels include waits behind the "
                                   "other stream's convolutions; the image branch's own convolution kernel is priced in `image_branch_kernel`",
+            "roofline_by_time": roofline_by_time(kernels, table_ms if dom_key else ms_step),
+            "fps": fps_summary(kernels, table_ms if dom_key else ms_step),
             "image_branch_kernel": image_branch_kernel(kernels),
             "step_mfma_frac": round(mfma_flops / (ms_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4) if ms_step else None,
             "step_mfma_flops": int(mfma_flops),
@@ -917,7 +1035,20 @@ def main():
                                           **extra}
             except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
                 result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": cores, "kind": "port", "sample": f"failed: {ex!r}"}
-        print(json.dumps(result))
+        # stdout carries ONE compact line (<= COMPACT_LIMIT bytes); the full record (kernel table, variants, per-stage parity
+        # against the CPU chain) goes to a file next to it
+        full_path = args.full_out or os.path.join("bench_out", args.workload + ("" if args.cloud == "uniform" else "_" + args.cloud)
+                                                  + ("_tiny" if args.tiny else "") + ".json")
+        abs_path = full_path if os.path.isabs(full_path) else os.path.join(ROOT, full_path)
+        try:
+            os.makedirs(os.path.dirname(abs_path), exist_ok=True)
+            with open(abs_path, "w") as fh:
+                json.dump(result, fh, allow_nan=False)
+                fh.write("\n")
+        except OSError as ex:        # a read-only tree must not cost the line
+            full_path = f"not written: {ex!r}"
+        sys.stdout.write(compact_line(result, full_path) + "\n")
+        sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

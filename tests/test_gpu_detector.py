@@ -433,6 +433,56 @@ def test_select_detections_synthetic(oracle):
         assert np.allclose(sc, 1 / (1 + np.exp(-raw[b][keep[b]])), atol=1e-6)
 
 
+def _strict(text):
+    """json.loads that refuses NaN / Infinity (what a strict parser on the driver's side would refuse)"""
+    def bad(tok):
+        raise ValueError(f"non-finite constant {tok} in the bench line")
+    return json.loads(text, parse_constant=bad)
+
+
+def _one_compact_line(stdout):
+    """the stdout contract: exactly ONE line, strict JSON, at most 4 KB (round 3's 24 KB line could not be parsed from the tail of
+    stdout the driver keeps), carrying the contract's keys + roofline (+ by time)"""
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, stdout[-2000:]
+    assert len(lines[0].encode()) <= 4096, len(lines[0])
+    r = _strict(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "roofline_by_time", "full_record"):
+        assert key in r, key
+    assert "workload" in r["config"] and "kernels" not in r
+    if r["roofline"] is not None:
+        for key in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"):
+            assert key in r["roofline"], key
+    return lines[0], r
+
+
+def test_bench_default_line_is_compact_and_complete():
+    """the DRIVER's command line (`python bench.py --gpus 1 --steps K --warmup W`, nothing else): one strict-JSON line of at most
+    4 KB with value, roofline (incl. the rocprof cross-check), roofline_by_time, cpu_baseline and the three clouds; every rate in
+    the kernel table of the full record below the machine's peaks"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line, r = _one_compact_line(p.stdout)
+    assert r["value"] > 0 and r["unit"] == "frames/s" and r["dtype"] == "f32" and r["vs_baseline"] is None
+    assert r["roofline"]["bound"] in ("mfma", "hbm") and 0 < r["roofline"]["frac"] <= 1
+    assert abs(r["roofline"]["frac"] - r["roofline"]["achieved"] / r["roofline"]["peak"]) < 2e-3
+    assert r["roofline_by_time"]["kernel"] and r["roofline_by_time"]["ms_per_step"] > 0
+    cb = r["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["sample"]
+    assert set(r["clouds"]) >= {"uniform", "kitti", "packed"} and all(v > 0 for v in r["clouds"].values())
+    assert r["clouds"]["uniform"] == r["value"] and r["no_prefetch_value"] > 0
+    full = _strict(open(os.path.join(ROOT, r["full_record"])).read())
+    for k in full["kernels"]:
+        assert k.get("hbm_frac", 0) <= 1.0, k                      # no fraction above the roofline (round 3: FPS 2.10)
+        assert k.get("executed_mfma_frac", k.get("mfma_frac", 0)) <= 1.0 or "executed_mfma_frac" in k, k
+        if k.get("traffic_bytes_per_launch") and k["ms_per_step"] > 0:
+            per_launch_s = k["ms_per_step"] / max(k["launches_per_step"], 1) * 1e-3
+            assert k["traffic_bytes_per_launch"] / per_launch_s <= 8.0e12 * 1.05, k    # counter bytes / time within the HBM peak
+    assert "gpu_vs_chain" in full["cpu_baseline"] and "stage_seconds" in full["cpu_baseline"]
+
+
 @pytest.mark.parametrize("workload,extra", [("detect", []), ("sa", []), ("ops", []), ("dense", ["--batch", "2"]),
                                             ("train", []), ("detect", ["--no-overlap"]), ("dense_detect", ["--batch", "2"])])
 def test_bench_workloads_smoke(workload, extra):
@@ -442,14 +492,11 @@ def test_bench_workloads_smoke(workload, extra):
            "--no-cpu-baseline"] + (["--tiny"] if workload != "sa" else []) + extra
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, p.stdout[-2000:]
-    r = json.loads(lines[0])
-    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "kernels"):
-        assert key in r, key
+    line, r = _one_compact_line(p.stdout)
     assert r["value"] > 0 and r["steps"] == 2 and r["n_gpus"] == 1
-    names = " ".join(k["kernel"] for k in r["kernels"])
+    full = json.load(open(os.path.join(ROOT, r["full_record"])))         # the kernel table lives in the full record
+    assert full["value"] == r["value"] and full["roofline"]["kernel"] == r["roofline"]["kernel"]
+    names = " ".join(k["kernel"] for k in full["kernels"])
     if workload in ("detect", "train", "dense_detect"):
         for needle in ("fps_pyramid/L1/furthest_point_sampling_xyz", "rpn_sa1/", "li_fusion1/feature_gather", "three_nn",
                        "three_interpolate", "proposal_layer/", "roipool3d_canonical", "rcnn_sa1/sa_mlp_",
@@ -470,9 +517,7 @@ def test_bench_self_launch_under_torch_distributed_run(extra):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, p.stdout[-2000:]
-    r = json.loads(lines[0])
+    line, r = _one_compact_line(p.stdout)
     assert r["n_gpus"] == 1 and r["value"] > 0 and r["steps"] == 2
     assert "dp1" in r["config"]["parallelism"] or "replicas x1" in r["config"]["parallelism"]
 
