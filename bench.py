@@ -371,6 +371,11 @@ def make_train_state(frames, seed, dev, tiny=False):
     return st
 
 
+def _grad_collectives():
+    from jmodt_amd.ops import affinity_train
+    return affinity_train.LAST_GRAD_COLLECTIVES
+
+
 def train_step(st, world):
     """one data-parallel finetune step: frozen composed detector forward (no grad) -> 512-d RoI features ->
     local forward/backward of the pairwise affinity losses -> ONE bucketed gradient all-reduce over RCCL -> Adam"""
@@ -1008,8 +1013,12 @@ def main():
             "grad_allreduce": ({"world": world, "bytes_per_step": next((k.get("algo_bytes_per_step") for k in kernels
                                                                          if k["kernel"].endswith("grad_allreduce(RCCL)")), None),
                                 "ms_per_step": next((k["ms_per_step"] for k in kernels if k["kernel"].endswith("grad_allreduce(RCCL)")), None),
+                                "issued": _grad_collectives(),
+                                "mode": "RCCL all_reduce(SUM) on the flat fp32 gradient bucket, issued whenever a process group exists (a "
+                                        "one-rank group included)" if dist is not None else "no process group: nothing issued",
                                 "note": "one flat fp32 all-reduce of the link / start-end heads' gradients per step (RCCL; HIP events on the "
-                                        "launching stream around the collective and its wait); world 1: no collective is issued"}
+                                        "launching stream around the collective and its wait) + two 3-float / 1-float all-reduces (global "
+                                        "loss-mean counts, loss); `issued` = gradient collectives of the last step"}
                                if args.workload == "train" else None),
             "kernels_from": (f"{table_steps} fully instrumented steps after the timed region" if dom_key else "the timed region"),
             "kernels": kernels,

@@ -374,7 +374,9 @@ static int check_mlp(const jm_mlp3_t* m, const char* who) {
 
 // projection partials of the last layer: one slot per 32 output columns of layer 2 (the single-wave kernel's tile; the
 // 128-column tiles use two slots each), summed in slot order by score_sum_kernel — no float atomics, bit-reproducible scores
-static int proj_slots(const jm_mlp3_t* mlp) { return divup(mlp->h2, 32); }
+// (the 128-column tile ALWAYS writes its two slots, also when h2 <= 64 leaves the second empty: for h2 <= 32 that is one slot
+// more than divup(h2, 32) — the buffer is sized for whichever kernel takes more)
+static int proj_slots(const jm_mlp3_t* mlp) { return imax(divup(mlp->h2, 32), 2 * divup(mlp->h2, BN)); }
 static size_t hidden_bytes(size_t m, const jm_mlp3_t* mlp) {
     return align_up(m * mlp->h1 * sizeof(float), 256) + align_up(m * proj_slots(mlp) * sizeof(float), 256);
 }

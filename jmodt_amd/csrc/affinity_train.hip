@@ -704,7 +704,9 @@ static TrainWs carve(int M, const jm_mlp3_t* mlp, void* ws) {
     w.h1 = take((size_t)M * mlp->h1);
     w.h2 = take((size_t)M * mlp->h2);
     w.y = take(M);
-    w.ypart = take((size_t)M * divup(mlp->h2, 32));
+    // one slot per 32 columns (single-wave kernel) or two per 128-column tile, written also when h2 <= 64 leaves the second
+    // empty: h2 <= 32 needs two slots, not divup(h2, 32) = 1
+    w.ypart = take((size_t)M * (size_t)imax(divup(mlp->h2, 32), 2 * divup(mlp->h2, TBN)));
     w.dy = take(M);
     w.p_dw3 = take((size_t)w.chunks * mlp->h2);
     w.p_db2 = take((size_t)w.chunks * mlp->h2);

@@ -38,6 +38,7 @@ static inline constexpr int tune_env(const char*, int dflt) { return dflt; }
 #endif
 
 static inline int divup(int a, int b) { return (a + b - 1) / b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---- wave64 DPP reductions ---------------------------------------------------------------

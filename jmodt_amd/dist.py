@@ -51,6 +51,16 @@ def shard_frames(num_frames: int, world: int, rank: int, pair_aligned: bool = Tr
     return begin * unit, (begin + count) * unit
 
 
+def collective_path(world: int = 1) -> bool:
+    """do the data-parallel steps issue their collectives?  Yes whenever a process group exists (world size 1 included);
+    a declared world > 1 without one is an error, not a silent single-process step"""
+    if dist.is_initialized():
+        return True
+    if world > 1:
+        raise RuntimeError(f"a data-parallel step over {world} ranks needs an initialised torch.distributed process group")
+    return False
+
+
 def _buckets(params: Sequence[torch.nn.Parameter], bucket_bytes: int) -> List[List[torch.nn.Parameter]]:
     out, cur, size = [], [], 0
     for p in params:
@@ -74,11 +84,16 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], world: Optional[in
     collective only reaches link bandwidth when each of the 7 peers receives megabytes; the whole
     finetune gradient (4.2 MB) or the joint model (66.9 MB) fits one or two buckets.
     Parameters without a gradient contribute zeros (all ranks must issue identical collectives).
-    Returns the number of collectives issued."""
+    Returns the number of collectives issued.
+
+    The collectives are issued whenever a process group EXISTS, a one-rank group included (RCCL / gloo accept it; the sum over
+    one rank is the identity, bit for bit): flatten -> all_reduce -> unflatten is the same code at every world size, so what a
+    one-GPU box executes under `bench.py --launch` is what an 8-GPU node executes.  Without a process group (a plain
+    single-process run) nothing is issued."""
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
     plist = [p for p in params if p.requires_grad]
-    if world == 1 or not plist:
+    if not collective_path(world) or not plist:
         return 0
     n = 0
     for bucket in _buckets(plist, bucket_bytes):

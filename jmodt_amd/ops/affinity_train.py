@@ -97,7 +97,8 @@ def finetune_step(roi_features: torch.Tensor, gt_tids: torch.Tensor, link_layer:
     out = training_affinity(roi_features, gt_tids, link_layer, se_layer)
     counts = torch.tensor([out["gt_links"].numel(), out["gt_starts"].numel(), out["gt_ends"].numel()],
                           dtype=torch.float64, device=roi_features.device)
-    if world > 1:
+    collective = jdist.collective_path(world)
+    if collective:
         tdist.all_reduce(counts, op=tdist.ReduceOp.SUM)
     loss = roi_features.new_zeros(())
     if out["gt_links"].numel():
@@ -109,7 +110,7 @@ def finetune_step(roi_features: torch.Tensor, gt_tids: torch.Tensor, link_layer:
     jdist.allreduce_gradients(params, world=world, average=False)
     optimizer.step()
     total = loss.detach().to(torch.float64).reshape(1)
-    if world > 1:
+    if collective:
         tdist.all_reduce(total, op=tdist.ReduceOp.SUM)
     return float(total.item())   # == reid_loss of the whole batch
 
@@ -361,11 +362,15 @@ def training_affinity_hip(roi_features: torch.Tensor, gt_tids: torch.Tensor, lin
     return out
 
 
+LAST_GRAD_COLLECTIVES = 0      # gradient collectives the last _finetune_step_hip issued (bench.py reports it)
+
+
 def _finetune_step_hip(roi_features, gt_tids, link_layer, se_layer, optimizer, world):
     import torch.distributed as tdist
     st = AffinityTrainState(roi_features, gt_tids)
     counts = st.counts
-    if world > 1:
+    collective = jdist.collective_path(world)       # a process group exists (a one-rank group included: same path at every size)
+    if collective:
         counts = counts.clone()
         tdist.all_reduce(counts, op=tdist.ReduceOp.SUM)
     params = _head_tensors(link_layer) + _head_tensors(se_layer)
@@ -376,11 +381,12 @@ def _finetune_step_hip(roi_features, gt_tids, link_layer, se_layer, optimizer, w
     # ONE flat fp32 all-reduce of the twelve head tensors (4.2 MB at 512-wide heads) over RCCL; timed on this stream when the
     # profiler is on (BASELINE.md §3 config 4 asks for the all-reduce time next to frames/s)
     from ..profile import prof
-    prof.region("grad_allreduce(RCCL)", lambda: jdist.allreduce_gradients(params, world=world, average=False),
-                algo_bytes=sum(p.numel() for p in params) * 4)
+    global LAST_GRAD_COLLECTIVES
+    LAST_GRAD_COLLECTIVES = prof.region("grad_allreduce(RCCL)", lambda: jdist.allreduce_gradients(params, world=world, average=False),
+                                        algo_bytes=sum(p.numel() for p in params) * 4)
     optimizer.step()
     total = _loss_from_parts(lp, sp, counts, 1.0, 1.0)
-    if world > 1:
+    if collective:
         tdist.all_reduce(total, op=tdist.ReduceOp.SUM)
     return total
 
@@ -398,7 +404,8 @@ def finetune_step_static(roi_features: torch.Tensor, gt_tids: torch.Tensor, link
     out = training_affinity_static(roi_features, gt_tids, link_layer, se_layer)
     with torch.no_grad():
         counts = torch.stack([out["valid"].sum(), out["start_valid"].sum(), out["end_valid"].sum()]).to(torch.float32)
-        if world > 1:
+        collective = jdist.collective_path(world)
+        if collective:
             tdist.all_reduce(counts, op=tdist.ReduceOp.SUM)
     loss, _ = reid_loss_static(out, counts)
     loss.backward()
@@ -406,6 +413,6 @@ def finetune_step_static(roi_features: torch.Tensor, gt_tids: torch.Tensor, link
     jdist.allreduce_gradients(params, world=world, average=False)
     optimizer.step()
     total = loss.detach().clone()
-    if world > 1:
+    if collective:
         tdist.all_reduce(total, op=tdist.ReduceOp.SUM)
     return total

@@ -99,6 +99,44 @@ def test_dp_finetune_step_matches_single_process(tmp_path):
             assert torch.equal(s0[name][k], s1[name][k]), (name, k)
 
 
+def _one_rank_worker(rank, port, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch.distributed as tdist
+    from jmodt_amd.ops.affinity_train import finetune_step_static
+    tdist.init_process_group("gloo")
+    assert jdist.collective_path(1)
+    ps = [torch.nn.Parameter(torch.ones(5)), torch.nn.Parameter(torch.ones(3, 3))]
+    ps[0].grad = torch.arange(5.0)
+    assert jdist.allreduce_gradients(ps, bucket_bytes=16) == 2           # ISSUED on the one-rank group (not skipped)
+    assert torch.equal(ps[0].grad, torch.arange(5.0)) and torch.equal(ps[1].grad, torch.zeros(3, 3))
+    feats, tids = _make_batch(123)
+    link, se = _make_heads()
+    opt = torch.optim.SGD(list(link.parameters()) + list(se.parameters()), lr=0.1)
+    loss = finetune_step_static(feats, tids, link, se, opt, world=1)
+    torch.save({"loss": float(loss), "link": link.state_dict(), "se": se.state_dict()}, os.path.join(tmpdir, "one.pt"))
+    tdist.destroy_process_group()
+
+
+def test_one_rank_process_group_takes_the_collective_path_and_changes_nothing(tmp_path):
+    """the data-parallel step issues its collectives whenever a process group exists, world size 1 included (what
+    `bench.py --launch` runs on a one-GPU box): counts, gradients and loss go through all_reduce, and the parameters after
+    the step equal the step without any process group bit for bit; a declared world > 1 without a group is an error"""
+    from jmodt_amd.ops.affinity_train import finetune_step_static
+    mp.spawn(_one_rank_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert not jdist.collective_path(1)
+    with pytest.raises(RuntimeError):
+        jdist.collective_path(2)
+    feats, tids = _make_batch(123)
+    link, se = _make_heads()
+    opt = torch.optim.SGD(list(link.parameters()) + list(se.parameters()), lr=0.1)
+    loss = float(finetune_step_static(feats, tids, link, se, opt, world=1))
+    one = torch.load(tmp_path / "one.pt")
+    assert one["loss"] == loss
+    for name, ref in (("link", link.state_dict()), ("se", se.state_dict())):
+        for k, v in ref.items():
+            assert torch.equal(one[name][k], v), (name, k)
+
+
 def test_static_training_affinity_equals_the_looped_form():
     """training_affinity_static (masks instead of torch.unique / a Python loop over frame pairs) gives the reference
     form's loss and gradients exactly (float64), incl. a pair without foreground on one side and duplicate track ids"""

@@ -520,6 +520,10 @@ def test_bench_self_launch_under_torch_distributed_run(extra):
     line, r = _one_compact_line(p.stdout)
     assert r["n_gpus"] == 1 and r["value"] > 0 and r["steps"] == 2
     assert "dp1" in r["config"]["parallelism"] or "replicas x1" in r["config"]["parallelism"]
+    if "train" in extra:
+        # the one-rank RCCL group takes the collective path: the gradient bucket went through all_reduce and was timed
+        ga = r["grad_allreduce"]
+        assert ga["issued"] == 1 and ga["ms_per_step"] > 0 and ga["bytes_per_step"] > 0 and ga["world"] == 1
 
 
 def test_bench_refuses_more_ranks_than_gpus():

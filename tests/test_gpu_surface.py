@@ -2,6 +2,8 @@
 (a5), the materialised-row affinity head `mlp3_forward` (a14), and the TRAINING affinity + finetune step on the
 device (a16: rcnn.py:204-287, train_functions.py:282-329) against float64 restatements written from the
 reference's own statements."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -36,12 +38,15 @@ def test_query_and_group_vs_oracle(oracle, use_xyz, C):
     assert got.shape == want.shape and np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("M,C,H", [(300, 512, 512), (1, 64, 96), (4097, 128, 64)])
+@pytest.mark.parametrize("M,C,H", [(300, 512, 512), (1, 64, 96), (4097, 128, 64), (5000, 64, (64, 32)), (9001, 32, (32, 7)),
+                                   (130, 64, (64, 32))])
 def test_mlp3_forward_values(M, C, H):
-    """jm_mlp3_forward (the affinity head on materialised rows, rcnn.py:272-285) vs a float64 numpy MLP"""
+    """jm_mlp3_forward (the affinity head on materialised rows, rcnn.py:272-285) vs a float64 numpy MLP.  h2 <= 32 on the
+    large-M path: the 128-column tiles write two projection-partial slots where divup(h2, 32) is one (the scratch is sized for
+    both kernels; an undersized one let M floats land past the workspace)"""
     from jmodt_amd.ops.affinity import make_affinity_mlp, mlp3_forward
     torch.manual_seed(M)
-    head = make_affinity_mlp(C, (H, H)).to(DEV).eval()
+    head = make_affinity_mlp(C, H if isinstance(H, tuple) else (H, H)).to(DEV).eval()
     with torch.no_grad():
         for m in head.modules():
             if isinstance(m, torch.nn.Conv1d):
@@ -150,7 +155,8 @@ def test_training_affinity_and_finetune_step_on_gpu():
             assert (ps.detach().double().cpu() - p64.detach())[big].abs().max().item() < 2e-4
 
 
-@pytest.mark.parametrize("frames,R,C,H,ntid", [(6, 64, 512, 512, 9), (4, 64, 512, 512, 30), (2, 48, 64, 64, 5), (8, 128, 128, 96, 40)])
+@pytest.mark.parametrize("frames,R,C,H,ntid", [(6, 64, 512, 512, 9), (4, 64, 512, 512, 30), (2, 48, 64, 64, 5), (8, 128, 128, 96, 40),
+                                               (8, 128, 64, 32, 40)])     # h2 = 32 on 65536 pair rows: two partial slots per tile
 def test_training_affinity_hip_kernels_vs_float64_reference(frames, R, C, H, ntid):
     """a16 on the matrix cores (csrc/affinity_train.hip): outputs, loss and the gradients of all twelve head tensors
     against (i) the float64 statement-by-statement copy of rcnn.py:204-287 + train_functions.py:282-329 differentiated by
@@ -247,6 +253,29 @@ def test_finetune_step_static_uses_the_hip_kernels():
     assert {"affinity_train_prepare", "affinity_train_link_step", "affinity_train_se_step"} <= names, names
     assert loss.is_cuda and 0 < loss.item() < 3
     assert all((a - b.detach()).abs().max().item() > 0 for a, b in zip(before, link.parameters()))
+
+
+def test_gradient_allreduce_runs_on_rccl_with_one_rank(tmp_path):
+    """flatten -> RCCL all_reduce -> unflatten of the 4 206 600-byte finetune gradient on DEVICE tensors, with a one-rank
+    process group (tools/train.py:86-88's DataParallel reduction as one process per GPU): the collective is issued and timed,
+    and three Adam steps through it leave exactly the parameters of three steps without any process group.  The first N > 1
+    run on an 8-GPU node then executes no code this box has not."""
+    import subprocess
+    import sys
+    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "rccl_one_rank_step.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    res = {}
+    for tag, extra in (("plain", []), ("group", ["--group"])):
+        out = str(tmp_path / f"{tag}.pt")
+        p = subprocess.run([sys.executable, helper, out] + extra, capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-3000:]
+        res[tag] = torch.load(out)
+    assert res["plain"]["issued"] == 0 and res["group"]["issued"] == 1
+    assert res["group"]["bytes_per_step"] == 4_206_600 and res["group"]["ms_per_step"] > 0
+    assert res["group"]["losses"] == res["plain"]["losses"]
+    for a, b in zip(res["group"]["params"], res["plain"]["params"]):
+        assert torch.equal(a, b)
 
 
 # ------------------------------------------------------------------ contraction-proof decision fixtures
