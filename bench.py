@@ -668,6 +668,10 @@ def main():
     ap.add_argument("--cloud", default="uniform", choices=["uniform", "kitti", "packed"],
                     help="detect only: the synthetic cloud the whole line (value, kernel table) is measured on; the default line "
                          "always carries all three values under `clouds`")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip everything that runs OTHER shapes after the timed region (the kitti / packed clouds, the dense-RCNN and "
+                         "experimental variants): what the rocprofv3 passes use, so that every dispatch of a profile belongs to the "
+                         "headline workload (profiles/make_traffic.py attributes counters per (kernel, grid, workgroup))")
     ap.add_argument("--full-out", default=None,
                     help="where the FULL record (kernel table, variants, parity block) is written; default bench_out/<workload>.json. "
                          "stdout carries one compact line of at most 4 KB")
@@ -832,7 +836,7 @@ def main():
 
     # the same workload with one overlap mechanism off at a time (a few steps, after the timed region, outside `value`)
     variants = {}
-    if args.workload == "detect" and args.steps >= 2:
+    if args.workload == "detect" and args.steps >= 2 and not args.headline_only:
         eng = st["engine"]
         n_var = max(2, min(5, args.steps))
 

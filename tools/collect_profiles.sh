@@ -2,9 +2,9 @@
 # Run ON THE GPU BOX (through gpurun): rocprofv3 kernel-trace stats + PMC passes (one counter per pass, never combined
 # with other trace domains) for the bench workloads.  The rocpd databases stay in /tmp (they exceed gpurun's 64 MiB
 # copy-back limit); only the text summaries land in gpurun_out/profiles/, from where they are copied into profiles/.
-#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r03'
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r04'
 set -u
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/profiles
 mkdir -p "$OUT"
@@ -24,11 +24,11 @@ run() {   # tag, extra rocprof flags, summarize mode, bench args...
 }
 # MIOpen tunes every new convolution shape on first use (seconds of naive_conv_* kernels on a fresh box): do that outside the profile
 timeout 600 python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /tmp/warm.log 2>&1
-run detect_kernel_stats "--stats" ""   --steps 7 --warmup 3 --no-cpu-baseline
+run detect_kernel_stats "--stats" ""   --steps 7 --warmup 3 --no-cpu-baseline --headline-only
 run sa_kernel_stats     "--stats" ""   --workload sa --steps 12 --warmup 3 --no-cpu-baseline
 run ops_kernel_stats    "--stats" ""   --workload ops --steps 7 --warmup 2 --no-cpu-baseline
 for c in FETCH_SIZE WRITE_SIZE MfmaUtil SQ_INSTS_VALU_MFMA_MOPS_F32; do
-    run detect_pmc_$c "--pmc $c" "--pmc" --steps 2 --warmup 1 --no-cpu-baseline
+    run detect_pmc_$c "--pmc $c" "--pmc" --steps 2 --warmup 1 --no-cpu-baseline --headline-only
 done
 for c in FETCH_SIZE WRITE_SIZE; do
     run sa_pmc_$c  "--pmc $c" "--pmc" --workload sa --steps 3 --warmup 1 --no-cpu-baseline
