@@ -902,6 +902,9 @@ def main():
         if dist is not None:
             dist.barrier(group=ctl)
 
+    if args.workload == "detect" and args.headline_only:
+        torch.cuda.synchronize()
+        variants["clouds"] = {"uniform": {"value": None, "rcnn": rcnn_rows(), "note": "--headline-only: the other clouds were not run"}}
     if rank == 0:
         kernels = prof.summary(table_steps, HBM_PEAK_GBS, MFMA_F32_PEAK_TF)
         # HBM bytes per launch from the committed rocprofv3 --pmc passes (collected separately, as the guide
