@@ -166,6 +166,27 @@ int jm_sa_mlp_forward_pre(int b, int n, int m, int c, int nsample, const float* 
                           const int* idx, int num_layers, const int* widths, const float* const* weights,
                           const float* const* biases, float* out, jm_stream_t stream);
 
+/* Duplicate-aware (LISTED) form of the fused set-abstraction block, exact (round 4; csrc/sa_groups.hip).
+ * ball_query back-fills a list with cnt < nsample hits with copies of its first hit (ball_query_gpu.cu:36-40), and the
+ * max-pool of _PointnetSAModuleBase.forward (pointnet2_modules.py:50-52) is idempotent: only a group's first d = cnt rows
+ * matter.  jm_sa_group_plan bins the groups (frame, centre) by q = max(qmin, ceil(log2 d)) — d = 1 + the last slot of the list
+ * that differs from its first entry, so the first 2^q entries contain every distinct entry of ANY list — into per-class lists in
+ * device memory; jm_sa_mlp_forward_listed runs jm_sa_mlp_forward_into's kernel on tiles of one class each, pooling over 2^q
+ * rows, and writes every group's output at its own position: bit-identical to jm_sa_mlp_forward_into (a row's value depends
+ * on its point and centre only, max on neither order nor multiplicity), rows executed 2^q instead of nsample per group.
+ * plan: jm_sa_group_plan_elems(groups, nsample) ints = [8 class counts | (log2 nsample + 1) x groups group ids]; no host
+ * decision and no host sync anywhere: both launches are always issued.
+ * jm_sa_mlp_listed_supported: 0 = no listed kernel for the shape, else the kernel (as jm_sa_mlp_supported) and
+ * jm_sa_mlp_listed_qmin its smallest class. */
+size_t jm_sa_group_plan_elems(int groups, int nsample);
+int jm_sa_group_plan(int groups, int nsample, const int* idx, int qmin, int* plan, jm_stream_t stream);
+int jm_sa_mlp_listed_supported(int b, int n, int m, int c, int nsample, int num_layers, const int* widths);
+int jm_sa_mlp_listed_qmin(int kind);
+int jm_sa_mlp_forward_listed(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
+                             const float* features, const int* idx, int num_layers, const int* widths,
+                             const float* const* weights, const float* const* biases, const int* plan, float* out,
+                             size_t out_frame_stride, jm_stream_t stream);
+
 /* ------------------------------------------------------------------ roipool3d_cuda -------- */
 
 /* forward / forward_slow (roipool3d/src/roipool3d.cpp:16-79, roipool3d_kernel.cu:31-237).

@@ -1,0 +1,112 @@
+// sa_groups.hip — the plan of the duplicate-aware RPN set abstraction (exact) + the listed entry of the fused SA kernels.
+//
+// ball_query (jmodt/ops/pointnet2/src/ball_query_gpu.cu:36-40) writes the FIRST hit into all nsample slots of a centre's
+// list and then overwrites slots 1 .. cnt - 1 with the further hits, in ascending point order: a list with cnt < nsample hits
+// ends in nsample - cnt copies of its first entry.  The grouped tensor of _PointnetSAModuleBase.forward
+// (pointnet2_modules.py:46-61) then repeats that row, and the max-pool over the group (pointnet2_modules.py:50-52) is
+// idempotent: only the first d = max(cnt, 1) rows of a group matter.  On FPS-thinned clouds most groups of the RPN levels
+// hold ONE point, the centre itself (tools/rpn_dup_stats.py: 94-97 % of the rows of the headline cloud are copies).
+//
+//   sg_plan_kernel   one lane per (frame, centre) group: d = 1 + the last slot whose entry differs from the first (= the hit
+//                    count of a ball-query list: the hits behind the first are strictly larger point indices), class
+//                    q = max(qmin, ceil(log2 d)), and the group id is appended to class q's list (one atomic per workgroup
+//                    and class).  The first 2^q entries of the group's list are its d distinct rows + back-fill copies.
+//   consumers        sa_mlp_wide_kernel / sa_xyz_valu_kernel / sa_mlp_pm_kernel in LISTED mode: tiles of ONE class (a tile
+//                    holds rows-per-tile >> q groups), pool over 2^q rows, output stored at the group's own position.
+// Where a group lands in its class list is not deterministic (atomics); its value is: a row depends on (point, centre) only
+// and max is order- and multiplicity-free, so the output is BIT-IDENTICAL to the dense kernels' run to run and mode to mode.
+// No host decision, no host sync: the class counts live in device memory and every consumer launch is always issued.
+#include "jm_common.h"
+
+namespace jm {
+
+int sa_mlp_wide_launch(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
+                       const float* features, const int* idx, int L, const int* widths, const float* const* weights,
+                       const float* const* biases, float* out, size_t obs, hipStream_t s, const int* cls_count, const int* glist);
+const char* sa_wide_unsupported(long long b, int n, int m, int c, int nsample, int group_all, int L, const int* widths);
+
+// cls_count[0..7] zeroed by the caller (hipMemsetAsync in the entry); glist: (qfull + 1) x groups
+template <int NS>
+__global__ void __launch_bounds__(256)
+sg_plan_kernel(int groups, int qmin, const int* __restrict__ idx, int* __restrict__ cls_count, int* __restrict__ glist) {
+    __shared__ int lcnt[8], lbase[8];
+    const int tid = threadIdx.x;
+    if (tid < 8) lcnt[tid] = 0;
+    __syncthreads();
+    const int g = blockIdx.x * 256 + tid;
+    int q = -1, rank = 0;
+    if (g < groups) {
+        const int4* row = reinterpret_cast<const int4*>(idx + (size_t)g * NS);
+        // d = 1 + the LAST slot that differs from the first: for a ball-query list that is its hit count; for any other list
+        // the first d entries still contain every distinct entry, so the listed form is exact whatever wrote idx
+        int d = 1, first = 0;
+#pragma unroll
+        for (int v = 0; v < NS / 4; ++v) {
+            const int4 e = row[v];
+            if (v == 0) first = e.x; else if (e.x != first) d = 4 * v + 1;
+            if (e.y != first) d = 4 * v + 2;
+            if (e.z != first) d = 4 * v + 3;
+            if (e.w != first) d = 4 * v + 4;
+        }
+        q = d <= 1 ? 0 : 32 - __clz(d - 1);                       // ceil(log2 d)
+        q = max(q, qmin);
+        rank = atomicAdd(&lcnt[q], 1);
+    }
+    __syncthreads();
+    if (tid < 8 && lcnt[tid] > 0) lbase[tid] = atomicAdd(&cls_count[tid], lcnt[tid]);
+    __syncthreads();
+    if (q >= 0) glist[(size_t)q * groups + lbase[q] + rank] = g;
+}
+
+}  // namespace jm
+
+using namespace jm;
+
+extern "C" size_t jm_sa_group_plan_elems(int groups, int nsample) {
+    if (groups < 0 || (nsample != 16 && nsample != 32 && nsample != 64)) return 0;
+    const int nq = nsample == 16 ? 5 : (nsample == 32 ? 6 : 7);
+    return 8 + (size_t)nq * (size_t)groups;
+}
+
+/* plan[0..7] = groups per class q (rows per group 2^q), plan[8 + q * groups ...] = class q's group ids (b * npoint + i).
+ * idx (groups, nsample) int32 as ball_query wrote it; qmin = the smallest class the consumer kernel tiles (0 = single rows). */
+extern "C" int jm_sa_group_plan(int groups, int nsample, const int* idx, int qmin, int* plan, jm_stream_t stream) {
+    JM_REQUIRE(groups >= 0 && (nsample == 16 || nsample == 32 || nsample == 64), "sa_group_plan: nsample in {16, 32, 64}");
+    JM_REQUIRE(qmin >= 0 && (1 << qmin) <= nsample, "sa_group_plan: smallest class 2^%d above nsample", qmin);
+    JM_REQUIRE(plan, "sa_group_plan: null plan");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(plan, 0, 8 * sizeof(int), s) != hipSuccess) { set_error("sa_group_plan: memset failed"); return JM_ELAUNCH; }
+    if (groups == 0) return JM_OK;
+    JM_REQUIRE(idx && (reinterpret_cast<uintptr_t>(idx) & 15u) == 0, "sa_group_plan: idx null or not 16-byte aligned");
+    const dim3 grid((unsigned)divup(groups, 256));
+    if (nsample == 16) hipLaunchKernelGGL(sg_plan_kernel<16>, grid, dim3(256), 0, s, groups, qmin, idx, plan, plan + 8);
+    else if (nsample == 32) hipLaunchKernelGGL(sg_plan_kernel<32>, grid, dim3(256), 0, s, groups, qmin, idx, plan, plan + 8);
+    else hipLaunchKernelGGL(sg_plan_kernel<64>, grid, dim3(256), 0, s, groups, qmin, idx, plan, plan + 8);
+    return check_launch("sa_group_plan");
+}
+
+/* which kernel takes the LISTED form of this scale: 0 none, 2 sa_mlp_wide_kernel (smallest class 2^0) */
+extern "C" int jm_sa_mlp_listed_supported(int b, int n, int m, int c, int nsample, int num_layers, const int* widths) {
+    if (b < 0 || n < 1 || m < 1 || c < 0 || num_layers < 1 || !widths || widths[0] != 3 + c) return 0;
+    if (jm_sa_mlp_supported(b, n, m, c, nsample, 0, num_layers, widths) == 2) return 2;
+    return 0;
+}
+
+extern "C" int jm_sa_mlp_listed_qmin(int kind) { return kind == 2 ? 0 : -1; }
+
+/* jm_sa_mlp_forward_into on the groups of `plan` (jm_sa_group_plan of the same idx): bit-identical output */
+extern "C" int jm_sa_mlp_forward_listed(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
+                                        const float* features, const int* idx, int num_layers, const int* widths,
+                                        const float* const* weights, const float* const* biases, const int* plan, float* out,
+                                        size_t out_frame_stride, jm_stream_t stream) {
+    JM_REQUIRE(b >= 0 && n >= 1 && m >= 0 && c >= 0, "sa_mlp_listed: bad sizes");
+    if (b == 0 || m == 0) return JM_OK;
+    JM_REQUIRE(xyz && new_xyz && idx && out && widths && weights && biases && plan && (features || c == 0), "sa_mlp_listed: null pointer");
+    JM_REQUIRE(num_layers >= 1 && widths[0] == 3 + c, "sa_mlp_listed: widths[0] = %d != 3 + C = %d", widths[0], 3 + c);
+    JM_REQUIRE(out_frame_stride == 0 || out_frame_stride >= (size_t)widths[num_layers] * (size_t)m,
+               "sa_mlp_listed: output frame stride below cout * npoint");
+    const int kind = jm_sa_mlp_listed_supported(b, n, m, c, nsample, num_layers, widths);
+    JM_REQUIRE(kind != 0, "sa_mlp_listed: no listed kernel for this shape");
+    return sa_mlp_wide_launch(b, n, m, c, nsample, xyz, new_xyz, features, idx, num_layers, widths, weights, biases, out,
+                              out_frame_stride, (hipStream_t)stream, plan, plan + 8);
+}

@@ -399,12 +399,47 @@ def _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp, out=None):
     return out
 
 
+LISTED = True         # duplicate-aware form of the RPN scales (csrc/sa_groups.hip): rows executed 2^ceil(log2 d) per group of d
+                      # distinct neighbours instead of nsample; bit-identical output
+
+
+def listed_kind(mlp: nn.Sequential, features, idx: torch.Tensor, B: int, N: int) -> int:
+    """which kernel takes the listed form of this scale (0: none — the dense entry is used)"""
+    if not LISTED or idx is None:
+        return 0
+    M, ns = idx.shape[1], idx.shape[2]
+    if _can_pre_project(mlp, features, idx, M, ns):
+        return 0
+    shapes = _layer_shapes(mlp)
+    if not shapes:
+        return 0
+    widths = [shapes[0][1]] + [cout for cout, _ in shapes]
+    arr = (ctypes.c_int * len(widths))(*widths)
+    return int(L.load().jm_sa_mlp_listed_supported(int(B), int(N), int(M), widths[0] - 3, int(ns), len(shapes), arr))
+
+
+@torch.no_grad()
+def group_plan(idx: torch.Tensor, qmin: int = 0) -> torch.Tensor:
+    """idx (B, M, ns) int32 neighbour lists -> the listed form's plan (int32: 8 class counts + per-class group ids)"""
+    lib = L.load()
+    B, M, ns = idx.shape
+    plan = torch.empty((int(lib.jm_sa_group_plan_elems(B * M, ns)),), dtype=_i32, device=idx.device)
+    L.check(lib.jm_sa_group_plan(B * M, ns, L.dev(idx, _i32, "idx"), int(qmin), L.dev(plan, _i32, "plan"), L.stream_ptr()), "sa_group_plan")
+    return plan
+
+
+class ListedStats:
+    """device-side record of the last listed scales: [(name, dense rows, plan tensor)] (bench.py reads the class counts back)"""
+    last = []
+
+
 @torch.no_grad()
 def sa_mlp_fused(xyz: torch.Tensor, new_xyz: Optional[torch.Tensor], features: Optional[torch.Tensor],
-                 idx: Optional[torch.Tensor], mlp: nn.Sequential, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 idx: Optional[torch.Tensor], mlp: nn.Sequential, out: Optional[torch.Tensor] = None, listed: bool = True) -> torch.Tensor:
     """xyz (B,N,3), new_xyz (B,M,3), features (B,C,N) or None, idx (B,M,ns) int32 -> (B, mlp_out, M);
     idx = new_xyz = None: GroupAll (one group of all N points per frame, xyz not re-centred) -> (B, mlp_out, 1).
-    out: optional (B, mlp_out, M) view to write into — a channel slice of a wider tensor (the MSG concatenation in place)"""
+    out: optional (B, mlp_out, M) view to write into — a channel slice of a wider tensor (the MSG concatenation in place).
+    listed: take the duplicate-aware form where a kernel has one (same bits, fewer rows)"""
     lib = L.load()
     if idx is not None and _can_pre_project(mlp, features, idx, idx.shape[1], idx.shape[2]):
         return _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp, out)
@@ -421,6 +456,17 @@ def sa_mlp_fused(xyz: torch.Tensor, new_xyz: Optional[torch.Tensor], features: O
     warr = (ctypes.c_void_p * nl)(*[wp.data_ptr() for wp, _, _, _ in layers])
     barr = (ctypes.c_void_p * nl)(*[bp.data_ptr() for _, bp, _, _ in layers])
     widths_c = (ctypes.c_int * (nl + 1))(*widths)
+    kind = listed_kind(mlp, features, idx, B, N) if listed else 0
+    if kind:
+        idx = idx.contiguous()
+        plan = group_plan(idx, int(lib.jm_sa_mlp_listed_qmin(kind)))
+        L.check(lib.jm_sa_mlp_forward_listed(B, N, M, C, ns, L.dev(xyz.contiguous(), _f32, "xyz"), L.dev(new_xyz.contiguous(), _f32, "new_xyz"),
+                                             L.dev(feats, _f32, "features") if feats is not None else None, L.dev(idx, _i32, "idx"),
+                                             nl, widths_c, warr, barr, L.dev(plan, _i32, "plan"), ctypes.c_void_p(out.data_ptr()), stride,
+                                             L.stream_ptr()), "sa_mlp_fused(listed)")
+        ListedStats.last.append((prof._key("sa_mlp_forward_listed"), B * M * ns, ns, plan))
+        del ListedStats.last[:-16]
+        return out
     L.check(lib.jm_sa_mlp_forward_into(B, N, M, C, ns, L.dev(xyz.contiguous(), _f32, "xyz"),
                                        L.dev(new_xyz.contiguous(), _f32, "new_xyz") if new_xyz is not None else None,
                                        L.dev(feats, _f32, "features") if feats is not None else None,

@@ -51,6 +51,15 @@ def _sa_mlp(a):
     return b * (12 * n + 12 * m + 4 * c * n + 4 * m * ns + 4 * w[-1] * m), flops, {}
 
 
+def _sa_mlp_listed(a):
+    """the dense block's algorithmic work + what one executed row costs: the rows executed (2^q per group of
+    class q) live in device memory (fused.ListedStats; bench.py multiplies)"""
+    nbytes, flops, _ = _sa_mlp(a)
+    nl = _i(a, 9)
+    w = [int(a[10][k]) for k in range(nl + 1)]
+    return nbytes, flops, dict(flops_per_row=2 * sum(w[k] * w[k + 1] for k in range(nl)), bytes_per_row=4 * (w[0] + 1), listed=True)
+
+
 def _sa_mlp_pre(a):
     b, n, m, c, ns, nl = _i(a, 0), _i(a, 1), _i(a, 2), _i(a, 3), _i(a, 4), _i(a, 9)
     w = [int(a[10][k]) for k in range(nl + 1)]
@@ -99,6 +108,7 @@ ALGO: Dict[str, Callable] = {
     "jm_three_interpolate": lambda a: (_i(a, 0) * (4 * _i(a, 1) * _i(a, 2) + 24 * _i(a, 3) + 4 * _i(a, 1) * _i(a, 3)), 0, {}),
     "jm_sa_mlp_forward": _sa_mlp,
     "jm_sa_mlp_forward_pre": _sa_mlp_pre,
+    "jm_sa_mlp_forward_listed": _sa_mlp_listed,
     "jm_roipool3d_forward": _roipool,
     "jm_roipool3d_canonical": _roipool,
     "jm_nms": lambda a: (_nms_bytes(_i(a, 0)), 0, dict(evals=_i(a, 0) * _i(a, 0) // 2)),
@@ -262,6 +272,8 @@ class Profiler:
             if "flops_per_row" in ex:
                 row["flops_per_row"] = ex["flops_per_row"]
                 row["bytes_per_row"] = ex["bytes_per_row"]
+                if ex.get("listed"):
+                    row["listed"] = True
             if "iterations" in ex:
                 # FPS keeps its cloud in registers: the bytes above are the reference's per-iteration re-reads (SURVEY.md §8d
                 # "streaming-equivalent"), never HBM traffic — no HBM fraction is formed on them (it would exceed 1); the

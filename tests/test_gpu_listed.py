@@ -1,0 +1,100 @@
+"""GPU tier (-m gpu): the duplicate-aware (LISTED) form of the RPN set-abstraction scales (csrc/sa_groups.hip + the listed modes
+of the fused SA kernels).  ball_query back-fills a short neighbour list with its first hit (ball_query_gpu.cu:36-40) and the
+max-pool of pointnet2_modules.py:50-52 is idempotent, so only a group's first d rows matter; the listed form executes
+2^ceil(log2 d) of them.  The claim is EXACTNESS: every comparison is torch.equal against the dense kernel of the same scale."""
+import numpy as np
+import pytest
+import torch
+
+from jmodt_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _lists(B, M, N, ns, pattern, seed):
+    """(B, M, ns) int32 neighbour lists in ball_query's form: d ascending distinct point indices, then copies of the first"""
+    rng = np.random.default_rng(seed)
+    idx = np.zeros((B, M, ns), np.int32)
+    d = {"singletons": np.ones((B, M), np.int64), "full": np.full((B, M), ns),
+         "mixed": rng.integers(1, ns + 1, (B, M)), "sparse": np.minimum(rng.geometric(0.6, (B, M)), ns)}[pattern]
+    for b in range(B):
+        for m in range(M):
+            k = int(d[b, m])
+            hits = np.sort(rng.choice(N, k, replace=False))
+            idx[b, m, :k] = hits
+            idx[b, m, k:] = hits[0]
+    if pattern == "mixed":
+        idx[0, 0] = 0                                   # a centre without any hit keeps the caller's zero fill
+        idx[0, 1] = np.array([5, 5, 5, 7] + [5] * (ns - 4))     # NOT ball_query's form: the last differing slot decides
+    return idx, d
+
+
+@pytest.mark.parametrize("ns", [16, 32])
+@pytest.mark.parametrize("qmin", [0, 2])
+def test_group_plan_bins_every_group_once_into_its_class(ns, qmin):
+    from jmodt_amd.ops.pointnet2.fused import group_plan
+    B, M, N = 3, 700, 900
+    idx, _ = _lists(B, M, N, ns, "mixed", 3)
+    plan = group_plan(T(idx), qmin).cpu().numpy()
+    G = B * M
+    flat = idx.reshape(G, ns)
+    need = np.array([1 + max([s for s in range(ns) if row[s] != row[0]], default=0) for row in flat])
+    q = np.maximum(np.ceil(np.log2(np.maximum(need, 1))).astype(int), qmin)
+    nq = int(np.log2(ns)) + 1
+    assert plan.shape[0] == 8 + nq * G
+    seen = []
+    for c in range(8):
+        cnt = plan[c]
+        assert cnt == (q == c).sum(), (c, cnt)
+        if c < nq:
+            members = plan[8 + c * G: 8 + c * G + cnt]
+            assert np.array_equal(np.sort(members), np.nonzero(q == c)[0])
+            seen.append(members)
+    assert np.array_equal(np.sort(np.concatenate(seen)), np.arange(G))
+
+
+WIDE = [  # (C, mlp spec after the +3, M, N): RPN SA3 / SA4 scales (config.py:75-82) and a narrow odd one
+    (256, [128, 196, 256], 256, 1024), (512, [256, 256, 512], 64, 256), (512, [256, 384, 512], 64, 256), (40, [48, 72], 98, 300)]
+
+
+@pytest.mark.parametrize("C,spec,M,N", WIDE)
+@pytest.mark.parametrize("ns", [16, 32])
+@pytest.mark.parametrize("pattern", ["singletons", "full", "mixed", "sparse"])
+def test_listed_wide_kernel_is_bit_identical_to_the_dense_kernel(C, spec, M, N, ns, pattern):
+    """sa_mlp_wide_kernel: tiles of one class each (32 >> q groups, pool over 2^q rows) == one group (or two) per tile"""
+    from jmodt_amd.ops.pointnet2 import fused
+    from jmodt_amd.ops.pointnet2.pytorch_utils import SharedMLP
+    B = 4
+    torch.manual_seed(C + ns)
+    mlp = SharedMLP([C + 3] + spec, bn=True).to(DEV).eval()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for m in mlp.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    xyz = synth.dense_cloud(B, N, 7, extent=6.0)
+    idx, d = _lists(B, M, N, ns, pattern, 11)
+    new_xyz = np.take_along_axis(xyz, idx[:, :, :1].astype(np.int64).repeat(3, 2), 1) + np.float32(0.01)
+    feats = np.random.default_rng(5).normal(size=(B, C, N)).astype(np.float32)
+    args = (T(xyz), T(new_xyz), T(feats), T(idx), mlp)
+    assert fused.listed_kind(mlp, args[2], args[3], B, N) == 2
+    full = torch.zeros((B, spec[-1] + 8, M), device=DEV)
+    dense = fused.sa_mlp_fused(*args, listed=False)
+    listed = fused.sa_mlp_fused(*args, listed=True)
+    into = fused.sa_mlp_fused(*args, out=full[:, 3:3 + spec[-1]], listed=True)        # a channel slice of a wider tensor
+    assert torch.equal(listed, dense)
+    assert torch.equal(into, dense) and float(full[:, :3].abs().max()) == 0 and float(full[:, 3 + spec[-1]:].abs().max()) == 0
+    # the rows the listed form executed: 2^ceil(log2 d) per group, from the plan's class counts
+    plan = fused.ListedStats.last[-1][3].cpu().numpy()
+    rows = sum(int(plan[c]) << c for c in range(8))
+    assert rows <= 2 * int(d.sum()) + 4 and rows <= B * M * ns
+    if pattern == "singletons":
+        assert rows == B * M
+    if pattern == "full":
+        assert rows == B * M * ns
