@@ -24,15 +24,16 @@ int sa_mlp_wide_launch(int b, int n, int m, int c, int nsample, const float* xyz
                        const float* features, const int* idx, int L, const int* widths, const float* const* weights,
                        const float* const* biases, float* out, size_t obs, hipStream_t s, const int* cls_count, const int* glist);
 const char* sa_wide_unsupported(long long b, int n, int m, int c, int nsample, int group_all, int L, const int* widths);
+int sa_xyz_valu_launch(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* idx,
+                       const int* widths, const float* const* weights, const float* const* biases, float* out, size_t obs, hipStream_t s,
+                       const int* cls_count, const int* glist);
 
 // cls_count[0..7] zeroed by the caller (hipMemsetAsync in the entry); glist: (qfull + 1) x groups
 template <int NS>
 __global__ void __launch_bounds__(256)
 sg_plan_kernel(int groups, int qmin, const int* __restrict__ idx, int* __restrict__ cls_count, int* __restrict__ glist) {
-    __shared__ int lcnt[8], lbase[8];
-    const int tid = threadIdx.x;
-    if (tid < 8) lcnt[tid] = 0;
-    __syncthreads();
+    __shared__ int wcnt[4][8], lbase[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.x * 256 + tid;
     int q = -1, rank = 0;
     if (g < groups) {
@@ -50,12 +51,26 @@ sg_plan_kernel(int groups, int qmin, const int* __restrict__ idx, int* __restric
         }
         q = d <= 1 ? 0 : 32 - __clz(d - 1);                       // ceil(log2 d)
         q = max(q, qmin);
-        rank = atomicAdd(&lcnt[q], 1);
+    }
+    // rank within the workgroup in ascending group order (ballot prefix): a class list is then a sequence of ascending runs, so
+    // neighbouring rows of a consumer's tile are neighbouring centres (coalescing loads and stores); only the ORDER OF THE RUNS
+    // (one global atomic per workgroup and class) varies from run to run, which no output depends on
+    for (int c = 0; c < 8; ++c) {
+        const unsigned long long mask = __ballot(q == c);
+        if (q == c) rank = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[wave][c] = __popcll(mask);
     }
     __syncthreads();
-    if (tid < 8 && lcnt[tid] > 0) lbase[tid] = atomicAdd(&cls_count[tid], lcnt[tid]);
+    if (tid < 8) {
+        const int n = wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+        if (n > 0) lbase[tid] = atomicAdd(&cls_count[tid], n);
+    }
     __syncthreads();
-    if (q >= 0) glist[(size_t)q * groups + lbase[q] + rank] = g;
+    if (q >= 0) {
+        int off = lbase[q];
+        for (int w = 0; w < wave; ++w) off += wcnt[w][q];
+        glist[(size_t)q * groups + off + rank] = g;
+    }
 }
 
 }  // namespace jm
@@ -85,14 +100,15 @@ extern "C" int jm_sa_group_plan(int groups, int nsample, const int* idx, int qmi
     return check_launch("sa_group_plan");
 }
 
-/* which kernel takes the LISTED form of this scale: 0 none, 2 sa_mlp_wide_kernel (smallest class 2^0) */
+/* which kernel takes the LISTED form of this scale (the kernel jm_sa_mlp_forward_into runs on it, so that listed == dense bit
+ * for bit): 0 none, 2 sa_mlp_wide_kernel, 3 sa_xyz_valu_kernel (smallest class 2^0 = single rows for both) */
 extern "C" int jm_sa_mlp_listed_supported(int b, int n, int m, int c, int nsample, int num_layers, const int* widths) {
     if (b < 0 || n < 1 || m < 1 || c < 0 || num_layers < 1 || !widths || widths[0] != 3 + c) return 0;
-    if (jm_sa_mlp_supported(b, n, m, c, nsample, 0, num_layers, widths) == 2) return 2;
-    return 0;
+    const int kind = jm_sa_mlp_supported(b, n, m, c, nsample, 0, num_layers, widths);
+    return kind == 2 || kind == 3 ? kind : 0;
 }
 
-extern "C" int jm_sa_mlp_listed_qmin(int kind) { return kind == 2 ? 0 : -1; }
+extern "C" int jm_sa_mlp_listed_qmin(int kind) { return kind == 2 || kind == 3 ? 0 : -1; }
 
 /* jm_sa_mlp_forward_into on the groups of `plan` (jm_sa_group_plan of the same idx): bit-identical output */
 extern "C" int jm_sa_mlp_forward_listed(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
@@ -107,6 +123,9 @@ extern "C" int jm_sa_mlp_forward_listed(int b, int n, int m, int c, int nsample,
                "sa_mlp_listed: output frame stride below cout * npoint");
     const int kind = jm_sa_mlp_listed_supported(b, n, m, c, nsample, num_layers, widths);
     JM_REQUIRE(kind != 0, "sa_mlp_listed: no listed kernel for this shape");
+    if (kind == 3)
+        return sa_xyz_valu_launch(b, n, m, nsample, xyz, new_xyz, idx, widths, weights, biases, out, out_frame_stride,
+                                  (hipStream_t)stream, plan, plan + 8);
     return sa_mlp_wide_launch(b, n, m, c, nsample, xyz, new_xyz, features, idx, num_layers, widths, weights, biases, out,
                               out_frame_stride, (hipStream_t)stream, plan, plan + 8);
 }

@@ -33,6 +33,9 @@ struct SaXyzParams {
     const float *b0, *b1, *b2;     // biases, zero padded
     float* out;                    // (B, C3, M), frame stride obs
     size_t obs;
+    int groups;                    // LISTED: B * M
+    const int* cls_count;          // LISTED: [8] groups per class q (device memory, sg_plan_kernel)
+    const int* glist;              // LISTED: class q's group ids at glist[q * groups ...]
 };
 
 // max over the 16 lanes of each DPP row (result in every lane of the row) of FOUR values at once: the four independent
@@ -58,6 +61,22 @@ __device__ __forceinline__ void samples_max4(float& a, float& b, float& c, float
                      "s_nop 1"
                      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
+// LISTED: max over the aligned groups of 2^q lanes (q wave-uniform, <= log2 NS): the first q of the same five steps
+template <int NS>
+__device__ __forceinline__ void samples_max4_q(int q, float& a, float& b, float& c, float& d) {
+    if (q >= 1) asm volatile("s_nop 1\n\t" JM_DPP4("quad_perm:[1,0,3,2]") "s_nop 0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if (q >= 2) asm volatile("s_nop 1\n\t" JM_DPP4("quad_perm:[2,3,0,1]") "s_nop 0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if (q >= 3) asm volatile("s_nop 1\n\t" JM_DPP4("row_half_mirror") "s_nop 0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if (q >= 4) asm volatile("s_nop 1\n\t" JM_DPP4("row_mirror") "s_nop 0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if (NS == 32 && q >= 5)
+        asm volatile("s_nop 1\n\t"
+                     "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "v_max_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "v_max_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "v_max_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "s_nop 1"
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 #undef JM_DPP4
 
 // ROWS rows per lane (rows tid, tid + T, ...: other centres of the same workgroup) share every weight load: the weights are
@@ -65,27 +84,65 @@ __device__ __forceinline__ void samples_max4(float& a, float& b, float& c, float
 // them (0.225 ms); two rows halve that traffic per FMA (0.144 ms at 256 registers, two waves per SIMD).  Sharing the weights
 // in the last layer only (two thirds of the FMAs) with the first two layers row by row, to fit 128 registers and four waves
 // per SIMD: hipcc still wants 256 registers, and capped at 128 it spills 115 of them — 0.355 ms.
-template <int H1, int H2, int C3, int NS, int ROWS>
+// LISTED (round 4, sa_groups.hip): a workgroup pass = 1024 rows of ONE class q = 1024 >> q groups of 2^q rows each (the first
+// 2^q entries of the group's neighbour list: its distinct rows + back-fill), the maximum runs over the aligned 2^q lanes, and
+// every group's channels go to its own (frame, centre) position: bit-identical to the dense mode (a row's value depends on
+// its point and its centre only), persistent grid with the pass count read from the plan in device memory.
+template <int H1, int H2, int C3, int NS, int ROWS, bool LISTED>
 __global__ void __launch_bounds__(1024 / ROWS)
 sa_xyz_valu_kernel(SaXyzParams p) {
     constexpr int T = 1024 / ROWS, CPW = 1024 / NS;       // threads, centres per workgroup (1024 rows)
-    __shared__ __attribute__((aligned(16))) float tile[C3][CPW + 4];
+    constexpr int QF = NS == 32 ? 5 : 4, TW = LISTED ? 64 : CPW;
+    __shared__ __attribute__((aligned(16))) float tile[C3][TW + 4];
+    __shared__ int TS[10];
     const int tid = threadIdx.x, lane = tid & 63;
     const float* __restrict__ W0t = p.w0; const float* __restrict__ W1t = p.w1; const float* __restrict__ W2t = p.w2;
     const float* __restrict__ B0 = p.b0; const float* __restrict__ B1 = p.b1; const float* __restrict__ B2 = p.b2;
-
+    int total = 1;
+    if (LISTED) {
+        if (tid == 0) {
+            int acc_t = 0;
+            for (int c = 0; c <= QF; ++c) {
+                TS[c] = acc_t;
+                acc_t += (int)((((long long)p.cls_count[c] << c) + 1023) >> 10);
+            }
+            TS[QF + 1] = acc_t;
+        }
+        __syncthreads();
+        total = TS[QF + 1];
+    }
+  for (int pass = LISTED ? (int)blockIdx.x : 0; pass < total; pass += LISTED ? (int)gridDim.x : 1) {
+    int q = QF, slot0 = 0, cnt_q = 0;
+    if (LISTED) {
+        q = 0;
+        for (int c = 1; c <= QF; ++c)
+            if (pass >= TS[c]) q = c;                     // the last class whose first pass is <= pass (empty classes lose)
+        q = __builtin_amdgcn_readfirstlane(q);
+        slot0 = (pass - TS[q]) * (1024 >> q);
+        cnt_q = p.cls_count[q];
+    }
+    long long goff[ROWS];                                 // LISTED: this row's group's output offset (frame * obs + centre), -1: padding
     f32x2 din[ROWS][2];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-        const long long row = (long long)blockIdx.x * 1024 + r * T + tid;   // (frame, centre, sample) flattened; M * NS % 1024 == 0
-        const int per_frame = p.M * NS;
-        const int bi = (int)(row / per_frame), rr = (int)(row - (long long)bi * per_frame);
-        const int centre = rr / NS;
+        long long row;
+        int g;
+        if (LISTED) {
+            const int v = r * T + tid, slot = slot0 + (v >> q);
+            const bool ok = slot < cnt_q;
+            g = p.glist[(size_t)q * p.groups + (ok ? slot : slot0)];       // padding rows repeat the pass's first group
+            row = (long long)g * NS + (v & ((1 << q) - 1));
+            goff[r] = ok ? (long long)((size_t)(g / p.M) * p.obs + (size_t)(g % p.M)) : -1;
+        } else {
+            row = (long long)blockIdx.x * 1024 + r * T + tid;             // (frame, centre, sample) flattened; M * NS % 1024 == 0
+            g = (int)(row / NS);
+        }
+        const int bi = g / p.M;
         const int k = p.idx[row];
-        const float* q = p.xyz + ((size_t)bi * p.N + k) * 3;
-        const float* c = p.new_xyz + ((size_t)bi * p.M + centre) * 3;
-        din[r][0] = (f32x2){q[0] - c[0], q[1] - c[1]};
-        din[r][1] = (f32x2){q[2] - c[2], 0.f};
+        const float* qq = p.xyz + ((size_t)bi * p.N + k) * 3;
+        const float* c = p.new_xyz + (size_t)g * 3;
+        din[r][0] = (f32x2){qq[0] - c[0], qq[1] - c[1]};
+        din[r][1] = (f32x2){qq[2] - c[2], 0.f};
     }
 
     // One layer for a chunk of 16 output channels: acc[r][8] (pairs) += in[r][kk] * Wt[kk][n0 .. n0 + 15] over kk < KIN; the
@@ -136,7 +193,9 @@ sa_xyz_valu_kernel(SaXyzParams p) {
     }
     // last layer chunk by chunk: the 16 channels of a chunk are reduced over the centre's samples (max and ReLU commute:
     // pointnet2_modules.py:48-52 applies the ReLU first) and parked in the workgroup's (channel, centre) tile at once
-    const bool writer = NS == 16 ? (lane & 15) == 0 : (lane & 31) == 16;
+    // (the maximum over 2^q lanes is valid in every lane of the group up to 16 lanes, in the odd DPP rows for 32)
+    const bool writer = LISTED ? (q == 5 ? (lane & 31) == 16 : (lane & ((1 << q) - 1)) == 0)
+                               : (NS == 16 ? (lane & 15) == 0 : (lane & 31) == 16);
 #pragma unroll
     for (int ch = 0; ch < C3 / 16; ++ch) {
         f32x2 acc[ROWS][8];
@@ -150,25 +209,49 @@ sa_xyz_valu_kernel(SaXyzParams p) {
                               "+v"(acc[r][6]), "+v"(acc[r][7]));
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
-            const int cl = (r * T + tid) / NS;                         // centre within the workgroup
+            const int cl = LISTED ? (r * T + tid) >> q : (r * T + tid) / NS;     // centre (group) within the workgroup's pass
 #pragma unroll
             for (int n = 0; n < 8; n += 2) {                           // channels 2n .. 2n + 3 of the chunk
                 float v0 = acc[r][n].x, v1 = acc[r][n].y, v2 = acc[r][n + 1].x, v3 = acc[r][n + 1].y;
-                samples_max4<NS>(v0, v1, v2, v3);
-                if (writer) {
+                if (LISTED) samples_max4_q<NS>(q, v0, v1, v2, v3); else samples_max4<NS>(v0, v1, v2, v3);
+                if (LISTED && q < 4) {
+                    // 1024 >> q > 64 groups per pass: no tile; the >= 4 writer lanes of a 16-lane row hold groups that are
+                    // neighbours in the class list, which the plan fills in runs of ascending group ids (coalescing stores)
+                    if (writer && goff[r] >= 0) {
+                        float* o = p.out + (size_t)goff[r] + (size_t)(ch * 16 + 2 * n) * (size_t)p.M;
+                        o[0] = fmaxf(v0, 0.f); o[(size_t)p.M] = fmaxf(v1, 0.f);
+                        o[2 * (size_t)p.M] = fmaxf(v2, 0.f); o[3 * (size_t)p.M] = fmaxf(v3, 0.f);
+                    }
+                } else if (writer) {
                     tile[ch * 16 + 2 * n + 0][cl] = fmaxf(v0, 0.f); tile[ch * 16 + 2 * n + 1][cl] = fmaxf(v1, 0.f);
                     tile[ch * 16 + 2 * n + 2][cl] = fmaxf(v2, 0.f); tile[ch * 16 + 2 * n + 3][cl] = fmaxf(v3, 0.f);
                 }
             }
         }
     }
-    __syncthreads();
-    const long long crow0 = (long long)blockIdx.x * CPW;               // first (frame, centre) of the workgroup: one frame
-    const int ob = (int)(crow0 / p.M), om = (int)(crow0 - (long long)ob * p.M);      // (CPW divides M)
-    for (int e = tid; e < C3 * CPW; e += T) {
-        const int n = e / CPW, j = e - n * CPW;
-        p.out[(size_t)ob * p.obs + (size_t)n * p.M + om + j] = tile[n][j];
+    if (LISTED) {
+        if (q >= 4) {                                                  // 64 (q = 4) or 32 (q = 5) groups through the tile
+            __syncthreads();
+            const int gpt = 1024 >> q;
+            for (int e = tid; e < C3 * gpt; e += T) {
+                const int n = e / gpt, j = e - n * gpt;
+                if (slot0 + j < cnt_q) {
+                    const int g = p.glist[(size_t)q * p.groups + slot0 + j];
+                    p.out[(size_t)(g / p.M) * p.obs + (size_t)n * p.M + (size_t)(g % p.M)] = tile[n][j];
+                }
+            }
+            __syncthreads();                                           // the next pass reuses the tile
+        }
+    } else {
+        __syncthreads();
+        const long long crow0 = (long long)blockIdx.x * CPW;           // first (frame, centre) of the workgroup: one frame
+        const int ob = (int)(crow0 / p.M), om = (int)(crow0 - (long long)ob * p.M);      // (CPW divides M)
+        for (int e = tid; e < C3 * CPW; e += T) {
+            const int n = e / CPW, j = e - n * CPW;
+            p.out[(size_t)ob * p.obs + (size_t)n * p.M + om + j] = tile[n][j];
+        }
     }
+  }
 }
 
 // widths[1..3] of the two scales this file instantiates; anything else stays on the matrix-core kernels
@@ -180,7 +263,8 @@ bool sa_xyz_valu_supported(int m, int c, int nsample, int num_layers, const int*
 }
 
 int sa_xyz_valu_launch(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* idx,
-                       const int* widths, const float* const* weights, const float* const* biases, float* out, size_t obs, hipStream_t s) {
+                       const int* widths, const float* const* weights, const float* const* biases, float* out, size_t obs, hipStream_t s,
+                       const int* cls_count, const int* glist) {
     SaXyzParams p{};
     p.N = n; p.M = m; p.ns = nsample; p.xyz = xyz; p.new_xyz = new_xyz; p.idx = idx;
     // the k-major copies behind the MFMA layouts (sa_mlp_pack_kernel): Kp x Np floats in
@@ -193,8 +277,17 @@ int sa_xyz_valu_launch(int b, int n, int m, int nsample, const float* xyz, const
     const long long rows = (long long)b * m * nsample;
     JM_REQUIRE(rows / 1024 < (1LL << 31), "sa_xyz: too many rows");
     const dim3 grid((unsigned)(rows / 1024));
-    if (nsample == 16) hipLaunchKernelGGL((sa_xyz_valu_kernel<16, 16, 32, 16, 2>), grid, dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((sa_xyz_valu_kernel<32, 32, 64, 32, 2>), grid, dim3(512), 0, s, p);
+    if (cls_count) {
+        // listed: passes <= the dense count + one partial pass per class; persistent over at most two workgroups per CU
+        p.groups = b * m; p.cls_count = cls_count; p.glist = glist;
+        const long long bound = rows / 1024 + (nsample == 16 ? 5 : 6);
+        const dim3 lgrid((unsigned)(bound < 512 ? bound : 512));
+        if (nsample == 16) hipLaunchKernelGGL((sa_xyz_valu_kernel<16, 16, 32, 16, 2, true>), lgrid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((sa_xyz_valu_kernel<32, 32, 64, 32, 2, true>), lgrid, dim3(512), 0, s, p);
+        return check_launch("sa_xyz_valu (listed)");
+    }
+    if (nsample == 16) hipLaunchKernelGGL((sa_xyz_valu_kernel<16, 16, 32, 16, 2, false>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((sa_xyz_valu_kernel<32, 32, 64, 32, 2, false>), grid, dim3(512), 0, s, p);
     return check_launch("sa_xyz_valu");
 }
 

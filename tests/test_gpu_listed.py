@@ -98,3 +98,32 @@ def test_listed_wide_kernel_is_bit_identical_to_the_dense_kernel(C, spec, M, N, 
         assert rows == B * M
     if pattern == "full":
         assert rows == B * M * ns
+
+
+@pytest.mark.parametrize("spec,ns", [([16, 16, 32], 16), ([32, 32, 64], 32)])
+@pytest.mark.parametrize("pattern", ["singletons", "full", "mixed", "sparse"])
+def test_listed_xyz_kernel_is_bit_identical_to_the_dense_kernel(spec, ns, pattern):
+    """sa_xyz_valu_kernel (the xyz-only scales of the first RPN level, config.py:75-82): passes of 1024 rows of one class"""
+    from jmodt_amd.ops.pointnet2 import fused
+    from jmodt_amd.ops.pointnet2.pytorch_utils import SharedMLP
+    B, M, N = 3, 320, 2000
+    torch.manual_seed(ns)
+    mlp = SharedMLP([3] + spec, bn=True).to(DEV).eval()
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for m in mlp.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    xyz = synth.dense_cloud(B, N, 9, extent=3.0)
+    idx, d = _lists(B, M, N, ns, pattern, 13)
+    new_xyz = np.take_along_axis(xyz, idx[:, :, :1].astype(np.int64).repeat(3, 2), 1)
+    args = (T(xyz), T(new_xyz), None, T(idx), mlp)
+    assert fused.listed_kind(mlp, None, args[3], B, N) == 3
+    dense = fused.sa_mlp_fused(*args, listed=False)
+    listed = fused.sa_mlp_fused(*args, listed=True)
+    full = torch.zeros((B, spec[-1] + 5, M), device=DEV)
+    into = fused.sa_mlp_fused(*args, out=full[:, 2:2 + spec[-1]], listed=True)
+    assert torch.equal(listed, dense) and torch.equal(into, dense)
+    assert float(full[:, :2].abs().max()) == 0 and float(full[:, 2 + spec[-1]:].abs().max()) == 0
+    assert float(dense.abs().max()) > 0
