@@ -187,6 +187,15 @@ int jm_sa_mlp_forward_listed(int b, int n, int m, int c, int nsample, const floa
                              const float* const* weights, const float* const* biases, const int* plan, float* out,
                              size_t out_frame_stride, jm_stream_t stream);
 
+/* the pre-projected two-layer block (jm_sa_mlp_pm_forward_into) in the listed form: plan from jm_sa_group_plan with
+ * qmin = jm_sa_mlp_pm_listed_qmin() (= 2: sa_mlp_pm_kernel's accumulator layout pools four consecutive rows in a lane) */
+int jm_sa_mlp_pm_listed_qmin(void);
+int jm_sa_mlp_pm_listed_supported(int b, int n, int m, int c, int nsample, int hidden, int cout);
+int jm_sa_mlp_pm_forward_listed(int b, int n, int m, int c, int nsample, int hidden, int cout, const float* u_point_major,
+                                const float* w1x, const float* new_xyz, const int* idx, const float* w_hidden,
+                                const float* b_hidden, const float* w_out, const float* b_out, const int* plan, float* out,
+                                size_t out_frame_stride, jm_stream_t stream);
+
 /* ------------------------------------------------------------------ roipool3d_cuda -------- */
 
 /* forward / forward_slow (roipool3d/src/roipool3d.cpp:16-79, roipool3d_kernel.cu:31-237).

@@ -45,6 +45,9 @@ struct SaPmParams {
     int tiles_per_frame, total_tiles, xcd_frames;
     const int* total_dev;                  // non-null: the number of tiles is read from device memory (<= total_tiles; the
                                            // duplicate-compacted form of sa_dedupe.hip, whose row count is data dependent)
+    int groups, qfull;                     // LISTED (sa_groups.hip): B * M, log2(ns)
+    const int* cls_count;                  // LISTED: [8] groups per class q of 2^q rows, q >= PM_QMIN (device memory)
+    const int* glist;                      // LISTED: class q's group ids b * M + i at glist[q * groups ...]
 #ifdef JM_TOOLS_BUILD
     int dbg;                               // tools build (JM_PM_DBG): timing experiments, wrong results
     long long* trace;                      // tools build: shader-clock stamps of workgroup 0's first MFMA wave (tools/sa_trace.py)
@@ -352,6 +355,234 @@ sa_mlp_pm_kernel(SaPmParams p) {
     else pm_gather_role<4>(p, lds, tid - 512);
 }
 
+// =============================================================================== LISTED mode (round 4, sa_groups.hip)
+// ball_query back-fills a list of cnt < nsample hits with copies of its first hit (ball_query_gpu.cu:36-40) and the max-pool is
+// idempotent: a group of class q only needs its first 2^q rows (q >= PM_QMIN = 2: the accumulator layout pools four
+// consecutive rows inside a lane).  A 128-row tile holds 128 >> q groups of ONE class; its rows, the per-centre table and the
+// output positions go through the class list (group id -> frame, centre); the pool partials are kept per QUAD of rows
+// (32 quads x 2 .. 8 per group) instead of per 16-row half block.  The k-loops, their operand order and the bias / ReLU
+// epilogues are the dense kernel's (pm_ktiles), so a row's value — and therefore every output — is bit-identical.
+constexpr int PM_QMIN = 2;
+constexpr int PM_VT_L = 32 * 128;          // per-centre table: <= 32 centres x <= 128 channels
+constexpr int PM_P_L = 32 * PM_PW;         // max-pool partials: 32 row quads x PM_PW columns
+
+struct PmListedSchedule {
+    int ts[8], total, n_local, nwg;
+    __device__ PmListedSchedule(const SaPmParams& p) {
+        int acc_t = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            ts[c] = acc_t;
+            if (c >= PM_QMIN && c <= p.qfull) acc_t += (int)((((long long)p.cls_count[c] << c) + PM_BM - 1) / PM_BM);
+        }
+        total = acc_t; nwg = gridDim.x;
+        n_local = total > (int)blockIdx.x ? (total - (int)blockIdx.x + nwg - 1) / nwg : 0;
+    }
+    // tile i of this workgroup: class q, first slot of the class list, groups in the class
+    __device__ void tile(const SaPmParams& p, int i, int& q, int& slot0, int& cnt) const {
+        const int t = (int)blockIdx.x + i * nwg;
+        q = PM_QMIN;
+#pragma unroll
+        for (int c = PM_QMIN + 1; c < 8; ++c)
+            if (c <= p.qfull && t >= ts[c]) q = c;            // the last class that starts at or before t (empty classes lose)
+        int start = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c == q) start = ts[c];
+        slot0 = (t - start) * (PM_BM >> q);
+        cnt = p.cls_count[q];
+    }
+};
+
+__device__ __forceinline__ void pm_mfma_role_listed(const SaPmParams& p, float* lds, int tid) {
+    const PmListedSchedule sch(p);
+    if (sch.n_local == 0) return;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rb = wave >> 1, cb = wave & 1;
+    const int lr = lane & 31, lk = lane >> 5;
+    float* X0 = lds;
+    float* X1 = X0 + (size_t)PM_BM * p.S0;
+    float* VT = X1 + (size_t)PM_BM * p.S1;
+    float* P = VT + PM_VT_L;                                        // [32 quads][PM_PW]
+    float* B1 = P + PM_P_L;                                         // the hidden layer's bias (np1 floats)
+    float* B2 = B1 + p.np1;                                         // the last layer's bias (np2 floats)
+    const int C = p.C, cout = p.cout;
+    const int row = rb * 32 + lr;
+    const float* x0p = X0 + (size_t)row * p.S0 + lk * 8;
+    const float* x1p = X1 + (size_t)row * p.S1 + lk * 8;
+    const int nkt0 = C >> 4, nkt1 = p.nkt1;
+    const size_t st1 = (size_t)p.np1 * 16, st2 = (size_t)p.np2 * 16;
+    const size_t lane_w = (size_t)lr * 16 + lk * 8;
+    f32x16 acc[2];
+    for (int e = tid; e < p.np1; e += 512) B1[e] = p.b1[e];
+    for (int e = tid; e < p.np2; e += 512) B2[e] = p.b2[e];
+    const float* wp1 = p.W1 + (size_t)cb * 512 + lane_w;
+    const float* wp2 = p.W2 + (size_t)cb * 512 + lane_w;
+    const bool has_a = cb < p.nblk1, has_b = cb < p.nblk2;
+    const float* after_b = has_a ? wp1 : wp2;
+    float wpre[2][8];
+    {
+        const float* q0 = has_a ? wp1 : wp2;
+        const float4 a = *reinterpret_cast<const float4*>(q0), b = *reinterpret_cast<const float4*>(q0 + 4);
+        const float4 c = *reinterpret_cast<const float4*>(q0 + 1024), d = *reinterpret_cast<const float4*>(q0 + 1028);
+        wpre[0][0] = a.x; wpre[0][1] = a.y; wpre[0][2] = a.z; wpre[0][3] = a.w; wpre[0][4] = b.x; wpre[0][5] = b.y; wpre[0][6] = b.z; wpre[0][7] = b.w;
+        wpre[1][0] = c.x; wpre[1][1] = c.y; wpre[1][2] = c.z; wpre[1][3] = c.w; wpre[1][4] = d.x; wpre[1][5] = d.y; wpre[1][6] = d.z; wpre[1][7] = d.w;
+    }
+    lds_barrier();                                                  // B0
+    for (int it = 0; it < sch.n_local; ++it) {
+        int q, slot0, cnt;
+        sch.tile(p, it, q, slot0, cnt);
+        const float* vtp = VT + (size_t)(row >> q) * C + lk * 8;
+        // ---------------- hidden layer, transposed (as the dense role)
+        {
+            const int nb = (p.nblk1 - cb + 1) >> 1;
+            if (nb > 0) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float* bq = B1 + (cb + 2 * j) * 32 + 4 * lk;
+                    const bool own = j < nb;
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const float4 bv = own ? *reinterpret_cast<const float4*>(bq + 8 * rq) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        acc[j][4 * rq + 0] = bv.x; acc[j][4 * rq + 1] = bv.y; acc[j][4 * rq + 2] = bv.z; acc[j][4 * rq + 3] = bv.w;
+                    }
+                }
+                const float* nxt = has_b ? wp2 : wp1;
+                if (nb == 2) pm_ktiles<2, true>(x0p, vtp, nkt0, wp1, st1, acc, wpre, nxt);
+                else pm_ktiles<1, true>(x0p, vtp, nkt0, wp1, st1, acc, wpre, nxt);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (j < nb) {
+                        float* Y = X1 + (size_t)row * p.S1 + (cb + 2 * j) * 32 + 4 * lk;
+#pragma unroll
+                        for (int rq = 0; rq < 4; ++rq) {
+                            float4 v;
+                            v.x = fmaxf(acc[j][4 * rq + 0], 0.f); v.y = fmaxf(acc[j][4 * rq + 1], 0.f);
+                            v.z = fmaxf(acc[j][4 * rq + 2], 0.f); v.w = fmaxf(acc[j][4 * rq + 3], 0.f);
+                            *reinterpret_cast<float4*>(Y + 8 * rq) = v;
+                        }
+                    }
+                }
+            }
+        }
+        lds_barrier();                                              // B1
+        // ---------------- last layer: acc[j][4 rq + t] = row 8 rq + 4 lk + t of the block, channel 32 blk + lr
+        for (int b0 = cb; b0 < p.nblk2; b0 += 4) {
+            const int nb = b0 + 2 < p.nblk2 ? 2 : 1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            const float* wp = p.W2 + (size_t)b0 * 512 + lane_w;
+            const float* nxt = b0 + 4 < p.nblk2 ? wp + 2048 : after_b;
+            if (nb == 2) pm_ktiles<2, false>(x1p, nullptr, nkt1, wp, st2, acc, wpre, nxt);
+            else pm_ktiles<1, false>(x1p, nullptr, nkt1, wp, st2, acc, wpre, nxt);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j < nb) {
+                    const int col = (b0 + 2 * j) * 32 + lr;
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq)                  // rows 8 rq + 4 lk .. + 3 of the block = quad rb * 8 + 2 rq + lk
+                        P[(rb * 8 + 2 * rq + lk) * PM_PW + col] =
+                            fmaxf(fmaxf(acc[j][4 * rq], acc[j][4 * rq + 1]), fmaxf(acc[j][4 * rq + 2], acc[j][4 * rq + 3]));
+                }
+            }
+        }
+        lds_barrier();                                              // B2
+        // ---------------- max over each group's 2^q rows = 2^(q-2) quads, + bias, ReLU (both commute with max)
+        {
+            const int ncen = PM_BM >> q, qpg = 1 << (q - 2);
+            for (int e = tid; e < ncen * cout; e += 512) {
+                const int col = e / ncen, c = e - col * ncen;
+                if (slot0 + c < cnt) {
+                    const int g = p.glist[(size_t)q * p.groups + slot0 + c];
+                    const float* pp = P + (size_t)(c * qpg) * PM_PW + col;
+                    float t = pp[0];
+                    for (int h = 1; h < qpg; ++h) t = fmaxf(t, pp[(size_t)h * PM_PW]);
+                    p.out[(size_t)(g / p.M) * p.obs + (size_t)col * p.M + (size_t)(g % p.M)] = fmaxf(t + B2[col], 0.f);
+                }
+            }
+        }
+    }
+}
+
+template <int ROUNDS>
+__device__ __forceinline__ void pm_gather_role_listed(const SaPmParams& p, float* lds, int ltid) {
+    const PmListedSchedule sch(p);
+    if (sch.n_local == 0) return;
+    const int lane = ltid & 63;
+    const int gw = __builtin_amdgcn_readfirstlane(ltid >> 6);
+    float* X0 = lds;
+    float* VT = X0 + (size_t)PM_BM * p.S0 + (size_t)PM_BM * p.S1;
+    constexpr int chunks = 2 * ROUNDS;
+    constexpr int rpi = 64 / chunks;
+    const int C = p.C;
+    const int lrow = lane / chunks, piece = lane - lrow * chunks;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 g[ROUNDS];
+    auto issue = [&](int i) __attribute__((always_inline)) {
+        int q, slot0, cnt;
+        sch.tile(p, i, q, slot0, cnt);
+        const int* gl = p.glist + (size_t)q * p.groups;
+        const int mask = (1 << q) - 1;
+        const float* src[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int rr = gw * rpi + lrow + r * 4 * rpi;           // row of the tile
+            const int slot = slot0 + (rr >> q);
+            const int gi = gl[slot < cnt ? slot : slot0];           // padding rows repeat the tile's first group (never stored)
+            const int id = p.idx[(size_t)gi * p.ns + (rr & mask)];
+            src[r] = p.u + ((size_t)(gi / p.M) * p.N + id) * C + 4 * piece;
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) g[r] = *reinterpret_cast<const f32x4*>(src[r]);
+    };
+    auto store = [&]() __attribute__((always_inline)) {
+        float* q = X0 + (size_t)(gw * rpi + lrow) * p.S0 + 4 * piece;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) *reinterpret_cast<f32x4*>(q + (size_t)r * 4 * rpi * p.S0) = g[r];
+    };
+    auto write_table = [&](int i) __attribute__((always_inline)) {
+        int q, slot0, cnt;
+        sch.tile(p, i, q, slot0, cnt);
+        const int* gl = p.glist + (size_t)q * p.groups;
+        const int ncen = PM_BM >> q;
+        for (int e = ltid; e < ncen * C; e += 256) {
+            const int c = e / C, k = e - c * C;
+            const int gi = gl[slot0 + c < cnt ? slot0 + c : slot0];
+            const float* cp = p.new_xyz + (size_t)gi * 3;
+            const float* wv = p.w1x + (size_t)k * 4;
+            VT[e] = __builtin_fmaf(wv[2], cp[2], __builtin_fmaf(wv[1], cp[1], wv[0] * cp[0]));
+        }
+    };
+    issue(0);
+    write_table(0);
+    store();
+    lds_barrier();                                                  // B0
+    for (int it = 0; it < sch.n_local; ++it) {
+        const bool has_next = it + 1 < sch.n_local;
+        if (has_next) issue(it + 1);
+        lds_barrier();                                              // B1
+        if (has_next) { store(); write_table(it + 1); }
+        lds_barrier();                                              // B2
+    }
+}
+
+__global__ void __launch_bounds__(768)
+sa_mlp_pm_listed_kernel(SaPmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    if (tid < 512) pm_mfma_role_listed(p, lds, tid);
+    else if (p.C == 128) pm_gather_role_listed<16>(p, lds, tid - 512);
+    else if (p.C == 64) pm_gather_role_listed<8>(p, lds, tid - 512);
+    else pm_gather_role_listed<4>(p, lds, tid - 512);
+}
+
+static size_t sa_pm_listed_lds_bytes(int c, int h, int cout) {
+    return ((size_t)PM_BM * (c + 4) + (size_t)PM_BM * (pad_to(h, 32) + 4) + PM_VT_L + PM_P_L + pad_to(h, 128) + pad_to(cout, 128)) * sizeof(float);
+}
+
 static size_t sa_pm_lds_bytes(int c, int h) {
     return ((size_t)PM_BM * (c + 4) + (size_t)PM_BM * (pad_to(h, 32) + 4) + PM_VT + PM_P + pad_to(h, 128)) * sizeof(float);
 }
@@ -443,4 +674,48 @@ extern "C" int jm_sa_mlp_pm_forward_dyn(int n, int m, int c, int nsample, int hi
     JM_REQUIRE(tiles_dev, "sa_mlp_pm_dyn: null tile count");
     return sa_mlp_pm_launch(1, n, m, c, nsample, hidden, cout, u_point_major, w1x, new_xyz, idx, w_hidden, b_hidden, w_out, b_out, out,
                             0, tiles_dev, stream);
+}
+
+/* LISTED form (csrc/sa_groups.hip; jm_sa_group_plan with qmin = jm_sa_mlp_pm_listed_qmin() = 2): the same block on tiles of one
+ * class each, 2^q rows per group, outputs at the groups' own positions; bit-identical to jm_sa_mlp_pm_forward_into */
+extern "C" int jm_sa_mlp_pm_listed_qmin(void) { return PM_QMIN; }
+
+extern "C" int jm_sa_mlp_pm_listed_supported(int b, int n, int m, int c, int nsample, int hidden, int cout) {
+    if (!jm_sa_mlp_pm_supported(b, n, m, c, nsample, hidden, cout)) return 0;
+    if ((long long)b * m >= (1LL << 31) / 64) return 0;
+    return sa_pm_listed_lds_bytes(c, hidden, cout) <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int jm_sa_mlp_pm_forward_listed(int b, int n, int m, int c, int nsample, int hidden, int cout, const float* u_point_major,
+                                           const float* w1x, const float* new_xyz, const int* idx, const float* w_hidden,
+                                           const float* b_hidden, const float* w_out, const float* b_out, const int* plan, float* out,
+                                           size_t out_frame_stride, jm_stream_t stream) {
+    JM_REQUIRE(b >= 0 && m >= 0, "sa_mlp_pm_listed: bad sizes");
+    JM_REQUIRE(out_frame_stride == 0 || out_frame_stride >= (size_t)cout * (size_t)m, "sa_mlp_pm_listed: output frame stride below cout * npoint");
+    if (b == 0 || m == 0) return JM_OK;
+    JM_REQUIRE(jm_sa_mlp_pm_listed_supported(b, n, m, c, nsample, hidden, cout), "sa_mlp_pm_listed: unsupported shape");
+    JM_REQUIRE(u_point_major && w1x && new_xyz && idx && w_hidden && b_hidden && w_out && b_out && out && plan, "sa_mlp_pm_listed: null pointer");
+    JM_REQUIRE(((reinterpret_cast<uintptr_t>(u_point_major) | reinterpret_cast<uintptr_t>(w_hidden) | reinterpret_cast<uintptr_t>(w_out) |
+                 reinterpret_cast<uintptr_t>(b_hidden)) & 15u) == 0, "sa_mlp_pm_listed: 16-byte alignment");
+    SaPmParams p{};
+    p.N = n; p.M = m; p.C = c; p.ns = nsample;
+    p.u = u_point_major; p.new_xyz = new_xyz; p.idx = idx; p.w1x = w1x;
+    p.H = hidden; p.nblk1 = pad_to(hidden, 32) / 32; p.nkt1 = pad_to(hidden, 16) / 16;
+    p.cout = cout; p.nblk2 = pad_to(cout, 32) / 32;
+    p.np1 = pad_to(hidden, 128); p.np2 = pad_to(cout, 128);
+    p.W1 = w_hidden; p.W2 = w_out; p.b1 = b_hidden; p.b2 = b_out; p.out = out;
+    p.obs = out_frame_stride ? out_frame_stride : (size_t)cout * (size_t)m;
+    p.S0 = c + 4; p.S1 = pad_to(hidden, 32) + 4;
+    p.groups = b * m; p.qfull = nsample == 16 ? 4 : (nsample == 32 ? 5 : 6);
+    p.cls_count = plan; p.glist = plan + 8;
+    const size_t lds_bytes = sa_pm_listed_lds_bytes(c, hidden, cout);
+    (void)hipFuncSetAttribute((const void*)sa_mlp_pm_listed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+    // tiles <= the dense count + one partial tile per class; persistent, one workgroup per CU at most
+    const long long bound = (long long)b * m * nsample / PM_BM + (p.qfull - PM_QMIN + 1);
+    const int grid = (int)(bound < cus ? bound : cus);
+    hipLaunchKernelGGL(sa_mlp_pm_listed_kernel, dim3((unsigned)grid), dim3(768), lds_bytes, (hipStream_t)stream, p);
+    return check_launch("sa_mlp_pm (listed)");
 }

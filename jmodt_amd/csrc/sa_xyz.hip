@@ -96,8 +96,8 @@ sa_xyz_valu_kernel(SaXyzParams p) {
     __shared__ __attribute__((aligned(16))) float tile[C3][TW + 4];
     __shared__ int TS[10];
     const int tid = threadIdx.x, lane = tid & 63;
-    const float* __restrict__ W0t = p.w0; const float* __restrict__ W1t = p.w1; const float* __restrict__ W2t = p.w2;
-    const float* __restrict__ B0 = p.b0; const float* __restrict__ B1 = p.b1; const float* __restrict__ B2 = p.b2;
+    const float* W0t = p.w0; const float* W1t = p.w1; const float* W2t = p.w2;
+    const float* B0 = p.b0; const float* B1 = p.b1; const float* B2 = p.b2;
     int total = 1;
     if (LISTED) {
         if (tid == 0) {
@@ -114,6 +114,9 @@ sa_xyz_valu_kernel(SaXyzParams p) {
   for (int pass = LISTED ? (int)blockIdx.x : 0; pass < total; pass += LISTED ? (int)gridDim.x : 1) {
     int q = QF, slot0 = 0, cnt_q = 0;
     if (LISTED) {
+        // the weights are loop invariant: left alone, hipcc hoists their scalar loads out of the pass loop and then spills 254
+        // SGPRs through v_writelane inside it (+60 % on full lists); opaque pointers per pass keep the loads where they are used
+        asm volatile("" : "+s"(W0t), "+s"(W1t), "+s"(W2t), "+s"(B0), "+s"(B1), "+s"(B2));
         q = 0;
         for (int c = 1; c <= QF; ++c)
             if (pass >= TS[c]) q = c;                     // the last class whose first pass is <= pass (empty classes lose)

@@ -165,12 +165,27 @@ def _pm_layers(mlp: nn.Sequential, device, extra: dict):
     return extra["pm"]
 
 
-def _sa_mlp_pm(u_pm: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w1x: torch.Tensor, pm, out=None) -> torch.Tensor:
-    """u_pm (B, N, C) point-major -> (B, cout, M) through jm_sa_mlp_pm_forward"""
+def _sa_mlp_pm(u_pm: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w1x: torch.Tensor, pm, out=None, listed: bool = True) -> torch.Tensor:
+    """u_pm (B, N, C) point-major -> (B, cout, M) through jm_sa_mlp_pm_forward (or its listed form: same bits, the rows a group
+    of d distinct neighbours executes are 2^max(2, ceil(log2 d)) instead of nsample)"""
     wh, bh, wo, bo, hidden, cout = pm
     B, N, C = u_pm.shape
     M, ns = idx.shape[1], idx.shape[2]
     out, stride = _out_slot(out, B, cout, M, u_pm.device)
+    lib = L.load()
+    if listed and LISTED and lib.jm_sa_mlp_pm_listed_supported(B, N, M, C, ns, hidden, cout):
+        idx = idx.contiguous()
+        hoisted, prof._hoisted = prof._hoisted, 0            # (the caller's hoisted-layer note belongs to the MLP call, not the plan)
+        plan = group_plan(idx, int(lib.jm_sa_mlp_pm_listed_qmin()))
+        prof._hoisted = hoisted
+        L.check(lib.jm_sa_mlp_pm_forward_listed(B, N, M, C, ns, hidden, cout, L.dev(u_pm, _f32, "u"), L.dev(w1x, _f32, "w1x"),
+                                                L.dev(new_xyz.contiguous(), _f32, "new_xyz"), L.dev(idx, _i32, "idx"),
+                                                L.dev(wh, _f32, "w_hidden"), L.dev(bh, _f32, "b_hidden"), L.dev(wo, _f32, "w_out"),
+                                                L.dev(bo, _f32, "b_out"), L.dev(plan, _i32, "plan"), ctypes.c_void_p(out.data_ptr()),
+                                                stride, L.stream_ptr()), "sa_mlp_pm(listed)")
+        ListedStats.last.append((prof._key("sa_mlp_pm_forward_listed"), B * M * ns, ns, plan))
+        del ListedStats.last[:-16]
+        return out
     L.check(L.load().jm_sa_mlp_pm_forward_into(B, N, M, C, ns, hidden, cout, L.dev(u_pm, _f32, "u"), L.dev(w1x, _f32, "w1x"),
                                                L.dev(new_xyz.contiguous(), _f32, "new_xyz"), L.dev(idx, _i32, "idx"), L.dev(wh, _f32, "w_hidden"),
                                                L.dev(bh, _f32, "b_hidden"), L.dev(wo, _f32, "w_out"), L.dev(bo, _f32, "b_out"),
@@ -358,7 +373,7 @@ def hoistable_first_layer(mlp: nn.Sequential, npoint: int, nsample: int, device)
 
 
 @torch.no_grad()
-def _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp, out=None):
+def _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp, out=None, listed=True):
     """QueryAndGroup + SharedMLP + max-pool with the first layer hoisted in front of the gather: W1 [xyz_j - c_i | f_j] + b1
     = u_j - W1x c_i with u = W1 [xyz | f] + b1 per point (two small batched GEMMs accumulating into one tensor); the
     kernel forms relu(u_j - W1x c_i) while gathering and runs layers 2..L (jm_sa_mlp_forward_pre)"""
@@ -379,13 +394,13 @@ def _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp, out=None):
             u = st(feats, xyz, point_major=pm is not None)                            # (B, H1, N) or (B, N, H1), one launch
             if pm is not None:
                 prof.hoisted_flops(2 * B * M * ns * H1 * W1.shape[1])
-                return _sa_mlp_pm(u, new_xyz, idx, w1x, pm, out)
+                return _sa_mlp_pm(u, new_xyz, idx, w1x, pm, out, listed)
     if u is None:
         u = torch.baddbmm(b1[None, :, None], W1[:, 3:].expand(B, -1, -1), feats)
         u = u.baddbmm_(W1[:, :3].expand(B, -1, -1), xyz.transpose(1, 2))
         if pm is not None:
             prof.hoisted_flops(2 * B * M * ns * H1 * W1.shape[1])
-            return _sa_mlp_pm(u.transpose(1, 2).contiguous(), new_xyz, idx, w1x, pm, out)
+            return _sa_mlp_pm(u.transpose(1, 2).contiguous(), new_xyz, idx, w1x, pm, out, listed)
     widths = [H1] + [cout for _, _, cout, _ in packed]
     nl = len(packed)
     prof.hoisted_flops(2 * B * M * ns * H1 * W1.shape[1])     # the first layer's per-row work this form avoids
@@ -442,7 +457,7 @@ def sa_mlp_fused(xyz: torch.Tensor, new_xyz: Optional[torch.Tensor], features: O
     listed: take the duplicate-aware form where a kernel has one (same bits, fewer rows)"""
     lib = L.load()
     if idx is not None and _can_pre_project(mlp, features, idx, idx.shape[1], idx.shape[2]):
-        return _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp, out)
+        return _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp, out, listed)
     layers = _packed_layers(mlp, xyz.device)
     B, N, _ = xyz.shape
     M, ns = (idx.shape[1], idx.shape[2]) if idx is not None else (1, N)

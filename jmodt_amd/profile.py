@@ -148,6 +148,10 @@ ALGO: Dict[str, Callable] = {
     "jm_sa_mlp_pm_forward": lambda a: (
         4 * _i(a, 0) * (_i(a, 2) * _i(a, 4) * (_i(a, 3) + 1) + _i(a, 2) * _i(a, 6)),
         2 * _i(a, 0) * _i(a, 2) * _i(a, 4) * (_i(a, 3) * _i(a, 5) + _i(a, 5) * _i(a, 6)), {}),
+    "jm_sa_mlp_pm_forward_listed": lambda a: (
+        4 * _i(a, 0) * (_i(a, 2) * _i(a, 4) * (_i(a, 3) + 1) + _i(a, 2) * _i(a, 6)),
+        2 * _i(a, 0) * _i(a, 2) * _i(a, 4) * (_i(a, 3) * _i(a, 5) + _i(a, 5) * _i(a, 6)),
+        dict(flops_per_row=2 * (_i(a, 3) * _i(a, 5) + _i(a, 5) * _i(a, 6)), bytes_per_row=4 * (_i(a, 3) + 1), listed=True)),
     # duplicate-compacted form: the row count lives in device memory (bench.py multiplies by the rows it reads back)
     "jm_sa_mlp_pm_forward_dyn": lambda a: (0, 0, dict(flops_per_row=2 * (_i(a, 2) * _i(a, 4) + _i(a, 4) * _i(a, 5)),
                                                       bytes_per_row=4 * (_i(a, 2) + 1))),

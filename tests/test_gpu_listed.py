@@ -127,3 +127,41 @@ def test_listed_xyz_kernel_is_bit_identical_to_the_dense_kernel(spec, ns, patter
     assert torch.equal(listed, dense) and torch.equal(into, dense)
     assert float(full[:, :2].abs().max()) == 0 and float(full[:, 2 + spec[-1]:].abs().max()) == 0
     assert float(dense.abs().max()) > 0
+
+
+@pytest.mark.parametrize("C,spec,ns", [(96, [64, 64, 128], 16), (96, [64, 96, 128], 32), (29, [32, 48, 96], 16)])
+@pytest.mark.parametrize("pattern", ["singletons", "full", "mixed", "sparse"])
+def test_listed_pm_kernel_is_bit_identical_to_the_dense_kernel(C, spec, ns, pattern):
+    """sa_mlp_pm_kernel (pre-projected two-layer scales: RPN SA2, config.py:75-82): 128-row tiles of one class each, classes of
+    4 .. nsample rows (the accumulator layout pools four consecutive rows inside a lane), partial maxima per row quad"""
+    from jmodt_amd.ops.pointnet2 import fused
+    from jmodt_amd.ops.pointnet2.pytorch_utils import SharedMLP
+    B, M, N = 3, 264, 1024
+    torch.manual_seed(ns + C)
+    mlp = SharedMLP([C + 3] + spec, bn=True).to(DEV).eval()
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for m in mlp.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    xyz = synth.dense_cloud(B, N, 9, extent=3.0)
+    idx, d = _lists(B, M, N, ns, pattern, 17)
+    new_xyz = np.take_along_axis(xyz, idx[:, :, :1].astype(np.int64).repeat(3, 2), 1) + np.float32(0.02)
+    feats = np.random.default_rng(6).normal(size=(B, C, N)).astype(np.float32)
+    args = (T(xyz), T(new_xyz), T(feats), T(idx), mlp)
+    assert fused.pm_plan(mlp, DEV, B, N, M, ns) is not None
+    fused.ListedStats.last.clear()
+    dense = fused.sa_mlp_fused(*args, listed=False)
+    assert not fused.ListedStats.last
+    listed = fused.sa_mlp_fused(*args, listed=True)
+    assert fused.ListedStats.last and fused.ListedStats.last[-1][0].endswith("sa_mlp_pm_forward_listed")
+    full = torch.zeros((B, spec[-1] + 5, M), device=DEV)
+    into = fused.sa_mlp_fused(*args, out=full[:, 2:2 + spec[-1]], listed=True)
+    assert torch.equal(listed, dense) and torch.equal(into, dense)
+    assert float(full[:, :2].abs().max()) == 0 and float(full[:, 2 + spec[-1]:].abs().max()) == 0
+    plan = fused.ListedStats.last[-1][3].cpu().numpy()
+    rows = sum(int(plan[c]) << c for c in range(8))
+    assert plan[0] == 0 and plan[1] == 0 and rows <= B * M * ns
+    if pattern == "singletons":
+        assert rows == 4 * B * M
