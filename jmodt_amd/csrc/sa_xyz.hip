@@ -23,6 +23,17 @@
 namespace jm {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// LISTED: the weight tables through the CONSTANT address space.  The persistent pass loop puts the output stores of pass i in
+// front of the weight loads of pass i + 1; from the global address space hipcc then cannot prove the tables unclobbered and
+// fetches them with (uniform) VECTOR loads — 824 global_load_dwordx4 instead of scalar-cache loads into the FMA's SGPR
+// operand: + 55 % on full lists.  Constant-address-space loads at a uniform address are always scalar.
+typedef const float __attribute__((address_space(4))) * cptr4;
+__device__ __forceinline__ f32x4v ld4(const float* q) {
+    const float4 v = *reinterpret_cast<const float4*>(q);
+    return (f32x4v){v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ f32x4v ld4(cptr4 q) { return *(const f32x4v __attribute__((address_space(4)))*)q; }
 
 struct SaXyzParams {
     int N, M, ns;                  // points per frame, centres per frame, samples per centre (16 or 32)
@@ -96,8 +107,6 @@ sa_xyz_valu_kernel(SaXyzParams p) {
     __shared__ __attribute__((aligned(16))) float tile[C3][TW + 4];
     __shared__ int TS[10];
     const int tid = threadIdx.x, lane = tid & 63;
-    const float* W0t = p.w0; const float* W1t = p.w1; const float* W2t = p.w2;
-    const float* B0 = p.b0; const float* B1 = p.b1; const float* B2 = p.b2;
     int total = 1;
     if (LISTED) {
         if (tid == 0) {
@@ -112,11 +121,17 @@ sa_xyz_valu_kernel(SaXyzParams p) {
         total = TS[QF + 1];
     }
   for (int pass = LISTED ? (int)blockIdx.x : 0; pass < total; pass += LISTED ? (int)gridDim.x : 1) {
+    // LISTED: the weights are loop invariant — left alone, hipcc hoists their scalar loads out of the pass loop and then spills
+    // 254 SGPRs through v_writelane inside it (+60 % on full lists).  Pointers made opaque per pass keep the loads where they are
+    // used; they stay __restrict__ (without it the loads may alias the output stores and leave the scalar cache: + 55 %)
+    // (an opaque zero OFFSET, not an opaque pointer: that one would lose its address space and turn into flat vector loads)
+    int zero = 0;
+    if (LISTED) asm volatile("" : "+s"(zero));
+    using wptr = typename std::conditional<LISTED, cptr4, const float* __restrict__>::type;
+    const wptr W0t = (wptr)(p.w0 + zero), W1t = (wptr)(p.w1 + zero), W2t = (wptr)(p.w2 + zero);
+    const wptr B0 = (wptr)(p.b0 + zero), B1 = (wptr)(p.b1 + zero), B2 = (wptr)(p.b2 + zero);
     int q = QF, slot0 = 0, cnt_q = 0;
     if (LISTED) {
-        // the weights are loop invariant: left alone, hipcc hoists their scalar loads out of the pass loop and then spills 254
-        // SGPRs through v_writelane inside it (+60 % on full lists); opaque pointers per pass keep the loads where they are used
-        asm volatile("" : "+s"(W0t), "+s"(W1t), "+s"(W2t), "+s"(B0), "+s"(B1), "+s"(B2));
         q = 0;
         for (int c = 1; c <= QF; ++c)
             if (pass >= TS[c]) q = c;                     // the last class whose first pass is <= pass (empty classes lose)
@@ -150,8 +165,8 @@ sa_xyz_valu_kernel(SaXyzParams p) {
 
     // One layer for a chunk of 16 output channels: acc[r][8] (pairs) += in[r][kk] * Wt[kk][n0 .. n0 + 15] over kk < KIN; the
     // addresses are uniform, so the weights are scalar loads into SGPRs (the SGPR operand of v_pk_fma_f32)
-    auto chunk16 = [&](auto KIN_, auto IN_, const f32x2 (*in)[decltype(IN_)::value], bool relu_in, const float* Wt, int ldw,
-                       const float* bias, int n0, f32x2 (&acc)[ROWS][8]) __attribute__((always_inline)) {
+    auto chunk16 = [&](auto KIN_, auto IN_, const f32x2 (*in)[decltype(IN_)::value], bool relu_in, wptr Wt, int ldw,
+                       wptr bias, int n0, f32x2 (&acc)[ROWS][8]) __attribute__((always_inline)) {
         constexpr int KIN = decltype(KIN_)::value;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r)
@@ -159,9 +174,9 @@ sa_xyz_valu_kernel(SaXyzParams p) {
             for (int n = 0; n < 8; ++n) acc[r][n] = (f32x2){bias[n0 + 2 * n], bias[n0 + 2 * n + 1]};
 #pragma unroll
         for (int kk = 0; kk < KIN; ++kk) {
-            float4 wc[4];
+            f32x4v wc[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wc[j] = *reinterpret_cast<const float4*>(&Wt[kk * ldw + n0 + 4 * j]);
+            for (int j = 0; j < 4; ++j) wc[j] = ld4(Wt + (kk * ldw + n0 + 4 * j));
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
                 float a = (kk & 1) ? in[r][kk >> 1].y : in[r][kk >> 1].x;
@@ -169,8 +184,8 @@ sa_xyz_valu_kernel(SaXyzParams p) {
                 const f32x2 pp = {a, a};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[r][2 * j] = __builtin_elementwise_fma(pp, (f32x2){wc[j].x, wc[j].y}, acc[r][2 * j]);
-                    acc[r][2 * j + 1] = __builtin_elementwise_fma(pp, (f32x2){wc[j].z, wc[j].w}, acc[r][2 * j + 1]);
+                    acc[r][2 * j] = __builtin_elementwise_fma(pp, (f32x2){wc[j][0], wc[j][1]}, acc[r][2 * j]);
+                    acc[r][2 * j + 1] = __builtin_elementwise_fma(pp, (f32x2){wc[j][2], wc[j][3]}, acc[r][2 * j + 1]);
                 }
             }
         }

@@ -45,7 +45,9 @@ for name, C, specs, M, N in LEVELS:
             args = (T(xyz), T(new_xyz), feats, T(idx), mlp)
             kind = fused.listed_kind(mlp, feats, args[3], B, N)
             td = timeit(lambda: fused.sa_mlp_fused(*args, listed=False))
-            tl = timeit(lambda: fused.sa_mlp_fused(*args, listed=True)) if kind else float("nan")
+            fused.ListedStats.last.clear()
+            tl = timeit(lambda: fused.sa_mlp_fused(*args, listed=True))
+            kind = kind or ("pm" if fused.ListedStats.last else 0)
             same = torch.equal(fused.sa_mlp_fused(*args, listed=False), fused.sa_mlp_fused(*args, listed=True))
             tp = timeit(lambda: fused.group_plan(args[3], 0))
             print(f"{name} ns={ns:2d} {str(spec):<16} {pattern:<10} mean d {d.mean():5.2f}: dense {td:7.1f} us  listed {tl:7.1f} us "
