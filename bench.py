@@ -94,6 +94,19 @@ def rcnn_rows():
     return {name: {"rows_dense": int(dense), "rows_executed": int(cnt[1].item()) * 128} for name, dense, cnt in fused.DedupeStats.last}
 
 
+def listed_rows():
+    """{bench row: rows dense / executed} of the listed RPN scales of the LAST forward (class counts in device memory: call after a
+    synchronize)"""
+    from jmodt_amd.ops.pointnet2 import fused
+    out = {}
+    for name, dense, ns, plan in fused.ListedStats.last:
+        pl = plan[:8].tolist()
+        r = out.setdefault(name, {"rows_dense": 0, "rows_executed": 0})
+        r["rows_dense"] += int(dense)
+        r["rows_executed"] += sum(int(pl[c]) << c for c in range(8))
+    return out
+
+
 def detect_step(st):
     """one batch; the NEXT batch's cloud is announced so that its FPS pyramid runs under this batch's work (a
     streaming detector always knows its next batch; here it is the same resident synthetic batch).  Every step
@@ -668,6 +681,8 @@ def main():
     ap.add_argument("--cloud", default="uniform", choices=["uniform", "kitti", "packed"],
                     help="detect only: the synthetic cloud the whole line (value, kernel table) is measured on; the default line "
                          "always carries all three values under `clouds`")
+    ap.add_argument("--no-listed", action="store_true",
+                    help="RPN set-abstraction scales on the dense kernels (every back-filled row executed) instead of the listed form")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip everything that runs OTHER shapes after the timed region (the kitti / packed clouds, the dense-RCNN and "
                          "experimental variants): what the rocprofv3 passes use, so that every dispatch of a profile belongs to the "
@@ -737,6 +752,9 @@ def main():
 
     from jmodt_amd import _lib
     _lib.load()
+    if args.no_listed:
+        from jmodt_amd.ops.pointnet2 import fused as _fused
+        _fused.LISTED = False
 
     seed = 1234 + rank
     if args.workload == "detect":
@@ -934,6 +952,18 @@ def main():
                 k["evals_per_s"] = round(ev / (k["ms_per_step"] * 1e-3), 1)
                 if k.get("brute_force_evals_per_step"):
                     k["evals_vs_brute_force"] = round(ev / k["brute_force_evals_per_step"], 5)
+        # the listed RPN scales: rows executed = sum over classes of groups << q, read back from the plans of the last step
+        listed_now = listed_rows()
+        for rows in (kernels, timed_rows):
+            for k in rows:
+                ln = listed_now.get(k["kernel"])
+                if k.get("listed") and ln and k["ms_per_step"] > 0:
+                    k["rows_executed"], k["rows_dense"] = ln["rows_executed"], ln["rows_dense"]
+                    hoisted = k.get("algo_flops_per_step", 0) - k.get("executed_flops_per_step", k.get("algo_flops_per_step", 0))
+                    k["executed_flops_per_step"] = int(ln["rows_executed"] * k["flops_per_row"])
+                    k["executed_mfma_frac"] = round(k["executed_flops_per_step"] / (k["ms_per_step"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)
+                    k["note"] = ("listed form: algo_flops = the dense block (SURVEY.md §8d), executed = 2^ceil(log2 d) rows per group of d "
+                                 "distinct neighbours" + (", first layer hoisted" if hoisted else ""))
         # the compacted RCNN scales: executed rows were read back from the device after the timed region
         rows_now = (variants.get("clouds") or {}).get("uniform", {}).get("rcnn", {})
         for rows in (kernels, timed_rows):

@@ -165,3 +165,49 @@ def test_listed_pm_kernel_is_bit_identical_to_the_dense_kernel(C, spec, ns, patt
     assert plan[0] == 0 and plan[1] == 0 and rows <= B * M * ns
     if pattern == "singletons":
         assert rows == 4 * B * M
+
+
+@pytest.mark.parametrize("kind", ["uniform", "kitti", "packed"])
+def test_rpn_levels_listed_on_off_bit_identical_at_full_width(kind):
+    """the four set-abstraction levels of the BENCHMARKED backbone (DetectorConfig.survey(): 16384 -> 4096 -> 1024 -> 256 -> 64
+    centres, both scales per level, full widths) on the three synthetic clouds: the listed form (sa_xyz_valu / sa_mlp_pm /
+    sa_mlp_wide in listed mode) against the dense kernels, level by level on identical inputs, torch.equal; and the rows it
+    executed, from the plans' class counts (94-97 % of the dense rows are copies on the headline cloud, none on the packed one)"""
+    from jmodt_amd.detector import DetectorConfig
+    from jmodt_amd.ops.pointnet2 import fused, pointnet2_utils
+    from tests.test_gpu_detector import make_engine
+    eng = make_engine(seed=5, cfg=DetectorConfig.survey()).to(DEV).eval()
+    net = eng.rpn.backbone_net
+    xyz = T(synth.frames(2, 16384, 99, kind=kind)[0])
+    g = torch.Generator().manual_seed(3)
+    cur, feats = xyz, None
+    executed, dense_rows = 0, 0
+    kernels = []
+    with torch.no_grad():
+        for lv, sa in enumerate(net.SA_modules):
+            _, new_xyz = pointnet2_utils.farthest_point_sample_xyz(cur, sa.npoint)
+            fused.LISTED = False
+            try:
+                _, want, _ = sa(cur, feats, new_xyz=new_xyz)
+            finally:
+                fused.LISTED = True
+            fused.ListedStats.last.clear()
+            _, got, _ = sa(cur, feats, new_xyz=new_xyz)
+            assert torch.equal(got, want), (kind, lv)
+            assert len(fused.ListedStats.last) == 2, (kind, lv, fused.ListedStats.last)          # both scales took the listed form
+            for name, rows, ns, plan in fused.ListedStats.last:
+                pl = plan[:8].cpu().numpy()
+                assert int(pl.sum()) == cur.shape[0] * sa.npoint                                # every group in exactly one class
+                executed += sum(int(pl[c]) << c for c in range(8))
+                dense_rows += rows
+                kernels.append(name)
+            cur = new_xyz
+            feats = torch.relu(torch.randn(cur.shape[0], got.shape[1], cur.shape[1], generator=g)).to(DEV)   # the next level's input
+    assert [k.split("_forward")[0] for k in kernels] == ["sa_mlp", "sa_mlp", "sa_mlp_pm", "sa_mlp_pm", "sa_mlp", "sa_mlp", "sa_mlp", "sa_mlp"]
+    print(kind, "rows dense -> executed:", dense_rows, executed, round(executed / dense_rows, 4))
+    if kind == "uniform":
+        assert executed < 0.12 * dense_rows
+    elif kind == "kitti":
+        assert executed < 0.25 * dense_rows
+    else:
+        assert executed <= dense_rows
