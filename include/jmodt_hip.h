@@ -174,18 +174,22 @@ int jm_sa_mlp_forward_pre(int b, int n, int m, int c, int nsample, const float* 
  * device memory; jm_sa_mlp_forward_listed runs jm_sa_mlp_forward_into's kernel on tiles of one class each, pooling over 2^q
  * rows, and writes every group's output at its own position: bit-identical to jm_sa_mlp_forward_into (a row's value depends
  * on its point and centre only, max on neither order nor multiplicity), rows executed 2^q instead of nsample per group.
- * plan: jm_sa_group_plan_elems(groups, nsample) ints = [8 class counts | (log2 nsample + 1) x groups group ids]; no host
- * decision and no host sync anywhere: both launches are always issued.
+ * plan = cls_count (8 ints: groups per class) + glist (jm_sa_group_list_elems(groups, nsample) = (log2 nsample + 1) x groups
+ * ints: class q's group ids at glist[q * groups ...]), both in device memory; no host decision and no host sync anywhere: the
+ * plan and the consumer are always launched.  jm_sa_group_plan_dual plans the two scales of a multi-scale level (same centres,
+ * two neighbour lists) in one launch: cls_count = 16 ints, [0..7] scale 0, [8..15] scale 1.
  * jm_sa_mlp_listed_supported: 0 = no listed kernel for the shape, else the kernel (as jm_sa_mlp_supported) and
  * jm_sa_mlp_listed_qmin its smallest class. */
-size_t jm_sa_group_plan_elems(int groups, int nsample);
-int jm_sa_group_plan(int groups, int nsample, const int* idx, int qmin, int* plan, jm_stream_t stream);
+size_t jm_sa_group_list_elems(int groups, int nsample);
+int jm_sa_group_plan(int groups, int nsample, const int* idx, int qmin, int* cls_count, int* glist, jm_stream_t stream);
+int jm_sa_group_plan_dual(int groups, int nsample0, const int* idx0, int qmin0, int nsample1, const int* idx1, int qmin1,
+                          int* cls_count, int* glist0, int* glist1, jm_stream_t stream);
 int jm_sa_mlp_listed_supported(int b, int n, int m, int c, int nsample, int num_layers, const int* widths);
 int jm_sa_mlp_listed_qmin(int kind);
 int jm_sa_mlp_forward_listed(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                              const float* features, const int* idx, int num_layers, const int* widths,
-                             const float* const* weights, const float* const* biases, const int* plan, float* out,
-                             size_t out_frame_stride, jm_stream_t stream);
+                             const float* const* weights, const float* const* biases, const int* cls_count, const int* glist,
+                             float* out, size_t out_frame_stride, jm_stream_t stream);
 
 /* the pre-projected two-layer block (jm_sa_mlp_pm_forward_into) in the listed form: plan from jm_sa_group_plan with
  * qmin = jm_sa_mlp_pm_listed_qmin() (= 2: sa_mlp_pm_kernel's accumulator layout pools four consecutive rows in a lane) */
@@ -193,8 +197,8 @@ int jm_sa_mlp_pm_listed_qmin(void);
 int jm_sa_mlp_pm_listed_supported(int b, int n, int m, int c, int nsample, int hidden, int cout);
 int jm_sa_mlp_pm_forward_listed(int b, int n, int m, int c, int nsample, int hidden, int cout, const float* u_point_major,
                                 const float* w1x, const float* new_xyz, const int* idx, const float* w_hidden,
-                                const float* b_hidden, const float* w_out, const float* b_out, const int* plan, float* out,
-                                size_t out_frame_stride, jm_stream_t stream);
+                                const float* b_hidden, const float* w_out, const float* b_out, const int* cls_count,
+                                const int* glist, float* out, size_t out_frame_stride, jm_stream_t stream);
 
 /* ------------------------------------------------------------------ roipool3d_cuda -------- */
 

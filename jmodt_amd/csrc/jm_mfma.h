@@ -166,4 +166,55 @@ __device__ __forceinline__ void wide_ktiles(const float* __restrict__ A, int nkt
     if (kt < nkt) mm(ac, bc);
 }
 
+// The same product with the B operand (weights from L1 / L2) requested ST k-tiles ahead through a ring of ST + 1 register
+// stages (ST + 1 even, so the A double buffer keeps its parity across trips).  For the kernels that run ONE wave per SIMD
+// (sa_mlp_wide_kernel: its LDS tiles leave room for one workgroup per CU) nothing else hides the ~1 us L2 round trip of a
+// weight tile; one tile ahead covers the 8 .. 16 MFMAs of one k-tile only.  Same k order, same accumulation chain: same bits.
+template <int NOWN, int ST>
+__device__ __forceinline__ void wide_ktiles_deep(const float* __restrict__ A, int nkt, const float* __restrict__ bp,
+                                                 size_t kt_stride, int a_off, f32x16 (&acc)[2], size_t lda = SW_LD) {
+    static_assert((ST + 1) % 2 == 0, "ring size must be even");
+    float b[ST + 1][NOWN][8];
+    float a0[8], a1[8];
+    auto loadB = [&](float (&d)[NOWN][8], const float* q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NOWN; ++j) {
+            const float4 lo = *reinterpret_cast<const float4*>(q + j * 2048);
+            const float4 hi = *reinterpret_cast<const float4*>(q + j * 2048 + 4);
+            d[j][0] = lo.x; d[j][1] = lo.y; d[j][2] = lo.z; d[j][3] = lo.w;
+            d[j][4] = hi.x; d[j][5] = hi.y; d[j][6] = hi.z; d[j][7] = hi.w;
+        }
+    };
+    auto loadA = [&](float (&a)[8], int kt) __attribute__((always_inline)) {
+        const float* q = A + (size_t)kt * 16 * lda + a_off;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) a[kk] = q[(2 * kk) * lda];
+    };
+    auto mm = [&](const float (&a)[8], const float (&w)[NOWN][8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int j = 0; j < NOWN; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], w[j][kk], acc[j], 0, 0, 0);
+    };
+    const int last = nkt - 1;
+#pragma unroll
+    for (int s = 0; s < ST; ++s) loadB(b[s], bp + (size_t)(s < last ? s : last) * kt_stride);   // clamped: unconditional loads
+    loadA(a0, 0);
+    for (int kt0 = 0; kt0 < nkt; kt0 += ST + 1) {
+#pragma unroll
+        for (int s = 0; s <= ST; ++s) {
+            const int kt = kt0 + s;
+            if (kt < nkt) {                                           // wave-uniform
+                const int nb = kt + ST < last ? kt + ST : last, na = kt + 1 < last ? kt + 1 : last;
+                loadB(b[(s + ST) % (ST + 1)], bp + (size_t)nb * kt_stride);
+                if (s & 1) loadA(a0, na); else loadA(a1, na);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s & 1) mm(a1, b[s]); else mm(a0, b[s]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
 }  // namespace jm

@@ -29,26 +29,43 @@ int sa_xyz_valu_launch(int b, int n, int m, int nsample, const float* xyz, const
                        const int* cls_count, const int* glist);
 
 // cls_count[0..7] zeroed by the caller (hipMemsetAsync in the entry); glist: (qfull + 1) x groups
+struct SgPlan {                       // up to two problems over the same groups (the two scales of an MSG level): blockIdx.y
+    int ns[2], qmin[2];
+    const int* idx[2];
+    int* cls_count[2];
+    int* glist[2];
+};
+
+// d = 1 + the LAST slot that differs from the first: for a ball-query list that is its hit count; for any other list the
+// first d entries still contain every distinct entry, so the listed form is exact whatever wrote idx
 template <int NS>
+__device__ __forceinline__ int sg_rows_needed(const int* __restrict__ row_) {
+    const int4* row = reinterpret_cast<const int4*>(row_);
+    int d = 1, first = 0;
+#pragma unroll
+    for (int v = 0; v < NS / 4; ++v) {
+        const int4 e = row[v];
+        if (v == 0) first = e.x; else if (e.x != first) d = 4 * v + 1;
+        if (e.y != first) d = 4 * v + 2;
+        if (e.z != first) d = 4 * v + 3;
+        if (e.w != first) d = 4 * v + 4;
+    }
+    return d;
+}
+
 __global__ void __launch_bounds__(256)
-sg_plan_kernel(int groups, int qmin, const int* __restrict__ idx, int* __restrict__ cls_count, int* __restrict__ glist) {
+sg_plan_kernel(int groups, SgPlan pl) {
     __shared__ int wcnt[4][8], lbase[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.x * 256 + tid;
+    const int g = blockIdx.x * 256 + tid, y = blockIdx.y;
+    const int NS = pl.ns[y], qmin = pl.qmin[y];
+    const int* __restrict__ idx = pl.idx[y];
+    int* __restrict__ cls_count = pl.cls_count[y];
+    int* __restrict__ glist = pl.glist[y];
     int q = -1, rank = 0;
     if (g < groups) {
-        const int4* row = reinterpret_cast<const int4*>(idx + (size_t)g * NS);
-        // d = 1 + the LAST slot that differs from the first: for a ball-query list that is its hit count; for any other list
-        // the first d entries still contain every distinct entry, so the listed form is exact whatever wrote idx
-        int d = 1, first = 0;
-#pragma unroll
-        for (int v = 0; v < NS / 4; ++v) {
-            const int4 e = row[v];
-            if (v == 0) first = e.x; else if (e.x != first) d = 4 * v + 1;
-            if (e.y != first) d = 4 * v + 2;
-            if (e.z != first) d = 4 * v + 3;
-            if (e.w != first) d = 4 * v + 4;
-        }
+        const int* row = idx + (size_t)g * NS;
+        const int d = NS == 16 ? sg_rows_needed<16>(row) : (NS == 32 ? sg_rows_needed<32>(row) : sg_rows_needed<64>(row));
         q = d <= 1 ? 0 : 32 - __clz(d - 1);                       // ceil(log2 d)
         q = max(q, qmin);
     }
@@ -77,27 +94,49 @@ sg_plan_kernel(int groups, int qmin, const int* __restrict__ idx, int* __restric
 
 using namespace jm;
 
-extern "C" size_t jm_sa_group_plan_elems(int groups, int nsample) {
+static int sg_nq(int nsample) { return nsample == 16 ? 5 : (nsample == 32 ? 6 : 7); }
+
+/* ints of a class list: (log2 nsample + 1) x groups */
+extern "C" size_t jm_sa_group_list_elems(int groups, int nsample) {
     if (groups < 0 || (nsample != 16 && nsample != 32 && nsample != 64)) return 0;
-    const int nq = nsample == 16 ? 5 : (nsample == 32 ? 6 : 7);
-    return 8 + (size_t)nq * (size_t)groups;
+    return (size_t)sg_nq(nsample) * (size_t)groups;
 }
 
-/* plan[0..7] = groups per class q (rows per group 2^q), plan[8 + q * groups ...] = class q's group ids (b * npoint + i).
- * idx (groups, nsample) int32 as ball_query wrote it; qmin = the smallest class the consumer kernel tiles (0 = single rows). */
-extern "C" int jm_sa_group_plan(int groups, int nsample, const int* idx, int qmin, int* plan, jm_stream_t stream) {
+static int sg_check(int groups, int nsample, const int* idx, int qmin, const int* cls_count, const int* glist) {
     JM_REQUIRE(groups >= 0 && (nsample == 16 || nsample == 32 || nsample == 64), "sa_group_plan: nsample in {16, 32, 64}");
     JM_REQUIRE(qmin >= 0 && (1 << qmin) <= nsample, "sa_group_plan: smallest class 2^%d above nsample", qmin);
-    JM_REQUIRE(plan, "sa_group_plan: null plan");
+    JM_REQUIRE(cls_count && (glist || groups == 0), "sa_group_plan: null plan");
+    JM_REQUIRE(groups == 0 || (idx && (reinterpret_cast<uintptr_t>(idx) & 15u) == 0), "sa_group_plan: idx null or not 16-byte aligned");
+    return JM_OK;
+}
+
+/* cls_count[0..7] = groups per class q (rows per group 2^q), glist[q * groups ...] = class q's group ids (b * npoint + i).
+ * idx (groups, nsample) int32 as ball_query wrote it; qmin = the smallest class the consumer kernel tiles (0 = single rows). */
+extern "C" int jm_sa_group_plan(int groups, int nsample, const int* idx, int qmin, int* cls_count, int* glist, jm_stream_t stream) {
+    if (int rc = sg_check(groups, nsample, idx, qmin, cls_count, glist)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(plan, 0, 8 * sizeof(int), s) != hipSuccess) { set_error("sa_group_plan: memset failed"); return JM_ELAUNCH; }
+    if (hipMemsetAsync(cls_count, 0, 8 * sizeof(int), s) != hipSuccess) { set_error("sa_group_plan: memset failed"); return JM_ELAUNCH; }
     if (groups == 0) return JM_OK;
-    JM_REQUIRE(idx && (reinterpret_cast<uintptr_t>(idx) & 15u) == 0, "sa_group_plan: idx null or not 16-byte aligned");
-    const dim3 grid((unsigned)divup(groups, 256));
-    if (nsample == 16) hipLaunchKernelGGL(sg_plan_kernel<16>, grid, dim3(256), 0, s, groups, qmin, idx, plan, plan + 8);
-    else if (nsample == 32) hipLaunchKernelGGL(sg_plan_kernel<32>, grid, dim3(256), 0, s, groups, qmin, idx, plan, plan + 8);
-    else hipLaunchKernelGGL(sg_plan_kernel<64>, grid, dim3(256), 0, s, groups, qmin, idx, plan, plan + 8);
+    SgPlan pl{};
+    pl.ns[0] = nsample; pl.qmin[0] = qmin; pl.idx[0] = idx; pl.cls_count[0] = cls_count; pl.glist[0] = glist;
+    hipLaunchKernelGGL(sg_plan_kernel, dim3((unsigned)divup(groups, 256), 1), dim3(256), 0, s, groups, pl);
     return check_launch("sa_group_plan");
+}
+
+/* the two scales of one multi-scale level (same centres, two neighbour lists) in ONE launch: cls_count = 16 ints
+ * ([0..7] scale 0, [8..15] scale 1: one memset), glist0 / glist1 as above */
+extern "C" int jm_sa_group_plan_dual(int groups, int nsample0, const int* idx0, int qmin0, int nsample1, const int* idx1, int qmin1,
+                                     int* cls_count, int* glist0, int* glist1, jm_stream_t stream) {
+    if (int rc = sg_check(groups, nsample0, idx0, qmin0, cls_count, glist0)) return rc;
+    if (int rc = sg_check(groups, nsample1, idx1, qmin1, cls_count, glist1)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(cls_count, 0, 16 * sizeof(int), s) != hipSuccess) { set_error("sa_group_plan: memset failed"); return JM_ELAUNCH; }
+    if (groups == 0) return JM_OK;
+    SgPlan pl{};
+    pl.ns[0] = nsample0; pl.qmin[0] = qmin0; pl.idx[0] = idx0; pl.cls_count[0] = cls_count; pl.glist[0] = glist0;
+    pl.ns[1] = nsample1; pl.qmin[1] = qmin1; pl.idx[1] = idx1; pl.cls_count[1] = cls_count + 8; pl.glist[1] = glist1;
+    hipLaunchKernelGGL(sg_plan_kernel, dim3((unsigned)divup(groups, 256), 2), dim3(256), 0, s, groups, pl);
+    return check_launch("sa_group_plan_dual");
 }
 
 /* which kernel takes the LISTED form of this scale (the kernel jm_sa_mlp_forward_into runs on it, so that listed == dense bit
@@ -110,14 +149,14 @@ extern "C" int jm_sa_mlp_listed_supported(int b, int n, int m, int c, int nsampl
 
 extern "C" int jm_sa_mlp_listed_qmin(int kind) { return kind == 2 || kind == 3 ? 0 : -1; }
 
-/* jm_sa_mlp_forward_into on the groups of `plan` (jm_sa_group_plan of the same idx): bit-identical output */
+/* jm_sa_mlp_forward_into on the groups of a plan (jm_sa_group_plan of the same idx): bit-identical output */
 extern "C" int jm_sa_mlp_forward_listed(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                                         const float* features, const int* idx, int num_layers, const int* widths,
-                                        const float* const* weights, const float* const* biases, const int* plan, float* out,
-                                        size_t out_frame_stride, jm_stream_t stream) {
+                                        const float* const* weights, const float* const* biases, const int* cls_count,
+                                        const int* glist, float* out, size_t out_frame_stride, jm_stream_t stream) {
     JM_REQUIRE(b >= 0 && n >= 1 && m >= 0 && c >= 0, "sa_mlp_listed: bad sizes");
     if (b == 0 || m == 0) return JM_OK;
-    JM_REQUIRE(xyz && new_xyz && idx && out && widths && weights && biases && plan && (features || c == 0), "sa_mlp_listed: null pointer");
+    JM_REQUIRE(xyz && new_xyz && idx && out && widths && weights && biases && cls_count && glist && (features || c == 0), "sa_mlp_listed: null pointer");
     JM_REQUIRE(num_layers >= 1 && widths[0] == 3 + c, "sa_mlp_listed: widths[0] = %d != 3 + C = %d", widths[0], 3 + c);
     JM_REQUIRE(out_frame_stride == 0 || out_frame_stride >= (size_t)widths[num_layers] * (size_t)m,
                "sa_mlp_listed: output frame stride below cout * npoint");
@@ -125,7 +164,7 @@ extern "C" int jm_sa_mlp_forward_listed(int b, int n, int m, int c, int nsample,
     JM_REQUIRE(kind != 0, "sa_mlp_listed: no listed kernel for this shape");
     if (kind == 3)
         return sa_xyz_valu_launch(b, n, m, nsample, xyz, new_xyz, idx, widths, weights, biases, out, out_frame_stride,
-                                  (hipStream_t)stream, plan, plan + 8);
+                                  (hipStream_t)stream, cls_count, glist);
     return sa_mlp_wide_launch(b, n, m, c, nsample, xyz, new_xyz, features, idx, num_layers, widths, weights, biases, out,
-                              out_frame_stride, (hipStream_t)stream, plan, plan + 8);
+                              out_frame_stride, (hipStream_t)stream, cls_count, glist);
 }

@@ -688,13 +688,13 @@ extern "C" int jm_sa_mlp_pm_listed_supported(int b, int n, int m, int c, int nsa
 
 extern "C" int jm_sa_mlp_pm_forward_listed(int b, int n, int m, int c, int nsample, int hidden, int cout, const float* u_point_major,
                                            const float* w1x, const float* new_xyz, const int* idx, const float* w_hidden,
-                                           const float* b_hidden, const float* w_out, const float* b_out, const int* plan, float* out,
-                                           size_t out_frame_stride, jm_stream_t stream) {
+                                           const float* b_hidden, const float* w_out, const float* b_out, const int* cls_count,
+                                           const int* glist, float* out, size_t out_frame_stride, jm_stream_t stream) {
     JM_REQUIRE(b >= 0 && m >= 0, "sa_mlp_pm_listed: bad sizes");
     JM_REQUIRE(out_frame_stride == 0 || out_frame_stride >= (size_t)cout * (size_t)m, "sa_mlp_pm_listed: output frame stride below cout * npoint");
     if (b == 0 || m == 0) return JM_OK;
     JM_REQUIRE(jm_sa_mlp_pm_listed_supported(b, n, m, c, nsample, hidden, cout), "sa_mlp_pm_listed: unsupported shape");
-    JM_REQUIRE(u_point_major && w1x && new_xyz && idx && w_hidden && b_hidden && w_out && b_out && out && plan, "sa_mlp_pm_listed: null pointer");
+    JM_REQUIRE(u_point_major && w1x && new_xyz && idx && w_hidden && b_hidden && w_out && b_out && out && cls_count && glist, "sa_mlp_pm_listed: null pointer");
     JM_REQUIRE(((reinterpret_cast<uintptr_t>(u_point_major) | reinterpret_cast<uintptr_t>(w_hidden) | reinterpret_cast<uintptr_t>(w_out) |
                  reinterpret_cast<uintptr_t>(b_hidden)) & 15u) == 0, "sa_mlp_pm_listed: 16-byte alignment");
     SaPmParams p{};
@@ -707,7 +707,7 @@ extern "C" int jm_sa_mlp_pm_forward_listed(int b, int n, int m, int c, int nsamp
     p.obs = out_frame_stride ? out_frame_stride : (size_t)cout * (size_t)m;
     p.S0 = c + 4; p.S1 = pad_to(hidden, 32) + 4;
     p.groups = b * m; p.qfull = nsample == 16 ? 4 : (nsample == 32 ? 5 : 6);
-    p.cls_count = plan; p.glist = plan + 8;
+    p.cls_count = cls_count; p.glist = glist;
     const size_t lds_bytes = sa_pm_listed_lds_bytes(c, hidden, cout);
     (void)hipFuncSetAttribute((const void*)sa_mlp_pm_listed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     int dev = 0, cus = 256;

@@ -34,6 +34,10 @@ namespace jm {
 // (SW_BM = 32 rows per tile, SW_LD = 36: padded row stride of the k-major LDS tiles; wide_ktiles: jm_mfma.h)
 constexpr int SW_KC = 128;                       // first-layer channels per gather chunk
 constexpr int SW_XBUF = SW_KC * SW_LD;           // floats per input chunk buffer
+#ifndef JM_SW_ST
+#define JM_SW_ST 3
+#endif
+constexpr int SW_ST = JM_SW_ST;                  // weight k-tiles in flight ahead of the MFMAs (jm_mfma.h: wide_ktiles_deep)
 
 struct SaWideParams {
     int N, M, C, ns;
@@ -218,11 +222,11 @@ sa_mlp_wide_kernel(SaWideParams p) {
                 set_bias(acc[0], bias, cb);
                 if (j0 + 1 < nb) {
                     set_bias(acc[1], bias, cb + 4);
-                    wide_ktiles<2>(A, kp / 16, bp, st, a_off, acc);
+                    wide_ktiles_deep<2, SW_ST>(A, kp / 16, bp, st, a_off, acc);
                     if (final_layer) { store_out(acc[0], cb); store_out(acc[1], cb + 4); }
                     else { store_hidden(acc[0], H, cb); store_hidden(acc[1], H, cb + 4); }
                 } else {
-                    wide_ktiles<1>(A, kp / 16, bp, st, a_off, acc);
+                    wide_ktiles_deep<1, SW_ST>(A, kp / 16, bp, st, a_off, acc);
                     if (final_layer) store_out(acc[0], cb); else store_hidden(acc[0], H, cb);
                 }
             }
@@ -241,8 +245,8 @@ sa_mlp_wide_kernel(SaWideParams p) {
             if (more) issue(c + 1);                               // loads in flight under this chunk's MFMAs
             const int kc = min(SW_KC, K0 - c * SW_KC);            // multiple of 16
             const float* bp = W0 + ((size_t)c * (SW_KC / 16) * np0 + wave * 32 + lr) * 16 + lk * 8;
-            if (nb0 > 1) wide_ktiles<2>(X + (c & 1) * SW_XBUF, kc / 16, bp, (size_t)np0 * 16, a_off, acc0);
-            else wide_ktiles<1>(X + (c & 1) * SW_XBUF, kc / 16, bp, (size_t)np0 * 16, a_off, acc0);
+            if (nb0 > 1) wide_ktiles_deep<2, SW_ST>(X + (c & 1) * SW_XBUF, kc / 16, bp, (size_t)np0 * 16, a_off, acc0);
+            else wide_ktiles_deep<1, SW_ST>(X + (c & 1) * SW_XBUF, kc / 16, bp, (size_t)np0 * 16, a_off, acc0);
             if (more) { park(X + ((c + 1) & 1) * SW_XBUF); lds_barrier(); }
         }
         store_hidden(acc0[0], HA, wave);

@@ -165,7 +165,8 @@ def _pm_layers(mlp: nn.Sequential, device, extra: dict):
     return extra["pm"]
 
 
-def _sa_mlp_pm(u_pm: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w1x: torch.Tensor, pm, out=None, listed: bool = True) -> torch.Tensor:
+def _sa_mlp_pm(u_pm: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w1x: torch.Tensor, pm, out=None, listed: bool = True,
+               plan=None) -> torch.Tensor:
     """u_pm (B, N, C) point-major -> (B, cout, M) through jm_sa_mlp_pm_forward (or its listed form: same bits, the rows a group
     of d distinct neighbours executes are 2^max(2, ceil(log2 d)) instead of nsample)"""
     wh, bh, wo, bo, hidden, cout = pm
@@ -175,15 +176,17 @@ def _sa_mlp_pm(u_pm: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w1x
     lib = L.load()
     if listed and LISTED and lib.jm_sa_mlp_pm_listed_supported(B, N, M, C, ns, hidden, cout):
         idx = idx.contiguous()
-        hoisted, prof._hoisted = prof._hoisted, 0            # (the caller's hoisted-layer note belongs to the MLP call, not the plan)
-        plan = group_plan(idx, int(lib.jm_sa_mlp_pm_listed_qmin()))
-        prof._hoisted = hoisted
+        if plan is None:
+            hoisted, prof._hoisted = prof._hoisted, 0        # (the caller's hoisted-layer note belongs to the MLP call, not the plan)
+            plan = group_plan(idx, int(lib.jm_sa_mlp_pm_listed_qmin()))
+            prof._hoisted = hoisted
+        cnt, gl = plan
         L.check(lib.jm_sa_mlp_pm_forward_listed(B, N, M, C, ns, hidden, cout, L.dev(u_pm, _f32, "u"), L.dev(w1x, _f32, "w1x"),
                                                 L.dev(new_xyz.contiguous(), _f32, "new_xyz"), L.dev(idx, _i32, "idx"),
                                                 L.dev(wh, _f32, "w_hidden"), L.dev(bh, _f32, "b_hidden"), L.dev(wo, _f32, "w_out"),
-                                                L.dev(bo, _f32, "b_out"), L.dev(plan, _i32, "plan"), ctypes.c_void_p(out.data_ptr()),
-                                                stride, L.stream_ptr()), "sa_mlp_pm(listed)")
-        ListedStats.last.append((prof._key("sa_mlp_pm_forward_listed"), B * M * ns, ns, plan))
+                                                L.dev(bo, _f32, "b_out"), ctypes.c_void_p(cnt.data_ptr()), ctypes.c_void_p(gl.data_ptr()),
+                                                ctypes.c_void_p(out.data_ptr()), stride, L.stream_ptr()), "sa_mlp_pm(listed)")
+        ListedStats.last.append((prof._key("sa_mlp_pm_forward_listed"), B * M * ns, ns, cnt))
         del ListedStats.last[:-16]
         return out
     L.check(L.load().jm_sa_mlp_pm_forward_into(B, N, M, C, ns, hidden, cout, L.dev(u_pm, _f32, "u"), L.dev(w1x, _f32, "w1x"),
@@ -373,7 +376,7 @@ def hoistable_first_layer(mlp: nn.Sequential, npoint: int, nsample: int, device)
 
 
 @torch.no_grad()
-def _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp, out=None, listed=True):
+def _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp, out=None, listed=True, plan=None):
     """QueryAndGroup + SharedMLP + max-pool with the first layer hoisted in front of the gather: W1 [xyz_j - c_i | f_j] + b1
     = u_j - W1x c_i with u = W1 [xyz | f] + b1 per point (two small batched GEMMs accumulating into one tensor); the
     kernel forms relu(u_j - W1x c_i) while gathering and runs layers 2..L (jm_sa_mlp_forward_pre)"""
@@ -394,13 +397,13 @@ def _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp, out=None, listed=True):
             u = st(feats, xyz, point_major=pm is not None)                            # (B, H1, N) or (B, N, H1), one launch
             if pm is not None:
                 prof.hoisted_flops(2 * B * M * ns * H1 * W1.shape[1])
-                return _sa_mlp_pm(u, new_xyz, idx, w1x, pm, out, listed)
+                return _sa_mlp_pm(u, new_xyz, idx, w1x, pm, out, listed, plan)
     if u is None:
         u = torch.baddbmm(b1[None, :, None], W1[:, 3:].expand(B, -1, -1), feats)
         u = u.baddbmm_(W1[:, :3].expand(B, -1, -1), xyz.transpose(1, 2))
         if pm is not None:
             prof.hoisted_flops(2 * B * M * ns * H1 * W1.shape[1])
-            return _sa_mlp_pm(u.transpose(1, 2).contiguous(), new_xyz, idx, w1x, pm, out, listed)
+            return _sa_mlp_pm(u.transpose(1, 2).contiguous(), new_xyz, idx, w1x, pm, out, listed, plan)
     widths = [H1] + [cout for _, _, cout, _ in packed]
     nl = len(packed)
     prof.hoisted_flops(2 * B * M * ns * H1 * W1.shape[1])     # the first layer's per-row work this form avoids
@@ -434,13 +437,48 @@ def listed_kind(mlp: nn.Sequential, features, idx: torch.Tensor, B: int, N: int)
 
 
 @torch.no_grad()
-def group_plan(idx: torch.Tensor, qmin: int = 0) -> torch.Tensor:
-    """idx (B, M, ns) int32 neighbour lists -> the listed form's plan (int32: 8 class counts + per-class group ids)"""
+def group_plan(idx: torch.Tensor, qmin: int = 0):
+    """idx (B, M, ns) int32 neighbour lists -> the listed form's plan (cls_count (8,) int32 = groups per class of 2^q rows,
+    glist = the classes' group ids), both in device memory"""
     lib = L.load()
     B, M, ns = idx.shape
-    plan = torch.empty((int(lib.jm_sa_group_plan_elems(B * M, ns)),), dtype=_i32, device=idx.device)
-    L.check(lib.jm_sa_group_plan(B * M, ns, L.dev(idx, _i32, "idx"), int(qmin), L.dev(plan, _i32, "plan"), L.stream_ptr()), "sa_group_plan")
-    return plan
+    buf = torch.empty((8 + int(lib.jm_sa_group_list_elems(B * M, ns)),), dtype=_i32, device=idx.device)
+    cnt, gl = buf[:8], buf[8:]
+    L.check(lib.jm_sa_group_plan(B * M, ns, L.dev(idx, _i32, "idx"), int(qmin), ctypes.c_void_p(cnt.data_ptr()),
+                                 ctypes.c_void_p(gl.data_ptr()), L.stream_ptr()), "sa_group_plan")
+    return cnt, gl
+
+
+@torch.no_grad()
+def group_plan_dual(idx0: torch.Tensor, qmin0: int, idx1: torch.Tensor, qmin1: int):
+    """the plans of the two scales of a multi-scale level (same centres) from ONE launch: ((cnt0, glist0), (cnt1, glist1))"""
+    lib = L.load()
+    B, M, ns0 = idx0.shape
+    ns1 = idx1.shape[2]
+    assert idx1.shape[:2] == (B, M)
+    n0, n1 = int(lib.jm_sa_group_list_elems(B * M, ns0)), int(lib.jm_sa_group_list_elems(B * M, ns1))
+    buf = torch.empty((16 + n0 + n1,), dtype=_i32, device=idx0.device)
+    gl0, gl1 = buf[16:16 + n0], buf[16 + n0:]
+    L.check(lib.jm_sa_group_plan_dual(B * M, ns0, L.dev(idx0, _i32, "idx0"), int(qmin0), ns1, L.dev(idx1, _i32, "idx1"), int(qmin1),
+                                      ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(gl0.data_ptr()), ctypes.c_void_p(gl1.data_ptr()),
+                                      L.stream_ptr()), "sa_group_plan_dual")
+    return (buf[:8], gl0), (buf[8:16], gl1)
+
+
+def listed_qmin(mlp: nn.Sequential, features, idx: torch.Tensor, B: int, N: int) -> int:
+    """the smallest class (log2 rows) of the kernel that will take this scale in the listed form, -1 when none will"""
+    if not LISTED or idx is None or features is not None and not features.is_cuda:
+        return -1
+    lib = L.load()
+    M, ns = idx.shape[1], idx.shape[2]
+    if _can_pre_project(mlp, features, idx, M, ns):
+        pm = pm_plan(mlp, idx.device, B, N, M, ns)
+        if pm is None:
+            return -1
+        W1 = _pre_layers(mlp, idx.device)[0]
+        return int(lib.jm_sa_mlp_pm_listed_qmin()) if lib.jm_sa_mlp_pm_listed_supported(B, N, M, W1.shape[0], ns, pm[4], pm[5]) else -1
+    kind = listed_kind(mlp, features, idx, B, N)
+    return int(lib.jm_sa_mlp_listed_qmin(kind)) if kind else -1
 
 
 class ListedStats:
@@ -450,14 +488,16 @@ class ListedStats:
 
 @torch.no_grad()
 def sa_mlp_fused(xyz: torch.Tensor, new_xyz: Optional[torch.Tensor], features: Optional[torch.Tensor],
-                 idx: Optional[torch.Tensor], mlp: nn.Sequential, out: Optional[torch.Tensor] = None, listed: bool = True) -> torch.Tensor:
+                 idx: Optional[torch.Tensor], mlp: nn.Sequential, out: Optional[torch.Tensor] = None, listed: bool = True,
+                 plan=None) -> torch.Tensor:
     """xyz (B,N,3), new_xyz (B,M,3), features (B,C,N) or None, idx (B,M,ns) int32 -> (B, mlp_out, M);
     idx = new_xyz = None: GroupAll (one group of all N points per frame, xyz not re-centred) -> (B, mlp_out, 1).
     out: optional (B, mlp_out, M) view to write into — a channel slice of a wider tensor (the MSG concatenation in place).
-    listed: take the duplicate-aware form where a kernel has one (same bits, fewer rows)"""
+    listed: take the duplicate-aware form where a kernel has one (same bits, fewer rows); plan: its (cls_count, glist) when the
+    caller planned already (group_plan_dual for the two scales of a level, with this scale's listed_qmin)"""
     lib = L.load()
     if idx is not None and _can_pre_project(mlp, features, idx, idx.shape[1], idx.shape[2]):
-        return _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp, out, listed)
+        return _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp, out, listed, plan)
     layers = _packed_layers(mlp, xyz.device)
     B, N, _ = xyz.shape
     M, ns = (idx.shape[1], idx.shape[2]) if idx is not None else (1, N)
@@ -474,12 +514,12 @@ def sa_mlp_fused(xyz: torch.Tensor, new_xyz: Optional[torch.Tensor], features: O
     kind = listed_kind(mlp, features, idx, B, N) if listed else 0
     if kind:
         idx = idx.contiguous()
-        plan = group_plan(idx, int(lib.jm_sa_mlp_listed_qmin(kind)))
+        cnt, gl = plan if plan is not None else group_plan(idx, int(lib.jm_sa_mlp_listed_qmin(kind)))
         L.check(lib.jm_sa_mlp_forward_listed(B, N, M, C, ns, L.dev(xyz.contiguous(), _f32, "xyz"), L.dev(new_xyz.contiguous(), _f32, "new_xyz"),
                                              L.dev(feats, _f32, "features") if feats is not None else None, L.dev(idx, _i32, "idx"),
-                                             nl, widths_c, warr, barr, L.dev(plan, _i32, "plan"), ctypes.c_void_p(out.data_ptr()), stride,
-                                             L.stream_ptr()), "sa_mlp_fused(listed)")
-        ListedStats.last.append((prof._key("sa_mlp_forward_listed"), B * M * ns, ns, plan))
+                                             nl, widths_c, warr, barr, ctypes.c_void_p(cnt.data_ptr()), ctypes.c_void_p(gl.data_ptr()),
+                                             ctypes.c_void_p(out.data_ptr()), stride, L.stream_ptr()), "sa_mlp_fused(listed)")
+        ListedStats.last.append((prof._key("sa_mlp_forward_listed"), B * M * ns, ns, cnt))
         del ListedStats.last[:-16]
         return out
     L.check(lib.jm_sa_mlp_forward_into(B, N, M, C, ns, L.dev(xyz.contiguous(), _f32, "xyz"),

@@ -57,6 +57,17 @@ class _PointnetSAModuleBase(nn.Module):
             g0, g1 = self.groupers
             neigh = list(pointnet2_utils.ball_query_dual(g0.radius, g0.nsample, g1.radius, g1.nsample, xyz, new_xyz, grid=grid))
 
+        # duplicate-aware form (csrc/sa_groups.hip): the two scales' group plans from ONE launch where both take it
+        plans = [None] * len(self.groupers)
+        if (len(self.groupers) == 2 and neigh[0] is not None and self.fuse and self.pool_method == "max_pool" and xyz.is_cuda
+                and not torch.is_grad_enabled() and not self.training and all(g.use_xyz for g in self.groupers)):
+            qm = [fused.listed_qmin(m, features, nb, xyz.shape[0], xyz.shape[1])
+                  if fused.can_fuse(m, new_xyz.shape[1], g.nsample, self.training, xyz.shape[0], xyz.shape[1]) else -1
+                  for m, g, nb in zip(self.mlps, self.groupers, neigh)]
+            if min(qm) >= 0:
+                neigh = [nb.contiguous() for nb in neigh]
+                plans = list(fused.group_plan_dual(neigh[0], qm[0], neigh[1], qm[1]))
+
         pooled = []
         # multi-scale grouping: the fused scales write straight into their channel slice of the concatenated result
         # (pointnet2_modules.py:54 of the reference: torch.cat(new_features_list, dim=1) — here no copy)
@@ -64,7 +75,7 @@ class _PointnetSAModuleBase(nn.Module):
         if (len(self.groupers) > 1 and new_xyz is not None and xyz.is_cuda and not torch.is_grad_enabled()):
             full = torch.empty((xyz.shape[0], sum(fused.out_width(m) for m in self.mlps), new_xyz.shape[1]),
                                dtype=torch.float32, device=xyz.device)
-        for grouper, mlp, nb in zip(self.groupers, self.mlps, neigh):
+        for grouper, mlp, nb, plan in zip(self.groupers, self.mlps, neigh, plans):
             slot = None
             if full is not None:
                 w = fused.out_width(mlp)
@@ -76,7 +87,7 @@ class _PointnetSAModuleBase(nn.Module):
                 # eval / no-grad: group + MLP + max-pool in one fp32-MFMA kernel, nothing materialised
                 if nb is None:
                     nb = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
-                pooled.append(fused.sa_mlp_fused(xyz, new_xyz, features, nb, mlp, out=slot))
+                pooled.append(fused.sa_mlp_fused(xyz, new_xyz, features, nb, mlp, out=slot, plan=plan))
                 continue
             if (eligible and isinstance(grouper, pointnet2_utils.GroupAll)
                     and fused.can_fuse(mlp, 1, xyz.shape[1], self.training, xyz.shape[0], xyz.shape[1], group_all=True)):

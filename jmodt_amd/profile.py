@@ -314,7 +314,7 @@ class LibProxy:
             return hit
         fn = getattr(object.__getattribute__(self, "_cdll"), sym)
         if (not sym.startswith("jm_") or sym.endswith("_bytes") or sym.endswith("_elems") or sym.endswith("_supported")
-                or sym.endswith("_offset") or sym.endswith("_capacity")) or sym in (
+                or sym.endswith("_offset") or sym.endswith("_capacity") or sym.endswith("_qmin")) or sym in (
                 "jm_version", "jm_last_error", "jm_sa_mlp_pack", "jm_image_fusion_pack", "jm_pts_in_boxes3d_cpu", "jm_roipool3d_cpu"):
             cache[sym] = fn
             return fn

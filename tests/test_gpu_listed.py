@@ -40,7 +40,8 @@ def test_group_plan_bins_every_group_once_into_its_class(ns, qmin):
     from jmodt_amd.ops.pointnet2.fused import group_plan
     B, M, N = 3, 700, 900
     idx, _ = _lists(B, M, N, ns, "mixed", 3)
-    plan = group_plan(T(idx), qmin).cpu().numpy()
+    cnt_t, gl_t = group_plan(T(idx), qmin)
+    plan = torch.cat([cnt_t, gl_t]).cpu().numpy()
     G = B * M
     flat = idx.reshape(G, ns)
     need = np.array([1 + max([s for s in range(ns) if row[s] != row[0]], default=0) for row in flat])
@@ -93,7 +94,7 @@ def test_listed_wide_kernel_is_bit_identical_to_the_dense_kernel(C, spec, M, N, 
     # the rows the listed form executed: 2^ceil(log2 d) per group, from the plan's class counts
     plan = fused.ListedStats.last[-1][3].cpu().numpy()
     rows = sum(int(plan[c]) << c for c in range(8))
-    assert rows <= 2 * int(d.sum()) + 4 and rows <= B * M * ns
+    assert rows <= 2 * int(d.sum()) + 4 and rows <= B * M * ns and int(plan.sum()) == B * M
     if pattern == "singletons":
         assert rows == B * M
     if pattern == "full":
@@ -211,3 +212,19 @@ def test_rpn_levels_listed_on_off_bit_identical_at_full_width(kind):
         assert executed < 0.25 * dense_rows
     else:
         assert executed <= dense_rows
+
+
+def test_group_plan_dual_equals_two_single_plans():
+    """the two scales of a level planned by one launch: the same class counts and the same class members as two single plans"""
+    from jmodt_amd.ops.pointnet2.fused import group_plan, group_plan_dual
+    B, M, N = 2, 900, 1200
+    i0, _ = _lists(B, M, N, 16, "sparse", 1)
+    i1, _ = _lists(B, M, N, 32, "mixed", 2)
+    (c0, g0), (c1, g1) = group_plan_dual(T(i0), 0, T(i1), 2)
+    for (c, g), (idx, q, ns) in zip(((c0, g0), (c1, g1)), ((i0, 0, 16), (i1, 2, 32))):
+        cs, gs = group_plan(T(idx), q)
+        assert torch.equal(c, cs)
+        G = B * M
+        for k in range(int(np.log2(ns)) + 1):
+            n = int(c[k])
+            assert torch.equal(torch.sort(g[k * G:k * G + n])[0], torch.sort(gs[k * G:k * G + n])[0])
