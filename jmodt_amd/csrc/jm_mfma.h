@@ -166,15 +166,16 @@ __device__ __forceinline__ void wide_ktiles(const float* __restrict__ A, int nkt
     if (kt < nkt) mm(ac, bc);
 }
 
-// The same product with the B operand (weights from L1 / L2) requested ST k-tiles ahead through a ring of ST + 1 register
-// stages (ST + 1 even, so the A double buffer keeps its parity across trips).  For the kernels that run ONE wave per SIMD
-// (sa_mlp_wide_kernel: its LDS tiles leave room for one workgroup per CU) nothing else hides the ~1 us L2 round trip of a
-// weight tile; one tile ahead covers the 8 .. 16 MFMAs of one k-tile only.  Same k order, same accumulation chain: same bits.
-template <int NOWN, int ST>
+// The same product with the B operand (weights from L1 / L2) requested a whole GROUP of GK k-tiles ahead: two register sets of
+// GK stages, the loads of group g + 1 issued in front of the MFMAs of group g, no branch inside a group (with wave-uniform
+// branches around single k-tiles hipcc's s_waitcnt placement falls back to vmcnt(0) and the prefetch is lost).  For the kernels
+// that run ONE wave per SIMD (sa_mlp_wide_kernel: its LDS tiles leave room for one workgroup per CU) nothing else hides the
+// ~1 us L2 round trip of a weight tile; one k-tile ahead covers the 8 .. 16 MFMAs of one k-tile only.  The nkt % GK last
+// k-tiles run one ahead.  Same k order, same accumulation chain as wide_ktiles: same bits.
+template <int NOWN, int GK>
 __device__ __forceinline__ void wide_ktiles_deep(const float* __restrict__ A, int nkt, const float* __restrict__ bp,
                                                  size_t kt_stride, int a_off, f32x16 (&acc)[2], size_t lda = SW_LD) {
-    static_assert((ST + 1) % 2 == 0, "ring size must be even");
-    float b[ST + 1][NOWN][8];
+    float b0[GK][NOWN][8], b1[GK][NOWN][8];
     float a0[8], a1[8];
     auto loadB = [&](float (&d)[NOWN][8], const float* q) __attribute__((always_inline)) {
 #pragma unroll
@@ -184,6 +185,10 @@ __device__ __forceinline__ void wide_ktiles_deep(const float* __restrict__ A, in
             d[j][0] = lo.x; d[j][1] = lo.y; d[j][2] = lo.z; d[j][3] = lo.w;
             d[j][4] = hi.x; d[j][5] = hi.y; d[j][6] = hi.z; d[j][7] = hi.w;
         }
+    };
+    auto loadG = [&](float (&d)[GK][NOWN][8], int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < GK; ++s) loadB(d[s], bp + (size_t)(g * GK + s) * kt_stride);
     };
     auto loadA = [&](float (&a)[8], int kt) __attribute__((always_inline)) {
         const float* q = A + (size_t)kt * 16 * lda + a_off;
@@ -197,22 +202,56 @@ __device__ __forceinline__ void wide_ktiles_deep(const float* __restrict__ A, in
             for (int j = 0; j < NOWN; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], w[j][kk], acc[j], 0, 0, 0);
     };
-    const int last = nkt - 1;
+    // the MFMAs of group g (k-tiles g GK ..), the A operand one k-tile ahead (LDS: short latency); GK even: a0 holds the first
+    auto group = [&](const float (&w)[GK][NOWN][8], int g, int nxt) __attribute__((always_inline)) {
 #pragma unroll
-    for (int s = 0; s < ST; ++s) loadB(b[s], bp + (size_t)(s < last ? s : last) * kt_stride);   // clamped: unconditional loads
-    loadA(a0, 0);
-    for (int kt0 = 0; kt0 < nkt; kt0 += ST + 1) {
+        for (int s = 0; s < GK; s += 2) {
+            loadA(a1, g * GK + s + 1);
+            mm(a0, w[s]);
+            loadA(a0, s + 2 < GK ? g * GK + s + 2 : nxt);
+            mm(a1, w[s + 1]);
+        }
+    };
+    static_assert(GK % 2 == 0, "even group size");
+    const int ngrp = nkt / GK, last = nkt - 1;
+    if (ngrp > 0) {
+        loadG(b0, 0);
+        loadA(a0, 0);
+        int g = 0;
+        for (; g + 2 <= ngrp; g += 2) {
+            loadG(b1, g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            group(b0, g, (g + 1) * GK);
+            __builtin_amdgcn_sched_barrier(0);
+            loadG(b0, g + 2 < ngrp ? g + 2 : g + 1);              // clamped: an unconditional (redundant at the end) load
+            __builtin_amdgcn_sched_barrier(0);
+            const int after = (g + 2) * GK;
+            group(b1, g + 1, after < last ? after : last);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (g < ngrp) {                                            // odd count: b0 holds the last group
+            const int after = (g + 1) * GK;
+            group(b0, g, after < last ? after : last);
+        }
+    }
+    // the remaining nkt % GK k-tiles, one ahead
+    int kt = ngrp * GK;
+    if (kt < nkt) {
+        loadB(b0[0], bp + (size_t)kt * kt_stride);
+        loadA(a0, kt);
+        for (; kt < nkt; ++kt) {
+            const int nx = kt + 1 < nkt ? kt + 1 : kt;
+            loadB(b1[0], bp + (size_t)nx * kt_stride);
+            loadA(a1, nx);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(a0, b0[0]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s <= ST; ++s) {
-            const int kt = kt0 + s;
-            if (kt < nkt) {                                           // wave-uniform
-                const int nb = kt + ST < last ? kt + ST : last, na = kt + 1 < last ? kt + 1 : last;
-                loadB(b[(s + ST) % (ST + 1)], bp + (size_t)nb * kt_stride);
-                if (s & 1) loadA(a0, na); else loadA(a1, na);
-                __builtin_amdgcn_sched_barrier(0);
-                if (s & 1) mm(a1, b[s]); else mm(a0, b[s]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int j = 0; j < NOWN; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b0[0][j][e] = b1[0][j][e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a0[e] = a1[e];
         }
     }
 }

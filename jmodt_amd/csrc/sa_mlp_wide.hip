@@ -35,9 +35,9 @@ namespace jm {
 constexpr int SW_KC = 128;                       // first-layer channels per gather chunk
 constexpr int SW_XBUF = SW_KC * SW_LD;           // floats per input chunk buffer
 #ifndef JM_SW_ST
-#define JM_SW_ST 3
+#define JM_SW_ST 4
 #endif
-constexpr int SW_ST = JM_SW_ST;                  // weight k-tiles in flight ahead of the MFMAs (jm_mfma.h: wide_ktiles_deep)
+constexpr int SW_ST = JM_SW_ST;                  // weight k-tiles requested per group, one group ahead of the MFMAs (jm_mfma.h: wide_ktiles_deep)
 
 struct SaWideParams {
     int N, M, C, ns;
