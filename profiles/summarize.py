@@ -69,7 +69,7 @@ def _shape_cols(cols):
     return pick("grid"), pick("workgroup", "block", "wg")
 
 
-def shape_table(cur, cols, name_col, top=70):
+def shape_table(cur, cols, name_col, top=160):
     grid, wg = _shape_cols(cols)
     if not grid or not wg:
         return f"(no grid / workgroup columns in the kernels view: {cols})"
@@ -108,8 +108,12 @@ def pmc(db_path, out_path=None):
     if grid and wg:
         key = ", ".join([kcol[0]] + grid + wg + [ccol[0]])
         rows = cur.execute(f"select {key}, count(*), avg({vcol[0]}), min({vcol[0]}), max({vcol[0]}) from counters_collection "
-                           f"group by {key} order by avg({vcol[0]}) desc limit 60").fetchall()
-        lines += ["", "per dispatch shape (top 60 by counter average)",
+                           f"group by {key} order by avg({vcol[0]}) desc").fetchall()
+        # every shape of the hand-written (jm::) kernels — profiles/make_traffic.py attributes counters per (kernel, grid,
+        # workgroup) — and the 40 largest library shapes
+        lib_rows = [r for r in rows if "jm::" not in r[0]][:40]
+        rows = [r for r in rows if "jm::" in r[0]] + lib_rows
+        lines += ["", "per dispatch shape (every jm:: shape, then the 40 largest library shapes, by counter average)",
                   f"{'kernel':<56} {'grid':>18} {'wg':>12} {'counter':<14} {'dispatches':>10} {'avg':>16} {'min':>16} {'max':>16}"]
         for r in rows:
             gs = "x".join(str(v) for v in r[1:4] if v not in (1, None)) or "1"
