@@ -637,7 +637,7 @@ def rocprof_average(kernel_row):
     needles = ROCPROF_NEEDLE.get(kernel_row)
     if not needles:
         return None
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_detect_kernel_stats.txt")
         try:
             lines = open(path).read().splitlines()
@@ -928,7 +928,7 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 --pmc passes (collected separately, as the guide
         # prescribes; bench.py itself runs un-profiled)
         tj = None
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04",):          # (older files attributed by kernel NAME over mixed workloads: not used any more)
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")))
                 break
@@ -936,8 +936,11 @@ def main():
                 continue
         if tj:
             for k in kernels:
-                if k["kernel"] in tj:
-                    k["traffic_bytes_per_launch"] = tj[k["kernel"]]["bytes"]
+                if k["kernel"] in tj and k["ms_per_step"] > 0:
+                    per_launch_s = k["ms_per_step"] / max(k["launches_per_step"], 1) * 1e-3
+                    if tj[k["kernel"]]["bytes"] / per_launch_s <= HBM_PEAK_GBS * 1e9:     # (a rate above the peak = not this dispatch)
+                        k["traffic_bytes_per_launch"] = tj[k["kernel"]]["bytes"]
+                        k["traffic_gbs"] = round(tj[k["kernel"]]["bytes"] / per_launch_s / 1e9, 1)
         ms_step = elapsed / args.steps * 1e3
         # the hash-grid ball queries: evaluations actually done (per step) next to the n * m of the scan they replace
         for k in kernels:

@@ -296,6 +296,44 @@ nms_mask_kernel(int nmax, const int* __restrict__ counts, int stride_cb, float t
     }
 }
 
+// The same mask at LANE granularity (round 4), for the small problems whose time is latency: the detections' rotated NMS is 8
+// frames x <= 128 boxes = 24 tiles, and the tile kernel above gives each of its 64 threads a row to walk through 64
+// polygon clips one after the other (0.32 ms for 131 k pairs).  Here a WAVE owns one mask word: (row, column block), lane l
+// evaluates the pair (row, 64 cb + l) — the same make_rbox / rbox_iou (iou_normal) call with the row box first, so the
+// predicate is bit for bit the tile kernel's — and the word is the wave's ballot.  Same words written (upper triangle incl.
+// the diagonal block), n * ceil(n / 64) waves per problem; the tile kernel stays for large n, where preparing a column
+// block's 64 boxes once per tile instead of once per row is the cheaper way (launch_nms_mask picks).
+template <bool NORMAL>
+__global__ void __launch_bounds__(256)
+nms_mask_lane_kernel(int nmax, const int* __restrict__ counts, int stride_cb, float thresh,
+                     const float* __restrict__ boxes_all, unsigned long long* __restrict__ mask_all) {
+    const int prob = blockIdx.y;
+    const int n = counts ? min(counts[prob], nmax) : nmax;
+    const float* boxes = boxes_all + (size_t)prob * nmax * 5;
+    unsigned long long* mask = mask_all + (size_t)prob * nmax * stride_cb;
+    const int col_blocks = (nmax + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const int unit = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int row = unit / col_blocks, cb = unit - row * col_blocks;
+    if (row >= n || cb * 64 >= n || cb < (row >> 6)) return;       // padding, or below the diagonal block (never read)
+    const int col = cb * 64 + lane;
+    const bool valid = col < n && col > row;
+    const float* rb5 = boxes + (size_t)row * 5;
+    const float* cb5 = boxes + (size_t)min(col, n - 1) * 5;        // clamped: every lane evaluates a real pair
+    bool hit;
+    if (NORMAL) {
+        const float a[5] = {rb5[0], rb5[1], rb5[2], rb5[3], rb5[4]};
+        const float b[5] = {cb5[0], cb5[1], cb5[2], cb5[3], cb5[4]};
+        hit = iou_normal(a, b) > thresh;
+    } else {
+        const RBox me = make_rbox(rb5);
+        const RBox other = make_rbox(cb5);
+        hit = rbox_iou(me, other) > thresh;
+    }
+    const unsigned long long word = __ballot(valid && hit);
+    if (lane == 0) mask[(size_t)row * stride_cb + cb] = word;
+}
+
 // ------------------------------------------------------------------ NMS greedy reduce (device)
 // Single workgroup of 1024 threads.  remv (col_blocks x u64) lives in LDS.  Semantics of
 // iou3d.cpp:98-114: ascending i, keep i if its bit is not set in remv, then
@@ -311,6 +349,7 @@ nms_mask_kernel(int nmax, const int* __restrict__ counts, int stride_cb, float t
 //    barriers are raw s_barrier + lgkmcnt(0) so those global loads stay in flight across them
 //    (a __syncthreads() would drain vmcnt).
 //  * selected words are OR-ed in registers and merged with LDS atomics (ds_or_b64).
+constexpr int NMS_LANE_MAX = 1024;   // up to here the pair mask is built one pair per lane (nms_mask_lane_kernel)
 constexpr int NMS_RT = 512;   // 4 row groups x 128 columns; 256-VGPR budget holds the 4-deep prefetch ring
 
 __global__ void __launch_bounds__(NMS_RT)
@@ -609,6 +648,14 @@ static int launch_nms_mask(int nprob, int nmax, const int* counts, const float* 
     const long long cb = (nmax + 63) / 64;
     const long long tiles = cb * (cb + 1) / 2;
     JM_REQUIRE(tiles < (1LL << 31) && nprob <= 65535, "nms_mask: too many boxes / problems");
+    if (nmax <= NMS_LANE_MAX) {                                    // latency-bound sizes: one pair per lane
+        const dim3 lgrid((unsigned)divup((long long)nmax * cb, 4), (unsigned)nprob);
+        if (normal)
+            hipLaunchKernelGGL(nms_mask_lane_kernel<true>, lgrid, dim3(256), 0, s, nmax, counts, (int)cb, thresh, boxes, mask);
+        else
+            hipLaunchKernelGGL(nms_mask_lane_kernel<false>, lgrid, dim3(256), 0, s, nmax, counts, (int)cb, thresh, boxes, mask);
+        return check_launch("nms_mask (lane)");
+    }
     dim3 grid((unsigned)tiles, (unsigned)nprob);
     if (normal)
         hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(64), 0, s, nmax, counts, (int)cb, thresh, boxes, mask);

@@ -289,6 +289,7 @@ class DetectAffinityEngine(nn.Module):
                                            # mode, scoped to those calls): 6.03 vs 6.34 ms over the seven 3x3 convolutions
                                            # (tools/miopen_find_probe.py); costs 1-3 s per new shape, once per process
         self.fuse_small_heads = True       # RCNN cls / reg heads: one MFMA launch per dense layer
+        self.fuse_head_stacks = True       # ... or, where conv1d_stack takes the shape, one launch per HEAD
         self.fuse_rcnn_lift = True         # xyz_up + merge_down (+ hoisted first SA layer) as one kernel
         self.fuse_attention = True         # LI-Fusion attention block as one kernel where it fits (else rocBLAS GEMMs)
         self.affinity_split_bf16 = False   # EXPERIMENTAL (csrc/affinity_x3.hip): link-head products as 3-term bf16 splits
@@ -800,10 +801,40 @@ class DetectAffinityEngine(nn.Module):
         """classification / regression heads on the RoI features (rcnn.py:186-200).  Only the detections consume them — the
         affinity head takes the features themselves — so `forward` runs them on the detections' side stream"""
         net = self.rcnn_net
-        rcnn_cls, rcnn_reg = self._t("rcnn_heads(span)", 0, lambda: (
-            self._head_forward("rcnn_cls", net.cls_layer, l_feats).squeeze(-1),
-            self._head_forward("rcnn_reg", net.reg_layer, l_feats).squeeze(-1)))
+
+        def heads():
+            st = self._rcnn_head_stacks(l_feats)
+            if st is not None:
+                # ONE launch per head (csrc/conv1d_stack.hip: the three dense layers chained on-chip on 32-RoI tiles) on the
+                # transposed rows, shared by both heads; outputs point-major = the (R, C) rows the decode reads
+                x = l_feats[:, :, 0].t().contiguous().unsqueeze(0)                 # (1, C, R)
+                return st[0](x, point_major=True)[0], st[1](x, point_major=True)[0]
+            return (self._head_forward("rcnn_cls", net.cls_layer, l_feats).squeeze(-1),
+                    self._head_forward("rcnn_reg", net.reg_layer, l_feats).squeeze(-1))
+        rcnn_cls, rcnn_reg = self._t("rcnn_heads(span)", 0, heads)
         return dict(rcnn_cls=rcnn_cls, rcnn_reg=rcnn_reg)
+
+    def _rcnn_head_stacks(self, l_feats: torch.Tensor):
+        """(cls stack, reg stack) when both heads (rcnn.py:57-89: Conv1d (+ BN) + ReLU x 2 -> Conv1d) run as one conv1d_stack
+        launch each on (1, C, R), else None"""
+        if not (self.fuse_head_stacks and self.fuse_small_heads and l_feats.is_cuda and l_feats.dtype == torch.float32
+                and l_feats.dim() == 3 and l_feats.shape[2] == 1 and l_feats.shape[0] % 32 == 0):
+            return None
+
+        def make():
+            from .ops.conv1d import PackedConv1dStack
+            out = []
+            for head in (self.rcnn_net.cls_layer, self.rcnn_net.reg_layer):
+                units = [m for m in head if not isinstance(m, nn.Dropout)]
+                if not 1 <= len(units) <= 3:
+                    return False
+                layers = [(*_unit_wb(u), getattr(u, "activation", None) is not None) for u in units]
+                out.append(PackedConv1dStack(layers, layers[0][0].shape[1]))
+            return tuple(out)
+        st = self._wb("rcnn_heads.stacks", make)
+        if st is False or not all(t.supported(1, l_feats.shape[0]) for t in st):
+            return None
+        return st
 
     # -- the whole path ----------------------------------------------------------------------------------
     @torch.no_grad()

@@ -715,10 +715,26 @@ def test_rcnn_heads_one_launch_per_layer_vs_rocblas(run):
             b = eng.rcnn_forward(pts)
         finally:
             eng.fuse_small_heads = True
+        eng.fuse_head_stacks = False
+        prof.reset()
+        prof.enabled = True
+        try:
+            c = eng.rcnn_forward(pts)
+            torch.cuda.synchronize()
+            names_rows = set(prof.records)
+        finally:
+            prof.enabled = False
+            prof.reset()
+            eng.fuse_head_stacks = True
     for k in ("rcnn_cls", "rcnn_reg"):
         close(a[k], b[k])
-        assert a[k].shape == b[k].shape
-    assert any("linear_rows" in n for n in names), names
+        close(c[k], b[k])
+        assert a[k].shape == b[k].shape == c[k].shape and a[k].is_contiguous()
+    # one conv1d_stack launch per head where the RoI count is a multiple of 32, else one jm_linear_rows launch per layer
+    R = a["rcnn_cls"].shape[0]
+    if R % 32 == 0:
+        assert not any("linear_rows" in n for n in names) and any("conv1d_stack" in n for n in names), names
+    assert any("linear_rows" in n for n in names_rows), names_rows
 
 
 @pytest.mark.parametrize("B,n,c0,c1,xyz1,widths,relus", [

@@ -6,6 +6,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from jmodt_amd import synth
 from jmodt_amd.ops.pointnet2 import fused
 from jmodt_amd.ops.pointnet2.pytorch_utils import SharedMLP
@@ -17,30 +18,7 @@ LEVELS = [("L1", 0, [[16, 16, 32], [32, 32, 64]], 4096, 16384), ("L2", 96, [[64,
 only = sys.argv[1:] or [l[0] for l in LEVELS]
 
 
-def timeit(fn, reps=20):
-    """GPU time per call: the calls are captured into a HIP graph (10 per graph) and replayed, so the host's ~20 us per launch
-    through Python / ctypes is not in the number"""
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
-    st = torch.cuda.Stream()
-    st.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(st):
-        fn()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=st):
-            for _ in range(10):
-                fn()
-    torch.cuda.synchronize()
-    g.replay()
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(reps):
-        g.replay()
-    e.record()
-    torch.cuda.synchronize()
-    return s.elapsed_time(e) / (10 * reps) * 1e3
+from rpn_listed_bench_timeit import timeit
 
 
 B = 8
