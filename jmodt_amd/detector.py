@@ -289,7 +289,11 @@ class DetectAffinityEngine(nn.Module):
                                            # mode, scoped to those calls): 6.03 vs 6.34 ms over the seven 3x3 convolutions
                                            # (tools/miopen_find_probe.py); costs 1-3 s per new shape, once per process
         self.fuse_small_heads = True       # RCNN cls / reg heads: one MFMA launch per dense layer
-        self.fuse_head_stacks = True       # ... or, where conv1d_stack takes the shape, one launch per HEAD
+        # ... or, where conv1d_stack takes the shape, one launch per HEAD.  Off: measured SLOWER (tools/rcnn_heads_bench.py,
+        # HIP-graph replays, 1024 RoIs: 185 us against 141 us for the six jm_linear_rows launches) — a head is 32 tiles of 32 RoIs,
+        # each a serial chain of three K = 512 / 256 layers on one CU, whereas a layer per launch spreads its 32 x 16 output tiles
+        # over the machine; neither is on the critical path (the detections' side stream)
+        self.fuse_head_stacks = False
         self.fuse_rcnn_lift = True         # xyz_up + merge_down (+ hoisted first SA layer) as one kernel
         self.fuse_attention = True         # LI-Fusion attention block as one kernel where it fits (else rocBLAS GEMMs)
         self.affinity_split_bf16 = False   # EXPERIMENTAL (csrc/affinity_x3.hip): link-head products as 3-term bf16 splits
