@@ -365,6 +365,22 @@ def dense_step(d):
 
 
 # ---------------------------------------------------------------------------------------------- train
+def make_joint_state(frames, seed, dev, tiny=False):
+    """BASELINE configs[3] in JOINT mode (tools/train.py:96-107 without cfg.TRAIN.FINETUNE): every parameter of the detector and
+    of the affinity heads trains; the step is jmodt_amd/train_joint.joint_step"""
+    st = make_detect_state(frames, seed, dev, tiny=tiny)
+    eng = st["engine"].train()
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    rois_per_frame = min(64, eng.cfg.rpn_post_nms_top_n)
+    st["tids"] = torch.randint(0, 13, (frames, rois_per_frame), generator=g).float().to(dev)
+    for p in eng.parameters():
+        p.requires_grad_(True)
+    st["opt"] = torch.optim.Adam(list(eng.parameters()), lr=2e-4, weight_decay=1e-2, fused=True)
+    st["rois_per_frame"] = rois_per_frame
+    st["joint"] = True
+    return st
+
+
 def make_train_state(frames, seed, dev, tiny=False):
     """BASELINE configs[3] per-GPU share: `frames` frames (= frames/2 (prev, next) pairs) through the FROZEN
     detector (cfg.RPN.FIXED + finetune: tools/train.py:96-107 trains only the link / start-end heads), then the
@@ -384,7 +400,10 @@ def make_train_state(frames, seed, dev, tiny=False):
     return st
 
 
-def _grad_collectives():
+def _grad_collectives(joint=False):
+    if joint:
+        from jmodt_amd import train_joint
+        return train_joint.LAST_GRAD_COLLECTIVES
     from jmodt_amd.ops import affinity_train
     return affinity_train.LAST_GRAD_COLLECTIVES
 
@@ -394,6 +413,10 @@ def train_step(st, world):
     local forward/backward of the pairwise affinity losses -> ONE bucketed gradient all-reduce over RCCL -> Adam"""
     from jmodt_amd.ops.affinity_train import finetune_step_static
     eng = st["engine"]
+    if st.get("joint"):
+        from jmodt_amd.train_joint import joint_step
+        return joint_step(eng, st["xyz"], st["image"], st["pts_xy"], st["tids"], st["opt"], world=world,
+                          rois_per_frame=st["rois_per_frame"])
     with torch.no_grad():
         pf = st.get("prefetch", True)
         _, inter = eng.detect(st["xyz"], st["image"], st["pts_xy"], next_xyz=st["xyz"] if pf else None, next_image=st["image"] if pf else None)
@@ -433,6 +456,9 @@ WORKLOAD_TEXT = {
            "pts x 133), RPN nms_normal (6300 boxes), proposal selection, fused RCNN SA1, 128x128 affinity, per frame",
     "train": "BASELINE configs[3]: frozen composed detector forward + data-parallel finetune step of the link / "
              "start-end heads (64 RoIs x 512-d per frame, pairwise affinity losses, bucketed fp32 gradient all-reduce, Adam)",
+    "train_joint": "BASELINE configs[3], joint mode: differentiable forward of the WHOLE detector (un-fused operator route: grouping / "
+                   "interpolation / LI-Fusion gather backward on the jm_*_grad kernels, convolutions on MIOpen's autograd), RPN + RCNN head "
+                   "sums + re-id loss, backward, bucketed fp32 all-reduce of all 16.7 M parameters (66.9 MB), Adam",
     "dense_detect": "BASELINE configs[4], composed: the SAME detect+affinity forward as `detect` on 65536-pt frames (co-operative "
                     "FPS, hash-grid ball query / 3-NN at the first level), 256 proposals/frame, 256x256 affinity per frame pair",
     "dense": "supplementary, BASELINE configs[4] shapes: 65536-pt clouds (co-operative FPS -> 4096, dual ball query, "
@@ -677,10 +703,13 @@ def main():
                     help="next batch's image pyramid: under this batch's backbone, after it, or not announced")
     ap.add_argument("--no-prefetch", action="store_true", help="do not start the next batch's FPS pyramid early")
     ap.add_argument("--tiny", action="store_true", help="smoke-sized shapes (tests only; the JSON says so)")
-    ap.add_argument("--workload", default="detect", choices=list(WORKLOAD_TEXT))
+    ap.add_argument("--workload", default="detect", choices=[w for w in WORKLOAD_TEXT if w != "train_joint"])
     ap.add_argument("--cloud", default="uniform", choices=["uniform", "kitti", "packed"],
                     help="detect only: the synthetic cloud the whole line (value, kernel table) is measured on; the default line "
                          "always carries all three values under `clouds`")
+    ap.add_argument("--joint", action="store_true",
+                    help="train only: joint mode — forward / backward through the WHOLE detector (un-fused autograd route) and the "
+                         "bucketed all-reduce of all 16.7 M parameters (66.9 MB), instead of the finetune step of the two heads (4.2 MB)")
     ap.add_argument("--no-listed", action="store_true",
                     help="RPN set-abstraction scales on the dense kernels (every back-filled row executed) instead of the listed form")
     ap.add_argument("--headline-only", action="store_true",
@@ -779,7 +808,7 @@ def main():
         dense_in = make_dense_inputs(args.batch, seed + 4, dev, small=args.tiny)
         step = lambda: dense_step(dense_in)  # noqa: E731
     else:
-        train_st = make_train_state(args.batch, seed + 3, dev, tiny=args.tiny)
+        train_st = (make_joint_state if args.joint else make_train_state)(args.batch, seed + 3, dev, tiny=args.tiny)
         train_st["engine"].overlap = not args.no_overlap
         train_st["prefetch"] = not args.no_prefetch
         train_st["engine"].prefetch_image = args.image_prefetch != "off"
@@ -1019,7 +1048,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": WORKLOAD_TEXT[args.workload] + (" [TINY smoke shapes: not a benchmark]" if args.tiny else "")
+            "config": {"workload": (WORKLOAD_TEXT["train_joint"] if args.workload == "train" and args.joint else WORKLOAD_TEXT[args.workload])
+                                   + (" [TINY smoke shapes: not a benchmark]" if args.tiny else "")
                                    + (f" [cloud: {args.cloud}]" if args.cloud != "uniform" else ""),
                        "frames_per_gpu_per_step": args.batch,
                        "points": (65536 if args.workload in ("dense", "dense_detect") else 16384) if not args.tiny else "tiny",
@@ -1053,10 +1083,12 @@ def main():
             "grad_allreduce": ({"world": world, "bytes_per_step": next((k.get("algo_bytes_per_step") for k in kernels
                                                                          if k["kernel"].endswith("grad_allreduce(RCCL)")), None),
                                 "ms_per_step": next((k["ms_per_step"] for k in kernels if k["kernel"].endswith("grad_allreduce(RCCL)")), None),
-                                "issued": _grad_collectives(),
+                                "issued": _grad_collectives(args.joint),
                                 "mode": "RCCL all_reduce(SUM) on the flat fp32 gradient bucket, issued whenever a process group exists (a "
                                         "one-rank group included)" if dist is not None else "no process group: nothing issued",
-                                "note": "one flat fp32 all-reduce of the link / start-end heads' gradients per step (RCCL; HIP events on the "
+                                "note": ("joint mode: the gradient of every parameter in 64 MiB flat fp32 buckets (66.9 MB = one collective at the "
+                                         "reference widths); " if args.joint else "") +
+                                        "one flat fp32 all-reduce of the link / start-end heads' gradients per step (RCCL; HIP events on the "
                                         "launching stream around the collective and its wait) + two 3-float / 1-float all-reduces (global "
                                         "loss-mean counts, loss); `issued` = gradient collectives of the last step"}
                                if args.workload == "train" else None),
@@ -1086,7 +1118,7 @@ def main():
                 result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": cores, "kind": "port", "sample": f"failed: {ex!r}"}
         # stdout carries ONE compact line (<= COMPACT_LIMIT bytes); the full record (kernel table, variants, per-stage parity
         # against the CPU chain) goes to a file next to it
-        full_path = args.full_out or os.path.join("bench_out", args.workload + ("" if args.cloud == "uniform" else "_" + args.cloud)
+        full_path = args.full_out or os.path.join("bench_out", args.workload + ("_joint" if args.joint else "") + ("" if args.cloud == "uniform" else "_" + args.cloud)
                                                   + ("_tiny" if args.tiny else "") + ".json")
         abs_path = full_path if os.path.isabs(full_path) else os.path.join(ROOT, full_path)
         try:

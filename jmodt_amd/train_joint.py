@@ -1,0 +1,117 @@
+"""Joint-mode training step of the detector + affinity heads (tools/train.py:96-107 without cfg.TRAIN.FINETUNE; BASELINE
+configs[3]'s second message size: the gradient of ALL 16.7 M parameters = 66.9 MB per step).
+
+The inference engine (detector.py) runs fused, folded, no-grad kernels; this module is the DIFFERENTIABLE composition of the
+same parameter containers — what the reference's `PointRCNN.forward` does in TRAIN mode (point_rcnn.py:24-70) with
+  * backbone.py:159-196 (`backbone_forward`): four set-abstraction levels through the un-fused operator route of
+    ops/pointnet2 (QueryAndGroup + SharedMLP + max-pool; grouping / interpolation / LI-Fusion gather backward = the jm_*_grad
+    kernels), the image blocks and the deconvolution pyramid on MIOpen's autograd, the attention fusion modules in plain torch;
+  * rpn.py:71-87 heads; ProposalLayer and roipool3d WITHOUT gradient (the reference's are not differentiable either:
+    proposal_layer.py / roipool3d_utils.py define no backward), so the backbone learns from the RPN heads and the RCNN from
+    its own;
+  * rcnn.py:158-202 (`rcnn_forward_train`) and the training affinity of rcnn.py:204-287 on the kernels of
+    csrc/affinity_train.hip (ops/affinity_train.affinity_train_loss, differentiable w.r.t. the RoI features).
+The reference's loss terms (train_functions.py) are the caller's business and out of scope;
+`thin_loss` is the smallest functional that sends a gradient into every parameter, which is what the data-parallel exchange
+needs: sums over frames, so that the gradient of a batch is the SUM of its shards' gradients and the all-reduce is a plain
+SUM (no count bookkeeping), + the re-id loss with its global-count weighting.
+"""
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import dist as jdist
+from .ops.fusion import feature_gather
+from .ops.roipool3d.roipool3d_utils import roipool3d_canonical_gpu
+from .profile import prof
+
+
+def backbone_forward(net, xyz: torch.Tensor, image: torch.Tensor, pts_xy: torch.Tensor) -> torch.Tensor:
+    """PointNet2MSG.forward (backbone.py:159-196) on the module containers, differentiable: (B, N, 3), (B, 3, H, W),
+    (B, N, 2) -> point features (B, C, N)"""
+    l_xyz, l_feats, l_xy, img = [xyz], [None], [pts_xy], [image]
+    for i, sa in enumerate(net.SA_modules):
+        new_xyz, feats, idx = sa(l_xyz[i], l_feats[i])
+        xy_i = torch.gather(l_xy[i], 1, idx.long().unsqueeze(-1).expand(-1, -1, 2))
+        im = net.Img_Block[i](img[i])
+        feats = net.Fusion_Conv[i](feats, feature_gather(im, xy_i))
+        l_xyz.append(new_xyz); l_feats.append(feats); l_xy.append(xy_i); img.append(im)
+    for i in range(-1, -(len(net.FP_modules) + 1), -1):
+        l_feats[i - 1] = net.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i])
+    de = torch.cat([net.DeConv[i](img[i + 1]) for i in range(len(net.DeConv))], dim=1)
+    fused_img = F.relu(net.image_fusion_bn(net.image_fusion_conv(de)))
+    return net.final_fusion_img_point(l_feats[0], feature_gather(fused_img, pts_xy))
+
+
+def rcnn_forward_train(net, pts_input: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """RCNN.forward (rcnn.py:176-202) on pooled RoI points (R, S, 5 + C) -> rcnn_cls (R, 1), rcnn_reg (R, 46), rcnn_feat (R, 512)"""
+    k = net.rcnn_input_channel
+    xyz = pts_input[..., 0:3].contiguous()
+    xyz_feature = net.xyz_up_layer(pts_input[..., 0:k].transpose(1, 2).contiguous().unsqueeze(3))
+    rpn_feature = pts_input[..., k:].transpose(1, 2).contiguous().unsqueeze(3)
+    merged = net.merge_down_layer(torch.cat((xyz_feature, rpn_feature), dim=1)).squeeze(3)
+    l_xyz, l_feat = xyz, merged
+    for sa in net.SA_modules:
+        l_xyz, l_feat, _ = sa(l_xyz, l_feat)
+    return dict(rcnn_cls=net.cls_layer(l_feat).squeeze(-1), rcnn_reg=net.reg_layer(l_feat).squeeze(-1), rcnn_feat=l_feat.squeeze(-1))
+
+
+def joint_forward(engine, xyz, image, pts_xy, rois_per_frame: int = 64) -> Dict[str, torch.Tensor]:
+    """the detector in TRAIN composition (point_rcnn.py:24-70): backbone + RPN heads with gradient, proposals and RoI pooling
+    without (the first `rois_per_frame` proposals of every frame stand in for ProposalTargetLayer's sampled RoIs,
+    config.py:153), RCNN with gradient on the pooled points"""
+    rpn, cfg = engine.rpn, engine.cfg
+    feats = backbone_forward(rpn.backbone_net, xyz, image, pts_xy)
+    rpn_cls = rpn.rpn_cls_layer(feats).transpose(1, 2).contiguous()          # (B, N, 1)
+    rpn_reg = rpn.rpn_reg_layer(feats).transpose(1, 2).contiguous()          # (B, N, C)
+    with torch.no_grad():
+        det = dict(rpn_cls=rpn_cls.detach(), rpn_reg=rpn_reg.detach(), backbone_xyz=xyz, backbone_features=feats.detach())
+        rois, _ = engine.proposals(det)
+        rois = rois[:, :rois_per_frame].contiguous()
+        pf = engine.pts_feature(det)
+        pooled, _ = roipool3d_canonical_gpu(xyz, pf, rois, cfg.pool_extra_width, cfg.rcnn_num_points)
+        pts_input = pooled.view(-1, cfg.rcnn_num_points, pooled.shape[-1])
+    out = rcnn_forward_train(engine.rcnn_net, pts_input)
+    out.update(rpn_cls=rpn_cls, rpn_reg=rpn_reg, backbone_features=feats, rois=rois)
+    return out
+
+
+def thin_loss(engine, out: Dict[str, torch.Tensor], gt_tids: torch.Tensor, counts: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a functional of every head output (sums over frames: shard gradients ADD) + the re-id loss of rcnn.py:204-287 /
+    train_functions.py:282-329 on the RoI features with the (global) element counts"""
+    from .ops.affinity_train import AffinityTrainState, affinity_train_loss
+    B = gt_tids.shape[0]
+    feats = out["rcnn_feat"].view(B, -1, out["rcnn_feat"].shape[-1])
+    st = AffinityTrainState(feats, gt_tids)
+    reid = affinity_train_loss(st, engine.rcnn_net.link_layer, engine.rcnn_net.se_layer, counts=counts)
+    n = float(out["rpn_cls"].shape[1])
+    return (out["rpn_cls"].sum() + out["rpn_reg"].sum()) / n + out["rcnn_cls"].sum() + out["rcnn_reg"].sum() + reid
+
+
+def joint_step(engine, xyz, image, pts_xy, gt_tids, optimizer, world: int = 1, rois_per_frame: int = 64,
+               bucket_bytes: int = 64 << 20) -> torch.Tensor:
+    """one data-parallel joint-mode step on this rank's frames: differentiable forward, thin loss, backward through the whole
+    detector, the gradient of every parameter all-reduced in 64 MiB buckets (66.9 MB at the reference widths: ONE
+    collective), optimizer step.  Returns the local loss (device scalar, detached)."""
+    import torch.distributed as tdist
+    from .ops.affinity_train import AffinityTrainState
+    params = [p for p in engine.parameters() if p.requires_grad]
+    optimizer.zero_grad(set_to_none=True)
+    out = prof.region("joint_forward(span)", lambda: joint_forward(engine, xyz, image, pts_xy, rois_per_frame))
+    counts = None
+    if jdist.collective_path(world):             # the re-id means run over the GLOBAL element counts (as in the finetune step)
+        B = gt_tids.shape[0]
+        with torch.no_grad():
+            counts = AffinityTrainState(out["rcnn_feat"].detach().view(B, -1, out["rcnn_feat"].shape[-1]), gt_tids).counts.clone()
+        tdist.all_reduce(counts, op=tdist.ReduceOp.SUM)
+    loss = thin_loss(engine, out, gt_tids, counts)
+    prof.region("joint_backward(span)", lambda: loss.backward())
+    global LAST_GRAD_COLLECTIVES
+    LAST_GRAD_COLLECTIVES = prof.region("grad_allreduce(RCCL)", lambda: jdist.allreduce_gradients(params, world=world, bucket_bytes=bucket_bytes, average=False),
+                                        algo_bytes=sum(p.numel() for p in params) * 4)
+    optimizer.step()
+    return loss.detach()
+
+
+LAST_GRAD_COLLECTIVES = 0

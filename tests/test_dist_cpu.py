@@ -137,6 +137,35 @@ def test_one_rank_process_group_takes_the_collective_path_and_changes_nothing(tm
             assert torch.equal(one[name][k], v), (name, k)
 
 
+def _joint_bucket_worker(rank, world, port, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as tdist
+    from jmodt_amd.detector import DetectAffinityEngine
+    tdist.init_process_group("gloo")
+    torch.manual_seed(0)
+    eng = DetectAffinityEngine()                                    # the reference widths: 16 732 011 parameters = 66.9 MB
+    params = list(eng.parameters())
+    for k, p in enumerate(params):                                  # a rank-dependent "gradient" with structure per tensor
+        p.grad = torch.full_like(p, float(rank + 1)) * (1.0 + (k % 7))
+    n = jdist.allreduce_gradients(params, world=world, bucket_bytes=64 << 20, average=False)
+    ok = all(torch.equal(p.grad, torch.full_like(p, 3.0) * (1.0 + (k % 7))) for k, p in enumerate(params))
+    n4 = jdist.allreduce_gradients(params, world=world, bucket_bytes=16 << 20, average=True)      # smaller buckets, mean
+    ok = ok and n4 >= 4 and all(torch.equal(p.grad, torch.full_like(p, 3.0) * (1.0 + (k % 7))) for k, p in enumerate(params))
+    torch.save({"collectives": n, "ok": ok, "bytes": sum(p.numel() for p in params) * 4}, os.path.join(tmpdir, f"j{rank}.pt"))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_joint_mode_gradient_exchange_of_all_parameters(tmp_path):
+    """BASELINE configs[3]'s second message size: the gradient of ALL parameters of the detector + affinity
+    heads, 66.9 MB fp32, fits ONE 64 MiB bucket (one collective; a 16 MiB bucket size makes it four) and comes back as the SUM over ranks (world size 2, gloo)"""
+    world = 2
+    mp.spawn(_joint_bucket_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = torch.load(tmp_path / f"j{r}.pt")
+        assert res["ok"] and res["collectives"] == 1 and res["bytes"] == 66_928_044, res
+
+
 def test_static_training_affinity_equals_the_looped_form():
     """training_affinity_static (masks instead of torch.unique / a Python loop over frame pairs) gives the reference
     form's loss and gradients exactly (float64), incl. a pair without foreground on one side and duplicate track ids"""

@@ -1,0 +1,108 @@
+"""GPU tier (-m gpu): the joint-mode training step (jmodt_amd/train_joint.py; tools/train.py:96-107 without FINETUNE, BASELINE
+configs[3]'s 66.9 MB gradient): the differentiable composition of the detector is the SAME network as the fused inference
+engine, and one step sends a finite gradient into every parameter."""
+import numpy as np
+import pytest
+import torch
+
+from jmodt_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def close(got, want, tol=1e-4):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    scale = max(1.0, float(want.abs().max()))
+    assert float((got - want).abs().max()) <= tol * scale, (float((got - want).abs().max()), scale)
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    from jmodt_amd.detector import DetectorConfig
+    from tests.test_gpu_detector import make_engine
+    eng = make_engine(seed=3, cfg=DetectorConfig.tiny()).to(DEV).eval()
+    xyz, img, xy = synth.frames(2, 2048, 77, H=96, W=320, native=(94, 310))
+    return eng, T(xyz), T(img), T(xy)
+
+
+def test_joint_forward_is_the_inference_engines_network(tiny):
+    """eval-mode BatchNorm on both sides: the differentiable route (un-fused operators, module forwards) against the fused,
+    folded kernels of DetectAffinityEngine — backbone features and RPN heads free running, the RCNN on the same pooled points"""
+    from jmodt_amd.train_joint import joint_forward, rcnn_forward_train
+    eng, xyz, img, xy = tiny
+    with torch.no_grad():
+        want = eng.rpn_forward(xyz, img, xy)
+    with torch.enable_grad():
+        got = joint_forward(eng, xyz, img, xy, rois_per_frame=eng.cfg.rpn_post_nms_top_n)
+    assert got["rpn_cls"].requires_grad and got["rcnn_reg"].requires_grad and got["rcnn_feat"].requires_grad
+    close(got["backbone_features"], want["backbone_features"])
+    close(got["rpn_cls"], want["rpn_cls"])
+    close(got["rpn_reg"], want["rpn_reg"])
+    with torch.no_grad():
+        rois, _ = eng.proposals(want)
+        pts_input = eng.roi_pool(want, rois)
+        ref = eng.rcnn_forward(pts_input)
+    with torch.enable_grad():
+        mine = rcnn_forward_train(eng.rcnn_net, pts_input)
+    close(mine["rcnn_cls"], ref["rcnn_cls"])
+    close(mine["rcnn_reg"], ref["rcnn_reg"])
+    close(mine["rcnn_feat"], ref["rcnn_feat"].squeeze(-1))
+
+
+def test_joint_step_reaches_every_parameter_and_updates_it(tiny):
+    """one step in train mode: every one of the detector's and the affinity heads' parameters receives a finite gradient, almost
+    all of them non-zero, and the fused Adam moves them; no process group: no collective is issued"""
+    import copy
+    from jmodt_amd import train_joint
+    eng0, xyz, img, xy = tiny
+    eng = copy.deepcopy(eng0).train()
+    for p in eng.parameters():
+        p.requires_grad_(True)
+    params = list(eng.parameters())
+    opt = torch.optim.Adam(params, lr=1e-3, fused=True)
+    R = min(64, eng.cfg.rpn_post_nms_top_n)
+    tids = torch.randint(0, 6, (2, R), generator=torch.Generator().manual_seed(4)).float().to(DEV)
+    before = [p.detach().clone() for p in params]
+    loss = train_joint.joint_step(eng, xyz, img, xy, tids, opt, world=1, rois_per_frame=R)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and train_joint.LAST_GRAD_COLLECTIVES == 0
+    missing = [n for n, p in eng.named_parameters() if p.grad is None]
+    assert not missing, missing
+    assert all(bool(torch.isfinite(p.grad).all()) for p in params)
+    nonzero = sum(int((p.grad != 0).any()) for p in params)
+    assert nonzero >= 0.97 * len(params), (nonzero, len(params))
+    moved = sum(int(not torch.equal(a, p.detach())) for a, p in zip(before, params))
+    assert moved >= 0.97 * len(params), (moved, len(params))
+    # the gradient that reaches the backbone comes from the RPN heads only: roipool3d is not differentiable (as in the reference)
+    assert float(eng.rpn.backbone_net.SA_modules[0].mlps[0][0].conv.weight.grad.abs().max()) > 0
+    assert float(eng.rpn.backbone_net.Img_Block[0].conv1.weight.grad.abs().max()) > 0
+    assert float(eng.rcnn_net.xyz_up_layer[0].conv.weight.grad.abs().max()) > 0
+    assert float(eng.rcnn_net.link_layer[0].conv.weight.grad.abs().max()) > 0
+
+
+def test_bench_joint_training_step_under_the_launcher():
+    """bench.py --workload train --joint on the launcher path (one-rank RCCL group): the bucketed all-reduce of ALL parameters
+    is issued and timed, bytes = 4 x the parameter count"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from jmodt_amd.detector import DetectAffinityEngine, DetectorConfig
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--workload", "train", "--joint", "--tiny", "--launch", "--batch", "2"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) <= 4096, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    nparams = sum(q.numel() for q in DetectAffinityEngine(DetectorConfig.tiny()).parameters())
+    ga = r["grad_allreduce"]
+    assert ga["issued"] >= 1 and ga["bytes_per_step"] == 4 * nparams and ga["ms_per_step"] > 0 and r["value"] > 0
+    assert "joint" in r["config"]["workload"]
