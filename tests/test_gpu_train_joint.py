@@ -57,10 +57,11 @@ def test_joint_forward_is_the_inference_engines_network(tiny):
 def test_joint_step_reaches_every_parameter_and_updates_it(tiny):
     """one step in train mode: every one of the detector's and the affinity heads' parameters receives a finite gradient, almost
     all of them non-zero, and the fused Adam moves them; no process group: no collective is issued"""
-    import copy
     from jmodt_amd import train_joint
-    eng0, xyz, img, xy = tiny
-    eng = copy.deepcopy(eng0).train()
+    from jmodt_amd.detector import DetectorConfig
+    from tests.test_gpu_detector import make_engine
+    _, xyz, img, xy = tiny
+    eng = make_engine(seed=3, cfg=DetectorConfig.tiny()).to(DEV).train()      # (a fresh one: the step changes the weights)
     for p in eng.parameters():
         p.requires_grad_(True)
     params = list(eng.parameters())
