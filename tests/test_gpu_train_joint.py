@@ -75,10 +75,16 @@ def test_joint_step_reaches_every_parameter_and_updates_it(tiny):
     missing = [n for n, p in eng.named_parameters() if p.grad is None]
     assert not missing, missing
     assert all(bool(torch.isfinite(p.grad).all()) for p in params)
-    nonzero = sum(int((p.grad != 0).any()) for p in params)
-    assert nonzero >= 0.97 * len(params), (nonzero, len(params))
+    # the only parameters with an all-zero gradient are the biases of convolutions that feed a TRAIN-mode BatchNorm (the batch
+    # mean removes them: d loss / d bias = 0 exactly) — the fusion convolutions of backbone.py:44-81 and image_fusion_conv
+    zero = sorted(n for n, p in eng.named_parameters() if not bool((p.grad != 0).any()))
+    expect = sorted([f"rpn.backbone_net.Fusion_Conv.{i}.{m}.bias" for i in range(len(eng.rpn.backbone_net.Fusion_Conv))
+                     for m in ("conv1", "IA_Layer.conv1.0")] +
+                    ["rpn.backbone_net.final_fusion_img_point.conv1.bias", "rpn.backbone_net.final_fusion_img_point.IA_Layer.conv1.0.bias",
+                     "rpn.backbone_net.image_fusion_conv.bias"])
+    assert set(zero) <= set(expect), sorted(set(zero) - set(expect))
     moved = sum(int(not torch.equal(a, p.detach())) for a, p in zip(before, params))
-    assert moved >= 0.97 * len(params), (moved, len(params))
+    assert moved >= len(params) - len(expect), (moved, len(params))
     # the gradient that reaches the backbone comes from the RPN heads only: roipool3d is not differentiable (as in the reference)
     assert float(eng.rpn.backbone_net.SA_modules[0].mlps[0][0].conv.weight.grad.abs().max()) > 0
     assert float(eng.rpn.backbone_net.Img_Block[0].conv1.weight.grad.abs().max()) > 0
