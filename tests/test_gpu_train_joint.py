@@ -83,8 +83,9 @@ def test_joint_step_reaches_every_parameter_and_updates_it(tiny):
                     ["rpn.backbone_net.final_fusion_img_point.conv1.bias", "rpn.backbone_net.final_fusion_img_point.IA_Layer.conv1.0.bias",
                      "rpn.backbone_net.image_fusion_conv.bias"])
     assert set(zero) <= set(expect), sorted(set(zero) - set(expect))
-    moved = sum(int(not torch.equal(a, p.detach())) for a, p in zip(before, params))
-    assert moved >= len(params) - len(expect), (moved, len(params))
+    # (their gradient is zero up to rounding: some come out as 1e-12 instead of 0 and do not move a float32 weight either)
+    stuck = [n for (n, p), a in zip(eng.named_parameters(), before) if torch.equal(a, p.detach()) and n not in expect]
+    assert not stuck, stuck
     # the gradient that reaches the backbone comes from the RPN heads only: roipool3d is not differentiable (as in the reference)
     assert float(eng.rpn.backbone_net.SA_modules[0].mlps[0][0].conv.weight.grad.abs().max()) > 0
     assert float(eng.rpn.backbone_net.Img_Block[0].conv1.weight.grad.abs().max()) > 0
