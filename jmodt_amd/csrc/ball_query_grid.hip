@@ -137,7 +137,7 @@ bq_grid_query_kernel(BgParams p, const float* __restrict__ new_xyz, const uint2*
             for (int r = 0; r < NR; ++r)
                 if (valid && d2 < p.r2[r]) {
                     atomicOr(&bm[r * stride + (k >> 5)], 1u << (k & 31));
-                    if (wpl != 8) atomicOr(&bm[r * stride + p.words + (k >> 10)], 1u << ((k >> 5) & 31));
+                    if (wpl > 8) atomicOr(&bm[r * stride + p.words + (k >> 10)], 1u << ((k >> 5) & 31));
                 }
         }
         __threadfence_block();      // the wave's ds_or traffic is complete before the bitmap is read back
@@ -146,8 +146,9 @@ bq_grid_query_kernel(BgParams p, const float* __restrict__ new_xyz, const uint2*
         for (int r = 0; r < NR; ++r) {
             unsigned* row = bm + r * stride + lane * wpl;
             int pc = 0;
-            if (wpl == 8) {                                               // n <= 16384: this lane's 256 bits in registers
-                const uint4 lo4 = *reinterpret_cast<const uint4*>(row), hi4 = *reinterpret_cast<const uint4*>(row + 4);
+            if (wpl <= 8) {                        // n <= 16384 (8 words per lane) or n <= 8192 (4): this lane's bits in registers
+                const uint4 lo4 = *reinterpret_cast<const uint4*>(row);
+                const uint4 hi4 = wpl == 8 ? *reinterpret_cast<const uint4*>(row + 4) : make_uint4(0u, 0u, 0u, 0u);
                 const unsigned wd[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
 #pragma unroll
                 for (int w = 0; w < 8; ++w) pc += __popc(wd[w]);
@@ -162,14 +163,14 @@ bq_grid_query_kernel(BgParams p, const float* __restrict__ new_xyz, const uint2*
 #pragma unroll
                         for (int w = 0; w < 8; ++w) {
                             unsigned bits = wd[w];
-                            if (bits && first_here < 0) first_here = (lane * 8 + w) * 32 + __ffs((int)bits) - 1;
+                            if (bits && first_here < 0) first_here = (lane * wpl + w) * 32 + __ffs((int)bits) - 1;
                             while (bits && rank < ns) {
-                                out[rank++] = (lane * 8 + w) * 32 + __ffs((int)bits) - 1;
+                                out[rank++] = (lane * wpl + w) * 32 + __ffs((int)bits) - 1;
                                 bits &= bits - 1;
                             }
                         }
                         *reinterpret_cast<uint4*>(row) = make_uint4(0u, 0u, 0u, 0u);
-                        *reinterpret_cast<uint4*>(row + 4) = make_uint4(0u, 0u, 0u, 0u);
+                        if (wpl == 8) *reinterpret_cast<uint4*>(row + 4) = make_uint4(0u, 0u, 0u, 0u);
                     }
                     const unsigned long long have = __ballot(pc > 0);
                     const int first = __builtin_amdgcn_readlane(first_here, __ffsll((long long)have) - 1);

@@ -127,7 +127,8 @@ sa_xyz_valu_kernel(SaXyzParams p) {
     // (an opaque zero OFFSET, not an opaque pointer: that one would lose its address space and turn into flat vector loads)
     int zero = 0;
     if (LISTED) asm volatile("" : "+s"(zero));
-    using wptr = typename std::conditional<LISTED, cptr4, const float* __restrict__>::type;
+    using wptr = cptr4;     // (the dense mode as well: from the global address space hipcc fetched 396 of its weight quads with
+                            // vector loads and spilled; through the scalar cache only: 137 -> ~100 us at [32, 32, 64] x 32)
     const wptr W0t = (wptr)(p.w0 + zero), W1t = (wptr)(p.w1 + zero), W2t = (wptr)(p.w2 + zero);
     const wptr B0 = (wptr)(p.b0 + zero), B1 = (wptr)(p.b1 + zero), B2 = (wptr)(p.b2 + zero);
     int q = QF, slot0 = 0, cnt_q = 0;

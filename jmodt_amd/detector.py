@@ -332,12 +332,14 @@ class DetectAffinityEngine(nn.Module):
         bumps `_version` on every in-place update (load_state_dict, optimizer steps, manual copy_), `.to()` changes the
         storage.  Same rule as the SA / FP module caches (ops/pointnet2/fused.py:_packed_layers); called at every public
         entry (a few hundred attribute reads, ~0.1 ms of host time per batch)."""
-        if self._sig_tensors is None:
-            # (the link / start-end heads are never folded: ops/affinity.py hands their live tensors to the kernels on every
-            # call, and the finetune step updates them every iteration — tools/train.py:96-107)
-            skip = {id(t) for head in (self.rcnn_net.link_layer, self.rcnn_net.se_layer) for t in head.parameters()}
-            self._sig_tensors = [t for t in list(self.parameters()) + list(self.buffers()) if id(t) not in skip]
-        sig = tuple([(t.data_ptr(), t._version) for t in self._sig_tensors])
+        # (the link / start-end heads are never folded: ops/affinity.py hands their live tensors to the kernels on every
+        # call, and the finetune step updates them every iteration — tools/train.py:96-107)
+        # The tensors are walked afresh on every call: a parameter that was REPLACED (load_state_dict(assign=True),
+        # `module.weight = nn.Parameter(...)`, parametrizations) is a new object, which a list cached at the first call would
+        # never see — its id is part of the signature
+        skip = {id(t) for head in (self.rcnn_net.link_layer, self.rcnn_net.se_layer) for t in head.parameters()}
+        self._sig_tensors = [t for t in list(self.parameters()) + list(self.buffers()) if id(t) not in skip]
+        sig = tuple([(id(t), t.data_ptr(), t._version) for t in self._sig_tensors])
         if sig != self._folded_sig:
             self._folded.clear()
             self._folded_sig = sig
@@ -706,7 +708,8 @@ class DetectAffinityEngine(nn.Module):
         if xyz.is_cuda and self.dedupe_rcnn:
             # + the number of distinct points per RoI slab: rows count .. S-1 are cyclic copies (roipool3d_kernel.cu:123-160)
             pooled, _, count = roipool3d_canonical_gpu(xyz, pts_feature, rois, cfg.pool_extra_width, S, return_count=True)
-            self._roi_count = (pooled, count.view(B * M))
+            # keyed by the pooled tensor's identity AND version: rcnn_forward compacts only the very tensor these counts describe
+            self._roi_count = ((pooled.data_ptr(), tuple(pooled.view(B * M, S, 5 + C).shape), pooled._version), count.view(B * M))
         else:
             pooled, _ = roipool3d_canonical_gpu(xyz, pts_feature, rois, cfg.pool_extra_width, S)
         return pooled.view(B * M, S, 5 + C)
@@ -751,7 +754,8 @@ class DetectAffinityEngine(nn.Module):
             g0 = sa1.groupers[0]
             pm = fused.pm_plan(sa1.mlps[0], pts_input.device, R, S, sa1.npoint, g0.nsample) is not None
             kept = getattr(self, "_roi_count", None)
-            count = kept[1] if kept is not None and kept[0].data_ptr() == pts_input.data_ptr() else None
+            count = (kept[1] if kept is not None and kept[0] == (pts_input.data_ptr(), tuple(pts_input.shape), pts_input._version)
+                     and kept[1].numel() == R else None)       # a slice or a modified copy of the pooled points: dense kernels
             dedupe = (pm and self.dedupe_rcnn and count is not None
                       and fused.dedupe_applies(sa1.mlps[0], pts_input.device, R, S, lifted.ho, sa1.npoint, g0.nsample))
             # (with the compaction, only canonical rows of u are ever gathered: the lift skips 32-point tiles of pure copies)

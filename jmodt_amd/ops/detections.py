@@ -79,6 +79,8 @@ class DetectionCache:
         """the per-frame counts on the host: ONE small D2H per batch, cached"""
         if self._count_host is None:
             self._count_host = [int(v) for v in self.count.cpu().tolist()]
+            from .pointnet2.pointnet2_utils import check_fps_failures
+            check_fps_failures()          # (the host has just waited for the device: the sampling flags are there too)
         return self._count_host
 
     def frame(self, b: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:

@@ -68,7 +68,30 @@ def farthest_point_sample_xyz(xyz: torch.Tensor, npoint: int):
     # the sampling chain); only clouds beyond the co-operative kernel's limit still need it
     temp = torch.full((B, N), 1e10, dtype=_f32, device=xyz.device) if N > 131072 else None
     pointnet2_cuda.farthest_point_sampling_wrapper(B, N, npoint, xyz, temp, idx, new_xyz)
+    if 16384 < N <= 131072 and npoint > 0:
+        # the co-operative kernel (several workgroups per cloud exchanging records) gives a cloud up when a peer never shows
+        # (csrc/fps.hip: the row becomes -1, its centres NaN) instead of hanging the GPU.  Nothing downstream may index with -1:
+        # the row is clamped to index 0 HERE and the failure is kept as a device flag that `check_fps_failures()` turns into an
+        # exception at the caller's next synchronisation point — no host sync on the sampling chain
+        bad = idx[:, :1] < 0
+        FPS_FAILED.append(bad.any())
+        del FPS_FAILED[:-64]
+        idx = torch.where(bad, torch.zeros_like(idx), idx)
+        new_xyz = torch.where(bad.unsqueeze(-1), xyz[:, :1].expand(-1, npoint, -1), new_xyz)
     return idx, new_xyz
+
+
+FPS_FAILED = []      # device bools of the co-operative FPS launches not yet checked
+
+
+def check_fps_failures() -> None:
+    """raise if a co-operative furthest_point_sample launch since the last call gave a cloud up (exchange time-out: a broken
+    device partition, or a launch overlapped with work that kept its peer workgroups off the machine for seconds).  Synchronises
+    on the flags: call it where the host waits for the device anyway (DetectionCache.counts_host does)."""
+    flags, FPS_FAILED[:] = list(FPS_FAILED), []
+    if flags and bool(torch.stack(flags).any().item()):
+        raise RuntimeError("furthest_point_sample: the co-operative kernel timed out waiting for a peer workgroup; the sampled "
+                           "indices of at least one cloud are invalid (they were clamped to 0)")
 
 
 class _GatherOperation(Function):
