@@ -27,6 +27,9 @@ def tiny():
     from tests.test_gpu_detector import make_engine
     eng = make_engine(seed=3, cfg=DetectorConfig.tiny()).to(DEV).eval()
     xyz, img, xy = synth.frames(2, 2048, 77, H=96, W=320, native=(94, 310))
+    # (synth.frames projects with the KITTI intrinsics of the 1280-wide canvas: on this 320-wide smoke image almost every point
+    # falls outside and the LI-Fusion gather returns its zero padding; here the image side must carry signal AND gradient)
+    xy = np.random.default_rng(5).uniform(-0.98, 0.98, size=xy.shape).astype(np.float32)
     return eng, T(xyz), T(img), T(xy)
 
 
