@@ -108,9 +108,12 @@ def bev_boxes(n, seed, extent=40.0, jitter_clusters=True):
 
 
 def pts_xy(pts, W=1280, H=384):
-    """project with a fixed KITTI-like pinhole and normalise to [-1,1] (kitti_dataset.py:254-255)"""
-    fu = fv = 721.5
-    cu, cv = 609.6, 172.9
+    """project with a fixed KITTI-like pinhole and normalise to [-1,1] (kitti_dataset.py:254-255).  The intrinsics are those of
+    the 1280-wide canvas, scaled with W: a smoke-sized canvas (96 x 320) sees the same field of view instead of having every
+    point fall outside it (round 4: the tiny tests' LI-Fusion gathers used to read nothing but zero padding)"""
+    sc = W / 1280.0
+    fu = fv = 721.5 * sc
+    cu, cv = 609.6 * sc, 172.9 * sc
     z = np.maximum(pts[..., 2], 0.5)
     u = fu * pts[..., 0] / z + cu
     v = fv * pts[..., 1] / z + cv
