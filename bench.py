@@ -629,11 +629,12 @@ def compact_line(full, full_path):
         c["clouds"] = {k: v.get("value") for k, v in cl.items() if isinstance(v, dict)}
         if cl["uniform"].get("value_dense_rcnn_kernels") is not None:
             c["clouds"]["uniform_dense_rcnn_kernels"] = cl["uniform"]["value_dense_rcnn_kernels"]
-    for k in ("no_prefetch_value", "no_overlap_value", "step_mfma_frac"):
+    for k in ("no_prefetch_value", "no_image_prefetch_value", "no_overlap_value", "step_mfma_frac"):
         if full.get(k) is not None:
             c[k] = full[k]
     if full.get("overlap"):
-        c["overlap"] = sub(full["overlap"], ("side_streams", "next_batch_fps_prefetch", "fps_chain_ms", "fps_exposed_ms", "image_branch_exposed_ms"))
+        c["overlap"] = sub(full["overlap"], ("side_streams", "next_batch_fps_prefetch", "next_batch_image_prefetch", "fps_chain_ms", "fps_exposed_ms",
+                                             "image_branch_exposed_ms"))
     if full.get("grad_allreduce"):
         c["grad_allreduce"] = sub(full["grad_allreduce"], ("world", "issued", "bytes_per_step", "ms_per_step", "mode"))
     if full.get("image_branch_kernel"):
@@ -699,8 +700,10 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 8; train: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="FPS chain and image branch on the main stream")
-    ap.add_argument("--image-prefetch", choices=["early", "late", "off"], default="off",
-                    help="next batch's image pyramid: under this batch's backbone, after it, or not announced")
+    ap.add_argument("--image-prefetch", choices=["early", "late", "off"], default="early",
+                    help="next batch's image pyramid: under this batch's backbone (default since round 4: with the lighter main chain "
+                         "the image stream is the critical path and this fills the step's tail, +4 %%), after it, or not announced "
+                         "(`no_image_prefetch_value` in the line)")
     ap.add_argument("--no-prefetch", action="store_true", help="do not start the next batch's FPS pyramid early")
     ap.add_argument("--tiny", action="store_true", help="smoke-sized shapes (tests only; the JSON says so)")
     ap.add_argument("--workload", default="detect", choices=[w for w in WORKLOAD_TEXT if w != "train_joint"])
@@ -803,6 +806,8 @@ def main():
         st = make_detect_state(args.batch, seed + 4, dev, tiny=args.tiny, points=65536, rois=256)
         st["engine"].overlap = not args.no_overlap
         st["prefetch"] = not args.no_prefetch
+        st["engine"].prefetch_image = args.image_prefetch != "off"
+        st["engine"].prefetch_image_late = args.image_prefetch == "late"
         step = lambda: detect_step(st)  # noqa: E731
     elif args.workload == "dense":
         dense_in = make_dense_inputs(args.batch, seed + 4, dev, small=args.tiny)
@@ -902,12 +907,19 @@ def main():
                 st["prefetch"], eng.overlap = keep
                 step()                                  # consume / re-announce under the restored settings
                 torch.cuda.synchronize()
+        if st["prefetch"] and eng.overlap and eng.prefetch_image:
+            eng.prefetch_image = False
+            try:
+                variants["no_image_prefetch_value"] = round(variant(True, True), 2)
+            finally:
+                eng.prefetch_image = True
         if st["prefetch"] and eng.overlap:
             variants["no_prefetch_value"] = round(variant(False, True), 2)
         if eng.overlap:
             variants["no_overlap_value"] = round(variant(False, False), 2)
         variants["clouds"] = None
-        variants["variants_note"] = (f"{n_var} steps each after the timed region, this rank x world: no_prefetch = every batch's FPS pyramid "
+        variants["variants_note"] = (f"{n_var} steps each after the timed region, this rank x world: no_image_prefetch = the next batch's image pyramid "
+                                     "is not started under this batch (its FPS pyramid still is); no_prefetch = every batch's FPS pyramid "
                                      "starts at the head of its OWN step (still on the side stream, nothing announced early); no_overlap = "
                                      "FPS chain, image branch and detection glue all on the main stream")
         # the RCNN stage skips (centre, sample) rows that are exact copies (csrc/sa_dedupe.hip); how many there are depends
@@ -1075,6 +1087,8 @@ def main():
                                   "which run on a side stream under its GEMMs; DetectionCache.associate (tests) is the survivor-only form"
                                   if args.workload in ("detect", "dense_detect") else None),
             "overlap": {"side_streams": not args.no_overlap, "next_batch_fps_prefetch": not (args.no_prefetch or args.no_overlap),
+                        "next_batch_image_prefetch": (args.image_prefetch if not (args.no_prefetch or args.no_overlap) and
+                                                      args.workload in ("detect", "train", "dense_detect") else "off"),
                         "fps_chain_ms": round(fps_total, 4), "fps_exposed_ms": round(exposed, 4),
                         "fps_critical_path_share": round(exposed / ms_step, 4) if ms_step else None,
                         "image_branch_exposed_ms": round(img_exposed, 4),
