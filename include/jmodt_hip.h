@@ -189,11 +189,7 @@ int jm_sa_mlp_listed_qmin(int kind);
 int jm_sa_mlp_forward_listed(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                              const float* features, const int* idx, int num_layers, const int* widths,
                              const float* const* weights, const float* const* biases, const int* cls_count, const int* glist,
-                             const float* features_point_major, float* out, size_t out_frame_stride, jm_stream_t stream);
-/* features_point_major: NULL, or the same features as (B, N, C) (C % 4 == 0, 16-byte aligned): the wide kernel then gathers a
- * row's channels with 16-byte loads from one contiguous row instead of C 4-byte loads from C cache lines of the (B, C, N) tensor
- * (the first layer's gather is what bounds that kernel on few rows); same values, same arithmetic, same bits.  Ignored by the
- * xyz-only kernel. */
+                             float* out, size_t out_frame_stride, jm_stream_t stream);
 
 /* the pre-projected two-layer block (jm_sa_mlp_pm_forward_into) in the listed form: plan from jm_sa_group_plan with
  * qmin = jm_sa_mlp_pm_listed_qmin() (= 2: sa_mlp_pm_kernel's accumulator layout pools four consecutive rows in a lane) */

@@ -75,7 +75,7 @@ SIGNATURES = {
     "jm_sa_mlp_listed_supported": (_I, [_I, _I, _I, _I, _I, _I, ctypes.POINTER(_I)]),
     "jm_sa_mlp_listed_qmin": (_I, [_I]),
     "jm_sa_mlp_forward_listed": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, ctypes.POINTER(_I), ctypes.POINTER(_P),
-                                      ctypes.POINTER(_P), _P, _P, _P, _P, _Z, _P]),
+                                      ctypes.POINTER(_P), _P, _P, _P, _Z, _P]),
     "jm_sa_mlp_pm_listed_qmin": (_I, []),
     "jm_sa_mlp_pm_listed_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "jm_sa_mlp_pm_forward_listed": (_I, [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),

@@ -22,8 +22,7 @@ namespace jm {
 
 int sa_mlp_wide_launch(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                        const float* features, const int* idx, int L, const int* widths, const float* const* weights,
-                       const float* const* biases, float* out, size_t obs, hipStream_t s, const int* cls_count, const int* glist,
-                       const float* features_pm);
+                       const float* const* biases, float* out, size_t obs, hipStream_t s, const int* cls_count, const int* glist);
 const char* sa_wide_unsupported(long long b, int n, int m, int c, int nsample, int group_all, int L, const int* widths);
 int sa_xyz_valu_launch(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* idx,
                        const int* widths, const float* const* weights, const float* const* biases, float* out, size_t obs, hipStream_t s,
@@ -154,8 +153,7 @@ extern "C" int jm_sa_mlp_listed_qmin(int kind) { return kind == 2 || kind == 3 ?
 extern "C" int jm_sa_mlp_forward_listed(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                                         const float* features, const int* idx, int num_layers, const int* widths,
                                         const float* const* weights, const float* const* biases, const int* cls_count,
-                                        const int* glist, const float* features_point_major, float* out, size_t out_frame_stride,
-                                        jm_stream_t stream) {
+                                        const int* glist, float* out, size_t out_frame_stride, jm_stream_t stream) {
     JM_REQUIRE(b >= 0 && n >= 1 && m >= 0 && c >= 0, "sa_mlp_listed: bad sizes");
     if (b == 0 || m == 0) return JM_OK;
     JM_REQUIRE(xyz && new_xyz && idx && out && widths && weights && biases && cls_count && glist && (features || c == 0), "sa_mlp_listed: null pointer");
@@ -168,5 +166,5 @@ extern "C" int jm_sa_mlp_forward_listed(int b, int n, int m, int c, int nsample,
         return sa_xyz_valu_launch(b, n, m, nsample, xyz, new_xyz, idx, widths, weights, biases, out, out_frame_stride,
                                   (hipStream_t)stream, cls_count, glist);
     return sa_mlp_wide_launch(b, n, m, c, nsample, xyz, new_xyz, features, idx, num_layers, widths, weights, biases, out,
-                              out_frame_stride, (hipStream_t)stream, cls_count, glist, c % 4 == 0 ? features_point_major : nullptr);
+                              out_frame_stride, (hipStream_t)stream, cls_count, glist);
 }

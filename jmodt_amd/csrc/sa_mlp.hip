@@ -479,7 +479,7 @@ namespace jm {
 int sa_mlp_wide_launch(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                        const float* features, const int* idx, int L, const int* widths, const float* const* weights,
                        const float* const* biases, float* out, size_t obs, hipStream_t s, const int* cls_count = nullptr,
-                       const int* glist = nullptr, const float* features_pm = nullptr);             // sa_mlp_wide.hip
+                       const int* glist = nullptr);                                                 // sa_mlp_wide.hip
 const char* sa_wide_unsupported(long long b, int n, int m, int c, int nsample, int group_all, int L, const int* widths);
 bool sa_xyz_valu_supported(int m, int c, int nsample, int num_layers, const int* widths);                          // sa_xyz.hip
 int sa_xyz_valu_launch(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const int* idx,

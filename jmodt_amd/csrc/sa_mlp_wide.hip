@@ -44,8 +44,6 @@ struct SaWideParams {
     const float* xyz;        // (B,N,3)
     const float* new_xyz;    // (B,M,3) or null (GroupAll)
     const float* feat;       // (B,C,N) or null
-    const float* feat_pm;    // the same features point-major (B,N,C), C % 4 == 0, or null: a gathered row is then C contiguous floats
-                             // (16-byte loads) instead of C loads from C different cache lines
     const int* idx;          // (B,M,ns) or null (GroupAll: point r of the frame)
     int L;                   // 2 or 3
     int kp[4];               // kp[l] = padded input channels of layer l (kp[0]: first-layer layout of sa_mlp_pack)
@@ -141,9 +139,6 @@ sa_mlp_wide_kernel(SaWideParams p) {
         }
         const float* feat_b = p.feat ? p.feat + (size_t)bi * C * Nn : nullptr;
         const float* pt = p.xyz + ((size_t)bi * Nn + gidx) * 3;
-        const float* feat_row = p.feat_pm ? p.feat_pm + ((size_t)bi * Nn + gidx) * C : nullptr;
-        const bool pm = p.feat_pm != nullptr;
-        const float relx = pt[0] - cx, rely = pt[1] - cy, relz = pt[2] - cz;   // (the same subtractions as `myrel` below)
 
         // xyz slots Cp, Cp+1, Cp+2 (Cp % 16 == 0) belong to the threads with gc = 0, 1, 2: one component each, loaded once
         const float myrel = gc < 3 ? pt[gc] - (gc == 0 ? cx : (gc == 1 ? cy : cz)) : 0.f;
@@ -151,26 +146,6 @@ sa_mlp_wide_kernel(SaWideParams p) {
         float gg[16];
         // (captures by value, no select among captured variables inside: such a select becomes an indexed load from the
         // closure object, which then lives in scratch together with gg)
-        // point-major features: thread (row, gc) fetches the channel QUADS gc + 8 j (j < 4) of the chunk as one 16-byte load
-        // each; the xyz group behind the features comes from registers
-        auto issue_pm = [=, &gg](int c) __attribute__((always_inline)) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k0 = c * SW_KC + 4 * (gc + 8 * j);
-                const bool isf = k0 < C;                          // C % 4 == 0: a quad is all features or none
-                const float4 v = *reinterpret_cast<const float4*>(isf ? feat_row + k0 : feat_row);   // unconditional, valid address
-                gg[4 * j + 0] = isf ? v.x : (k0 == Cp ? relx : 0.f);
-                gg[4 * j + 1] = isf ? v.y : (k0 == Cp ? rely : 0.f);
-                gg[4 * j + 2] = isf ? v.z : (k0 == Cp ? relz : 0.f);
-                gg[4 * j + 3] = isf ? v.w : 0.f;
-            }
-        };
-        auto park_pm = [=, &gg](float* Xb) __attribute__((always_inline)) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) Xb[(4 * (gc + 8 * j) + t) * SW_LD + (tid & 31)] = gg[4 * j + t];
-        };
         auto issue = [=, &gg](int c) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -262,16 +237,17 @@ sa_mlp_wide_kernel(SaWideParams p) {
         const int nb0 = np0 >> 7;
         set_bias(acc0[0], bs0, wave);
         if (nb0 > 1) set_bias(acc0[1], bs0, wave + 4);
-        if (pm) { issue_pm(0); park_pm(X); } else { issue(0); park(X); }
+        issue(0);
+        park(X);
         lds_barrier();
         for (int c = 0; c < nchunks; ++c) {
             const bool more = c + 1 < nchunks;
-            if (more) { if (pm) issue_pm(c + 1); else issue(c + 1); }   // loads in flight under this chunk's MFMAs
+            if (more) issue(c + 1);                               // loads in flight under this chunk's MFMAs
             const int kc = min(SW_KC, K0 - c * SW_KC);            // multiple of 16
             const float* bp = W0 + ((size_t)c * (SW_KC / 16) * np0 + wave * 32 + lr) * 16 + lk * 8;
             if (nb0 > 1) wide_ktiles_deep<2, SW_ST>(X + (c & 1) * SW_XBUF, kc / 16, bp, (size_t)np0 * 16, a_off, acc0);
             else wide_ktiles_deep<1, SW_ST>(X + (c & 1) * SW_XBUF, kc / 16, bp, (size_t)np0 * 16, a_off, acc0);
-            if (more) { if (pm) park_pm(X + ((c + 1) & 1) * SW_XBUF); else park(X + ((c + 1) & 1) * SW_XBUF); lds_barrier(); }
+            if (more) { park(X + ((c + 1) & 1) * SW_XBUF); lds_barrier(); }
         }
         store_hidden(acc0[0], HA, wave);
         if (nb0 > 1) store_hidden(acc0[1], HA, wave + 4);
@@ -309,8 +285,7 @@ const char* sa_wide_unsupported(long long b, int n, int m, int c, int nsample, i
 // cls_count / glist: the listed mode's plan (sa_groups.hip), both null for the dense mode
 int sa_mlp_wide_launch(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                        const float* features, const int* idx, int L, const int* widths, const float* const* weights,
-                       const float* const* biases, float* out, size_t obs, hipStream_t s, const int* cls_count, const int* glist,
-                       const float* features_pm) {
+                       const float* const* biases, float* out, size_t obs, hipStream_t s, const int* cls_count, const int* glist) {
     const char* why = sa_wide_unsupported(b, n, m, c, nsample, idx == nullptr, L, widths);
     JM_REQUIRE(why == nullptr, "sa_mlp (wide): unsupported shape, needs %s", why);
     JM_REQUIRE((cls_count == nullptr) == (glist == nullptr), "sa_mlp (wide): class counts and group list are both given or both NULL");
@@ -318,9 +293,6 @@ int sa_mlp_wide_launch(int b, int n, int m, int c, int nsample, const float* xyz
     SaWideParams p{};
     p.N = n; p.M = m; p.C = c; p.ns = nsample;
     p.xyz = xyz; p.new_xyz = new_xyz; p.feat = features; p.idx = idx; p.L = L;
-    JM_REQUIRE(!features_pm || (features && c % 4 == 0 && idx && (reinterpret_cast<uintptr_t>(features_pm) & 15u) == 0),
-               "sa_mlp (wide): point-major features need C %% 4 == 0, 16-byte alignment and neighbour lists");
-    p.feat_pm = features_pm;
     p.kp[0] = pad_to(widths[0] - 3, 16) + 16;                      // == sa_first_kp(widths[0]) of sa_mlp.hip
     for (int l = 1; l <= L; ++l) p.kp[l] = pad_to(widths[l], 16);
     for (int l = 0; l < L; ++l) {

@@ -417,7 +417,6 @@ def _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp, out=None, listed=True, p
     return out
 
 
-WIDE_POINT_MAJOR = True   # listed wide scales gather their rows from a point-major copy of the level's features
 LISTED = True         # duplicate-aware form of the RPN scales (csrc/sa_groups.hip): rows executed 2^ceil(log2 d) per group of d
                       # distinct neighbours instead of nsample; bit-identical output
 
@@ -490,13 +489,12 @@ class ListedStats:
 @torch.no_grad()
 def sa_mlp_fused(xyz: torch.Tensor, new_xyz: Optional[torch.Tensor], features: Optional[torch.Tensor],
                  idx: Optional[torch.Tensor], mlp: nn.Sequential, out: Optional[torch.Tensor] = None, listed: bool = True,
-                 plan=None, features_pm: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 plan=None) -> torch.Tensor:
     """xyz (B,N,3), new_xyz (B,M,3), features (B,C,N) or None, idx (B,M,ns) int32 -> (B, mlp_out, M);
     idx = new_xyz = None: GroupAll (one group of all N points per frame, xyz not re-centred) -> (B, mlp_out, 1).
     out: optional (B, mlp_out, M) view to write into — a channel slice of a wider tensor (the MSG concatenation in place).
     listed: take the duplicate-aware form where a kernel has one (same bits, fewer rows); plan: its (cls_count, glist) when the
-    caller planned already (group_plan_dual for the two scales of a level, with this scale's listed_qmin); features_pm: the
-    features once more as (B, N, C) for the wide kernel's row gathers (made here when the caller has none)"""
+    caller planned already (group_plan_dual for the two scales of a level, with this scale's listed_qmin)"""
     lib = L.load()
     if idx is not None and _can_pre_project(mlp, features, idx, idx.shape[1], idx.shape[2]):
         return _sa_mlp_fused_pre(xyz, new_xyz, features, idx, mlp, out, listed, plan)
@@ -517,16 +515,9 @@ def sa_mlp_fused(xyz: torch.Tensor, new_xyz: Optional[torch.Tensor], features: O
     if kind:
         idx = idx.contiguous()
         cnt, gl = plan if plan is not None else group_plan(idx, int(lib.jm_sa_mlp_listed_qmin(kind)))
-        if kind == 2 and feats is not None and C % 4 == 0 and WIDE_POINT_MAJOR:
-            if features_pm is None:
-                features_pm = feats.transpose(1, 2).contiguous()       # (B, N, C): one small copy, rows then load 16 bytes at a time
-            assert tuple(features_pm.shape) == (B, N, C) and features_pm.is_contiguous()
-        else:
-            features_pm = None
         L.check(lib.jm_sa_mlp_forward_listed(B, N, M, C, ns, L.dev(xyz.contiguous(), _f32, "xyz"), L.dev(new_xyz.contiguous(), _f32, "new_xyz"),
                                              L.dev(feats, _f32, "features") if feats is not None else None, L.dev(idx, _i32, "idx"),
                                              nl, widths_c, warr, barr, ctypes.c_void_p(cnt.data_ptr()), ctypes.c_void_p(gl.data_ptr()),
-                                             L.dev(features_pm, _f32, "features_pm") if features_pm is not None else None,
                                              ctypes.c_void_p(out.data_ptr()), stride, L.stream_ptr()), "sa_mlp_fused(listed)")
         ListedStats.last.append((prof._key("sa_mlp_forward_listed"), B * M * ns, ns, cnt))
         del ListedStats.last[:-16]

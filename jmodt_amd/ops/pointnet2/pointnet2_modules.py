@@ -59,7 +59,6 @@ class _PointnetSAModuleBase(nn.Module):
 
         # duplicate-aware form (csrc/sa_groups.hip): the two scales' group plans from ONE launch where both take it
         plans = [None] * len(self.groupers)
-        feats_pm = None
         if (len(self.groupers) == 2 and neigh[0] is not None and self.fuse and self.pool_method == "max_pool" and xyz.is_cuda
                 and not torch.is_grad_enabled() and not self.training and all(g.use_xyz for g in self.groupers)):
             qm = [fused.listed_qmin(m, features, nb, xyz.shape[0], xyz.shape[1])
@@ -68,9 +67,6 @@ class _PointnetSAModuleBase(nn.Module):
             if min(qm) >= 0:
                 neigh = [nb.contiguous() for nb in neigh]
                 plans = list(fused.group_plan_dual(neigh[0], qm[0], neigh[1], qm[1]))
-                if (features is not None and fused.WIDE_POINT_MAJOR and features.shape[1] % 4 == 0
-                        and any(fused.listed_kind(m, features, nb, xyz.shape[0], xyz.shape[1]) == 2 for m, nb in zip(self.mlps, neigh))):
-                    feats_pm = features.to(torch.float32).transpose(1, 2).contiguous()     # once for both scales
 
         pooled = []
         # multi-scale grouping: the fused scales write straight into their channel slice of the concatenated result
@@ -91,7 +87,7 @@ class _PointnetSAModuleBase(nn.Module):
                 # eval / no-grad: group + MLP + max-pool in one fp32-MFMA kernel, nothing materialised
                 if nb is None:
                     nb = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
-                pooled.append(fused.sa_mlp_fused(xyz, new_xyz, features, nb, mlp, out=slot, plan=plan, features_pm=feats_pm))
+                pooled.append(fused.sa_mlp_fused(xyz, new_xyz, features, nb, mlp, out=slot, plan=plan))
                 continue
             if (eligible and isinstance(grouper, pointnet2_utils.GroupAll)
                     and fused.can_fuse(mlp, 1, xyz.shape[1], self.training, xyz.shape[0], xyz.shape[1], group_all=True)):
