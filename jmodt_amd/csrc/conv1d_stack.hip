@@ -17,6 +17,18 @@
 // v_mfma_f32_32x32x2_f32: exact-f32 products, 1e-4 parity with the fp32 reference path.
 #include "jm_mfma.h"
 
+// (A/B switch of the weight prefetch depth, jm_mfma.h: -DJM_WK_DEEP=4 requests a group of four k-tiles ahead)
+#ifndef JM_WK_DEEP
+#define JM_WK_DEEP 0
+#endif
+#if JM_WK_DEEP
+#define JM_WK2(...) wide_ktiles_deep<2, JM_WK_DEEP>(__VA_ARGS__)
+#define JM_WK1(...) wide_ktiles_deep<1, JM_WK_DEEP>(__VA_ARGS__)
+#else
+#define JM_WK2(...) wide_ktiles<2>(__VA_ARGS__)
+#define JM_WK1(...) wide_ktiles<1>(__VA_ARGS__)
+#endif
+
 namespace jm {
 
 struct ConvStackParams {
@@ -92,12 +104,12 @@ conv1d_stack_kernel(ConvStackParams p) {
             set_bias(acc[0], bias, cb);
             if (j0 + 1 < nb) {
                 set_bias(acc[1], bias, cb + 4);
-                wide_ktiles<2>(Aa, kap / 16, Wa + off, st, offa, acc, lda);
-                if (Ab) wide_ktiles<2>(Ab, kbp / 16, Wb + off, st, offb, acc, ldb);
+                JM_WK2(Aa, kap / 16, Wa + off, st, offa, acc, lda);
+                if (Ab) JM_WK2(Ab, kbp / 16, Wb + off, st, offb, acc, ldb);
                 fin(acc[0], cb); fin(acc[1], cb + 4);
             } else {
-                wide_ktiles<1>(Aa, kap / 16, Wa + off, st, offa, acc, lda);
-                if (Ab) wide_ktiles<1>(Ab, kbp / 16, Wb + off, st, offb, acc, ldb);
+                JM_WK1(Aa, kap / 16, Wa + off, st, offa, acc, lda);
+                if (Ab) JM_WK1(Ab, kbp / 16, Wb + off, st, offb, acc, ldb);
                 fin(acc[0], cb);
             }
         }

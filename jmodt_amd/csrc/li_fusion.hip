@@ -18,6 +18,18 @@
 // v_mfma_f32_32x32x2_f32: exact-f32 products, 1e-4 parity with the fp32 reference path.
 #include "jm_mfma.h"
 
+// (A/B switch of the weight prefetch depth, jm_mfma.h: -DJM_WK_DEEP=4 requests a group of four k-tiles ahead)
+#ifndef JM_WK_DEEP
+#define JM_WK_DEEP 0
+#endif
+#if JM_WK_DEEP
+#define JM_WK2(...) wide_ktiles_deep<2, JM_WK_DEEP>(__VA_ARGS__)
+#define JM_WK1(...) wide_ktiles_deep<1, JM_WK_DEEP>(__VA_ARGS__)
+#else
+#define JM_WK2(...) wide_ktiles<2>(__VA_ARGS__)
+#define JM_WK1(...) wide_ktiles<1>(__VA_ARGS__)
+#endif
+
 namespace jm {
 
 struct LiFusionParams {
@@ -84,12 +96,12 @@ attention_fusion_kernel(LiFusionParams p) {
             set_bias(acc[0], bias, cb);
             if (j0 + 1 < nb) {
                 set_bias(acc[1], bias, cb + 4);
-                wide_ktiles<2>(A0, k0p / 16, Wa + off, st, off0, acc, lda0);
-                if (A1) wide_ktiles<2>(A1, k1p / 16, Wb + off, st, off1, acc, lda1);
+                JM_WK2(A0, k0p / 16, Wa + off, st, off0, acc, lda0);
+                if (A1) JM_WK2(A1, k1p / 16, Wb + off, st, off1, acc, lda1);
                 fin(acc[0], cb); fin(acc[1], cb + 4);
             } else {
-                wide_ktiles<1>(A0, k0p / 16, Wa + off, st, off0, acc, lda0);
-                if (A1) wide_ktiles<1>(A1, k1p / 16, Wb + off, st, off1, acc, lda1);
+                JM_WK1(A0, k0p / 16, Wa + off, st, off0, acc, lda0);
+                if (A1) JM_WK1(A1, k1p / 16, Wb + off, st, off1, acc, lda1);
                 fin(acc[0], cb);
             }
         }
