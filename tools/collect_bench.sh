@@ -3,14 +3,18 @@
 #   gpurun --timeout 2400 -- 'bash tools/collect_bench.sh'
 OUT=gpurun_out/bench_lines
 mkdir -p $OUT
-python bench.py 2>$OUT/default.err | grep "^{" > $OUT/default.json
-for w in train sa ops dense dense_detect; do
-    python bench.py --workload $w --no-cpu-baseline 2>$OUT/$w.err | grep "^{" > $OUT/$w.json
+# <name>.json = the FULL record (kernel table, variants, parity block), <name>.line.json = the compact stdout line
+python bench.py --full-out $OUT/default.json 2>$OUT/default.err | grep "^{" > $OUT/default.line.json
+python bench.py --workload sa --full-out $OUT/sa.json 2>$OUT/sa.err | grep "^{" > $OUT/sa.line.json
+for w in train ops dense dense_detect; do
+    python bench.py --workload $w --no-cpu-baseline --full-out $OUT/$w.json 2>$OUT/$w.err | grep "^{" > $OUT/$w.line.json
 done
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --workload train --no-cpu-baseline 2>$OUT/train_launch.err | grep "^{" > $OUT/train_launch.json
-for f in $OUT/*.json; do python - "$f" <<'PY'
+python bench.py --cloud kitti --no-cpu-baseline --full-out $OUT/detect_kitti.json 2>$OUT/detect_kitti.err | grep "^{" > $OUT/detect_kitti.line.json
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --workload train --no-cpu-baseline --full-out $OUT/train_launch.json 2>$OUT/train_launch.err | grep "^{" > $OUT/train_launch.line.json
+python bench.py --workload train --joint --launch --no-cpu-baseline --steps 6 --warmup 2 --full-out $OUT/train_joint_launch.json 2>$OUT/train_joint_launch.err | grep "^{" > $OUT/train_joint_launch.line.json
+for f in $OUT/*.line.json; do python - "$f" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
-print(sys.argv[1].split("/")[-1], d["value"], d["unit"], d["ms_per_step"], d.get("roofline", {}).get("kernel"), d.get("roofline", {}).get("frac"))
+print(sys.argv[1].split("/")[-1], d["value"], d["unit"], d["ms_per_step"], (d.get("roofline") or {}).get("kernel"), (d.get("roofline") or {}).get("frac"))
 PY
 done
