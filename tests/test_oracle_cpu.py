@@ -93,6 +93,31 @@ def test_ball_query_edge_cases(oracle):
     assert np.array_equal(idx[0, 0], [0, 1, 2])           # > nsample hits: first nsample in index order
 
 
+@pytest.mark.parametrize("kind,radius,nsample", [("uniform", 0.5, 32), ("kitti", 0.5, 32), ("packed", 0.5, 16), ("uniform", 0.1, 16)])
+def test_ball_query_lists_end_in_copies_of_their_first_hit(oracle, kind, radius, nsample):
+    """what the duplicate-aware (listed) set abstraction of round 4 relies on, stated against the oracle's restatement of
+    ball_query_gpu.cu:36-45: a list is `cnt` strictly ascending point indices followed by nsample - cnt copies of the first, so
+    with d = 1 + the last slot that differs from slot 0 (csrc/sa_groups.hip) the first d rows hold every distinct row of the
+    group, and max-pooling the first 2^ceil(log2 d) rows of the grouped tensor equals max-pooling all nsample"""
+    xyz = synth.frames(1, 4096, 21, kind=kind)[0]
+    centres = xyz[:, ::5].copy()
+    idx = oracle.ball_query(radius, nsample, xyz, centres)[0]
+    feats = np.random.default_rng(2).normal(size=(1, 7, xyz.shape[1])).astype(np.float32)
+    grouped = oracle.grouping_operation(feats, idx[None])[0]                      # (C, M, nsample)
+    rows_full, rows_listed = 0, 0
+    for m, row in enumerate(idx):
+        differ = np.nonzero(row != row[0])[0]
+        d = 1 + (differ[-1] if len(differ) else 0)
+        assert np.all(np.diff(row[:d]) > 0) and np.all(row[d:] == row[0]), (m, row)
+        q = int(np.ceil(np.log2(d))) if d > 1 else 0
+        assert np.array_equal(grouped[:, m, :1 << q].max(-1), grouped[:, m].max(-1))
+        rows_full += nsample
+        rows_listed += 1 << q
+    assert rows_listed <= rows_full
+    if kind != "packed":
+        assert rows_listed < 0.5 * rows_full                                       # most rows of a sparse cloud are copies
+
+
 # ------------------------------------------------------------------ gather / group / 3nn / interpolate
 def test_gather_group_interp(oracle):
     rng = np.random.default_rng(3)
