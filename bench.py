@@ -91,7 +91,7 @@ def rcnn_rows():
     """(dense rows, executed rows) of the duplicate-compacted RCNN scales of the LAST forward (device counters: call after a
     synchronize)"""
     from jmodt_amd.ops.pointnet2 import fused
-    return {name: {"rows_dense": int(dense), "rows_executed": int(cnt[1].item()) * 128} for name, dense, cnt in fused.DedupeStats.last}
+    return {e[0]: {"rows_dense": int(e[1]), "rows_executed": fused.DedupeStats.rows_executed(e)} for e in fused.DedupeStats.last}
 
 
 def listed_rows():

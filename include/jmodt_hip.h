@@ -182,6 +182,8 @@ int jm_sa_mlp_forward_pre(int b, int n, int m, int c, int nsample, const float* 
  * jm_sa_mlp_listed_qmin its smallest class. */
 size_t jm_sa_group_list_elems(int groups, int nsample);
 int jm_sa_group_plan(int groups, int nsample, const int* idx, int qmin, int* cls_count, int* glist, jm_stream_t stream);
+int jm_sa_group_plan_dev(int groups, int nsample, const int* idx, int qmin, const int* groups_dev, int* cls_count, int* glist,
+                         jm_stream_t stream);   /* valid groups = min(groups_dev[0], groups), read on the device */
 int jm_sa_group_plan_dual(int groups, int nsample0, const int* idx0, int qmin0, int nsample1, const int* idx1, int qmin1,
                           int* cls_count, int* glist0, int* glist1, jm_stream_t stream);
 int jm_sa_mlp_listed_supported(int b, int n, int m, int c, int nsample, int num_layers, const int* widths);
@@ -192,8 +194,10 @@ int jm_sa_mlp_forward_listed(int b, int n, int m, int c, int nsample, const floa
                              float* out, size_t out_frame_stride, jm_stream_t stream);
 
 /* the pre-projected two-layer block (jm_sa_mlp_pm_forward_into) in the listed form: plan from jm_sa_group_plan with
- * qmin = jm_sa_mlp_pm_listed_qmin() (= 2: sa_mlp_pm_kernel's accumulator layout pools four consecutive rows in a lane) */
-int jm_sa_mlp_pm_listed_qmin(void);
+ * qmin = jm_sa_mlp_pm_listed_qmin(c, hidden, cout): 2 (sa_mlp_pm_kernel's accumulator layout pools four consecutive rows in a
+ * lane), 3 where the per-quad tables do not fit the LDS next to the tiles (C = hidden = 128: the RCNN scales, through
+ * fused.sa_scale_pm_dedupe), -1: no listed form */
+int jm_sa_mlp_pm_listed_qmin(int c, int hidden, int cout);
 int jm_sa_mlp_pm_listed_supported(int b, int n, int m, int c, int nsample, int hidden, int cout);
 int jm_sa_mlp_pm_forward_listed(int b, int n, int m, int c, int nsample, int hidden, int cout, const float* u_point_major,
                                 const float* w1x, const float* new_xyz, const int* idx, const float* w_hidden,

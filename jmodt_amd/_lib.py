@@ -71,12 +71,13 @@ SIGNATURES = {
                                         ctypes.POINTER(_P), _P, _Z, _P]),
     "jm_sa_group_list_elems": (_Z, [_I, _I]),
     "jm_sa_group_plan": (_I, [_I, _I, _P, _I, _P, _P, _P]),
+    "jm_sa_group_plan_dev": (_I, [_I, _I, _P, _I, _P, _P, _P, _P]),
     "jm_sa_group_plan_dual": (_I, [_I, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P]),
     "jm_sa_mlp_listed_supported": (_I, [_I, _I, _I, _I, _I, _I, ctypes.POINTER(_I)]),
     "jm_sa_mlp_listed_qmin": (_I, [_I]),
     "jm_sa_mlp_forward_listed": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, ctypes.POINTER(_I), ctypes.POINTER(_P),
                                       ctypes.POINTER(_P), _P, _P, _P, _Z, _P]),
-    "jm_sa_mlp_pm_listed_qmin": (_I, []),
+    "jm_sa_mlp_pm_listed_qmin": (_I, [_I, _I, _I]),
     "jm_sa_mlp_pm_listed_supported": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "jm_sa_mlp_pm_forward_listed": (_I, [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "jm_sa_mlp_pm_forward_into": (_I, [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),

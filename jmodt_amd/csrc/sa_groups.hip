@@ -30,6 +30,7 @@ int sa_xyz_valu_launch(int b, int n, int m, int nsample, const float* xyz, const
 
 // cls_count[0..7] zeroed by the caller (hipMemsetAsync in the entry); glist: (qfull + 1) x groups
 struct SgPlan {                       // up to two problems over the same groups (the two scales of an MSG level): blockIdx.y
+    const int* groups_dev;            // optional: the number of valid groups lives in device memory (<= groups; sa_dedupe's virtual centres)
     int ns[2], qmin[2];
     const int* idx[2];
     int* cls_count[2];
@@ -63,7 +64,8 @@ sg_plan_kernel(int groups, SgPlan pl) {
     int* __restrict__ cls_count = pl.cls_count[y];
     int* __restrict__ glist = pl.glist[y];
     int q = -1, rank = 0;
-    if (g < groups) {
+    const int valid = pl.groups_dev ? min(*pl.groups_dev, groups) : groups;
+    if (g < valid) {
         const int* row = idx + (size_t)g * NS;
         const int d = NS == 16 ? sg_rows_needed<16>(row) : (NS == 32 ? sg_rows_needed<32>(row) : sg_rows_needed<64>(row));
         q = d <= 1 ? 0 : 32 - __clz(d - 1);                       // ceil(log2 d)
@@ -121,6 +123,22 @@ extern "C" int jm_sa_group_plan(int groups, int nsample, const int* idx, int qmi
     pl.ns[0] = nsample; pl.qmin[0] = qmin; pl.idx[0] = idx; pl.cls_count[0] = cls_count; pl.glist[0] = glist;
     hipLaunchKernelGGL(sg_plan_kernel, dim3((unsigned)divup(groups, 256), 1), dim3(256), 0, s, groups, pl);
     return check_launch("sa_group_plan");
+}
+
+/* the same with the number of valid groups read from device memory (groups_dev[0] <= groups; the rows behind it are never read):
+ * the duplicate-compacted RCNN scales plan their virtual centres (csrc/sa_dedupe.hip), whose count is data dependent */
+extern "C" int jm_sa_group_plan_dev(int groups, int nsample, const int* idx, int qmin, const int* groups_dev, int* cls_count, int* glist,
+                                    jm_stream_t stream) {
+    if (int rc = sg_check(groups, nsample, idx, qmin, cls_count, glist)) return rc;
+    JM_REQUIRE(groups_dev, "sa_group_plan_dev: null group count");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(cls_count, 0, 8 * sizeof(int), s) != hipSuccess) { set_error("sa_group_plan: memset failed"); return JM_ELAUNCH; }
+    if (groups == 0) return JM_OK;
+    SgPlan pl{};
+    pl.groups_dev = groups_dev;
+    pl.ns[0] = nsample; pl.qmin[0] = qmin; pl.idx[0] = idx; pl.cls_count[0] = cls_count; pl.glist[0] = glist;
+    hipLaunchKernelGGL(sg_plan_kernel, dim3((unsigned)divup(groups, 256), 1), dim3(256), 0, s, groups, pl);
+    return check_launch("sa_group_plan_dev");
 }
 
 /* the two scales of one multi-scale level (same centres, two neighbour lists) in ONE launch: cls_count = 16 ints

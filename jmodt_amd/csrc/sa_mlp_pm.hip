@@ -45,8 +45,9 @@ struct SaPmParams {
     int tiles_per_frame, total_tiles, xcd_frames;
     const int* total_dev;                  // non-null: the number of tiles is read from device memory (<= total_tiles; the
                                            // duplicate-compacted form of sa_dedupe.hip, whose row count is data dependent)
-    int groups, qfull;                     // LISTED (sa_groups.hip): B * M, log2(ns)
-    const int* cls_count;                  // LISTED: [8] groups per class q of 2^q rows, q >= PM_QMIN (device memory)
+    int groups, qfull, qmin;               // LISTED (sa_groups.hip): B * M, log2(ns), smallest class (2: row quads, 3: octets)
+    int vt_floats, p_cols;                 // LISTED: floats of the per-centre table, columns of the partial-maximum rows
+    const int* cls_count;                  // LISTED: [8] groups per class q of 2^q rows, q >= qmin (device memory)
     const int* glist;                      // LISTED: class q's group ids b * M + i at glist[q * groups ...]
 #ifdef JM_TOOLS_BUILD
     int dbg;                               // tools build (JM_PM_DBG): timing experiments, wrong results
@@ -355,16 +356,15 @@ sa_mlp_pm_kernel(SaPmParams p) {
     else pm_gather_role<4>(p, lds, tid - 512);
 }
 
+constexpr int PM_QMIN_DEFAULT = 2;
 // =============================================================================== LISTED mode (round 4, sa_groups.hip)
 // ball_query back-fills a list of cnt < nsample hits with copies of its first hit (ball_query_gpu.cu:36-40) and the max-pool is
-// idempotent: a group of class q only needs its first 2^q rows (q >= PM_QMIN = 2: the accumulator layout pools four
-// consecutive rows inside a lane).  A 128-row tile holds 128 >> q groups of ONE class; its rows, the per-centre table and the
-// output positions go through the class list (group id -> frame, centre); the pool partials are kept per QUAD of rows
-// (32 quads x 2 .. 8 per group) instead of per 16-row half block.  The k-loops, their operand order and the bias / ReLU
-// epilogues are the dense kernel's (pm_ktiles), so a row's value — and therefore every output — is bit-identical.
-constexpr int PM_QMIN = 2;
-constexpr int PM_VT_L = 32 * 128;          // per-centre table: <= 32 centres x <= 128 channels
-constexpr int PM_P_L = 32 * PM_PW;         // max-pool partials: 32 row quads x PM_PW columns
+// idempotent: a group of class q only needs its first 2^q rows.  A 128-row tile holds 128 >> q groups of ONE class; its rows,
+// the per-centre table and the output positions go through the class list (group id -> frame, centre); the pool partials are
+// kept per row QUAD (smallest class q_min = 2: the accumulator layout pools four consecutive rows inside a lane) or per row
+// OCTET (q_min = 3: + one exchange between the lane halves) instead of per 16-row half block — q_min = 3 where the quads' table
+// and partials would not fit the LDS next to 128-wide tiles (the RCNN scales).  The k-loops, their operand order and the bias /
+// ReLU epilogues are the dense kernel's (pm_ktiles), so a row's value — and therefore every output — is bit-identical.
 
 struct PmListedSchedule {
     int ts[8], total, n_local, nwg;
@@ -373,7 +373,7 @@ struct PmListedSchedule {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             ts[c] = acc_t;
-            if (c >= PM_QMIN && c <= p.qfull) acc_t += (int)((((long long)p.cls_count[c] << c) + PM_BM - 1) / PM_BM);
+            if (c >= p.qmin && c <= p.qfull) acc_t += (int)((((long long)p.cls_count[c] << c) + PM_BM - 1) / PM_BM);
         }
         total = acc_t; nwg = gridDim.x;
         n_local = total > (int)blockIdx.x ? (total - (int)blockIdx.x + nwg - 1) / nwg : 0;
@@ -381,10 +381,10 @@ struct PmListedSchedule {
     // tile i of this workgroup: class q, first slot of the class list, groups in the class
     __device__ void tile(const SaPmParams& p, int i, int& q, int& slot0, int& cnt) const {
         const int t = (int)blockIdx.x + i * nwg;
-        q = PM_QMIN;
+        q = p.qmin;
 #pragma unroll
-        for (int c = PM_QMIN + 1; c < 8; ++c)
-            if (c <= p.qfull && t >= ts[c]) q = c;            // the last class that starts at or before t (empty classes lose)
+        for (int c = 3; c < 8; ++c)
+            if (c > p.qmin && c <= p.qfull && t >= ts[c]) q = c;   // the last class that starts at or before t (empty classes lose)
         int start = 0;
 #pragma unroll
         for (int c = 0; c < 8; ++c)
@@ -404,8 +404,9 @@ __device__ __forceinline__ void pm_mfma_role_listed(const SaPmParams& p, float* 
     float* X0 = lds;
     float* X1 = X0 + (size_t)PM_BM * p.S0;
     float* VT = X1 + (size_t)PM_BM * p.S1;
-    float* P = VT + PM_VT_L;                                        // [32 quads][PM_PW]
-    float* B1 = P + PM_P_L;                                         // the hidden layer's bias (np1 floats)
+    float* P = VT + p.vt_floats;                                    // [128 >> qmin row quads / octets][p_cols]
+    const int pcols = p.p_cols, qmin = p.qmin;
+    float* B1 = P + (size_t)(PM_BM >> qmin) * pcols;                // the hidden layer's bias (np1 floats)
     float* B2 = B1 + p.np1;                                         // the last layer's bias (np2 floats)
     const int C = p.C, cout = p.cout;
     const int row = rb * 32 + lr;
@@ -483,23 +484,29 @@ __device__ __forceinline__ void pm_mfma_role_listed(const SaPmParams& p, float* 
                 if (j < nb) {
                     const int col = (b0 + 2 * j) * 32 + lr;
 #pragma unroll
-                    for (int rq = 0; rq < 4; ++rq)                  // rows 8 rq + 4 lk .. + 3 of the block = quad rb * 8 + 2 rq + lk
-                        P[(rb * 8 + 2 * rq + lk) * PM_PW + col] =
-                            fmaxf(fmaxf(acc[j][4 * rq], acc[j][4 * rq + 1]), fmaxf(acc[j][4 * rq + 2], acc[j][4 * rq + 3]));
+                    for (int rq = 0; rq < 4; ++rq) {                // rows 8 rq + 4 lk .. + 3 of the block = quad rb * 8 + 2 rq + lk
+                        float v = fmaxf(fmaxf(acc[j][4 * rq], acc[j][4 * rq + 1]), fmaxf(acc[j][4 * rq + 2], acc[j][4 * rq + 3]));
+                        if (qmin == 2) {
+                            P[(size_t)(rb * 8 + 2 * rq + lk) * pcols + col] = v;
+                        } else {                                    // octet rb * 4 + rq = this quad and the other lane half's
+                            v = fmaxf(v, __shfl_xor(v, 32));
+                            if (lk == 0) P[(size_t)(rb * 4 + rq) * pcols + col] = v;
+                        }
+                    }
                 }
             }
         }
         lds_barrier();                                              // B2
         // ---------------- max over each group's 2^q rows = 2^(q-2) quads, + bias, ReLU (both commute with max)
         {
-            const int ncen = PM_BM >> q, qpg = 1 << (q - 2);
+            const int ncen = PM_BM >> q, qpg = 1 << (q - qmin);
             for (int e = tid; e < ncen * cout; e += 512) {
                 const int col = e / ncen, c = e - col * ncen;
                 if (slot0 + c < cnt) {
                     const int g = p.glist[(size_t)q * p.groups + slot0 + c];
-                    const float* pp = P + (size_t)(c * qpg) * PM_PW + col;
+                    const float* pp = P + (size_t)(c * qpg) * pcols + col;
                     float t = pp[0];
-                    for (int h = 1; h < qpg; ++h) t = fmaxf(t, pp[(size_t)h * PM_PW]);
+                    for (int h = 1; h < qpg; ++h) t = fmaxf(t, pp[(size_t)h * pcols]);
                     p.out[(size_t)(g / p.M) * p.obs + (size_t)col * p.M + (size_t)(g % p.M)] = fmaxf(t + B2[col], 0.f);
                 }
             }
@@ -579,8 +586,9 @@ sa_mlp_pm_listed_kernel(SaPmParams p) {
     else pm_gather_role_listed<4>(p, lds, tid - 512);
 }
 
-static size_t sa_pm_listed_lds_bytes(int c, int h, int cout) {
-    return ((size_t)PM_BM * (c + 4) + (size_t)PM_BM * (pad_to(h, 32) + 4) + PM_VT_L + PM_P_L + pad_to(h, 128) + pad_to(cout, 128)) * sizeof(float);
+static size_t sa_pm_listed_lds_bytes(int c, int h, int cout, int qmin) {
+    return ((size_t)PM_BM * (c + 4) + (size_t)PM_BM * (pad_to(h, 32) + 4) + (size_t)(PM_BM >> qmin) * c +
+            (size_t)(PM_BM >> qmin) * pad_to(cout, 128) + pad_to(h, 128) + pad_to(cout, 128)) * sizeof(float);
 }
 
 static size_t sa_pm_lds_bytes(int c, int h) {
@@ -676,14 +684,21 @@ extern "C" int jm_sa_mlp_pm_forward_dyn(int n, int m, int c, int nsample, int hi
                             0, tiles_dev, stream);
 }
 
-/* LISTED form (csrc/sa_groups.hip; jm_sa_group_plan with qmin = jm_sa_mlp_pm_listed_qmin() = 2): the same block on tiles of one
- * class each, 2^q rows per group, outputs at the groups' own positions; bit-identical to jm_sa_mlp_pm_forward_into */
-extern "C" int jm_sa_mlp_pm_listed_qmin(void) { return PM_QMIN; }
+/* LISTED form (csrc/sa_groups.hip): the same block on tiles of one class each, 2^q rows per group, outputs at the groups' own
+ * positions; bit-identical to jm_sa_mlp_pm_forward_into.  jm_sa_mlp_pm_listed_qmin: the smallest class this shape tiles — 2 (row
+ * quads), or 3 (octets) where the quads' table and partial maxima do not fit the LDS next to the tiles (C = hidden = 128), or -1
+ * when the shape has no listed form; the plan must be made with that qmin (jm_sa_group_plan) */
+extern "C" int jm_sa_mlp_pm_listed_qmin(int c, int hidden, int cout) {
+    if ((c != 32 && c != 64 && c != 128) || hidden < 1 || hidden > 128 || cout < 1 || cout > PM_PW) return -1;
+    for (int q = PM_QMIN_DEFAULT; q <= 3; ++q)
+        if (sa_pm_listed_lds_bytes(c, hidden, cout, q) <= 160 * 1024) return q;
+    return -1;
+}
 
 extern "C" int jm_sa_mlp_pm_listed_supported(int b, int n, int m, int c, int nsample, int hidden, int cout) {
     if (!jm_sa_mlp_pm_supported(b, n, m, c, nsample, hidden, cout)) return 0;
     if ((long long)b * m >= (1LL << 31) / 64) return 0;
-    return sa_pm_listed_lds_bytes(c, hidden, cout) <= 160 * 1024 ? 1 : 0;
+    return jm_sa_mlp_pm_listed_qmin(c, hidden, cout) >= 0 ? 1 : 0;
 }
 
 extern "C" int jm_sa_mlp_pm_forward_listed(int b, int n, int m, int c, int nsample, int hidden, int cout, const float* u_point_major,
@@ -707,14 +722,16 @@ extern "C" int jm_sa_mlp_pm_forward_listed(int b, int n, int m, int c, int nsamp
     p.obs = out_frame_stride ? out_frame_stride : (size_t)cout * (size_t)m;
     p.S0 = c + 4; p.S1 = pad_to(hidden, 32) + 4;
     p.groups = b * m; p.qfull = nsample == 16 ? 4 : (nsample == 32 ? 5 : 6);
+    p.qmin = jm_sa_mlp_pm_listed_qmin(c, hidden, cout);
+    p.vt_floats = (PM_BM >> p.qmin) * c; p.p_cols = p.np2;
     p.cls_count = cls_count; p.glist = glist;
-    const size_t lds_bytes = sa_pm_listed_lds_bytes(c, hidden, cout);
+    const size_t lds_bytes = sa_pm_listed_lds_bytes(c, hidden, cout, p.qmin);
     (void)hipFuncSetAttribute((const void*)sa_mlp_pm_listed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
     // tiles <= the dense count + one partial tile per class; persistent, one workgroup per CU at most
-    const long long bound = (long long)b * m * nsample / PM_BM + (p.qfull - PM_QMIN + 1);
+    const long long bound = (long long)b * m * nsample / PM_BM + (p.qfull - p.qmin + 1);
     const int grid = (int)(bound < cus ? bound : cus);
     hipLaunchKernelGGL(sa_mlp_pm_listed_kernel, dim3((unsigned)grid), dim3(768), lds_bytes, (hipStream_t)stream, p);
     return check_launch("sa_mlp_pm (listed)");

@@ -178,7 +178,7 @@ def _sa_mlp_pm(u_pm: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w1x
         idx = idx.contiguous()
         if plan is None:
             hoisted, prof._hoisted = prof._hoisted, 0        # (the caller's hoisted-layer note belongs to the MLP call, not the plan)
-            plan = group_plan(idx, int(lib.jm_sa_mlp_pm_listed_qmin()))
+            plan = group_plan(idx, int(lib.jm_sa_mlp_pm_listed_qmin(C, hidden, cout)))
             prof._hoisted = hoisted
         cnt, gl = plan
         L.check(lib.jm_sa_mlp_pm_forward_listed(B, N, M, C, ns, hidden, cout, L.dev(u_pm, _f32, "u"), L.dev(w1x, _f32, "w1x"),
@@ -199,9 +199,21 @@ def _sa_mlp_pm(u_pm: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w1x
 DEDUPE = True         # RCNN scales: skip (centre, sample) rows that are exact copies (csrc/sa_dedupe.hip), bit-identical output
 
 
+DEDUPE_LISTED = True  # ... and run the compacted segments through the LISTED kernel (2^q rows per segment of d entries, not 16)
+
+
 class DedupeStats:
-    """device-side record of the last duplicate-compacted scales: [(name, dense rows, counters tensor)]"""
+    """device-side record of the last duplicate-compacted scales: [(name, dense rows, counters tensor, class counts or None)]"""
     last = []
+
+    @staticmethod
+    def rows_executed(entry) -> int:
+        """rows the MFMA kernel ran for one recorded scale (synchronises): 128 per tile of the 16-row form, or groups << q"""
+        _, _, counters, cls = entry
+        if cls is None:
+            return int(counters[1].item()) * 128
+        c = cls[:8].tolist()
+        return sum(int(c[q]) << q for q in range(8))
 
 
 def dedupe_applies(mlp: nn.Sequential, device, R: int, n: int, H1: int, npoint: int, nsample: int) -> bool:
@@ -248,16 +260,27 @@ def sa_scale_pm_dedupe(xyz: torch.Tensor, u_pm: torch.Tensor, mlp: nn.Sequential
                                   L.dev(vxyz, _f32, "vxyz"), L.dev(counters, _i32, "counters"), L.stream_ptr()), "sa_dedupe_plan")
     outv = torch.empty((cout, cap), dtype=_f32, device=dev)
     prof.hoisted_flops(0)
-    L.check(lib.jm_sa_mlp_pm_forward_dyn(R * n, cap, H1, 16, hidden, cout, L.dev(u_pm.contiguous(), _f32, "u"), L.dev(w1x, _f32, "w1x"),
-                                         L.dev(vxyz, _f32, "vxyz"), L.dev(vidx, _i32, "vidx"), L.dev(wh, _f32, "w_hidden"),
-                                         L.dev(bh, _f32, "b_hidden"), L.dev(wo, _f32, "w_out"), L.dev(bo, _f32, "b_out"),
-                                         ctypes.c_void_p(outv.data_ptr()), ctypes.c_void_p(counters.data_ptr() + 4), L.stream_ptr()),
-            "sa_mlp_pm(dedupe)")
+    cls = None
+    if LISTED and DEDUPE_LISTED and lib.jm_sa_mlp_pm_listed_supported(1, R * n, cap, H1, 16, hidden, cout):
+        # the virtual centres' lists ARE in ball-query form (distinct entries, padded with the first): the listed kernel runs a
+        # segment of d entries on 2^max(qmin, ceil(log2 d)) rows instead of 16 — most segments of a sparse RoI hold 1..4 rows
+        cls, gl = group_plan(vidx.view(1, cap, 16), int(lib.jm_sa_mlp_pm_listed_qmin(H1, hidden, cout)), counters[0:1])
+        L.check(lib.jm_sa_mlp_pm_forward_listed(1, R * n, cap, H1, 16, hidden, cout, L.dev(u_pm.contiguous(), _f32, "u"), L.dev(w1x, _f32, "w1x"),
+                                                L.dev(vxyz, _f32, "vxyz"), L.dev(vidx, _i32, "vidx"), L.dev(wh, _f32, "w_hidden"),
+                                                L.dev(bh, _f32, "b_hidden"), L.dev(wo, _f32, "w_out"), L.dev(bo, _f32, "b_out"),
+                                                ctypes.c_void_p(cls.data_ptr()), ctypes.c_void_p(gl.data_ptr()),
+                                                ctypes.c_void_p(outv.data_ptr()), 0, L.stream_ptr()), "sa_mlp_pm(dedupe, listed)")
+    else:
+        L.check(lib.jm_sa_mlp_pm_forward_dyn(R * n, cap, H1, 16, hidden, cout, L.dev(u_pm.contiguous(), _f32, "u"), L.dev(w1x, _f32, "w1x"),
+                                             L.dev(vxyz, _f32, "vxyz"), L.dev(vidx, _i32, "vidx"), L.dev(wh, _f32, "w_hidden"),
+                                             L.dev(bh, _f32, "b_hidden"), L.dev(wo, _f32, "w_out"), L.dev(bo, _f32, "b_out"),
+                                             ctypes.c_void_p(outv.data_ptr()), ctypes.c_void_p(counters.data_ptr() + 4), L.stream_ptr()),
+                "sa_mlp_pm(dedupe)")
     out = torch.empty((R, cout, npoint), dtype=_f32, device=dev)
     L.check(lib.jm_sa_dedupe_combine(R, npoint, cout, cap, L.dev(outv, _f32, "outv"), L.dev(rep, _i32, "rep"),
                                      L.dev(seg_start, _i32, "seg_start"), L.dev(seg_cnt, _i32, "seg_cnt"),
                                      ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "sa_dedupe_combine")
-    DedupeStats.last.append((name, R * npoint * nsample, counters))
+    DedupeStats.last.append((name, R * npoint * nsample, counters, cls))
     return new_xyz, out, rep
 
 
@@ -437,15 +460,20 @@ def listed_kind(mlp: nn.Sequential, features, idx: torch.Tensor, B: int, N: int)
 
 
 @torch.no_grad()
-def group_plan(idx: torch.Tensor, qmin: int = 0):
+def group_plan(idx: torch.Tensor, qmin: int = 0, groups_dev: Optional[torch.Tensor] = None):
     """idx (B, M, ns) int32 neighbour lists -> the listed form's plan (cls_count (8,) int32 = groups per class of 2^q rows,
-    glist = the classes' group ids), both in device memory"""
+    glist = the classes' group ids), both in device memory; groups_dev: (1,) int32 on the device = how many of the B * M groups
+    are valid (the rest of idx is never read)"""
     lib = L.load()
     B, M, ns = idx.shape
     buf = torch.empty((8 + int(lib.jm_sa_group_list_elems(B * M, ns)),), dtype=_i32, device=idx.device)
     cnt, gl = buf[:8], buf[8:]
-    L.check(lib.jm_sa_group_plan(B * M, ns, L.dev(idx, _i32, "idx"), int(qmin), ctypes.c_void_p(cnt.data_ptr()),
-                                 ctypes.c_void_p(gl.data_ptr()), L.stream_ptr()), "sa_group_plan")
+    if groups_dev is not None:
+        L.check(lib.jm_sa_group_plan_dev(B * M, ns, L.dev(idx, _i32, "idx"), int(qmin), ctypes.c_void_p(groups_dev.data_ptr()),
+                                         ctypes.c_void_p(cnt.data_ptr()), ctypes.c_void_p(gl.data_ptr()), L.stream_ptr()), "sa_group_plan_dev")
+    else:
+        L.check(lib.jm_sa_group_plan(B * M, ns, L.dev(idx, _i32, "idx"), int(qmin), ctypes.c_void_p(cnt.data_ptr()),
+                                     ctypes.c_void_p(gl.data_ptr()), L.stream_ptr()), "sa_group_plan")
     return cnt, gl
 
 
@@ -476,7 +504,8 @@ def listed_qmin(mlp: nn.Sequential, features, idx: torch.Tensor, B: int, N: int)
         if pm is None:
             return -1
         W1 = _pre_layers(mlp, idx.device)[0]
-        return int(lib.jm_sa_mlp_pm_listed_qmin()) if lib.jm_sa_mlp_pm_listed_supported(B, N, M, W1.shape[0], ns, pm[4], pm[5]) else -1
+        return (int(lib.jm_sa_mlp_pm_listed_qmin(W1.shape[0], pm[4], pm[5]))
+                if lib.jm_sa_mlp_pm_listed_supported(B, N, M, W1.shape[0], ns, pm[4], pm[5]) else -1)
     kind = listed_kind(mlp, features, idx, B, N)
     return int(lib.jm_sa_mlp_listed_qmin(kind)) if kind else -1
 

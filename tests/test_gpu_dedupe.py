@@ -100,12 +100,25 @@ def test_sa_dedupe_two_levels_bit_identical_to_dense(R, n, max_cnt):
         d2_xyz, d2_out, _ = sa2(new_xyz, out)
     assert torch.equal(res2[0], d2_xyz) and torch.equal(res2[1], d2_out)
     torch.cuda.synchronize()
-    for name, dense_rows, counters in fused.DedupeStats.last:
+    for entry in fused.DedupeStats.last:
+        name, dense_rows, counters, cls = entry
         c = counters.cpu().numpy()
         assert c[0] == c[2] and c[1] == (c[0] + 7) // 8 and 0 < c[1] * 128 <= dense_rows + 128 * 8, (name, c, dense_rows)
+        # round 4: the segments go through the LISTED kernel — every virtual centre sits in exactly one class, and a segment of
+        # d entries runs 2^max(3, ceil(log2 d)) rows (octets at the RCNN widths), never more than the 16 of the segment form
+        assert cls is not None and int(cls.sum()) == c[0] and int(cls[:3].sum()) == 0
+        assert fused.DedupeStats.rows_executed(entry) <= c[1] * 128
     if max_cnt <= 60:
-        name, dense_rows, counters = fused.DedupeStats.last[0]
-        assert int(counters[1]) * 128 < dense_rows // 8                  # few distinct points: >= 8x fewer rows
+        entry = fused.DedupeStats.last[0]
+        assert fused.DedupeStats.rows_executed(entry) < entry[1] // 8    # few distinct points: >= 8x fewer rows
+    # the same scales through the 16-row segment form (round 3): identical bits
+    fused.DEDUPE_LISTED = False
+    try:
+        seg = fused.sa_scale_pm_dedupe(xyz, u, sa1.mlps[0], sa1.npoint, g1.radius, g1.nsample, canon, "l1")
+        assert fused.DedupeStats.last[-1][3] is None
+    finally:
+        fused.DEDUPE_LISTED = True
+    assert torch.equal(seg[1], out)
 
 
 @pytest.mark.parametrize("kind", ["uniform", "kitti"])
@@ -131,6 +144,6 @@ def test_engine_dedupe_on_off_bit_identical(kind):
     for k in ("rcnn_feat", "rcnn_cls", "rcnn_reg"):
         assert torch.equal(i1[k], dense[k]), k
         assert torch.equal(again[k], dense[k]), k
-    rows = {name: (dense_rows, int(cnt[1]) * 128) for name, dense_rows, cnt in stats}
+    rows = {e[0]: (e[1], fused.DedupeStats.rows_executed(e)) for e in stats}
     assert rows["rcnn_sa1"][1] < rows["rcnn_sa1"][0] and rows["rcnn_sa2"][1] < rows["rcnn_sa2"][0]
     print(kind, "rows dense -> executed:", rows)
