@@ -747,6 +747,14 @@ def main():
         raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank}, the node has {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        # one process per GPU: every rank runs MIOpen's find step for the image convolutions at start-up; give each its own user
+        # database so that eight ranks do not serialise on (or trip over) the file locks of a shared one.  Read at MIOpen's first use
+        for var, sub in (("MIOPEN_USER_DB_PATH", "db"), ("MIOPEN_CUSTOM_CACHE_DIR", "cache")):
+            if var not in os.environ:
+                path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"jm_miopen_{os.getuid()}", f"rank{local_rank}", sub)
+                os.makedirs(path, exist_ok=True)
+                os.environ[var] = path
     dist = None
     if world > 1 or os.environ.get("JM_BENCH_FORCE_DIST") == "1":   # (the env switch exercises the RCCL path on one GPU)
         import torch.distributed as dist
