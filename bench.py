@@ -747,7 +747,7 @@ def main():
         raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank}, the node has {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("JM_BENCH_FORCE_DIST") == "1":       # (--launch takes this path on one GPU: the GPU tier runs it)
         # one process per GPU: every rank runs MIOpen's find step for the image convolutions at start-up; give each its own user
         # database so that eight ranks do not serialise on (or trip over) the file locks of a shared one.  Read at MIOpen's first use
         for var, sub in (("MIOPEN_USER_DB_PATH", "db"), ("MIOPEN_CUSTOM_CACHE_DIR", "cache")):
