@@ -1013,6 +1013,10 @@ def main():
                     k["rows_executed"], k["rows_dense"] = ln["rows_executed"], ln["rows_dense"]
                     hoisted = k.get("algo_flops_per_step", 0) - k.get("executed_flops_per_step", k.get("algo_flops_per_step", 0))
                     k["executed_flops_per_step"] = int(ln["rows_executed"] * k["flops_per_row"])
+                    k["algo_flops_per_step"] = int(ln["rows_dense"] * k["flops_per_row"] + hoisted)     # the dense block, SURVEY.md §8d
+                    k["algo_bytes_per_step"] = int(ln["rows_executed"] * k["bytes_per_row"])
+                    k["achieved_tflops"] = round(k["algo_flops_per_step"] / (k["ms_per_step"] * 1e-3) / 1e12, 2)
+                    k["mfma_frac"] = round(k["achieved_tflops"] / MFMA_F32_PEAK_TF, 4)
                     k["executed_mfma_frac"] = round(k["executed_flops_per_step"] / (k["ms_per_step"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)
                     k["note"] = ("listed form: algo_flops = the dense block (SURVEY.md §8d), executed = 2^ceil(log2 d) rows per group of d "
                                  "distinct neighbours" + (", first layer hoisted" if hoisted else ""))

@@ -54,10 +54,11 @@ def _sa_mlp(a):
 def _sa_mlp_listed(a):
     """the dense block's algorithmic work + what one executed row costs: the rows executed (2^q per group of
     class q) live in device memory (fused.ListedStats; bench.py multiplies)"""
-    nbytes, flops, _ = _sa_mlp(a)
     nl = _i(a, 9)
     w = [int(a[10][k]) for k in range(nl + 1)]
-    return nbytes, flops, dict(flops_per_row=2 * sum(w[k] * w[k + 1] for k in range(nl)), bytes_per_row=4 * (w[0] + 1), listed=True)
+    # no flops / bytes from the arguments: the dense block's figure is rows_dense x flops_per_row and the executed one
+    # rows_executed x flops_per_row, both from the plan's counters (bench.py) — the arguments alone only know the capacity
+    return 0, 0, dict(flops_per_row=2 * sum(w[k] * w[k + 1] for k in range(nl)), bytes_per_row=4 * (w[0] + 1), listed=True)
 
 
 def _sa_mlp_pre(a):
@@ -149,9 +150,7 @@ ALGO: Dict[str, Callable] = {
         4 * _i(a, 0) * (_i(a, 2) * _i(a, 4) * (_i(a, 3) + 1) + _i(a, 2) * _i(a, 6)),
         2 * _i(a, 0) * _i(a, 2) * _i(a, 4) * (_i(a, 3) * _i(a, 5) + _i(a, 5) * _i(a, 6)), {}),
     "jm_sa_mlp_pm_forward_listed": lambda a: (
-        4 * _i(a, 0) * (_i(a, 2) * _i(a, 4) * (_i(a, 3) + 1) + _i(a, 2) * _i(a, 6)),
-        2 * _i(a, 0) * _i(a, 2) * _i(a, 4) * (_i(a, 3) * _i(a, 5) + _i(a, 5) * _i(a, 6)),
-        dict(flops_per_row=2 * (_i(a, 3) * _i(a, 5) + _i(a, 5) * _i(a, 6)), bytes_per_row=4 * (_i(a, 3) + 1), listed=True)),
+        0, 0, dict(flops_per_row=2 * (_i(a, 3) * _i(a, 5) + _i(a, 5) * _i(a, 6)), bytes_per_row=4 * (_i(a, 3) + 1), listed=True)),
     # duplicate-compacted form: the row count lives in device memory (bench.py multiplies by the rows it reads back)
     "jm_sa_mlp_pm_forward_dyn": lambda a: (0, 0, dict(flops_per_row=2 * (_i(a, 2) * _i(a, 4) + _i(a, 4) * _i(a, 5)),
                                                       bytes_per_row=4 * (_i(a, 2) + 1))),
