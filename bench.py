@@ -320,7 +320,14 @@ def ops_step(d):
         for b in range(B):
             nms_normal_gpu(d["bev"][b], d["scores"][b], 0.8)
     distance_based_proposal(d["rpn_scores"], d["rpn_props"], 9000, 100, 0.8, "normal")
-    with torch.no_grad(), prof.scope("rcnn_sa1"):
+    from jmodt_amd.ops.pointnet2 import fused as _fused
+    keep_listed, _fused.LISTED = _fused.LISTED, False
+    try:
+        with torch.no_grad(), prof.scope("rcnn_sa1"):            # the DENSE kernel at the SURVEY.md §8d shape (831 GFLOP per 1024 RoIs)
+            d["rcnn_sa1"](d["roi_xyz"], d["roi_feat"])
+    finally:
+        _fused.LISTED = keep_listed
+    with torch.no_grad(), prof.scope("rcnn_sa1_listed"):         # the same call in the duplicate-aware form (what a caller gets)
         d["rcnn_sa1"](d["roi_xyz"], d["roi_feat"])
     for P in (64, 128, 256):        # the affinity head at BASELINE configs[0] / [2] / [4] sizes, one problem each
         with prof.scope(f"affinity_{P}x{P}"):
