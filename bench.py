@@ -98,8 +98,11 @@ def listed_rows():
     """{bench row: rows dense / executed} of the listed RPN scales of the LAST forward (class counts in device memory: call after a
     synchronize)"""
     from jmodt_amd.ops.pointnet2 import fused
-    out = {}
-    for name, dense, ns, plan in fused.ListedStats.last:
+    out, seen = {}, set()
+    for name, dense, ns, plan in reversed(fused.ListedStats.last):       # newest first: one entry per (row, scale) = the LAST step's
+        if (name, ns) in seen:
+            continue
+        seen.add((name, ns))
         pl = plan[:8].tolist()
         r = out.setdefault(name, {"rows_dense": 0, "rows_executed": 0})
         r["rows_dense"] += int(dense)
