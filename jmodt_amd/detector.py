@@ -267,6 +267,17 @@ def _unit_wb(unit: nn.Module) -> Tuple[torch.Tensor, torch.Tensor]:
     return _fold_conv_bn(unit.conv, bn)
 
 
+_REGISTRATION_EPOCH = [0]        # bumped whenever ANY nn.Module of the process registers a parameter or a buffer
+
+
+def _bump_registration_epoch(*_args):
+    _REGISTRATION_EPOCH[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump_registration_epoch)
+torch.nn.modules.module.register_module_buffer_registration_hook(_bump_registration_epoch)
+
+
 class DetectAffinityEngine(nn.Module):
     """PointRCNN-with-affinity inference (point_rcnn.py:24-70 in EVAL mode + tools/eval.py:84-190 post-processing +
     tracker.py:81-112 affinity), batch-level, device-resident end to end."""
@@ -280,6 +291,7 @@ class DetectAffinityEngine(nn.Module):
         self._folded: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._folded_sig = None            # (data_ptr, _version) of every parameter / buffer the folded entries were made from
         self._sig_tensors: Optional[List[torch.Tensor]] = None
+        self._sig_epoch = -1
         self.overlap = True                # FPS pyramid + image branch on side streams
         self.last_fps_idx: List[torch.Tensor] = []
         self.sparse_image_fusion = True    # final image feature only under the bilinear taps (else dense deconvolutions)
@@ -337,8 +349,14 @@ class DetectAffinityEngine(nn.Module):
         # The tensors are walked afresh on every call: a parameter that was REPLACED (load_state_dict(assign=True),
         # `module.weight = nn.Parameter(...)`, parametrizations) is a new object, which a list cached at the first call would
         # never see — its id is part of the signature
-        skip = {id(t) for head in (self.rcnn_net.link_layer, self.rcnn_net.se_layer) for t in head.parameters()}
-        self._sig_tensors = [t for t in list(self.parameters()) + list(self.buffers()) if id(t) not in skip]
+        # ... but walking 300 modules costs the host ~1 ms, three times per step (the 4-frame training step is host-bound): the
+        # list is rebuilt only when some module of the process (re-)registered a parameter or buffer since it was made — torch's
+        # global registration hooks bump _REGISTRATION_EPOCH on every `register_parameter` / `register_buffer`, which is what an
+        # attribute assignment of a Parameter, load_state_dict(assign=True) and parametrizations go through
+        if self._sig_tensors is None or self._sig_epoch != _REGISTRATION_EPOCH[0]:
+            skip = {id(t) for head in (self.rcnn_net.link_layer, self.rcnn_net.se_layer) for t in head.parameters()}
+            self._sig_tensors = [t for t in list(self.parameters()) + list(self.buffers()) if id(t) not in skip]
+            self._sig_epoch = _REGISTRATION_EPOCH[0]
         sig = tuple([(id(t), t.data_ptr(), t._version) for t in self._sig_tensors])
         if sig != self._folded_sig:
             self._folded.clear()

@@ -28,6 +28,7 @@ class _PointnetSAModuleBase(nn.Module):
         self.mlps = None
         self.pool_method = "max_pool"
         self.fuse = True   # use the fused kernel when eligible (inference); False forces the unfused path
+        self._listed_qmin = {}   # shape key -> per-scale smallest listed class (-1: dense kernel)
 
     def _pool(self, x: torch.Tensor) -> torch.Tensor:
         # (B, C, npoint, nsample) -> (B, C, npoint)
@@ -61,9 +62,16 @@ class _PointnetSAModuleBase(nn.Module):
         plans = [None] * len(self.groupers)
         if (len(self.groupers) == 2 and neigh[0] is not None and self.fuse and self.pool_method == "max_pool" and xyz.is_cuda
                 and not torch.is_grad_enabled() and not self.training and all(g.use_xyz for g in self.groupers)):
-            qm = [fused.listed_qmin(m, features, nb, xyz.shape[0], xyz.shape[1])
-                  if fused.can_fuse(m, new_xyz.shape[1], g.nsample, self.training, xyz.shape[0], xyz.shape[1]) else -1
-                  for m, g, nb in zip(self.mlps, self.groupers, neigh)]
+            # (shape-only decisions, a dozen ctypes queries per level: remembered per shape — the host enqueues the 4-frame
+            # training step only just ahead of the GPU)
+            key = (xyz.shape[0], xyz.shape[1], new_xyz.shape[1], None if features is None else features.shape[1], fused.LISTED,
+                   fused.PM_KERNEL, fused.PRE_PROJECT)
+            qm = self._listed_qmin.get(key)
+            if qm is None:
+                qm = self._listed_qmin[key] = [
+                    fused.listed_qmin(m, features, nb, xyz.shape[0], xyz.shape[1])
+                    if fused.can_fuse(m, new_xyz.shape[1], g.nsample, self.training, xyz.shape[0], xyz.shape[1]) else -1
+                    for m, g, nb in zip(self.mlps, self.groupers, neigh)]
             if min(qm) >= 0:
                 neigh = [nb.contiguous() for nb in neigh]
                 plans = list(fused.group_plan_dual(neigh[0], qm[0], neigh[1], qm[1]))

@@ -239,3 +239,34 @@ def test_msg_concatenation_slots_and_widths():
     for bad in (full[:, :32].transpose(1, 2), torch.empty(B, 32, M, dtype=torch.float64), full[:, :33], full[:, :32, ::2]):
         with pytest.raises(AssertionError):
             fused._out_slot(bad, B, 32, M if bad.shape[-1] == M else bad.shape[-1], full.device)
+
+
+def test_folded_weight_cache_sees_in_place_updates_and_replaced_parameters():
+    """the engine folds / packs weights once and keys the cache on every parameter's (identity, storage, version): an in-place
+    update (optimizer step, load_state_dict) bumps the version, a REPLACED parameter object (module.weight = nn.Parameter(...),
+    load_state_dict(assign=True)) is a new identity — found without re-walking the module tree on every call, through torch's
+    parameter-registration hook"""
+    import time
+    e = DetectAffinityEngine(DetectorConfig.tiny())
+    e._refresh()
+    e._folded["probe"] = 1
+    e._refresh()
+    assert "probe" in e._folded                                         # nothing changed: the cache stays
+    with torch.no_grad():
+        e.rpn.rpn_cls_layer[0].conv.weight.mul_(1.5)                     # in place: _version
+    e._refresh()
+    assert "probe" not in e._folded
+    e._folded["probe"] = 1
+    conv = e.rpn.rpn_cls_layer[0].conv
+    conv.weight = torch.nn.Parameter(conv.weight.detach().clone())       # a new object with the same values
+    e._refresh()
+    assert "probe" not in e._folded and any(t is conv.weight for t in e._sig_tensors)
+    e._folded["probe"] = 1
+    sd = {k: v.clone() for k, v in e.state_dict().items()}
+    e.load_state_dict(sd, assign=True)                                   # every parameter replaced
+    e._refresh()
+    assert "probe" not in e._folded
+    t0 = time.perf_counter()
+    for _ in range(20):
+        e._refresh()
+    assert (time.perf_counter() - t0) / 20 < 0.5e-3 * 4                  # no module walk on the steady path (~0.1 ms on this host)
