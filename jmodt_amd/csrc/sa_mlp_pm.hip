@@ -360,11 +360,12 @@ constexpr int PM_QMIN_DEFAULT = 2;
 // =============================================================================== LISTED mode (round 4, sa_groups.hip)
 // ball_query back-fills a list of cnt < nsample hits with copies of its first hit (ball_query_gpu.cu:36-40) and the max-pool is
 // idempotent: a group of class q only needs its first 2^q rows.  A 128-row tile holds 128 >> q groups of ONE class; its rows,
-// the per-centre table and the output positions go through the class list (group id -> frame, centre); the pool partials are
-// kept per row QUAD (smallest class q_min = 2: the accumulator layout pools four consecutive rows inside a lane) or per row
-// OCTET (q_min = 3: + one exchange between the lane halves) instead of per 16-row half block — q_min = 3 where the quads' table
-// and partials would not fit the LDS next to 128-wide tiles (the RCNN scales).  The k-loops, their operand order and the bias /
-// ReLU epilogues are the dense kernel's (pm_ktiles), so a row's value — and therefore every output — is bit-identical.
+// the per-centre table and the output positions go through the class list (group id -> frame, centre).  Classes of 4 rows (the
+// accumulator layout pools four consecutive rows inside a lane) and 8 rows (+ one exchange between the lane halves) store their
+// groups' outputs straight from the accumulators; classes of 16 .. nsample rows go through the dense role's half-block partials.
+// The smallest class q_min is 2 — or 3 where the per-centre table of 32 groups does not fit the LDS next to the tiles (C = hidden
+// = 128 with 256 output columns: RCNN SA2).  The k-loops, their operand order and the bias / ReLU epilogues are the dense
+// kernel's (pm_ktiles), so a row's value — and therefore every output — is bit-identical.
 
 struct PmListedSchedule {
     int ts[8], total, n_local, nwg;
@@ -404,9 +405,9 @@ __device__ __forceinline__ void pm_mfma_role_listed(const SaPmParams& p, float* 
     float* X0 = lds;
     float* X1 = X0 + (size_t)PM_BM * p.S0;
     float* VT = X1 + (size_t)PM_BM * p.S1;
-    float* P = VT + p.vt_floats;                                    // [128 >> qmin row quads / octets][p_cols]
-    const int pcols = p.p_cols, qmin = p.qmin;
-    float* B1 = P + (size_t)(PM_BM >> qmin) * pcols;                // the hidden layer's bias (np1 floats)
+    float* P = VT + p.vt_floats;                                    // [16][p_cols]: (half row block, lane half) x column, classes q >= 4
+    const int pcols = p.p_cols;
+    float* B1 = P + (size_t)16 * pcols;                             // the hidden layer's bias (np1 floats)
     float* B2 = B1 + p.np1;                                         // the last layer's bias (np2 floats)
     const int C = p.C, cout = p.cout;
     const int row = rb * 32 + lr;
@@ -435,6 +436,19 @@ __device__ __forceinline__ void pm_mfma_role_listed(const SaPmParams& p, float* 
         int q, slot0, cnt;
         sch.tile(p, it, q, slot0, cnt);
         const float* vtp = VT + (size_t)(row >> q) * C + lk * 8;
+        // classes of 4 / 8 rows: a group's maximum forms inside the lane (+ one exchange between the lane halves) and is stored
+        // straight from the accumulators — this lane's four row quads rq belong to the groups below (output offsets, -1: padding)
+        long long goff[4] = {-1, -1, -1, -1};
+        if (q <= 3) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int slot = q == 2 ? rb * 8 + 2 * rq + lk : rb * 4 + rq;
+                if (slot0 + slot < cnt) {
+                    const int g = p.glist[(size_t)q * p.groups + slot0 + slot];
+                    goff[rq] = (long long)((size_t)(g / p.M) * p.obs + (size_t)(g % p.M));
+                }
+            }
+        }
         // ---------------- hidden layer, transposed (as the dense role)
         {
             const int nb = (p.nblk1 - cb + 1) >> 1;
@@ -483,23 +497,30 @@ __device__ __forceinline__ void pm_mfma_role_listed(const SaPmParams& p, float* 
             for (int j = 0; j < 2; ++j) {
                 if (j < nb) {
                     const int col = (b0 + 2 * j) * 32 + lr;
+                    if (q <= 3) {
+                        const float bias = B2[col];                 // (zero padded to np2)
 #pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {                // rows 8 rq + 4 lk .. + 3 of the block = quad rb * 8 + 2 rq + lk
-                        float v = fmaxf(fmaxf(acc[j][4 * rq], acc[j][4 * rq + 1]), fmaxf(acc[j][4 * rq + 2], acc[j][4 * rq + 3]));
-                        if (qmin == 2) {
-                            P[(size_t)(rb * 8 + 2 * rq + lk) * pcols + col] = v;
-                        } else {                                    // octet rb * 4 + rq = this quad and the other lane half's
-                            v = fmaxf(v, __shfl_xor(v, 32));
-                            if (lk == 0) P[(size_t)(rb * 4 + rq) * pcols + col] = v;
+                        for (int rq = 0; rq < 4; ++rq) {            // rows 8 rq + 4 lk .. + 3 of the block: one quad per lane half
+                            float v = fmaxf(fmaxf(acc[j][4 * rq], acc[j][4 * rq + 1]), fmaxf(acc[j][4 * rq + 2], acc[j][4 * rq + 3]));
+                            if (q == 3) v = fmaxf(v, __shfl_xor(v, 32));      // octet = this quad and the other lane half's
+                            if ((q == 2 || lk == 0) && goff[rq] >= 0 && col < cout)
+                                p.out[(size_t)goff[rq] + (size_t)col * p.M] = fmaxf(v + bias, 0.f);   // + bias, ReLU: as the final pass
                         }
+                    } else {                                        // the dense role's partials: rows 0-15 are r < 8, rows 16-31 r >= 8
+                        float lo = acc[j][0], hi = acc[j][8];
+#pragma unroll
+                        for (int r = 1; r < 8; ++r) { lo = fmaxf(lo, acc[j][r]); hi = fmaxf(hi, acc[j][r + 8]); }
+                        P[(size_t)((2 * rb) * 2 + lk) * pcols + col] = lo;
+                        P[(size_t)((2 * rb + 1) * 2 + lk) * pcols + col] = hi;
                     }
                 }
             }
         }
         lds_barrier();                                              // B2
-        // ---------------- max over each group's 2^q rows = 2^(q-2) quads, + bias, ReLU (both commute with max)
-        {
-            const int ncen = PM_BM >> q, qpg = 1 << (q - qmin);
+        // ---------------- classes of >= 16 rows: max over the group's 2^q / 16 half blocks x 2 lane halves, + bias, ReLU (both
+        // commute with max) — the dense role's final pass with the group id from the list
+        if (q >= 4) {
+            const int ncen = PM_BM >> q, qpg = 2 << (q - 4);
             for (int e = tid; e < ncen * cout; e += 512) {
                 const int col = e / ncen, c = e - col * ncen;
                 if (slot0 + c < cnt) {
@@ -588,7 +609,7 @@ sa_mlp_pm_listed_kernel(SaPmParams p) {
 
 static size_t sa_pm_listed_lds_bytes(int c, int h, int cout, int qmin) {
     return ((size_t)PM_BM * (c + 4) + (size_t)PM_BM * (pad_to(h, 32) + 4) + (size_t)(PM_BM >> qmin) * c +
-            (size_t)(PM_BM >> qmin) * pad_to(cout, 128) + pad_to(h, 128) + pad_to(cout, 128)) * sizeof(float);
+            (size_t)16 * pad_to(cout, 128) + pad_to(h, 128) + pad_to(cout, 128)) * sizeof(float);
 }
 
 static size_t sa_pm_lds_bytes(int c, int h) {

@@ -105,8 +105,9 @@ def test_sa_dedupe_two_levels_bit_identical_to_dense(R, n, max_cnt):
         c = counters.cpu().numpy()
         assert c[0] == c[2] and c[1] == (c[0] + 7) // 8 and 0 < c[1] * 128 <= dense_rows + 128 * 8, (name, c, dense_rows)
         # round 4: the segments go through the LISTED kernel — every virtual centre sits in exactly one class, and a segment of
-        # d entries runs 2^max(3, ceil(log2 d)) rows (octets at the RCNN widths), never more than the 16 of the segment form
-        assert cls is not None and int(cls.sum()) == c[0] and int(cls[:3].sum()) == 0
+        # d entries runs 2^max(qmin, ceil(log2 d)) rows (quads at SA1's widths, octets at SA2's), never more than the 16 of the
+        # segment form
+        assert cls is not None and int(cls.sum()) == c[0] and int(cls[:2].sum()) == 0
         assert fused.DedupeStats.rows_executed(entry) <= c[1] * 128
     if max_cnt <= 60:
         entry = fused.DedupeStats.last[0]

@@ -164,7 +164,9 @@ def test_listed_pm_kernel_is_bit_identical_to_the_dense_kernel(C, spec, ns, patt
     assert float(full[:, :2].abs().max()) == 0 and float(full[:, 2 + spec[-1]:].abs().max()) == 0
     plan = fused.ListedStats.last[-1][3].cpu().numpy()
     rows = sum(int(plan[c]) << c for c in range(8))
-    qmin = 3 if spec[0] == 128 else 2                          # C = hidden = 128: the quads' tables do not fit the LDS
+    from jmodt_amd import _lib
+    qmin = int(_lib.load().jm_sa_mlp_pm_listed_qmin(spec[0], spec[1], spec[2]))     # 3 only for RCNN SA2 (C = hidden = 128, 256 outputs)
+    assert qmin == (3 if spec == [128, 128, 256] else 2)
     assert int(plan[:qmin].sum()) == 0 and rows <= B * M * ns
     if pattern == "singletons":
         assert rows == (1 << qmin) * B * M
