@@ -757,7 +757,7 @@ def main():
         raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank}, the node has {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or os.environ.get("JM_BENCH_FORCE_DIST") == "1":       # (--launch takes this path on one GPU: the GPU tier runs it)
+    if world > 1 or "RANK" in os.environ or os.environ.get("JM_BENCH_FORCE_DIST") == "1":   # (--launch takes this path on one GPU)
         # one process per GPU: every rank runs MIOpen's find step for the image convolutions at start-up; give each its own user
         # database so that eight ranks do not serialise on (or trip over) the file locks of a shared one.  Read at MIOpen's first use
         for var, sub in (("MIOPEN_USER_DB_PATH", "db"), ("MIOPEN_CUSTOM_CACHE_DIR", "cache")):
@@ -766,7 +766,8 @@ def main():
                 os.makedirs(path, exist_ok=True)
                 os.environ[var] = path
     dist = None
-    if world > 1 or os.environ.get("JM_BENCH_FORCE_DIST") == "1":   # (the env switch exercises the RCCL path on one GPU)
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ      # under torch.distributed.run
+    if world > 1 or launched or os.environ.get("JM_BENCH_FORCE_DIST") == "1":   # (a one-rank launch takes the collective path too)
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:      # JM_BENCH_FORCE_DIST=1 from a plain shell: a world of one
             import socket
@@ -908,7 +909,7 @@ def main():
     variants = {}
     if args.workload == "detect" and args.steps >= 2 and not args.headline_only:
         eng = st["engine"]
-        n_var = max(2, min(5, args.steps))
+        n_var = max(2, min(10, args.steps))        # (5 steps = a 60 ms window: the per-cloud values scattered by 8 % between runs)
 
         def variant(prefetch, overlap):
             keep = (st["prefetch"], eng.overlap)
