@@ -9,7 +9,9 @@ python bench.py --workload sa --full-out $OUT/sa.json 2>$OUT/sa.err | grep "^{" 
 for w in train ops dense dense_detect; do
     python bench.py --workload $w --no-cpu-baseline --full-out $OUT/$w.json 2>$OUT/$w.err | grep "^{" > $OUT/$w.line.json
 done
-python bench.py --cloud kitti --no-cpu-baseline --full-out $OUT/detect_kitti.json 2>$OUT/detect_kitti.err | grep "^{" > $OUT/detect_kitti.line.json
+for c in kitti packed; do
+    python bench.py --cloud $c --no-cpu-baseline --full-out $OUT/detect_$c.json 2>$OUT/detect_$c.err | grep "^{" > $OUT/detect_$c.line.json
+done
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --workload train --no-cpu-baseline --full-out $OUT/train_launch.json 2>$OUT/train_launch.err | grep "^{" > $OUT/train_launch.line.json
 python bench.py --workload train --joint --launch --no-cpu-baseline --steps 6 --warmup 2 --full-out $OUT/train_joint_launch.json 2>$OUT/train_joint_launch.err | grep "^{" > $OUT/train_joint_launch.line.json
 for f in $OUT/*.line.json; do python - "$f" <<'PY'
