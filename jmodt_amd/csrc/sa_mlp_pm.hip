@@ -46,7 +46,7 @@ struct SaPmParams {
     const int* total_dev;                  // non-null: the number of tiles is read from device memory (<= total_tiles; the
                                            // duplicate-compacted form of sa_dedupe.hip, whose row count is data dependent)
     int groups, qfull, qmin;               // LISTED (sa_groups.hip): B * M, log2(ns), smallest class (2: row quads, 3: octets)
-    int vt_floats, p_cols;                 // LISTED: floats of the per-centre table, columns of the partial-maximum rows
+    int vt_floats, p_cols;                 // LISTED: floats of the region shared by the per-centre table and the partial-maximum rows; their columns
     const int* cls_count;                  // LISTED: [8] groups per class q of 2^q rows, q >= qmin (device memory)
     const int* glist;                      // LISTED: class q's group ids b * M + i at glist[q * groups ...]
 #ifdef JM_TOOLS_BUILD
@@ -363,8 +363,8 @@ constexpr int PM_QMIN_DEFAULT = 2;
 // the per-centre table and the output positions go through the class list (group id -> frame, centre).  Classes of 4 rows (the
 // accumulator layout pools four consecutive rows inside a lane) and 8 rows (+ one exchange between the lane halves) store their
 // groups' outputs straight from the accumulators; classes of 16 .. nsample rows go through the dense role's half-block partials.
-// The smallest class q_min is 2 — or 3 where the per-centre table of 32 groups does not fit the LDS next to the tiles (C = hidden
-// = 128 with 256 output columns: RCNN SA2).  The k-loops, their operand order and the bias / ReLU epilogues are the dense
+// The smallest class q_min is 2 wherever the tiles, the 32-centre table (which shares its LDS region with the partial rows: the two
+// are never live in the same tile) and the biases fit the 160 KB — every shape of the reference configuration; 3 otherwise.  The k-loops, their operand order and the bias / ReLU epilogues are the dense
 // kernel's (pm_ktiles), so a row's value — and therefore every output — is bit-identical.
 
 struct PmListedSchedule {
@@ -405,9 +405,13 @@ __device__ __forceinline__ void pm_mfma_role_listed(const SaPmParams& p, float* 
     float* X0 = lds;
     float* X1 = X0 + (size_t)PM_BM * p.S0;
     float* VT = X1 + (size_t)PM_BM * p.S1;
-    float* P = VT + p.vt_floats;                                    // [16][p_cols]: (half row block, lane half) x column, classes q >= 4
+    // the per-centre table and the partial-maximum rows SHARE one region: a tile of class q <= 3 has a table of 32 / 16 centres
+    // and no partials (its outputs leave from the accumulators), a tile of class q >= 4 a table of <= 8 centres and the
+    // partials behind it.  A workgroup's tiles ascend in class, so the table the gather role writes for the NEXT tile while this
+    // tile's last layer runs either belongs to a tile without partials in flight (this tile's class <= 3) or stays below them
+    float* P = VT + 8 * p.C;                                        // [16][p_cols]: (half row block, lane half) x column, classes q >= 4
     const int pcols = p.p_cols;
-    float* B1 = P + (size_t)16 * pcols;                             // the hidden layer's bias (np1 floats)
+    float* B1 = VT + p.vt_floats;                                   // the hidden layer's bias (np1 floats)
     float* B2 = B1 + p.np1;                                         // the last layer's bias (np2 floats)
     const int C = p.C, cout = p.cout;
     const int row = rb * 32 + lr;
@@ -607,9 +611,14 @@ sa_mlp_pm_listed_kernel(SaPmParams p) {
     else pm_gather_role_listed<4>(p, lds, tid - 512);
 }
 
+// floats of the region the per-centre table and the partial rows share (see pm_mfma_role_listed)
+static size_t sa_pm_listed_region(int c, int cout, int qmin) {
+    const size_t table = (size_t)(PM_BM >> qmin) * c, with_partials = (size_t)8 * c + (size_t)16 * pad_to(cout, 128);
+    return table > with_partials ? table : with_partials;
+}
 static size_t sa_pm_listed_lds_bytes(int c, int h, int cout, int qmin) {
-    return ((size_t)PM_BM * (c + 4) + (size_t)PM_BM * (pad_to(h, 32) + 4) + (size_t)(PM_BM >> qmin) * c +
-            (size_t)16 * pad_to(cout, 128) + pad_to(h, 128) + pad_to(cout, 128)) * sizeof(float);
+    return ((size_t)PM_BM * (c + 4) + (size_t)PM_BM * (pad_to(h, 32) + 4) + sa_pm_listed_region(c, cout, qmin) + pad_to(h, 128) +
+            pad_to(cout, 128)) * sizeof(float);
 }
 
 static size_t sa_pm_lds_bytes(int c, int h) {
@@ -744,7 +753,7 @@ extern "C" int jm_sa_mlp_pm_forward_listed(int b, int n, int m, int c, int nsamp
     p.S0 = c + 4; p.S1 = pad_to(hidden, 32) + 4;
     p.groups = b * m; p.qfull = nsample == 16 ? 4 : (nsample == 32 ? 5 : 6);
     p.qmin = jm_sa_mlp_pm_listed_qmin(c, hidden, cout);
-    p.vt_floats = (PM_BM >> p.qmin) * c; p.p_cols = p.np2;
+    p.vt_floats = (int)sa_pm_listed_region(c, cout, p.qmin); p.p_cols = p.np2;
     p.cls_count = cls_count; p.glist = glist;
     const size_t lds_bytes = sa_pm_listed_lds_bytes(c, hidden, cout, p.qmin);
     (void)hipFuncSetAttribute((const void*)sa_mlp_pm_listed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

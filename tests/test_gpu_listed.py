@@ -131,7 +131,7 @@ def test_listed_xyz_kernel_is_bit_identical_to_the_dense_kernel(spec, ns, patter
 
 
 @pytest.mark.parametrize("C,spec,ns", [(96, [64, 64, 128], 16), (96, [64, 96, 128], 32), (29, [32, 48, 96], 16),
-                                       (128, [128, 128, 128], 64), (128, [128, 128, 256], 64)])     # the RCNN scales: octet classes
+                                       (128, [128, 128, 128], 64), (128, [128, 128, 256], 64)])     # the RCNN scales (ns = 64, LDS-tight)
 @pytest.mark.parametrize("pattern", ["singletons", "full", "mixed", "sparse"])
 def test_listed_pm_kernel_is_bit_identical_to_the_dense_kernel(C, spec, ns, pattern):
     """sa_mlp_pm_kernel (pre-projected two-layer scales: RPN SA2, config.py:75-82): 128-row tiles of one class each, classes of
@@ -165,8 +165,8 @@ def test_listed_pm_kernel_is_bit_identical_to_the_dense_kernel(C, spec, ns, patt
     plan = fused.ListedStats.last[-1][3].cpu().numpy()
     rows = sum(int(plan[c]) << c for c in range(8))
     from jmodt_amd import _lib
-    qmin = int(_lib.load().jm_sa_mlp_pm_listed_qmin(spec[0], spec[1], spec[2]))     # 3 only for RCNN SA2 (C = hidden = 128, 256 outputs)
-    assert qmin == (3 if spec == [128, 128, 256] else 2)
+    qmin = int(_lib.load().jm_sa_mlp_pm_listed_qmin(spec[0], spec[1], spec[2]))
+    assert qmin == 2                                            # quads at every shape of the reference configuration
     assert int(plan[:qmin].sum()) == 0 and rows <= B * M * ns
     if pattern == "singletons":
         assert rows == (1 << qmin) * B * M
