@@ -1,8 +1,11 @@
 """stream-safety soak of the composed engine: the same resident batch through N steps with every overlap / prefetch on,
 interleaved with allocator churn on the main stream; every step's intermediate results must equal step 0's bit for bit
 (the affinity head's atomically accumulated sums to 1e-6)"""
-import os, sys
+import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# a private, empty MIOpen user database: a bench.py run on the same box leaves find-mode results (split-K kernels with atomic adds,
+# 1e-7 run to run) in the shared one, and immediate mode then picks them up — every key of every step "mismatches" (seen in round 4)
+os.environ["MIOPEN_USER_DB_PATH"] = tempfile.mkdtemp(prefix="jm_soak_miopen_")
 import torch
 import bench
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 150
