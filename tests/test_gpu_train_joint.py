@@ -117,3 +117,37 @@ def test_bench_joint_training_step_under_the_launcher():
     ga = r["grad_allreduce"]
     assert ga["issued"] >= 1 and ga["bytes_per_step"] == 4 * nparams and ga["ms_per_step"] > 0 and r["value"] > 0
     assert "joint" in r["config"]["workload"]
+
+
+def test_joint_forward_matches_the_references_complete_forward():
+    """the DIFFERENTIABLE composition (train_joint.joint_forward / rcnn_forward_train) against the reference's own
+    `PointRCNN.forward` executed over the oracle's extension entry points (tests/golden/forward_ref.npz, the fixture the inference
+    engine is checked against): same weights by name, eval-mode BatchNorm, backbone + RPN heads free running, the RCNN on the
+    pooled points the engine forms from the REFERENCE's proposals.  With this the training route of round 4 is pinned to the
+    reference's Python as well, not only to the engine"""
+    from jmodt_amd.detector import DetectAffinityEngine
+    from jmodt_amd.train_joint import backbone_forward, rcnn_forward_train
+    from tests.test_gpu_detector import close as close_np
+    from tests.test_oracle_cpu import reference_forward_fixture
+    cfg, sd, g = reference_forward_fixture()
+    eng = DetectAffinityEngine(cfg)
+    own = eng.state_dict()
+    eng.load_state_dict({**{k: v for k, v in own.items() if k not in sd}, **sd}, strict=True)
+    eng = eng.to(DEV).eval()
+    xyz, img, xy = T(g["xyz"]), T(g["img"]), T(g["pts_xy"])
+    with torch.enable_grad():
+        feats = backbone_forward(eng.rpn.backbone_net, xyz, img, xy)
+        rpn_cls = eng.rpn.rpn_cls_layer(feats).transpose(1, 2)
+        rpn_reg = eng.rpn.rpn_reg_layer(feats).transpose(1, 2)
+    assert feats.requires_grad
+    close_np(feats, g["out.backbone_features"])
+    close_np(rpn_cls, g["out.rpn_cls"])
+    close_np(rpn_reg, g["out.rpn_reg"])
+    ref_rpn = dict(backbone_xyz=xyz, backbone_features=T(g["out.backbone_features"]), rpn_cls=T(g["out.rpn_cls"]), rpn_reg=T(g["out.rpn_reg"]))
+    with torch.no_grad():
+        pts = eng.roi_pool(ref_rpn, T(g["out.rois"]))
+    with torch.enable_grad():
+        out = rcnn_forward_train(eng.rcnn_net, pts)
+    close_np(out["rcnn_feat"].unsqueeze(-1), g["out.rcnn_feat"])
+    close_np(out["rcnn_cls"], g["out.rcnn_cls"])
+    close_np(out["rcnn_reg"], g["out.rcnn_reg"])
