@@ -663,6 +663,11 @@ def compact_line(full, full_path):
 # bench row -> kernel-name needles in the committed rocprofv3 per-shape table (profiles/<round>_detect_kernel_stats.txt): the
 # kernels one C-ABI entry launches
 ROCPROF_NEEDLE = {"rcnn_sa1/sa_mlp_pm_forward": ["sa_mlp_pm_kernel"],
+                  # (side-stream rows whose HIP-event time is mostly queueing behind the image branch's persistent workgroups: the
+                  # kernels' own durations from the committed trace go next to it, `rocprof_kernel_us`)
+                  "detections/nms_batched": ["nms_mask_lane_kernel<false>", "nms_reduce_kernel"],
+                  "proposal_layer/argsort_desc_stable": ["argsort_desc_kernel"],
+                  "roipool3d_canonical_cnt": ["roipool3d_kernel<true, true>"],
                   "affinity_8x128x128/affinity_forward_batched": ["mlp_gemm_kernel<0", "mlp_gemm_kernel<1", "fill_kernel",
                                                                   "softmax_stats_kernel", "dual_softmax_kernel"]}
 
@@ -1002,6 +1007,11 @@ def main():
                         k["traffic_bytes_per_launch"] = tj[k["kernel"]]["bytes"]
                         k["traffic_gbs"] = round(tj[k["kernel"]]["bytes"] / per_launch_s / 1e9, 1)
         ms_step = elapsed / args.steps * 1e3
+        for k in kernels:
+            if k["kernel"] in ROCPROF_NEEDLE and not k["kernel"].startswith("affinity"):
+                rp = rocprof_average(k["kernel"])
+                if rp:
+                    k["rocprof_kernel_us"] = rp["avg_us"]
         # the hash-grid ball queries: evaluations actually done (per step) next to the n * m of the scan they replace
         for k in kernels:
             scope = k["kernel"].rsplit("/", 1)[0] + "/ball_query" if "/" in k["kernel"] else "ball_query"
