@@ -758,10 +758,20 @@ def main():
         raise SystemExit(f"bench.py --gpus {args.gpus} inside a torch.distributed.run job of WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the jmodt ops have no CPU fallback")
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank}, the node has {torch.cuda.device_count()} GPU(s)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    shared = os.environ.get("JM_BENCH_SHARE_GPU") == "1" and torch.cuda.device_count() >= 1
+    if shared:
+        # TEST HOOK (tests/test_gpu_detector.py): several ranks on ONE GPU, so that a one-GPU box can execute the N > 1 control plane of
+        # the inference workloads (rendezvous, gloo barriers, MAX over ranks, rank-0 output, per-rank MIOpen paths).  Never a
+        # benchmark: the line says so, and the RCCL workloads refuse it (two ranks cannot share a device in one communicator)
+        if args.workload == "train":
+            raise SystemExit("bench.py: JM_BENCH_SHARE_GPU is for the replica workloads only (RCCL needs one GPU per rank)")
+        device_index = local_rank % torch.cuda.device_count()
+    else:
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank}, the node has {torch.cuda.device_count()} GPU(s)")
+        device_index = local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1 or "RANK" in os.environ or os.environ.get("JM_BENCH_FORCE_DIST") == "1":   # (--launch takes this path on one GPU)
         # one process per GPU: every rank runs MIOpen's find step for the image convolutions at start-up; give each its own user
         # database so that eight ranks do not serialise on (or trip over) the file locks of a shared one.  Read at MIOpen's first use
@@ -1098,7 +1108,8 @@ def main():
                                    + (f" [cloud: {args.cloud}]" if args.cloud != "uniform" else ""),
                        "frames_per_gpu_per_step": args.batch,
                        "points": (65536 if args.workload in ("dense", "dense_detect") else 16384) if not args.tiny else "tiny",
-                       "parallelism": f"dp{world} (gradient all-reduce)" if args.workload == "train" else f"replicas x{world}",
+                       "parallelism": (f"dp{world} (gradient all-reduce)" if args.workload == "train" else f"replicas x{world}")
+                                      + (" [TEST: ranks share one GPU, not a benchmark]" if shared else ""),
                        "process_groups": (None if dist is None else
                                           ("data plane RCCL (gradient all-reduce), control plane gloo (barriers, max over ranks)"
                                            if args.workload == "train" else

@@ -530,6 +530,30 @@ def test_bench_self_launch_under_torch_distributed_run(extra):
         assert ga["issued"] == 1 and ga["ms_per_step"] > 0 and ga["bytes_per_step"] > 0 and ga["world"] == 1
 
 
+def test_bench_two_ranks_through_the_drivers_launch_command():
+    """the driver's N > 1 command line — `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 2 ...` — executed on this one-GPU box with both ranks on cuda:0 (JM_BENCH_SHARE_GPU=1, a test
+    hook): rendezvous, the gloo control plane (barriers, MAX of the elapsed times over ranks), rank-0-only output, per-rank MIOpen
+    paths.  value = frames of BOTH ranks / the slower rank's time; the line says that it is not a benchmark"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--tiny",
+           "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["JM_BENCH_SHARE_GPU"] = "1"
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line, r = _one_compact_line(p.stdout)                     # exactly ONE line although two ranks ran
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["steps"] == 3 and r["scaling"] == "weak"
+    assert "replicas x2" in r["config"]["parallelism"] and "not a benchmark" in r["config"]["parallelism"]
+    assert "gloo" in r["config"]["process_groups"] and "no RCCL" in r["config"]["process_groups"]
+    full = json.load(open(os.path.join(ROOT, r["full_record"])))
+    assert abs(full["value"] - 2 * full["config"]["frames_per_gpu_per_step"] * 3 / (full["ms_per_step"] * 3e-3)) < 0.02 * full["value"]
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     """--gpus 2 on a one-GPU box: the self-launched job must fail loudly (no silent fallback to one GPU)"""
     if torch.cuda.device_count() >= 2:
