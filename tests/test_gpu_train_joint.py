@@ -151,3 +151,58 @@ def test_joint_forward_matches_the_references_complete_forward():
     close_np(out["rcnn_feat"].unsqueeze(-1), g["out.rcnn_feat"])
     close_np(out["rcnn_cls"], g["out.rcnn_cls"])
     close_np(out["rcnn_reg"], g["out.rcnn_reg"])
+
+
+def test_joint_backward_matches_the_references_autograd():
+    """gradients of ALL detector parameters through the differentiable route (jm_*_grad kernels + torch autograd on the module
+    containers) against the reference's own backward — `model.rpn(input)` / `PointRCNN.forward` with autograd on, its
+    pointnet2_utils Functions bound to the CPU oracle (tests/golden/make_golden_backward.py -> backward_ref.npz: per tensor the
+    L2 norm, the sum, max |g| and 64 entries).  Same weights / frames as forward_ref.npz, eval-mode BatchNorm, the thin loss of
+    train_joint without its re-id term.  240 tensors: backbone SA / FP / image blocks / LI-Fusion / deconvolutions, RPN heads,
+    RCNN lift, set abstraction and heads"""
+    import json
+    import os
+    from jmodt_amd.detector import DetectAffinityEngine
+    from jmodt_amd.train_joint import backbone_forward, rcnn_forward_train
+    from tests.test_oracle_cpu import reference_forward_fixture
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "backward_ref.npz"))
+    names = json.loads(str(ref["names"]))
+    cfg, sd, g = reference_forward_fixture()
+    eng = DetectAffinityEngine(cfg)
+    own = eng.state_dict()
+    eng.load_state_dict({**{k: v for k, v in own.items() if k not in sd}, **sd}, strict=True)
+    eng = eng.to(DEV).eval()
+    for p in eng.parameters():
+        p.requires_grad_(True)
+    xyz, img, xy = T(g["xyz"]), T(g["img"]), T(g["pts_xy"])
+    N = xyz.shape[1]
+    with torch.enable_grad():
+        feats = backbone_forward(eng.rpn.backbone_net, xyz, img, xy)
+        loss_rpn = (eng.rpn.rpn_cls_layer(feats).sum() + eng.rpn.rpn_reg_layer(feats).sum()) / N
+    loss_rpn.backward()
+    assert abs(float(loss_rpn) - float(ref["loss_rpn"])) < 1e-4 * max(1.0, abs(float(ref["loss_rpn"])))
+    grads = {k: p.grad.detach().clone() for k, p in eng.named_parameters() if p.grad is not None}
+    assert all(k.startswith("rpn.") for k in grads)
+    eng.zero_grad(set_to_none=True)
+    ref_rpn = dict(backbone_xyz=xyz, backbone_features=T(g["out.backbone_features"]), rpn_cls=T(g["out.rpn_cls"]), rpn_reg=T(g["out.rpn_reg"]))
+    with torch.no_grad():
+        pts = eng.roi_pool(ref_rpn, T(g["out.rois"]))
+    with torch.enable_grad():
+        out = rcnn_forward_train(eng.rcnn_net, pts)
+        loss_rcnn = out["rcnn_cls"].sum() + out["rcnn_reg"].sum()
+    loss_rcnn.backward()
+    assert abs(float(loss_rcnn) - float(ref["loss_rcnn"])) < 1e-4 * abs(float(ref["loss_rcnn"]))
+    grads.update({k: p.grad.detach().clone() for k, p in eng.named_parameters() if p.grad is not None})
+    assert sorted(grads) == names, (sorted(set(names) - set(grads))[:5], sorted(set(grads) - set(names))[:5])
+    worst = (0.0, None)
+    for i, k in enumerate(names):
+        flat = grads[k].double().reshape(-1).cpu()
+        norm, total, mx = ref["stats"][i]
+        pos = torch.from_numpy(np.floor(np.linspace(0, flat.numel() - 1, ref["samples"].shape[1])).astype(np.int64))
+        scale = max(float(mx), 1e-6)
+        e_s = float((flat[pos] - torch.from_numpy(ref["samples"][i]).double()).abs().max()) / scale
+        e_n = abs(float(flat.norm()) - norm) / max(norm, 1e-6)
+        e_m = abs(float(flat.abs().max()) - mx) / scale
+        worst = max(worst, (max(e_s, e_n, e_m), k))
+        assert e_s <= 5e-4 and e_n <= 5e-4 and e_m <= 5e-4, (k, e_s, e_n, e_m, norm, mx)
+    print("worst relative gradient error", worst)
