@@ -207,3 +207,40 @@ def test_joint_backward_matches_the_references_autograd():
         assert e_s <= 5e-4 and e_n <= 5e-4 and e_m <= 5e-4, (k, e_s, e_n, e_m, norm, mx)
     print("worst relative gradient error", worst)
     assert worst[0] > 0                                        # (not a comparison of a thing with itself)
+
+
+def test_joint_step_data_parallel_equals_single_process(tmp_path):
+    """the data-parallel joint step (tools/train.py:86-107: nn.DataParallel's scatter / gather / gradient reduction as one process
+    per GPU): two ranks, each on its pair-aligned half of a 4-frame batch, re-id element counts and the gradients of all parameters
+    all-reduced (SUM, several buckets) — against ONE process on the whole batch.  The ranks share cuda:0 and exchange over gloo
+    (RCCL cannot put two ranks on one device); eval-mode BatchNorm, so that no statistic depends on the shard"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "joint_dp_worker.py")
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, helper, str(tmp_path / f"r{r}.pt")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(base, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+             for r in range(2)]
+    single = subprocess.run([sys.executable, helper, str(tmp_path / "one.pt"), "--single"], capture_output=True, text=True, timeout=900, env=base)
+    assert single.returncode == 0, single.stderr[-3000:]
+    for p in procs:
+        _, err = p.communicate(timeout=900)
+        assert p.returncode == 0, err[-3000:]
+    one = torch.load(tmp_path / "one.pt")
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert r0["frames"] == (0, 2) and r1["frames"] == (2, 4) and one["collectives"] == 0 and r0["collectives"] >= 2
+    assert abs(r0["loss"] + r1["loss"] - one["loss"]) < 1e-4 * max(1.0, abs(one["loss"]))     # the shards' losses ADD
+    assert sorted(r0["grads"]) == sorted(one["grads"])
+    worst = 0.0
+    for k, ref in one["grads"].items():
+        assert torch.equal(r0["grads"][k], r1["grads"][k]), k                                 # replicas hold the same reduced gradient
+        scale = max(float(ref.abs().max()), 1e-6)
+        err = float((r0["grads"][k] - ref).abs().max()) / scale
+        worst = max(worst, err)
+        assert err <= 2e-4, (k, err, scale)
+    print("worst relative gradient difference DP vs single process:", worst)
