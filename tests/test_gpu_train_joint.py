@@ -239,8 +239,10 @@ def test_joint_step_data_parallel_equals_single_process(tmp_path):
     worst = 0.0
     for k, ref in one["grads"].items():
         assert torch.equal(r0["grads"][k], r1["grads"][k]), k                                 # replicas hold the same reduced gradient
-        scale = max(float(ref.abs().max()), 1e-6)
-        err = float((r0["grads"][k] - ref).abs().max()) / scale
-        worst = max(worst, err)
-        assert err <= 2e-4, (k, err, scale)
+        # (+ 1e-7 absolute: the link head's last bias has a gradient of exactly zero in exact arithmetic — the dual softmax is
+        # invariant to a constant added to every score — and rounding residues of 1e-9 on either side)
+        scale = float(ref.abs().max())
+        err = float((r0["grads"][k] - ref).abs().max())
+        worst = max(worst, err / max(scale, 1e-3))
+        assert err <= 2e-4 * scale + 1e-7, (k, err, scale)
     print("worst relative gradient difference DP vs single process:", worst)
