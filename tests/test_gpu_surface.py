@@ -278,6 +278,35 @@ def test_gradient_allreduce_runs_on_rccl_with_one_rank(tmp_path):
         assert torch.equal(a, b)
 
 
+def test_finetune_step_hip_data_parallel_equals_single_process(tmp_path):
+    """the finetune step on the training KERNELS under world size 2: each rank back-propagates its local sums over the GLOBAL
+    element counts (all-reduced on the device), the flat gradient bucket is summed, and the parameters after the step equal one
+    process on the whole batch — the CPU tier shows this for the plain-torch form (tests/test_dist_cpu.py); here the hand-written
+    kernels and device-tensor collectives run it (two ranks on cuda:0 over gloo: RCCL cannot share a device)"""
+    import socket
+    import subprocess
+    import sys
+    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "finetune_dp_worker.py")
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, helper, str(tmp_path / f"r{r}.pt")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(base, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+             for r in range(2)]
+    one = subprocess.run([sys.executable, helper, str(tmp_path / "one.pt"), "--single"], capture_output=True, text=True, timeout=600, env=base)
+    assert one.returncode == 0, one.stderr[-3000:]
+    for p in procs:
+        _, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-3000:]
+    ref, r0, r1 = (torch.load(tmp_path / f) for f in ("one.pt", "r0.pt", "r1.pt"))
+    assert r0["frames"] == (0, 4) and r1["frames"] == (4, 8)
+    assert abs(r0["loss"] - ref["loss"]) < 1e-5 and abs(r1["loss"] - ref["loss"]) < 1e-5      # the all-reduced whole-batch loss
+    for a, b, want in zip(r0["params"], r1["params"], ref["params"]):
+        assert torch.equal(a, b)                                                          # replicas stay identical
+        assert float((a - want).abs().max()) <= 1e-6 + 1e-5 * float(want.abs().max())       # DP == single process
+
+
 # ------------------------------------------------------------------ contraction-proof decision fixtures
 # Index outputs depend on comparisons of float32 expressions whose rounding depends on whether the compiler contracts
 # a*b + c into an FMA (DESIGN.md §3 states the two conventions used).  These inputs make every compared quantity EXACT
