@@ -183,9 +183,13 @@ def check(rc, what):
         raise RuntimeError(f"jmodt_amd.{what} failed (code {rc}): {msg}")
 
 
+_current_device = torch._C._cuda_getDevice                    # (the raw queries: torch.cuda.current_stream() builds a Stream object and
+_current_raw_stream = torch._C._cuda_getCurrentRawStream      # re-checks the lazy initialisation, ~8 us x 80 launches per step)
+
+
 def stream_ptr():
     """the hipStream_t torch is currently launching on (never the legacy default stream implicitly)"""
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_current_raw_stream(_current_device()))
 
 
 def dev(t: torch.Tensor, dtype, name: str):
@@ -194,7 +198,7 @@ def dev(t: torch.Tensor, dtype, name: str):
         raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
     if not t.is_cuda:
         raise RuntimeError(f"{name} must be a GPU tensor (jmodt_amd has no CPU path); got device {t.device}")
-    if t.device.index != torch.cuda.current_device():
+    if t.device.index != _current_device():
         # the launch goes to the CURRENT device's current stream (stream_ptr); a tensor living elsewhere would be
         # dereferenced on the wrong GPU.  Callers switch with `torch.cuda.device(t.device)` (one process per GPU
         # never needs to).

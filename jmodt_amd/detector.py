@@ -267,15 +267,7 @@ def _unit_wb(unit: nn.Module) -> Tuple[torch.Tensor, torch.Tensor]:
     return _fold_conv_bn(unit.conv, bn)
 
 
-_REGISTRATION_EPOCH = [0]        # bumped whenever ANY nn.Module of the process registers a parameter or a buffer
-
-
-def _bump_registration_epoch(*_args):
-    _REGISTRATION_EPOCH[0] += 1
-
-
-torch.nn.modules.module.register_module_parameter_registration_hook(_bump_registration_epoch)
-torch.nn.modules.module.register_module_buffer_registration_hook(_bump_registration_epoch)
+from ._registry import EPOCH as _REGISTRATION_EPOCH      # bumped whenever ANY nn.Module of the process registers a parameter / buffer
 
 
 class DetectAffinityEngine(nn.Module):

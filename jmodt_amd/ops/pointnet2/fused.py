@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib as L
+from ..._registry import module_tensors
 from ...profile import prof
 
 _f32, _i32 = torch.float32, torch.int32
@@ -69,7 +70,7 @@ def can_fuse(mlp: nn.Sequential, npoint: int, nsample: int, training: bool, batc
     if training:
         return False          # batch statistics: BatchNorm cannot be folded
     shapes = _layer_shapes(mlp)
-    if not shapes or not next(mlp.parameters()).is_cuda:
+    if not shapes or not module_tensors(mlp)[0].is_cuda:
         return False
     widths = [shapes[0][1]] + [cout for cout, _ in shapes]
     arr = (ctypes.c_int * len(widths))(*widths)
@@ -83,8 +84,8 @@ _packed_cache = weakref.WeakKeyDictionary()   # module -> (signature, packed lay
 def _packed_layers(mlp: nn.Sequential, device):
     """[(wp, bp, cout, cin)] in the kernel's device layout (jm_sa_mlp_pack), cached per module until a
     parameter or BatchNorm buffer changes (torch bumps `_version` on every in-place update)."""
-    tensors = [t for t in list(mlp.parameters()) + list(mlp.buffers())]
-    sig = tuple((t.data_ptr(), t._version) for t in tensors) + (str(device),)
+    tensors = module_tensors(mlp)
+    sig = tuple((id(t), t.data_ptr(), t._version) for t in tensors) + (str(device),)
     hit = _packed_cache.get(mlp)
     if hit is not None and hit[0] == sig:
         return hit[1]
@@ -324,8 +325,8 @@ def pm_plan(mlp: nn.Sequential, device, B: int, N: int, M: int, ns: int):
 
 def _pre_layers(mlp: nn.Sequential, device):
     """the pre-projected form's operands: (W1 (H1, 3 + C) folded, b1, W1x (H1, 4), [(wp, bp, cout, cin)] of layers 2..L)"""
-    tensors = list(mlp.parameters()) + list(mlp.buffers())
-    sig = tuple((t.data_ptr(), t._version) for t in tensors) + (str(device), "pre")
+    tensors = module_tensors(mlp)
+    sig = tuple((id(t), t.data_ptr(), t._version) for t in tensors) + (str(device), "pre")
     hit = _pre_cache.get(mlp)
     if hit is not None and hit[0] == sig:
         return hit[1]
@@ -564,8 +565,8 @@ _folded_cache = weakref.WeakKeyDictionary()   # module -> (signature, [(W, b)])
 
 def _folded_layers(mlp: nn.Sequential):
     """[(W (out, in), b (out))] with eval-mode BatchNorm folded, cached until a parameter / buffer changes"""
-    tensors = list(mlp.parameters()) + list(mlp.buffers())
-    sig = tuple((t.data_ptr(), t._version) for t in tensors)
+    tensors = module_tensors(mlp)
+    sig = tuple((id(t), t.data_ptr(), t._version) for t in tensors)
     hit = _folded_cache.get(mlp)
     if hit is not None and hit[0] == sig:
         return hit[1]
