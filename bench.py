@@ -115,7 +115,13 @@ def detect_step(st):
     streaming detector always knows its next batch; here it is the same resident synthetic batch).  Every step
     still launches exactly one FPS pyramid and one of everything else inside the timed region."""
     pf = st.get("prefetch", True)
-    return st["engine"](st["xyz"], st["image"], st["pts_xy"], next_xyz=st["xyz"] if pf else None, next_image=st["image"] if pf else None)
+    return st["engine"](st["xyz"], st["image"], st["pts_xy"], next_xyz=_upcoming(st) if pf else None, next_image=st["image"] if pf else None)
+
+
+def _upcoming(st):
+    """the clouds of the next `prefetch_depth` batches (the same resident synthetic batch each): one FPS pyramid is started per
+    step whatever the depth, it is only started earlier"""
+    return [st["xyz"]] * max(1, int(st["engine"].prefetch_depth))
 
 
 def _liven(eng, seed):
@@ -211,12 +217,22 @@ def make_sa_inputs(B, seed, dev):
     return xyz, feats
 
 
-def sa_step(xyz, feats, overlap=True):
+def sa_step(xyz, feats, overlap=True, ahead=None):
     """FPS + dual ball_query + group_points (xyz and features, both scales) over the 4 levels; the FPS chain
-    (coordinates only) runs ahead on a side stream (ops/pointnet2/pyramid.py)"""
+    (coordinates only) runs ahead on a side stream (ops/pointnet2/pyramid.py).
+    ahead = {"depth": D, "fifo": [], "n": 0} kept between steps: the FPS pyramids of the next D batches (the same resident cloud)
+    are in flight, each chain on a side stream of its own — every step still starts exactly one pyramid, D steps early"""
     from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
     from jmodt_amd.ops.pointnet2.pyramid import FpsPyramid
-    pyr = FpsPyramid(xyz, [lv["m"] for lv in SA_LEVELS], overlap=overlap)
+    npts = [lv["m"] for lv in SA_LEVELS]
+    if ahead is not None and overlap and ahead["depth"] > 0:
+        fifo, slots = ahead["fifo"], (0, 4, 5, 6)
+        while len(fifo) < ahead["depth"] + 1:
+            fifo.append(FpsPyramid(xyz, npts, overlap=True, slot=slots[ahead["n"] % min(len(slots), ahead["depth"] + 1)]))
+            ahead["n"] += 1
+        pyr = fifo.pop(0)
+    else:
+        pyr = FpsPyramid(xyz, npts, overlap=overlap)
     outs, cur = [], xyz
     for li, lv in enumerate(SA_LEVELS):
         (r0, r1), (ns0, ns1), c = lv["radii"], lv["ns"], lv["c"]
@@ -429,7 +445,7 @@ def train_step(st, world):
                           rois_per_frame=st["rois_per_frame"])
     with torch.no_grad():
         pf = st.get("prefetch", True)
-        _, inter = eng.detect(st["xyz"], st["image"], st["pts_xy"], next_xyz=st["xyz"] if pf else None, next_image=st["image"] if pf else None)
+        _, inter = eng.detect(st["xyz"], st["image"], st["pts_xy"], next_xyz=_upcoming(st) if pf else None, next_image=st["image"] if pf else None)
     B = st["xyz"].shape[0]
     feats = inter["rcnn_feat"].view(B, -1, inter["rcnn_feat"].shape[1])[:, :st["rois_per_frame"]].contiguous()
     # static-shape, sync-free: the host never waits for the device inside a step
@@ -461,7 +477,7 @@ WORKLOAD_TEXT = {
               "heads, proposal layer, roipool3d+canonical, RCNN 3xSA + heads, box decode, detection NMS, pairwise "
               "affinity of consecutive frames), 16384-pt frames, 384x1280 image canvas, 128 proposals/frame",
     "sa": "BASELINE configs[1]: pointnet2 FPS + ball_query(2 radii) + group_points over the 4 RPN SA levels "
-          "(16384->4096->1024->256->64), 16384-pt synthetic clouds",
+          "(16384->4096->1024->256->64), 16384-pt synthetic clouds; the FPS pyramids of upcoming batches run ahead on side streams",
     "ops": "supplementary: three_nn+interpolate (4 FP levels), LI-Fusion gather (5 maps), roipool3d (128 RoIs x 512 "
            "pts x 133), RPN nms_normal (6300 boxes), proposal selection, fused RCNN SA1, 128x128 affinity, per frame",
     "train": "BASELINE configs[3]: frozen composed detector forward + data-parallel finetune step of the link / "
@@ -587,8 +603,10 @@ def roofline_by_time(kernels, ms_step):
     return r
 
 
-def fps_summary(kernels, ms_step):
-    """the FPS chain as a top-level figure: its largest level's time per iteration and the chain's share of the step"""
+def fps_summary(kernels, ms_step, in_flight=1):
+    """the FPS chain as a top-level figure: its largest level's time per iteration and the chain's share of the step
+    (in_flight chains of consecutive batches run side by side: a share above 1 then means `in_flight` overlapping chains, each
+    longer than a step)"""
     rows = [k for k in kernels if "us_per_fps_iteration" in k and k["kernel"].startswith("fps_pyramid/")]
     if not rows:
         return None
@@ -597,7 +615,7 @@ def fps_summary(kernels, ms_step):
     exposed = sum(k["ms_per_step"] for k in kernels if k.get("stall") and k["kernel"].startswith("fps_exposed"))
     return {"kernel": big["kernel"], "us_per_fps_iteration": big["us_per_fps_iteration"], "ms_per_step": big["ms_per_step"],
             "chain_ms_per_step": round(chain, 4), "chain_share_of_step": round(chain / ms_step, 4) if ms_step else None,
-            "exposed_ms_per_step": round(exposed, 4), "hidden_by_prefetch": fps_hidden(kernels)}
+            "exposed_ms_per_step": round(exposed, 4), "hidden_by_prefetch": fps_hidden(kernels), "chains_in_flight": in_flight}
 
 
 COMPACT_LIMIT = 4096     # bytes: the driver records the TAIL of stdout; round 3's 24 KB line could not be parsed from it
@@ -639,11 +657,11 @@ def compact_line(full, full_path):
         c["clouds"] = {k: v.get("value") for k, v in cl.items() if isinstance(v, dict)}
         if cl["uniform"].get("value_dense_rcnn_kernels") is not None:
             c["clouds"]["uniform_dense_rcnn_kernels"] = cl["uniform"]["value_dense_rcnn_kernels"]
-    for k in ("no_prefetch_value", "no_image_prefetch_value", "no_overlap_value", "step_mfma_frac"):
+    for k in ("no_prefetch_value", "prefetch_depth_values", "no_image_prefetch_value", "no_overlap_value", "step_mfma_frac"):
         if full.get(k) is not None:
             c[k] = full[k]
     if full.get("overlap"):
-        c["overlap"] = sub(full["overlap"], ("side_streams", "next_batch_fps_prefetch", "next_batch_image_prefetch", "fps_chain_ms", "fps_exposed_ms",
+        c["overlap"] = sub(full["overlap"], ("side_streams", "next_batch_fps_prefetch", "fps_pyramids_ahead", "next_batch_image_prefetch", "fps_chain_ms", "fps_exposed_ms",
                                              "image_branch_exposed_ms"))
     if full.get("grad_allreduce"):
         c["grad_allreduce"] = sub(full["grad_allreduce"], ("world", "issued", "bytes_per_step", "ms_per_step", "mode"))
@@ -720,6 +738,11 @@ def main():
                          "the image stream is the critical path and this fills the step's tail, +4 %%), after it, or not announced "
                          "(`no_image_prefetch_value` in the line)")
     ap.add_argument("--no-prefetch", action="store_true", help="do not start the next batch's FPS pyramid early")
+    ap.add_argument("--prefetch-depth", type=int, default=None,
+                    help="FPS pyramids of this many upcoming batches in flight, each serial chain on a side stream of its own (one CU per "
+                         "frame).  Default 2 for `sa` (configs[1] IS a sampling chain: 1397 / 2754 / 3920 frames/s at 0 / 1 / 2), 1 for the "
+                         "engine workloads (work-bound: a second chain in flight changes nothing at 8 frames per step and costs 2-4 %% at "
+                         "4, tools/prefetch_depth_probe.py)")
     ap.add_argument("--tiny", action="store_true", help="smoke-sized shapes (tests only; the JSON says so)")
     ap.add_argument("--workload", default="detect", choices=[w for w in WORKLOAD_TEXT if w != "train_joint"])
     ap.add_argument("--cloud", default="uniform", choices=["uniform", "kitti", "packed"],
@@ -823,22 +846,27 @@ def main():
         _fused.LISTED = False
 
     seed = 1234 + rank
+    if args.prefetch_depth is None:
+        args.prefetch_depth = 2 if args.workload == "sa" else 1
     if args.workload == "detect":
         st = make_detect_state(args.batch, seed + 2, dev, tiny=args.tiny, kind=args.cloud)
         st["engine"].overlap = not args.no_overlap
+        st["engine"].prefetch_depth = args.prefetch_depth
         st["prefetch"] = not args.no_prefetch
         st["engine"].prefetch_image = args.image_prefetch != "off"
         st["engine"].prefetch_image_late = args.image_prefetch == "late"
         step = lambda: detect_step(st)  # noqa: E731
     elif args.workload == "sa":
         xyz, feats = make_sa_inputs(args.batch, seed + 1, dev)
-        step = lambda: sa_step(xyz, feats, overlap=not args.no_overlap)  # noqa: E731
+        sa_ahead = {"depth": 0 if args.no_prefetch else args.prefetch_depth, "fifo": [], "n": 0}
+        step = lambda: sa_step(xyz, feats, overlap=not args.no_overlap, ahead=sa_ahead)  # noqa: E731
     elif args.workload == "ops":
         ops_in = make_ops_inputs(args.batch, seed + 2, dev, small=args.tiny)
         step = lambda: ops_step(ops_in)  # noqa: E731
     elif args.workload == "dense_detect":
         st = make_detect_state(args.batch, seed + 4, dev, tiny=args.tiny, points=65536, rois=256)
         st["engine"].overlap = not args.no_overlap
+        st["engine"].prefetch_depth = args.prefetch_depth
         st["prefetch"] = not args.no_prefetch
         st["engine"].prefetch_image = args.image_prefetch != "off"
         st["engine"].prefetch_image_late = args.image_prefetch == "late"
@@ -849,6 +877,7 @@ def main():
     else:
         train_st = (make_joint_state if args.joint else make_train_state)(args.batch, seed + 3, dev, tiny=args.tiny)
         train_st["engine"].overlap = not args.no_overlap
+        train_st["engine"].prefetch_depth = args.prefetch_depth
         train_st["prefetch"] = not args.no_prefetch
         train_st["engine"].prefetch_image = args.image_prefetch != "off"
         train_st["engine"].prefetch_image_late = args.image_prefetch == "late"
@@ -922,6 +951,30 @@ def main():
 
     # the same workload with one overlap mechanism off at a time (a few steps, after the timed region, outside `value`)
     variants = {}
+    if args.workload == "sa" and args.steps >= 2 and not args.headline_only and sa_ahead["depth"] > 0 and not args.no_overlap:
+        # the same workload with nothing announced early: every batch's FPS pyramid starts at the head of its own step
+        keep_depth, n_var = sa_ahead["depth"], max(2, min(10, args.steps))
+        rates = {}
+        for d in sorted({0, 1, keep_depth}):
+            if d == keep_depth:
+                continue
+            for pyr in sa_ahead["fifo"]:
+                pyr.release()
+            sa_ahead.update(depth=d, fifo=[])
+            step(); step()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(n_var):
+                step()
+            torch.cuda.synchronize()
+            rates[d] = round(world * args.batch * n_var / (time.perf_counter() - t2), 2)
+        for pyr in sa_ahead["fifo"]:
+            pyr.release()
+        sa_ahead.update(depth=keep_depth, fifo=[])
+        variants["no_prefetch_value"] = rates.get(0)
+        variants["prefetch_depth_values"] = {str(d): v for d, v in rates.items()}
+        variants["variants_note"] = (f"{n_var} steps each after the timed region: the same step with the FPS pyramids of 0 / 1 upcoming batches "
+                                     f"in flight instead of {keep_depth} (0 = every batch's chain starts at the head of its own step)")
     if args.workload == "detect" and args.steps >= 2 and not args.headline_only:
         eng = st["engine"]
         n_var = max(2, min(10, args.steps))        # (5 steps = a 60 ms window: the per-cloud values scattered by 8 % between runs)
@@ -1119,7 +1172,9 @@ def main():
                                   "algorithmic bytes / 8 TB/s) of the main chain; measured times of small kernels include waits behind the "
                                   "other stream's convolutions; the image branch's own convolution kernel is priced in `image_branch_kernel`",
             "roofline_by_time": roofline_by_time(kernels, table_ms if dom_key else ms_step),
-            "fps": fps_summary(kernels, table_ms if dom_key else ms_step),
+            "fps": fps_summary(kernels, table_ms if dom_key else ms_step,
+                               in_flight=1 if (args.no_prefetch or args.no_overlap or args.workload not in ("sa", "detect", "train", "dense_detect"))
+                               else (args.prefetch_depth + 1 if args.workload == "sa" else max(1, args.prefetch_depth))),
             "image_branch_kernel": image_branch_kernel(kernels),
             "step_mfma_frac": round(mfma_flops / (ms_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4) if ms_step else None,
             "step_mfma_flops": int(mfma_flops),
@@ -1131,6 +1186,7 @@ def main():
                                   "which run on a side stream under its GEMMs; DetectionCache.associate (tests) is the survivor-only form"
                                   if args.workload in ("detect", "dense_detect") else None),
             "overlap": {"side_streams": not args.no_overlap, "next_batch_fps_prefetch": not (args.no_prefetch or args.no_overlap),
+                        "fps_pyramids_ahead": 0 if (args.no_prefetch or args.no_overlap) else args.prefetch_depth,
                         "next_batch_image_prefetch": (args.image_prefetch if not (args.no_prefetch or args.no_overlap) and
                                                       args.workload in ("detect", "train", "dense_detect") else "off"),
                         "fps_chain_ms": round(fps_total, 4), "fps_exposed_ms": round(exposed, 4),

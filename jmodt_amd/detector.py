@@ -37,6 +37,8 @@ from .ops.pointnet2 import fused, pointnet2_utils
 from .ops.pointnet2 import pytorch_utils as pt_utils
 from .ops.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModule, PointnetSAModuleMSG
 from .ops.pointnet2.pyramid import FpsPyramid, side_stream
+
+_FPS_SLOTS = (0, 4, 5, 6)      # side-stream slots of the FPS pyramids in flight (1: image branch, 2: start/end head, 3: detections)
 from .profile import prof
 from .ops.rcnn_lift import PackedRcnnLift
 from .ops.roipool3d.roipool3d_utils import roipool3d_canonical_gpu
@@ -302,8 +304,10 @@ class DetectAffinityEngine(nn.Module):
         self.fuse_attention = True         # LI-Fusion attention block as one kernel where it fits (else rocBLAS GEMMs)
         self.affinity_split_bf16 = False   # EXPERIMENTAL (csrc/affinity_x3.hip): link-head products as 3-term bf16 splits
         self.dedupe_rcnn = True            # RCNN SA1 / SA2: skip (centre, sample) rows that are exact copies (bit-identical output)
-        self._prefetched = None
+        self._prefetched = []              # FIFO of (xyz, FpsPyramid): the announced upcoming batches, next one first
         self._prefetched_img = None
+        self.prefetch_depth = 1            # how many upcoming batches may have their FPS pyramid in flight (prefetch([x1, x2, ...]))
+        self._fps_launches = 0
         self.prefetch_image = True         # prefetch(xyz, image) also starts the next batch's image pyramid
         self.prefetch_image_late = False   # ... after this batch's backbone (under proposals / RCNN) instead of under it
 
@@ -424,18 +428,36 @@ class DetectAffinityEngine(nn.Module):
 
     # -- stage 1: backbone + RPN heads -----------------------------------------------------------------
     @torch.no_grad()
-    def prefetch(self, xyz: torch.Tensor, image: Optional[torch.Tensor] = None) -> None:
+    def prefetch(self, xyz, image: Optional[torch.Tensor] = None) -> None:
         """announce the NEXT batch: its FPS pyramid (coordinates only, one workgroup per frame, ~6 ms of
         latency-bound sampling) starts now on the side stream, under the current batch's set abstraction /
         RCNN work, instead of at the head of the next call's critical path; with `image`, so does its image pyramid
         (the four convolution blocks depend on the image alone, backbone.py:162-168), which then no longer holds the
-        point branch of the next call at every LI-Fusion level.  The next call must pass the same tensor objects."""
+        point branch of the next call at every LI-Fusion level.  The next call must pass the same tensor objects.
+
+        `xyz` may be a LIST of the upcoming clouds, next one first: up to `prefetch_depth` of them are kept in flight, each
+        chain on a side stream of its own.  A sampling chain is serial and occupies one CU per frame: where a step is shorter
+        than the chain (4 frames per step: 6.0 ms of chain against 5 ms of everything else), announcing only the next batch
+        makes the chain the step; two in flight take it off the critical path again.  Clouds that are already in flight (same
+        objects, same order) are left alone, so announcing [k+1, k+2] at step k and [k+2, k+3] at step k+1 starts one pyramid
+        per step."""
         self._refresh()
-        if self.overlap:
-            self._prefetched = (xyz, FpsPyramid(xyz, list(self.cfg.sa_npoints), overlap=True, with_interp=True,
-                                                grid_radii=self._grid_radii()))
-            if image is not None and self.prefetch_image:
-                self._prefetched_img = (image, self._launch_image_branch(image))
+        if not self.overlap:
+            return
+        upcoming = list(xyz) if isinstance(xyz, (list, tuple)) else [xyz]
+        fifo = self._prefetched
+        for i, x in enumerate(upcoming[:max(1, int(self.prefetch_depth))]):
+            if i < len(fifo) and fifo[i][0] is x:
+                continue
+            for _, stale in fifo[i:]:
+                stale.release()
+            del fifo[i:]
+            slot = _FPS_SLOTS[self._fps_launches % min(len(_FPS_SLOTS), max(1, int(self.prefetch_depth)))]
+            self._fps_launches += 1
+            fifo.append((x, FpsPyramid(x, list(self.cfg.sa_npoints), overlap=True, with_interp=True,
+                                       grid_radii=self._grid_radii(), slot=slot)))
+        if image is not None and self.prefetch_image:
+            self._prefetched_img = (image, self._launch_image_branch(image))
 
     def _grid_radii(self):
         """largest ball-query radius per RPN SA level: the pyramid builds the levels' neighbour-search grids on its side stream"""
@@ -451,11 +473,12 @@ class DetectAffinityEngine(nn.Module):
                 ib["stream"].wait_stream(cur)                   # same for the image pyramid's blocks
 
     def _take_prefetched(self, xyz: torch.Tensor):
-        hit, self._prefetched = self._prefetched, None
-        if hit is not None and hit[0] is xyz:
-            return hit[1]
-        if hit is not None:
-            hit[1].release()
+        fifo = self._prefetched
+        if fifo and fifo[0][0] is xyz:
+            return fifo.pop(0)[1]
+        for _, stale in fifo:          # another cloud than the announced one: what is in flight is of no use
+            stale.release()
+        del fifo[:]
         return None
 
     def _take_prefetched_image(self, image: torch.Tensor):
@@ -512,9 +535,10 @@ class DetectAffinityEngine(nn.Module):
 
     @torch.no_grad()
     def backbone(self, xyz: torch.Tensor, image: torch.Tensor, pts_xy: torch.Tensor,
-                 next_xyz: Optional[torch.Tensor] = None, next_image: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 next_xyz=None, next_image: Optional[torch.Tensor] = None) -> torch.Tensor:
         """xyz (B, N, 3), image (B, 3, H, W), pts_xy (B, N, 2) in [-1, 1] -> point features (B, 128, N)
-        (PointNet2MSG.forward, backbone.py:159-196)"""
+        (PointNet2MSG.forward, backbone.py:159-196).  next_xyz: the next batch's cloud, or the list of the upcoming ones
+        (`prefetch`); next_image: the next batch's image"""
         cfg, net = self.cfg, self.rpn.backbone_net
         dev = xyz.device
         main = torch.cuda.current_stream(dev)

@@ -37,7 +37,8 @@ def _side_priority(slot: int) -> int:
 
 
 def side_stream(device, slot: int = 0) -> torch.cuda.Stream:
-    """a per-(device, slot) auxiliary stream, created once (slot 0: FPS chain, slot 1: image branch)"""
+    """a per-(device, slot) auxiliary stream, created once (slot 0: FPS chain, 1: image branch, 2: start/end head, 3: detections,
+    4-6: further FPS chains in flight, detector.prefetch_depth > 1)"""
     d = torch.device(device)
     key = (d.index if d.index is not None else torch.cuda.current_device(), slot)
     if key not in _side:
@@ -50,12 +51,13 @@ _side_stream = side_stream   # round-1 name
 
 class FpsPyramid:
     def __init__(self, xyz: torch.Tensor, npoints: List[int], overlap: bool = True, with_interp: bool = False,
-                 grid_radii: Optional[List[float]] = None):
-        """grid_radii[k] (optional): the largest ball-query radius of level k — the level's neighbour-search grid
+                 grid_radii: Optional[List[float]] = None, slot: int = 0):
+        """slot: which side stream (`side_stream(device, slot)`) — several pyramids in flight need one each.
+        grid_radii[k] (optional): the largest ball-query radius of level k — the level's neighbour-search grid
         (pointnet2_utils.BallQueryGrid over the level's INPUT points) is then built here, on the side stream, ahead of the
         sampling that produces the level's centres; `grid(k)` hands it out"""
         main = torch.cuda.current_stream(xyz.device)
-        side = side_stream(xyz.device) if overlap else main
+        side = side_stream(xyz.device, slot) if overlap else main
         self._main, self._side, self._xyz = main, side, xyz   # xyz stays referenced until release()
         side.wait_stream(main)           # xyz is ready; previous consumers of our buffers are done
         if side is not main:

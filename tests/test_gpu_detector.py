@@ -309,7 +309,37 @@ def test_next_batch_prefetch_gives_identical_results(run):
         _, _, i2 = eng(a, img, xy)                        # `other` was announced, `a` arrives: dropped, recomputed
     for k in ("backbone_features", "rois", "rcnn_feat"):
         assert torch.equal(i1[k], run["inter"][k]) and torch.equal(i2[k], run["inter"][k]), k
-    assert eng._prefetched is None
+    assert eng._prefetched == []
+
+
+def test_two_fps_pyramids_in_flight_give_identical_results(run):
+    """prefetch_depth 2: the two upcoming clouds are announced as a list, each FPS chain on a side stream of its own; one
+    pyramid is started per step in steady state, results do not change, and an announcement that does not come true is dropped"""
+    eng = run["eng"]
+    a, img, xy = T(run["xyz"]), T(run["img"]), T(run["xy"])
+    b = a.clone()
+    other = T(run["xyz"][:, ::-1].copy())
+    eng.prefetch_depth = 2
+    try:
+        with torch.no_grad():
+            n0 = eng._fps_launches
+            eng(a, img, xy, next_xyz=[b, a], next_image=img)            # starts b and a
+            assert eng._fps_launches == n0 + 2 and [x is y for (x, _), y in zip(eng._prefetched, (b, a))] == [True, True]
+            assert eng._prefetched[0][1]._side != eng._prefetched[1][1]._side
+            _, _, i1 = eng(b, img, xy, next_xyz=[a, b], next_image=img)  # consumes b; a is in flight already: starts b only
+            assert eng._fps_launches == n0 + 3
+            _, _, i2 = eng(a, img, xy, next_xyz=[b, other])              # consumes a; b in flight, starts other
+            assert eng._fps_launches == n0 + 4
+            _, _, i3 = eng(b, img, xy, next_xyz=[a])                     # consumes b; `other` does not come true: dropped, a started
+            assert eng._fps_launches == n0 + 5 and len(eng._prefetched) == 1
+            _, _, i4 = eng(a, img, xy)
+            torch.cuda.synchronize()
+    finally:
+        eng.prefetch_depth = 1
+    for k in ("backbone_features", "rois", "rcnn_feat"):
+        for got in (i1, i2, i3, i4):
+            assert torch.equal(got[k], run["inter"][k]), k
+    assert eng._prefetched == []
 
 
 @pytest.mark.parametrize("late", [False, True])
@@ -887,7 +917,7 @@ def test_engine_stream_safety_soak(run):
         assert torch.equal(cache.count, run["cache"].count)
     with torch.no_grad():
         eng(a, img, xy)                                    # consume the last announcement
-    assert eng._prefetched is None and eng._prefetched_img is None
+    assert eng._prefetched == [] and eng._prefetched_img is None
 
 
 # ------------------------------------------------------------------------------------------------------------------
