@@ -70,17 +70,40 @@ group_points_kernel(int c, int n, int q_total, const float* __restrict__ points,
     }
 }
 
+// Backward of the grouping: grad_points[b][c][idx[b][q]] += grad_out[b][c][q] (group_points_gpu.cu:48-86: one atomicAdd per
+// element).  A ball-query list ends in copies of its first hit (ball_query_gpu.cu:36-40) — on the FPS-thinned RPN clouds 9 of 10
+// slots — so most of a wave's 64 consecutive q would add to the SAME address, which the L2 atomic unit serialises.  Each RUN of
+// equal consecutive indices inside a wave is therefore summed in registers first (segmented shuffle scan, run bounds from one ballot
+// of the head flags) and only its last lane issues the atomic.  (Float atomics: the summation order was never fixed.)
 __global__ void __launch_bounds__(256)
 group_points_grad_kernel(int c, int n, int q_total, const float* __restrict__ grad_out,
                          const int* __restrict__ idx, float* __restrict__ grad_points) {
     const int bi = blockIdx.z;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= q_total) return;
-    const int i = idx[(size_t)bi * q_total + q];
+    const int lane = threadIdx.x & 63;
+    const bool live = q < q_total;
+    const int i = live ? idx[(size_t)bi * q_total + q] : -1 - lane;            // dead lanes: runs of their own, never stored
+    const int prev = __shfl_up(i, 1);
+    const unsigned long long heads = __ballot(lane == 0 || i != prev);
+    const int start = 63 - __builtin_clzll(heads & (~0ull >> (63 - lane)));     // first lane of this lane's run
+    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
     const int c0 = blockIdx.y * GP_CPT;
     const int c1 = min(c, c0 + GP_CPT);
-    for (int ci = c0; ci < c1; ++ci)
-        unsafeAtomicAdd(grad_points + ((size_t)bi * c + ci) * n + i, grad_out[((size_t)bi * c + ci) * q_total + q]);
+    if (heads == ~0ull) {                                                       // no two neighbours alike: the plain form
+        if (live)
+            for (int ci = c0; ci < c1; ++ci)
+                unsafeAtomicAdd(grad_points + ((size_t)bi * c + ci) * n + i, grad_out[((size_t)bi * c + ci) * q_total + q]);
+        return;
+    }
+    for (int ci = c0; ci < c1; ++ci) {
+        float v = live ? grad_out[((size_t)bi * c + ci) * q_total + q] : 0.f;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float up = __shfl_up(v, d);
+            if (lane - d >= start) v += up;
+        }
+        if (live && tail) unsafeAtomicAdd(grad_points + ((size_t)bi * c + ci) * n + i, v);
+    }
 }
 
 // ------------------------------------------------------------------ three_nn

@@ -247,6 +247,31 @@ def test_group_gather_forward_backward(oracle):
     assert np.array_equal(pu.grouping_operation(T(feats), T(gidx4)).cpu().numpy(), oracle.grouping_operation(feats, gidx4))
 
 
+@pytest.mark.parametrize("shape", [(2, 19, 3000, 257, 32), (1, 8, 64, 50, 16), (3, 5, 500, 41, 7)])
+def test_grouping_grad_on_back_filled_neighbour_lists(oracle, shape):
+    """a4 backward on the lists ball_query writes (ball_query_gpu.cu:36-40: cnt distinct hits, then copies of the first): the kernel
+    sums each run of equal consecutive indices inside a wave before its atomic; runs cross group, wave and workgroup boundaries here
+    (odd nsample, whole groups of one index, lists without any repetition)"""
+    from jmodt_amd.ops.pointnet2 import pointnet2_utils as pu
+    B, C, N, M, S = shape
+    rng = np.random.default_rng(sum(shape))
+    gidx = np.empty((B, M, S), dtype=np.int32)
+    for b in range(B):
+        for m in range(M):
+            cnt = int(rng.integers(1, S + 1)) if m % 5 else (1 if m % 2 else S)
+            hits = np.sort(rng.choice(N, size=cnt, replace=False)).astype(np.int32)
+            gidx[b, m, :cnt] = hits
+            gidx[b, m, cnt:] = hits[0]
+    gidx[:, 3:6] = gidx[:, 3:4, :1]            # three consecutive groups of ONE index: a run longer than a group
+    feats = rng.normal(size=(B, C, N)).astype(np.float32)
+    tf = T(feats).requires_grad_(True)
+    out = pu.grouping_operation(tf, T(gidx))
+    g = rng.normal(size=out.shape).astype(np.float32)
+    out.backward(T(g))
+    want = oracle.grouping_operation_grad(g, gidx, N)
+    assert np.allclose(tf.grad.cpu().numpy(), want, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(want).max())))
+
+
 # ------------------------------------------------------------------ three_nn / interpolate
 @pytest.mark.parametrize("n,m", [(300, 75), (1024, 256), (77, 2), (513, 131)])
 def test_three_nn_interpolate(oracle, n, m):
