@@ -4,7 +4,9 @@ The host-side caches of folded / packed weights (detector.py, ops/pointnet2/fuse
 storage, version).  Collecting those tensors means walking module trees — ~1 ms for the engine, and two hundred small walks per
 step for the set-abstraction MLPs — which the 4-frame training step cannot afford on the host.  torch's global registration hooks
 fire on every `register_parameter` / `register_buffer` (what an attribute assignment of a Parameter, load_state_dict(assign=True)
-and parametrizations go through): a cached tensor list stays valid until EPOCH moves."""
+and parametrizations go through): a cached tensor list stays valid until EPOCH moves.  In-place updates, `.data` swaps and `module.to()` keep the
+Parameter objects and are seen by the (identity, storage, version) signatures.  Code that writes `module._parameters[name]` / `_buffers[name]`
+directly (torch.__future__.set_overwrite_module_params_on_conversion(True)) bypasses the hooks: call `invalidate()` afterwards."""
 import weakref
 
 import torch
@@ -18,6 +20,11 @@ def _bump(*_args):
 
 torch.nn.modules.module.register_module_parameter_registration_hook(_bump)
 torch.nn.modules.module.register_module_buffer_registration_hook(_bump)
+
+def invalidate() -> None:
+    """forget every cached tensor list (after parameters / buffers were replaced behind torch's registration API)"""
+    _bump()
+
 
 _tensors = weakref.WeakKeyDictionary()       # module -> (epoch, [parameters + buffers])
 
