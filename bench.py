@@ -603,6 +603,42 @@ def roofline_by_time(kernels, ms_step):
     return r
 
 
+def isolated_affinity(st, roofline, n=10):
+    """the roofline kernel ALONE on the machine, same operands as in the step (HIP events on the launching stream, after the
+    timed region): in the step it shares the CUs with the next batch's image pyramid and the detections' side stream, so the
+    in-step fraction says how the step is packed as much as how good the kernel is"""
+    from jmodt_amd.ops.affinity import pairwise_affinity_batched
+    eng = st["engine"]
+    with torch.no_grad():
+        _, _, inter = eng(st["xyz"], st["image"], st["pts_xy"])
+        B = st["xyz"].shape[0]
+        feats = inter["rcnn_feat"].view(B, -1, inter["rcnn_feat"].shape[1])
+        prev = torch.roll(feats, 1, 0)
+        link, se = eng.rcnn_net.link_layer, eng.rcnn_net.se_layer
+        keep = prof.enabled
+        prof.enabled = False
+        try:
+            for _ in range(2):
+                pairwise_affinity_batched(prev, feats, link, se)
+            torch.cuda.synchronize()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+            ev[0].record()
+            for i in range(n):
+                pairwise_affinity_batched(prev, feats, link, se)
+                ev[i + 1].record()
+            torch.cuda.synchronize()
+        finally:
+            prof.enabled = keep
+    ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))
+    avg = sum(ms) / n
+    flops = roofline["achieved"] * 1e12 * roofline.get("avg_launch_ms", 0) * 1e-3 if roofline.get("avg_launch_ms") else None
+    if not flops:
+        return None
+    return {"avg_launch_ms": round(avg, 4), "min_launch_ms": round(ms[0], 4), "achieved": round(flops / (avg * 1e-3) / 1e12, 2),
+            "frac": round(flops / (avg * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+            "note": f"{n} back-to-back calls of the same entry with nothing else on the GPU (link + start/end heads, softmax included)"}
+
+
 def fps_summary(kernels, ms_step, in_flight=1):
     """the FPS chain as a top-level figure: its largest level's time per iteration and the chain's share of the step
     (in_flight chains of consecutive batches run side by side: a share above 1 then means `in_flight` overlapping chains, each
@@ -643,6 +679,8 @@ def compact_line(full, full_path):
             r["avg_launch_ms"], r["max_launch_ms"] = round(r["avg_launch_ms"], 5), round(r["max_launch_ms"], 5)
         if rf.get("rocprof"):
             r["rocprof"] = sub(rf["rocprof"], ("avg_us", "frac", "source"), 80)
+        if rf.get("isolated"):
+            r["isolated"] = sub(rf["isolated"], ("avg_launch_ms", "frac"))
         c["roofline"] = r
     else:
         c["roofline"] = None
@@ -1142,6 +1180,10 @@ def main():
                 if ex:
                     rp["frac"] = round(ex / (rp["avg_us"] * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, 4)
                 roofline["rocprof"] = rp
+            if args.workload in ("detect", "dense_detect") and roofline["kernel"].startswith("affinity_") and not args.tiny:
+                iso = isolated_affinity(st, roofline)
+                if iso:
+                    roofline["isolated"] = iso
         result = {
             "metric": METRIC,
             "value": round(frames / elapsed, 2),
