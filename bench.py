@@ -614,17 +614,17 @@ def isolated_affinity(st, roofline, n=10):
         B = st["xyz"].shape[0]
         feats = inter["rcnn_feat"].view(B, -1, inter["rcnn_feat"].shape[1])
         prev = torch.roll(feats, 1, 0)
-        link, se = eng.rcnn_net.link_layer, eng.rcnn_net.se_layer
+        link = eng.rcnn_net.link_layer
         keep = prof.enabled
         prof.enabled = False
         try:
             for _ in range(2):
-                pairwise_affinity_batched(prev, feats, link, se)
+                pairwise_affinity_batched(prev, feats, link, None)
             torch.cuda.synchronize()
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
             ev[0].record()
             for i in range(n):
-                pairwise_affinity_batched(prev, feats, link, se)
+                pairwise_affinity_batched(prev, feats, link, None)        # the link head = the entry the roofline row times
                 ev[i + 1].record()
             torch.cuda.synchronize()
         finally:
@@ -636,7 +636,8 @@ def isolated_affinity(st, roofline, n=10):
         return None
     return {"avg_launch_ms": round(avg, 4), "min_launch_ms": round(ms[0], 4), "achieved": round(flops / (avg * 1e-3) / 1e12, 2),
             "frac": round(flops / (avg * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
-            "note": f"{n} back-to-back calls of the same entry with nothing else on the GPU (link + start/end heads, softmax included)"}
+            "note": f"{n} back-to-back calls of the same entry (jm_affinity_forward_batched: both GEMMs, projection sum, dual softmax) with "
+                    "nothing else on the GPU"}
 
 
 def fps_summary(kernels, ms_step, in_flight=1):

@@ -385,7 +385,8 @@ extern "C" int jm_conv3x3_wino_bias_relu(int b, int h, int w, int cin, int cout,
     const unsigned long long total = (unsigned long long)b * pxs * pys * (cout / WN_TN);
     JM_REQUIRE(total < 0x7FFFFFFFull, "conv3x3_wino: grid limit");
     const int npatches = b * pxs * pys, group = tune_env("JM_WN_G", 16);
-    const unsigned grid = (unsigned)std::min<unsigned long long>(total, 2ull * 256ull * (unsigned)tune_env("JM_WN_WGS", 1));
+    // (tools build: JM_WN_GRID < 512 leaves CUs to the kernels of other streams — the persistent workgroups fill every SIMD's register file)
+    const unsigned grid = (unsigned)std::min<unsigned long long>(total, (unsigned long long)tune_env("JM_WN_GRID", 2 * 256 * tune_env("JM_WN_WGS", 1)));
     hipLaunchKernelGGL(conv3x3_wino_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, w, cin, cout, pxs, pys, npatches, group,
                        (unsigned)total, (unsigned)xb, x_channels_last, packed, bias, out_channels_last, relu);
     return check_launch("conv3x3_wino");
