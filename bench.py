@@ -603,6 +603,25 @@ def roofline_by_time(kernels, ms_step):
     return r
 
 
+def normalise_fractions(result):
+    """every `*_frac` of the record is a fraction of a PEAK the kernel could reach: rows whose algorithmic figure (the dense /
+    un-hoisted / direct formulation of SURVEY.md §8d) differs from what the kernel executes carry the executed fraction as
+    `mfma_frac` and the formulation's equivalent rate as `dense_equivalent_tflops` — a rate, not a fraction (it exceeds the peak
+    wherever work is skipped: Winograd, hoisted first layers, listed / compacted rows)"""
+    for k in result.get("kernels") or []:
+        if "executed_mfma_frac" in k:
+            k["dense_equivalent_tflops"] = k.get("achieved_tflops")
+            k["mfma_frac"] = k.pop("executed_mfma_frac")
+            if k.get("ms_per_step"):
+                k["achieved_tflops"] = round(k["executed_flops_per_step"] / (k["ms_per_step"] * 1e-3) / 1e12, 2)
+    for key in ("roofline", "roofline_by_time", "image_branch_kernel"):
+        r = result.get(key)
+        if isinstance(r, dict):
+            for sub in ("algorithmic", "direct_form"):
+                if isinstance(r.get(sub), dict):
+                    r[sub].pop("frac_of_peak", None)
+
+
 def isolated_affinity(st, roofline, n=10):
     """the roofline kernel ALONE on the machine, same operands as in the step (HIP events on the launching stream, after the
     timed region): in the step it shares the CUs with the next batch's image pyramid and the detections' side stream, so the
@@ -1273,6 +1292,7 @@ def main():
                                           **extra}
             except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
                 result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": cores, "kind": "port", "sample": f"failed: {ex!r}"}
+        normalise_fractions(result)
         # stdout carries ONE compact line (<= COMPACT_LIMIT bytes); the full record (kernel table, variants, per-stage parity
         # against the CPU chain) goes to a file next to it
         full_path = args.full_out or os.path.join("bench_out", args.workload + ("_joint" if args.joint else "") + ("" if args.cloud == "uniform" else "_" + args.cloud)

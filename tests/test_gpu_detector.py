@@ -510,7 +510,7 @@ def test_bench_default_line_is_compact_and_complete():
     full = _strict(open(os.path.join(ROOT, r["full_record"])).read())
     for k in full["kernels"]:
         assert k.get("hbm_frac", 0) <= 1.0, k                      # no fraction above the roofline (round 3: FPS 2.10)
-        assert k.get("executed_mfma_frac", k.get("mfma_frac", 0)) <= 1.0 or "executed_mfma_frac" in k, k
+        assert k.get("mfma_frac", 0) <= 1.0 and "executed_mfma_frac" not in k, k      # (executed flops; the dense formulation's rate is `dense_equivalent_tflops`)
         if k.get("traffic_bytes_per_launch") and k["ms_per_step"] > 0:
             per_launch_s = k["ms_per_step"] / max(k["launches_per_step"], 1) * 1e-3
             assert k["traffic_bytes_per_launch"] / per_launch_s <= 8.0e12 * 1.05, k    # counter bytes / time within the HBM peak
@@ -531,6 +531,8 @@ def test_bench_workloads_smoke(workload, extra):
     full = json.load(open(os.path.join(ROOT, r["full_record"])))         # the kernel table lives in the full record
     assert full["value"] == r["value"] and full["roofline"]["kernel"] == r["roofline"]["kernel"]
     names = " ".join(k["kernel"] for k in full["kernels"])
+    for k in full["kernels"]:                                             # a fraction is a fraction of a peak, whatever the workload
+        assert k.get("mfma_frac", 0) <= 1.0 and k.get("hbm_frac", 0) <= 1.0 and "executed_mfma_frac" not in k, k
     if workload in ("detect", "train", "dense_detect"):
         for needle in ("fps_pyramid/L1/furthest_point_sampling_xyz", "rpn_sa1/", "li_fusion1/feature_gather", "three_nn",
                        "three_interpolate", "proposal_layer/", "roipool3d_canonical", "rcnn_sa1/sa_mlp_",
