@@ -744,7 +744,7 @@ ROCPROF_NEEDLE = {"rcnn_sa1/sa_mlp_pm_forward": ["sa_mlp_pm_kernel"],
                   "detections/nms_batched": ["nms_mask_lane_kernel<false>", "nms_reduce_kernel"],
                   "proposal_layer/argsort_desc_stable": ["argsort_desc_kernel"],
                   "roipool3d_canonical_cnt": ["roipool3d_kernel<true, true>"],
-                  "affinity_8x128x128/affinity_forward_batched": ["mlp_gemm_kernel<0", "mlp_gemm_kernel<1", "fill_kernel",
+                  "affinity_8x128x128/affinity_forward_batched": ["affinity_fused_kernel", "af_pack_kernel",
                                                                   "softmax_stats_kernel", "dual_softmax_kernel"]}
 
 

@@ -492,13 +492,29 @@ extern "C" size_t jm_affinity_workspace_bytes(int p, int d, const jm_mlp3_t* lin
     return b;
 }
 
+namespace jm {      // affinity_fused.hip
+bool fused_link_supported(int c, int h1, int h2);
+size_t fused_link_workspace_bytes(int c);
+int fused_link_scores(int M, int D, int PD, int c, const float* pf, const float* df, const float* w1, const float* b1, const float* w2,
+                      const float* b2, const float* w3, const float* b3, float* score, float* ws, hipStream_t s);
+}
+constexpr int JM_AFF_FUSED_DEFAULT = 1;      // (tools build: JM_AFF_FUSED=0 -> the two-launch chain, for A/B runs)
+// scratch of the batched link head in front of the raw scores: the packed weights of the one-kernel form, or the hidden tensor
+static bool link_fused(const jm_mlp3_t* link) {
+    static const int fused = tune_env("JM_AFF_FUSED", JM_AFF_FUSED_DEFAULT);
+    return fused && fused_link_supported(link->c, link->h1, link->h2);
+}
+static size_t link_scratch_bytes(size_t pd, const jm_mlp3_t* link) {
+    return link_fused(link) ? align_up(fused_link_workspace_bytes(link->c), 256) : hidden_bytes(pd, link);
+}
+
 // ---------------------------------------------------------------- batched forms: nb independent (P, D) problems
 // (the detector scores every frame of a batch against its predecessor: 8 x 128^2 pair rows become ONE GEMM chain of
 // 131072 rows instead of 8 chains of 16384 — one launch per layer, full waves of workgroups, no per-call tails)
 extern "C" size_t jm_affinity_batched_workspace_bytes(int nb, int p, int d, const jm_mlp3_t* link) {
     if (nb <= 0 || p <= 0 || d <= 0 || !link) return 0;
     const size_t pd = (size_t)nb * p * d, r = (size_t)nb * ((size_t)p + d);
-    return hidden_bytes(pd, link) + align_up(pd * sizeof(float), 256) + align_up(2 * r * sizeof(float), 256);
+    return link_scratch_bytes(pd, link) + align_up(pd * sizeof(float), 256) + align_up(2 * r * sizeof(float), 256);
 }
 
 extern "C" int jm_affinity_forward_batched(int nb, int p, int d, const float* pred_feat, const float* det_feat,
@@ -516,13 +532,19 @@ extern "C" int jm_affinity_forward_batched(int nb, int p, int d, const float* pr
     hipStream_t s = (hipStream_t)stream;
     const size_t pd = (size_t)nb * p * d, r = (size_t)nb * ((size_t)p + d);
     char* w = (char*)ws;
-    float* hidden = (float*)w; w += hidden_bytes(pd, link);
+    float* hidden = (float*)w; w += link_scratch_bytes(pd, link);
     float* sraw = (float*)w;   w += align_up(pd * sizeof(float), 256);
     float* stats = (float*)w;
     float* S = link_raw ? link_raw : sraw;
-    MlpJob lj{(int)pd, nullptr, pred_feat, det_feat, d, link, hidden, S};
-    lj.PD = p * d;
-    rc = run_mlps(&lj, 1, s);
+    if (link_fused(link)) {
+        // both hidden layers in one kernel, the hidden activation in LDS (affinity_fused.hip); the scratch holds the packed weights
+        rc = fused_link_scores((int)pd, d, p * d, link->c, pred_feat, det_feat, link->w1, link->b1, link->w2, link->b2, link->w3, link->b3,
+                               S, hidden, s);
+    } else {
+        MlpJob lj{(int)pd, nullptr, pred_feat, det_feat, d, link, hidden, S};
+        lj.PD = p * d;
+        rc = run_mlps(&lj, 1, s);
+    }
     if (rc) return rc;
     if (link_out) {
         hipLaunchKernelGGL(softmax_stats_kernel, dim3((unsigned)(p + d), (unsigned)nb), dim3(256), 0, s, p, d, S, stats);

@@ -20,8 +20,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 # bench row (kernels[].kernel) -> (workload, [(kernel-name substring, grid, workgroup), ...] = the kernels one entry launches)
 MAP = {
-    "affinity_8x128x128/affinity_forward_batched": ("detect", [("mlp_gemm_kernel<0, 16, true>", "1048576", "256"),
-                                                               ("mlp_gemm_kernel<1, 16, true>", "1048576", "256")]),
+    "affinity_8x128x128/affinity_forward_batched": ("detect", [("affinity_fused_kernel", "2097152", "1024")]),
     "roipool3d_canonical_cnt": ("detect", [("roipool3d_kernel<true, true>", "65536x8", "512")]),
     "conv3x3_rgb_bias_relu": ("detect", [("conv3x3_rgb_kernel", "2560x384x8", "256")]),
     "fps_pyramid/L1/furthest_point_sampling_xyz": ("detect", [("fps_regs2_kernel<16, 1024, true>", "8192", "1024")]),

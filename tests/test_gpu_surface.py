@@ -407,6 +407,33 @@ def test_pairwise_affinity_batched_matches_per_problem(oracle, nb, P, D, C):
     assert torch.equal(raw3, raw4) and torch.equal(A3, A4) and torch.equal(s3, s4) and torch.equal(e3, e4)
 
 
+@pytest.mark.parametrize("nb,P,D,C", [(2, 37, 50, 128), (1, 65, 63, 512), (3, 128, 128, 64), (5, 3, 200, 256), (1, 1, 1, 512)])
+def test_link_head_one_kernel_form_vs_float64(nb, P, D, C):
+    """csrc/affinity_fused.hip (both hidden layers of the 512-512 link head in one kernel, hidden activation in LDS) on shapes
+    whose 64-row tiles end inside a problem, cross prediction rows and problem boundaries, and on every supported input width:
+    raw scores against a float64 evaluation of the reference's module (rcnn.py:239-258), the dual softmax on top, run-to-run bits"""
+    from jmodt_amd.ops.affinity import make_affinity_mlp, pairwise_affinity_batched
+    torch.manual_seed(nb * 1000 + P * 10 + D)
+    link = make_affinity_mlp(C, (512, 512)).to(DEV).eval()
+    with torch.no_grad():
+        for m in link.modules():
+            if isinstance(m, torch.nn.Conv1d):
+                m.bias.normal_(0, 0.05)
+    pf = torch.relu(torch.randn(nb, P, C, device=DEV))
+    df = torch.relu(torch.randn(nb, D, C, device=DEV))
+    A, raw = pairwise_affinity_batched(pf, df, link, None, return_raw=True)
+    cor = (pf[:, :, None, :] - df[:, None, :, :]).abs().double().reshape(nb, P * D, C).transpose(1, 2)
+    want = link.double()(cor).reshape(nb, P, D)
+    link.float()
+    scale = max(1.0, want.abs().max().item())
+    assert (raw.double() - want).abs().max().item() < 1e-4 * scale              # (measured: 3e-7)
+    sm = (torch.softmax(want, 2) + torch.softmax(want, 1)) / 2
+    assert (A.double() - sm).abs().max().item() < 1e-4
+    for _ in range(2):
+        A2, raw2 = pairwise_affinity_batched(pf, df, link, None, return_raw=True)
+        assert torch.equal(raw2, raw) and torch.equal(A2, A)
+
+
 # ------------------------------------------------------------------ EXPERIMENTAL split-bf16 affinity (csrc/affinity_x3.hip)
 @pytest.mark.parametrize("nb,P,D,C", [(8, 128, 128, 512), (2, 64, 64, 512), (1, 37, 50, 64)])
 def test_affinity_split_bf16_error_not_above_exact_fp32(nb, P, D, C):
