@@ -1,11 +1,11 @@
 """affinity link head: the two-launch GEMM chain (affinity.hip) against the one-kernel form that keeps the hidden activation in LDS
-(affinity_fused.hip; tools build, JM_AFF_FUSED=1).  Checks the scores against float64 and times both forms of the SAME process
+(affinity_fused.hip, the default; tools build: JM_AFF_FUSED=0 selects the two-launch chain, JM_AFF_GRID=256 a persistent grid).  Checks the scores against float64 and times both forms of the SAME process
 image by running itself twice.      gpurun -- 'python tools/aff_fused_ab.py'"""
 import os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) == 1:
-    for flag, rows32, grid, rm in (("0", "0", "-1", "0"), ("1", "0", "-1", "0"), ("1", "0", "-1", "1"), ("1", "0", "0", "1"), ("1", "1", "-1", "0")):
-        env = dict(os.environ, JM_AFF_FUSED=flag, JM_AFF_ROWS32=rows32, JM_AFF_GRID=grid, JM_AFF_RM=rm)
+    for flag, grid in (("0", "-1"), ("1", "-1"), ("1", "256")):
+        env = dict(os.environ, JM_AFF_FUSED=flag, JM_AFF_GRID=grid)
         subprocess.run([sys.executable, os.path.abspath(__file__), flag], env=env, check=False)
     sys.exit(0)
 import torch
@@ -18,7 +18,7 @@ torch.manual_seed(0)
 dev = torch.device("cuda:0")
 C = 512
 link = nn.Sequential(nn.Conv1d(C, 512, 1), nn.ReLU(), nn.Conv1d(512, 512, 1), nn.ReLU(), nn.Conv1d(512, 1, 1)).to(dev)
-print(f"JM_AFF_FUSED={os.environ.get('JM_AFF_FUSED')} JM_AFF_ROWS32={os.environ.get('JM_AFF_ROWS32')} JM_AFF_GRID={os.environ.get('JM_AFF_GRID')} JM_AFF_RM={os.environ.get('JM_AFF_RM')} (-1: a workgroup per tile, 0: persistent)")
+print(f"JM_AFF_FUSED={os.environ.get('JM_AFF_FUSED')} JM_AFF_GRID={os.environ.get('JM_AFF_GRID')} (-1: a workgroup per tile, n: persistent on n workgroups)")
 for nb, P, D in ((2, 37, 50), (1, 64, 64), (3, 128, 128), (8, 128, 128), (8, 256, 256)):
     pf = torch.randn(nb, P, C, device=dev)
     df = torch.randn(nb, D, C, device=dev)
