@@ -23,16 +23,21 @@
 // Per tile 67 MFLOP and 2 MB of weights from L2 (8 B per clock and CU at the matrix pipe's rate); HBM traffic per call = the
 // operands and the scores.
 //
-// Measured (tools/aff_fused_ab.py, link head alone incl. the dual softmax, 20 calls; tools/aff_fused_step.sh in the step):
-//   two launches (affinity.hip)            8 x 128^2 1146 us = 0.763 of the fp32 MFMA peak    8 x 256^2 4470 us = 0.783
-//   this kernel                                      1122 us = 0.779                                   4405 us = 0.794
-//   ... with the LDS tile k-major T[k][68] (eight ds_read_b32 per row block and k-tile, ds_write_b128 of the hidden activation):
+// Measured (tools/aff_fused_ab.py, link head alone incl. the dual softmax, 20 calls, ReLU-ed random features; tools/aff_fused_step.sh
+// in the step):
+//   two launches (affinity.hip)            8 x 128^2 1153 us = 0.759 of the fp32 MFMA peak    8 x 256^2 4491 us = 0.779
+//   this kernel                                      1054 us = 0.830                                   4162 us = 0.840
+//   ... operands requested per whole k-tile (two register sets, 16 MFMAs per phase) instead of per half k-tile:
+//                                                    1122 us = 0.779                                   4405 us = 0.794
+//   ... and the LDS tile k-major T[k][68] (eight ds_read_b32 per row block and k-tile, ds_write_b128 of the hidden activation):
 //                                                    1160 us = 0.754                                   4603 us = 0.760
 //   ... 32-row tiles, 8 waves x 64 columns, two workgroups per CU (phases of one under the MFMA loops of the other, but every
 //       weight register feeds ONE MFMA: twice the stream from L2):  1390 us = 0.630                    5454 us = 0.641
-// In the composed step the entry takes the same 1.25 ms either way (it shares the machine with the next batch's image pyramid and
-// the detections' stream) and the headline is unchanged (781-785 against 784 frames/s); what changes is 0.57 GB of HBM traffic per
-// step that no longer exists, and 268 MB of workspace.
+//   (timing-only experiments: every weight load an L1 hit -10 %, every LDS read the same k-tile -5 %; unrestricted Gaussian
+//    features instead of ReLU-ed ones +4 %: the matrix pipe's clock follows the data)
+// In the composed step (HIP events around the entry, which shares the machine with the next batch's image pyramid and the
+// detections' stream): 1.19-1.20 ms = 0.73 against 1.25 ms = 0.70, headline +0.9 % (776 against 770 frames/s, tools build);
+// 0.57 GB of HBM traffic per step no longer exists, nor 268 MB of workspace.
 #include <algorithm>
 
 #include "jm_common.h"
@@ -41,8 +46,23 @@ namespace jm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// (timing experiments of the tools build, wrong results: every weight k-tile = the first one, i.e. an L1 hit instead of the stream
+// from L2 / every LDS read = the first k-tile)
+#ifdef JM_AFF_EXP_B0
+#define AF_EXP_B(kc) ((kc) & 0)
+#else
+#define AF_EXP_B(kc) (kc)
+#endif
+#ifdef JM_AFF_EXP_A0
+#define AF_EXP_A(kc) ((kc) & 0)
+#else
+#define AF_EXP_A(kc) (kc)
+#endif
 constexpr int AF_K = 512;                        // h1 = h2 (and the largest c)
 constexpr int AF_ROWS = 64, AF_LD = AF_K + 4, AF_NW = 16, AF_NT = AF_NW * 64;
+#ifndef AF_RING
+#define AF_RING 4                                 // weight register sets in flight (half k-tiles); 8 measured the same
+#endif
 constexpr size_t AF_LDS = ((size_t)AF_ROWS * AF_LD + (size_t)AF_NW * AF_ROWS) * sizeof(float);
 
 struct FusedLink {
@@ -82,44 +102,50 @@ affinity_fused_kernel(FusedLink p) {
     const float bias1 = p.b1[col], bias2 = p.b2[col], w3 = p.w3[col];
     const float b3 = p.b3[0];
 
-    // one layer over the LDS tile: k-tiles in pairs, the operands of k-tile t + 1 (two 1 KB weight loads from L2, four ds_read_b128)
-    // requested in front of the MFMAs of k-tile t — two named register sets and scheduling fences, because hipcc otherwise rotates
-    // the loop into load -> s_waitcnt vmcnt(0) -> use (the first version: one L2 round trip per eight MFMAs)
+    // one layer over the LDS tile, in HALF k-tiles (four k-steps = eight MFMAs): a ring of AF_RING weight register sets (one 1 KB
+    // wave load each) runs AF_RING - 1 halves ahead of the MFMAs (with the weights pinned to L1 the kernel is 10 % faster, but a ring of 8
+    // instead of 4 changes nothing: it is not the latency of the stream) and the LDS operands (one ds_read_b128 per row block) one half
+    // ahead.  Static ring indices under full unrolling + scheduling fences: hipcc otherwise rotates the loop into load ->
+    // s_waitcnt vmcnt(0) -> use (the first version: one L2 round trip per eight MFMAs)
     auto layer = [&](const float* __restrict__ wp, int KT, f32x16& acc0, f32x16& acc1) __attribute__((always_inline)) {
         const float4* bp = reinterpret_cast<const float4*>(wp) + (size_t)wave * KT * 128 + lane;
         const float* ap = T + (size_t)lr * AF_LD + 8 * lk;
-        float4 bA[2], bB[2], aA[2][2], aB[2][2];              // a[row block][k half]
-#define AF_LOAD(KT_, BR, AR)                                                                   \
+        const int NH = 2 * KT;                                 // (a multiple of 8: c % 64 == 0)
+        float4 b[AF_RING], a[2][2];                            // a[buffer][row block]
+#define AF_LOAD_B(H) bp[(size_t)AF_EXP_B(min((H), NH - 1)) * 64]          /* (unconditional: past the end the last half is re-read, unused) */
+#define AF_LOAD_A(H, BUF)                                                                      \
         {                                                                                      \
-            const int kc = min((KT_), KT - 1);          /* (unconditional: past the end the last k-tile is re-read, unused) */ \
-            BR[0] = bp[(size_t)kc * 128]; BR[1] = bp[(size_t)kc * 128 + 64];                   \
-            _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) {                                 \
-                const float4* a4 = reinterpret_cast<const float4*>(ap + (size_t)32 * rb * AF_LD + 16 * kc); \
-                AR[rb][0] = a4[0]; AR[rb][1] = a4[1];                                          \
-            }                                                                                  \
+            const int hc = AF_EXP_A(min((H), NH - 1));                                         \
+            a[BUF][0] = *reinterpret_cast<const float4*>(ap + 16 * (hc >> 1) + 4 * (hc & 1));  \
+            a[BUF][1] = *reinterpret_cast<const float4*>(ap + (size_t)32 * AF_LD + 16 * (hc >> 1) + 4 * (hc & 1)); \
         }
-#define AF_STEP(AR, H, E, BV)                                                                  \
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AR[0][H].E, BV, acc0, 0, 0, 0);        \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AR[1][H].E, BV, acc1, 0, 0, 0);
-#define AF_MFMA8(BR, AR)                                                                       \
-        {                                                                                      \
-            AF_STEP(AR, 0, x, BR[0].x) AF_STEP(AR, 0, y, BR[0].y) AF_STEP(AR, 0, z, BR[0].z) AF_STEP(AR, 0, w, BR[0].w) \
-            AF_STEP(AR, 1, x, BR[1].x) AF_STEP(AR, 1, y, BR[1].y) AF_STEP(AR, 1, z, BR[1].z) AF_STEP(AR, 1, w, BR[1].w) \
+#define AF_STEP(BUF, E, BV)                                                                    \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[BUF][0].E, BV, acc0, 0, 0, 0);       \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[BUF][1].E, BV, acc1, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < AF_RING - 1; ++j) b[j] = AF_LOAD_B(j);
+        AF_LOAD_A(0, 0)
+        // (the LDS reads between the two MFMA quads of a phase, or no fence between loads and MFMAs at all, or a ring of 2 / 8:
+        // all within the run-to-run noise of this form)
+#define AF_PHASE(H0, J)                                                                         \
+            {                                                                                  \
+                b[((J) + AF_RING - 1) % AF_RING] = AF_LOAD_B((H0) + (J) + AF_RING - 1);        \
+                AF_LOAD_A((H0) + (J) + 1, ((J) + 1) & 1)                                       \
+                __builtin_amdgcn_sched_barrier(0);                                             \
+                AF_STEP((J) & 1, x, b[(J) % AF_RING].x) AF_STEP((J) & 1, y, b[(J) % AF_RING].y) \
+                AF_STEP((J) & 1, z, b[(J) % AF_RING].z) AF_STEP((J) & 1, w, b[(J) % AF_RING].w) \
+                __builtin_amdgcn_sched_barrier(0);                                             \
+            }
+        // (all 64 halves of c = 512 unrolled — no loop header, where hipcc's wait insertion falls back to vmcnt(1) once per trip —
+        // spills: 1.4 KB of scratch, 2 x slower)
+        for (int h0 = 0; h0 < NH; h0 += AF_RING) {
+#pragma unroll
+            for (int j = 0; j < AF_RING; ++j) AF_PHASE(h0, j)
         }
-        AF_LOAD(0, bA, aA)
-        for (int kt = 0; kt < KT; kt += 2) {
-            AF_LOAD(kt + 1, bB, aB)
-            __builtin_amdgcn_sched_barrier(0);
-            AF_MFMA8(bA, aA)
-            __builtin_amdgcn_sched_barrier(0);
-            AF_LOAD(kt + 2, bA, aA)
-            __builtin_amdgcn_sched_barrier(0);
-            AF_MFMA8(bB, aB)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#undef AF_LOAD
+#undef AF_PHASE
+#undef AF_LOAD_B
+#undef AF_LOAD_A
 #undef AF_STEP
-#undef AF_MFMA8
     };
 
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
