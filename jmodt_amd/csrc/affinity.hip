@@ -661,8 +661,16 @@ extern "C" int jm_affinity_forward(int p, int d, const float* pred_feat, const f
         rc = jm_affinity_start_end(p, d, pred_feat, det_feat, se, start, end, w, ws_bytes - (size_t)(w - (char*)ws), stream);
         if (rc) return rc;
     }
-    const MlpJob lj{(int)pd, nullptr, pred_feat, det_feat, d, link, hidden, S};
-    rc = run_mlps(&lj, 1, s);
+    static const int small_m = tune_env("JM_GEMM_SMALL_M", 4096);
+    if (link_fused(link) && pd > (size_t)small_m && hidden_bytes(pd, link) >= fused_link_workspace_bytes(link->c)) {
+        // above the single-wave kernels' range: the one-kernel form (affinity_fused.hip; 128 x 128 pairs = 256 tiles, one per CU);
+        // the packed weights take the place of the hidden tensor
+        rc = fused_link_scores((int)pd, d, 0, link->c, pred_feat, det_feat, link->w1, link->b1, link->w2, link->b2, link->w3, link->b3,
+                               S, hidden, s);
+    } else {
+        const MlpJob lj{(int)pd, nullptr, pred_feat, det_feat, d, link, hidden, S};
+        rc = run_mlps(&lj, 1, s);
+    }
     if (rc) return rc;
     if (link_out) {
         hipLaunchKernelGGL(softmax_stats_kernel, dim3((unsigned)r), dim3(256), 0, s, p, d, S, stats);
