@@ -183,8 +183,12 @@ def check(rc, what):
         raise RuntimeError(f"jmodt_amd.{what} failed (code {rc}): {msg}")
 
 
-_current_device = torch._C._cuda_getDevice                    # (the raw queries: torch.cuda.current_stream() builds a Stream object and
-_current_raw_stream = torch._C._cuda_getCurrentRawStream      # re-checks the lazy initialisation, ~8 us x 80 launches per step)
+# the raw queries: torch.cuda.current_stream() builds a Stream object and re-checks the lazy initialisation, ~8 us x 80 launches
+# per step.  They are private symbols that CPU-only torch builds do not define (and no stable API): resolved with getattr, the
+# public calls stand in where they are missing
+_current_device = getattr(torch._C, "_cuda_getDevice", None) or (lambda: torch.cuda.current_device())
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_current_raw_stream = _raw_stream or (lambda device: torch.cuda.current_stream(device).cuda_stream)
 
 
 def stream_ptr():

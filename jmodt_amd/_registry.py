@@ -3,7 +3,7 @@
 The host-side caches of folded / packed weights (detector.py, ops/pointnet2/fused.py) are keyed on every tensor's (identity,
 storage, version).  Collecting those tensors means walking module trees — ~1 ms for the engine, and two hundred small walks per
 step for the set-abstraction MLPs — which the 4-frame training step cannot afford on the host.  torch's global registration hooks
-fire on every `register_parameter` / `register_buffer` (what an attribute assignment of a Parameter, load_state_dict(assign=True)
+fire on every `register_parameter` / `register_buffer` / `register_module` (what an attribute assignment of a Parameter, load_state_dict(assign=True)
 and parametrizations go through): a cached tensor list stays valid until EPOCH moves.  In-place updates, `.data` swaps and `module.to()` keep the
 Parameter objects and are seen by the (identity, storage, version) signatures.  Code that writes `module._parameters[name]` / `_buffers[name]`
 directly (torch.__future__.set_overwrite_module_params_on_conversion(True)) bypasses the hooks: call `invalidate()` afterwards."""
@@ -20,6 +20,19 @@ def _bump(*_args):
 
 torch.nn.modules.module.register_module_parameter_registration_hook(_bump)
 torch.nn.modules.module.register_module_buffer_registration_hook(_bump)
+# re-parenting an already built submodule (`engine.rpn = other_rpn`, add_module) registers no parameter: its own hook
+torch.nn.modules.module.register_module_module_registration_hook(_bump)
+
+_orig_delattr = torch.nn.Module.__delattr__
+
+
+def _delattr(self, name):            # `del module.child` / `del module.weight`: no registration hook fires
+    _bump()
+    return _orig_delattr(self, name)
+
+
+torch.nn.Module.__delattr__ = _delattr
+
 
 def invalidate() -> None:
     """forget every cached tensor list (after parameters / buffers were replaced behind torch's registration API)"""

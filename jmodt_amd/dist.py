@@ -51,9 +51,26 @@ def shard_frames(num_frames: int, world: int, rank: int, pair_aligned: bool = Tr
     return begin * unit, (begin + count) * unit
 
 
-def collective_path(world: int = 1) -> bool:
-    """do the data-parallel steps issue their collectives?  Yes whenever a process group exists (world size 1 included);
-    a declared world > 1 without one is an error, not a silent single-process step"""
+def group_world(world: Optional[int] = None) -> int:
+    """the number of ranks a data-parallel step runs over: the process group's size whenever one exists (`world` = None, the
+    default of every step function, or an int that must then EQUAL it: a caller that declares 1 inside an 8-rank group gets an
+    error, not an 8-rank sum divided by 1), else the declared `world` (None = 1)"""
+    if dist.is_initialized():
+        size = dist.get_world_size()
+        if world is not None and int(world) != size:
+            raise RuntimeError(f"world={world} declared inside a process group of {size} ranks: pass world=None (= the group's size), "
+                               f"or local=True for a step without collectives")
+        return size
+    return 1 if world is None else int(world)
+
+
+def collective_path(world: Optional[int] = None, local: bool = False) -> bool:
+    """do the data-parallel steps issue their collectives?  Yes whenever a process group exists (world size 1 included) unless the
+    caller opts out with local=True; a declared world that differs from the group's size, or a declared world > 1 without a
+    group, is an error, not a silently different step"""
+    if local:
+        return False
+    world = group_world(world)
     if dist.is_initialized():
         return True
     if world > 1:
@@ -77,7 +94,7 @@ def _buckets(params: Sequence[torch.nn.Parameter], bucket_bytes: int) -> List[Li
 
 @torch.no_grad()
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], world: Optional[int] = None,
-                        bucket_bytes: int = 64 << 20, average: bool = True) -> int:
+                        bucket_bytes: int = 64 << 20, average: bool = True, local: bool = False) -> int:
     """Sum (or average) .grad over all ranks with a few large flat collectives.
 
     bucket_bytes defaults to 64 MiB: xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a
@@ -89,18 +106,18 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], world: Optional[in
     The collectives are issued whenever a process group EXISTS, a one-rank group included (RCCL / gloo accept it; the sum over
     one rank is the identity, bit for bit): flatten -> all_reduce -> unflatten is the same code at every world size, so what a
     one-GPU box executes under `bench.py --launch` is what an 8-GPU node executes.  Without a process group (a plain
-    single-process run) nothing is issued."""
-    if world is None:
-        world = dist.get_world_size() if dist.is_initialized() else 1
+    single-process run), or with local=True, nothing is issued.  `world` is only a DECLARATION that is checked against the
+    group (group_world): the mean divides by the group's size, never by a number the caller passed."""
     plist = [p for p in params if p.requires_grad]
-    if not collective_path(world) or not plist:
+    if not collective_path(world, local) or not plist:
         return 0
+    size = dist.get_world_size()
     n = 0
     for bucket in _buckets(plist, bucket_bytes):
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         if average:
-            flat.div_(world)
+            flat.div_(size)
         off = 0
         for p in bucket:
             k = p.numel()

@@ -84,20 +84,23 @@ def reid_loss(out: Dict[str, torch.Tensor], link_weight: float = 1.0, se_weight:
 
 
 def finetune_step(roi_features: torch.Tensor, gt_tids: torch.Tensor, link_layer: nn.Module, se_layer: nn.Module,
-                  optimizer: torch.optim.Optimizer, world: int = 1) -> float:
+                  optimizer: torch.optim.Optimizer, world: Optional[int] = None, local: bool = False) -> float:
     """One data-parallel finetune step (tools/train.py:96-107 trains only the link/se heads): local
     forward/backward on this rank's frame pairs, then ONE bucketed gradient all-reduce over RCCL.
 
     The reference computes the loss AFTER DataParallel has gathered every replica's outputs, i.e.
     each term is a mean over the links / starts / ends of the WHOLE batch.  To reproduce that
     gradient exactly, each rank back-propagates its local SUMS divided by the GLOBAL element counts
-    (one 3-float all-reduce), and the gradient all-reduce is a plain SUM."""
+    (one 3-float all-reduce), and the gradient all-reduce is a plain SUM.
+
+    world: None (default) = the process group's size when one exists, else a single-process step; an int is a declaration
+    that must equal the group's size (dist.group_world).  local=True: no collectives even inside a group."""
     import torch.distributed as tdist
     optimizer.zero_grad(set_to_none=True)
     out = training_affinity(roi_features, gt_tids, link_layer, se_layer)
     counts = torch.tensor([out["gt_links"].numel(), out["gt_starts"].numel(), out["gt_ends"].numel()],
                           dtype=torch.float64, device=roi_features.device)
-    collective = jdist.collective_path(world)
+    collective = jdist.collective_path(world, local)
     if collective:
         tdist.all_reduce(counts, op=tdist.ReduceOp.SUM)
     loss = roi_features.new_zeros(())
@@ -107,7 +110,7 @@ def finetune_step(roi_features: torch.Tensor, gt_tids: torch.Tensor, link_layer:
         loss = loss + (torch.sigmoid(out["rcnn_end"].view(-1)) - out["gt_ends"]).abs().sum() / counts[2].item()
         loss.backward()
     params = list(link_layer.parameters()) + list(se_layer.parameters())
-    jdist.allreduce_gradients(params, world=world, average=False)
+    jdist.allreduce_gradients(params, world=world, average=False, local=local)
     optimizer.step()
     total = loss.detach().to(torch.float64).reshape(1)
     if collective:
@@ -365,11 +368,11 @@ def training_affinity_hip(roi_features: torch.Tensor, gt_tids: torch.Tensor, lin
 LAST_GRAD_COLLECTIVES = 0      # gradient collectives the last _finetune_step_hip issued (bench.py reports it)
 
 
-def _finetune_step_hip(roi_features, gt_tids, link_layer, se_layer, optimizer, world):
+def _finetune_step_hip(roi_features, gt_tids, link_layer, se_layer, optimizer, world, local=False):
     import torch.distributed as tdist
     st = AffinityTrainState(roi_features, gt_tids)
     counts = st.counts
-    collective = jdist.collective_path(world)       # a process group exists (a one-rank group included: same path at every size)
+    collective = jdist.collective_path(world, local)       # a process group exists (a one-rank group included: same path at every size)
     if collective:
         counts = counts.clone()
         tdist.all_reduce(counts, op=tdist.ReduceOp.SUM)
@@ -382,7 +385,7 @@ def _finetune_step_hip(roi_features, gt_tids, link_layer, se_layer, optimizer, w
     # profiler is on (BASELINE.md §3 config 4 asks for the all-reduce time next to frames/s)
     from ..profile import prof
     global LAST_GRAD_COLLECTIVES
-    LAST_GRAD_COLLECTIVES = prof.region("grad_allreduce(RCCL)", lambda: jdist.allreduce_gradients(params, world=world, average=False),
+    LAST_GRAD_COLLECTIVES = prof.region("grad_allreduce(RCCL)", lambda: jdist.allreduce_gradients(params, world=world, average=False, local=local),
                                         algo_bytes=sum(p.numel() for p in params) * 4)
     optimizer.step()
     total = _loss_from_parts(lp, sp, counts, 1.0, 1.0)
@@ -392,25 +395,25 @@ def _finetune_step_hip(roi_features, gt_tids, link_layer, se_layer, optimizer, w
 
 
 def finetune_step_static(roi_features: torch.Tensor, gt_tids: torch.Tensor, link_layer: nn.Module, se_layer: nn.Module,
-                         optimizer: torch.optim.Optimizer, world: int = 1) -> torch.Tensor:
+                         optimizer: torch.optim.Optimizer, world: Optional[int] = None, local: bool = False) -> torch.Tensor:
     """`finetune_step` without host synchronisation: static-shape forward/backward, the three global element counts
     and the gradients all-reduced on the device (RCCL), Adam; returns the whole-batch loss as a DEVICE scalar.
     GPU tensors: the hand-written kernels (csrc/affinity_train.hip); CPU tensors (the gloo tests of the data-parallel
     logic): the plain-torch static form."""
     import torch.distributed as tdist
     if roi_features.is_cuda:
-        return _finetune_step_hip(roi_features, gt_tids, link_layer, se_layer, optimizer, world)
+        return _finetune_step_hip(roi_features, gt_tids, link_layer, se_layer, optimizer, world, local)
     optimizer.zero_grad(set_to_none=True)
     out = training_affinity_static(roi_features, gt_tids, link_layer, se_layer)
     with torch.no_grad():
         counts = torch.stack([out["valid"].sum(), out["start_valid"].sum(), out["end_valid"].sum()]).to(torch.float32)
-        collective = jdist.collective_path(world)
+        collective = jdist.collective_path(world, local)
         if collective:
             tdist.all_reduce(counts, op=tdist.ReduceOp.SUM)
     loss, _ = reid_loss_static(out, counts)
     loss.backward()
     params = list(link_layer.parameters()) + list(se_layer.parameters())
-    jdist.allreduce_gradients(params, world=world, average=False)
+    jdist.allreduce_gradients(params, world=world, average=False, local=local)
     optimizer.step()
     total = loss.detach().clone()
     if collective:

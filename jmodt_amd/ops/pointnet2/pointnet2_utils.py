@@ -74,21 +74,37 @@ def farthest_point_sample_xyz(xyz: torch.Tensor, npoint: int):
         # the row is clamped to index 0 HERE and the failure is kept as a device flag that `check_fps_failures()` turns into an
         # exception at the caller's next synchronisation point — no host sync on the sampling chain
         bad = idx[:, :1] < 0
-        FPS_FAILED.append(bad.any())
-        del FPS_FAILED[:-64]
+        flag = bad.any()
+        ev = torch.cuda.Event()
+        ev.record()                               # on the stream that produced the flag (an FPS side stream under the prefetch)
+        FPS_FAILED.append((flag, ev))
+        if len(FPS_FAILED) > FPS_FAILED_KEEP:     # a caller that never checks: the oldest flags are dropped, loudly
+            import warnings
+            warnings.warn(f"furthest_point_sample: {len(FPS_FAILED) - FPS_FAILED_KEEP} unchecked co-operative-kernel failure "
+                          f"flag(s) dropped; call check_fps_failures() at a synchronisation point", RuntimeWarning, stacklevel=2)
+            del FPS_FAILED[:-FPS_FAILED_KEEP]
         idx = torch.where(bad, torch.zeros_like(idx), idx)
         new_xyz = torch.where(bad.unsqueeze(-1), xyz[:, :1].expand(-1, npoint, -1), new_xyz)
     return idx, new_xyz
 
 
-FPS_FAILED = []      # device bools of the co-operative FPS launches not yet checked
+FPS_FAILED = []      # (device bool, event recorded behind it on ITS stream) of the co-operative FPS launches not yet checked
+FPS_FAILED_KEEP = 64
 
 
-def check_fps_failures() -> None:
+def check_fps_failures(wait: bool = False) -> None:
     """raise if a co-operative furthest_point_sample launch since the last call gave a cloud up (exchange time-out: a broken
-    device partition, or a launch overlapped with work that kept its peer workgroups off the machine for seconds).  Synchronises
-    on the flags: call it where the host waits for the device anyway (DetectionCache.counts_host does)."""
-    flags, FPS_FAILED[:] = list(FPS_FAILED), []
+    device partition, or a launch overlapped with work that kept its peer workgroups off the machine for seconds).
+    The flags are written on the stream that ran the sampling (a side stream under the next-batch prefetch), not on the caller's:
+    only flags whose own event has COMPLETED are read (and consumed); the others stay listed for the next call — wait=True
+    synchronises on them instead.  Call it where the host waits for the device anyway (DetectionCache.counts_host does)."""
+    ready, pending = [], []
+    for flag, ev in FPS_FAILED:
+        if wait:
+            ev.synchronize()
+        (ready if wait or ev.query() else pending).append((flag, ev))
+    FPS_FAILED[:] = pending
+    flags = [f for f, _ in ready]
     if flags and bool(torch.stack(flags).any().item()):
         raise RuntimeError("furthest_point_sample: the co-operative kernel timed out waiting for a peer workgroup; the sampled "
                            "indices of at least one cloud are invalid (they were clamped to 0)")

@@ -289,3 +289,12 @@ def test_module_tensor_lists_follow_registrations():
     assert not any(t is conv.weight for t in _registry.module_tensors(mlp))
     _registry.invalidate()                                                          # ... with an explicit way out
     assert any(t is conv.weight for t in _registry.module_tensors(mlp))
+    # re-parenting an already built submodule registers no parameter: the MODULE registration hook moves the epoch too
+    other = pt_utils.SharedMLP([6, 8, 8], bn=True)
+    c = _registry.module_tensors(mlp)
+    mlp.layer0 = other.layer0
+    d = _registry.module_tensors(mlp)
+    assert d is not c and any(t is other.layer0.conv.weight for t in d)
+    del mlp.layer1                                                                  # ... and so does removing one
+    e = _registry.module_tensors(mlp)
+    assert e is not d and len(e) < len(d)

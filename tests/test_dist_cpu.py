@@ -104,7 +104,10 @@ def _one_rank_worker(rank, port, tmpdir):
     import torch.distributed as tdist
     from jmodt_amd.ops.affinity_train import finetune_step_static
     tdist.init_process_group("gloo")
-    assert jdist.collective_path(1)
+    assert jdist.collective_path(1) and jdist.collective_path(None) and jdist.group_world() == 1
+    assert not jdist.collective_path(None, local=True)                   # the explicit opt-out inside a group
+    with pytest.raises(RuntimeError, match="declared inside a process group"):
+        jdist.group_world(4)                                             # a declaration that differs from the group's size
     ps = [torch.nn.Parameter(torch.ones(5)), torch.nn.Parameter(torch.ones(3, 3))]
     ps[0].grad = torch.arange(5.0)
     assert jdist.allreduce_gradients(ps, bucket_bytes=16) == 2           # ISSUED on the one-rank group (not skipped)
