@@ -394,8 +394,13 @@ def dense_step(d):
 def make_joint_state(frames, seed, dev, tiny=False):
     """BASELINE configs[3] in JOINT mode (tools/train.py:96-107 without cfg.TRAIN.FINETUNE): every parameter of the detector and
     of the affinity heads trains; the step is jmodt_amd/train_joint.joint_step"""
+    from jmodt_amd import train_joint
     st = make_detect_state(frames, seed, dev, tiny=tiny)
-    eng = st["engine"].train()
+    eng = st["engine"]
+    if os.environ.get("JM_JOINT_ROUTE", "rows") == "rows":
+        train_joint.freeze_bn(eng)       # train mode (RPN-head dropout active), BatchNorm on its running statistics: cfg.RPN.FIXED-style
+    else:
+        eng.train()                      # the un-fused operator route: BatchNorm on batch statistics
     g = torch.Generator(device="cpu").manual_seed(seed)
     rois_per_frame = min(64, eng.cfg.rpn_post_nms_top_n)
     st["tids"] = torch.randint(0, 13, (frames, rois_per_frame), generator=g).float().to(dev)
@@ -442,7 +447,8 @@ def train_step(st, world):
     if st.get("joint"):
         from jmodt_amd.train_joint import joint_step
         return joint_step(eng, st["xyz"], st["image"], st["pts_xy"], st["tids"], st["opt"], world=world,
-                          rois_per_frame=st["rois_per_frame"])
+                          rois_per_frame=st["rois_per_frame"], route=os.environ.get("JM_JOINT_ROUTE", "auto"),
+                          next_xyz=st["xyz"] if st.get("prefetch", True) else None)
     with torch.no_grad():
         pf = st.get("prefetch", True)
         _, inter = eng.detect(st["xyz"], st["image"], st["pts_xy"], next_xyz=_upcoming(st) if pf else None, next_image=st["image"] if pf else None)

@@ -602,6 +602,77 @@ int jm_affinity_train_feature_grad(int npairs, int r, int c, const float* tids, 
                                    const float* dx_link, const float* dx_se, float* dpooled_ws, float* dfeat,
                                    jm_stream_t stream);
 
+/* ------------------------------------------------------------------ training path on rows ---- */
+/* The joint-mode training step (tools/train.py:96-107 without cfg.TRAIN.FINETUNE; point_rcnn.py:24-70 in TRAIN mode) keeps every
+ * per-point / per-(centre, neighbour) activation as a ROW-major (rows, channels) float32 tensor.  These entries are the forward
+ * AND backward of what the reference runs through torch autograd there: SharedMLP / Conv1d stacks (pytorch_utils.py:6-33),
+ * set abstraction (pointnet2_modules.py:46-61 with pointnet2_utils.py:156-197,231-290), feature propagation (:139-153 with
+ * pointnet2_utils.py:105-150), the LI-Fusion gather and attention block (backbone.py:35-89).  `*_dev` row counts live in device
+ * memory (NULL: the host bound is the count); `ld*` = floats between consecutive rows; widths and ld* are multiples of 4. */
+
+/* y (m, n) = act(x1 (m, k1) w[:, :k1]^T + x2 (m, k2) w[:, k1:]^T + bias) * rowscale[row];  w (n, k1 + k2) rows ldw apart
+ * (an nn.Conv1d / Conv2d 1x1 / Linear weight as it is); x2 / bias / rowscale may be NULL (k2 = 0); act 0 none, 1 ReLU, 2 tanh.
+ * The two-operand form is the concatenation of pointnet2_modules.py:157-160 / backbone.py:78 without the copy. */
+int jm_rows_linear_forward(int m, const int* m_dev, int k1, int k2, int n, const float* x1, int ldx1, const float* x2, int ldx2,
+                           const float* w, int ldw, const float* bias, int act, const float* rowscale, float* y, int ldy,
+                           jm_stream_t stream);
+/* dx (m, k) = (dy (m, n) w (n, k)) .* (mask (m, k) > 0), optionally added to dx: what autograd computes for conv + ReLU of
+ * the layer below (mask = that layer's output); mask may be NULL; w + k1 with the same ldw addresses the second operand */
+int jm_rows_linear_dgrad(int m, const int* m_dev, int n, int k, const float* dy, int lddy, const float* w, int ldw,
+                         const float* mask, int ldm, int accumulate, float* dx, int lddx, jm_stream_t stream);
+/* dw (n, k) (+)= dy (m, n)^T x (m, k), dbias (n) (+)= column sums of dy (NULL: skipped).  The m rows are split over
+ * jm_rows_wgrad_splits(m, n, k) partials in ws, reduced in split order: deterministic, no float atomics */
+int jm_rows_wgrad_splits(int m, int n, int k);
+size_t jm_rows_wgrad_workspace_bytes(int m, int n, int k);
+int jm_rows_linear_wgrad(int m, const int* m_dev, int n, int k, const float* dy, int lddy, const float* x, int ldx,
+                         float* dw, int lddw, float* dbias, int accumulate, void* ws, size_t ws_bytes, jm_stream_t stream);
+/* out (n) (+)= column sums of x (m, n); ws >= jm_rows_reduce_workspace_bytes(n) */
+size_t jm_rows_reduce_workspace_bytes(int n);
+int jm_rows_colsum(int m, const int* m_dev, int n, const float* x, int ldx, float* out, int accumulate, void* ws, size_t ws_bytes,
+                   jm_stream_t stream);
+/* dy = y > 0 ? dy : 0 in place (the ReLU of a block's last layer, whose gradient arrives from outside the block) */
+int jm_rows_relu_mask(int m, const int* m_dev, int n, float* dy, int ldd, const float* y, int ldy, jm_stream_t stream);
+
+/* Set-abstraction rows: the DISTINCT (centre, neighbour) pairs of every group.  idx (groups, ns) int32 = ball_query's lists
+ * (ns <= 64), entries local to their point set (frame / RoI) of n_per_set points; group g belongs to set g / groups_per_set;
+ * canon (sets, n_per_set) int32 or NULL maps a point to the first point it is an exact copy of (cyclic roipool3d padding).
+ * d (groups): rows per group; offsets (groups + 1): exclusive scan, offsets[groups] = the row count R (device memory);
+ * row_point (R) = set * n_per_set + canonical entry, row_group (R) = g; buffers sized groups * ns.  Three launches. */
+int jm_sa_rows_plan(int groups, int ns, const int* idx, const int* canon, int n_per_set, int groups_per_set, int* d, int* offsets,
+                    int* row_point, int* row_group, jm_stream_t stream);
+/* h1[r, :] = relu((u ? u[row_point[r], :] : b1) + w1x (h, 3) (xyz[row_point[r]] - ctr[row_group[r]])): the first SharedMLP layer
+ * on [xyz_j - c_i ; f_j] (pointnet2_utils.py:259-269) with its feature part u = W1f f + b1 computed per point; ctr NULL = GroupAll */
+int jm_sa_rows_h1(int rows, const int* rows_dev, int h, const float* u, int ldu, const float* b1, const float* w1x, const float* xyz,
+                  const float* ctr, const int* row_point, const int* row_group, float* h1, int ldh, jm_stream_t stream);
+/* out (groups, c) = max over each group's rows (F.max_pool2d, pointnet2_modules.py:50-55), argrow (groups, c) = the first row holding it */
+int jm_sa_rows_pool(int groups, int c, const float* h, int ldh, const int* offsets, float* out, int ldo, int* argrow, jm_stream_t stream);
+/* dh (rows, c) = d(out) routed to the arg-max rows where the pooled (post-ReLU) value is positive, 0 elsewhere */
+int jm_sa_rows_pool_grad(int rows, const int* rows_dev, int c, const float* dout, int lddo, const float* out, int ldo, const int* argrow,
+                         const int* row_group, float* dh, int ldd, jm_stream_t stream);
+/* du[row_point[r], :] += dh1[r, :] (the grouping_operation backward of group_points_gpu.cu:48-86 on the compacted rows) */
+int jm_sa_rows_scatter_add(int rows, const int* rows_dev, int h, const float* dh1, int ldd, const int* row_point, float* du, int ldu,
+                           jm_stream_t stream);
+/* dw1x (h, 3) (+)= sum_r dh1[r, :]^T (xyz[row_point[r]] - ctr[row_group[r]]); ws >= jm_rows_reduce_workspace_bytes(3 h) */
+int jm_sa_rows_xyz_wgrad(int rows, const int* rows_dev, int h, const float* dh1, int ldd, const float* xyz, const float* ctr,
+                         const int* row_point, const int* row_group, float* dw1x, int accumulate, void* ws, size_t ws_bytes, jm_stream_t stream);
+
+/* three_interpolate (interpolate_gpu.cu:77-161) on rows: known (b m, c) -> out (b n, c); the gradient adds into dknown (pre-zeroed) */
+int jm_three_interpolate_rows(int b, int n, int m, int c, const float* known, int ldk, const int* idx, const float* w, float* out, int ldo,
+                              jm_stream_t stream);
+int jm_three_interpolate_rows_grad(int b, int n, int m, int c, const float* dout, int ldo, const int* idx, const float* w, float* dknown, int ldk,
+                                   jm_stream_t stream);
+/* feature_gather (backbone.py:79-89) from a channels-last map (b, h, w, c) to rows (b n, c); the gradient adds into a
+ * channels-last map (pre-zeroed) */
+int jm_feature_gather_rows(int b, int c, int h, int w, int n, const float* fmap_cl, const float* xy, float* out, int ldo, jm_stream_t stream);
+int jm_feature_gather_rows_grad(int b, int c, int h, int w, int n, const float* grad_out, int ldo, const float* xy, float* grad_fmap_cl,
+                                jm_stream_t stream);
+/* IA_Layer gate (backbone.py:54-62): g[r] = sigmoid(z[r * ldz]); and the backward through J = relu(conv1(img)) * g:
+ * dj (m, pc) <- gradient w.r.t. conv1's pre-activation (in place), dz (m, 4) = [d(gate logit), 0, 0, 0], dt (m, rc) = gradient
+ * w.r.t. the tanh's argument; j = the gated output, t = the tanh output, w3 (rc) = fc3's weight */
+int jm_rows_sigmoid(int m, const float* z, int ldz, float* g, jm_stream_t stream);
+int jm_rows_gate_backward(int m, int pc, int rc, float* dj, int ldj, const float* j, int ldjj, const float* g, const float* t, int ldt,
+                          const float* w3, float* dz, float* dt, int lddt, jm_stream_t stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

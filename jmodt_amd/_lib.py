@@ -153,6 +153,26 @@ SIGNATURES = {
     "jm_affinity_train_se_step": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, ctypes.POINTER(Mlp3), _P, _P,
                                        ctypes.POINTER(Mlp3Grad), _P, _P, _Z, _P]),
     "jm_affinity_train_feature_grad": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "jm_rows_linear_forward": (_I, [_I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P]),
+    "jm_rows_linear_dgrad": (_I, [_I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P]),
+    "jm_rows_wgrad_splits": (_I, [_I, _I, _I]),
+    "jm_rows_wgrad_workspace_bytes": (_Z, [_I, _I, _I]),
+    "jm_rows_linear_wgrad": (_I, [_I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _Z, _P]),
+    "jm_rows_reduce_workspace_bytes": (_Z, [_I]),
+    "jm_rows_colsum": (_I, [_I, _P, _I, _P, _I, _P, _I, _P, _Z, _P]),
+    "jm_rows_relu_mask": (_I, [_I, _P, _I, _P, _I, _P, _I, _P]),
+    "jm_sa_rows_plan": (_I, [_I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "jm_sa_rows_h1": (_I, [_I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "jm_sa_rows_pool": (_I, [_I, _I, _P, _I, _P, _P, _I, _P, _P]),
+    "jm_sa_rows_pool_grad": (_I, [_I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P]),
+    "jm_sa_rows_scatter_add": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _P]),
+    "jm_sa_rows_xyz_wgrad": (_I, [_I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
+    "jm_three_interpolate_rows": (_I, [_I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
+    "jm_three_interpolate_rows_grad": (_I, [_I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
+    "jm_feature_gather_rows": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
+    "jm_feature_gather_rows_grad": (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
+    "jm_rows_sigmoid": (_I, [_I, _P, _I, _P, _P]),
+    "jm_rows_gate_backward": (_I, [_I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _I, _P]),
 }
 
 _lib = None

@@ -149,6 +149,49 @@ feature_gather_grad_kernel(int C, int H, int W, int N, const float* __restrict__
     }
 }
 
+// ---- training path: ROW-major output (B N, C) from a channels-last map; thread = (point, 4 channels), consecutive lanes =
+// consecutive channel quads of one point: the four tap vectors are contiguous 16-byte reads, the output row one contiguous store
+__global__ void __launch_bounds__(256)
+feature_gather_rows_kernel(int B, int C, int H, int W, int N, const float* __restrict__ fmap, const float* __restrict__ xy,
+                           float* __restrict__ out, int ldo) {
+    const int q = C / 4;
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= (long long)B * N * q) return;
+    const int pt = (int)(i / q), c = (int)(i % q) * 4;
+    const int bi = pt / N;
+    const float2 p = *reinterpret_cast<const float2*>(xy + (size_t)pt * 2);
+    const Taps t = make_taps(p.x, p.y, H, W, (long long)W * C, C);
+    const float* base = fmap + (size_t)bi * H * W * C + c;
+    const float4 a = *reinterpret_cast<const float4*>(base + t.o_nw);
+    const float4 b = *reinterpret_cast<const float4*>(base + t.o_ne);
+    const float4 d = *reinterpret_cast<const float4*>(base + t.o_sw);
+    const float4 e = *reinterpret_cast<const float4*>(base + t.o_se);
+    float r[4];
+    r[0] = a.x * t.w_nw; r[0] += b.x * t.w_ne; r[0] += d.x * t.w_sw; r[0] += e.x * t.w_se;
+    r[1] = a.y * t.w_nw; r[1] += b.y * t.w_ne; r[1] += d.y * t.w_sw; r[1] += e.y * t.w_se;
+    r[2] = a.z * t.w_nw; r[2] += b.z * t.w_ne; r[2] += d.z * t.w_sw; r[2] += e.z * t.w_se;
+    r[3] = a.w * t.w_nw; r[3] += b.w * t.w_ne; r[3] += d.w * t.w_sw; r[3] += e.w * t.w_se;
+    *reinterpret_cast<float4*>(out + (size_t)pt * ldo + c) = make_float4(r[0], r[1], r[2], r[3]);
+}
+
+// thread = (point, channel): a wave adds 64 consecutive channels of one tap = 256 contiguous bytes per atomic instruction
+__global__ void __launch_bounds__(256)
+feature_gather_rows_grad_kernel(int B, int C, int H, int W, int N, const float* __restrict__ grad_out, int ldo, const float* __restrict__ xy,
+                                float* __restrict__ grad_fmap) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= (long long)B * N * C) return;
+    const int pt = (int)(i / C), c = (int)(i % C);
+    const int bi = pt / N;
+    const float2 p = *reinterpret_cast<const float2*>(xy + (size_t)pt * 2);
+    const Taps t = make_taps(p.x, p.y, H, W, (long long)W * C, C);
+    const float g = grad_out[(size_t)pt * ldo + c];
+    float* base = grad_fmap + (size_t)bi * H * W * C + c;
+    if (t.w_nw != 0.f) unsafeAtomicAdd(base + t.o_nw, g * t.w_nw);
+    if (t.w_ne != 0.f) unsafeAtomicAdd(base + t.o_ne, g * t.w_ne);
+    if (t.w_sw != 0.f) unsafeAtomicAdd(base + t.o_sw, g * t.w_sw);
+    if (t.w_se != 0.f) unsafeAtomicAdd(base + t.o_se, g * t.w_se);
+}
+
 }  // namespace jm
 
 using namespace jm;
@@ -186,4 +229,26 @@ extern "C" int jm_feature_gather_grad(int b, int c, int h, int w, int n, const f
                        (hipStream_t)stream, c, h, w, n, grad_out, xy, grad_fmap, (long long)sb, (long long)sc,
                        (long long)sh, (long long)sw);
     return check_launch("feature_gather_grad");
+}
+
+/* training path: channels-last map (B, H, W, C) -> rows (B N, C) (ldo floats apart); same taps / products / summation order */
+extern "C" int jm_feature_gather_rows(int b, int c, int h, int w, int n, const float* fmap_cl, const float* xy, float* out, int ldo,
+                                      jm_stream_t stream) {
+    JM_REQUIRE(b > 0 && c > 0 && c % 4 == 0 && h >= 1 && w >= 1 && n > 0 && ldo % 4 == 0 && ldo >= c && fmap_cl && xy && out,
+               "feature_gather_rows: bad arguments (c %d and ldo %d must be multiples of 4)", c, ldo);
+    JM_REQUIRE((reinterpret_cast<uintptr_t>(fmap_cl) & 15u) == 0 && (reinterpret_cast<uintptr_t>(xy) & 7u) == 0, "feature_gather_rows: alignment");
+    const long long work = (long long)b * n * (c / 4);
+    hipLaunchKernelGGL(feature_gather_rows_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b, c, h, w, n, fmap_cl, xy,
+                       out, ldo);
+    return check_launch("feature_gather_rows");
+}
+
+/* grad_fmap_cl (B, H, W, C) pre-zeroed by the caller (or holding a gradient to add to) */
+extern "C" int jm_feature_gather_rows_grad(int b, int c, int h, int w, int n, const float* grad_out, int ldo, const float* xy, float* grad_fmap_cl,
+                                           jm_stream_t stream) {
+    JM_REQUIRE(b > 0 && c > 0 && h >= 1 && w >= 1 && n > 0 && ldo >= c && grad_out && xy && grad_fmap_cl, "feature_gather_rows_grad: bad arguments");
+    const long long work = (long long)b * n * c;
+    hipLaunchKernelGGL(feature_gather_rows_grad_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b, c, h, w, n,
+                       grad_out, ldo, xy, grad_fmap_cl);
+    return check_launch("feature_gather_rows_grad");
 }

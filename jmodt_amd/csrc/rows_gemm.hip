@@ -1,0 +1,312 @@
+// rows_gemm.hip — dense layers of the TRAINING path on row-major ("point-major") activations: forward, data gradient and
+// weight gradient of  Y = act(X W^T + b)  on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), for the joint-mode step of
+// BASELINE configs[3] (tools/train.py:96-107 without cfg.TRAIN.FINETUNE).
+//
+// What it replaces: torch autograd over the reference's module tree — pytorch_utils.py:6-33 (SharedMLP = Conv2d 1x1 + BN +
+// ReLU on (B, C, npoint, nsample) tensors), pointnet2_modules.py:46-61 (set abstraction), :139-153 (feature propagation),
+// backbone.py:35-81 (LI-Fusion attention block), rpn.py:34-58 / rcnn.py:43-89 (heads).  Every one of those is, per point or
+// per (centre, neighbour) row, a chain of dense layers; in the training path all of them keep their activations as
+// (rows, channels) row-major tensors, so ONE GEMM family serves them all and nothing is ever transposed:
+//     forward   Y (M, N)  = act(X (M, K) W (N, K)^T + b)      X may be the concatenation [X1 | X2] of two row tensors
+//                                                             (skip connections: never materialised)
+//     dgrad     dX (M, K) = (dY (M, N) W (N, K)) .* (mask > 0)  W read k-major IN PLACE; mask = the layer input's own
+//                                                             post-ReLU activation, so dX is already the gradient w.r.t. the
+//                                                             previous layer's pre-activation
+//     wgrad     dW (N, K) = dY^T X, split over the M rows       both operands k-major in place; split partials reduced in a
+//                                                             fixed order by rows_wgrad_reduce_kernel (no float atomics)
+// The row count may live in DEVICE memory (`m_dev`): the set-abstraction rows are compacted to the DISTINCT (centre, neighbour)
+// pairs of every ball-query group on the device (rows_ops.hip: sa_rows_plan), and the host never learns how many there are.
+// Grids are persistent over the tiles that exist.
+//
+// Tile: 128 x 128 x 16, four waves of 64 x 64 (2 x 2 MFMA blocks of 32 x 32), operands double-buffered through k-major LDS
+// tiles (the layout of csrc/affinity_train.hip's train_gemm_kernel, whose operand forms these are).  Contraction tails
+// (K % 16 != 0: the 196-wide hidden layer of RPN SA3, config.py:76) are zero-filled at LDS store time; every global load is
+// unconditional on a clamped, valid address.  Requirements (checked by the entries): K % 4 == 0 and lda / ldb % 4 == 0 for
+// row operands, N % 4 == 0 for k-major operands.
+#include "jm_rows.h"
+
+namespace jm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int RBM = 128, RBN = 128, RBK = 16, RLDP = RBM + 4;
+enum { RM_FWD = 0, RM_DGRAD = 1, RM_WGRAD = 2 };
+
+struct RGemm {
+    int M, N, K;                   // output rows, output columns, contraction length
+    const int* m_dev;              // FWD / DGRAD: valid rows = min(M, *m_dev); WGRAD: valid contraction = min(K, *m_dev)
+    const float* A; int lda;       // FWD / DGRAD: (M, K) rows; WGRAD: (K, M) — element (row r, contraction c) = A[c * lda + r]
+    const float* A2; int lda2;     // FWD: contraction indices K1 .. K - 1 are columns 0 .. of A2's rows
+    int K1;
+    const float* B; int ldb;       // FWD: (N, K) rows (the layer's weight); DGRAD / WGRAD: (K, N) k-major
+    const float* bias; int act;    // FWD: act 0 none, 1 ReLU, 2 tanh
+    const float* rowscale;         // FWD: out *= rowscale[row] after the activation (the attention gate)
+    const float* mask; int ldm;    // DGRAD: out = mask[row, col] > 0 ? acc : 0
+    int accumulate;                // DGRAD: out += acc
+    float* out; int ldo;
+    int splits;                    // WGRAD: blockIdx.y = split; partial s at out + s * M * ldo
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+rows_gemm_kernel(RGemm p) {
+    __shared__ __attribute__((aligned(16))) float As[2][RBK][RLDP];
+    __shared__ __attribute__((aligned(16))) float Bs[2][RBK][RLDP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lk = lane >> 5;
+    const int valid = p.m_dev ? min(MODE == RM_WGRAD ? p.K : p.M, max(*p.m_dev, 0)) : (MODE == RM_WGRAD ? p.K : p.M);
+    const int Mv = MODE == RM_WGRAD ? p.M : valid;
+    const int Kv = MODE == RM_WGRAD ? valid : p.K;
+    const int ntn = (p.N + RBN - 1) / RBN;
+    const int ntiles = ((Mv + RBM - 1) / RBM) * ntn;
+    int k_begin = 0, k_end = Kv;
+    if (MODE == RM_WGRAD) {
+        const int kchunk = ((Kv + p.splits - 1) / p.splits + RBK - 1) / RBK * RBK;
+        k_begin = min((int)blockIdx.y * kchunk, Kv);
+        k_end = min(Kv, k_begin + kchunk);
+    }
+    const int nkt = (k_end - k_begin + RBK - 1) / RBK;
+
+    // staging roles: 128 x 16 floats per operand per k-tile = 512 float4 = 2 per thread
+    //   row operands: 4 consecutive k of one row, scattered to S[k .. k + 3][row]
+    //   k-major operands: 4 consecutive rows of one contraction index, one ds_write_b128 to S[k][row .. row + 3]
+    int t_row[2], t_kq[2], d_k[2], d_r4[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = tid + 256 * i;
+        t_row[i] = f >> 2; t_kq[i] = (f & 3) * 4;
+        d_k[i] = f >> 5;   d_r4[i] = (f & 31) * 4;
+    }
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m0 = (tile / ntn) * RBM, n0 = (tile % ntn) * RBN;
+        float4 ra[2], rb[2];
+        bool a_in[2], b_in[2];
+        auto g_load = [&](int k0) {          // k0 = absolute contraction index of the k-tile's first element
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (MODE == RM_WGRAD) {
+                    const int kc = k0 + d_k[i];
+                    a_in[i] = kc < k_end; b_in[i] = a_in[i];
+                    const size_t kk = (size_t)min(kc, max(Kv - 1, 0));
+                    ra[i] = *reinterpret_cast<const float4*>(p.A + kk * p.lda + min(m0 + d_r4[i], p.M - 4));
+                    rb[i] = *reinterpret_cast<const float4*>(p.B + kk * p.ldb + min(n0 + d_r4[i], p.N - 4));
+                } else {
+                    const int m = min(m0 + t_row[i], Mv - 1);
+                    const int k = k0 + t_kq[i];
+                    a_in[i] = k < p.K;
+                    const int kc = min(k, p.K - 4);
+                    if (MODE == RM_FWD && p.A2 != nullptr && kc >= p.K1)
+                        ra[i] = *reinterpret_cast<const float4*>(p.A2 + (size_t)m * p.lda2 + (kc - p.K1));
+                    else
+                        ra[i] = *reinterpret_cast<const float4*>(p.A + (size_t)m * p.lda + kc);
+                    if (MODE == RM_FWD) {
+                        b_in[i] = a_in[i];
+                        const int n = min(n0 + t_row[i], p.N - 1);
+                        rb[i] = *reinterpret_cast<const float4*>(p.B + (size_t)n * p.ldb + kc);
+                    } else {
+                        const int kd = k0 + d_k[i];
+                        b_in[i] = kd < p.K;
+                        rb[i] = *reinterpret_cast<const float4*>(p.B + (size_t)min(kd, p.K - 1) * p.ldb + min(n0 + d_r4[i], p.N - 4));
+                    }
+                }
+            }
+        };
+        auto s_store = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float4 a = a_in[i] ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 b = b_in[i] ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (MODE == RM_WGRAD) {
+                    *reinterpret_cast<float4*>(&As[buf][d_k[i]][d_r4[i]]) = a;
+                } else {
+                    As[buf][t_kq[i] + 0][t_row[i]] = a.x; As[buf][t_kq[i] + 1][t_row[i]] = a.y;
+                    As[buf][t_kq[i] + 2][t_row[i]] = a.z; As[buf][t_kq[i] + 3][t_row[i]] = a.w;
+                }
+                if (MODE == RM_FWD) {
+                    Bs[buf][t_kq[i] + 0][t_row[i]] = b.x; Bs[buf][t_kq[i] + 1][t_row[i]] = b.y;
+                    Bs[buf][t_kq[i] + 2][t_row[i]] = b.z; Bs[buf][t_kq[i] + 3][t_row[i]] = b.w;
+                } else {
+                    *reinterpret_cast<float4*>(&Bs[buf][d_k[i]][d_r4[i]]) = b;
+                }
+            }
+        };
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        if (nkt > 0) {
+            g_load(k_begin);
+            s_store(0);
+            __syncthreads();
+            for (int kt = 0; kt < nkt; ++kt) {
+                const int buf = kt & 1;
+                g_load(k_begin + min(kt + 1, nkt - 1) * RBK);       // unconditional (last tile re-read, unused)
+                __builtin_amdgcn_sched_barrier(0);                  // loads stay above the MFMAs
+#pragma unroll
+                for (int kk = 0; kk < RBK / 2; ++kk) {
+                    const int k2 = kk * 2 + lk;
+                    const float a0 = As[buf][k2][wm * 64 + lr], a1 = As[buf][k2][wm * 64 + 32 + lr];
+                    const float b0 = Bs[buf][k2][wn * 64 + lr], b1 = Bs[buf][k2][wn * 64 + 32 + lr];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + 1 < nkt) s_store(buf ^ 1);
+                __syncthreads();
+            }
+        }
+
+        // epilogue.  C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+        float* out = p.out + (MODE == RM_WGRAD ? (size_t)blockIdx.y * p.M * p.ldo : 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + lr;
+                const bool cok = col < p.N;
+                const float bv = (MODE == RM_FWD && p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    const bool ok = cok && row < Mv;
+                    float v = acc[i][j][r];
+                    if (MODE == RM_FWD) {
+                        v += bv;
+                        if (p.act == 1) v = fmaxf(v, 0.f);
+                        else if (p.act == 2) v = tanhf(v);
+                        if (p.rowscale != nullptr && ok) v *= p.rowscale[row];
+                    }
+                    if (MODE == RM_DGRAD) {
+                        if (p.mask != nullptr) v = (ok && p.mask[(size_t)row * p.ldm + col] > 0.f) ? v : 0.f;
+                        if (p.accumulate && ok) v += out[(size_t)row * p.ldo + col];
+                    }
+                    if (ok) out[(size_t)row * p.ldo + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// dW[n, k] (+)= sum over the split partials in split order (the bias gradient = column sums of dY: jm_rows_colsum)
+__global__ void rows_wgrad_reduce_kernel(int N, int K, int splits, const float* __restrict__ part, int ldp, float* __restrict__ dW, int ldw,
+                                         int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * (K / 4)) return;
+    const int n = i / (K / 4), k4 = (i % (K / 4)) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < splits; ++t) {
+        const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)t * N + n) * ldp + k4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float* d = dW + (size_t)n * ldw + k4;
+    if (accumulate) { d[0] += s.x; d[1] += s.y; d[2] += s.z; d[3] += s.w; }
+    else { d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w; }
+}
+
+static int persistent_grid(long long tiles) { return (int)(tiles < 1 ? 1 : (tiles > 2048 ? 2048 : tiles)); }
+
+}  // namespace jm
+
+using namespace jm;
+
+extern "C" {
+
+int jm_rows_linear_forward(int m, const int* m_dev, int k1, int k2, int n, const float* x1, int ldx1, const float* x2, int ldx2,
+                           const float* w, int ldw, const float* bias, int act, const float* rowscale, float* y, int ldy,
+                           jm_stream_t stream) {
+    const int k = k1 + k2;
+    JM_REQUIRE(m >= 0 && n > 0 && k1 > 0 && k2 >= 0 && x1 && w && y, "rows_linear_forward: bad arguments");
+    JM_REQUIRE(k1 % 4 == 0 && k2 % 4 == 0 && ldx1 % 4 == 0 && ldw % 4 == 0 && (k2 == 0 || (x2 && ldx2 % 4 == 0)) && ldx1 >= k1 && ldw >= k,
+               "rows_linear_forward: widths and leading dimensions must be multiples of 4 (k1 %d, k2 %d, ldx1 %d, ldx2 %d, ldw %d)", k1, k2, ldx1, ldx2, ldw);
+    JM_REQUIRE(act >= 0 && act <= 2 && ldy >= n, "rows_linear_forward: act %d, ldy %d < n %d", act, ldy, n);
+    if (m == 0) return JM_OK;
+    RGemm p{};
+    p.M = m; p.N = n; p.K = k; p.m_dev = m_dev; p.A = x1; p.lda = ldx1; p.A2 = k2 ? x2 : nullptr; p.lda2 = ldx2; p.K1 = k1;
+    p.B = w; p.ldb = ldw; p.bias = bias; p.act = act; p.rowscale = rowscale; p.out = y; p.ldo = ldy; p.splits = 1;
+    const long long tiles = (long long)divup(m, RBM) * divup(n, RBN);
+    hipLaunchKernelGGL((rows_gemm_kernel<RM_FWD>), dim3((unsigned)persistent_grid(tiles)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("rows_linear_forward");
+}
+
+int jm_rows_linear_dgrad(int m, const int* m_dev, int n, int k, const float* dy, int lddy, const float* w, int ldw,
+                         const float* mask, int ldm, int accumulate, float* dx, int lddx, jm_stream_t stream) {
+    // dx (m, k) = (dy (m, n) w (n, k)) .* (mask > 0): the GEMM's contraction is the layer's OUTPUT width n
+    JM_REQUIRE(m >= 0 && n > 0 && k > 0 && dy && w && dx, "rows_linear_dgrad: bad arguments");
+    JM_REQUIRE(n % 4 == 0 && k % 4 == 0 && lddy % 4 == 0 && ldw % 4 == 0 && lddy >= n && ldw >= k && lddx >= k && (!mask || ldm >= k),
+               "rows_linear_dgrad: widths and leading dimensions must be multiples of 4 (n %d, k %d, lddy %d, ldw %d)", n, k, lddy, ldw);
+    if (m == 0) return JM_OK;
+    RGemm p{};
+    p.M = m; p.N = k; p.K = n; p.m_dev = m_dev; p.A = dy; p.lda = lddy; p.B = w; p.ldb = ldw; p.mask = mask; p.ldm = ldm;
+    p.accumulate = accumulate; p.out = dx; p.ldo = lddx; p.splits = 1;
+    const long long tiles = (long long)divup(m, RBM) * divup(k, RBN);
+    hipLaunchKernelGGL((rows_gemm_kernel<RM_DGRAD>), dim3((unsigned)persistent_grid(tiles)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("rows_linear_dgrad");
+}
+
+int jm_rows_wgrad_splits(int m, int n, int k) {
+    // enough (tile, split) workgroups to fill 256 CUs twice over, but at least 512 contraction rows per split
+    const int tiles = divup(n, RBM) * divup(k, RBN);
+    int s = divup(1024, tiles);
+    const int cap = imax(1, m / 512);
+    if (s > cap) s = cap;
+    if (s > 256) s = 256;
+    return imax(1, s);
+}
+
+size_t jm_rows_reduce_workspace_bytes(int n) { return (size_t)JM_ROWS_CHUNKS * (size_t)n * sizeof(float); }
+
+size_t jm_rows_wgrad_workspace_bytes(int m, int n, int k) {
+    // the split partials of dW, then the row-chunk partials of the bias gradient
+    return (size_t)jm_rows_wgrad_splits(m, n, k) * (size_t)n * (size_t)k * sizeof(float) + jm_rows_reduce_workspace_bytes(n);
+}
+
+int jm_rows_colsum(int m, const int* m_dev, int n, const float* x, int ldx, float* out, int accumulate, void* ws, size_t ws_bytes,
+                   jm_stream_t stream) {
+    JM_REQUIRE(m >= 0 && n > 0 && x && out && ldx >= n, "rows_colsum: bad arguments");
+    if (!ws || ws_bytes < jm_rows_reduce_workspace_bytes(n)) {
+        set_error("rows_colsum: workspace of %zu bytes, need %zu", ws_bytes, jm_rows_reduce_workspace_bytes(n));
+        return JM_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(rows_colsum_part_kernel, dim3((unsigned)divup(n, 64), JM_ROWS_CHUNKS), dim3(256), 0, s, m, m_dev, n, JM_ROWS_CHUNKS, x, ldx,
+                       (float*)ws);
+    hipLaunchKernelGGL(rows_sum_partials_kernel, dim3((unsigned)divup(n, 256)), dim3(256), 0, s, n, JM_ROWS_CHUNKS, (const float*)ws, out, accumulate);
+    return check_launch("rows_colsum");
+}
+
+
+int jm_rows_linear_wgrad(int m, const int* m_dev, int n, int k, const float* dy, int lddy, const float* x, int ldx,
+                         float* dw, int lddw, float* dbias, int accumulate, void* ws, size_t ws_bytes, jm_stream_t stream) {
+    // dw (n, k) (+)= dy (m, n)^T x (m, k); dbias (n) (+)= column sums of dy (NULL: skipped)
+    JM_REQUIRE(m >= 0 && n > 0 && k > 0 && dy && x && dw, "rows_linear_wgrad: bad arguments");
+    JM_REQUIRE(n % 4 == 0 && k % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddy >= n && ldx >= k && lddw >= k,
+               "rows_linear_wgrad: widths and leading dimensions must be multiples of 4 (n %d, k %d, lddy %d, ldx %d)", n, k, lddy, ldx);
+    const int splits = jm_rows_wgrad_splits(m, n, k);
+    if (ws_bytes < jm_rows_wgrad_workspace_bytes(m, n, k) || !ws) {
+        set_error("rows_linear_wgrad: workspace of %zu bytes, need %zu", ws_bytes, jm_rows_wgrad_workspace_bytes(m, n, k));
+        return JM_EWORKSPACE;
+    }
+    RGemm p{};
+    p.M = n; p.N = k; p.K = m; p.m_dev = m_dev; p.A = dy; p.lda = lddy; p.B = x; p.ldb = ldx; p.out = (float*)ws; p.ldo = k; p.splits = splits;
+    hipLaunchKernelGGL((rows_gemm_kernel<RM_WGRAD>), dim3((unsigned)(divup(n, RBM) * divup(k, RBN)), (unsigned)splits), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    const int quads = n * (k / 4);
+    hipLaunchKernelGGL(rows_wgrad_reduce_kernel, dim3((unsigned)divup(quads, 256)), dim3(256), 0, (hipStream_t)stream, n, k, splits,
+                       (const float*)ws, k, dw, lddw, accumulate);
+    if (dbias) {
+        float* bws = (float*)ws + (size_t)splits * n * k;
+        return jm_rows_colsum(m, m_dev, n, dy, lddy, dbias, accumulate, bws, jm_rows_reduce_workspace_bytes(n), stream);
+    }
+    return check_launch("rows_linear_wgrad");
+}
+
+}  // extern "C"

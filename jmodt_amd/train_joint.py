@@ -89,18 +89,47 @@ def thin_loss(engine, out: Dict[str, torch.Tensor], gt_tids: torch.Tensor, count
     return (out["rpn_cls"].sum() + out["rpn_reg"].sum()) / n + out["rcnn_cls"].sum() + out["rcnn_reg"].sum() + reid
 
 
-def joint_step(engine, xyz, image, pts_xy, gt_tids, optimizer, world: int = 1, rois_per_frame: int = 64,
-               bucket_bytes: int = 64 << 20) -> torch.Tensor:
+def frozen_bn(engine) -> bool:
+    """is every BatchNorm of the detector in eval mode (running statistics: cfg.RPN.FIXED-style, point_rcnn.py:29-30)?"""
+    return not any(m.training for m in engine.modules() if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)))
+
+
+def freeze_bn(engine) -> None:
+    """train mode for everything but the BatchNorms (frozen statistics, trainable gamma / beta)"""
+    engine.train()
+    for m in engine.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            m.eval()
+
+
+def joint_step(engine, xyz, image, pts_xy, gt_tids, optimizer, world: Optional[int] = None, rois_per_frame: int = 64,
+               bucket_bytes: int = 64 << 20, route: str = "auto", next_xyz=None, local: bool = False) -> torch.Tensor:
     """one data-parallel joint-mode step on this rank's frames: differentiable forward, thin loss, backward through the whole
     detector, the gradient of every parameter all-reduced in 64 MiB buckets (66.9 MB at the reference widths: ONE
-    collective), optimizer step.  Returns the local loss (device scalar, detached)."""
+    collective), optimizer step.  Returns the local loss (device scalar, detached).
+
+    route: "rows" = forward and backward on the hand-written row kernels (train_rows.py; BatchNorm frozen: eval-mode statistics),
+    "operators" = the un-fused operator route above (torch autograd over (B, C, npoint, nsample) tensors; any BatchNorm mode),
+    "auto" = rows whenever the BatchNorms are frozen.  next_xyz: the next batch's cloud — its FPS pyramid / neighbour search
+    starts on the side stream under this step (rows route).  world / local: see dist.group_world."""
     import torch.distributed as tdist
     from .ops.affinity_train import AffinityTrainState
     params = [p for p in engine.parameters() if p.requires_grad]
     optimizer.zero_grad(set_to_none=True)
-    out = prof.region("joint_forward(span)", lambda: joint_forward(engine, xyz, image, pts_xy, rois_per_frame))
+    if route == "auto":
+        route = "rows" if frozen_bn(engine) and xyz.is_cuda else "operators"
+    if route == "rows":
+        if not frozen_bn(engine):
+            raise RuntimeError("joint_step(route='rows') folds the BatchNorms: call train_joint.freeze_bn(engine) (or engine.eval()) first")
+        from .train_rows import joint_forward_rows
+        pyr = engine._take_prefetched(xyz)
+        if next_xyz is not None:
+            engine.prefetch(next_xyz, None)
+        out = prof.region("joint_forward(span)", lambda: joint_forward_rows(engine, xyz, image, pts_xy, rois_per_frame, pyr))
+    else:
+        out = prof.region("joint_forward(span)", lambda: joint_forward(engine, xyz, image, pts_xy, rois_per_frame))
     counts = None
-    if jdist.collective_path(world):             # the re-id means run over the GLOBAL element counts (as in the finetune step)
+    if jdist.collective_path(world, local):      # the re-id means run over the GLOBAL element counts (as in the finetune step)
         B = gt_tids.shape[0]
         with torch.no_grad():
             counts = AffinityTrainState(out["rcnn_feat"].detach().view(B, -1, out["rcnn_feat"].shape[-1]), gt_tids).counts.clone()
@@ -108,7 +137,8 @@ def joint_step(engine, xyz, image, pts_xy, gt_tids, optimizer, world: int = 1, r
     loss = thin_loss(engine, out, gt_tids, counts)
     prof.region("joint_backward(span)", lambda: loss.backward())
     global LAST_GRAD_COLLECTIVES
-    LAST_GRAD_COLLECTIVES = prof.region("grad_allreduce(RCCL)", lambda: jdist.allreduce_gradients(params, world=world, bucket_bytes=bucket_bytes, average=False),
+    LAST_GRAD_COLLECTIVES = prof.region("grad_allreduce(RCCL)", lambda: jdist.allreduce_gradients(params, world=world, bucket_bytes=bucket_bytes,
+                                                                                                  average=False, local=local),
                                         algo_bytes=sum(p.numel() for p in params) * 4)
     optimizer.step()
     return loss.detach()

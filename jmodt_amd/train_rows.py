@@ -1,0 +1,267 @@
+"""The joint-mode training forward on ROW-major activations: the differentiable composition of the detector whose forward AND
+backward are the hand-written kernels of csrc/rows_gemm.hip / csrc/rows_ops.hip (ops/rows.py), not torch autograd over the
+reference's (B, C, npoint, nsample) tensors.
+
+Same network and parameter containers as jmodt_amd/train_joint.py's operator route (point_rcnn.py:24-70 in TRAIN mode:
+backbone.py:159-196, rpn.py:71-87, rcnn.py:158-202), same outputs, with
+  * every per-point / per-(centre, neighbour) activation a (rows, channels) tensor — set abstraction on the DISTINCT rows of the
+    ball-query groups (device-side plan, nothing of size npoint x nsample x C exists), feature propagation, the LI-Fusion
+    gather + attention block, the RPN / RCNN heads, the RCNN input MLPs;
+  * BatchNorm in EVAL mode (frozen running statistics: cfg.RPN.FIXED-style, point_rcnn.py:29-30), folded into the neighbouring
+    weight with plain differentiable torch arithmetic on the parameters — d(loss)/d(gamma, beta) follow by autograd from the folded
+    weight's gradient (`BnFold`: all scales of the network from four concatenated vectors, not four launches per layer);
+  * the FPS pyramid, the ball queries and the 3-NN search (coordinates only, no gradient) on the engine's side stream, started
+    a step ahead when the caller announces the next batch (FpsPyramid);
+  * the image branch's 3x3 convolutions and the deconvolution pyramid on MIOpen's autograd in channels-last memory (not a
+    SURVEY.md §8 row), the final fusion map composed per level as detector._image_fusion_map does.
+"""
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .ops import rows as R
+from .ops.pointnet2 import pointnet2_utils
+from .ops.pointnet2.pyramid import FpsPyramid
+from .ops.roipool3d.roipool3d_utils import roipool3d_canonical_gpu
+from .profile import prof
+
+
+class BnFold:
+    """eval-mode BatchNorm scale / shift of EVERY BatchNorm of a module tree, computed by four batched launches:
+    s = gamma / sqrt(running_var + eps), t = beta - running_mean * s; `of(bn)` hands out the two (C,) views.  Differentiable
+    w.r.t. gamma and beta (the running statistics are buffers)."""
+
+    def __init__(self, root: nn.Module):
+        bns = [m for m in root.modules() if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d))]
+        self._slots = {}
+        if not bns:
+            return
+        eps = {m.eps for m in bns}
+        assert len(eps) == 1, "mixed BatchNorm eps"
+        gamma = torch.cat([m.weight for m in bns])
+        beta = torch.cat([m.bias for m in bns])
+        with torch.no_grad():
+            mean = torch.cat([m.running_mean for m in bns])
+            inv = torch.rsqrt(torch.cat([m.running_var for m in bns]) + eps.pop())
+        s = gamma * inv
+        t = beta - mean * s
+        off = 0
+        for m in bns:
+            c = m.num_features
+            self._slots[id(m)] = (s[off:off + c], t[off:off + c])
+            off += c
+
+    def of(self, bn: nn.Module) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self._slots[id(bn)]
+
+    def unit(self, unit: nn.Module) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """folded (W (out, in), b (out)) of a pytorch_utils Conv1d / Conv2d unit (conv [+ bn.bn]), differentiable"""
+        bn = unit.bn.bn if hasattr(unit, "bn") else None
+        return self.conv(unit.conv, bn)
+
+    def conv(self, conv: nn.Module, bn: Optional[nn.Module]) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        W = conv.weight.reshape(conv.weight.shape[0], -1)
+        b = conv.bias
+        if bn is None:
+            return W, b
+        s, t = self.of(bn)
+        return W * s[:, None], (t if b is None else b * s + t)
+
+
+def _pad_rows(W: torch.Tensor, b: Optional[torch.Tensor], mult: int = 4):
+    """zero rows appended so that the layer's output width is a multiple of `mult` (the 1-wide objectness and the 46-wide RCNN
+    regression layers: the row kernels work on multiples of four channels)"""
+    n = W.shape[0]
+    pad = (-n) % mult
+    if pad == 0:
+        return W, b
+    return F.pad(W, (0, 0, 0, pad)), (F.pad(b, (0, pad)) if b is not None else None)
+
+
+def _head_rows(fold: BnFold, head: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """a Conv1d head (rpn.py:34-58, rcnn.py:43-89) on rows: (M, C) -> (M, pad4(out)); Dropout between the units when active"""
+    units, cur_layers, cur_acts = list(head), [], []
+    out = x
+    for m in units:
+        if isinstance(m, nn.Dropout):
+            if m.training and m.p > 0:
+                if cur_layers:
+                    out = R.rows_mlp(out, cur_layers, cur_acts)
+                    cur_layers, cur_acts = [], []
+                out = F.dropout(out, m.p, True)
+            continue
+        W, b = fold.unit(m)
+        cur_layers.append(_pad_rows(W, b))
+        cur_acts.append(1 if getattr(m, "activation", None) is not None else 0)
+    if cur_layers:
+        out = R.rows_mlp(out, cur_layers, cur_acts)
+    return out
+
+
+def _attention_rows(fold: BnFold, mod, point: torch.Tensor, img: torch.Tensor) -> torch.Tensor:
+    """AttentionFusion.forward (backbone.py:35-81) on rows: point (M, pc), img (M, ic) -> (M, oc)"""
+    ia = mod.IA_Layer
+    rc = ia.fc1.weight.shape[0]
+    # gate = sigmoid(fc3(tanh(fc1(img) + fc2(point)))): fc1 / fc2 as ONE two-operand layer
+    w12 = torch.cat([ia.fc1.weight, ia.fc2.weight], dim=1)
+    t = R.rows_mlp(img, [_pad_rows(w12, ia.fc1.bias + ia.fc2.bias)], [2], x2=point)            # (M, pad4(rc)); padded columns tanh(0) = 0
+    w3 = ia.fc3.weight
+    if t.shape[1] != rc:
+        w3 = F.pad(w3, (0, t.shape[1] - rc))
+    z = R.rows_mlp(t, [_pad_rows(w3, ia.fc3.bias)], [0])                                        # (M, 4): column 0 is the logit
+    gate = torch.sigmoid(z[:, :1])
+    Wi, bi = fold.conv(ia.conv1[0], ia.conv1[1])
+    j = R.rows_mlp(img, [(Wi, bi)], [1]) * gate
+    Wf, bf = fold.conv(mod.conv1, mod.bn1)
+    return R.rows_mlp(point, [(Wf, bf)], [1], x2=j)
+
+
+def _sa_level_rows(fold: BnFold, sa, xyz: torch.Tensor, feats: Optional[torch.Tensor], new_xyz: torch.Tensor, grid=None,
+                   canon: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """one PointnetSAModuleMSG level on rows: xyz (S, n, 3), feats (S n, C) or None, new_xyz (S, m, 3) -> (S m, sum C_k)"""
+    S, n, _ = xyz.shape
+    flat_xyz, flat_ctr = xyz.reshape(-1, 3), new_xyz.reshape(-1, 3).contiguous()
+    groupers = list(sa.groupers)
+    if len(groupers) == 2:
+        g0, g1 = groupers
+        neigh = pointnet2_utils.ball_query_dual(g0.radius, g0.nsample, g1.radius, g1.nsample, xyz, new_xyz, grid=grid)
+    else:
+        neigh = [pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz) for g in groupers]
+    outs = []
+    for nb, mlp in zip(neigh, sa.mlps):
+        plan = R.RowsPlan(nb, n, canon)
+        outs.append(R.sa_scale_rows(feats, flat_xyz, flat_ctr, plan, [fold.unit(u) for u in mlp]))
+    return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
+
+
+def _image_pyramid(fold: BnFold, net, image: torch.Tensor) -> List[torch.Tensor]:
+    """the four BasicBlocks (backbone.py:16-32; conv3x3 + BN + ReLU + conv3x3 / 2), BatchNorm folded, channels-last"""
+    x = image.contiguous(memory_format=torch.channels_last)
+    maps = []
+    for blk in net.Img_Block:
+        s, t = fold.of(blk.bn1)
+        w1 = (blk.conv1.weight * s[:, None, None, None]).contiguous(memory_format=torch.channels_last)
+        y = F.relu(F.conv2d(x, w1, t, stride=1, padding=1), inplace=True)
+        x = F.conv2d(y, blk.conv2.weight.contiguous(memory_format=torch.channels_last), blk.conv2.bias, stride=blk.conv2.stride,
+                     padding=blk.conv2.padding)
+        maps.append(x)
+    return maps
+
+
+def _image_fusion_map(fold: BnFold, net, maps: List[torch.Tensor]) -> torch.Tensor:
+    """relu(bn(conv1x1(cat_i deconv_i(img_i)))) (backbone.py:187-193) with the 1x1 convolution's slice composed into every level's
+    kernel == stride transposed convolution (linear o linear): the 64-channel concatenation never exists; the composition is
+    differentiable torch arithmetic on the parameters"""
+    Wf, bf = fold.conv(net.image_fusion_conv, net.image_fusion_bn)           # (q, sum reduce), (q)
+    acc, off, bias = None, 0, bf
+    for dc, m in zip(net.DeConv, maps):
+        r = dc.out_channels
+        Ws = Wf[:, off:off + r]
+        wc = torch.einsum("crhw,qr->cqhw", dc.weight, Ws)
+        bias = bias + Ws @ dc.bias
+        y = F.conv_transpose2d(m, wc, None, stride=dc.stride)
+        acc = y if acc is None else acc + y
+        off += r
+    return F.relu(acc + bias[None, :, None, None])
+
+
+def backbone_forward_rows(engine, xyz: torch.Tensor, image: torch.Tensor, pts_xy: torch.Tensor, fold: BnFold,
+                          pyr: Optional[FpsPyramid] = None) -> torch.Tensor:
+    """PointNet2MSG.forward (backbone.py:159-196) on rows -> point features (B N, C)"""
+    net, cfg = engine.rpn.backbone_net, engine.cfg
+    B, N, _ = xyz.shape
+    own = pyr is None
+    if own:
+        pyr = FpsPyramid(xyz, list(cfg.sa_npoints), overlap=engine.overlap, with_interp=True, grid_radii=engine._grid_radii())
+    maps = prof.region("image_pyramid(MIOpen)", lambda: _image_pyramid(fold, net, image))
+    l_xyz, l_feats, l_xy = [xyz], [None], [pts_xy]
+    for i, sa in enumerate(net.SA_modules):
+        idx, new_xyz = pyr.level(i)
+        with prof.scope(f"rpn_sa{i + 1}"):
+            feats = _sa_level_rows(fold, sa, l_xyz[i], l_feats[i], new_xyz, grid=pyr.grid(i))
+        xy_i = torch.gather(l_xy[i], 1, idx.long().unsqueeze(-1).expand(-1, -1, 2))
+        with prof.scope(f"li_fusion{i + 1}"):
+            feats = _attention_rows(fold, net.Fusion_Conv[i], feats, R.feature_gather_rows(maps[i], xy_i))
+        l_xyz.append(new_xyz); l_feats.append(feats); l_xy.append(xy_i)
+    nfp = len(net.FP_modules)
+    for i in range(-1, -(nfp + 1), -1):
+        with prof.scope(f"fp{nfp + 1 + i}"):
+            nn3, w = pyr.interp(nfp + i)
+            carried = R.three_interpolate_rows(l_feats[i], nn3, w)
+            mlp = net.FP_modules[i].mlp
+            layers = [fold.unit(u) for u in mlp]
+            l_feats[i - 1] = R.rows_mlp(carried, layers, [1] * len(layers), x2=l_feats[i - 1])
+    fused_img = prof.region("image_deconv+fusion_conv(MIOpen)", lambda: _image_fusion_map(fold, net, maps))
+    with prof.scope("li_fusion_final"):
+        out = _attention_rows(fold, net.final_fusion_img_point, l_feats[0], R.feature_gather_rows(fused_img, pts_xy))
+    if own:
+        pyr.release()
+    return out
+
+
+def rcnn_forward_rows(engine, pts_input: torch.Tensor, fold: BnFold, count: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """RCNN.forward (rcnn.py:176-202) on pooled RoI points (R, S, 5 + C): rcnn_cls (R, 1), rcnn_reg (R, 46), rcnn_feat (R, 512).
+    count (R,) int32: distinct points per RoI (rows count .. S - 1 are cyclic copies, roipool3d_kernel.cu:123-160) — the first
+    level's rows are then planned on the canonical points only"""
+    net = engine.rcnn_net
+    Rn, S, Cin = pts_input.shape
+    k = net.rcnn_input_channel
+    rows = pts_input.reshape(Rn * S, Cin)
+    xyz = pts_input[:, :, 0:3].contiguous()
+    x5 = F.pad(rows[:, :k], (0, (-k) % 4))                                   # (R S, 8): K = 5 padded to a multiple of 4
+    rpn_feat = rows[:, k:].contiguous()
+    up = [fold.unit(u) for u in net.xyz_up_layer]
+    W0, b0 = up[0]
+    up[0] = (F.pad(W0, (0, x5.shape[1] - W0.shape[1])), b0)
+    xyz_feat = R.rows_mlp(x5, up, [1] * len(up))
+    Wm, bm = fold.unit(net.merge_down_layer[0])
+    feats = R.rows_mlp(xyz_feat, [(Wm, bm)], [1], x2=rpn_feat)              # (R S, C): merge_down on [xyz_feature | rpn_feature]
+    l_xyz = xyz
+    canon = None
+    if count is not None:
+        from .ops.pointnet2 import fused
+        canon = fused.canon_from_count(count, S)
+    for li, sa in enumerate(net.SA_modules):
+        with prof.scope(f"rcnn_sa{li + 1}"):
+            n = l_xyz.shape[1]
+            if sa.npoint is not None:
+                _, new_xyz = pointnet2_utils.farthest_point_sample_xyz(l_xyz, sa.npoint)
+                feats = _sa_level_rows(fold, sa, l_xyz, feats, new_xyz, canon=canon if li == 0 else None)
+                l_xyz = new_xyz
+            else:       # GroupAll: one group of all n points per RoI, coordinates not re-centred (pointnet2_utils.py:273-290)
+                idx = torch.arange(n, dtype=torch.int32, device=xyz.device).expand(Rn, 1, n).contiguous()
+                plan = R.RowsPlan(idx, n)
+                feats = R.sa_scale_rows(feats, l_xyz.reshape(-1, 3), None, plan, [fold.unit(u) for u in sa.mlps[0]])
+                l_xyz = None
+    ncls = net.cls_layer[-1].conv.out_channels
+    nreg = net.reg_layer[-1].conv.out_channels
+    return dict(rcnn_cls=_head_rows(fold, net.cls_layer, feats)[:, :ncls], rcnn_reg=_head_rows(fold, net.reg_layer, feats)[:, :nreg],
+                rcnn_feat=feats)
+
+
+def joint_forward_rows(engine, xyz, image, pts_xy, rois_per_frame: int = 64, pyr: Optional[FpsPyramid] = None) -> Dict[str, torch.Tensor]:
+    """the detector in TRAIN composition (point_rcnn.py:24-70) on rows; same outputs as train_joint.joint_forward"""
+    rpn, cfg = engine.rpn, engine.cfg
+    B, N, _ = xyz.shape
+    fold = BnFold(engine)
+    feats = backbone_forward_rows(engine, xyz, image, pts_xy, fold, pyr)                 # (B N, C)
+    ncls = rpn.rpn_cls_layer[-1].conv.out_channels
+    nreg = rpn.rpn_reg_layer[-1].conv.out_channels
+    rpn_cls = _head_rows(fold, rpn.rpn_cls_layer, feats)[:, :ncls].reshape(B, N, ncls)
+    rpn_reg = _head_rows(fold, rpn.rpn_reg_layer, feats)[:, :nreg].reshape(B, N, nreg)
+    C = feats.shape[1]
+    with torch.no_grad():
+        det = dict(rpn_cls=rpn_cls.detach().contiguous(), rpn_reg=rpn_reg.detach().contiguous(), backbone_xyz=xyz)
+        rois, _ = engine.proposals(det)
+        rois = rois[:, :rois_per_frame].contiguous()
+        pf = torch.empty((B, N, 2 + C), dtype=torch.float32, device=xyz.device)           # point_rcnn.py:42-44, proposal_target_layer.py:26
+        pf[:, :, 0] = (torch.sigmoid(det["rpn_cls"][:, :, 0]) > cfg.rpn_score_thresh).float()
+        pf[:, :, 1] = torch.norm(xyz, p=2, dim=2) / 70.0 - 0.5
+        pf[:, :, 2:] = feats.detach().view(B, N, C)                                       # rows ARE the (B, N, C) layout roipool reads
+        pooled, _, count = roipool3d_canonical_gpu(xyz, pf, rois, cfg.pool_extra_width, cfg.rcnn_num_points, return_count=True)
+        pts_input = pooled.view(-1, cfg.rcnn_num_points, pooled.shape[-1])
+    out = rcnn_forward_rows(engine, pts_input, fold, count.view(-1))
+    out.update(rpn_cls=rpn_cls, rpn_reg=rpn_reg, backbone_features=feats.view(B, N, C).transpose(1, 2), rois=rois)
+    return out
