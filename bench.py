@@ -398,7 +398,7 @@ def make_joint_state(frames, seed, dev, tiny=False):
     st = make_detect_state(frames, seed, dev, tiny=tiny)
     eng = st["engine"]
     if os.environ.get("JM_JOINT_ROUTE", "rows") == "rows":
-        train_joint.freeze_bn(eng)       # train mode (RPN-head dropout active), BatchNorm on its running statistics: cfg.RPN.FIXED-style
+        train_joint.prepare_rows(eng)    # train mode (RPN-head dropout active), BatchNorm on its running statistics: cfg.RPN.FIXED-style
     else:
         eng.train()                      # the un-fused operator route: BatchNorm on batch statistics
     g = torch.Generator(device="cpu").manual_seed(seed)

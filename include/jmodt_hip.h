@@ -621,7 +621,8 @@ int jm_rows_linear_forward(int m, const int* m_dev, int k1, int k2, int n, const
 int jm_rows_linear_dgrad(int m, const int* m_dev, int n, int k, const float* dy, int lddy, const float* w, int ldw,
                          const float* mask, int ldm, int accumulate, float* dx, int lddx, jm_stream_t stream);
 /* dw (n, k) (+)= dy (m, n)^T x (m, k), dbias (n) (+)= column sums of dy (NULL: skipped).  The m rows are split over
- * jm_rows_wgrad_splits(m, n, k) partials in ws, reduced in split order: deterministic, no float atomics */
+ * jm_rows_wgrad_splits(m, n, k) partials in ws, reduced in split order: deterministic, no float atomics; a short contraction
+ * (one split) writes dw / dbias straight from the accumulators and needs no workspace */
 int jm_rows_wgrad_splits(int m, int n, int k);
 size_t jm_rows_wgrad_workspace_bytes(int m, int n, int k);
 int jm_rows_linear_wgrad(int m, const int* m_dev, int n, int k, const float* dy, int lddy, const float* x, int ldx,
@@ -630,8 +631,8 @@ int jm_rows_linear_wgrad(int m, const int* m_dev, int n, int k, const float* dy,
 size_t jm_rows_reduce_workspace_bytes(int n);
 int jm_rows_colsum(int m, const int* m_dev, int n, const float* x, int ldx, float* out, int accumulate, void* ws, size_t ws_bytes,
                    jm_stream_t stream);
-/* dy = y > 0 ? dy : 0 in place (the ReLU of a block's last layer, whose gradient arrives from outside the block) */
-int jm_rows_relu_mask(int m, const int* m_dev, int n, float* dy, int ldd, const float* y, int ldy, jm_stream_t stream);
+/* out = y > 0 ? dy : 0 (the ReLU of a block's last layer, whose gradient arrives from outside the block); out may be dy */
+int jm_rows_relu_mask(int m, const int* m_dev, int n, const float* dy, int ldd, const float* y, int ldy, float* out, int ldo, jm_stream_t stream);
 
 /* Set-abstraction rows: the DISTINCT (centre, neighbour) pairs of every group.  idx (groups, ns) int32 = ball_query's lists
  * (ns <= 64), entries local to their point set (frame / RoI) of n_per_set points; group g belongs to set g / groups_per_set;
@@ -641,9 +642,11 @@ int jm_rows_relu_mask(int m, const int* m_dev, int n, float* dy, int ldd, const 
 int jm_sa_rows_plan(int groups, int ns, const int* idx, const int* canon, int n_per_set, int groups_per_set, int* d, int* offsets,
                     int* row_point, int* row_group, jm_stream_t stream);
 /* h1[r, :] = relu((u ? u[row_point[r], :] : b1) + w1x (h, 3) (xyz[row_point[r]] - ctr[row_group[r]])): the first SharedMLP layer
- * on [xyz_j - c_i ; f_j] (pointnet2_utils.py:259-269) with its feature part u = W1f f + b1 computed per point; ctr NULL = GroupAll */
+ * on [xyz_j - c_i ; f_j] (pointnet2_utils.py:259-269) with its feature part u = W1f f + b1 computed per point; ctr NULL = GroupAll.
+ * delta (rows, 4) or NULL: also stores [xyz_j - c_i, 0] per row — the operand of the backward's d(w1x) = dh1^T delta
+ * (jm_rows_linear_wgrad with k = 4, whose bias output is d(b1)) */
 int jm_sa_rows_h1(int rows, const int* rows_dev, int h, const float* u, int ldu, const float* b1, const float* w1x, const float* xyz,
-                  const float* ctr, const int* row_point, const int* row_group, float* h1, int ldh, jm_stream_t stream);
+                  const float* ctr, const int* row_point, const int* row_group, float* h1, int ldh, float* delta, jm_stream_t stream);
 /* out (groups, c) = max over each group's rows (F.max_pool2d, pointnet2_modules.py:50-55), argrow (groups, c) = the first row holding it */
 int jm_sa_rows_pool(int groups, int c, const float* h, int ldh, const int* offsets, float* out, int ldo, int* argrow, jm_stream_t stream);
 /* dh (rows, c) = d(out) routed to the arg-max rows where the pooled (post-ReLU) value is positive, 0 elsewhere */
@@ -672,6 +675,60 @@ int jm_feature_gather_rows_grad(int b, int c, int h, int w, int n, const float* 
 int jm_rows_sigmoid(int m, const float* z, int ldz, float* g, jm_stream_t stream);
 int jm_rows_gate_backward(int m, int pc, int rc, float* dj, int ldj, const float* j, int ldjj, const float* g, const float* t, int ldt,
                           const float* w3, float* dz, float* dt, int lddt, jm_stream_t stream);
+
+/* Whole chains of the row kernels behind ONE call (csrc/rows_chain.hip): the host-side layer loops of a dense stack and of one
+ * set-abstraction scale, forward and backward, so that the caller's interpreter is not in the launch path.  Same kernels, same
+ * bits as the single-layer entries above; the caller provides every buffer. */
+#define JM_ROWS_MAX_LAYERS 6
+typedef struct {
+    int nl, m;                       /* layers, rows */
+    const int* m_dev;                /* row count in device memory, or NULL */
+    int k1, k2;                      /* widths of the two input operands (k2 = 0: one) */
+    const float* x1; int ldx1; const float* x2; int ldx2;
+    int widths[JM_ROWS_MAX_LAYERS];  /* output width of layer l */
+    int acts[JM_ROWS_MAX_LAYERS];    /* 0 none, 1 ReLU, 2 tanh */
+    const float* w[JM_ROWS_MAX_LAYERS]; int ldw[JM_ROWS_MAX_LAYERS]; const float* b[JM_ROWS_MAX_LAYERS];
+    float* y[JM_ROWS_MAX_LAYERS];    /* (m, widths[l]) outputs, kept for the backward */
+} jm_rows_mlp_t;
+typedef struct {
+    const float* dout; int lddout;   /* gradient w.r.t. y[nl - 1] */
+    float* dw[JM_ROWS_MAX_LAYERS]; int lddw[JM_ROWS_MAX_LAYERS]; float* db[JM_ROWS_MAX_LAYERS];   /* db[l] NULL: layer without bias */
+    float* dx1; float* dx2;          /* (m, k1), (m, k2) or NULL */
+    float* scratch[2];               /* two (m, max width) row buffers */
+    void* ws; size_t ws_bytes;       /* >= the largest jm_rows_wgrad_workspace_bytes of the stack */
+} jm_rows_mlp_grad_t;
+int jm_rows_mlp_forward(const jm_rows_mlp_t* d, jm_stream_t stream);
+int jm_rows_mlp_backward(const jm_rows_mlp_t* d, const jm_rows_mlp_grad_t* g, jm_stream_t stream);
+int jm_rows_tanh_grad(int m, const int* m_dev, int n, const float* dy, int ldd, const float* y, int ldy, float* out, int ldo, jm_stream_t stream);
+typedef struct {
+    int nl, groups, max_rows;        /* layers (>= 2), groups, row capacity (= groups * nsample) */
+    const int* rows_dev; const int* offsets; const int* row_point; const int* row_group;   /* jm_sa_rows_plan's outputs */
+    int points, c;                   /* rows of f, feature width (0: xyz only) */
+    const float* f; int ldf; const float* xyz; const float* ctr;
+    int widths[JM_ROWS_MAX_LAYERS];  /* output width of layer l (widths[0] = H1) */
+    const float* w1x; const float* w1f; const float* b1;       /* layer 0: (H1, 3) packed, (H1, c), (H1) */
+    const float* w[JM_ROWS_MAX_LAYERS]; const float* b[JM_ROWS_MAX_LAYERS];   /* layers 1 .. nl - 1, contiguous (out, in) */
+    float* u; float* delta; float* h[JM_ROWS_MAX_LAYERS];      /* (points, H1); (max_rows, 4); (max_rows, widths[l]) — kept for the backward */
+    float* out; int ldo; int* argrow;                          /* pooled (groups, widths[nl - 1]) rows ldo apart; (groups, widths[nl - 1]) */
+} jm_sa_scale_t;
+typedef struct {
+    const float* dout; int lddout;
+    float* dw1; float* db1; float* dw4;    /* (H1, 3 + c) on [xyz ; f]; (H1); (H1, 4) scratch */
+    float* dw[JM_ROWS_MAX_LAYERS]; float* db[JM_ROWS_MAX_LAYERS];
+    float* du; float* df; int df_accumulate;                   /* (points, H1) scratch; (points, c) or NULL */
+    float* scratch[2]; void* ws; size_t ws_bytes;
+} jm_sa_scale_grad_t;
+int jm_sa_scale_forward(const jm_sa_scale_t* d, jm_stream_t stream);
+int jm_sa_scale_backward(const jm_sa_scale_t* d, const jm_sa_scale_grad_t* g, jm_stream_t stream);
+
+/* Eval-mode BatchNorm folded into the preceding convolution, for all n (convolution, BatchNorm) pairs of a network in one launch:
+ * wf[l] (rows_l, cols_l) = w[l] * s[soff[l] + row] with s = gamma / sqrt(running_var + eps) (pytorch_utils.py:21-33 / backbone.py
+ * conv + bn chains at inference statistics); the pointer arrays are HOST arrays of device pointers.  The backward: dw[l] = dwf[l] * s,
+ * ds[soff[l] + row] = sum_col dwf[l] * w[l] (ds rows of layers not listed keep their value: zero it first) */
+int jm_fold_bn_multi(int n, const float* const* w, float* const* wf, const int* rows, const int* cols, const int* soff, const float* s,
+                     jm_stream_t stream);
+int jm_fold_bn_multi_grad(int n, const float* const* dwf, const float* const* w, float* const* dw, const int* rows, const int* cols,
+                          const int* soff, const float* s, float* ds, jm_stream_t stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

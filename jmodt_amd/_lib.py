@@ -31,6 +31,36 @@ class Mlp3Grad(ctypes.Structure):
     _fields_ = [("dw1", _P), ("db1", _P), ("dw2", _P), ("db2", _P), ("dw3", _P), ("db3", _P)]
 
 
+ROWS_MAX_LAYERS = 6
+
+
+class RowsMlp(ctypes.Structure):
+    """jm_rows_mlp_t"""
+    _fields_ = [("nl", _I), ("m", _I), ("m_dev", _P), ("k1", _I), ("k2", _I), ("x1", _P), ("ldx1", _I), ("x2", _P), ("ldx2", _I),
+                ("widths", _I * ROWS_MAX_LAYERS), ("acts", _I * ROWS_MAX_LAYERS), ("w", _P * ROWS_MAX_LAYERS), ("ldw", _I * ROWS_MAX_LAYERS),
+                ("b", _P * ROWS_MAX_LAYERS), ("y", _P * ROWS_MAX_LAYERS)]
+
+
+class RowsMlpGrad(ctypes.Structure):
+    """jm_rows_mlp_grad_t"""
+    _fields_ = [("dout", _P), ("lddout", _I), ("dw", _P * ROWS_MAX_LAYERS), ("lddw", _I * ROWS_MAX_LAYERS), ("db", _P * ROWS_MAX_LAYERS),
+                ("dx1", _P), ("dx2", _P), ("scratch", _P * 2), ("ws", _P), ("ws_bytes", _Z)]
+
+
+class SaScale(ctypes.Structure):
+    """jm_sa_scale_t"""
+    _fields_ = [("nl", _I), ("groups", _I), ("max_rows", _I), ("rows_dev", _P), ("offsets", _P), ("row_point", _P), ("row_group", _P),
+                ("points", _I), ("c", _I), ("f", _P), ("ldf", _I), ("xyz", _P), ("ctr", _P), ("widths", _I * ROWS_MAX_LAYERS),
+                ("w1x", _P), ("w1f", _P), ("b1", _P), ("w", _P * ROWS_MAX_LAYERS), ("b", _P * ROWS_MAX_LAYERS),
+                ("u", _P), ("delta", _P), ("h", _P * ROWS_MAX_LAYERS), ("out", _P), ("ldo", _I), ("argrow", _P)]
+
+
+class SaScaleGrad(ctypes.Structure):
+    """jm_sa_scale_grad_t"""
+    _fields_ = [("dout", _P), ("lddout", _I), ("dw1", _P), ("db1", _P), ("dw4", _P), ("dw", _P * ROWS_MAX_LAYERS), ("db", _P * ROWS_MAX_LAYERS),
+                ("du", _P), ("df", _P), ("df_accumulate", _I), ("scratch", _P * 2), ("ws", _P), ("ws_bytes", _Z)]
+
+
 # name -> (restype, argtypes); mirrors include/jmodt_hip.h one to one
 SIGNATURES = {
     "jm_version": (_I, []),
@@ -160,9 +190,9 @@ SIGNATURES = {
     "jm_rows_linear_wgrad": (_I, [_I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _Z, _P]),
     "jm_rows_reduce_workspace_bytes": (_Z, [_I]),
     "jm_rows_colsum": (_I, [_I, _P, _I, _P, _I, _P, _I, _P, _Z, _P]),
-    "jm_rows_relu_mask": (_I, [_I, _P, _I, _P, _I, _P, _I, _P]),
+    "jm_rows_relu_mask": (_I, [_I, _P, _I, _P, _I, _P, _I, _P, _I, _P]),
     "jm_sa_rows_plan": (_I, [_I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
-    "jm_sa_rows_h1": (_I, [_I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "jm_sa_rows_h1": (_I, [_I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "jm_sa_rows_pool": (_I, [_I, _I, _P, _I, _P, _P, _I, _P, _P]),
     "jm_sa_rows_pool_grad": (_I, [_I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P]),
     "jm_sa_rows_scatter_add": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _P]),
@@ -171,6 +201,13 @@ SIGNATURES = {
     "jm_three_interpolate_rows_grad": (_I, [_I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
     "jm_feature_gather_rows": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "jm_feature_gather_rows_grad": (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
+    "jm_rows_mlp_forward": (_I, [ctypes.POINTER(RowsMlp), _P]),
+    "jm_rows_mlp_backward": (_I, [ctypes.POINTER(RowsMlp), ctypes.POINTER(RowsMlpGrad), _P]),
+    "jm_rows_tanh_grad": (_I, [_I, _P, _I, _P, _I, _P, _I, _P, _I, _P]),
+    "jm_sa_scale_forward": (_I, [ctypes.POINTER(SaScale), _P]),
+    "jm_sa_scale_backward": (_I, [ctypes.POINTER(SaScale), ctypes.POINTER(SaScaleGrad), _P]),
+    "jm_fold_bn_multi": (_I, [_I, _P, _P, _P, _P, _P, _P, _P]),
+    "jm_fold_bn_multi_grad": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "jm_rows_sigmoid": (_I, [_I, _P, _I, _P, _P]),
     "jm_rows_gate_backward": (_I, [_I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _I, _P]),
 }

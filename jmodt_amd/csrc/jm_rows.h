@@ -2,7 +2,7 @@
 #pragma once
 #include "jm_common.h"
 
-#define JM_ROWS_CHUNKS 256      /* row chunks of the two-stage (deterministic) reductions */
+#define JM_ROWS_CHUNKS 128      /* most row chunks of a two-stage (deterministic) reduction; rows_chunks() picks fewer for short tensors */
 
 namespace jm {
 
@@ -12,8 +12,15 @@ __device__ __forceinline__ int dev_count(int bound, const int* dev) { return dev
 static __global__ void rows_sum_partials_kernel(int n, int chunks, const float* __restrict__ partial, float* __restrict__ out, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += partial[(size_t)k * n + i];
+    // four independent chains: the loads of consecutive chunks are in flight together (a single chain is one L2 round trip per chunk)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= chunks; k += 4) {
+        s0 += partial[(size_t)k * n + i];       s1 += partial[(size_t)(k + 1) * n + i];
+        s2 += partial[(size_t)(k + 2) * n + i]; s3 += partial[(size_t)(k + 3) * n + i];
+    }
+    for (; k < chunks; ++k) s0 += partial[(size_t)k * n + i];
+    const float s = (s0 + s1) + (s2 + s3);
     out[i] = accumulate ? out[i] + s : s;
 }
 
@@ -33,6 +40,12 @@ rows_colsum_part_kernel(int M, const int* __restrict__ m_dev, int N, int chunks,
     part[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && col < N) partial[(size_t)blockIdx.y * N + col] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+}
+
+// row chunks of a two-stage reduction over (at most) m rows: about 1024 rows per chunk
+static inline int rows_chunks(int m) {
+    int c = (m + 1023) / 1024;
+    return c < 1 ? 1 : (c > JM_ROWS_CHUNKS ? JM_ROWS_CHUNKS : c);
 }
 
 static int grid_for(long long work, int block = 256, int cap = 65535 * 4) {

@@ -29,7 +29,8 @@ namespace jm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int RBM = 128, RBN = 128, RBK = 16, RLDP = RBM + 4;
+constexpr int RBM = 128, RBN = 128, RBK = 32, RLDP = RBM + 4;
+constexpr int RNLD = RBK / 8;       // float4 loads per thread and operand per k-tile (128 x RBK floats / 256 threads / 4)
 enum { RM_FWD = 0, RM_DGRAD = 1, RM_WGRAD = 2 };
 
 struct RGemm {
@@ -44,7 +45,10 @@ struct RGemm {
     const float* mask; int ldm;    // DGRAD: out = mask[row, col] > 0 ? acc : 0
     int accumulate;                // DGRAD: out += acc
     float* out; int ldo;
-    int splits;                    // WGRAD: blockIdx.y = split; partial s at out + s * M * ldo
+    int splits;                    // WGRAD: blockIdx.y = split; splits > 1: partial s at out + s * M * ldo (reduced by
+                                   // rows_wgrad_reduce_kernel), splits == 1: out IS dW (accumulate honoured)
+    float* bias_out;               // WGRAD: row sums of A = column sums of dY (the bias gradient): (splits, M) partials, or the (M)
+                                   // result itself when splits == 1; NULL: skipped
 };
 
 template <int MODE>
@@ -68,24 +72,26 @@ rows_gemm_kernel(RGemm p) {
     }
     const int nkt = (k_end - k_begin + RBK - 1) / RBK;
 
-    // staging roles: 128 x 16 floats per operand per k-tile = 512 float4 = 2 per thread
+    // staging roles: 128 x RBK floats per operand per k-tile = RNLD float4 per thread
     //   row operands: 4 consecutive k of one row, scattered to S[k .. k + 3][row]
     //   k-major operands: 4 consecutive rows of one contraction index, one ds_write_b128 to S[k][row .. row + 3]
-    int t_row[2], t_kq[2], d_k[2], d_r4[2];
+    // RBK = 32: a k-tile is 2048 MFMA cycles per wave (0.85 us), longer than a global-load round trip, so even ONE workgroup per CU
+    // (the short grids of the small layers) keeps the matrix pipe fed; with RBK = 16 those launches ran at load latency per k-tile
+    int t_row[RNLD], t_kq[RNLD], d_k[RNLD], d_r4[RNLD];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RNLD; ++i) {
         const int f = tid + 256 * i;
-        t_row[i] = f >> 2; t_kq[i] = (f & 3) * 4;
-        d_k[i] = f >> 5;   d_r4[i] = (f & 31) * 4;
+        t_row[i] = f / (RBK / 4); t_kq[i] = (f % (RBK / 4)) * 4;
+        d_k[i] = f >> 5;          d_r4[i] = (f & 31) * 4;
     }
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int m0 = (tile / ntn) * RBM, n0 = (tile % ntn) * RBN;
-        float4 ra[2], rb[2];
-        bool a_in[2], b_in[2];
+        float4 ra[RNLD], rb[RNLD];
+        bool a_in[RNLD], b_in[RNLD];
         auto g_load = [&](int k0) {          // k0 = absolute contraction index of the k-tile's first element
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < RNLD; ++i) {
                 if (MODE == RM_WGRAD) {
                     const int kc = k0 + d_k[i];
                     a_in[i] = kc < k_end; b_in[i] = a_in[i];
@@ -115,7 +121,7 @@ rows_gemm_kernel(RGemm p) {
         };
         auto s_store = [&](int buf) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < RNLD; ++i) {
                 float4 a = a_in[i] ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
                 float4 b = b_in[i] ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
                 if (MODE == RM_WGRAD) {
@@ -133,6 +139,8 @@ rows_gemm_kernel(RGemm p) {
             }
         };
 
+        float bsum = 0.f;
+        const bool do_bias = MODE == RM_WGRAD && p.bias_out != nullptr && n0 == 0 && tid < RBM;
         f32x16 acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -160,13 +168,21 @@ rows_gemm_kernel(RGemm p) {
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (do_bias) {          // the first column tile of every row block also sums its dY tile over the contraction
+#pragma unroll
+                    for (int kk = 0; kk < RBK; ++kk) bsum += As[buf][kk][tid];
+                }
                 if (kt + 1 < nkt) s_store(buf ^ 1);
                 __syncthreads();
             }
         }
 
         // epilogue.  C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-        float* out = p.out + (MODE == RM_WGRAD ? (size_t)blockIdx.y * p.M * p.ldo : 0);
+        float* out = p.out + ((MODE == RM_WGRAD && p.splits > 1) ? (size_t)blockIdx.y * p.M * p.ldo : 0);
+        if (do_bias && m0 + tid < p.M) {
+            float* bo = p.bias_out + (p.splits > 1 ? (size_t)blockIdx.y * p.M : 0) + m0 + tid;
+            *bo = (p.splits == 1 && p.accumulate) ? *bo + bsum : bsum;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -189,6 +205,7 @@ rows_gemm_kernel(RGemm p) {
                         if (p.mask != nullptr) v = (ok && p.mask[(size_t)row * p.ldm + col] > 0.f) ? v : 0.f;
                         if (p.accumulate && ok) v += out[(size_t)row * p.ldo + col];
                     }
+                    if (MODE == RM_WGRAD && p.splits == 1 && p.accumulate && ok) v += out[(size_t)row * p.ldo + col];
                     if (ok) out[(size_t)row * p.ldo + col] = v;
                 }
             }
@@ -196,20 +213,125 @@ rows_gemm_kernel(RGemm p) {
     }
 }
 
-// dW[n, k] (+)= sum over the split partials in split order (the bias gradient = column sums of dY: jm_rows_colsum)
-__global__ void rows_wgrad_reduce_kernel(int N, int K, int splits, const float* __restrict__ part, int ldp, float* __restrict__ dW, int ldw,
-                                         int accumulate) {
+// dW[n, k] (+)= sum over the split partials in split order, and the same for the bias gradient's (splits, N) partials (threads
+// behind the N * K / 4 weight quads); four independent chains per thread so that the partials' loads overlap
+__global__ void rows_wgrad_reduce_kernel(int N, int K, int splits, const float* __restrict__ part, float* __restrict__ dW, int ldw,
+                                         const float* __restrict__ bias_part, float* __restrict__ dbias, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * (K / 4)) return;
-    const int n = i / (K / 4), k4 = (i % (K / 4)) * 4;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int t = 0; t < splits; ++t) {
-        const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)t * N + n) * ldp + k4);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    const int quads = N * (K / 4);
+    if (i < quads) {
+        const int n = i / (K / 4), k4 = (i % (K / 4)) * 4;
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+        int t = 0;
+        for (; t + 4 <= splits; t += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)t * N + n) * K + k4);
+            const float4 w = *reinterpret_cast<const float4*>(part + ((size_t)(t + 1) * N + n) * K + k4);
+            const float4 x = *reinterpret_cast<const float4*>(part + ((size_t)(t + 2) * N + n) * K + k4);
+            const float4 y = *reinterpret_cast<const float4*>(part + ((size_t)(t + 3) * N + n) * K + k4);
+            s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+            s1.x += w.x; s1.y += w.y; s1.z += w.z; s1.w += w.w;
+            s2.x += x.x; s2.y += x.y; s2.z += x.z; s2.w += x.w;
+            s3.x += y.x; s3.y += y.y; s3.z += y.z; s3.w += y.w;
+        }
+        for (; t < splits; ++t) {
+            const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)t * N + n) * K + k4);
+            s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+        }
+        s0.x += s2.x; s0.y += s2.y; s0.z += s2.z; s0.w += s2.w;
+        s1.x += s3.x; s1.y += s3.y; s1.z += s3.z; s1.w += s3.w;
+        float* d = dW + (size_t)n * ldw + k4;
+        if (accumulate) { d[0] += s0.x + s1.x; d[1] += s0.y + s1.y; d[2] += s0.z + s1.z; d[3] += s0.w + s1.w; }
+        else { d[0] = s0.x + s1.x; d[1] = s0.y + s1.y; d[2] = s0.z + s1.z; d[3] = s0.w + s1.w; }
+    } else if (dbias != nullptr && i - quads < N) {
+        const int n = i - quads;
+        float s = 0.f;
+        for (int t = 0; t < splits; ++t) s += bias_part[(size_t)t * N + n];
+        dbias[n] = accumulate ? dbias[n] + s : s;
     }
-    float* d = dW + (size_t)n * ldw + k4;
-    if (accumulate) { d[0] += s.x; d[1] += s.y; d[2] += s.z; d[3] += s.w; }
-    else { d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w; }
+}
+
+// Small-problem variant (FWD / DGRAD with a few hundred to a few thousand rows: the coarse backbone levels, the RoI heads — 150 of
+// the ~250 GEMMs of a joint-mode step): ONE wave per 32 x 32 output tile, operands straight from L2 into the MFMA registers (no
+// LDS, no barrier), SPF steps of 8 contraction elements in flight.  A 128 x 128-tile launch of such a problem is 8 - 32
+// workgroups marching through the contraction at one global-load latency per k-tile (30 - 130 us measured); here it is
+// (M / 32)(N / 32) independent waves.  Lane (r = lane & 31, h = lane >> 5) holds 4 consecutive k of its row per step; MFMA step q
+// pairs k = 8 s + q (h = 0) with k = 8 s + 4 + q (h = 1) on both operands.  Same operand forms and epilogues as rows_gemm_kernel.
+constexpr int SPF = 4;
+
+template <int MODE>
+__global__ void __launch_bounds__(64)
+rows_gemm_small_kernel(RGemm p) {
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int row = min(m0 + r, p.M - 1), col = min(n0 + r, p.N - 1);
+    const int nk = (p.K + 7) / 8;
+    auto loadA = [&](int s) {
+        const int k = 8 * s + 4 * h;
+        const int kc = min(k, p.K - 4);
+        float4 v;
+        if (MODE == RM_FWD && p.A2 != nullptr && kc >= p.K1) v = *reinterpret_cast<const float4*>(p.A2 + (size_t)row * p.lda2 + (kc - p.K1));
+        else v = *reinterpret_cast<const float4*>(p.A + (size_t)row * p.lda + kc);
+        return k < p.K ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto loadB = [&](int s) {
+        const int k = 8 * s + 4 * h;
+        const int kc = min(k, p.K - 4);
+        float4 v;
+        if (MODE == RM_FWD) {
+            v = *reinterpret_cast<const float4*>(p.B + (size_t)col * p.ldb + kc);
+        } else {
+            const float* q = p.B + (size_t)kc * p.ldb + col;       // 4 contraction rows of this lane's column
+            v = make_float4(q[0], q[p.ldb], q[2 * (size_t)p.ldb], q[3 * (size_t)p.ldb]);
+        }
+        return k < p.K ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float4 ra[SPF], rb[SPF];
+#pragma unroll
+    for (int s = 0; s < SPF; ++s) {
+        const int ss = min(s, nk - 1);
+        ra[s] = loadA(ss); rb[s] = loadB(ss);
+    }
+    for (int s0 = 0; s0 < nk; s0 += SPF) {
+#pragma unroll
+        for (int s = 0; s < SPF; ++s) {
+            if (s0 + s < nk) {           // wave-uniform
+                const float4 a = ra[s], b = rb[s];
+                const int nx = min(s0 + s + SPF, nk - 1);        // refill this slot (clamped: unconditional load)
+                ra[s] = loadA(nx); rb[s] = loadB(nx);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            }
+        }
+    }
+    const int c = n0 + r;
+    const bool cok = c < p.N;
+    const float bv = (MODE == RM_FWD && p.bias != nullptr && cok) ? p.bias[c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int orow = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const bool ok = cok && orow < p.M;
+        float v = acc[i];
+        if (MODE == RM_FWD) {
+            v += bv;
+            if (p.act == 1) v = fmaxf(v, 0.f);
+            else if (p.act == 2) v = tanhf(v);
+            if (p.rowscale != nullptr && ok) v *= p.rowscale[orow];
+        } else {
+            if (p.mask != nullptr) v = (ok && p.mask[(size_t)orow * p.ldm + c] > 0.f) ? v : 0.f;
+            if (p.accumulate && ok) v += p.out[(size_t)orow * p.ldo + c];
+        }
+        if (ok) p.out[(size_t)orow * p.ldo + c] = v;
+    }
+}
+
+// which launch a FWD / DGRAD problem of m rows (host count; a device-side count always takes the persistent tiles) gets
+static bool small_problem(int m, const int* m_dev, int n) {
+    return m_dev == nullptr && (long long)divup(m, RBM) * divup(n, RBN) < 96 && (long long)divup(m, 32) * divup(n, 32) <= 16384;
 }
 
 static int persistent_grid(long long tiles) { return (int)(tiles < 1 ? 1 : (tiles > 2048 ? 2048 : tiles)); }
@@ -233,7 +355,10 @@ int jm_rows_linear_forward(int m, const int* m_dev, int k1, int k2, int n, const
     p.M = m; p.N = n; p.K = k; p.m_dev = m_dev; p.A = x1; p.lda = ldx1; p.A2 = k2 ? x2 : nullptr; p.lda2 = ldx2; p.K1 = k1;
     p.B = w; p.ldb = ldw; p.bias = bias; p.act = act; p.rowscale = rowscale; p.out = y; p.ldo = ldy; p.splits = 1;
     const long long tiles = (long long)divup(m, RBM) * divup(n, RBN);
-    hipLaunchKernelGGL((rows_gemm_kernel<RM_FWD>), dim3((unsigned)persistent_grid(tiles)), dim3(256), 0, (hipStream_t)stream, p);
+    if (small_problem(m, m_dev, n))
+        hipLaunchKernelGGL((rows_gemm_small_kernel<RM_FWD>), dim3((unsigned)divup(n, 32), (unsigned)divup(m, 32)), dim3(64), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((rows_gemm_kernel<RM_FWD>), dim3((unsigned)persistent_grid(tiles)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("rows_linear_forward");
 }
 
@@ -248,17 +373,22 @@ int jm_rows_linear_dgrad(int m, const int* m_dev, int n, int k, const float* dy,
     p.M = m; p.N = k; p.K = n; p.m_dev = m_dev; p.A = dy; p.lda = lddy; p.B = w; p.ldb = ldw; p.mask = mask; p.ldm = ldm;
     p.accumulate = accumulate; p.out = dx; p.ldo = lddx; p.splits = 1;
     const long long tiles = (long long)divup(m, RBM) * divup(k, RBN);
-    hipLaunchKernelGGL((rows_gemm_kernel<RM_DGRAD>), dim3((unsigned)persistent_grid(tiles)), dim3(256), 0, (hipStream_t)stream, p);
+    if (small_problem(m, m_dev, k))
+        hipLaunchKernelGGL((rows_gemm_small_kernel<RM_DGRAD>), dim3((unsigned)divup(k, 32), (unsigned)divup(m, 32)), dim3(64), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((rows_gemm_kernel<RM_DGRAD>), dim3((unsigned)persistent_grid(tiles)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("rows_linear_dgrad");
 }
 
 int jm_rows_wgrad_splits(int m, int n, int k) {
-    // enough (tile, split) workgroups to fill 256 CUs twice over, but at least 512 contraction rows per split
+    // enough (tile, split) workgroups to fill 256 CUs twice over with at least 128 contraction rows (8 k-tiles) per split: a
+    // k-tile costs a workgroup one global-load latency (~1.5 us) whatever the tile count, so a long contraction on a handful of
+    // tiles is pure latency; a short contraction runs un-split and writes dW / dbias straight from the accumulators (one launch)
     const int tiles = divup(n, RBM) * divup(k, RBN);
-    int s = divup(1024, tiles);
-    const int cap = imax(1, m / 512);
+    int s = divup(512, tiles);
+    const int cap = imax(1, m / 128);
     if (s > cap) s = cap;
-    if (s > 256) s = 256;
+    if (s > 128) s = 128;
     return imax(1, s);
 }
 
@@ -266,7 +396,8 @@ size_t jm_rows_reduce_workspace_bytes(int n) { return (size_t)JM_ROWS_CHUNKS * (
 
 size_t jm_rows_wgrad_workspace_bytes(int m, int n, int k) {
     // the split partials of dW, then the row-chunk partials of the bias gradient
-    return (size_t)jm_rows_wgrad_splits(m, n, k) * (size_t)n * (size_t)k * sizeof(float) + jm_rows_reduce_workspace_bytes(n);
+    const size_t s = (size_t)jm_rows_wgrad_splits(m, n, k);
+    return s > 1 ? s * ((size_t)n * (size_t)k + (size_t)n) * sizeof(float) : 0;
 }
 
 int jm_rows_colsum(int m, const int* m_dev, int n, const float* x, int ldx, float* out, int accumulate, void* ws, size_t ws_bytes,
@@ -277,9 +408,10 @@ int jm_rows_colsum(int m, const int* m_dev, int n, const float* x, int ldx, floa
         return JM_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(rows_colsum_part_kernel, dim3((unsigned)divup(n, 64), JM_ROWS_CHUNKS), dim3(256), 0, s, m, m_dev, n, JM_ROWS_CHUNKS, x, ldx,
+    const int chunks = rows_chunks(m);
+    hipLaunchKernelGGL(rows_colsum_part_kernel, dim3((unsigned)divup(n, 64), (unsigned)chunks), dim3(256), 0, s, m, m_dev, n, chunks, x, ldx,
                        (float*)ws);
-    hipLaunchKernelGGL(rows_sum_partials_kernel, dim3((unsigned)divup(n, 256)), dim3(256), 0, s, n, JM_ROWS_CHUNKS, (const float*)ws, out, accumulate);
+    hipLaunchKernelGGL(rows_sum_partials_kernel, dim3((unsigned)divup(n, 256)), dim3(256), 0, s, n, chunks, (const float*)ws, out, accumulate);
     return check_launch("rows_colsum");
 }
 
@@ -291,20 +423,28 @@ int jm_rows_linear_wgrad(int m, const int* m_dev, int n, int k, const float* dy,
     JM_REQUIRE(n % 4 == 0 && k % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddy >= n && ldx >= k && lddw >= k,
                "rows_linear_wgrad: widths and leading dimensions must be multiples of 4 (n %d, k %d, lddy %d, ldx %d)", n, k, lddy, ldx);
     const int splits = jm_rows_wgrad_splits(m, n, k);
-    if (ws_bytes < jm_rows_wgrad_workspace_bytes(m, n, k) || !ws) {
+    if (splits > 1 && (ws_bytes < jm_rows_wgrad_workspace_bytes(m, n, k) || !ws)) {
         set_error("rows_linear_wgrad: workspace of %zu bytes, need %zu", ws_bytes, jm_rows_wgrad_workspace_bytes(m, n, k));
         return JM_EWORKSPACE;
     }
+    if (m == 0) {           // no rows: the gradients are zero
+        if (!accumulate) {
+            for (int r = 0; r < n; ++r) (void)hipMemsetAsync(dw + (size_t)r * lddw, 0, (size_t)k * sizeof(float), (hipStream_t)stream);
+            if (dbias) (void)hipMemsetAsync(dbias, 0, (size_t)n * sizeof(float), (hipStream_t)stream);
+        }
+        return check_launch("rows_linear_wgrad");
+    }
     RGemm p{};
-    p.M = n; p.N = k; p.K = m; p.m_dev = m_dev; p.A = dy; p.lda = lddy; p.B = x; p.ldb = ldx; p.out = (float*)ws; p.ldo = k; p.splits = splits;
+    p.M = n; p.N = k; p.K = m; p.m_dev = m_dev; p.A = dy; p.lda = lddy; p.B = x; p.ldb = ldx; p.splits = splits; p.accumulate = accumulate;
+    float* bias_part = (float*)ws + (size_t)splits * n * k;
+    if (splits > 1) { p.out = (float*)ws; p.ldo = k; p.bias_out = dbias ? bias_part : nullptr; }
+    else { p.out = dw; p.ldo = lddw; p.bias_out = dbias; }
     hipLaunchKernelGGL((rows_gemm_kernel<RM_WGRAD>), dim3((unsigned)(divup(n, RBM) * divup(k, RBN)), (unsigned)splits), dim3(256), 0,
                        (hipStream_t)stream, p);
-    const int quads = n * (k / 4);
-    hipLaunchKernelGGL(rows_wgrad_reduce_kernel, dim3((unsigned)divup(quads, 256)), dim3(256), 0, (hipStream_t)stream, n, k, splits,
-                       (const float*)ws, k, dw, lddw, accumulate);
-    if (dbias) {
-        float* bws = (float*)ws + (size_t)splits * n * k;
-        return jm_rows_colsum(m, m_dev, n, dy, lddy, dbias, accumulate, bws, jm_rows_reduce_workspace_bytes(n), stream);
+    if (splits > 1) {
+        const int work = n * (k / 4) + (dbias ? n : 0);
+        hipLaunchKernelGGL(rows_wgrad_reduce_kernel, dim3((unsigned)divup(work, 256)), dim3(256), 0, (hipStream_t)stream, n, k, splits,
+                           (const float*)ws, dw, lddw, (const float*)bias_part, dbias, accumulate);
     }
     return check_launch("rows_linear_wgrad");
 }

@@ -77,7 +77,8 @@ sa_rows_scan_kernel(int G, const int* __restrict__ d, int* __restrict__ offsets)
 __global__ void __launch_bounds__(256)
 sa_rows_h1_kernel(int R, const int* __restrict__ r_dev, int H, const float* __restrict__ u, int ldu, const float* __restrict__ b1,
                   const float* __restrict__ w1x, const float* __restrict__ xyz, const float* __restrict__ ctr,
-                  const int* __restrict__ row_point, const int* __restrict__ row_group, float* __restrict__ h1, int ldh) {
+                  const int* __restrict__ row_point, const int* __restrict__ row_group, float* __restrict__ h1, int ldh,
+                  float* __restrict__ delta) {
     const int Rv = dev_count(R, r_dev);
     const int q = H / 4;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < (long long)Rv * q; i += (long long)gridDim.x * blockDim.x) {
@@ -85,6 +86,7 @@ sa_rows_h1_kernel(int R, const int* __restrict__ r_dev, int H, const float* __re
         const int p = row_point[r], g = row_group[r];
         float dx = xyz[(size_t)p * 3 + 0], dy = xyz[(size_t)p * 3 + 1], dz = xyz[(size_t)p * 3 + 2];
         if (ctr) { dx -= ctr[(size_t)g * 3 + 0]; dy -= ctr[(size_t)g * 3 + 1]; dz -= ctr[(size_t)g * 3 + 2]; }
+        if (delta != nullptr && c == 0) *reinterpret_cast<float4*>(delta + (size_t)r * 4) = make_float4(dx, dy, dz, 0.f);
         float4 v = u ? *reinterpret_cast<const float4*>(u + (size_t)p * ldu + c) : *reinterpret_cast<const float4*>(b1 + c);
         float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -139,25 +141,40 @@ sa_rows_scatter_kernel(int R, const int* __restrict__ r_dev, int H, const float*
     }
 }
 
-// partial[s, c, a] = sum over the rows of chunk s of dh1[r, c] * (xyz[p_r, a] - ctr[g_r, a]);   workgroup = chunk, thread = channel
+// partial[s, c, a] = sum over the rows of chunk s of dh1[r, c] * (xyz[p_r, a] - ctr[g_r, a]);   workgroup = chunk; thread =
+// (channel, row subset): 256 / H subsets stride the chunk's rows and are combined through LDS in subset order
 __global__ void __launch_bounds__(256)
 sa_rows_xyz_wgrad_kernel(int R, const int* __restrict__ r_dev, int H, int chunks, const float* __restrict__ dh1, int ldd,
                          const float* __restrict__ xyz, const float* __restrict__ ctr, const int* __restrict__ row_point,
                          const int* __restrict__ row_group, float* __restrict__ partial) {
+    __shared__ float red[256 * 3];
     const int Rv = dev_count(R, r_dev);
     const int per = (Rv + chunks - 1) / chunks;
     const int r0 = min(Rv, (int)blockIdx.x * per), r1 = min(Rv, r0 + per);
-    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    const int nsub = H >= 256 ? 1 : 256 / H;
+    for (int cb = 0; cb < H; cb += 256) {
+        const int c = cb + (int)threadIdx.x % min(H, 256), sub = (int)threadIdx.x / min(H, 256);
         float sx = 0.f, sy = 0.f, sz = 0.f;
-        for (int r = r0; r < r1; ++r) {
-            const int p = row_point[r], g = row_group[r];
-            float dx = xyz[(size_t)p * 3 + 0], dy = xyz[(size_t)p * 3 + 1], dz = xyz[(size_t)p * 3 + 2];
-            if (ctr) { dx -= ctr[(size_t)g * 3 + 0]; dy -= ctr[(size_t)g * 3 + 1]; dz -= ctr[(size_t)g * 3 + 2]; }
-            const float v = dh1[(size_t)r * ldd + c];
-            sx += v * dx; sy += v * dy; sz += v * dz;
+        if (c < H && sub < nsub)
+            for (int r = r0 + sub; r < r1; r += nsub) {
+                const int p = row_point[r], g = row_group[r];
+                float dx = xyz[(size_t)p * 3 + 0], dy = xyz[(size_t)p * 3 + 1], dz = xyz[(size_t)p * 3 + 2];
+                if (ctr) { dx -= ctr[(size_t)g * 3 + 0]; dy -= ctr[(size_t)g * 3 + 1]; dz -= ctr[(size_t)g * 3 + 2]; }
+                const float v = dh1[(size_t)r * ldd + c];
+                sx += v * dx; sy += v * dy; sz += v * dz;
+            }
+        red[threadIdx.x * 3 + 0] = sx; red[threadIdx.x * 3 + 1] = sy; red[threadIdx.x * 3 + 2] = sz;
+        __syncthreads();
+        if (sub == 0 && c < H) {
+            const int w = min(H, 256);
+            for (int k = 1; k < nsub; ++k) {
+                sx += red[((size_t)k * w + threadIdx.x) * 3 + 0]; sy += red[((size_t)k * w + threadIdx.x) * 3 + 1];
+                sz += red[((size_t)k * w + threadIdx.x) * 3 + 2];
+            }
+            float* o = partial + ((size_t)blockIdx.x * H + c) * 3;
+            o[0] = sx; o[1] = sy; o[2] = sz;
         }
-        float* o = partial + ((size_t)blockIdx.x * H + c) * 3;
-        o[0] = sx; o[1] = sy; o[2] = sz;
+        __syncthreads();
     }
 }
 
@@ -199,17 +216,17 @@ three_interpolate_rows_grad_kernel(int B, int n, int m, int C, const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------ element-wise
-// dy = y > 0 ? dy : 0 in place
+// out = y > 0 ? dy : 0 (out may be dy)
 __global__ void __launch_bounds__(256)
-rows_relu_mask_kernel(int M, const int* __restrict__ m_dev, int N, float* __restrict__ dy, int ldd, const float* __restrict__ y, int ldy) {
+rows_relu_mask_kernel(int M, const int* __restrict__ m_dev, int N, const float* dy, int ldd, const float* __restrict__ y, int ldy, float* out, int ldo) {
     const int Mv = dev_count(M, m_dev);
     const int q = N / 4;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < (long long)Mv * q; i += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(i / q), c = (int)(i % q) * 4;
-        float4 d = *reinterpret_cast<float4*>(dy + (size_t)r * ldd + c);
+        float4 d = *reinterpret_cast<const float4*>(dy + (size_t)r * ldd + c);
         const float4 v = *reinterpret_cast<const float4*>(y + (size_t)r * ldy + c);
         d.x = v.x > 0.f ? d.x : 0.f; d.y = v.y > 0.f ? d.y : 0.f; d.z = v.z > 0.f ? d.z : 0.f; d.w = v.w > 0.f ? d.w : 0.f;
-        *reinterpret_cast<float4*>(dy + (size_t)r * ldd + c) = d;
+        *reinterpret_cast<float4*>(out + (size_t)r * ldo + c) = d;
     }
 }
 
@@ -244,6 +261,41 @@ rows_gate_backward_kernel(int M, int PC, int RC, float* __restrict__ dj, int ldj
     }
 }
 
+// ------------------------------------------------------------------------------------------------ BatchNorm folding, multi-tensor
+// Every BatchNorm-followed convolution of the network in ONE launch (the table travels in the kernel arguments, as the fused
+// optimizers' multi-tensor kernels do): wf[l] = w[l] * s[soff[l] + row], and the backward dw[l] = dwf[l] * s, ds[row] = sum_col
+// dwf[l][row, col] * w[l][row, col].  A layer's (rows, cols) block is contiguous per row in whatever memory format it has.
+#define JM_FOLD_MAX 48
+struct FoldEntry { const float* a; const float* b; float* o; int rows, cols, soff; };
+struct FoldTable { int n; FoldEntry e[JM_FOLD_MAX]; };
+
+__global__ void __launch_bounds__(256)
+fold_bn_multi_kernel(FoldTable t, const float* __restrict__ s) {
+    const FoldEntry e = t.e[blockIdx.x];
+    const long long total = (long long)e.rows * e.cols;
+    for (long long i = blockIdx.y * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.y * blockDim.x)
+        e.o[i] = e.a[i] * s[e.soff + (int)(i / e.cols)];
+}
+
+// one wave per row: a = dwf, b = w, o = dw
+__global__ void __launch_bounds__(256)
+fold_bn_multi_grad_kernel(FoldTable t, const float* __restrict__ s, float* __restrict__ ds) {
+    const FoldEntry e = t.e[blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.y * 4 + (threadIdx.x >> 6); row < e.rows; row += gridDim.y * 4) {
+        const float sv = s[e.soff + row];
+        const size_t base = (size_t)row * e.cols;
+        float acc = 0.f;
+        for (int c = lane; c < e.cols; c += 64) {
+            const float g = e.a[base + c];
+            acc += g * e.b[base + c];
+            e.o[base + c] = g * sv;
+        }
+        acc = wave_sum_f32(acc);
+        if (lane == 0) ds[e.soff + row] = acc;
+    }
+}
+
 }  // namespace jm
 
 using namespace jm;
@@ -264,12 +316,12 @@ int jm_sa_rows_plan(int groups, int ns, const int* idx, const int* canon, int n_
 }
 
 int jm_sa_rows_h1(int rows, const int* rows_dev, int h, const float* u, int ldu, const float* b1, const float* w1x, const float* xyz,
-                  const float* ctr, const int* row_point, const int* row_group, float* h1, int ldh, jm_stream_t stream) {
+                  const float* ctr, const int* row_point, const int* row_group, float* h1, int ldh, float* delta, jm_stream_t stream) {
     JM_REQUIRE(rows >= 0 && h > 0 && h % 4 == 0 && (u || b1) && w1x && xyz && row_point && row_group && h1 && ldh % 4 == 0 && (!u || ldu % 4 == 0),
                "sa_rows_h1: bad arguments (h %d, ldu %d, ldh %d)", h, ldu, ldh);
     if (rows == 0) return JM_OK;
     hipLaunchKernelGGL(sa_rows_h1_kernel, dim3((unsigned)grid_for((long long)rows * (h / 4), 256, 8192)), dim3(256), 0, (hipStream_t)stream, rows,
-                       rows_dev, h, u, ldu, b1, w1x, xyz, ctr, row_point, row_group, h1, ldh);
+                       rows_dev, h, u, ldu, b1, w1x, xyz, ctr, row_point, row_group, h1, ldh, delta);
     return check_launch("sa_rows_h1");
 }
 
@@ -307,9 +359,10 @@ int jm_sa_rows_xyz_wgrad(int rows, const int* rows_dev, int h, const float* dh1,
         return JM_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(sa_rows_xyz_wgrad_kernel, dim3(JM_ROWS_CHUNKS), dim3(256), 0, s, rows, rows_dev, h, JM_ROWS_CHUNKS, dh1, ldd, xyz, ctr,
+    const int chunks = rows_chunks(rows);
+    hipLaunchKernelGGL(sa_rows_xyz_wgrad_kernel, dim3((unsigned)chunks), dim3(256), 0, s, rows, rows_dev, h, chunks, dh1, ldd, xyz, ctr,
                        row_point, row_group, (float*)ws);
-    hipLaunchKernelGGL(rows_sum_partials_kernel, dim3((unsigned)divup(h * 3, 256)), dim3(256), 0, s, h * 3, JM_ROWS_CHUNKS, (const float*)ws, dw1x,
+    hipLaunchKernelGGL(rows_sum_partials_kernel, dim3((unsigned)divup(h * 3, 256)), dim3(256), 0, s, h * 3, chunks, (const float*)ws, dw1x,
                        accumulate);
     return check_launch("sa_rows_xyz_wgrad");
 }
@@ -331,11 +384,12 @@ int jm_three_interpolate_rows_grad(int b, int n, int m, int c, const float* dout
     return check_launch("three_interpolate_rows_grad");
 }
 
-int jm_rows_relu_mask(int m, const int* m_dev, int n, float* dy, int ldd, const float* y, int ldy, jm_stream_t stream) {
-    JM_REQUIRE(m >= 0 && n > 0 && n % 4 == 0 && ldd % 4 == 0 && ldy % 4 == 0 && dy && y, "rows_relu_mask: bad arguments (n %d, ldd %d, ldy %d)", n, ldd, ldy);
+int jm_rows_relu_mask(int m, const int* m_dev, int n, const float* dy, int ldd, const float* y, int ldy, float* out, int ldo, jm_stream_t stream) {
+    JM_REQUIRE(m >= 0 && n > 0 && n % 4 == 0 && ldd % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && dy && y && out,
+               "rows_relu_mask: bad arguments (n %d, ldd %d, ldy %d, ldo %d)", n, ldd, ldy, ldo);
     if (m == 0) return JM_OK;
     hipLaunchKernelGGL(rows_relu_mask_kernel, dim3((unsigned)grid_for((long long)m * (n / 4), 256, 8192)), dim3(256), 0, (hipStream_t)stream, m, m_dev,
-                       n, dy, ldd, y, ldy);
+                       n, dy, ldd, y, ldy, out, ldo);
     return check_launch("rows_relu_mask");
 }
 
@@ -351,6 +405,30 @@ int jm_rows_gate_backward(int m, int pc, int rc, float* dj, int ldj, const float
     hipLaunchKernelGGL(rows_gate_backward_kernel, dim3((unsigned)divup(m, 4)), dim3(256), 0, (hipStream_t)stream, m, pc, rc, dj, ldj, j, ldjj, g, t,
                        ldt, w3, dz, dt, lddt);
     return check_launch("rows_gate_backward");
+}
+
+int jm_fold_bn_multi(int n, const float* const* w, float* const* wf, const int* rows, const int* cols, const int* soff, const float* s,
+                     jm_stream_t stream) {
+    JM_REQUIRE(n >= 0 && (n == 0 || (w && wf && rows && cols && soff && s)), "fold_bn_multi: bad arguments");
+    for (int b = 0; b < n; b += JM_FOLD_MAX) {
+        FoldTable t{};
+        t.n = n - b < JM_FOLD_MAX ? n - b : JM_FOLD_MAX;
+        for (int i = 0; i < t.n; ++i) t.e[i] = FoldEntry{w[b + i], nullptr, wf[b + i], rows[b + i], cols[b + i], soff[b + i]};
+        hipLaunchKernelGGL(fold_bn_multi_kernel, dim3((unsigned)t.n, 32), dim3(256), 0, (hipStream_t)stream, t, s);
+    }
+    return check_launch("fold_bn_multi");
+}
+
+int jm_fold_bn_multi_grad(int n, const float* const* dwf, const float* const* w, float* const* dw, const int* rows, const int* cols,
+                          const int* soff, const float* s, float* ds, jm_stream_t stream) {
+    JM_REQUIRE(n >= 0 && (n == 0 || (dwf && w && dw && rows && cols && soff && s && ds)), "fold_bn_multi_grad: bad arguments");
+    for (int b = 0; b < n; b += JM_FOLD_MAX) {
+        FoldTable t{};
+        t.n = n - b < JM_FOLD_MAX ? n - b : JM_FOLD_MAX;
+        for (int i = 0; i < t.n; ++i) t.e[i] = FoldEntry{dwf[b + i], w[b + i], dw[b + i], rows[b + i], cols[b + i], soff[b + i]};
+        hipLaunchKernelGGL(fold_bn_multi_grad_kernel, dim3((unsigned)t.n, 32), dim3(256), 0, (hipStream_t)stream, t, s, ds);
+    }
+    return check_launch("fold_bn_multi_grad");
 }
 
 }  // extern "C"

@@ -121,9 +121,12 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], world: Optional[in
         off = 0
         for p in bucket:
             k = p.numel()
-            if p.grad is None:
-                p.grad = torch.empty_like(p)
-            p.grad.copy_(flat[off:off + k].view_as(p))
+            if p.is_contiguous():
+                p.grad = flat[off:off + k].view_as(p)       # the reduced bucket IS the gradient storage: no copy back (252 launches
+            else:                                           # per joint-mode step); other memory formats keep their own layout
+                if p.grad is None:
+                    p.grad = torch.empty_like(p)
+                p.grad.copy_(flat[off:off + k].view_as(p))
             off += k
         n += 1
     return n

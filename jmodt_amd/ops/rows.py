@@ -76,20 +76,23 @@ def linear_dgrad(dy: torch.Tensor, w: torch.Tensor, k0: int, k: int, mask: Optio
     return dx
 
 
-def linear_wgrad(dy: torch.Tensor, xs: Sequence[torch.Tensor], want_bias: bool = True, m_dev: Optional[torch.Tensor] = None):
-    """(dw (N, sum k_i) = dy^T [x_1 | x_2 | ...], dbias (N) or None)"""
+def linear_wgrad(dy: torch.Tensor, xs: Sequence[torch.Tensor], want_bias: bool = True, m_dev: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None, col0: int = 0):
+    """(dw (N, sum k_i) = dy^T [x_1 | x_2 | ...], dbias (N) or None); out / col0: write the block into columns col0 .. of an
+    existing (N, >= col0 + sum k_i) tensor instead"""
     lib = L.load()
     M, n = dy.shape
     ktot = sum(x.shape[1] for x in xs)
-    dw = torch.empty((n, ktot), dtype=_f32, device=dy.device)
+    dw = out if out is not None else torch.empty((n, ktot), dtype=_f32, device=dy.device)
     db = torch.empty((n,), dtype=_f32, device=dy.device) if want_bias else None
     pdy, lddy = _rows(dy, "dy")
-    off = 0
+    off = col0
+    ktot = dw.shape[1]
     for i, x in enumerate(xs):
         k = x.shape[1]
         px, ldx = _rows(x, "x")
         nbytes = int(lib.jm_rows_wgrad_workspace_bytes(M, n, k))
-        ws = _ws(nbytes, dy.device)
+        ws = _ws(nbytes, dy.device) if nbytes else None
         L.check(lib.jm_rows_linear_wgrad(M, _ptr(m_dev), n, k, pdy, lddy, px, ldx, ctypes.c_void_p(dw.data_ptr() + 4 * off), ktot,
                                          _ptr(db) if (want_bias and i == 0) else None, 0, _ptr(ws), nbytes, L.stream_ptr()), "rows_linear_wgrad")
         off += k
@@ -107,67 +110,102 @@ def colsum(x: torch.Tensor, m_dev: Optional[torch.Tensor] = None) -> torch.Tenso
     return out
 
 
-def relu_mask_(dy: torch.Tensor, y: torch.Tensor, m_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+def relu_mask(dy: torch.Tensor, y: torch.Tensor, m_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y > 0 ? dy : 0 as a new tensor (dy = a gradient autograd handed in: never modified)"""
+    out = torch.empty_like(y)
     pdy, ldd = _rows(dy, "dy")
     py, ldy = _rows(y, "y")
-    L.check(L.load().jm_rows_relu_mask(dy.shape[0], _ptr(m_dev), dy.shape[1], pdy, ldd, py, ldy, L.stream_ptr()), "rows_relu_mask")
-    return dy
+    L.check(L.load().jm_rows_relu_mask(dy.shape[0], _ptr(m_dev), dy.shape[1], pdy, ldd, py, ldy, _ptr(out), y.shape[1], L.stream_ptr()),
+            "rows_relu_mask")
+    return out
+
+
+def _vp(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _wgrad_ws_bytes(lib, M, pairs) -> int:
+    return max([int(lib.jm_rows_wgrad_workspace_bytes(M, n, k)) for n, k in pairs] + [0])
 
 
 class _RowsMLP(Function):
     """a chain of dense layers on rows: x = [x1 | x2] -> act_0(W_0 x + b_0) -> ... ; acts[l] in {0 none, 1 ReLU, 2 tanh}.
-    apply(x1, x2 or None, acts, W_0, b_0, W_1, b_1, ...) with b_l a tensor or None"""
+    apply(x1, x2 or None, acts, W_0, b_0, W_1, b_1, ...) with b_l a tensor or None.  ONE C call per direction
+    (csrc/rows_chain.hip: jm_rows_mlp_forward / _backward)."""
+
+    @staticmethod
+    def _desc(x1, x2, acts, Ws, bs, ys):
+        nl = len(acts)
+        d = L.RowsMlp()
+        d.nl, d.m, d.m_dev = nl, x1.shape[0], None
+        d.k1, d.k2 = x1.shape[1], (x2.shape[1] if x2 is not None else 0)
+        p1, d.ldx1 = _rows(x1, "x1")
+        d.x1 = p1.value
+        if x2 is not None:
+            p2, d.ldx2 = _rows(x2, "x2")
+            d.x2 = p2.value
+        kin = d.k1 + d.k2
+        for l in range(nl):
+            W = Ws[l]
+            if W.shape[1] != kin:
+                raise ValueError(f"layer {l}: weight of {W.shape[1]} input channels for an input of {kin}")
+            pw, ldw = _rows(W, f"W{l}")
+            d.widths[l], d.acts[l], d.w[l], d.ldw[l] = W.shape[0], int(acts[l]), pw.value, ldw
+            d.b[l] = _vp(bs[l])
+            d.y[l] = ys[l].data_ptr()
+            kin = W.shape[0]
+        return d
 
     @staticmethod
     def forward(ctx, x1, x2, acts, *wb):
         nl = len(acts)
-        assert len(wb) == 2 * nl
-        ys = []
-        cur, cur2 = x1, x2
-        for l in range(nl):
-            W, b = wb[2 * l], wb[2 * l + 1]
-            y = linear_forward(cur, W, b, acts[l], cur2)
-            ys.append(y)
-            cur, cur2 = y, None
+        assert len(wb) == 2 * nl and nl <= L.ROWS_MAX_LAYERS
+        Ws, bs = wb[0::2], wb[1::2]
+        M = x1.shape[0]
+        ys = [torch.empty((M, W.shape[0]), dtype=_f32, device=x1.device) for W in Ws]
+        d = _RowsMLP._desc(x1, x2, acts, Ws, bs, ys)
+        L.check(L.load().jm_rows_mlp_forward(ctypes.byref(d), L.stream_ptr()), "rows_mlp_forward")
         ctx.acts = tuple(acts)
         ctx.has_x2 = x2 is not None
-        ctx.has_b = tuple(b is not None for b in wb[1::2])
-        ctx.save_for_backward(x1, *( [x2] if x2 is not None else []), *wb[0::2], *ys)
+        ctx.has_b = tuple(b is not None for b in bs)
+        ctx.save_for_backward(x1, *([x2] if x2 is not None else []), *Ws, *ys)
         return ys[-1]
 
     @staticmethod
     def backward(ctx, dout):
+        lib = L.load()
         acts, nl = ctx.acts, len(ctx.acts)
         saved = list(ctx.saved_tensors)
         x1 = saved.pop(0)
         x2 = saved.pop(0) if ctx.has_x2 else None
         Ws, ys = saved[:nl], saved[nl:]
-        dy = dout.contiguous()
-        if dy.data_ptr() == dout.data_ptr():
-            dy = dy.clone()                      # masked in place below: never the caller's gradient buffer
-        grads = [None] * (2 * nl)
+        dev = x1.device
+        M = x1.shape[0]
+        if not (dout.stride(1) == 1 and dout.stride(0) % 4 == 0 and dout.data_ptr() % 16 == 0):
+            dout = dout.contiguous()
+        d = _RowsMLP._desc(x1, x2, acts, Ws, [None] * nl, ys)
+        g = L.RowsMlpGrad()
+        g.dout, g.lddout = dout.data_ptr(), dout.stride(0) if M > 1 else dout.shape[1]
+        dws = [torch.empty_like(W) if W.is_contiguous() else torch.empty(W.shape, dtype=_f32, device=dev) for W in Ws]
+        dbs = [torch.empty((W.shape[0],), dtype=_f32, device=dev) if hb else None for W, hb in zip(Ws, ctx.has_b)]
+        for l in range(nl):
+            g.dw[l], g.lddw[l], g.db[l] = dws[l].data_ptr(), dws[l].shape[1], _vp(dbs[l])
         need_x1, need_x2 = ctx.needs_input_grad[0], ctx.has_x2 and ctx.needs_input_grad[1]
-        # gradient w.r.t. the last layer's pre-activation
-        if acts[-1] == 1:
-            relu_mask_(dy, ys[-1])
-        elif acts[-1] == 2:
-            dy = dy * (1.0 - ys[-1] * ys[-1])
-        dx1 = dx2 = None
-        for l in range(nl - 1, -1, -1):
-            ins = [ys[l - 1]] if l > 0 else ([x1, x2] if x2 is not None else [x1])
-            dw, db = linear_wgrad(dy, ins, want_bias=ctx.has_b[l])
-            grads[2 * l], grads[2 * l + 1] = dw, db
-            if l > 0:
-                a = acts[l - 1]
-                nxt = linear_dgrad(dy, Ws[l], 0, ys[l - 1].shape[1], mask=ys[l - 1] if a == 1 else None)
-                if a == 2:
-                    nxt = nxt * (1.0 - ys[l - 1] * ys[l - 1])
-                dy = nxt
-            else:
-                if need_x1:
-                    dx1 = linear_dgrad(dy, Ws[0], 0, x1.shape[1])
-                if need_x2:
-                    dx2 = linear_dgrad(dy, Ws[0], x1.shape[1], x2.shape[1])
+        dx1 = torch.empty_like(x1) if need_x1 else None
+        dx2 = torch.empty_like(x2) if need_x2 else None
+        g.dx1, g.dx2 = _vp(dx1), _vp(dx2)
+        wmax = max(W.shape[0] for W in Ws)
+        scratch = torch.empty((2, M, wmax), dtype=_f32, device=dev)
+        g.scratch[0], g.scratch[1] = scratch[0].data_ptr(), scratch[1].data_ptr()
+        pairs = [(Ws[l].shape[0], Ws[l].shape[1]) for l in range(1, nl)] + [(Ws[0].shape[0], x1.shape[1])] + \
+                ([(Ws[0].shape[0], x2.shape[1])] if x2 is not None else [])
+        nbytes = _wgrad_ws_bytes(lib, M, pairs)
+        ws = _ws(nbytes, dev) if nbytes else None
+        g.ws, g.ws_bytes = _vp(ws), nbytes
+        L.check(lib.jm_rows_mlp_backward(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "rows_mlp_backward")
+        grads = []
+        for l in range(nl):
+            grads += [dws[l], dbs[l]]
         return (dx1, dx2, None, *grads)
 
 
@@ -201,97 +239,147 @@ class RowsPlan:
         self.rows_dev = self.offsets[G:]          # (1,) int32 view: the row count, in device memory
 
 
-class _SaScale(Function):
-    """QueryAndGroup + SharedMLP + max-pool of one scale (pointnet2_modules.py:46-55) on the plan's rows.
-    apply(f (P, C) or None, xyz (P, 3), ctr (G, 3) or None, plan, W1x (H1, 3), W1f (H1, C) or None, b1, W2, b2, ..., WL, bL)
-    -> pooled (G, C_L).  Every layer is conv + ReLU (BatchNorm folded by the caller)."""
+class _SaLevel(Function):
+    """QueryAndGroup + SharedMLP + max-pool (pointnet2_modules.py:46-55) of ALL scales of one set-abstraction level on their plans'
+    rows; the scales' pooled features land in their channel slices of ONE (G, sum C_k) tensor (the torch.cat of :54 without a copy).
+    apply(f (P, C) or None, xyz (P, 3), ctr (G, 3) or None, plans, nlayers, W1_0, b1_0, W2_0, b2_0, ..., W1_1, b1_1, ...) with
+    W1_k (H1, 3 + C) = the first layer's weight on [xyz ; f] as QueryAndGroup concatenates them.  Every layer is conv + ReLU.
+    One C call per scale and direction (csrc/rows_chain.hip: jm_sa_scale_forward / _backward)."""
 
     @staticmethod
-    def forward(ctx, f, xyz, ctr, plan, w1x, w1f, b1, *wb):
-        lib = L.load()
-        R, rdev = plan.max_rows, plan.rows_dev
-        H1 = w1x.shape[0]
-        dev = xyz.device
-        u = None
+    def _desc(plan, nl, f, xyz, ctr, w1x, w1f, b1, Ws, bs, slab, widths, out, c0, argrow):
+        d = L.SaScale()
+        d.nl, d.groups, d.max_rows = nl, plan.groups, plan.max_rows
+        d.rows_dev, d.offsets, d.row_point, d.row_group = plan.rows_dev.data_ptr(), plan.offsets.data_ptr(), plan.row_point.data_ptr(), plan.row_group.data_ptr()
+        d.points, d.c = (f.shape[0], f.shape[1]) if f is not None else (xyz.shape[0], 0)
         if f is not None:
-            u = linear_forward(f, w1f, b1, 0)                             # per POINT: (P, H1)
-        h = torch.empty((R, H1), dtype=_f32, device=dev)
-        L.check(lib.jm_sa_rows_h1(R, _ptr(rdev), H1, _ptr(u), H1, _ptr(b1), L.dev(w1x.contiguous(), _f32, "w1x"), L.dev(xyz, _f32, "xyz"),
-                                  L.dev(ctr, _f32, "ctr") if ctr is not None else None, _ptr(plan.row_point), _ptr(plan.row_group), _ptr(h), H1,
-                                  L.stream_ptr()), "sa_rows_h1")
-        hs = [h]
-        for l in range(0, len(wb), 2):
-            h = linear_forward(h, wb[l], wb[l + 1], 1, m_dev=rdev)
-            hs.append(h)
-        C = h.shape[1]
-        out = torch.empty((plan.groups, C), dtype=_f32, device=dev)
-        argrow = torch.empty((plan.groups, C), dtype=_i32, device=dev)
-        L.check(lib.jm_sa_rows_pool(plan.groups, C, _ptr(h), C, _ptr(plan.offsets), _ptr(out), C, _ptr(argrow), L.stream_ptr()), "sa_rows_pool")
-        ctx.plan = plan
-        ctx.has_f, ctx.has_ctr = f is not None, ctr is not None
-        ctx.nl = len(wb) // 2
-        keep = [xyz, w1x, out, argrow] + ([f, w1f] if f is not None else []) + ([ctr] if ctr is not None else []) + list(wb[0::2]) + hs[:-1]
-        ctx.save_for_backward(*keep)
+            pf, d.ldf = _rows(f, "f")
+            d.f = pf.value
+        d.xyz, d.ctr = xyz.data_ptr(), _vp(ctr)
+        d.w1x, d.w1f, d.b1 = w1x.data_ptr(), _vp(w1f), b1.data_ptr()
+        for l in range(nl):
+            d.widths[l] = widths[l]
+        for l in range(1, nl):
+            d.w[l], d.b[l] = Ws[l - 1].data_ptr(), _vp(bs[l - 1]) if bs is not None else None
+        # slab layout (floats): u (points, H1) | delta (R, 4) | h[0] (R, H1) | ... | h[nl - 1]
+        base, R, H1 = slab.data_ptr(), plan.max_rows, widths[0]
+        off = 0
+        d.u = base
+        off += d.points * H1 if f is not None else 0
+        d.delta = base + 4 * off
+        off += R * 4
+        for l in range(nl):
+            d.h[l] = base + 4 * off
+            off += R * widths[l]
+        d.out, d.ldo, d.argrow = out.data_ptr() + 4 * c0, out.shape[1], argrow.data_ptr()
+        return d
+
+    @staticmethod
+    def _slab_elems(plan, nl, f, xyz, widths):
+        return (f.shape[0] * widths[0] if f is not None else 0) + plan.max_rows * (4 + sum(widths[:nl]))
+
+    @staticmethod
+    def forward(ctx, f, xyz, ctr, plans, nlayers, *wb):
+        lib = L.load()
+        dev = xyz.device
+        K, per = len(plans), 2 * nlayers
+        G = plans[0].groups
+        couts = [wb[k * per + per - 2].shape[0] for k in range(K)]
+        out = torch.empty((G, sum(couts)), dtype=_f32, device=dev)
+        L.dev(xyz, _f32, "xyz")
+        if ctr is not None:
+            L.dev(ctr, _f32, "ctr")
+        keep, c0 = [], 0
+        for k, plan in enumerate(plans):
+            W1, b1 = wb[k * per], wb[k * per + 1]
+            Ws = [wb[k * per + 2 * l].contiguous() for l in range(1, nlayers)]
+            bs = [wb[k * per + 2 * l + 1] for l in range(1, nlayers)]
+            widths = [W1.shape[0]] + [W.shape[0] for W in Ws]
+            w1x = W1[:, :3].contiguous()
+            w1f = W1[:, 3:].contiguous() if f is not None else None        # (aligned copy: the row kernels read 16-byte vectors)
+            slab = torch.empty((_SaLevel._slab_elems(plan, nlayers, f, xyz, widths),), dtype=_f32, device=dev)
+            argrow = torch.empty((G, couts[k]), dtype=_i32, device=dev)
+            d = _SaLevel._desc(plan, nlayers, f, xyz, ctr, w1x, w1f, b1, Ws, bs, slab, widths, out, c0, argrow)
+            L.check(lib.jm_sa_scale_forward(ctypes.byref(d), L.stream_ptr()), "sa_scale_forward")
+            keep.append([slab, argrow, w1x] + ([w1f] if f is not None else []) + Ws)
+            c0 += couts[k]
+        ctx.plans, ctx.nlayers, ctx.couts, ctx.has_f, ctx.has_ctr = plans, nlayers, couts, f is not None, ctr is not None
+        ctx.counts = [len(kk) for kk in keep]
+        ctx.w1_cols = wb[0].shape[1]
+        ctx.save_for_backward(out, xyz, *([ctr] if ctr is not None else []), *([f] if f is not None else []), *[t for kk in keep for t in kk])
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = L.load()
-        plan = ctx.plan
-        R, rdev = plan.max_rows, plan.rows_dev
         saved = list(ctx.saved_tensors)
-        xyz, w1x, out, argrow = saved[:4]
-        saved = saved[4:]
-        f = w1f = ctr = None
-        if ctx.has_f:
-            f, w1f = saved[:2]
-            saved = saved[2:]
-        if ctx.has_ctr:
-            ctr = saved.pop(0)
-        Ws, hs = saved[:ctx.nl], saved[ctx.nl:]           # hs[0] = H1 ... hs[nl - 1] = input of the last layer
-        dev = xyz.device
+        out, xyz = saved.pop(0), saved.pop(0)
+        ctr = saved.pop(0) if ctx.has_ctr else None
+        f = saved.pop(0) if ctx.has_f else None
+        dev = out.device
+        nl, per = ctx.nlayers, 2 * ctx.nlayers
         dout = dout.contiguous()
-        C = out.shape[1]
-        dh = torch.empty((R, C), dtype=_f32, device=dev)
-        L.check(lib.jm_sa_rows_pool_grad(R, _ptr(rdev), C, _ptr(dout), C, _ptr(out), C, _ptr(argrow), _ptr(plan.row_group), _ptr(dh), C,
-                                         L.stream_ptr()), "sa_rows_pool_grad")
-        grads_wb = [None] * (2 * ctx.nl)
-        for l in range(ctx.nl - 1, -1, -1):
-            x_in = hs[l]
-            dw, db = linear_wgrad(dh, [x_in], True, m_dev=rdev)
-            grads_wb[2 * l], grads_wb[2 * l + 1] = dw, db
-            dh = linear_dgrad(dh, Ws[l], 0, x_in.shape[1], mask=x_in, m_dev=rdev)
-        # dh = gradient w.r.t. the first layer's pre-activation on the rows
-        H1 = dh.shape[1]
-        dw1x = torch.empty((H1, 3), dtype=_f32, device=dev)
-        nbytes = int(lib.jm_rows_reduce_workspace_bytes(3 * H1))
-        ws = _ws(nbytes, dev)
-        L.check(lib.jm_sa_rows_xyz_wgrad(R, _ptr(rdev), H1, _ptr(dh), H1, _ptr(xyz), _ptr(ctr), _ptr(plan.row_point), _ptr(plan.row_group),
-                                         _ptr(dw1x), 0, _ptr(ws), nbytes, L.stream_ptr()), "sa_rows_xyz_wgrad")
-        db1 = colsum(dh, m_dev=rdev)
-        df = dw1f = None
-        if ctx.has_f:
-            du = torch.zeros((f.shape[0], H1), dtype=_f32, device=dev)
-            L.check(lib.jm_sa_rows_scatter_add(R, _ptr(rdev), H1, _ptr(dh), H1, _ptr(plan.row_point), _ptr(du), H1, L.stream_ptr()),
-                    "sa_rows_scatter_add")
-            dw1f, _ = linear_wgrad(du, [f], False)
-            if ctx.needs_input_grad[0]:
-                df = linear_dgrad(du, w1f, 0, f.shape[1])
-        return (df, None, None, None, dw1x, dw1f, db1, *grads_wb)
+        grads, c0 = [], 0
+        df = torch.empty_like(f) if (ctx.has_f and ctx.needs_input_grad[0]) else None
+        for k, plan in enumerate(ctx.plans):
+            mine, saved = saved[:ctx.counts[k]], saved[ctx.counts[k]:]
+            slab, argrow, w1x = mine[0], mine[1], mine[2]
+            mine = mine[3:]
+            w1f = mine.pop(0) if ctx.has_f else None
+            Ws = mine
+            widths = [w1x.shape[0]] + [W.shape[0] for W in Ws]
+            H1, R = widths[0], plan.max_rows
+            b1_dummy = w1x          # (the backward never reads b1; the field must not be NULL)
+            d = _SaLevel._desc(plan, nl, f, xyz, ctr, w1x, w1f, b1_dummy, Ws, None, slab, widths, out, c0, argrow)
+            g = L.SaScaleGrad()
+            g.dout, g.lddout = dout.data_ptr() + 4 * c0, dout.shape[1]
+            dW1 = torch.empty((H1, ctx.w1_cols), dtype=_f32, device=dev)
+            db1 = torch.empty((H1,), dtype=_f32, device=dev)
+            dws = [torch.empty_like(W) for W in Ws]
+            dbs = [torch.empty((W.shape[0],), dtype=_f32, device=dev) for W in Ws]
+            wmax = max(widths)
+            nsc = 2 * R * wmax + H1 * 4 + (f.shape[0] * H1 if f is not None else 0)
+            scratch = torch.empty((nsc,), dtype=_f32, device=dev)
+            base = scratch.data_ptr()
+            g.scratch[0], g.scratch[1] = base, base + 4 * R * wmax
+            g.dw4 = base + 8 * R * wmax
+            g.du = base + 8 * R * wmax + 16 * H1 if f is not None else None
+            g.dw1, g.db1 = dW1.data_ptr(), db1.data_ptr()
+            for l in range(1, nl):
+                g.dw[l], g.db[l] = dws[l - 1].data_ptr(), dbs[l - 1].data_ptr()
+            g.df, g.df_accumulate = _vp(df), 1 if k > 0 else 0
+            pairs = [(widths[l], widths[l - 1]) for l in range(1, nl)] + [(H1, 4)]
+            nbytes = _wgrad_ws_bytes(lib, R, pairs)
+            if f is not None:
+                nbytes = max(nbytes, int(lib.jm_rows_wgrad_workspace_bytes(f.shape[0], H1, f.shape[1])))
+            ws = _ws(nbytes, dev) if nbytes else None
+            g.ws, g.ws_bytes = _vp(ws), nbytes
+            L.check(lib.jm_sa_scale_backward(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "sa_scale_backward")
+            gk = [dW1, db1]
+            for l in range(1, nl):
+                gk += [dws[l - 1], dbs[l - 1]]
+            grads += gk
+            c0 += ctx.couts[k]
+        return (df, None, None, None, None, *grads)
 
 
-def sa_scale_rows(f: Optional[torch.Tensor], xyz: torch.Tensor, ctr: Optional[torch.Tensor], plan: RowsPlan,
-                  layers: Sequence[Tuple[torch.Tensor, torch.Tensor]]) -> torch.Tensor:
-    """one set-abstraction scale on rows: f (P, C) point features (None: xyz only), xyz (P, 3) flat points, ctr (G, 3) group centres
-    (None: GroupAll, coordinates not re-centred), layers = [(W (out, in), b)] with layer 0's input = [xyz (3) ; f (C)] as
-    QueryAndGroup concatenates them (pointnet2_utils.py:259-269) -> (G, C_out)"""
-    W1, b1 = layers[0]
-    w1x = W1[:, :3].contiguous()
-    w1f = W1[:, 3:].contiguous() if f is not None else None
+def sa_level_rows(f: Optional[torch.Tensor], xyz: torch.Tensor, ctr: Optional[torch.Tensor], plans: Sequence[RowsPlan],
+                  scales: Sequence[Sequence[Tuple[torch.Tensor, torch.Tensor]]]) -> torch.Tensor:
+    """all scales of one set-abstraction level on rows: f (P, C) point features (None: xyz only), xyz (P, 3) flat points, ctr (G, 3)
+    group centres (None: GroupAll, coordinates not re-centred), scales[k] = [(W (out, in), b)] of scale k with layer 0's input =
+    [xyz (3) ; f (C)] as QueryAndGroup concatenates them (pointnet2_utils.py:259-269) -> (G, sum_k C_out_k)"""
+    nl = len(scales[0])
+    assert all(len(sc) == nl for sc in scales) and nl >= 2
     flat = []
-    for W, b in layers[1:]:
-        flat += [W, b]
-    return _SaScale.apply(f, xyz, ctr, plan, w1x, w1f, b1, *flat)
+    for sc in scales:
+        for W, b in sc:
+            flat += [W, b]
+    return _SaLevel.apply(f, xyz, ctr, tuple(plans), nl, *flat)
+
+
+def sa_scale_rows(f, xyz, ctr, plan: RowsPlan, layers) -> torch.Tensor:
+    """one scale (see sa_level_rows)"""
+    return sa_level_rows(f, xyz, ctr, [plan], [layers])
 
 
 # ---------------------------------------------------------------------------------------------------- interpolation / gather on rows
@@ -355,3 +443,59 @@ class _FeatureGatherRows(Function):
 def feature_gather_rows(feature_map: torch.Tensor, xy: torch.Tensor) -> torch.Tensor:
     """feature_map (B, C, H, W) (channels-last memory), xy (B, N, 2) in [-1, 1] -> (B N, C): backbone.py:79-89 on rows"""
     return _FeatureGatherRows.apply(feature_map, xy)
+
+
+# ---------------------------------------------------------------------------------------------------- BatchNorm folding
+class _FoldAll(Function):
+    """wf_l = w_l * s[soff_l + row] for every (convolution, BatchNorm) pair of a network in ONE launch, and its backward in one more
+    (csrc/rows_ops.hip: fold_bn_multi).  apply(s (sum C,), soffs, w_0, w_1, ...) -> (wf_0, wf_1, ...), each wf_l laid out like w_l."""
+
+    @staticmethod
+    def _table(ts):
+        n = len(ts)
+        return (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+
+    @staticmethod
+    def forward(ctx, s, soffs, *ws):
+        n = len(ws)
+        for w in ws:
+            if not (w.is_contiguous() or (w.dim() == 4 and w.is_contiguous(memory_format=torch.channels_last))):
+                raise RuntimeError("fold: weights must be dense (contiguous or channels-last)")
+        outs = [torch.empty_like(w) for w in ws]
+        rows = (ctypes.c_int * n)(*[w.shape[0] for w in ws])
+        cols = (ctypes.c_int * n)(*[w.numel() // w.shape[0] for w in ws])
+        so = (ctypes.c_int * n)(*soffs)
+        L.check(L.load().jm_fold_bn_multi(n, _FoldAll._table(ws), _FoldAll._table(outs), rows, cols, so, L.dev(s, _f32, "s"), L.stream_ptr()),
+                "fold_bn_multi")
+        ctx.save_for_backward(s, *ws)
+        ctx.soffs = soffs
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dwfs):
+        s, *ws = ctx.saved_tensors
+        live = [i for i, g in enumerate(dwfs) if g is not None]
+        ds = torch.zeros_like(s)
+        dws = [None] * len(ws)
+        if live:
+            gs = []
+            for i in live:
+                g, w = dwfs[i], ws[i]
+                if g.shape != w.shape:
+                    g = g.reshape(w.shape)
+                if g.stride() != w.stride():         # same memory order as the weight (channels-last 3x3 kernels)
+                    g = torch.empty_like(w).copy_(g)
+                gs.append(g)
+                dws[i] = torch.empty_like(w)
+            n = len(live)
+            rows = (ctypes.c_int * n)(*[ws[i].shape[0] for i in live])
+            cols = (ctypes.c_int * n)(*[ws[i].numel() // ws[i].shape[0] for i in live])
+            so = (ctypes.c_int * n)(*[ctx.soffs[i] for i in live])
+            L.check(L.load().jm_fold_bn_multi_grad(n, _FoldAll._table(gs), _FoldAll._table([ws[i] for i in live]),
+                                                   _FoldAll._table([dws[i] for i in live]), rows, cols, so, _ptr(s), _ptr(ds), L.stream_ptr()),
+                    "fold_bn_multi_grad")
+        return (ds, None, *dws)
+
+
+def fold_all(s: torch.Tensor, soffs: Sequence[int], weights: Sequence[torch.Tensor]):
+    return _FoldAll.apply(s, tuple(int(o) for o in soffs), *weights)

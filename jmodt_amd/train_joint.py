@@ -89,9 +89,24 @@ def thin_loss(engine, out: Dict[str, torch.Tensor], gt_tids: torch.Tensor, count
     return (out["rpn_cls"].sum() + out["rpn_reg"].sum()) / n + out["rcnn_cls"].sum() + out["rcnn_reg"].sum() + reid
 
 
+_bn_lists = {}       # id(engine) -> (registration epoch, [BatchNorm modules], [parameters])
+
+
+def _engine_lists(engine):
+    """(BatchNorm modules, parameters) of the engine, re-collected only after a registration anywhere in the process: three module
+    walks per step are 3 ms of host time on a step the host must keep ahead of"""
+    from ._registry import EPOCH
+    hit = _bn_lists.get(id(engine))
+    if hit is None or hit[0] != EPOCH[0] or hit[3]() is not engine:
+        import weakref
+        hit = _bn_lists[id(engine)] = (EPOCH[0], [m for m in engine.modules() if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d))],
+                                       list(engine.parameters()), weakref.ref(engine))
+    return hit[1], hit[2]
+
+
 def frozen_bn(engine) -> bool:
     """is every BatchNorm of the detector in eval mode (running statistics: cfg.RPN.FIXED-style, point_rcnn.py:29-30)?"""
-    return not any(m.training for m in engine.modules() if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)))
+    return not any(m.training for m in _engine_lists(engine)[0])
 
 
 def freeze_bn(engine) -> None:
@@ -100,6 +115,14 @@ def freeze_bn(engine) -> None:
     for m in engine.modules():
         if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
             m.eval()
+
+
+def prepare_rows(engine) -> None:
+    """once, before the optimizer is built: BatchNorms frozen, the image blocks' 3x3 kernels in channels-last memory (what
+    MIOpen's fp32 kernels take without a transposition pass; the folded copies and the gradients then have that layout too)"""
+    freeze_bn(engine)
+    for blk in engine.rpn.backbone_net.Img_Block:
+        blk.to(memory_format=torch.channels_last)
 
 
 def joint_step(engine, xyz, image, pts_xy, gt_tids, optimizer, world: Optional[int] = None, rois_per_frame: int = 64,
@@ -114,7 +137,7 @@ def joint_step(engine, xyz, image, pts_xy, gt_tids, optimizer, world: Optional[i
     starts on the side stream under this step (rows route).  world / local: see dist.group_world."""
     import torch.distributed as tdist
     from .ops.affinity_train import AffinityTrainState
-    params = [p for p in engine.parameters() if p.requires_grad]
+    params = [p for p in _engine_lists(engine)[1] if p.requires_grad]
     optimizer.zero_grad(set_to_none=True)
     if route == "auto":
         route = "rows" if frozen_bn(engine) and xyz.is_cuda else "operators"

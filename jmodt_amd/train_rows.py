@@ -23,21 +23,57 @@ import torch.nn.functional as F
 
 from .ops import rows as R
 from .ops.pointnet2 import pointnet2_utils
-from .ops.pointnet2.pyramid import FpsPyramid
+from .ops.pointnet2.pyramid import FpsPyramid, side_stream
 from .ops.roipool3d.roipool3d_utils import roipool3d_canonical_gpu
 from .profile import prof
 
 
+_pairs_cache = {}      # id(root) -> (registration epoch, weakref to root, pairs)
+
+
+def bn_pairs(root: nn.Module):
+    """[(convolution / Linear module, BatchNorm module)] of every BatchNorm of the detector, found by structure: pytorch_utils units
+    (`unit.conv`, `unit.bn.bn`), IA_Layer.conv1 = Sequential(Conv1d, BatchNorm1d, ReLU), AttentionFusion (conv1, bn1), the image
+    blocks (conv1, bn1), (image_fusion_conv, image_fusion_bn) — backbone.py:16-32,35-81,150-157, pytorch_utils.py:36-102.
+    The walk (2 ms of host time for the detector) is repeated only after a module / parameter registration (_registry.EPOCH)."""
+    import weakref
+    from ._registry import EPOCH
+    hit = _pairs_cache.get(id(root))
+    if hit is not None and hit[0] == EPOCH[0] and hit[1]() is root:
+        return hit[2]
+    pairs = _bn_pairs_walk(root)
+    nbn = sum(1 for m in root.modules() if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)))
+    assert len(pairs) == len({id(b) for _, b in pairs}) == nbn, "a BatchNorm of the network is not paired with its convolution (train_rows.bn_pairs)"
+    _pairs_cache[id(root)] = (EPOCH[0], weakref.ref(root), pairs)
+    return pairs
+
+
+def _bn_pairs_walk(root: nn.Module):
+    pairs = []
+    for m in root.modules():
+        if hasattr(m, "conv") and hasattr(m, "bn") and hasattr(m.bn, "bn"):
+            pairs.append((m.conv, m.bn.bn))
+        elif isinstance(m, nn.Sequential) and len(m) >= 2 and isinstance(m[0], (nn.Conv1d, nn.Conv2d)) and isinstance(m[1], (nn.BatchNorm1d, nn.BatchNorm2d)):
+            pairs.append((m[0], m[1]))
+        elif hasattr(m, "conv1") and hasattr(m, "bn1") and isinstance(m.bn1, (nn.BatchNorm1d, nn.BatchNorm2d)):
+            pairs.append((m.conv1, m.bn1))
+        elif hasattr(m, "image_fusion_conv") and hasattr(m, "image_fusion_bn"):
+            pairs.append((m.image_fusion_conv, m.image_fusion_bn))
+    return pairs
+
+
 class BnFold:
-    """eval-mode BatchNorm scale / shift of EVERY BatchNorm of a module tree, computed by four batched launches:
-    s = gamma / sqrt(running_var + eps), t = beta - running_mean * s; `of(bn)` hands out the two (C,) views.  Differentiable
-    w.r.t. gamma and beta (the running statistics are buffers)."""
+    """eval-mode BatchNorm folded into the preceding convolution for the WHOLE network with a handful of launches:
+    s = gamma / sqrt(running_var + eps), t = beta - running_mean * s from four concatenated vectors, every folded weight
+    W * s[:, None] from ONE multi-tensor kernel (ops/rows.fold_all) whose backward — d(W) = d(Wf) * s, d(s) = rowsum(d(Wf) * W) —
+    is one more.  Differentiable w.r.t. W, gamma, beta (the running statistics are buffers)."""
 
     def __init__(self, root: nn.Module):
-        bns = [m for m in root.modules() if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d))]
+        pairs = bn_pairs(root)
         self._slots = {}
-        if not bns:
+        if not pairs:
             return
+        bns = [bn for _, bn in pairs]
         eps = {m.eps for m in bns}
         assert len(eps) == 1, "mixed BatchNorm eps"
         gamma = torch.cat([m.weight for m in bns])
@@ -47,27 +83,29 @@ class BnFold:
             inv = torch.rsqrt(torch.cat([m.running_var for m in bns]) + eps.pop())
         s = gamma * inv
         t = beta - mean * s
-        off = 0
-        for m in bns:
-            c = m.num_features
-            self._slots[id(m)] = (s[off:off + c], t[off:off + c])
-            off += c
-
-    def of(self, bn: nn.Module) -> Tuple[torch.Tensor, torch.Tensor]:
-        return self._slots[id(bn)]
+        sizes = [m.num_features for m in bns]
+        soffs = [sum(sizes[:i]) for i in range(len(sizes))]
+        ts = torch.split(t, sizes)
+        ss = torch.split(s, sizes)
+        wfs = R.fold_all(s, soffs, [conv.weight for conv, _ in pairs])
+        for (conv, bn), wf, sv, tv in zip(pairs, wfs, ss, ts):
+            b = conv.bias
+            self._slots[id(conv)] = (wf, tv if b is None else b * sv + tv)
 
     def unit(self, unit: nn.Module) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """folded (W (out, in), b (out)) of a pytorch_utils Conv1d / Conv2d unit (conv [+ bn.bn]), differentiable"""
-        bn = unit.bn.bn if hasattr(unit, "bn") else None
-        return self.conv(unit.conv, bn)
+        return self.conv(unit.conv, unit.bn.bn if hasattr(unit, "bn") else None)
 
     def conv(self, conv: nn.Module, bn: Optional[nn.Module]) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-        W = conv.weight.reshape(conv.weight.shape[0], -1)
-        b = conv.bias
+        """(W (out, in * kernel), b) of a 1x1 convolution / Linear [+ BatchNorm]"""
         if bn is None:
-            return W, b
-        s, t = self.of(bn)
-        return W * s[:, None], (t if b is None else b * s + t)
+            return conv.weight.reshape(conv.weight.shape[0], -1), conv.bias
+        wf, b = self._slots[id(conv)]
+        return wf.reshape(wf.shape[0], -1), b
+
+    def conv4d(self, conv: nn.Module) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(folded weight in the convolution's own 4-D shape and memory format, bias) of a BatchNorm-followed Conv2d"""
+        return self._slots[id(conv)]
 
 
 def _pad_rows(W: torch.Tensor, b: Optional[torch.Tensor], mult: int = 4):
@@ -129,11 +167,8 @@ def _sa_level_rows(fold: BnFold, sa, xyz: torch.Tensor, feats: Optional[torch.Te
         neigh = pointnet2_utils.ball_query_dual(g0.radius, g0.nsample, g1.radius, g1.nsample, xyz, new_xyz, grid=grid)
     else:
         neigh = [pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz) for g in groupers]
-    outs = []
-    for nb, mlp in zip(neigh, sa.mlps):
-        plan = R.RowsPlan(nb, n, canon)
-        outs.append(R.sa_scale_rows(feats, flat_xyz, flat_ctr, plan, [fold.unit(u) for u in mlp]))
-    return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
+    plans = [R.RowsPlan(nb, n, canon) for nb in neigh]
+    return R.sa_level_rows(feats, flat_xyz, flat_ctr, plans, [[fold.unit(u) for u in mlp] for mlp in sa.mlps])
 
 
 def _image_pyramid(fold: BnFold, net, image: torch.Tensor) -> List[torch.Tensor]:
@@ -141,11 +176,9 @@ def _image_pyramid(fold: BnFold, net, image: torch.Tensor) -> List[torch.Tensor]
     x = image.contiguous(memory_format=torch.channels_last)
     maps = []
     for blk in net.Img_Block:
-        s, t = fold.of(blk.bn1)
-        w1 = (blk.conv1.weight * s[:, None, None, None]).contiguous(memory_format=torch.channels_last)
+        w1, t = fold.conv4d(blk.conv1)         # (channels-last when the parameter is: train_joint.prepare_rows converts them once)
         y = F.relu(F.conv2d(x, w1, t, stride=1, padding=1), inplace=True)
-        x = F.conv2d(y, blk.conv2.weight.contiguous(memory_format=torch.channels_last), blk.conv2.bias, stride=blk.conv2.stride,
-                     padding=blk.conv2.padding)
+        x = F.conv2d(y, blk.conv2.weight, blk.conv2.bias, stride=blk.conv2.stride, padding=blk.conv2.padding)
         maps.append(x)
     return maps
 
@@ -175,13 +208,31 @@ def backbone_forward_rows(engine, xyz: torch.Tensor, image: torch.Tensor, pts_xy
     own = pyr is None
     if own:
         pyr = FpsPyramid(xyz, list(cfg.sa_npoints), overlap=engine.overlap, with_interp=True, grid_radii=engine._grid_radii())
-    maps = prof.region("image_pyramid(MIOpen)", lambda: _image_pyramid(fold, net, image))
+    # stream I: the image pyramid and the fused image map (MIOpen), forward here and — autograd runs a node's backward on the stream
+    # of its forward — BACKWARD there too: the convolutions' large kernels run next to the point branch's many small launches
+    main = torch.cuda.current_stream(xyz.device)
+    img_stream = side_stream(xyz.device, 1) if engine.overlap else main
+    img_stream.wait_stream(main)
+    with torch.cuda.stream(img_stream):
+        maps = prof.region("image_pyramid(MIOpen)", lambda: _image_pyramid(fold, net, image))
+        map_events = []
+        for m in maps:
+            ev = torch.cuda.Event()
+            ev.record(img_stream)
+            map_events.append(ev)
+        fused_img = prof.region("image_deconv+fusion_conv(MIOpen)", lambda: _image_fusion_map(fold, net, maps))
+        fused_ev = torch.cuda.Event()
+        fused_ev.record(img_stream)
+    if img_stream is not main:
+        for t in list(maps) + [fused_img, image]:
+            t.record_stream(main if t is not image else img_stream)
     l_xyz, l_feats, l_xy = [xyz], [None], [pts_xy]
     for i, sa in enumerate(net.SA_modules):
         idx, new_xyz = pyr.level(i)
         with prof.scope(f"rpn_sa{i + 1}"):
             feats = _sa_level_rows(fold, sa, l_xyz[i], l_feats[i], new_xyz, grid=pyr.grid(i))
         xy_i = torch.gather(l_xy[i], 1, idx.long().unsqueeze(-1).expand(-1, -1, 2))
+        main.wait_event(map_events[i])
         with prof.scope(f"li_fusion{i + 1}"):
             feats = _attention_rows(fold, net.Fusion_Conv[i], feats, R.feature_gather_rows(maps[i], xy_i))
         l_xyz.append(new_xyz); l_feats.append(feats); l_xy.append(xy_i)
@@ -193,7 +244,7 @@ def backbone_forward_rows(engine, xyz: torch.Tensor, image: torch.Tensor, pts_xy
             mlp = net.FP_modules[i].mlp
             layers = [fold.unit(u) for u in mlp]
             l_feats[i - 1] = R.rows_mlp(carried, layers, [1] * len(layers), x2=l_feats[i - 1])
-    fused_img = prof.region("image_deconv+fusion_conv(MIOpen)", lambda: _image_fusion_map(fold, net, maps))
+    main.wait_event(fused_ev)
     with prof.scope("li_fusion_final"):
         out = _attention_rows(fold, net.final_fusion_img_point, l_feats[0], R.feature_gather_rows(fused_img, pts_xy))
     if own:
@@ -262,6 +313,18 @@ def joint_forward_rows(engine, xyz, image, pts_xy, rois_per_frame: int = 64, pyr
         pf[:, :, 2:] = feats.detach().view(B, N, C)                                       # rows ARE the (B, N, C) layout roipool reads
         pooled, _, count = roipool3d_canonical_gpu(xyz, pf, rois, cfg.pool_extra_width, cfg.rcnn_num_points, return_count=True)
         pts_input = pooled.view(-1, cfg.rcnn_num_points, pooled.shape[-1])
-    out = rcnn_forward_rows(engine, pts_input, fold, count.view(-1))
+    # stream R: the RCNN (rcnn.py:158-202).  Its BACKWARD then runs there too (autograd: a node's backward on its forward's
+    # stream), next to the backbone's backward on the main stream — neither feeds the other: roipool3d has no gradient
+    main = torch.cuda.current_stream(xyz.device)
+    side = side_stream(xyz.device, 3) if engine.overlap else main
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        out = rcnn_forward_rows(engine, pts_input, fold, count.view(-1))
+    if side is not main:
+        main.wait_stream(side)
+        for t in out.values():
+            t.record_stream(main)
+        pts_input.record_stream(side)
+        count.record_stream(side)
     out.update(rpn_cls=rpn_cls, rpn_reg=rpn_reg, backbone_features=feats.view(B, N, C).transpose(1, 2), rois=rois)
     return out

@@ -26,10 +26,11 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 @pytest.mark.parametrize("M,k1,k2,n,act", [(300, 64, 0, 76, 1), (1000, 196, 0, 256, 1), (257, 96, 128, 128, 1), (4096, 24, 24, 4, 2),
-                                           (130, 8, 0, 128, 0), (5000, 128, 0, 196, 1), (64, 512, 512, 512, 1)])
+                                           (130, 8, 0, 128, 0), (5000, 128, 0, 196, 1), (64, 512, 512, 512, 1), (20000, 128, 0, 256, 1), (33000, 64, 36, 132, 1)])
 def test_rows_linear_forward_dgrad_wgrad_vs_float64(M, k1, k2, n, act):
     """every GEMM mode on shapes with row / column / contraction tails (196, 24, 76, 4 = the widths of config.py:75-77 that are
-    no multiple of 16), one and two operands, against float64"""
+    no multiple of 16), one and two operands, against float64; the last two shapes take the 128 x 128 persistent tiles, the others
+    the one-wave 32 x 32 tiles (a device-side row count always takes the former)"""
     from jmodt_amd.ops import rows as R
     x1, x2 = rnd(M, k1, seed=1), (rnd(M, k2, seed=2) if k2 else None)
     w, b = rnd(n, k1 + k2, seed=3, scale=0.2), rnd(n, seed=4)
@@ -56,6 +57,8 @@ def test_rows_linear_forward_dgrad_wgrad_vs_float64(M, k1, k2, n, act):
     m_dev = torch.tensor([mv], dtype=torch.int32, device=DEV)
     y2 = R.linear_forward(x1, w, b, act, x2, m_dev=m_dev)
     close(y2[:mv], want[:mv], what="forward, device row count")
+    dx3 = R.linear_dgrad(dy, w, 0, k1, mask=mask, m_dev=m_dev)
+    close(dx3[:mv], ((dy.double() @ w.double()[:, :k1]) * (mask > 0))[:mv], what="dgrad, device row count")
     dw2, db2 = R.linear_wgrad(dy, [x1, x2] if k2 else [x1], m_dev=m_dev)
     close(dw2, dy[:mv].double().t() @ xx[:mv].double(), tol=2e-4, what="wgrad, device row count")
     close(db2, dy[:mv].double().sum(0), tol=2e-4, what="bias grad, device row count")

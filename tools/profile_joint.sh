@@ -18,4 +18,5 @@ db=$(find /tmp/prof_$TAG -name '*.db' | head -1)
 if [ -z "$db" ]; then echo "no db"; tail -5 /tmp/prof_$TAG.log; exit 1; fi
 python "$REPO/profiles/summarize.py" "$db" "$OUT/${TAG}_kernel_stats.txt" > /dev/null
 tail -1 /tmp/prof_$TAG.log | cut -c1-600
+mkdir -p "$REPO/gpurun_out/bench_out"; cp /tmp/bench_out/*.json "$REPO/gpurun_out/bench_out/" 2>/dev/null; cp "$REPO"/bench_out/*.json "$REPO/gpurun_out/bench_out/" 2>/dev/null
 head -70 "$OUT/${TAG}_kernel_stats.txt"
