@@ -51,6 +51,11 @@ struct RGemm {
                                    // result itself when splits == 1; NULL: skipped
 };
 
+__host__ __device__ __forceinline__ int wgrad_live_splits(int rows, int splits) {
+    const int want = (rows + 127) / 128;
+    return want < 1 ? 1 : (want > splits ? splits : want);
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256)
 rows_gemm_kernel(RGemm p) {
@@ -66,7 +71,12 @@ rows_gemm_kernel(RGemm p) {
     const int ntiles = ((Mv + RBM - 1) / RBM) * ntn;
     int k_begin = 0, k_end = Kv;
     if (MODE == RM_WGRAD) {
-        const int kchunk = ((Kv + p.splits - 1) / p.splits + RBK - 1) / RBK * RBK;
+        // the split count was chosen on the host for the row CAPACITY; with the count in device memory only the splits that have
+        // at least 128 rows' worth of work exist (the others return: rows_wgrad_reduce_kernel applies the same rule and never
+        // reads their partials) — a scale whose groups hold one distinct neighbour each runs 4 splits, not 128
+        const int live = wgrad_live_splits(Kv, p.splits);
+        if ((int)blockIdx.y >= live) return;
+        const int kchunk = ((Kv + live - 1) / live + RBK - 1) / RBK * RBK;
         k_begin = min((int)blockIdx.y * kchunk, Kv);
         k_end = min(Kv, k_begin + kchunk);
     }
@@ -215,8 +225,10 @@ rows_gemm_kernel(RGemm p) {
 
 // dW[n, k] (+)= sum over the split partials in split order, and the same for the bias gradient's (splits, N) partials (threads
 // behind the N * K / 4 weight quads); four independent chains per thread so that the partials' loads overlap
-__global__ void rows_wgrad_reduce_kernel(int N, int K, int splits, const float* __restrict__ part, float* __restrict__ dW, int ldw,
-                                         const float* __restrict__ bias_part, float* __restrict__ dbias, int accumulate) {
+__global__ void rows_wgrad_reduce_kernel(int N, int K, int splits, int m, const int* __restrict__ m_dev, const float* __restrict__ part,
+                                         float* __restrict__ dW, int ldw, const float* __restrict__ bias_part, float* __restrict__ dbias,
+                                         int accumulate) {
+    splits = wgrad_live_splits(dev_count(m, m_dev), splits);          // the splits rows_gemm_kernel<RM_WGRAD> actually wrote
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int quads = N * (K / 4);
     if (i < quads) {
@@ -443,7 +455,7 @@ int jm_rows_linear_wgrad(int m, const int* m_dev, int n, int k, const float* dy,
                        (hipStream_t)stream, p);
     if (splits > 1) {
         const int work = n * (k / 4) + (dbias ? n : 0);
-        hipLaunchKernelGGL(rows_wgrad_reduce_kernel, dim3((unsigned)divup(work, 256)), dim3(256), 0, (hipStream_t)stream, n, k, splits,
+        hipLaunchKernelGGL(rows_wgrad_reduce_kernel, dim3((unsigned)divup(work, 256)), dim3(256), 0, (hipStream_t)stream, n, k, splits, m, m_dev,
                            (const float*)ws, dw, lddw, (const float*)bias_part, dbias, accumulate);
     }
     return check_launch("rows_linear_wgrad");

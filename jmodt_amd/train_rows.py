@@ -171,33 +171,65 @@ def _sa_level_rows(fold: BnFold, sa, xyz: torch.Tensor, feats: Optional[torch.Te
     return R.sa_level_rows(feats, flat_xyz, flat_ctr, plans, [[fold.unit(u) for u in mlp] for mlp in sa.mlps])
 
 
+class _Conv3x3BiasRelu(torch.autograd.Function):
+    """relu(conv3x3(x, w, padding 1) + b) of an image block's first layer (backbone.py:16-32 conv1 + bn1 + relu, BatchNorm folded
+    into w / b by the caller).  Forward = the inference engine's one-pass kernels (csrc/conv_rgb.hip for the 3-channel first layer,
+    the fused Winograd F(2x2, 3x3) of csrc/conv_wino.hip for the others: no bias / ReLU passes over the 0.5 GB activations);
+    backward: d(x) of the Winograd layers = the same kernel on the flipped, transposed weight (a stride-1 3x3 convolution's data
+    gradient IS one), d(w) on MIOpen (aten.convolution_backward), d(b) = a channel sum."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        from .ops.fusion import conv3x3_rgb_bias_relu, conv3x3_wino_bias_relu, pack_rgb_weight, pack_wino_weight, wino_supported
+        cout, cin = w.shape[0], w.shape[1]
+        if cin == 3:
+            y = conv3x3_rgb_bias_relu(x, w, b, pack_rgb_weight(w))
+            ctx.kind = "rgb"
+        elif wino_supported(cin, cout) and x.is_contiguous(memory_format=torch.channels_last):
+            y = conv3x3_wino_bias_relu(x, pack_wino_weight(w), b, cout)
+            ctx.kind = "wino"
+        else:
+            y = torch.relu_(F.conv2d(x, w, b, stride=1, padding=1))
+            ctx.kind = "miopen"
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .ops.fusion import conv3x3_wino_bias_relu, pack_wino_weight, wino_supported
+        x, w, y = ctx.saved_tensors
+        cout, cin = w.shape[0], w.shape[1]
+        dpre = torch.ops.aten.threshold_backward(dy, y, 0)
+        need_x = ctx.needs_input_grad[0]
+        dx = None
+        wino_dx = need_x and ctx.kind == "wino" and wino_supported(cout, cin) and dpre.is_contiguous(memory_format=torch.channels_last)
+        if wino_dx:
+            dx = conv3x3_wino_bias_relu(dpre, pack_wino_weight(w.flip(2, 3).transpose(0, 1)), None, cin, relu=False)
+        gx, dw, db = torch.ops.aten.convolution_backward(dpre, x, w, [cout], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                        [need_x and not wino_dx, True, True])
+        return (dx if wino_dx else gx), dw, db
+
+
 def _image_pyramid(fold: BnFold, net, image: torch.Tensor) -> List[torch.Tensor]:
     """the four BasicBlocks (backbone.py:16-32; conv3x3 + BN + ReLU + conv3x3 / 2), BatchNorm folded, channels-last"""
-    x = image.contiguous(memory_format=torch.channels_last)
+    x = image
     maps = []
     for blk in net.Img_Block:
         w1, t = fold.conv4d(blk.conv1)         # (channels-last when the parameter is: train_joint.prepare_rows converts them once)
-        y = F.relu(F.conv2d(x, w1, t, stride=1, padding=1), inplace=True)
+        y = _Conv3x3BiasRelu.apply(x, w1, t)
         x = F.conv2d(y, blk.conv2.weight, blk.conv2.bias, stride=blk.conv2.stride, padding=blk.conv2.padding)
         maps.append(x)
     return maps
 
 
 def _image_fusion_map(fold: BnFold, net, maps: List[torch.Tensor]) -> torch.Tensor:
-    """relu(bn(conv1x1(cat_i deconv_i(img_i)))) (backbone.py:187-193) with the 1x1 convolution's slice composed into every level's
-    kernel == stride transposed convolution (linear o linear): the 64-channel concatenation never exists; the composition is
-    differentiable torch arithmetic on the parameters"""
-    Wf, bf = fold.conv(net.image_fusion_conv, net.image_fusion_bn)           # (q, sum reduce), (q)
-    acc, off, bias = None, 0, bf
-    for dc, m in zip(net.DeConv, maps):
-        r = dc.out_channels
-        Ws = Wf[:, off:off + r]
-        wc = torch.einsum("crhw,qr->cqhw", dc.weight, Ws)
-        bias = bias + Ws @ dc.bias
-        y = F.conv_transpose2d(m, wc, None, stride=dc.stride)
-        acc = y if acc is None else acc + y
-        off += r
-    return F.relu(acc + bias[None, :, None, None])
+    """relu(bn(conv1x1(cat_i deconv_i(img_i)))) (backbone.py:187-193), BatchNorm folded.  The training path keeps the reference's
+    un-composed form: four kernel == stride transposed convolutions, their 64-channel concatenation, one 1x1 convolution —
+    204 GFLOP per 4 frames forward + backward against 363 for the composed form the inference engine gathers from
+    (tools/joint_image_probe.py: 5.1 against 6.1 ms)"""
+    de = torch.cat([dc(m) for dc, m in zip(net.DeConv, maps)], dim=1)
+    Wf, bf = fold.conv4d(net.image_fusion_conv)
+    return F.relu(F.conv2d(de, Wf, bf), inplace=True)
 
 
 def backbone_forward_rows(engine, xyz: torch.Tensor, image: torch.Tensor, pts_xy: torch.Tensor, fold: BnFold,

@@ -200,6 +200,32 @@ def test_three_interpolate_rows_and_feature_gather_rows_vs_operators():
     assert torch.equal(got.view(B, n, 16).transpose(1, 2).contiguous(), feature_gather(fmap.detach(), xy))
 
 
+@pytest.mark.parametrize("cin,cout", [(3, 64), (64, 128), (128, 256)])
+def test_image_block_first_layer_forward_kernels_and_winograd_data_gradient(cin, cout):
+    """conv3x3 + bias + ReLU of the image blocks in the training path (train_rows._Conv3x3BiasRelu): one-pass forward kernels, data
+    gradient of the Winograd layers = the same kernel on the flipped / transposed weight — against F.conv2d + relu under autograd"""
+    from jmodt_amd.train_rows import _Conv3x3BiasRelu
+    B, H, W = 2, 24, 40
+    x = rnd(B, cin, H, W, seed=1)
+    if cin != 3:
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(cin != 3)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=0.1).contiguous(memory_format=torch.channels_last).requires_grad_()
+    b = rnd(cout, seed=3, scale=0.1).requires_grad_()
+    y = _Conv3x3BiasRelu.apply(x, w, b)
+    g = rnd(B, cout, H, W, seed=4).contiguous(memory_format=torch.channels_last)
+    y.backward(g)
+    x2 = x.detach().double().requires_grad_(cin != 3)
+    w2, b2 = w.detach().double().requires_grad_(), b.detach().double().requires_grad_()
+    ref = F.relu(F.conv2d(x2, w2, b2, padding=1))
+    ref.backward(g.double())
+    close(y, ref, what="forward")
+    close(w.grad, w2.grad, tol=2e-4, what="d weight")
+    close(b.grad, b2.grad, tol=2e-4, what="d bias")
+    if cin != 3:
+        close(x.grad, x2.grad, tol=2e-4, what="d input")
+
+
 @pytest.fixture(scope="module")
 def tiny():
     from jmodt_amd.detector import DetectorConfig
