@@ -144,27 +144,74 @@ def joint_step(engine, xyz, image, pts_xy, gt_tids, optimizer, world: Optional[i
     if route == "rows":
         if not frozen_bn(engine):
             raise RuntimeError("joint_step(route='rows') folds the BatchNorms: call train_joint.freeze_bn(engine) (or engine.eval()) first")
-        from .train_rows import joint_forward_rows
-        pyr = engine._take_prefetched(xyz)
-        if next_xyz is not None:
-            engine.prefetch(next_xyz, None)
-        out = prof.region("joint_forward(span)", lambda: joint_forward_rows(engine, xyz, image, pts_xy, rois_per_frame, pyr))
+        loss = prof.region("joint_forward+backward(span)", lambda: _rows_forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local,
+                                                                                        rois_per_frame, next_xyz))
     else:
         out = prof.region("joint_forward(span)", lambda: joint_forward(engine, xyz, image, pts_xy, rois_per_frame))
-    counts = None
-    if jdist.collective_path(world, local):      # the re-id means run over the GLOBAL element counts (as in the finetune step)
-        B = gt_tids.shape[0]
-        with torch.no_grad():
-            counts = AffinityTrainState(out["rcnn_feat"].detach().view(B, -1, out["rcnn_feat"].shape[-1]), gt_tids).counts.clone()
-        tdist.all_reduce(counts, op=tdist.ReduceOp.SUM)
-    loss = thin_loss(engine, out, gt_tids, counts)
-    prof.region("joint_backward(span)", lambda: loss.backward())
+        counts = None
+        if jdist.collective_path(world, local):      # the re-id means run over the GLOBAL element counts (as in the finetune step)
+            B = gt_tids.shape[0]
+            with torch.no_grad():
+                counts = AffinityTrainState(out["rcnn_feat"].detach().view(B, -1, out["rcnn_feat"].shape[-1]), gt_tids).counts.clone()
+            tdist.all_reduce(counts, op=tdist.ReduceOp.SUM)
+        loss = thin_loss(engine, out, gt_tids, counts)
+        prof.region("joint_backward(span)", lambda: loss.backward())
     global LAST_GRAD_COLLECTIVES
     LAST_GRAD_COLLECTIVES = prof.region("grad_allreduce(RCCL)", lambda: jdist.allreduce_gradients(params, world=world, bucket_bytes=bucket_bytes,
                                                                                                   average=False, local=local),
                                         algo_bytes=sum(p.numel() for p in params) * 4)
     optimizer.step()
     return loss.detach()
+
+
+def _rows_forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local, rois_per_frame, next_xyz):
+    """forward and backward of the rows route, issued in the order that keeps three streams busy: backbone + RPN heads forward
+    (main / image streams) -> proposals + RoI pooling (no gradient) -> the BACKWARD of the RPN part of the loss (main / image
+    streams: the loss is a sum, its parts back-propagate independently) -> RCNN forward, its loss and backward on the RCNN stream,
+    under the backbone's backward.  Same gradients as one backward over the summed loss: the two graphs share no node (the
+    pooled RoI points carry no gradient)."""
+    import torch.distributed as tdist
+    from .ops.affinity_train import AffinityTrainState, affinity_train_loss
+    from .train_rows import BnFold, pooled_rois, rcnn_branch_rows, rpn_forward_rows
+    pyr = engine._take_prefetched(xyz)
+    if next_xyz is not None:
+        engine.prefetch(next_xyz, None)
+    fold = BnFold(engine)
+    out = rpn_forward_rows(engine, xyz, image, pts_xy, fold, pyr)
+    rois, pts_input, count = pooled_rois(engine, xyz, out, rois_per_frame)
+    pooled_ev = torch.cuda.Event()
+    pooled_ev.record()                          # (the fold's tensors the RCNN reads were made before this point too)
+    n = float(out["rpn_cls"].shape[1])
+    rpn_loss = (out["rpn_cls"].sum() + out["rpn_reg"].sum()) / n
+    rpn_loss.backward()
+    rc = rcnn_branch_rows(engine, pts_input, count, fold, ready=pooled_ev)
+    side = rc.pop("_stream")
+    main = torch.cuda.current_stream(xyz.device)
+    B = gt_tids.shape[0]
+    with torch.cuda.stream(side):
+        feats = rc["rcnn_feat"].view(B, -1, rc["rcnn_feat"].shape[-1])
+        st = AffinityTrainState(feats, gt_tids)
+        counts = None
+        if jdist.collective_path(world, local):      # the re-id means run over the GLOBAL element counts (as in the finetune step)
+            counts = st.counts.clone()
+            tdist.all_reduce(counts, op=tdist.ReduceOp.SUM)
+        reid = affinity_train_loss(st, engine.rcnn_net.link_layer, engine.rcnn_net.se_layer, counts=counts)
+        rcnn_loss = rc["rcnn_cls"].sum() + rc["rcnn_reg"].sum() + reid
+        rcnn_loss.backward()
+        total = rcnn_loss.detach() + rpn_loss.detach()
+    if side is not main:
+        gt_tids.record_stream(side)
+        main.wait_stream(side)               # every gradient is in place before the all-reduce / optimizer on the main stream
+        total.record_stream(main)
+    img = _image_stream(engine, xyz.device)
+    if img is not None:
+        main.wait_stream(img)
+    return total
+
+
+def _image_stream(engine, device):
+    from .ops.pointnet2.pyramid import side_stream
+    return side_stream(device, 1) if engine.overlap else None
 
 
 LAST_GRAD_COLLECTIVES = 0

@@ -240,26 +240,37 @@ def backbone_forward_rows(engine, xyz: torch.Tensor, image: torch.Tensor, pts_xy
     own = pyr is None
     if own:
         pyr = FpsPyramid(xyz, list(cfg.sa_npoints), overlap=engine.overlap, with_interp=True, grid_radii=engine._grid_radii())
-    # stream I: the image pyramid and the fused image map (MIOpen), forward here and — autograd runs a node's backward on the stream
-    # of its forward — BACKWARD there too: the convolutions' large kernels run next to the point branch's many small launches
+    # stream I: the image pyramid and the fused image map (MIOpen + the one-pass first layers), forward here and — autograd runs a
+    # node's backward on the stream of its forward — BACKWARD there too: the convolutions' large kernels run next to the point
+    # branch's many small launches.  ORDER of issue matters twice.  Forward: block i is issued one level ahead of its consumer (the
+    # LI-Fusion gather of level i), so the convolutions run under set abstraction i.  Backward: the autograd engine hands out READY
+    # nodes latest-created first, so a branch created at the very start of the forward (round-5 first form: the whole pyramid and
+    # the fusion map up front) is launched only after every point-branch node — 10 ms of convolution backward alone at the end of
+    # the step (tools/joint_timeline.sh).  Created where they are consumed, block i's backward is handed out right after level i's
+    # set abstraction backward and runs under levels i-1 .. 1; the fusion map's right after the final attention block's.
     main = torch.cuda.current_stream(xyz.device)
     img_stream = side_stream(xyz.device, 1) if engine.overlap else main
-    img_stream.wait_stream(main)
-    with torch.cuda.stream(img_stream):
-        maps = prof.region("image_pyramid(MIOpen)", lambda: _image_pyramid(fold, net, image))
-        map_events = []
-        for m in maps:
+    maps, map_events = [], []
+
+    def image_block(i):
+        img_stream.wait_stream(main) if i == 0 else None
+        with torch.cuda.stream(img_stream):
+            blk = net.Img_Block[i]
+            w1, t = fold.conv4d(blk.conv1)         # (channels-last when the parameter is: train_joint.prepare_rows converts them once)
+            y = _Conv3x3BiasRelu.apply(image if i == 0 else maps[i - 1], w1, t)
+            m = F.conv2d(y, blk.conv2.weight, blk.conv2.bias, stride=blk.conv2.stride, padding=blk.conv2.padding)
             ev = torch.cuda.Event()
             ev.record(img_stream)
-            map_events.append(ev)
-        fused_img = prof.region("image_deconv+fusion_conv(MIOpen)", lambda: _image_fusion_map(fold, net, maps))
-        fused_ev = torch.cuda.Event()
-        fused_ev.record(img_stream)
+        if img_stream is not main:
+            m.record_stream(main)
+        maps.append(m)
+        map_events.append(ev)
+
     if img_stream is not main:
-        for t in list(maps) + [fused_img, image]:
-            t.record_stream(main if t is not image else img_stream)
+        image.record_stream(img_stream)
     l_xyz, l_feats, l_xy = [xyz], [None], [pts_xy]
     for i, sa in enumerate(net.SA_modules):
+        prof.region(f"image_block_{i + 1}(MIOpen)", lambda k=i: image_block(k))
         idx, new_xyz = pyr.level(i)
         with prof.scope(f"rpn_sa{i + 1}"):
             feats = _sa_level_rows(fold, sa, l_xyz[i], l_feats[i], new_xyz, grid=pyr.grid(i))
@@ -268,6 +279,13 @@ def backbone_forward_rows(engine, xyz: torch.Tensor, image: torch.Tensor, pts_xy
         with prof.scope(f"li_fusion{i + 1}"):
             feats = _attention_rows(fold, net.Fusion_Conv[i], feats, R.feature_gather_rows(maps[i], xy_i))
         l_xyz.append(new_xyz); l_feats.append(feats); l_xy.append(xy_i)
+    # the fused image map: issued here (under the feature-propagation modules), consumed by the final attention block
+    with torch.cuda.stream(img_stream):
+        fused_img = prof.region("image_deconv+fusion_conv(MIOpen)", lambda: _image_fusion_map(fold, net, maps))
+        fused_ev = torch.cuda.Event()
+        fused_ev.record(img_stream)
+    if img_stream is not main:
+        fused_img.record_stream(main)
     nfp = len(net.FP_modules)
     for i in range(-1, -(nfp + 1), -1):
         with prof.scope(f"fp{nfp + 1 + i}"):
@@ -324,39 +342,74 @@ def rcnn_forward_rows(engine, pts_input: torch.Tensor, fold: BnFold, count: Opti
                 rcnn_feat=feats)
 
 
-def joint_forward_rows(engine, xyz, image, pts_xy, rois_per_frame: int = 64, pyr: Optional[FpsPyramid] = None) -> Dict[str, torch.Tensor]:
-    """the detector in TRAIN composition (point_rcnn.py:24-70) on rows; same outputs as train_joint.joint_forward"""
-    rpn, cfg = engine.rpn, engine.cfg
+def rpn_forward_rows(engine, xyz, image, pts_xy, fold: BnFold, pyr: Optional[FpsPyramid] = None) -> Dict[str, torch.Tensor]:
+    """backbone + RPN heads on rows (rpn.py:71-87): rpn_cls (B, N, 1), rpn_reg (B, N, C), backbone_features (B, C, N) view, and the
+    (B N, C) feature rows themselves"""
+    rpn = engine.rpn
     B, N, _ = xyz.shape
-    fold = BnFold(engine)
     feats = backbone_forward_rows(engine, xyz, image, pts_xy, fold, pyr)                 # (B N, C)
     ncls = rpn.rpn_cls_layer[-1].conv.out_channels
     nreg = rpn.rpn_reg_layer[-1].conv.out_channels
     rpn_cls = _head_rows(fold, rpn.rpn_cls_layer, feats)[:, :ncls].reshape(B, N, ncls)
     rpn_reg = _head_rows(fold, rpn.rpn_reg_layer, feats)[:, :nreg].reshape(B, N, nreg)
     C = feats.shape[1]
-    with torch.no_grad():
-        det = dict(rpn_cls=rpn_cls.detach().contiguous(), rpn_reg=rpn_reg.detach().contiguous(), backbone_xyz=xyz)
-        rois, _ = engine.proposals(det)
-        rois = rois[:, :rois_per_frame].contiguous()
-        pf = torch.empty((B, N, 2 + C), dtype=torch.float32, device=xyz.device)           # point_rcnn.py:42-44, proposal_target_layer.py:26
-        pf[:, :, 0] = (torch.sigmoid(det["rpn_cls"][:, :, 0]) > cfg.rpn_score_thresh).float()
-        pf[:, :, 1] = torch.norm(xyz, p=2, dim=2) / 70.0 - 0.5
-        pf[:, :, 2:] = feats.detach().view(B, N, C)                                       # rows ARE the (B, N, C) layout roipool reads
-        pooled, _, count = roipool3d_canonical_gpu(xyz, pf, rois, cfg.pool_extra_width, cfg.rcnn_num_points, return_count=True)
-        pts_input = pooled.view(-1, cfg.rcnn_num_points, pooled.shape[-1])
-    # stream R: the RCNN (rcnn.py:158-202).  Its BACKWARD then runs there too (autograd: a node's backward on its forward's
-    # stream), next to the backbone's backward on the main stream — neither feeds the other: roipool3d has no gradient
-    main = torch.cuda.current_stream(xyz.device)
-    side = side_stream(xyz.device, 3) if engine.overlap else main
-    side.wait_stream(main)
+    return dict(rpn_cls=rpn_cls, rpn_reg=rpn_reg, backbone_features=feats.view(B, N, C).transpose(1, 2), feature_rows=feats)
+
+
+@torch.no_grad()
+def pooled_rois(engine, xyz, rpn_out: Dict[str, torch.Tensor], rois_per_frame: int):
+    """ProposalLayer + roipool3d WITHOUT gradient (the reference's are not differentiable either): rois (B, K, 7), pooled points
+    (B K, S, 5 + C), distinct points per RoI (B K) — the first `rois_per_frame` proposals of every frame stand in for
+    ProposalTargetLayer's sampled RoIs (config.py:153)"""
+    cfg = engine.cfg
+    B, N, _ = xyz.shape
+    feats = rpn_out["feature_rows"].detach()
+    C = feats.shape[1]
+    det = dict(rpn_cls=rpn_out["rpn_cls"].detach().contiguous(), rpn_reg=rpn_out["rpn_reg"].detach().contiguous(), backbone_xyz=xyz)
+    rois, _ = engine.proposals(det)
+    rois = rois[:, :rois_per_frame].contiguous()
+    pf = torch.empty((B, N, 2 + C), dtype=torch.float32, device=xyz.device)           # point_rcnn.py:42-44, proposal_target_layer.py:26
+    pf[:, :, 0] = (torch.sigmoid(det["rpn_cls"][:, :, 0]) > cfg.rpn_score_thresh).float()
+    pf[:, :, 1] = torch.norm(xyz, p=2, dim=2) / 70.0 - 0.5
+    pf[:, :, 2:] = feats.view(B, N, C)                                                # rows ARE the (B, N, C) layout roipool reads
+    pooled, _, count = roipool3d_canonical_gpu(xyz, pf, rois, cfg.pool_extra_width, cfg.rcnn_num_points, return_count=True)
+    return rois, pooled.view(-1, cfg.rcnn_num_points, pooled.shape[-1]), count.view(-1)
+
+
+def rcnn_branch_rows(engine, pts_input, count, fold: BnFold, ready: Optional[torch.cuda.Event] = None) -> Dict[str, torch.Tensor]:
+    """stream R: the RCNN (rcnn.py:158-202).  Its BACKWARD then runs there too (autograd: a node's backward on its forward's
+    stream), next to the backbone's backward on the main stream — neither feeds the other: roipool3d has no gradient.  The
+    caller's stream waits for the outputs (main.wait_stream) before it reads them."""
+    dev = pts_input.device
+    main = torch.cuda.current_stream(dev)
+    side = side_stream(dev, 3) if engine.overlap else main
+    # `ready`: an event recorded on the main stream behind the RoI pooling — the branch must not wait for what the caller has
+    # queued on the main stream SINCE (the backbone's whole backward)
+    if ready is not None and side is not main:
+        side.wait_event(ready)
+    else:
+        side.wait_stream(main)
     with torch.cuda.stream(side):
-        out = rcnn_forward_rows(engine, pts_input, fold, count.view(-1))
+        out = rcnn_forward_rows(engine, pts_input, fold, count)
     if side is not main:
-        main.wait_stream(side)
-        for t in out.values():
-            t.record_stream(main)
         pts_input.record_stream(side)
         count.record_stream(side)
-    out.update(rpn_cls=rpn_cls, rpn_reg=rpn_reg, backbone_features=feats.view(B, N, C).transpose(1, 2), rois=rois)
+    out["_stream"] = side
+    return out
+
+
+def joint_forward_rows(engine, xyz, image, pts_xy, rois_per_frame: int = 64, pyr: Optional[FpsPyramid] = None) -> Dict[str, torch.Tensor]:
+    """the detector in TRAIN composition (point_rcnn.py:24-70) on rows; same outputs as train_joint.joint_forward"""
+    fold = BnFold(engine)
+    out = rpn_forward_rows(engine, xyz, image, pts_xy, fold, pyr)
+    rois, pts_input, count = pooled_rois(engine, xyz, out, rois_per_frame)
+    rc = rcnn_branch_rows(engine, pts_input, count, fold)
+    side = rc.pop("_stream")
+    main = torch.cuda.current_stream(xyz.device)
+    if side is not main:
+        main.wait_stream(side)
+        for t in rc.values():
+            t.record_stream(main)
+    out.update(rc, rois=rois)
+    out.pop("feature_rows")
     return out

@@ -217,9 +217,11 @@ def test_image_block_first_layer_forward_kernels_and_winograd_data_gradient(cin,
     y.backward(g)
     x2 = x.detach().double().requires_grad_(cin != 3)
     w2, b2 = w.detach().double().requires_grad_(), b.detach().double().requires_grad_()
-    ref = F.relu(F.conv2d(x2, w2, b2, padding=1))
-    ref.backward(g.double())
-    close(y, ref, what="forward")
+    pre = F.conv2d(x2, w2, b2, padding=1)
+    close(y, F.relu(pre), what="forward")
+    # the backward against float64 THROUGH THE SAME ReLU mask: an output whose pre-activation is within rounding of zero may sit on
+    # the other side of the kink in float64, and one such element moves a weight gradient entry by |g x| ~ O(1)
+    (pre * (y.detach() > 0).double()).backward(g.double())
     close(w.grad, w2.grad, tol=2e-4, what="d weight")
     close(b.grad, b2.grad, tol=2e-4, what="d bias")
     if cin != 3:
