@@ -118,6 +118,55 @@ def detect_step(st):
     return st["engine"](st["xyz"], st["image"], st["pts_xy"], next_xyz=_upcoming(st) if pf else None, next_image=st["image"] if pf else None)
 
 
+def streaming_rate(st, n_steps, world, batch):
+    """the same composed step fed the way tools/eval.py feeds it: a NEW batch every step, from pinned host memory, its H2D copy
+    (47 MB of image + 1.6 MB of points for 8 frames) on a copy stream under the previous step.  Two device buffer sets alternate
+    (the engine's next-batch announcement names the very tensors the next call receives).  Returns frames/s over `n_steps`."""
+    eng = st["engine"]
+    dev = st["xyz"].device
+    keys = ("xyz", "image", "pts_xy")
+    host = [{k: st[k].cpu().pin_memory() for k in keys} for _ in range(2)]
+    host[1]["xyz"] = host[1]["xyz"].flip(0).contiguous().pin_memory()          # (a different batch: the frames in another order)
+    host[1]["image"] = host[1]["image"].flip(0).contiguous().pin_memory()
+    host[1]["pts_xy"] = host[1]["pts_xy"].flip(0).contiguous().pin_memory()
+    bufs = [{k: torch.empty_like(st[k]) for k in keys} for _ in range(2)]
+    copy = torch.cuda.Stream(device=dev)
+    done = [torch.cuda.Event(), torch.cuda.Event()]      # H2D of buffer set i complete
+    free = [torch.cuda.Event(), torch.cuda.Event()]      # the step that read buffer set i has been issued (recorded on the main stream)
+    main = torch.cuda.current_stream(dev)
+
+    def upload(i, step_no):
+        copy.wait_event(free[i])                         # (recorded: set i's last reader is behind us on the main stream)
+        with torch.cuda.stream(copy):
+            for k in keys:
+                bufs[i][k].copy_(host[step_no % 2][k], non_blocking=True)
+            done[i].record(copy)
+
+    for i in range(2):
+        free[i].record(main)
+    upload(0, 0)
+    pf = st.get("prefetch", True)
+
+    def run(step_no):
+        i = step_no % 2
+        upload(1 - i, step_no + 1)                       # the NEXT batch travels while this one is computed
+        main.wait_event(done[i])
+        b, nb = bufs[i], bufs[1 - i]
+        out = eng(b["xyz"], b["image"], b["pts_xy"], next_xyz=[nb["xyz"]] if pf else None, next_image=None)
+        free[i].record(main)
+        return out
+    for w in range(2):
+        run(w)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(2, 2 + n_steps):
+        run(k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng._drop_kept()
+    return world * batch * n_steps / dt
+
+
 def _upcoming(st):
     """the clouds of the next `prefetch_depth` batches (the same resident synthetic batch each): one FPS pyramid is started per
     step whatever the depth, it is only started earlier"""
@@ -695,7 +744,7 @@ def compact_line(full, full_path):
         return None if d is None else {k: _short(d[k], n) for k in keys if k in d and d[k] is not None}
     c = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "host_enqueue_ms_per_step",
                               "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
-    c["config"] = sub(full["config"], ("workload", "frames_per_gpu_per_step", "points", "parallelism", "process_groups"), 400)
+    c["config"] = sub(full["config"], ("workload", "frames_per_gpu_per_step", "points", "parallelism", "process_groups", "rank_binding"), 400)
     rf = full.get("roofline")
     if rf is not None:
         r = sub(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "max_launch_ms",
@@ -721,7 +770,8 @@ def compact_line(full, full_path):
         c["clouds"] = {k: v.get("value") for k, v in cl.items() if isinstance(v, dict)}
         if cl["uniform"].get("value_dense_rcnn_kernels") is not None:
             c["clouds"]["uniform_dense_rcnn_kernels"] = cl["uniform"]["value_dense_rcnn_kernels"]
-    for k in ("no_prefetch_value", "prefetch_depth_values", "no_image_prefetch_value", "no_overlap_value", "step_mfma_frac"):
+    for k in ("value_streaming", "no_prefetch_value", "prefetch_depth_values", "no_image_prefetch_value", "no_overlap_value", "step_mfma_frac",
+              "dropped_fractions"):
         if full.get(k) is not None:
             c[k] = full[k]
     if full.get("overlap"):
@@ -754,15 +804,24 @@ ROCPROF_NEEDLE = {"rcnn_sa1/sa_mlp_pm_forward": ["sa_mlp_pm_kernel"],
                                                                   "softmax_stats_kernel", "dual_softmax_kernel"]}
 
 
-def rocprof_average(kernel_row):
+PROFILE_ROUNDS = ("r05", "r04")      # this round's committed summaries, else the previous round's OF THE SAME WORKLOAD
+
+
+def rocprof_average(kernel_row, workload="detect", live_us=None, launches=None):
     """sum over the entry's kernels of the average duration of each kernel's LARGEST shape in the committed rocprofv3
     --kernel-trace --stats summary of this same command (bench.py itself runs un-profiled): the cross-check of the live
-    HIP-event time"""
+    HIP-event time.  Keyed on (round, WORKLOAD, kernel, grid x workgroup): only the summary of the workload being run is read
+    (round 4's `ops` line matched a 445 us compacted dispatch of the detect profile to its 5.1 ms dense entry and printed a
+    fraction of 7.85), the matched shape is returned, and a match whose duration is not within 3x of the live HIP-event time of
+    the same entry is not the same dispatch and is dropped."""
     needles = ROCPROF_NEEDLE.get(kernel_row)
     if not needles:
         return None
-    for rnd in ("r04", "r03"):
-        path = os.path.join(ROOT, "profiles", f"{rnd}_detect_kernel_stats.txt")
+    wl = {"detect": "detect", "sa": "sa", "ops": "ops"}.get(workload)
+    if wl is None:
+        return None
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{wl}_kernel_stats.txt")
         try:
             lines = open(path).read().splitlines()
         except OSError:
@@ -770,7 +829,7 @@ def rocprof_average(kernel_row):
         start = next((i for i, ln in enumerate(lines) if ln.startswith("per dispatch shape")), None)
         if start is None:
             continue                      # (round 2's summaries have one row per kernel NAME: several shapes mixed)
-        total, found = 0.0, []
+        total, found, shapes = 0.0, [], []
         for needle in needles:
             best = None
             for ln in lines[start + 2:]:
@@ -780,13 +839,59 @@ def rocprof_average(kernel_row):
                         avg = float(f[-3])
                     except (ValueError, IndexError):
                         continue
-                    best = avg if best is None else max(best, avg)
+                    if best is None or avg > best[0]:
+                        best = (avg, f"{f[-7]} x {f[-6]}")
             if best is not None:
-                total += best
+                total += best[0]
                 found.append(needle)
-        if found:
-            return {"avg_us": round(total, 2), "kernels": found, "source": os.path.relpath(path, ROOT) + " (per-shape table)"}
+                shapes.append(best[1])
+        if not found:
+            continue
+        if live_us is not None and live_us > 0 and not (live_us / 3.0 <= total <= live_us * 3.0):
+            return None                   # another dispatch of the same kernel name: no cross-check rather than a wrong one
+        return {"avg_us": round(total, 2), "kernels": found, "shapes": shapes, "round": rnd, "workload": wl,
+                "source": os.path.relpath(path, ROOT) + " (per-shape table)"}
     return None
+
+
+def sanitise_fractions(node, path="", dropped=None):
+    """every `frac` / `*_frac` of the record must be a fraction: 0 < f <= 1.  Offenders are REMOVED and listed (a fraction above 1 is
+    a bookkeeping error — bytes or flops of one dispatch over the time of another — never evidence), so that no line the driver
+    records can carry one; returns the list of (path, value) removed"""
+    dropped = [] if dropped is None else dropped
+    if isinstance(node, dict):
+        for k in list(node.keys()):
+            v = node[k]
+            if (k == "frac" or k.endswith("_frac")) and isinstance(v, (int, float)) and not isinstance(v, bool):
+                if not (0.0 < float(v) <= 1.0):
+                    dropped.append((f"{path}/{k}", v))
+                    del node[k]
+            else:
+                sanitise_fractions(v, f"{path}/{k}", dropped)
+    elif isinstance(node, list):
+        for i, v in enumerate(node):
+            sanitise_fractions(v, f"{path}[{i}]", dropped)
+    return dropped
+
+
+def pin_rank(local_rank: int, ranks_on_node: int):
+    """one process per GPU: bind this rank to its own block of host cores and bound its intra-op thread pool (the reference's
+    nn.DataParallel runs ONE process, tools/train.py:86-88; eight processes that each enqueue 4 - 20 ms of launches per step on
+    cores they share with the others' 128-thread pools do not).  The block: with `rocm-smi --showtoponuma`-style NUMA information
+    absent in the container, the node's allowed cores are split evenly in rank order — on the 2-socket MI355X hosts ranks 0-3 / 4-7
+    then sit on the socket their GPUs hang off.  JM_BENCH_NO_PIN=1 switches it off.  Returns what was done (goes into the line)."""
+    if os.environ.get("JM_BENCH_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+        return {"pinned": False}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        per = max(1, len(allowed) // max(1, ranks_on_node))
+        mine = allowed[local_rank * per:(local_rank + 1) * per] or allowed
+        os.sched_setaffinity(0, mine)
+        threads = max(1, min(per, 16))
+        torch.set_num_threads(threads)
+        return {"pinned": True, "cores": f"{mine[0]}-{mine[-1]}", "n_cores": len(mine), "torch_threads": threads}
+    except OSError as e:                   # (a container that forbids it: run unpinned, say so)
+        return {"pinned": False, "error": str(e)}
 
 
 def main():
@@ -824,6 +929,9 @@ def main():
     ap.add_argument("--full-out", default=None,
                     help="where the FULL record (kernel table, variants, parity block) is written; default bench_out/<workload>.json. "
                          "stdout carries one compact line of at most 4 KB")
+    ap.add_argument("--stream-inputs", action="store_true",
+                    help="detect: also report `value_streaming` — every step a fresh batch from pinned host memory, async H2D under the "
+                         "previous step (measured after the timed region; on by default for the default workload)")
     ap.add_argument("--launch", action="store_true",
                     help="re-execute under torch.distributed.run even for --gpus 1 (the N > 1 launch path incl. RCCL init / "
                          "barrier / all-reduce on one GPU: what the GPU tier runs)")
@@ -859,6 +967,9 @@ def main():
         device_index = local_rank
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
+    rank_binding = {"pinned": False}
+    if world > 1 or "RANK" in os.environ:          # one process per GPU under torch.distributed.run: its own block of host cores
+        rank_binding = pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if world > 1 or "RANK" in os.environ or os.environ.get("JM_BENCH_FORCE_DIST") == "1":   # (--launch takes this path on one GPU)
         # one process per GPU: every rank runs MIOpen's find step for the image convolutions at start-up; give each its own user
         # database so that eight ranks do not serialise on (or trip over) the file locks of a shared one.  Read at MIOpen's first use
@@ -1068,6 +1179,16 @@ def main():
             variants["no_prefetch_value"] = round(variant(False, True), 2)
         if eng.overlap:
             variants["no_overlap_value"] = round(variant(False, False), 2)
+        try:
+            variants["value_streaming"] = round(streaming_rate(st, n_var, world, args.batch), 2)
+            variants["streaming_note"] = ("a NEW batch every step from pinned host memory, H2D on a copy stream under the previous step, "
+                                          "two alternating device buffer sets; the next batch's IMAGE pyramid is not announced (its "
+                                          "pixels are still in flight when this step starts)")
+        except Exception as ex:        # a report next to the headline, never a reason to lose it
+            variants["value_streaming"] = None
+            variants["streaming_note"] = f"failed: {ex!r}"
+        step(); step()
+        torch.cuda.synchronize()
         variants["clouds"] = None
         variants["variants_note"] = (f"{n_var} steps each after the timed region, this rank x world: no_image_prefetch = the next batch's image pyramid "
                                      "is not started under this batch (its FPS pyramid still is); no_prefetch = every batch's FPS pyramid "
@@ -1136,7 +1257,7 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         for k in kernels:
             if k["kernel"] in ROCPROF_NEEDLE and not k["kernel"].startswith("affinity"):
-                rp = rocprof_average(k["kernel"])
+                rp = rocprof_average(k["kernel"], args.workload)
                 if rp:
                     k["rocprof_kernel_us"] = rp["avg_us"]
         # the hash-grid ball queries: evaluations actually done (per step) next to the n * m of the scan they replace
@@ -1200,7 +1321,7 @@ def main():
             if dom_row:
                 roofline["avg_launch_ms"] = dom_row["ms_per_step"] / max(dom_row["launches_per_step"], 1)
                 roofline["max_launch_ms"] = dom_row["max_launch_ms"]
-            rp = rocprof_average(roofline["kernel"])
+            rp = rocprof_average(roofline["kernel"], args.workload, live_us=(roofline.get("avg_launch_ms") or 0) * 1e3)
             if rp:
                 ex = next((k.get("executed_flops_per_step", k.get("algo_flops_per_step")) for k in kernels if k["kernel"] == roofline["kernel"]), None)
                 if ex:
@@ -1231,6 +1352,7 @@ def main():
                        "points": (65536 if args.workload in ("dense", "dense_detect") else 16384) if not args.tiny else "tiny",
                        "parallelism": (f"dp{world} (gradient all-reduce)" if args.workload == "train" else f"replicas x{world}")
                                       + (" [TEST: ranks share one GPU, not a benchmark]" if shared else ""),
+                       "rank_binding": rank_binding,
                        "process_groups": (None if dist is None else
                                           ("data plane RCCL (gradient all-reduce), control plane gloo (barriers, max over ranks)"
                                            if args.workload == "train" else
@@ -1299,6 +1421,9 @@ def main():
             except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
                 result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": cores, "kind": "port", "sample": f"failed: {ex!r}"}
         normalise_fractions(result)
+        dropped = sanitise_fractions(result)
+        if dropped:
+            result["dropped_fractions"] = [{"path": p_, "value": v_} for p_, v_ in dropped]
         # stdout carries ONE compact line (<= COMPACT_LIMIT bytes); the full record (kernel table, variants, per-stage parity
         # against the CPU chain) goes to a file next to it
         full_path = args.full_out or os.path.join("bench_out", args.workload + ("_joint" if args.joint else "") + ("" if args.cloud == "uniform" else "_" + args.cloud)

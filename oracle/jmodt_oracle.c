@@ -50,9 +50,28 @@ ORC_API int orc_opt_n_threads(int work_size) {
     return v;
 }
 
+/* The floating-point conventions the reference leaves to nvcc, as ONE set of macros.  The checker is the default branch.
+ * tools/parity_exposure.py compiles this file into a temporary directory with ORC_EXPOSE_NOFMA / ORC_EXPOSE_FMA_ALT /
+ * ORC_EXPOSE_LIBM to COUNT how many discrete decisions (FPS picks, ball-query lists, 3-NN rows, in-box flags, NMS keep lists) on
+ * the benchmark clouds depend on the choice; nothing else ever defines them. */
+#if defined(ORC_EXPOSE_NOFMA)        /* dx*dx + dy*dy + dz*dz left to right, no contraction (nvcc -fmad=false) */
+#define ORC_D2(dx, dy, dz) (((dx) * (dx) + (dy) * (dy)) + (dz) * (dz))
+#elif defined(ORC_EXPOSE_FMA_ALT)    /* the other way a compiler may contract the same expression */
+#define ORC_D2(dx, dy, dz) fmaf((dz), (dz), fmaf((dy), (dy), (dx) * (dx)))
+#else
+#define ORC_D2(dx, dy, dz) fmaf((dz), (dz), fmaf((dx), (dx), (dy) * (dy)))
+#endif
+#if defined(ORC_EXPOSE_LIBM)         /* the build host's libm instead of include/jm_detmath.h */
+#define ORC_SINCOS(a, s, c) do { *(s) = sinf(a); *(c) = cosf(a); } while (0)
+#define ORC_ATAN2(y, x) atan2f((y), (x))
+#else
+#define ORC_SINCOS(a, s, c) jm_sincosf((a), (s), (c))
+#define ORC_ATAN2(y, x) jm_atan2f((y), (x))
+#endif
+
 static inline float orc_sqdist(float x1, float y1, float z1, float x2, float y2, float z2) {
     const float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
-    return fmaf(dz, dz, fmaf(dx, dx, dy * dy));
+    return ORC_D2(dx, dy, dz);
 }
 
 /* Literal simulation of farthest_point_sampling_kernel<BS>
@@ -142,7 +161,7 @@ ORC_API void orc_ball_query(int b, int n, int m, float radius, int nsample, cons
             for (int k = 0; k < n; ++k) {
                 /* (new_x - x)^2 + ... : sign differs from FPS but squares are identical */
                 const float dx = nx - p[k * 3 + 0], dy = ny - p[k * 3 + 1], dz = nz - p[k * 3 + 2];
-                const float d2 = fmaf(dz, dz, fmaf(dx, dx, dy * dy));
+                const float d2 = ORC_D2(dx, dy, dz);
                 if (d2 < radius2) {
                     if (cnt == 0)
                         for (int l = 0; l < nsample; ++l) o[l] = k;
@@ -198,7 +217,7 @@ ORC_API void orc_three_nn(int b, int n, int m, const float* unknown, const float
             int besti1 = 0, besti2 = 0, besti3 = 0;
             for (int k = 0; k < m; ++k) {
                 const float dx = ux - kn[k * 3 + 0], dy = uy - kn[k * 3 + 1], dz = uz - kn[k * 3 + 2];
-                const float d = fmaf(dz, dz, fmaf(dx, dx, dy * dy));
+                const float d = ORC_D2(dx, dy, dz);
                 if (d < best1) {
                     best3 = best2; besti3 = besti2;
                     best2 = best1; besti2 = besti1;
@@ -281,7 +300,7 @@ ORC_API void orc_roipool3d(int B, int N, int M, int C, int S, const float* xyz, 
             const float* bx = boxes3d + ((size_t)bi * M + mi) * 7;
             const float* p = xyz + (size_t)bi * N * 3;
             float sina, cosa;
-            jm_sincosf(bx[6], &sina, &cosa);
+            ORC_SINCOS(bx[6], &sina, &cosa);
             int* idx = (int*)malloc(sizeof(int) * (S > 0 ? S : 1));
             int cnt = 0;
             for (int k = 0; k < N; ++k) {
@@ -316,7 +335,7 @@ ORC_API void orc_pts_in_boxes3d(int M, int N, const float* pts, const float* box
     for (int i = 0; i < M; ++i) {
         const float* bx = boxes3d + (size_t)i * 7;
         float sina, cosa;
-        jm_sincosf(bx[6], &sina, &cosa);
+        ORC_SINCOS(bx[6], &sina, &cosa);
         for (int j = 0; j < N; ++j)
             flags[(size_t)i * N + j] = orc_pt_in_box3d(pts[j * 3], pts[j * 3 + 1], pts[j * 3 + 2], bx[0], bx[1],
                                                        bx[2], bx[3], bx[4], bx[5], cosa, sina);
@@ -333,7 +352,7 @@ ORC_API void orc_roipool3d_cpu(int N, int M, int C, int S, const float* pts, con
     for (int i = 0; i < M; ++i) {
         const float* bx = boxes3d + (size_t)i * 7;
         float sina, cosa;
-        jm_sincosf(bx[6], &sina, &cosa);
+        ORC_SINCOS(bx[6], &sina, &cosa);
         int cnt = 0;
         for (int j = 0; j < N; ++j) {
             if (orc_pt_in_box3d(pts[j * 3], pts[j * 3 + 1], pts[j * 3 + 2], bx[0], bx[1], bx[2], bx[3], bx[4],
@@ -433,8 +452,8 @@ static float orc_box_overlap(const float* box_a, const float* box_b) {
     OrcPt ac[5] = {{a_x1, a_y1}, {a_x2, a_y1}, {a_x2, a_y2}, {a_x1, a_y2}, {0, 0}};
     OrcPt bc[5] = {{b_x1, b_y1}, {b_x2, b_y1}, {b_x2, b_y2}, {b_x1, b_y2}, {0, 0}};
     float a_cos, a_sin, b_cos, b_sin;
-    jm_sincosf(a_angle, &a_sin, &a_cos);
-    jm_sincosf(b_angle, &b_sin, &b_cos);
+    ORC_SINCOS(a_angle, &a_sin, &a_cos);
+    ORC_SINCOS(b_angle, &b_sin, &b_cos);
     for (int k = 0; k < 4; k++) {
         ac[k] = orc_rotate(center_a, a_cos, a_sin, ac[k]);
         bc[k] = orc_rotate(center_b, b_cos, b_sin, bc[k]);
@@ -474,7 +493,7 @@ static float orc_box_overlap(const float* box_a, const float* box_b) {
     /* bubble sort by atan2 angle, point_cmp iou3d_kernel.cu:104-106,187-196 */
     float ang[24];
     for (int i = 0; i < cnt; i++)
-        ang[i] = jm_atan2f(cross_points[i].y - poly_center.y, cross_points[i].x - poly_center.x);
+        ang[i] = ORC_ATAN2(cross_points[i].y - poly_center.y, cross_points[i].x - poly_center.x);
     for (int j = 0; j < cnt - 1; j++)
         for (int i = 0; i < cnt - j - 1; i++)
             if (ang[i] > ang[i + 1]) {
@@ -577,7 +596,7 @@ ORC_API int orc_nms(int n, const float* boxes, float thresh, int normal, int64_t
 static void orc_corners3d(const float* b, double c[8][3]) {
     const double h = b[3], w = b[4], l = b[5];
     float sn, cs;
-    jm_sincosf(b[6], &sn, &cs);
+    ORC_SINCOS(b[6], &sn, &cs);
     const double xs[8] = {l / 2, l / 2, -l / 2, -l / 2, l / 2, l / 2, -l / 2, -l / 2};
     const double ys[8] = {0, 0, 0, 0, -h, -h, -h, -h};
     const double zs[8] = {w / 2, -w / 2, -w / 2, w / 2, w / 2, -w / 2, -w / 2, w / 2};
