@@ -865,7 +865,7 @@ extern "C" int jm_affinity_train_prepare(int npairs, int r, int c, const float* 
     JM_REQUIRE(npairs >= 0 && r >= 1 && r <= 256 && c >= 1, "affinity_train_prepare: bad sizes (pairs=%d R=%d C=%d; R <= 256)", npairs, r, c);
     hipStream_t s = (hipStream_t)stream;
     JM_REQUIRE(counts, "affinity_train_prepare: null counts");
-    (void)hipMemsetAsync(counts, 0, 3 * sizeof(float), s);
+    (void)jm_zero_async(counts, 3 * sizeof(float), s);
     if (npairs == 0) return JM_OK;
     JM_REQUIRE(feats && tids && pooled_prev && pooled_next && rep_ws && rep_prev && rep_next && n_pair && gt_starts && gt_ends,
                "affinity_train_prepare: null pointer");

@@ -266,7 +266,7 @@ static int bg_query(int b, int n, int m, float cell_radius, int nr, const float*
                     int* const* idx, void* ws, hipStream_t s) {
     const float h = cell_radius * 1.01f;
     const BgWs w = bg_carve(b, n, ws);
-    (void)hipMemsetAsync(w.evals, 0, 32 * sizeof(unsigned long long), s);
+    (void)jm_zero_async(w.evals, 32 * sizeof(unsigned long long), s);
     BgParams p{};
     p.n = n; p.m = m; p.b = b; p.inv_h = 1.f / h; p.T = bg_table_size(n);
     p.evals = w.evals;

@@ -590,7 +590,7 @@ static int fps_impl(int b, int n, int m, const float* xyz, float* temp, int* idx
                 hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(bs), 0, s, n, m, bs_log2, xyz, temp, idx);
                 return check_launch("fps(stream)");
             }
-            (void)hipMemsetAsync(ws, 0, need, s);
+            (void)jm_zero_async(ws, need, s);
             for (int c0 = 0; c0 < b; c0 += per_launch) {
                 const int nc = b - c0 < per_launch ? b - c0 : per_launch;
                 const int grid = 8 * ((nc + 7) / 8) * G;

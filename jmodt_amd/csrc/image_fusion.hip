@@ -261,7 +261,7 @@ extern "C" int jm_image_fusion_gather(int b, int n, int h, int w, int q, int num
     p.hist = wsp.hist; p.cursor = wsp.cursor; p.bstart = wsp.bstart; p.tstart = wsp.tstart;
     p.bias = bias32; p.xy = xy; p.out = out;
     hipStream_t s = (hipStream_t)stream;
-    (void)hipMemsetAsync(p.hist, 0, 257 * sizeof(int), s);
+    (void)jm_zero_async(p.hist, 257 * sizeof(int), s);
     const long long pts = (long long)b * n;
     hipLaunchKernelGGL(if_taps_kernel, dim3((unsigned)((pts + 255) / 256)), dim3(256), 0, s, p);
     hipLaunchKernelGGL(if_scan_kernel, dim3(1), dim3(256), 0, s, p);

@@ -549,7 +549,7 @@ int launch_nms_first_k(int nprob, int nmax, const int* counts, const float* boxe
                        int64_t* keep, int* num_keep, unsigned long long* evals, hipStream_t s) {
     JM_REQUIRE(group >= 1 && cap0 >= 0 && cap1 >= 0 && cap0 <= NFK_CAP && cap1 <= NFK_CAP,
                "nms_first_k: at most %d survivors per problem", NFK_CAP);
-    if (evals) (void)hipMemsetAsync(evals, 0, sizeof(unsigned long long) * nprob, s);
+    if (evals) (void)jm_zero_async(evals, sizeof(unsigned long long) * nprob, s);
     hipLaunchKernelGGL(nms_first_k_kernel, dim3(nprob), dim3(NFK_T), 0, s, nmax, counts, thresh, boxes, group, cap0, cap1,
                        (long long*)keep, num_keep, evals);
     return check_launch("nms_first_k");
@@ -688,7 +688,7 @@ extern "C" int jm_nms(int boxes_num, const float* boxes, float nms_overlap_thres
     JM_REQUIRE(boxes_num >= 0, "nms: bad size");
     JM_REQUIRE(num_keep, "nms: null num_keep");
     if (boxes_num == 0) {
-        (void)hipMemsetAsync(num_keep, 0, sizeof(int), (hipStream_t)stream);
+        (void)jm_zero_async(num_keep, sizeof(int), (hipStream_t)stream);
         return check_launch("nms(memset)");
     }
     JM_REQUIRE(boxes && keep && ws, "nms: null pointer");
@@ -718,7 +718,7 @@ extern "C" int jm_nms_normal_first_k_batched(int num_problems, int max_boxes, co
     if (num_problems == 0) return JM_OK;
     JM_REQUIRE(num_keep, "nms_normal_first_k: null num_keep");
     if (max_boxes == 0 || first_k == 0) {
-        (void)hipMemsetAsync(num_keep, 0, sizeof(int) * num_problems, (hipStream_t)stream);
+        (void)jm_zero_async(num_keep, sizeof(int) * num_problems, (hipStream_t)stream);
         return check_launch("nms_normal_first_k(memset)");
     }
     JM_REQUIRE(boxes && keep, "nms_normal_first_k: null pointer");
@@ -733,7 +733,7 @@ extern "C" int jm_nms_batched(int num_problems, int max_boxes, const int* counts
     if (num_problems == 0) return JM_OK;
     JM_REQUIRE(num_keep, "nms_batched: null num_keep");
     if (max_boxes == 0) {
-        (void)hipMemsetAsync(num_keep, 0, sizeof(int) * num_problems, (hipStream_t)stream);
+        (void)jm_zero_async(num_keep, sizeof(int) * num_problems, (hipStream_t)stream);
         return check_launch("nms_batched(memset)");
     }
     JM_REQUIRE(counts && boxes && keep && ws, "nms_batched: null pointer");

@@ -37,6 +37,21 @@ static inline int tune_env(const char* name, int dflt) { const char* e = getenv(
 static inline constexpr int tune_env(const char*, int dflt) { return dflt; }
 #endif
 
+// Zero-fill as a KERNEL, not hipMemsetAsync: a memset captured into a HIP graph is not reliably ordered against the kernel nodes
+// around it when the graph is replayed on this stack (tools/graph_memset_probe.py; it showed up as accumulators that were not
+// zero under a replayed backward pass) — and every entry of this library must behave the same eagerly and under capture.
+static __global__ void jm_zero_words_kernel(unsigned* __restrict__ p, size_t nwords) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline hipError_t jm_zero_async(void* p, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    if ((bytes & 3u) || (reinterpret_cast<uintptr_t>(p) & 3u)) return hipMemsetAsync(p, 0, bytes, s);   // (no such caller)
+    const size_t nwords = bytes >> 2;
+    const size_t blocks = (nwords + 255) / 256;
+    hipLaunchKernelGGL(jm_zero_words_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, (unsigned*)p, nwords);
+    return hipGetLastError();
+}
+
 static inline int divup(int a, int b) { return (a + b - 1) / b; }
 static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

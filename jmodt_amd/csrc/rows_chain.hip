@@ -129,7 +129,7 @@ int jm_sa_scale_backward(const jm_sa_scale_t* d, const jm_sa_scale_grad_t* g, jm
     const int ldw1 = 3 + d->c;
     hipLaunchKernelGGL(rows_copy_cols_kernel, dim3((unsigned)divup(H1 * 3, 256)), dim3(256), 0, s, H1, 3, (const float*)g->dw4, 4, g->dw1, ldw1, 0);
     if (d->c > 0) {
-        (void)hipMemsetAsync(g->du, 0, (size_t)d->points * H1 * sizeof(float), s);
+        (void)jm_zero_async(g->du, (size_t)d->points * H1 * sizeof(float), s);
         JM_TRY(jm_sa_rows_scatter_add(R, d->rows_dev, H1, dy, H1, d->row_point, g->du, H1, stream));
         JM_TRY(jm_rows_linear_wgrad(d->points, nullptr, H1, d->c, g->du, H1, d->f, d->ldf, g->dw1 + 3, ldw1, nullptr, 0, g->ws, g->ws_bytes, stream));
         if (g->df) JM_TRY(jm_rows_linear_dgrad(d->points, nullptr, H1, d->c, g->du, H1, d->w1f, d->c, nullptr, 0, g->df_accumulate, g->df, d->c, stream));

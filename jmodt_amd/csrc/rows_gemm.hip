@@ -441,8 +441,8 @@ int jm_rows_linear_wgrad(int m, const int* m_dev, int n, int k, const float* dy,
     }
     if (m == 0) {           // no rows: the gradients are zero
         if (!accumulate) {
-            for (int r = 0; r < n; ++r) (void)hipMemsetAsync(dw + (size_t)r * lddw, 0, (size_t)k * sizeof(float), (hipStream_t)stream);
-            if (dbias) (void)hipMemsetAsync(dbias, 0, (size_t)n * sizeof(float), (hipStream_t)stream);
+            for (int r = 0; r < n; ++r) (void)jm_zero_async(dw + (size_t)r * lddw, (size_t)k * sizeof(float), (hipStream_t)stream);
+            if (dbias) (void)jm_zero_async(dbias, (size_t)n * sizeof(float), (hipStream_t)stream);
         }
         return check_launch("rows_linear_wgrad");
     }

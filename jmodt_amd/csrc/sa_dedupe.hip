@@ -166,7 +166,7 @@ extern "C" int jm_sa_dedupe_plan(int r, int n, int m, int nsample, const int* ca
                "sa_dedupe_plan: sizes out of range (n <= %d, m <= %d, nsample <= 256)", SD_MAX_N, SD_MAX_M);
     JM_REQUIRE(counters, "sa_dedupe_plan: null counters");
     hipStream_t s = (hipStream_t)stream;
-    (void)hipMemsetAsync(counters, 0, 4 * sizeof(int), s);
+    (void)jm_zero_async(counters, 4 * sizeof(int), s);
     if (r == 0) return JM_OK;
     JM_REQUIRE(canon && fps_idx && nb && new_xyz && rep && seg_start && seg_cnt && vidx && vxyz, "sa_dedupe_plan: null pointer");
     const long long vmax = jm_sa_dedupe_capacity(r, m, nsample);

@@ -117,7 +117,7 @@ static int sg_check(int groups, int nsample, const int* idx, int qmin, const int
 extern "C" int jm_sa_group_plan(int groups, int nsample, const int* idx, int qmin, int* cls_count, int* glist, jm_stream_t stream) {
     if (int rc = sg_check(groups, nsample, idx, qmin, cls_count, glist)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(cls_count, 0, 8 * sizeof(int), s) != hipSuccess) { set_error("sa_group_plan: memset failed"); return JM_ELAUNCH; }
+    if (jm_zero_async(cls_count, 8 * sizeof(int), s) != hipSuccess) { set_error("sa_group_plan: memset failed"); return JM_ELAUNCH; }
     if (groups == 0) return JM_OK;
     SgPlan pl{};
     pl.ns[0] = nsample; pl.qmin[0] = qmin; pl.idx[0] = idx; pl.cls_count[0] = cls_count; pl.glist[0] = glist;
@@ -132,7 +132,7 @@ extern "C" int jm_sa_group_plan_dev(int groups, int nsample, const int* idx, int
     if (int rc = sg_check(groups, nsample, idx, qmin, cls_count, glist)) return rc;
     JM_REQUIRE(groups_dev, "sa_group_plan_dev: null group count");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(cls_count, 0, 8 * sizeof(int), s) != hipSuccess) { set_error("sa_group_plan: memset failed"); return JM_ELAUNCH; }
+    if (jm_zero_async(cls_count, 8 * sizeof(int), s) != hipSuccess) { set_error("sa_group_plan: memset failed"); return JM_ELAUNCH; }
     if (groups == 0) return JM_OK;
     SgPlan pl{};
     pl.groups_dev = groups_dev;
@@ -148,7 +148,7 @@ extern "C" int jm_sa_group_plan_dual(int groups, int nsample0, const int* idx0, 
     if (int rc = sg_check(groups, nsample0, idx0, qmin0, cls_count, glist0)) return rc;
     if (int rc = sg_check(groups, nsample1, idx1, qmin1, cls_count, glist1)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(cls_count, 0, 16 * sizeof(int), s) != hipSuccess) { set_error("sa_group_plan: memset failed"); return JM_ELAUNCH; }
+    if (jm_zero_async(cls_count, 16 * sizeof(int), s) != hipSuccess) { set_error("sa_group_plan: memset failed"); return JM_ELAUNCH; }
     if (groups == 0) return JM_OK;
     SgPlan pl{};
     pl.ns[0] = nsample0; pl.qmin[0] = qmin0; pl.idx[0] = idx0; pl.cls_count[0] = cls_count; pl.glist[0] = glist0;

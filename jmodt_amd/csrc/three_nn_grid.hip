@@ -176,7 +176,7 @@ extern "C" int jm_three_nn_ws(int b, int n, int m, const float* unknown, const f
     float4* sorted = (float4*)w; w += align_up((size_t)b * m * sizeof(float4), 256);
     float4* hdr = (float4*)w;    w += align_up((size_t)b * sizeof(float4), 256);
     int* todo = (int*)w;
-    (void)hipMemsetAsync(todo, 0, sizeof(int), s);
+    (void)jm_zero_async(todo, sizeof(int), s);
     int T = 4096;
     while (T < m && T < BG_T_MAX) T *= 2;
 #define JM_TG_BUILD(TPT)                                                                                                       \

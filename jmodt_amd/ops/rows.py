@@ -238,6 +238,16 @@ class RowsPlan:
                                          L.stream_ptr()), "sa_rows_plan")
         self.rows_dev = self.offsets[G:]          # (1,) int32 view: the row count, in device memory
 
+    @classmethod
+    def from_tensors(cls, d: torch.Tensor, offsets: torch.Tensor, row_point: torch.Tensor, row_group: torch.Tensor, groups: int,
+                     ns: int) -> "RowsPlan":
+        """a plan whose four device tensors were made elsewhere (e.g. by a replayed graph: train_graphs.py)"""
+        p = cls.__new__(cls)
+        p.groups, p.max_rows, p.ns = int(groups), int(groups) * int(ns), int(ns)
+        p.d, p.offsets, p.row_point, p.row_group = d, offsets, row_point, row_group
+        p.rows_dev = offsets[groups:]
+        return p
+
 
 class _SaLevel(Function):
     """QueryAndGroup + SharedMLP + max-pool (pointnet2_modules.py:46-55) of ALL scales of one set-abstraction level on their plans'

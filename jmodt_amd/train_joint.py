@@ -132,16 +132,24 @@ def joint_step(engine, xyz, image, pts_xy, gt_tids, optimizer, world: Optional[i
     collective), optimizer step.  Returns the local loss (device scalar, detached).
 
     route: "rows" = forward and backward on the hand-written row kernels (train_rows.py; BatchNorm frozen: eval-mode statistics),
+    "graphs" = the rows route with every single-stream piece captured once as a HIP graph and replayed (train_graphs.py: the same
+    kernels and gradients, ~30 graph launches instead of ~1050 kernel launches through ~60 autograd Functions),
     "operators" = the un-fused operator route above (torch autograd over (B, C, npoint, nsample) tensors; any BatchNorm mode),
-    "auto" = rows whenever the BatchNorms are frozen.  next_xyz: the next batch's cloud — its FPS pyramid / neighbour search
+    "auto" = graphs whenever the BatchNorms are frozen.  next_xyz: the next batch's cloud — its FPS pyramid / neighbour search
     starts on the side stream under this step (rows route).  world / local: see dist.group_world."""
     import torch.distributed as tdist
     from .ops.affinity_train import AffinityTrainState
     params = [p for p in _engine_lists(engine)[1] if p.requires_grad]
     optimizer.zero_grad(set_to_none=True)
     if route == "auto":
-        route = "rows" if frozen_bn(engine) and xyz.is_cuda else "operators"
-    if route == "rows":
+        route = "graphs" if frozen_bn(engine) and xyz.is_cuda else "operators"
+    if route == "graphs":
+        if not frozen_bn(engine):
+            raise RuntimeError("joint_step(route='graphs') folds the BatchNorms: call train_joint.freeze_bn(engine) (or engine.eval()) first")
+        from . import train_graphs
+        loss = prof.region("joint_forward+backward(span)", lambda: train_graphs.forward_backward(
+            engine, xyz, image, pts_xy, gt_tids, world, local, rois_per_frame, next_xyz)[0])
+    elif route == "rows":
         if not frozen_bn(engine):
             raise RuntimeError("joint_step(route='rows') folds the BatchNorms: call train_joint.freeze_bn(engine) (or engine.eval()) first")
         loss = prof.region("joint_forward+backward(span)", lambda: _rows_forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local,

@@ -68,8 +68,10 @@ class BnFold:
     W * s[:, None] from ONE multi-tensor kernel (ops/rows.fold_all) whose backward — d(W) = d(Wf) * s, d(s) = rowsum(d(Wf) * W) —
     is one more.  Differentiable w.r.t. W, gamma, beta (the running statistics are buffers)."""
 
-    def __init__(self, root: nn.Module):
-        pairs = bn_pairs(root)
+    def __init__(self, root, pairs=None):
+        """root: the module whose BatchNorms are folded — or `pairs`, an explicit [(convolution, BatchNorm)] list (a section of
+        the network: train_graphs.py)"""
+        pairs = bn_pairs(root) if pairs is None else list(pairs)
         self._slots = {}
         if not pairs:
             return
@@ -171,6 +173,15 @@ def _sa_level_rows(fold: BnFold, sa, xyz: torch.Tensor, feats: Optional[torch.Te
     return R.sa_level_rows(feats, flat_xyz, flat_ctr, plans, [[fold.unit(u) for u in mlp] for mlp in sa.mlps])
 
 
+def _channel_sums(g: torch.Tensor) -> torch.Tensor:
+    """(B, C, H, W) -> (C) sums over batch and pixels.  On channels-last maps = the column sums of the (B H W, C) row matrix on the
+    two-pass kernels of csrc/jm_rows.h: torch's reduction of many inputs to few outputs zeroes a semaphore buffer with a memset,
+    which is not reliably ordered inside a replayed HIP graph on this stack (graphed.py)"""
+    if g.is_cuda and g.dtype == torch.float32 and g.shape[1] % 4 == 0 and g.is_contiguous(memory_format=torch.channels_last):
+        return R.colsum(g.permute(0, 2, 3, 1).reshape(-1, g.shape[1]))
+    return g.sum(dim=(0, 2, 3))
+
+
 class _Conv3x3BiasRelu(torch.autograd.Function):
     """relu(conv3x3(x, w, padding 1) + b) of an image block's first layer (backbone.py:16-32 conv1 + bn1 + relu, BatchNorm folded
     into w / b by the caller).  Forward = the inference engine's one-pass kernels (csrc/conv_rgb.hip for the 3-channel first layer,
@@ -205,9 +216,31 @@ class _Conv3x3BiasRelu(torch.autograd.Function):
         wino_dx = need_x and ctx.kind == "wino" and wino_supported(cout, cin) and dpre.is_contiguous(memory_format=torch.channels_last)
         if wino_dx:
             dx = conv3x3_wino_bias_relu(dpre, pack_wino_weight(w.flip(2, 3).transpose(0, 1)), None, cin, relu=False)
-        gx, dw, db = torch.ops.aten.convolution_backward(dpre, x, w, [cout], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                        [need_x and not wino_dx, True, True])
-        return (dx if wino_dx else gx), dw, db
+        # d(b) = the channel sums of d(pre), as a plain reduction: the library's own bias gradient comes out as ZEROS when the
+        # call is replayed from a HIP graph (train_graphs.py; tools/_dbg notes in graphed.py) — and costs a launch either way
+        gx, dw, _ = torch.ops.aten.convolution_backward(dpre, x, w, [cout], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                       [need_x and not wino_dx, True, False])
+        return (dx if wino_dx else gx), dw, _channel_sums(dpre)
+
+
+class _BiasReluInplace(torch.autograd.Function):
+    """relu(x + b[c]) written over x (a convolution's bias-free output, which nothing else reads), d(b) = channel sums of the
+    masked gradient: one elementwise pass forward (csrc/elementwise.hip on channels-last maps), no bias inside the convolution —
+    see _Conv3x3BiasRelu.backward for why the convolution library's bias gradient is avoided"""
+
+    @staticmethod
+    def forward(ctx, x, b):
+        from .ops.fusion import bias_relu_
+        y = bias_relu_(x, b)
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dpre = torch.ops.aten.threshold_backward(dy, y, 0)
+        return dpre, _channel_sums(dpre)
 
 
 def _image_pyramid(fold: BnFold, net, image: torch.Tensor) -> List[torch.Tensor]:
@@ -227,9 +260,14 @@ def _image_fusion_map(fold: BnFold, net, maps: List[torch.Tensor]) -> torch.Tens
     un-composed form: four kernel == stride transposed convolutions, their 64-channel concatenation, one 1x1 convolution —
     204 GFLOP per 4 frames forward + backward against 363 for the composed form the inference engine gathers from
     (tools/joint_image_probe.py: 5.1 against 6.1 ms)"""
-    de = torch.cat([dc(m) for dc, m in zip(net.DeConv, maps)], dim=1)
+    de = torch.cat([F.conv_transpose2d(m, dc.weight, None, stride=dc.stride, padding=dc.padding, output_padding=dc.output_padding)
+                    for dc, m in zip(net.DeConv, maps)], dim=1)
     Wf, bf = fold.conv4d(net.image_fusion_conv)
-    return F.relu(F.conv2d(de, Wf, bf), inplace=True)
+    # the deconvolutions' biases ride through the (linear) 1x1 convolution: Wf (de + b_d) + bf = Wf de + (Wf b_d + bf) — a 64-vector
+    # product instead of a pass over the concatenated map, and no bias inside any library convolution
+    biases = [dc.bias if dc.bias is not None else m.new_zeros(dc.out_channels) for dc, m in zip(net.DeConv, maps)]
+    b_eff = bf + Wf.reshape(Wf.shape[0], -1) @ torch.cat(biases)
+    return _BiasReluInplace.apply(F.conv2d(de, Wf, None), b_eff)
 
 
 def backbone_forward_rows(engine, xyz: torch.Tensor, image: torch.Tensor, pts_xy: torch.Tensor, fold: BnFold,
