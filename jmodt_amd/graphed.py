@@ -46,6 +46,16 @@ def is_static(t: torch.Tensor) -> bool:
 
 _cap_streams = {}
 import os as _os
+TIMELINE = None                                          # a list while a GPU-side timeline is being collected (train_graphs trace)
+
+
+def _stamp(name: str, what: str):
+    if TIMELINE is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        TIMELINE.append((name, what, ev))
+
+
 _SYNC = _os.environ.get("JM_GRAPH_SYNC", "")             # debugging: a device synchronisation behind every replay ("f", "b", "fb")
 
 
@@ -69,15 +79,17 @@ def _dense_span(t: torch.Tensor) -> int:
 
 class _Entry:
     __slots__ = ("s_in", "copy_in", "outs", "outs_graph", "g_f", "g_b", "s_gout", "gin", "grad_in", "diff_out", "single", "pool",
-                 "held", "replays", "gout_flat", "pool_b")
+                 "held", "replays", "gout_flat", "pool_b", "name")
 
 
 class _Replay(torch.autograd.Function):
     @staticmethod
     def forward(ctx, entry: _Entry, *inputs):
+        _stamp(entry.name, "fwd<")
         for i in entry.copy_in:
             entry.s_in[i].copy_(inputs[i])
         entry.g_f.replay()
+        _stamp(entry.name, "fwd>")
         if "f" in _SYNC:
             torch.cuda.synchronize()
         entry.replays += 1
@@ -91,6 +103,7 @@ class _Replay(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         e = ctx.entry
+        _stamp(e.name, "bwd<")
         live = [g for g, d in zip(grads, e.diff_out) if d]
         if any(g is None for g in live):
             e.gout_flat.zero_()
@@ -102,6 +115,7 @@ class _Replay(torch.autograd.Function):
         again = [(gi, gi.clone()) for i, gi in zip(e.grad_in, e.gin)
                  if gi is not None and isinstance(e.s_in[i], torch.nn.Parameter) and e.s_in[i].grad is gi]
         e.g_b.replay()
+        _stamp(e.name, "bwd>")
         if "b" in _SYNC:
             torch.cuda.synchronize()
         for gi, prev in again:
@@ -122,8 +136,9 @@ class _Replay(torch.autograd.Function):
 
 
 class GraphedSection:
-    def __init__(self, fn: Callable, name: str, warmup: int = 2):
-        self.fn, self.name, self.warmup = fn, name, warmup
+    def __init__(self, fn: Callable, name: str, warmup: int = 2, enabled: bool = True):
+        """enabled=False: a pass-through (fn runs eagerly under plain autograd) — the caller's composition stays the same"""
+        self.fn, self.name, self.warmup, self.enabled = fn, name, warmup, enabled
         self._cache: Dict[tuple, _Entry] = {}
         self.captures = 0
 
@@ -135,6 +150,8 @@ class GraphedSection:
         return tuple(k)
 
     def __call__(self, *args: torch.Tensor):
+        if not self.enabled:
+            return self.fn(*args)
         for a in args:
             if not (isinstance(a, torch.Tensor) and a.is_cuda):
                 raise RuntimeError(f"section {self.name}: every argument must be a GPU tensor (got {type(a).__name__})")
@@ -147,9 +164,11 @@ class GraphedSection:
             outs = _Replay.apply(e, *args)
         else:
             with torch.no_grad():
+                _stamp(e.name, "fwd<")
                 for i in e.copy_in:
                     e.s_in[i].copy_(args[i])
                 e.g_f.replay()
+                _stamp(e.name, "fwd>")
                 e.replays += 1
                 outs = tuple(o.detach() for o in e.outs)
         return outs[0] if e.single else outs
@@ -162,6 +181,7 @@ class GraphedSection:
         if trace:
             print(f"[graphed] capturing {self.name}: {len(args)} inputs, grad={grad}", flush=True)
         e = _Entry()
+        e.name = self.name
         e.replays = 0
         e.held = list(args)              # static inputs stay referenced: their addresses are inside the graphs
         s_in, copy_in = [], []

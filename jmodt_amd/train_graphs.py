@@ -52,20 +52,27 @@ def _split_params(all_pairs, mods: Sequence[nn.Module]):
 class JointGraphs:
     """the sections of one engine at one batch shape; built lazily by `joint_graphs(engine)`"""
 
-    def __init__(self, engine):
+    def __init__(self, engine, graphed: Optional[str] = None):
+        """graphed: comma-separated section groups to CAPTURE — geom, image, level, fp, final, pooled, rcnn — the others run
+        eagerly under plain autograd in the same composition (default: the JM_JOINT_GRAPHED environment switch, else all)"""
+        import os
+        if graphed is None:
+            graphed = os.environ.get("JM_JOINT_GRAPHED", "geom,image,level,fp,final,pooled,rcnn")
+        on = {g.strip() for g in graphed.split(",") if g.strip()}
+        self.graphed = on
         self.engine = engine
         net, rcnn = engine.rpn.backbone_net, engine.rcnn_net
         self.all_pairs = TR.bn_pairs(engine)
         self.nlev = len(net.SA_modules)
-        self.sec_geom = GraphedSection(self._geom_fn, "geometry")
-        self.sec_take = GraphedSection(lambda *ts: tuple(t.clone() for t in ts), "geometry_take")
-        self.sec_img = [GraphedSection(lambda *ts, k=i: self._img_fn(k, *ts), f"image_{i + 1}") for i in range(self.nlev)]
-        self.sec_fmap = GraphedSection(self._fmap_fn, "fused_map")
-        self.sec_level = [GraphedSection(lambda *ts, k=i: self._level_fn(k, *ts), f"level_{i + 1}") for i in range(self.nlev)]
-        self.sec_fp = GraphedSection(self._fp_fn, "fp")
-        self.sec_final = GraphedSection(self._final_fn, "final")
-        self.sec_pooled = GraphedSection(self._pooled_fn, "pooled")
-        self.sec_rcnn = GraphedSection(self._rcnn_fn, "rcnn")
+        self.sec_geom = GraphedSection(self._geom_fn, "geometry", enabled="geom" in on)
+        self.sec_take = GraphedSection(lambda *ts: tuple(t.clone() for t in ts), "geometry_take", enabled="geom" in on)
+        self.sec_img = [GraphedSection(lambda *ts, k=i: self._img_fn(k, *ts), f"image_{i + 1}", enabled="image" in on) for i in range(self.nlev)]
+        self.sec_fmap = GraphedSection(self._fmap_fn, "fused_map", enabled="image" in on)
+        self.sec_level = [GraphedSection(lambda *ts, k=i: self._level_fn(k, *ts), f"level_{i + 1}", enabled="level" in on) for i in range(self.nlev)]
+        self.sec_fp = GraphedSection(self._fp_fn, "fp", enabled="fp" in on)
+        self.sec_final = GraphedSection(self._final_fn, "final", enabled="final" in on)
+        self.sec_pooled = GraphedSection(self._pooled_fn, "pooled", enabled="pooled" in on)
+        self.sec_rcnn = GraphedSection(self._rcnn_fn, "rcnn", enabled="rcnn" in on)
         # which modules every section touches -> (pairs, leaf parameters)
         self.p_img = [_split_params(self.all_pairs, [net.Img_Block[i]]) for i in range(self.nlev)]
         self.p_fmap = _split_params(self.all_pairs, list(net.DeConv) + [net.image_fusion_conv, net.image_fusion_bn])
@@ -228,7 +235,7 @@ class JointGraphs:
         self._announced = None
         main.wait_event(hit[2])
         with torch.no_grad():
-            taken = self.sec_take(*self._geom_out)
+            taken = self.sec_take(*self._geom_out) if self.sec_take.enabled else self._geom_out
         if fs is not main:
             fs.wait_stream(main)          # the next announcement overwrites what `geometry_take` has just read
         return taken
@@ -308,23 +315,50 @@ def joint_graphs(engine) -> JointGraphs:
 
 
 def forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local, rois_per_frame, next_xyz, next_xy=None):
-    """forward, thin loss and ONE backward of the joint-mode step on sections; returns the local loss (device scalar)"""
+    """forward, thin loss and backward of the joint-mode step on sections; returns (local loss (device scalar), outputs).
+    Issued in the order that keeps the streams busy: backbone + RPN heads forward (M / I) -> proposals + RoI pooling (no
+    gradient) -> the BACKWARD of the RPN part of the loss (M / I: the loss is a sum, its parts back-propagate independently and
+    share no section) -> RCNN forward, re-id loss and their backward on stream R, under the backbone's backward."""
+    import os
+    import time
     import torch.distributed as tdist
     from . import dist as jdist
     from .ops.affinity_train import AffinityTrainState, affinity_train_loss
+    trace = bool(os.environ.get("JM_STEP_TRACE"))
+    marks = [("start", time.perf_counter())]
+    if trace:
+        from . import graphed
+        torch.cuda.synchronize()
+        graphed.TIMELINE = []
+        t_ref = torch.cuda.Event(enable_timing=True)
+        t_ref.record()
+
+    def mark(name):
+        if trace:
+            marks.append((name, time.perf_counter()))
     jg = joint_graphs(engine)
     jg.rois_per_frame = rois_per_frame
     dev = xyz.device
     main = torch.cuda.current_stream(dev)
     geom = jg.geometry(xyz, pts_xy)
+    mark("geometry_take")
     if next_xyz is not None:
         jg.announce(next_xyz, pts_xy if next_xy is None else next_xy)
+    mark("announce")
     feats, rpn_cls, rpn_reg = jg.forward_backbone(xyz, image, pts_xy, geom)
+    mark("backbone_forward")
     with torch.no_grad():
         rois, pts_input, count = jg.sec_pooled(xyz, rpn_cls, rpn_reg, feats)
+    pooled_ev = torch.cuda.Event()
+    pooled_ev.record()
+    mark("pooled")
+    n = float(rpn_cls.shape[1])
+    rpn_loss = (rpn_cls.sum() + rpn_reg.sum()) / n
+    rpn_loss.backward()
+    mark("rpn_backward")
     side = side_stream(dev, 3) if engine.overlap else main
     if side is not main:
-        side.wait_stream(main)
+        side.wait_event(pooled_ev)            # not main's position NOW: that would put the RCNN behind the backbone's whole backward
     B = gt_tids.shape[0]
     with torch.cuda.stream(side):
         rcnn_cls, rcnn_reg, rcnn_feat = jg.sec_rcnn(pts_input, count, *jg.p_rcnn[1])
@@ -335,15 +369,25 @@ def forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local, rois_per
             tdist.all_reduce(counts, op=tdist.ReduceOp.SUM)
         reid = affinity_train_loss(st, engine.rcnn_net.link_layer, engine.rcnn_net.se_layer, counts=counts)
         rcnn_loss = rcnn_cls.sum() + rcnn_reg.sum() + reid
+        rcnn_loss.backward()
+        total = rcnn_loss.detach() + rpn_loss.detach()
+    mark("rcnn")
+    # every stream that ran a piece of the step is joined before the all-reduce / optimizer on the main stream
     if side is not main:
         gt_tids.record_stream(side)
-        main.wait_stream(side)
-    n = float(rpn_cls.shape[1])
-    loss = (rpn_cls.sum() + rpn_reg.sum()) / n + rcnn_loss
-    loss.backward()
-    # every stream that ran a piece of the backward is joined before the all-reduce / optimizer on the main stream
+        total.record_stream(main)
     for slot in (1, 3):
         if engine.overlap:
             main.wait_stream(side_stream(dev, slot))
-    return loss.detach(), dict(rois=rois, rpn_cls=rpn_cls, rpn_reg=rpn_reg, backbone_features=feats, rcnn_cls=rcnn_cls, rcnn_reg=rcnn_reg,
-                               rcnn_feat=rcnn_feat)
+    if trace:
+        t0 = marks[0][1]
+        print("[step] host: " + "  ".join(f"{nm} {1e3 * (t - t0):.2f}" for nm, t in marks[1:]), flush=True)
+        torch.cuda.synchronize()
+        tl, graphed.TIMELINE = graphed.TIMELINE, None
+        spans = {}
+        for name, what, ev in tl:
+            spans.setdefault((name, what[:3]), []).append(t_ref.elapsed_time(ev))
+        print("[step] device (ms after the step's start; section: begin-end): " +
+              "  ".join(f"{k[0]}.{k[1]} {v[0]:.2f}-{v[-1]:.2f}" for k, v in sorted(spans.items(), key=lambda kv: kv[1][0])), flush=True)
+    return total, dict(rois=rois, rpn_cls=rpn_cls, rpn_reg=rpn_reg, backbone_features=feats, rcnn_cls=rcnn_cls, rcnn_reg=rcnn_reg,
+                       rcnn_feat=rcnn_feat)

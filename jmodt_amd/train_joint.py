@@ -135,14 +135,17 @@ def joint_step(engine, xyz, image, pts_xy, gt_tids, optimizer, world: Optional[i
     "graphs" = the rows route with every single-stream piece captured once as a HIP graph and replayed (train_graphs.py: the same
     kernels and gradients, ~30 graph launches instead of ~1050 kernel launches through ~60 autograd Functions),
     "operators" = the un-fused operator route above (torch autograd over (B, C, npoint, nsample) tensors; any BatchNorm mode),
-    "auto" = graphs whenever the BatchNorms are frozen.  next_xyz: the next batch's cloud — its FPS pyramid / neighbour search
+    "auto" = rows whenever the BatchNorms are frozen (the faster of the two on this stack: see below).  next_xyz: the next batch's cloud — its FPS pyramid / neighbour search
     starts on the side stream under this step (rows route).  world / local: see dist.group_world."""
     import torch.distributed as tdist
     from .ops.affinity_train import AffinityTrainState
     params = [p for p in _engine_lists(engine)[1] if p.requires_grad]
     optimizer.zero_grad(set_to_none=True)
     if route == "auto":
-        route = "graphs" if frozen_bn(engine) and xyz.is_cuda else "operators"
+        # rows, not graphs: measured on one MI355X (4 frames, tools/joint_stream_probe.py / bench.py) the graphs route takes the
+        # host from 18 ms to 4 ms per step but its replayed sections do not overlap across streams the way the eager launches do —
+        # 25.7 ms per step at 4 hardware queues (39 - 41 ms at 1, 6 or 8) against 23.6 ms for the rows route at 8 (DESIGN.md §6)
+        route = "rows" if frozen_bn(engine) and xyz.is_cuda else "operators"
     if route == "graphs":
         if not frozen_bn(engine):
             raise RuntimeError("joint_step(route='graphs') folds the BatchNorms: call train_joint.freeze_bn(engine) (or engine.eval()) first")

@@ -177,7 +177,8 @@ def _channel_sums(g: torch.Tensor) -> torch.Tensor:
     """(B, C, H, W) -> (C) sums over batch and pixels.  On channels-last maps = the column sums of the (B H W, C) row matrix on the
     two-pass kernels of csrc/jm_rows.h: torch's reduction of many inputs to few outputs zeroes a semaphore buffer with a memset,
     which is not reliably ordered inside a replayed HIP graph on this stack (graphed.py)"""
-    if g.is_cuda and g.dtype == torch.float32 and g.shape[1] % 4 == 0 and g.is_contiguous(memory_format=torch.channels_last):
+    if (g.is_cuda and torch.cuda.is_current_stream_capturing() and g.dtype == torch.float32 and g.shape[1] % 4 == 0
+            and g.is_contiguous(memory_format=torch.channels_last)):
         return R.colsum(g.permute(0, 2, 3, 1).reshape(-1, g.shape[1]))
     return g.sum(dim=(0, 2, 3))
 
