@@ -300,6 +300,19 @@ int jm_decode_rpn_proposals(long long num_points, int reg_channels, const float*
 int jm_decode_rcnn_boxes(long long num_rois, int reg_channels, const float* rois, const float* rcnn_reg,
                          float loc_scope, float loc_bin_size, int num_head_bin, const float* anchor_hwl,
                          int avg_by_bin, float* boxes, jm_stream_t stream);
+/* Detection post-processing around the per-frame NMS (tools/eval.py:171-193), batched over the frames,
+ * as two launches around jm_nms_batched.  jm_detections_sort: boxes (B,M,7), raw_scores (B,M) logits -> order (B,M) int64 = the
+ * stable descending order of the logits with the slots whose sigmoid score is <= score_thresh behind the accepted ones
+ * (scores.sort(descending) of eval.py:181 on the thresholded set), counts (B) int32 accepted slots, bev (B,M,5) = the sorted boxes as
+ * [x - l/2, z - w/2, x + l/2, z + w/2, ry] (kitti_utils.py:136-149).  M <= 1024.
+ * jm_detections_gather: + feats (B,M,C), keep (B,M) int64 / num_keep (B) of jm_nms_batched (positions in sorted order) ->
+ * out_boxes (B,M,7), out_scores (B,M) sigmoid, out_raw (B,M), out_feats (B,M,C), out_count (B) int32, out_slot (B,M) int64 = the RoI
+ * slot of the k-th survivor; everything behind the last survivor is zero. */
+int jm_detections_sort(int frames, int slots, const float* boxes, const float* raw_scores, float score_thresh, long long* order,
+                       int* counts, float* bev, jm_stream_t stream);
+int jm_detections_gather(int frames, int slots, int channels, const float* boxes, const float* raw_scores, const float* feats,
+                         const long long* order, const long long* keep, const int* num_keep, float* out_boxes, float* out_scores,
+                         float* out_raw, float* out_feats, int* out_count, long long* out_slot, jm_stream_t stream);
 /* boxes_iou3d_gpu (iou3d_utils.py:25-54) for a whole batch (the RoI sampler's per-frame
  * Python loop, proposal_target_layer.py:137-151,288): boxes_a (B,Na,7), boxes_b (B,Nb,7) [x,y,z,h,w,l,ry] with
  * y = box bottom -> iou3d (B,Na,Nb).  counts_b (B) device int32 or NULL: valid boxes per frame in boxes_b
@@ -419,6 +432,30 @@ int jm_conv3x3_wino_bias_relu(int b, int h, int w, int cin, int cout, const floa
  * element-wise pass of the image branch's BasicBlock (backbone.py:16-32) once its eval-mode BatchNorm is folded into
  * the first convolution (replaces a BatchNorm pass + a ReLU pass over up to 1 GB). */
 int jm_bias_relu_channels_last(long long numel, int channels, float* x, const float* bias, jm_stream_t stream);
+
+/* A dense layer on a (B, C, n) per-point tensor with FEW points (the coarse end of the backbone: feature propagation level 4,
+ * pointnet2_modules.py:139-153, and the LI-Fusion attention block of level 4, backbone.py:35-81), one launch of independent waves
+ * (csrc/points_gemm.hip): out = act(W [x1 ; x2] + bias) (* rowscale per point).  x1 (B,k1,n), x2 (B,k2,n) or NULL (k2 = 0): the
+ * channel concatenation is never built; w (n_out, >= k1 + k2) row-major with leading dimension ldw; act 0 none, 1 ReLU, 2 tanh,
+ * 3 sigmoid; rowscale[(b n + p) * rowscale_stride] or NULL; out (B,n_out,n), or point-major rows (B n, ldo) with out_rows.
+ * n % 32 == 0, (k1 + k2) % 4 == 0, ldw % 4 == 0. */
+int jm_points_linear_supported(int b, int n, int k1, int k2, int n_out);
+int jm_points_linear(int b, int n, int k1, const float* x1, int k2, const float* x2, int n_out, const float* w, int ldw,
+                     const float* bias, int act, const float* rowscale, int rowscale_stride, int out_rows, int ldo, float* out,
+                     jm_stream_t stream);
+
+/* Glue passes of the composed detector as single launches (round 5).
+ * jm_three_nn_weights: dist2 (rows, 3) squared distances of jm_three_nn -> weight (rows, 3) = the normalised inverse distances of
+ *   PointnetFPModule.forward (pointnet2_modules.py:148-150: dist = sqrt(dist2), 1 / (dist + 1e-8), divided by their sum).
+ * jm_gather_point_rows: out (B,m,width) = src (B,n,width) rows at idx (B,m) int32 — `torch.gather(l_xy, 1, li_index...)` of
+ *   backbone.py:170-171 on the int32 FPS indices.
+ * jm_pts_feature: the RoI-pooling input of the RCNN stage (point_rcnn.py:42-44, proposal_target_layer.py:26): rpn_cls (B,N) logits
+ *   with element stride ld_cls, xyz (B,N,3), feats (B,C,N) -> out (B,N,2+C) = [sigmoid(cls) > score_thresh, |xyz| / 70 - 0.5,
+ *   features point-major]. */
+int jm_three_nn_weights(long long rows, const float* dist2, float* weight, jm_stream_t stream);
+int jm_gather_point_rows(int b, int n, int m, int width, const float* src, const int* idx, float* out, jm_stream_t stream);
+int jm_pts_feature(int b, int n, int c, const float* rpn_cls, int ld_cls, const float* xyz, const float* feats, float score_thresh,
+                   float* out, jm_stream_t stream);
 
 /* The final LI-Fusion image feature AT THE POINTS (jmodt/detection/modeling/backbone.py:187-195):
  *   feature_gather(relu(bn(conv1x1(cat_i deconv_i(img_i)))), xy)

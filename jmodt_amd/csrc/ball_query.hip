@@ -165,7 +165,7 @@ ball_query_kernel(BqParams p, const float* __restrict__ new_xyz, const float* __
                 if (val < 0 && s < total + cw) val = hits[(w * ns + (s - total)) * 64 + l];
                 total += cw;
             }
-            if (total > 0) out[e] = (s < total) ? val : first;  // no hit: keep the caller's fill
+            out[e] = total > 0 ? ((s < total) ? val : first) : 0;  // no hit: 0, what the reference's caller pre-fills (pointnet2_utils.py:218)
         }
     }
 }

@@ -175,6 +175,9 @@ bq_grid_query_kernel(BgParams p, const float* __restrict__ new_xyz, const uint2*
                     const unsigned long long have = __ballot(pc > 0);
                     const int first = __builtin_amdgcn_readlane(first_here, __ffsll((long long)have) - 1);
                     for (int s2 = hits + lane; s2 < ns; s2 += 64) out[s2] = first;
+                } else {                                                  // no hit: 0, what the reference's caller pre-fills
+                    int* out = p.idx[r] + ((size_t)bi * p.m + c) * p.ns[r];
+                    for (int s2 = lane; s2 < p.ns[r]; s2 += 64) out[s2] = 0;
                 }
             } else {
                 // only the bitmap words flagged in the second level are read: this lane owns words [lane * wpl, (lane + 1) * wpl)
@@ -212,6 +215,9 @@ bq_grid_query_kernel(BgParams p, const float* __restrict__ new_xyz, const uint2*
                     for (int s2 = hits + lane; s2 < ns; s2 += 64) out[s2] = first;
                     __threadfence_block();
                     for (int w = lane; w < BG_L2; w += 64) l2[w] = 0u;    // (every flagged word was cleared by its owner above)
+                } else {
+                    int* out = p.idx[r] + ((size_t)bi * p.m + c) * p.ns[r];
+                    for (int s2 = lane; s2 < p.ns[r]; s2 += 64) out[s2] = 0;
                 }
             }
         }

@@ -369,6 +369,29 @@ class DetectAffinityEngine(nn.Module):
                 ia.fc1.weight, ia.fc1.bias, ia.fc2.weight, ia.fc2.bias, ia.fc3.weight, ia.fc3.bias, W_i, b_i, W_f, b_f))
             if packed.supported(point_feats.shape[0], point_feats.shape[2]):
                 return packed(point_feats, img_feats)
+        if point_feats.is_cuda and point_feats.dtype == torch.float32 and self.fuse_attention:
+            # the coarse level (8 x 64 points, 512 / 1024-wide operands: the tile of li_fusion.hip does not fit the LDS): four launches
+            # of csrc/points_gemm.hip — fc1 / fc2 as one two-operand layer with tanh, fc3 with the sigmoid (point-major: the gate),
+            # the image convolution with ReLU and the gate as a per-point scale, the fusion convolution on [point ; image]
+            from .ops.conv1d import points_linear, points_linear_supported
+            Bn, pc, n = point_feats.shape
+            icn = img_feats.shape[1]
+            rc = ia.fc1.weight.shape[0]
+            if (points_linear_supported(Bn, n, icn, pc, rc) and rc % 4 == 0 and points_linear_supported(Bn, n, pc, W_i.shape[0], W_f.shape[0])):
+                def make():
+                    w12 = torch.cat([ia.fc1.weight.detach(), ia.fc2.weight.detach()], dim=1).contiguous()
+                    b12 = (ia.fc1.bias.detach() + ia.fc2.bias.detach()).contiguous()
+                    w3 = torch.zeros((4, rc), dtype=torch.float32, device=w12.device)
+                    w3[0] = ia.fc3.weight.detach().reshape(-1)
+                    b3 = torch.zeros((4,), dtype=torch.float32, device=w12.device)
+                    b3[0] = ia.fc3.bias.detach().reshape(-1)[0]
+                    return w12, b12, w3, b3, W_i.contiguous(), b_i.contiguous(), W_f.contiguous(), b_f.contiguous()
+                w12, b12, w3, b3, Wi_c, bi_c, Wf_c, bf_c = self._wb(tag + ".points", make)
+                P, I = point_feats.contiguous(), img_feats.contiguous()
+                t = points_linear(I, w12, b12, 2, x2=P)                                              # (B, rc, n)
+                gate = points_linear(t, w3, b3, 3, out_rows=4)                                       # (B n, 4): column 0
+                img_new = points_linear(I, Wi_c, bi_c, 1, rowscale=gate, rowscale_stride=4)          # (B, pc', n)
+                return points_linear(P, Wf_c, bf_c, 1, x2=img_new)
         it, pt = img_feats.transpose(1, 2), point_feats.transpose(1, 2)                    # (B, n, C) views
         gate = torch.sigmoid(ia.fc3(torch.tanh(ia.fc1(it) + ia.fc2(pt))))                  # (B, n, 1)
         img_new = torch.relu(torch.baddbmm(b_i[None, :, None], W_i.expand(img_feats.shape[0], -1, -1), img_feats))
@@ -564,7 +587,8 @@ class DetectAffinityEngine(nn.Module):
             self.last_fps_idx.append(idx)
             with prof.scope(f"rpn_sa{i + 1}"):
                 _, feats, _ = sa(l_xyz[i], l_feats[i], new_xyz=new_xyz, grid=pyr.grid(i))
-            xy_i = torch.gather(l_xy[i], 1, idx.long().unsqueeze(-1).expand(-1, -1, 2))       # backbone.py:170-171
+            xy_i = (pointnet2_utils.gather_point_rows(l_xy[i], idx) if idx.is_cuda else
+                    torch.gather(l_xy[i], 1, idx.long().unsqueeze(-1).expand(-1, -1, 2)))       # backbone.py:170-171
             prof.stall(f"image_exposed_wait_L{i + 1}", lambda e=img_events[i]: main.wait_event(e))
             with prof.scope(f"li_fusion{i + 1}"):
                 gathered = feature_gather(img_maps[i], xy_i)
@@ -724,6 +748,16 @@ class DetectAffinityEngine(nn.Module):
         B, N, _ = xyz.shape
         C = feats.shape[1]
         pf = torch.empty((B, N, 2 + C), dtype=torch.float32, device=xyz.device)
+        cls = rpn_out["rpn_cls"]
+        if (xyz.is_cuda and feats.is_contiguous() and xyz.is_contiguous() and feats.dtype == torch.float32 and cls.dtype == torch.float32
+                and cls.stride(0) == N * cls.stride(1)):
+            # mask + depth + transposed features as ONE launch (csrc/elementwise.hip) instead of seven element-wise passes
+            import ctypes
+            from . import _lib as L
+            L.check(L.load().jm_pts_feature(B, N, C, ctypes.c_void_p(cls.data_ptr()), int(cls.stride(1)), L.dev(xyz, torch.float32, "xyz"),
+                                            L.dev(feats, torch.float32, "features"), float(cfg.rpn_score_thresh),
+                                            ctypes.c_void_p(pf.data_ptr()), L.stream_ptr()), "pts_feature")
+            return pf
         pf[:, :, 0] = (torch.sigmoid(rpn_out["rpn_cls"][:, :, 0]) > cfg.rpn_score_thresh).float()   # point_rcnn.py:42-43
         pf[:, :, 1] = torch.norm(xyz, p=2, dim=2) / 70.0 - 0.5                                       # :44; ptl.py:26
         pf[:, :, 2:] = feats.transpose(1, 2)

@@ -62,3 +62,30 @@ class PackedConv1dStack:
             L.dev(self.w0b, _f32, "w0b") if self.w0b is not None else None, self._w_c, self._b_c, self._relu_c,
             int(point_major), ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "conv1d_stack")
         return out
+
+
+def points_linear_supported(B: int, n: int, k1: int, k2: int, n_out: int) -> bool:
+    return bool(L.load().jm_points_linear_supported(int(B), int(n), int(k1), int(k2), int(n_out)))
+
+
+@torch.no_grad()
+def points_linear(x1: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0, x2: Optional[torch.Tensor] = None,
+                  rowscale: Optional[torch.Tensor] = None, rowscale_stride: int = 1, out_rows: Optional[int] = None) -> torch.Tensor:
+    """act(W [x1 ; x2] + bias) (* rowscale per point) on (B, C, n) tensors with few points — one launch of independent waves
+    (csrc/points_gemm.hip: the coarse end of the backbone, where the 32-point-tile kernels cannot fill the machine and the
+    library GEMMs are slow).  W (n_out, k1 + k2) contiguous; act 0 none / 1 ReLU / 2 tanh / 3 sigmoid; out_rows = ld: the output as
+    point-major rows (B n, ld) instead of (B, n_out, n)."""
+    B, k1, n = x1.shape
+    k2 = 0 if x2 is None else x2.shape[1]
+    n_out = W.shape[0]
+    if W.shape[1] != k1 + k2:
+        raise ValueError(f"points_linear: weight of {W.shape[1]} input channels for operands of {k1} + {k2}")
+    if out_rows:
+        out = torch.empty((B * n, int(out_rows)), dtype=_f32, device=x1.device)
+    else:
+        out = torch.empty((B, n_out, n), dtype=_f32, device=x1.device)
+    L.check(L.load().jm_points_linear(
+        B, n, k1, L.dev(x1, _f32, "x1"), k2, L.dev(x2, _f32, "x2") if x2 is not None else None, n_out, L.dev(W, _f32, "W"), W.shape[1],
+        L.dev(bias, _f32, "bias") if bias is not None else None, int(act), L.dev(rowscale, _f32, "rowscale") if rowscale is not None else None,
+        int(rowscale_stride), 1 if out_rows else 0, int(out_rows or 0), ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "points_linear")
+    return out

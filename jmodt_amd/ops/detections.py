@@ -115,24 +115,29 @@ def select_detections(pred_boxes3d: torch.Tensor, raw_scores: torch.Tensor, feat
                       score_thresh: float = 0.2, nms_thresh: float = 0.1) -> DetectionCache:
     """pred_boxes3d (B, M, 7), raw_scores (B, M) logits, feats (B, M, C) -> DetectionCache.
     tools/eval.py:171-193 for every frame at once: keep sigmoid(score) > score_thresh, rotated BEV NMS in
-    descending raw-score order (stable), gather the survivors — no host round trip."""
+    descending raw-score order (stable), gather the survivors — no host round trip, three launches (csrc/detections.hip:
+    sort + BEV form, jm_nms_batched, gather)."""
     B, M = raw_scores.shape
     dev = raw_scores.device
-    norm = torch.sigmoid(raw_scores)
-    valid = norm > score_thresh
-    key = torch.where(valid, raw_scores, raw_scores.new_full((), float("-inf")))
-    order = torch.sort(key, dim=1, descending=True, stable=True)[1]                     # valid ones first
-    counts = valid.sum(dim=1).to(torch.int32)
-    sorted_boxes = torch.gather(pred_boxes3d, 1, order.unsqueeze(-1).expand(-1, -1, 7))
-    bev = boxes3d_to_bev_torch(sorted_boxes.view(-1, 7)).view(B, M, 5).contiguous()
+    lib = L.load()
+    C = feats.shape[2]
+    boxes_c, raw_c, feats_c = pred_boxes3d.contiguous(), raw_scores.contiguous(), feats.contiguous()
+    boxes_in = L.dev(boxes_c, _f32, "pred_boxes3d")
+    order = torch.empty((B, M), dtype=torch.int64, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    bev = torch.empty((B, M, 5), dtype=_f32, device=dev)
+    L.check(lib.jm_detections_sort(B, M, boxes_in, L.dev(raw_c, _f32, "raw_scores"), float(score_thresh), ctypes.c_void_p(order.data_ptr()),
+                                   ctypes.c_void_p(counts.data_ptr()), ctypes.c_void_p(bev.data_ptr()), L.stream_ptr()), "detections_sort")
     keep, num_keep = iou3d_cuda.nms_batched_device(bev, counts, nms_thresh, 0)           # positions in sorted order
-    slot = torch.arange(M, device=dev).unsqueeze(0)
-    live = slot < num_keep.unsqueeze(1)
-    keep = torch.where(live, keep, torch.zeros_like(keep))
-    src = torch.gather(order, 1, keep)                                                  # RoI slots, (B, M)
-    zero = pred_boxes3d.new_zeros(())
-    boxes = torch.where(live.unsqueeze(-1), torch.gather(pred_boxes3d, 1, src.unsqueeze(-1).expand(-1, -1, 7)), zero)
-    out_feats = torch.where(live.unsqueeze(-1), torch.gather(feats, 1, src.unsqueeze(-1).expand(-1, -1, feats.shape[2])), zero)
-    return DetectionCache(boxes=boxes, scores=torch.where(live, torch.gather(norm, 1, src), zero),
-                          raw_scores=torch.where(live, torch.gather(raw_scores, 1, src), zero), feats=out_feats,
-                          count=num_keep.to(torch.int32), roi_index=torch.where(live, src, torch.zeros_like(src)))
+    boxes = torch.empty((B, M, 7), dtype=_f32, device=dev)
+    scores = torch.empty((B, M), dtype=_f32, device=dev)
+    raw_out = torch.empty((B, M), dtype=_f32, device=dev)
+    out_feats = torch.empty((B, M, C), dtype=_f32, device=dev)
+    count = torch.empty((B,), dtype=torch.int32, device=dev)
+    slot = torch.empty((B, M), dtype=torch.int64, device=dev)
+    L.check(lib.jm_detections_gather(B, M, C, boxes_in, L.dev(raw_c, _f32, "raw_scores"), L.dev(feats_c, _f32, "feats"),
+                                     ctypes.c_void_p(order.data_ptr()), ctypes.c_void_p(keep.data_ptr()), L.dev(num_keep, torch.int32, "num_keep"),
+                                     ctypes.c_void_p(boxes.data_ptr()), ctypes.c_void_p(scores.data_ptr()), ctypes.c_void_p(raw_out.data_ptr()),
+                                     ctypes.c_void_p(out_feats.data_ptr()), ctypes.c_void_p(count.data_ptr()), ctypes.c_void_p(slot.data_ptr()),
+                                     L.stream_ptr()), "detections_gather")
+    return DetectionCache(boxes=boxes, scores=scores, raw_scores=raw_out, feats=out_feats, count=count, roi_index=slot)

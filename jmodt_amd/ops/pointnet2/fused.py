@@ -599,6 +599,15 @@ def shared_mlp_points(mlp: nn.Sequential, parts) -> Optional[torch.Tensor]:
                 [(W, b, True) for W, b in layers], parts[0].shape[1], parts[1].shape[1] if len(parts) == 2 else 0))
         if st[1].supported(B, n):
             return st[1](*parts)
+    if parts[0].is_cuda and len(parts) <= 2 and all(p.dtype == torch.float32 for p in parts):
+        # few points (feature propagation level 4: 8 x 256): one launch of independent waves per layer (csrc/points_gemm.hip)
+        from ..conv1d import points_linear, points_linear_supported
+        k1, k2 = parts[0].shape[1], (parts[1].shape[1] if len(parts) == 2 else 0)
+        if points_linear_supported(B, n, k1, k2, layers[0][0].shape[0]) and all(W.shape[1] % 4 == 0 for W, _ in layers):
+            x = points_linear(parts[0].contiguous(), layers[0][0], layers[0][1], 1, x2=parts[1].contiguous() if k2 else None)
+            for W, b in layers[1:]:
+                x = points_linear(x, W, b, 1)
+            return x
     W, b = layers[0]
     x, off = None, 0
     for part in parts:

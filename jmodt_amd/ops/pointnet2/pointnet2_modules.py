@@ -170,9 +170,13 @@ class PointnetFPModule(nn.Module):
             carried = known_feats.expand(known_feats.shape[0], known_feats.shape[1], unknown.shape[1])
         else:
             # inverse-distance weights over the three nearest coarse points (pointnet2_modules.py:147-152)
-            d3, nn3 = pointnet2_utils.three_nn(unknown, known)
-            inv = (d3 + 1e-8).reciprocal()
-            carried = pointnet2_utils.three_interpolate(known_feats, nn3, inv / inv.sum(dim=2, keepdim=True))
+            if unknown.is_cuda and not torch.is_grad_enabled():
+                nn3, w = pointnet2_utils.three_nn_weights(unknown, known)      # search + one launch (same numbers as pyramid.py's)
+            else:
+                d3, nn3 = pointnet2_utils.three_nn(unknown, known)
+                inv = (d3 + 1e-8).reciprocal()
+                w = inv / inv.sum(dim=2, keepdim=True)
+            carried = pointnet2_utils.three_interpolate(known_feats, nn3, w)
         if not torch.is_grad_enabled() and not self.training and carried.is_cuda:
             # inference: one batched GEMM per layer (BatchNorm folded), skip concatenation never materialised
             parts = [carried] if unknow_feats is None else [carried, unknow_feats]

@@ -166,6 +166,40 @@ class _ThreeNN(Function):
 three_nn = _ThreeNN.apply
 
 
+@torch.no_grad()
+def three_nn_weights(unknown: torch.Tensor, known: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(idx (B, N, 3) int32, weight (B, N, 3)) = three_nn + the normalised inverse distances of PointnetFPModule.forward
+    (pointnet2_modules.py:147-150: dist_recip = 1 / (dist + 1e-8), weight = dist_recip / sum) — search + ONE launch instead of
+    search + sqrt + add + reciprocal + sum + div"""
+    _need(unknown, "unknown"); _need(known, "known")
+    B, N, _ = unknown.size()
+    m = known.size(1)
+    dist2 = torch.empty((B, N, 3), dtype=_f32, device=unknown.device)
+    idx = torch.empty((B, N, 3), dtype=_i32, device=unknown.device)
+    lib = L.load()
+    ws_bytes = lib.jm_three_nn_workspace_bytes(B, N, m)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=unknown.device) if ws_bytes else None
+    L.check(lib.jm_three_nn_ws(B, N, m, L.dev(unknown, _f32, "unknown"), L.dev(known, _f32, "known"), L.dev(dist2, _f32, "dist2"),
+                               L.dev(idx, _i32, "idx"), ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, ws_bytes, L.stream_ptr()),
+            "three_nn")
+    weight = torch.empty((B, N, 3), dtype=_f32, device=unknown.device)
+    L.check(lib.jm_three_nn_weights(B * N, L.dev(dist2, _f32, "dist2"), L.dev(weight, _f32, "weight"), L.stream_ptr()), "three_nn_weights")
+    return idx, weight
+
+
+@torch.no_grad()
+def gather_point_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """src (B, n, w) float32, idx (B, m) int32 -> (B, m, w): src[b, idx[b, j], :] in one launch (backbone.py:170-171's
+    torch.gather on the LI-Fusion pixel coordinates, without the int64 copy of the indices)"""
+    src = src.contiguous()
+    B, n, w = src.shape
+    m = idx.shape[1]
+    out = torch.empty((B, m, w), dtype=_f32, device=src.device)
+    L.check(L.load().jm_gather_point_rows(B, n, m, w, L.dev(src, _f32, "src"), L.dev(idx.contiguous(), _i32, "idx"), L.dev(out, _f32, "out"),
+                                          L.stream_ptr()), "gather_point_rows")
+    return out
+
+
 class _ThreeInterpolate(Function):
     @staticmethod
     def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
@@ -263,8 +297,8 @@ class BallQueryGrid:
 
     def query(self, new_xyz, r0, ns0, r1=0.0, ns1=0):
         B, npoint = new_xyz.shape[0], new_xyz.shape[1]
-        idx0 = torch.zeros((B, npoint, ns0), dtype=_i32, device=new_xyz.device)
-        idx1 = torch.zeros((B, npoint, ns1), dtype=_i32, device=new_xyz.device) if ns1 else None
+        idx0 = torch.empty((B, npoint, ns0), dtype=_i32, device=new_xyz.device)      # (the kernels write 0 into the slots of an empty ball)
+        idx1 = torch.empty((B, npoint, ns1), dtype=_i32, device=new_xyz.device) if ns1 else None
         if prof.enabled and prof.only is None:
             BQ_EVALS.append((prof._key("ball_query"), self.ws, L.load().jm_ball_query_evals_offset(self.B, self.N), self.B * self.N))
         L.check(L.load().jm_ball_query_grid_query(B, self.N, npoint, self.cell_radius, float(r0), ns0, float(r1), ns1,
@@ -296,7 +330,7 @@ class _BallQuery(Function):
         _need(new_xyz, "new_xyz"); _need(xyz, "xyz")
         B, N, _ = xyz.size()
         npoint = new_xyz.size(1)
-        idx = torch.zeros((B, npoint, nsample), dtype=_i32, device=xyz.device)
+        idx = torch.empty((B, npoint, nsample), dtype=_i32, device=xyz.device)              # (empty balls come back as 0 from the kernel)
         ws, ws_bytes = _ball_query_workspace(B, N, xyz.device)
         L.check(L.load().jm_ball_query_ws(B, N, npoint, float(radius), nsample, L.dev(new_xyz, _f32, "new_xyz"),
                                           L.dev(xyz, _f32, "xyz"), L.dev(idx, _i32, "idx"),
@@ -321,8 +355,8 @@ def ball_query_dual(radius0: float, nsample0: int, radius1: float, nsample1: int
         return grid.query(new_xyz, radius0, nsample0, radius1, nsample1)
     B, N, _ = xyz.size()
     npoint = new_xyz.size(1)
-    idx0 = torch.zeros((B, npoint, nsample0), dtype=_i32, device=xyz.device)
-    idx1 = torch.zeros((B, npoint, nsample1), dtype=_i32, device=xyz.device)
+    idx0 = torch.empty((B, npoint, nsample0), dtype=_i32, device=xyz.device)
+    idx1 = torch.empty((B, npoint, nsample1), dtype=_i32, device=xyz.device)
     ws, ws_bytes = _ball_query_workspace(B, N, xyz.device)
     L.check(L.load().jm_ball_query_dual_ws(B, N, npoint, float(radius0), nsample0, float(radius1), nsample1,
                                            L.dev(new_xyz, _f32, "new_xyz"), L.dev(xyz, _f32, "xyz"),

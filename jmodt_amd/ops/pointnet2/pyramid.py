@@ -89,9 +89,7 @@ class FpsPyramid:
                 with prof.scope("fp_neighbours"):
                     for k in range(len(npoints)):
                         unknown = xyz if k == 0 else self._levels[k - 1][1]
-                        d3, nn3 = pointnet2_utils.three_nn(unknown, self._levels[k][1])
-                        inv = (d3 + 1e-8).reciprocal()
-                        w = inv / inv.sum(dim=2, keepdim=True)
+                        nn3, w = pointnet2_utils.three_nn_weights(unknown, self._levels[k][1])
                         ev = torch.cuda.Event()
                         ev.record(side)
                         self._interp.append((nn3, w, ev))

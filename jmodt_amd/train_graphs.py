@@ -100,7 +100,7 @@ class JointGraphs:
                 g = pointnet2_utils.BallQueryGrid(cur, radii[i])
                 grid = g if g.ws is not None else None
             idx, new_xyz = pointnet2_utils.farthest_point_sample_xyz(cur, cfg.sa_npoints[i])
-            xy_i = torch.gather(cur_xy, 1, idx.long().unsqueeze(-1).expand(-1, -1, 2))
+            xy_i = pointnet2_utils.gather_point_rows(cur_xy, idx)
             groupers = list(sa.groupers)
             if len(groupers) == 2:
                 g0, g1 = groupers
@@ -119,9 +119,8 @@ class JointGraphs:
             cur, cur_xy = new_xyz, xy_i
         for k in range(len(levels)):
             unknown = xyz if k == 0 else levels[k - 1]
-            d3, nn3 = pointnet2_utils.three_nn(unknown, levels[k])
-            inv = (d3 + 1e-8).reciprocal()
-            out += [nn3, inv / inv.sum(dim=2, keepdim=True)]
+            nn3, w = pointnet2_utils.three_nn_weights(unknown, levels[k])
+            out += [nn3, w]
         self._meta[tuple(xyz.shape)] = meta
         return tuple(out)
 

@@ -313,7 +313,8 @@ def backbone_forward_rows(engine, xyz: torch.Tensor, image: torch.Tensor, pts_xy
         idx, new_xyz = pyr.level(i)
         with prof.scope(f"rpn_sa{i + 1}"):
             feats = _sa_level_rows(fold, sa, l_xyz[i], l_feats[i], new_xyz, grid=pyr.grid(i))
-        xy_i = torch.gather(l_xy[i], 1, idx.long().unsqueeze(-1).expand(-1, -1, 2))
+        xy_i = (pointnet2_utils.gather_point_rows(l_xy[i], idx) if idx.is_cuda else
+                    torch.gather(l_xy[i], 1, idx.long().unsqueeze(-1).expand(-1, -1, 2)))
         main.wait_event(map_events[i])
         with prof.scope(f"li_fusion{i + 1}"):
             feats = _attention_rows(fold, net.Fusion_Conv[i], feats, R.feature_gather_rows(maps[i], xy_i))
