@@ -446,7 +446,7 @@ def make_joint_state(frames, seed, dev, tiny=False):
     from jmodt_amd import train_joint
     st = make_detect_state(frames, seed, dev, tiny=tiny)
     eng = st["engine"]
-    if os.environ.get("JM_JOINT_ROUTE", "rows") == "rows":
+    if os.environ.get("JM_JOINT_ROUTE", "rows") in ("rows", "graphs", "auto"):
         train_joint.prepare_rows(eng)    # train mode (RPN-head dropout active), BatchNorm on its running statistics: cfg.RPN.FIXED-style
     else:
         eng.train()                      # the un-fused operator route: BatchNorm on batch statistics

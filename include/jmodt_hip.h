@@ -433,6 +433,20 @@ int jm_conv3x3_wino_bias_relu(int b, int h, int w, int cin, int cout, const floa
  * the first convolution (replaces a BatchNorm pass + a ReLU pass over up to 1 GB). */
 int jm_bias_relu_channels_last(long long numel, int channels, float* x, const float* bias, jm_stream_t stream);
 
+/* jm_conv1d_stack_forward on 64-POINT tiles (csrc/conv1d_stack64.hip, round 5): the same stacks (rpn.py:34-58 heads,
+ * pointnet2_modules.py:139-153 feature-propagation MLPs, the hoisted first set-abstraction layer) with the A operand row-major in LDS
+ * and the weights streamed in MFMA B-operand order, each weight register feeding two matrix instructions.  Weights are packed per layer
+ * with jm_conv1d_stack64_pack: layer 0 from the (n_out, c0 + c1) matrix on the concatenated input, layer l > 0 from (n_out, widths[l-1]);
+ * packed holds jm_conv1d_stack64_packed_elems(n_out, k) floats, bias_padded ceil(n_out / 32) * 32 floats (bias NULL: zeros).
+ * n % 64 == 0; _supported says whether the tiles fit the LDS (else: jm_conv1d_stack_forward). */
+int jm_conv1d_stack64_supported(int b, int n, int c0, int c1, int xyz1, int num_layers, const int* widths);
+size_t jm_conv1d_stack64_packed_elems(int n_out, int k);
+int jm_conv1d_stack64_pack(int n_out, int k, const float* w, int ldw, const float* bias, float* packed, float* bias_padded,
+                           jm_stream_t stream);
+int jm_conv1d_stack64_forward(int b, int n, int c0, const float* x0, int c1, const float* x1, int xyz1, int num_layers,
+                              const int* widths, const float* const* packed, const float* const* biases_padded, const int* relu,
+                              int out_point_major, float* out, jm_stream_t stream);
+
 /* A dense layer on a (B, C, n) per-point tensor with FEW points (the coarse end of the backbone: feature propagation level 4,
  * pointnet2_modules.py:139-153, and the LI-Fusion attention block of level 4, backbone.py:35-81), one launch of independent waves
  * (csrc/points_gemm.hip): out = act(W [x1 ; x2] + bias) (* rowscale per point).  x1 (B,k1,n), x2 (B,k2,n) or NULL (k2 = 0): the

@@ -126,6 +126,10 @@ SIGNATURES = {
     "jm_proposal_select_evals_offset": (_Z, [_I, _I, _I]),
     "jm_proposal_select": (_I, [_I, _I, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _Z, _P]),
     "jm_decode_rpn_proposals": (_I, [ctypes.c_longlong, _I, _P, _P, _F, _F, _I, ctypes.POINTER(_F), _I, _P, _P]),
+    "jm_conv1d_stack64_supported": (_I, [_I, _I, _I, _I, _I, _I, _P]),
+    "jm_conv1d_stack64_packed_elems": (_Z, [_I, _I]),
+    "jm_conv1d_stack64_pack": (_I, [_I, _I, _P, _I, _P, _P, _P, _P]),
+    "jm_conv1d_stack64_forward": (_I, [_I, _I, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "jm_points_linear_supported": (_I, [_I, _I, _I, _I, _I]),
     "jm_points_linear": (_I, [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
     "jm_three_nn_weights": (_I, [ctypes.c_longlong, _P, _P, _P]),

@@ -18,7 +18,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SOURCES = ["capi.hip", "fps.hip", "ball_query.hip", "ball_query_grid.hip", "three_nn_grid.hip", "pointnet2_gather.hip", "roipool3d.hip", "iou3d.hip",
-           "feature_gather.hip", "affinity.hip", "affinity_fused.hip", "affinity_train.hip", "affinity_x3.hip", "sa_mlp.hip", "sa_mlp_pm.hip", "sa_dedupe.hip", "sa_mlp_wide.hip", "sa_groups.hip", "sa_xyz.hip", "li_fusion.hip", "image_fusion.hip", "elementwise.hip", "rcnn_lift.hip", "conv1d_stack.hip", "conv_rgb.hip", "conv_wino.hip", "sort.hip", "proposal.hip", "detections.hip", "points_gemm.hip", "rows_gemm.hip", "rows_ops.hip", "rows_chain.hip"]
+           "feature_gather.hip", "affinity.hip", "affinity_fused.hip", "affinity_train.hip", "affinity_x3.hip", "sa_mlp.hip", "sa_mlp_pm.hip", "sa_dedupe.hip", "sa_mlp_wide.hip", "sa_groups.hip", "sa_xyz.hip", "li_fusion.hip", "image_fusion.hip", "elementwise.hip", "rcnn_lift.hip", "conv1d_stack.hip", "conv1d_stack64.hip", "conv_rgb.hip", "conv_wino.hip", "sort.hip", "proposal.hip", "detections.hip", "points_gemm.hip", "rows_gemm.hip", "rows_ops.hip", "rows_chain.hip"]
 HEADERS = ["jm_common.h", "jm_mfma.h", "jm_grid.h", "fps_common.h", "jm_rows.h", os.path.join(ROOT, "include", "jmodt_hip.h"), os.path.join(ROOT, "include", "jm_detmath.h")]
 LIB = os.path.join(HERE, "libjmodt_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")

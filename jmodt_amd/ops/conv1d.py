@@ -14,6 +14,11 @@ from .. import _lib as L
 from .fusion import _pack
 
 _f32 = torch.float32
+import os as _os
+# the 64-point-tile kernel (csrc/conv1d_stack64.hip): 0 never, 1 where it measured faster than the 32-point kernel (single-layer
+# stacks: the hoisted first set-abstraction layers, 13 against 20 us and 76 against 80 us), 2 wherever its tiles fit the LDS
+# (tools/conv1d_bench.py: RPN heads 189 against 187 us, FP1 181 against 160 us — one workgroup per CU, nothing hides its phases)
+TILE64 = int(_os.environ.get("JM_CONV1D_TILE64", "1"))
 
 
 class PackedConv1dStack:
@@ -41,9 +46,28 @@ class PackedConv1dStack:
         self._relu_c = (ctypes.c_int * nl)(*self.relu)
         self._w_c = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in self.w])
         self._b_c = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in self.b])
+        # the 64-point-tile kernel's layout (csrc/conv1d_stack64.hip): layer 0 on the concatenated input, B-operand order
+        lib = L.load()
+        self.w64, self.b64 = [], []
+        for W, b, _ in layers:
+            Wc = W.detach().to(_f32).contiguous()
+            n_out, k = Wc.shape
+            wp = torch.empty((int(lib.jm_conv1d_stack64_packed_elems(n_out, k)),), dtype=_f32, device=dev)
+            bp = torch.empty(((n_out + 31) // 32 * 32,), dtype=_f32, device=dev)
+            bb = b.detach().to(_f32).contiguous() if b is not None else None
+            L.check(lib.jm_conv1d_stack64_pack(n_out, k, L.dev(Wc, _f32, "W"), k, L.dev(bb, _f32, "b") if bb is not None else None,
+                                               ctypes.c_void_p(wp.data_ptr()), ctypes.c_void_p(bp.data_ptr()), L.stream_ptr()), "conv1d_stack64_pack")
+            self.w64.append(wp)
+            self.b64.append(bp)
+        self._w64_c = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in self.w64])
+        self._b64_c = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in self.b64])
 
     def supported(self, B: int, n: int) -> bool:
-        return bool(L.load().jm_conv1d_stack_supported(B, n, self.c0, self.c1, int(self.xyz1), len(self.widths), self._widths_c))
+        return self.supported64(B, n) or bool(L.load().jm_conv1d_stack_supported(B, n, self.c0, self.c1, int(self.xyz1), len(self.widths),
+                                                                                 self._widths_c))
+
+    def supported64(self, B: int, n: int) -> bool:
+        return (TILE64 == 2 or (TILE64 == 1 and len(self.widths) == 1)) and bool(L.load().jm_conv1d_stack64_supported(B, n, self.c0, self.c1, int(self.xyz1), len(self.widths), self._widths_c))
 
     @torch.no_grad()
     def __call__(self, x0: torch.Tensor, x1: Optional[torch.Tensor] = None, point_major: bool = False) -> torch.Tensor:
@@ -56,6 +80,12 @@ class PackedConv1dStack:
             x1 = x1.to(_f32).contiguous()
             assert tuple(x1.shape) == ((B, n, 3) if self.xyz1 else (B, self.c1, n))
         out = torch.empty((B, n, self.widths[-1]) if point_major else (B, self.widths[-1], n), dtype=_f32, device=x0.device)
+        if self.supported64(B, n):
+            L.check(L.load().jm_conv1d_stack64_forward(
+                B, n, self.c0, L.dev(x0, _f32, "x0"), self.c1, L.dev(x1, _f32, "x1") if x1 is not None else None, int(self.xyz1),
+                len(self.widths), self._widths_c, self._w64_c, self._b64_c, self._relu_c, int(point_major), ctypes.c_void_p(out.data_ptr()),
+                L.stream_ptr()), "conv1d_stack64")
+            return out
         L.check(L.load().jm_conv1d_stack_forward(
             B, n, self.c0, L.dev(x0, _f32, "x0"), self.c1, L.dev(x1, _f32, "x1") if x1 is not None else None, int(self.xyz1),
             len(self.widths), self._widths_c, L.dev(self.w0a, _f32, "w0a"),

@@ -805,9 +805,13 @@ def test_rcnn_heads_one_launch_per_layer_vs_rocblas(run):
     (2, 32, 16, 0, False, [5], [True]),
     (1, 96, 259, 0, False, [300, 130], [True, True]),
 ])
-def test_conv1d_stack_vs_fp64(B, n, c0, c1, xyz1, widths, relus):
-    """csrc/conv1d_stack.hip vs the same chain in fp64 torch"""
+@pytest.mark.parametrize("tile64", [0, 2])
+def test_conv1d_stack_vs_fp64(B, n, c0, c1, xyz1, widths, relus, tile64, monkeypatch):
+    """csrc/conv1d_stack.hip (32-point tiles) and csrc/conv1d_stack64.hip (64-point tiles wherever they fit) vs the same chain in
+    fp64 torch"""
+    import jmodt_amd.ops.conv1d as C1
     from jmodt_amd.ops.conv1d import PackedConv1dStack
+    monkeypatch.setattr(C1, "TILE64", tile64)
     g = torch.Generator().manual_seed(B * 1000 + n + c0)
     cin = c0 + c1
     layers, k = [], cin

@@ -24,7 +24,7 @@ run() {   # tag, extra rocprof flags, summarize mode, bench args...
 }
 # MIOpen tunes every new convolution shape on first use (seconds of naive_conv_* kernels on a fresh box): do that outside the profile
 timeout 600 python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /tmp/warm.log 2>&1
-run detect_kernel_stats "--stats" ""   --steps 7 --warmup 3 --no-cpu-baseline --headline-only
+run detect_kernel_stats "--stats" ""   --steps 40 --warmup 3 --no-cpu-baseline --headline-only
 run sa_kernel_stats     "--stats" ""   --workload sa --steps 12 --warmup 3 --no-cpu-baseline
 run ops_kernel_stats    "--stats" ""   --workload ops --steps 7 --warmup 2 --no-cpu-baseline
 for c in FETCH_SIZE WRITE_SIZE MfmaUtil SQ_INSTS_VALU_MFMA_MOPS_F32; do

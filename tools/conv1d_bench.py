@@ -43,5 +43,10 @@ for name, B, n, c0, c1, xyz1, widths, relus in cases:
             if r: x = torch.relu_(x)
         return x
     fl = 2 * B * n * sum(a * b for a, b in zip([c0 + c1] + widths[:-1], widths))
+    import jmodt_amd.ops.conv1d as C1
+    C1.TILE64 = 0
     t_k, t_l = timeit(lambda: st(x0, x1)), timeit(lib)
-    print(f"{name:28s} stack {t_k:8.1f} us ({fl / t_k / 1e6:6.1f} TF)   library {t_l:8.1f} us   max diff {(st(x0, x1) - lib()).abs().max().item():.2e}", flush=True)
+    C1.TILE64 = 2
+    t_64 = timeit(lambda: st(x0, x1)) if st.supported64(B, n) else float("nan")
+    print(f"{name:28s} 32-point tiles {t_k:8.1f} us ({fl / t_k / 1e6:6.1f} TF)   64-point tiles {t_64:8.1f} us ({fl / t_64 / 1e6:6.1f} TF)   library {t_l:8.1f} us   "
+          f"max diff {(st(x0, x1) - lib()).abs().max().item():.2e}", flush=True)
