@@ -89,6 +89,9 @@ def thin_loss(engine, out: Dict[str, torch.Tensor], gt_tids: torch.Tensor, count
     return (out["rpn_cls"].sum() + out["rpn_reg"].sum()) / n + out["rcnn_cls"].sum() + out["rcnn_reg"].sum() + reid
 
 
+import os as _os
+CONV_FIND = bool(int(_os.environ.get("JM_JOINT_CONV_FIND", "1")))    # see joint_step
+
 _bn_lists = {}       # id(engine) -> (registration epoch, [BatchNorm modules], [parameters])
 
 
@@ -140,6 +143,10 @@ def joint_step(engine, xyz, image, pts_xy, gt_tids, optimizer, world: Optional[i
     import torch.distributed as tdist
     from .ops.affinity_train import AffinityTrainState
     params = [p for p in _engine_lists(engine)[1] if p.requires_grad]
+    if CONV_FIND and xyz.is_cuda and not torch.backends.cudnn.benchmark:
+        # MIOpen's find mode for the image branch's convolutions, forward AND backward (a process-wide flag: the autograd engine's
+        # thread sees it too): the kernels it measures at first use instead of the immediate-mode heuristic's
+        torch.backends.cudnn.benchmark = True
     optimizer.zero_grad(set_to_none=True)
     if route == "auto":
         # rows, not graphs: measured on one MI355X (4 frames, tools/joint_stream_probe.py / bench.py) the graphs route takes the
