@@ -447,6 +447,8 @@ def make_joint_state(frames, seed, dev, tiny=False):
     st = make_detect_state(frames, seed, dev, tiny=tiny)
     eng = st["engine"]
     if os.environ.get("JM_JOINT_ROUTE", "rows") in ("rows", "graphs", "auto"):
+        if "JM_JOINT_CONV_FIND" not in os.environ and not tiny:
+            train_joint.CONV_FIND = True     # MIOpen's find mode for the image convolutions, forward and backward (+2 %; seconds at first use)
         train_joint.prepare_rows(eng)    # train mode (RPN-head dropout active), BatchNorm on its running statistics: cfg.RPN.FIXED-style
     else:
         eng.train()                      # the un-fused operator route: BatchNorm on batch statistics

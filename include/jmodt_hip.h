@@ -292,6 +292,12 @@ int jm_proposal_select(int b, int n, const float* scores, const float* proposals
 int jm_decode_rpn_proposals(long long num_points, int reg_channels, const float* xyz, const float* rpn_reg,
                             float loc_scope, float loc_bin_size, int num_head_bin, const float* anchor_hwl,
                             int avg_by_bin, float* proposals, jm_stream_t stream);
+/* jm_decode_rpn_proposals on a STRIDED regression tensor: element (frame b, point p, channel i) at
+ * rpn_reg[b * batch_stride + p * point_stride + i * channel_stride] — e.g. the RPN head's own (B, C, N) output read in place
+ * (point_stride 1, channel_stride N: coalesced, no transposed copy).  xyz (B,n,3), proposals (B,n,7). */
+int jm_decode_rpn_proposals_strided(int b, int n, int reg_channels, const float* xyz, const float* rpn_reg, long long batch_stride,
+                                    long long point_stride, long long channel_stride, float loc_scope, float loc_bin_size,
+                                    int num_head_bin, const float* anchor_hwl, int avg_by_bin, float* proposals, jm_stream_t stream);
 /* RCNN box decode = decode_bbox_target as the detection post-processing calls it (tools/eval.py:108-116;
  * bbox_transform.py:27-260 with roi_box3d (P,7), get_xz_fine=True, get_y_by_bin=False, get_ry_fine=True,
  * RY_WITH_BIN=False): offsets are in the RoI's canonical frame; the result is rotated back by the RoI heading
@@ -464,12 +470,12 @@ int jm_points_linear(int b, int n, int k1, const float* x1, int k2, const float*
  * jm_gather_point_rows: out (B,m,width) = src (B,n,width) rows at idx (B,m) int32 — `torch.gather(l_xy, 1, li_index...)` of
  *   backbone.py:170-171 on the int32 FPS indices.
  * jm_pts_feature: the RoI-pooling input of the RCNN stage (point_rcnn.py:42-44, proposal_target_layer.py:26): rpn_cls (B,N) logits
- *   with element stride ld_cls, xyz (B,N,3), feats (B,C,N) -> out (B,N,2+C) = [sigmoid(cls) > score_thresh, |xyz| / 70 - 0.5,
+ *   at rpn_cls[b * batch_stride_cls + p * ld_cls] (the heads' own channel-major output is read in place), xyz (B,N,3), feats (B,C,N) -> out (B,N,2+C) = [sigmoid(cls) > score_thresh, |xyz| / 70 - 0.5,
  *   features point-major]. */
 int jm_three_nn_weights(long long rows, const float* dist2, float* weight, jm_stream_t stream);
 int jm_gather_point_rows(int b, int n, int m, int width, const float* src, const int* idx, float* out, jm_stream_t stream);
-int jm_pts_feature(int b, int n, int c, const float* rpn_cls, int ld_cls, const float* xyz, const float* feats, float score_thresh,
-                   float* out, jm_stream_t stream);
+int jm_pts_feature(int b, int n, int c, const float* rpn_cls, long long batch_stride_cls, int ld_cls, const float* xyz, const float* feats,
+                   float score_thresh, float* out, jm_stream_t stream);
 
 /* The final LI-Fusion image feature AT THE POINTS (jmodt/detection/modeling/backbone.py:187-195):
  *   feature_gather(relu(bn(conv1x1(cat_i deconv_i(img_i)))), xy)

@@ -134,7 +134,9 @@ SIGNATURES = {
     "jm_points_linear": (_I, [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
     "jm_three_nn_weights": (_I, [ctypes.c_longlong, _P, _P, _P]),
     "jm_gather_point_rows": (_I, [_I, _I, _I, _I, _P, _P, _P, _P]),
-    "jm_pts_feature": (_I, [_I, _I, _I, _P, _I, _P, _P, _F, _P, _P]),
+    "jm_pts_feature": (_I, [_I, _I, _I, _P, ctypes.c_longlong, _I, _P, _P, _F, _P, _P]),
+    "jm_decode_rpn_proposals_strided": (_I, [_I, _I, _I, _P, _P, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _F, _F, _I,
+                                            ctypes.POINTER(_F), _I, _P, _P]),
     "jm_detections_sort": (_I, [_I, _I, _P, _P, _F, _P, _P, _P, _P]),
     "jm_detections_gather": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "jm_decode_rcnn_boxes": (_I, [ctypes.c_longlong, _I, _P, _P, _F, _F, _I, ctypes.POINTER(_F), _I, _P, _P]),

@@ -68,7 +68,7 @@ gather_point_rows_kernel(int n, int m, int width, const float* __restrict__ src,
 // per-point RoI-pooling input [mask, depth, features] (point_rcnn.py:42-44, proposal_target_layer.py:26): mask = sigmoid(cls) >
 // thresh, depth = |xyz| / 70 - 0.5, features transposed from (B, C, N) to point-major through a 32-point x 32-channel LDS tile
 __global__ void __launch_bounds__(256)
-pts_feature_kernel(int N, int C, const float* __restrict__ cls, int ldc, const float* __restrict__ xyz, const float* __restrict__ feats,
+pts_feature_kernel(int N, int C, const float* __restrict__ cls, long long bsc, int ldc, const float* __restrict__ xyz, const float* __restrict__ feats,
                    float thresh, float* __restrict__ out) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -86,7 +86,7 @@ pts_feature_kernel(int N, int C, const float* __restrict__ cls, int ldc, const f
     if (blockIdx.y == 0 && threadIdx.x < 32) {
         const int p = p0 + threadIdx.x;
         if (p < N) {
-            const float x = cls[((size_t)b * N + p) * ldc];
+            const float x = cls[(size_t)b * bsc + (size_t)p * ldc];
             const float s = 1.f / (1.f + expf(-x));
             const float* q = xyz + ((size_t)b * N + p) * 3;
             const float d = sqrtf((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]);
@@ -117,12 +117,12 @@ extern "C" int jm_gather_point_rows(int b, int n, int m, int width, const float*
     return check_launch("gather_point_rows");
 }
 
-extern "C" int jm_pts_feature(int b, int n, int c, const float* rpn_cls, int ld_cls, const float* xyz, const float* feats, float score_thresh,
+extern "C" int jm_pts_feature(int b, int n, int c, const float* rpn_cls, long long batch_stride_cls, int ld_cls, const float* xyz, const float* feats, float score_thresh,
                               float* out, jm_stream_t stream) {
     JM_REQUIRE(b >= 0 && n >= 0 && c >= 0 && ld_cls >= 1, "pts_feature: bad sizes");
     if (b == 0 || n == 0) return JM_OK;
     JM_REQUIRE(rpn_cls && xyz && (c == 0 || feats) && out && b <= 65535, "pts_feature: null pointer / batch > 65535");
     hipLaunchKernelGGL(pts_feature_kernel, dim3((unsigned)divup(n, 32), (unsigned)imax(1, divup(c, 32)), (unsigned)b), dim3(256), 0,
-                       (hipStream_t)stream, n, c, rpn_cls, ld_cls, xyz, feats, score_thresh, out);
+                       (hipStream_t)stream, n, c, rpn_cls, batch_stride_cls, ld_cls, xyz, feats, score_thresh, out);
     return check_launch("pts_feature");
 }

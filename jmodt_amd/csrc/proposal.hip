@@ -227,46 +227,51 @@ extern "C" int jm_proposal_select(int b, int n, const float* scores, const float
 // easydict), so this kernel is checked against the oracle's restatement only ("parity unpinned").
 namespace jm {
 
+// reg element (point p of frame b, channel i) = reg[b * bstride + p * pstride + i * cstride]: point-major rows (bstride = n C, pstride = C,
+// cstride = 1: the reference's (B, N, C) layout) or the RPN head's own (B, C, N) output (pstride = 1, cstride = N: a lane = a point,
+// every channel read is one coalesced 256-byte row — the point-major form walks 304-byte rows with 4-byte loads, 4 x the bytes)
 __global__ void __launch_bounds__(256)
-decode_rpn_kernel(long long total, int C, int nb, int nh, float loc_scope, float bin_size, float a_h, float a_w,
-                  float a_l, int avg_by_bin, const float* __restrict__ xyz, const float* __restrict__ reg,
-                  float* __restrict__ out) {
+decode_rpn_kernel(long long total, int n, long long bstride, long long pstride, long long cstride, int nb, int nh, float loc_scope,
+                  float bin_size, float a_h, float a_w, float a_l, int avg_by_bin, const float* __restrict__ xyz,
+                  const float* __restrict__ reg, float* __restrict__ out) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= total) return;
-    const float* r = reg + p * C;
+    const long long fb = p / n;
+    const float* rbase = reg + fb * bstride + (p - fb * n) * pstride;
+    auto R = [&](int i) { return rbase[(long long)i * cstride]; };
     auto axis = [&](int bin_off, int res_off) {
         if (avg_by_bin) {
             float mx = -INFINITY;
-            for (int i = 0; i < nb; ++i) mx = fmaxf(mx, r[bin_off + i]);
+            for (int i = 0; i < nb; ++i) mx = fmaxf(mx, R(bin_off + i));
             float den = 0.f, num = 0.f;
             for (int i = 0; i < nb; ++i) {
-                const float e = expf(r[bin_off + i] - mx);
+                const float e = expf(R(bin_off + i) - mx);
                 const float centre = (float)i * bin_size + bin_size / 2 - loc_scope;
                 den += e;
-                num += e * (centre + r[res_off + i] * bin_size);
+                num += e * (centre + R(res_off + i) * bin_size);
             }
             return num / den;
         }
         int best = 0;
-        float bv = r[bin_off];
-        for (int i = 1; i < nb; ++i) if (r[bin_off + i] > bv) { bv = r[bin_off + i]; best = i; }   // first maximum
-        return (float)best * bin_size + bin_size / 2 - loc_scope + r[res_off + best] * bin_size;
+        float bv = R(bin_off);
+        for (int i = 1; i < nb; ++i) { const float v = R(bin_off + i); if (v > bv) { bv = v; best = i; } }   // first maximum
+        return (float)best * bin_size + bin_size / 2 - loc_scope + R(res_off + best) * bin_size;
     };
     const float pos_x = axis(0, 2 * nb) + xyz[p * 3 + 0];
     const float pos_z = axis(nb, 3 * nb) + xyz[p * 3 + 2];
     int off = 4 * nb;
-    float pos_y = xyz[p * 3 + 1] + r[off];
+    float pos_y = xyz[p * 3 + 1] + R(off);
     off += 1;
     int rb = 0;
-    float rv = r[off];
-    for (int i = 1; i < nh; ++i) if (r[off + i] > rv) { rv = r[off + i]; rb = i; }
+    float rv = R(off);
+    for (int i = 1; i < nh; ++i) { const float v = R(off + i); if (v > rv) { rv = v; rb = i; } }
     const float two_pi = 6.283185307179586f, pi = 3.141592653589793f;
     const float apc = two_pi / (float)nh;
-    float ry = fmodf((float)rb * apc + r[off + nh + rb] * (apc / 2), two_pi);
+    float ry = fmodf((float)rb * apc + R(off + nh + rb) * (apc / 2), two_pi);
     if (ry < 0.f) ry += two_pi;          // python % is non-negative
     if (ry > pi) ry -= two_pi;
     off += 2 * nh;
-    const float h = r[off] * a_h + a_h, w = r[off + 1] * a_w + a_w, l = r[off + 2] * a_l + a_l;
+    const float h = R(off) * a_h + a_h, w = R(off + 1) * a_w + a_w, l = R(off + 2) * a_l + a_l;
     pos_y += h / 2;                      // proposal_layer.py:33: y becomes the bottom centre
     float* o = out + p * 7;
     o[0] = pos_x; o[1] = pos_y; o[2] = pos_z; o[3] = h; o[4] = w; o[5] = l; o[6] = ry;
@@ -274,19 +279,38 @@ decode_rpn_kernel(long long total, int C, int nb, int nh, float loc_scope, float
 
 }  // namespace jm
 
-extern "C" int jm_decode_rpn_proposals(long long num_points, int reg_channels, const float* xyz, const float* rpn_reg,
-                                       float loc_scope, float loc_bin_size, int num_head_bin, const float* anchor_hwl,
-                                       int avg_by_bin, float* proposals, jm_stream_t stream) {
+static int decode_rpn_launch(long long num_points, int n, long long bstride, long long pstride, long long cstride, int reg_channels,
+                             const float* xyz, const float* rpn_reg, float loc_scope, float loc_bin_size, int num_head_bin,
+                             const float* anchor_hwl, int avg_by_bin, float* proposals, jm_stream_t stream) {
     JM_REQUIRE(num_points >= 0 && loc_bin_size > 0.f && num_head_bin >= 1 && anchor_hwl, "decode_rpn: bad arguments");
     if (num_points == 0) return JM_OK;
     JM_REQUIRE(xyz && rpn_reg && proposals, "decode_rpn: null pointer");
     const int nb = (int)(loc_scope / loc_bin_size) * 2;          // per_loc_bin_num (bbox_transform.py:45)
     JM_REQUIRE(nb >= 1 && reg_channels == 4 * nb + 1 + 2 * num_head_bin + 3,
                "decode_rpn: %d regression channels, expected 4*%d + 1 + 2*%d + 3", reg_channels, nb, num_head_bin);
-    hipLaunchKernelGGL(decode_rpn_kernel, dim3((unsigned)divup(num_points, 256LL)), dim3(256), 0, (hipStream_t)stream,
-                       num_points, reg_channels, nb, num_head_bin, loc_scope, loc_bin_size, anchor_hwl[0], anchor_hwl[1],
-                       anchor_hwl[2], avg_by_bin ? 1 : 0, xyz, rpn_reg, proposals);
-    return check_launch("decode_rpn");
+    hipLaunchKernelGGL(jm::decode_rpn_kernel, dim3((unsigned)jm::divup(num_points, 256LL)), dim3(256), 0, (hipStream_t)stream, num_points, n,
+                       bstride, pstride, cstride, nb, num_head_bin, loc_scope, loc_bin_size, anchor_hwl[0], anchor_hwl[1], anchor_hwl[2],
+                       avg_by_bin ? 1 : 0, xyz, rpn_reg, proposals);
+    return jm::check_launch("decode_rpn");
+}
+
+extern "C" int jm_decode_rpn_proposals(long long num_points, int reg_channels, const float* xyz, const float* rpn_reg,
+                                       float loc_scope, float loc_bin_size, int num_head_bin, const float* anchor_hwl,
+                                       int avg_by_bin, float* proposals, jm_stream_t stream) {
+    const int n = (int)(num_points < 1 ? 1 : (num_points > 0x7fffffffLL ? 0x7fffffffLL : num_points));     // one "frame" of rows
+    JM_REQUIRE(num_points <= 0x7fffffffLL, "decode_rpn: too many points");
+    return decode_rpn_launch(num_points, n, 0, reg_channels, 1, reg_channels, xyz, rpn_reg, loc_scope, loc_bin_size, num_head_bin, anchor_hwl,
+                             avg_by_bin, proposals, stream);
+}
+
+extern "C" int jm_decode_rpn_proposals_strided(int b, int n, int reg_channels, const float* xyz, const float* rpn_reg, long long batch_stride,
+                                               long long point_stride, long long channel_stride, float loc_scope, float loc_bin_size,
+                                               int num_head_bin, const float* anchor_hwl, int avg_by_bin, float* proposals,
+                                               jm_stream_t stream) {
+    JM_REQUIRE(b >= 0 && n >= 0 && batch_stride >= 0 && point_stride >= 1 && channel_stride >= 1, "decode_rpn_strided: bad arguments");
+    if (b == 0 || n == 0) return JM_OK;
+    return decode_rpn_launch((long long)b * n, n, batch_stride, point_stride, channel_stride, reg_channels, xyz, rpn_reg, loc_scope,
+                             loc_bin_size, num_head_bin, anchor_hwl, avg_by_bin, proposals, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -719,7 +719,9 @@ class DetectAffinityEngine(nn.Module):
         def heads():
             both = self._rpn_heads_stack(feats)
             if both is not None:                                   # (B, 1 + C, N): one launch for the two heads
-                return both[:, :1].transpose(1, 2).contiguous(), both[:, 1:].transpose(1, 2).contiguous()
+                # (B, N, 1) / (B, N, C) VIEWS of the stack's channel-major output: the decode, the score sort's input copy and the
+                # RoI-pooling input read it in place (two transposed copies per step gone, the decode's loads coalesced)
+                return both[:, :1].transpose(1, 2), both[:, 1:].transpose(1, 2)
             cls = self._head_forward("rpn_cls", self.rpn.rpn_cls_layer, feats).transpose(1, 2).contiguous()   # (B, N, 1)
             reg = self._head_forward("rpn_reg", self.rpn.rpn_reg_layer, feats).transpose(1, 2).contiguous()   # (B, N, C)
             return cls, reg
@@ -750,11 +752,11 @@ class DetectAffinityEngine(nn.Module):
         pf = torch.empty((B, N, 2 + C), dtype=torch.float32, device=xyz.device)
         cls = rpn_out["rpn_cls"]
         if (xyz.is_cuda and feats.is_contiguous() and xyz.is_contiguous() and feats.dtype == torch.float32 and cls.dtype == torch.float32
-                and cls.stride(0) == N * cls.stride(1)):
+                and cls.stride(0) >= 0 and cls.stride(1) >= 1):
             # mask + depth + transposed features as ONE launch (csrc/elementwise.hip) instead of seven element-wise passes
             import ctypes
             from . import _lib as L
-            L.check(L.load().jm_pts_feature(B, N, C, ctypes.c_void_p(cls.data_ptr()), int(cls.stride(1)), L.dev(xyz, torch.float32, "xyz"),
+            L.check(L.load().jm_pts_feature(B, N, C, ctypes.c_void_p(cls.data_ptr()), int(cls.stride(0)), int(cls.stride(1)), L.dev(xyz, torch.float32, "xyz"),
                                             L.dev(feats, torch.float32, "features"), float(cfg.rpn_score_thresh),
                                             ctypes.c_void_p(pf.data_ptr()), L.stream_ptr()), "pts_feature")
             return pf

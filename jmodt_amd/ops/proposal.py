@@ -93,9 +93,16 @@ def decode_rpn_proposals(xyz: torch.Tensor, rpn_reg: torch.Tensor, loc_scope: fl
     lib = L.load()
     B, N, C = rpn_reg.shape
     xyz = xyz.contiguous().to(_f32)
-    rpn_reg = rpn_reg.contiguous().to(_f32)
     out = torch.empty((B, N, 7), dtype=_f32, device=xyz.device)
     anchor = (ctypes.c_float * 3)(*[float(a) for a in anchor_size])
+    if rpn_reg.is_cuda and rpn_reg.dtype == _f32 and not rpn_reg.is_contiguous() and min(rpn_reg.stride()) >= 1:
+        # a strided view — the heads' own (B, C, N) output seen as (B, N, C): read in place, one coalesced row per channel
+        L.check(lib.jm_decode_rpn_proposals_strided(B, N, C, L.dev(xyz, _f32, "xyz"), ctypes.c_void_p(rpn_reg.data_ptr()), rpn_reg.stride(0),
+                                                    rpn_reg.stride(1), rpn_reg.stride(2), float(loc_scope), float(loc_bin_size),
+                                                    int(num_head_bin), anchor, int(bool(avg_by_bin)), ctypes.c_void_p(out.data_ptr()),
+                                                    L.stream_ptr()), "decode_rpn_proposals")
+        return out
+    rpn_reg = rpn_reg.contiguous().to(_f32)
     L.check(lib.jm_decode_rpn_proposals(B * N, C, L.dev(xyz, _f32, "xyz"), L.dev(rpn_reg, _f32, "rpn_reg"),
                                         float(loc_scope), float(loc_bin_size), int(num_head_bin), anchor,
                                         int(bool(avg_by_bin)), ctypes.c_void_p(out.data_ptr()), L.stream_ptr()),

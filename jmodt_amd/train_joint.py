@@ -90,7 +90,7 @@ def thin_loss(engine, out: Dict[str, torch.Tensor], gt_tids: torch.Tensor, count
 
 
 import os as _os
-CONV_FIND = bool(int(_os.environ.get("JM_JOINT_CONV_FIND", "1")))    # see joint_step
+CONV_FIND = bool(int(_os.environ.get("JM_JOINT_CONV_FIND", "0")))    # see joint_step (bench.py switches it on: seconds of search per shape)
 
 _bn_lists = {}       # id(engine) -> (registration epoch, [BatchNorm modules], [parameters])
 

@@ -83,7 +83,7 @@ def test_pts_feature_one_launch(B, N, C):
     xyz = (torch.rand(B, N, 3, generator=g) * 60).to(DEV)
     feats = torch.randn(B, C, N, generator=g).to(DEV)
     out = torch.empty((B, N, 2 + C), device=DEV)
-    L.check(L.load().jm_pts_feature(B, N, C, ctypes.c_void_p(cls.data_ptr()), 1, L.dev(xyz, torch.float32, "xyz"), L.dev(feats, torch.float32, "f"),
+    L.check(L.load().jm_pts_feature(B, N, C, ctypes.c_void_p(cls.data_ptr()), N, 1, L.dev(xyz, torch.float32, "xyz"), L.dev(feats, torch.float32, "f"),
                                     0.3, ctypes.c_void_p(out.data_ptr()), L.stream_ptr()), "pts_feature")
     assert torch.equal(out[:, :, 0], (torch.sigmoid(cls[:, :, 0]) > 0.3).float())
     depth = torch.norm(xyz.double(), p=2, dim=2) / 70.0 - 0.5
@@ -109,3 +109,15 @@ def test_points_linear_vs_float64(B, n, k1, k2, nout, act):
     got = points_linear(x1, W, b, act, x2=x2, rowscale=scale, rowscale_stride=4, out_rows=nout + (-nout) % 4)
     want_rows = (want * scale[:, 0].double().view(B, 1, n)).transpose(1, 2).reshape(B * n, nout)
     assert float((got[:, :nout].double() - want_rows).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_decode_rpn_proposals_reads_a_channel_major_view_in_place():
+    """the RPN heads' (B, 1 + C, N) output seen as a (B, N, C) view: same proposals as from the contiguous copy, bit for bit"""
+    from jmodt_amd.ops.proposal import decode_rpn_proposals
+    g = torch.Generator().manual_seed(3)
+    B, N, C = 3, 1000, 76
+    both = torch.randn(B, 1 + C, N, generator=g).to(DEV)
+    xyz = (torch.rand(B, N, 3, generator=g) * 40).to(DEV)
+    view = both[:, 1:].transpose(1, 2)
+    assert not view.is_contiguous()
+    assert torch.equal(decode_rpn_proposals(xyz, view), decode_rpn_proposals(xyz, view.contiguous()))
