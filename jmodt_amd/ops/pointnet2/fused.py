@@ -133,14 +133,23 @@ def _pack_k8(W: torch.Tensor, b: torch.Tensor):
     return wp, bp
 
 
+_width_cache = weakref.WeakKeyDictionary()    # module -> (registration epoch, width)
+
+
 def out_width(mlp: nn.Sequential) -> int:
-    """output channels of a SharedMLP (its last convolution's width)"""
+    """output channels of a SharedMLP (its last convolution's width); the module walk (16 per composed step, 1100 `named_modules`
+    frames) is repeated only after a module / parameter registration somewhere in the process (_registry.EPOCH)"""
+    from ..._registry import EPOCH
+    hit = _width_cache.get(mlp)
+    if hit is not None and hit[0] == EPOCH[0]:
+        return hit[1]
     w = None
     for m in mlp.modules():
         if isinstance(m, (nn.Conv2d, nn.Conv1d)):
             w = m.out_channels
     if w is None:
         raise ValueError("SharedMLP without a convolution")
+    _width_cache[mlp] = (EPOCH[0], int(w))
     return int(w)
 
 
