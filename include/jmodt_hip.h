@@ -680,6 +680,17 @@ int jm_rows_linear_dgrad(int m, const int* m_dev, int n, int k, const float* dy,
 /* dw (n, k) (+)= dy (m, n)^T x (m, k), dbias (n) (+)= column sums of dy (NULL: skipped).  The m rows are split over
  * jm_rows_wgrad_splits(m, n, k) partials in ws, reduced in split order: deterministic, no float atomics; a short contraction
  * (one split) writes dw / dbias straight from the accumulators and needs no workspace */
+/* The image branch's kernel == stride transposed convolutions (backbone.py:150-157,187-189: DeConv) as GEMMs whose (rows, columns)
+ * matrix is stored PIXEL-SHUFFLED: x (m = B h w, c) = the channels-last input map as rows, wt (k k r, c) with
+ * wt[(dy k + dx) r + rr][ci] = W[ci][rr][dy][dx], y = the channels-last (B, h k, w k, ctot) map, this level's r channels at coff:
+ * y[b][y k + dy][x k + dx][coff + rr] = sum_ci x[(b, y, x)][ci] wt[...][ci] (no bias).  _dgrad: dx (m, c) from dy in that layout;
+ * _wgrad: dwt (k k r, c), workspace jm_rows_wgrad_workspace_bytes(m, k k r, c).  c, r, ctot, coff multiples of 4. */
+int jm_rows_deconv_forward(int m, int c, int k, int r, int h, int w, const float* x, int ldx, const float* wt, float* y, int ctot, int coff,
+                           jm_stream_t stream);
+int jm_rows_deconv_dgrad(int m, int c, int k, int r, int h, int w, const float* dy, int ctot, int coff, const float* wt, float* dx, int lddx,
+                         jm_stream_t stream);
+int jm_rows_deconv_wgrad(int m, int c, int k, int r, int h, int w, const float* dy, int ctot, int coff, const float* x, int ldx, float* dwt,
+                         void* ws, size_t ws_bytes, jm_stream_t stream);
 int jm_rows_wgrad_splits(int m, int n, int k);
 size_t jm_rows_wgrad_workspace_bytes(int m, int n, int k);
 int jm_rows_linear_wgrad(int m, const int* m_dev, int n, int k, const float* dy, int lddy, const float* x, int ldx,

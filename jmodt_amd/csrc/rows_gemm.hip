@@ -33,7 +33,38 @@ constexpr int RBM = 128, RBN = 128, RBK = 32, RLDP = RBM + 4;
 constexpr int RNLD = RBK / 8;       // float4 loads per thread and operand per k-tile (128 x RBK floats / 256 threads / 4)
 enum { RM_FWD = 0, RM_DGRAD = 1, RM_WGRAD = 2 };
 
+// A matrix stored PIXEL-SHUFFLED (round 5: the image branch's kernel == stride transposed convolutions as GEMMs, backbone.py:187-193):
+// the (rows m = (b, y, x), columns n = ((dy k + dx) r + rr)) matrix is the channels-last map Y (B, h k, w k, ctot) with
+// element (m, n) at Y[b][y k + dy][x k + dx][coff + rr] — the GEMM's output rows land where ConvTranspose2d(kernel = stride = k) puts
+// them, and the backward's operand is read from there; r % 4 == 0, so a float4 along n stays inside one pixel
+struct RShuffle { int on, k, r, h, w, ctot, coff; };
+
+// the address is ADDITIVE in a row part and a column part: shuf(m, n) = row_part(m) + col_part(n).  Rows are walked incrementally
+// (RowPos: one division per tile, not per element — the first form divided five times per stored element and was slower than the
+// library convolution it replaces)
+struct RowPos { int b, y, x; };
+__device__ __forceinline__ RowPos row_pos(const RShuffle& s, int m) {
+    const int t = m / s.w;
+    return RowPos{t / s.h, t % s.h, m - t * s.w};
+}
+__device__ __forceinline__ void row_advance(const RShuffle& s, RowPos& p, int d) {
+    p.x += d;
+    while (p.x >= s.w) {
+        p.x -= s.w;
+        if (++p.y == s.h) { p.y = 0; ++p.b; }
+    }
+}
+__device__ __forceinline__ size_t row_part(const RShuffle& s, const RowPos& p) {
+    return (((size_t)(p.b * s.h + p.y) * s.k) * ((size_t)s.w * s.k) + (size_t)p.x * s.k) * s.ctot;
+}
+__device__ __forceinline__ size_t col_part(const RShuffle& s, int n) {
+    const int q = n / s.r, rr = n - q * s.r, dy = q / s.k, dx = q - dy * s.k;
+    return ((size_t)dy * ((size_t)s.w * s.k) + dx) * s.ctot + s.coff + rr;
+}
+__device__ __forceinline__ size_t shuf_addr(const RShuffle& s, int m, int n) { return row_part(s, row_pos(s, m)) + col_part(s, n); }
+
 struct RGemm {
+    RShuffle sh;                   // FWD: the OUTPUT is stored shuffled; DGRAD / WGRAD: the A operand (dY) is read shuffled
     int M, N, K;                   // output rows, output columns, contraction length
     const int* m_dev;              // FWD / DGRAD: valid rows = min(M, *m_dev); WGRAD: valid contraction = min(K, *m_dev)
     const float* A; int lda;       // FWD / DGRAD: (M, K) rows; WGRAD: (K, M) — element (row r, contraction c) = A[c * lda + r]
@@ -99,6 +130,23 @@ rows_gemm_kernel(RGemm p) {
         const int m0 = (tile / ntn) * RBM, n0 = (tile % ntn) * RBN;
         float4 ra[RNLD], rb[RNLD];
         bool a_in[RNLD], b_in[RNLD];
+        // shuffled A operand: the part of the address that is fixed for the tile (DGRAD: this thread's rows; WGRAD: its columns) and,
+        // for WGRAD, the walking position of the contraction row of every load slot
+        size_t sh_fix[RNLD];
+        RowPos sh_pos[RNLD];
+        int sh_at[RNLD];
+        if (p.sh.on && MODE != RM_FWD) {
+#pragma unroll
+            for (int i = 0; i < RNLD; ++i) {
+                if (MODE == RM_DGRAD) {
+                    sh_fix[i] = row_part(p.sh, row_pos(p.sh, min(m0 + t_row[i], Mv - 1)));
+                } else {
+                    sh_fix[i] = col_part(p.sh, min(m0 + d_r4[i], p.M - 4));
+                    sh_at[i] = min(k_begin + d_k[i], max(Kv - 1, 0));
+                    sh_pos[i] = row_pos(p.sh, sh_at[i]);
+                }
+            }
+        }
         auto g_load = [&](int k0) {          // k0 = absolute contraction index of the k-tile's first element
 #pragma unroll
             for (int i = 0; i < RNLD; ++i) {
@@ -106,7 +154,12 @@ rows_gemm_kernel(RGemm p) {
                     const int kc = k0 + d_k[i];
                     a_in[i] = kc < k_end; b_in[i] = a_in[i];
                     const size_t kk = (size_t)min(kc, max(Kv - 1, 0));
-                    ra[i] = *reinterpret_cast<const float4*>(p.A + kk * p.lda + min(m0 + d_r4[i], p.M - 4));
+                    if (p.sh.on) {
+                        if ((int)kk > sh_at[i]) { row_advance(p.sh, sh_pos[i], (int)kk - sh_at[i]); sh_at[i] = (int)kk; }   // (k-tiles ascend)
+                        ra[i] = *reinterpret_cast<const float4*>(p.A + row_part(p.sh, sh_pos[i]) + sh_fix[i]);
+                    } else {
+                        ra[i] = *reinterpret_cast<const float4*>(p.A + kk * p.lda + min(m0 + d_r4[i], p.M - 4));
+                    }
                     rb[i] = *reinterpret_cast<const float4*>(p.B + kk * p.ldb + min(n0 + d_r4[i], p.N - 4));
                 } else {
                     const int m = min(m0 + t_row[i], Mv - 1);
@@ -115,6 +168,8 @@ rows_gemm_kernel(RGemm p) {
                     const int kc = min(k, p.K - 4);
                     if (MODE == RM_FWD && p.A2 != nullptr && kc >= p.K1)
                         ra[i] = *reinterpret_cast<const float4*>(p.A2 + (size_t)m * p.lda2 + (kc - p.K1));
+                    else if (MODE == RM_DGRAD && p.sh.on)
+                        ra[i] = *reinterpret_cast<const float4*>(p.A + sh_fix[i] + col_part(p.sh, kc));
                     else
                         ra[i] = *reinterpret_cast<const float4*>(p.A + (size_t)m * p.lda + kc);
                     if (MODE == RM_FWD) {
@@ -195,11 +250,25 @@ rows_gemm_kernel(RGemm p) {
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            // shuffled output: this thread's 16 rows of the block, walked from the block's first one
+            size_t sh_row[16];
+            if (MODE == RM_FWD && p.sh.on) {
+                RowPos rp = row_pos(p.sh, min(m0 + wm * 64 + i * 32 + 4 * lk, max(Mv - 1, 0)));
+                int at = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int off = (r & 3) + 8 * (r >> 2);
+                    row_advance(p.sh, rp, off - at);
+                    at = off;
+                    sh_row[r] = row_part(p.sh, rp);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int col = n0 + wn * 64 + j * 32 + lr;
                 const bool cok = col < p.N;
                 const float bv = (MODE == RM_FWD && p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+                const size_t sh_col = (MODE == RM_FWD && p.sh.on) ? col_part(p.sh, min(col, p.N - 1)) : 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -216,7 +285,7 @@ rows_gemm_kernel(RGemm p) {
                         if (p.accumulate && ok) v += out[(size_t)row * p.ldo + col];
                     }
                     if (MODE == RM_WGRAD && p.splits == 1 && p.accumulate && ok) v += out[(size_t)row * p.ldo + col];
-                    if (ok) out[(size_t)row * p.ldo + col] = v;
+                    if (ok) out[(MODE == RM_FWD && p.sh.on) ? sh_row[r] + sh_col : (size_t)row * p.ldo + col] = v;
                 }
             }
         }
@@ -390,6 +459,68 @@ int jm_rows_linear_dgrad(int m, const int* m_dev, int n, int k, const float* dy,
     else
         hipLaunchKernelGGL((rows_gemm_kernel<RM_DGRAD>), dim3((unsigned)persistent_grid(tiles)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("rows_linear_dgrad");
+}
+
+// ---- kernel == stride transposed convolution (backbone.py:150-157 DeConv) as a GEMM with a pixel-shuffled output: x (m = B h w, c) rows of
+// the channels-last input map, wt (k k r, c) with wt[(dy k + dx) r + rr][ci] = W[ci][rr][dy][dx]; y = the channels-last (B, h k, w k, ctot)
+// map, this level in channels coff .. coff + r
+static int deconv_check(int m, int c, int k, int r, int h, int w, int ctot, int coff) {
+    JM_REQUIRE(m >= 0 && c >= 4 && c % 4 == 0 && k >= 1 && r >= 4 && r % 4 == 0 && h >= 1 && w >= 1 && m % (h * w) == 0 && ctot % 4 == 0 &&
+                   coff % 4 == 0 && coff >= 0 && coff + r <= ctot,
+               "rows_deconv: channels and the output slice in multiples of 4, m = B h w (m %d, c %d, k %d, r %d, h %d, w %d, ctot %d, coff %d)", m,
+               c, k, r, h, w, ctot, coff);
+    return JM_OK;
+}
+
+int jm_rows_deconv_forward(int m, int c, int k, int r, int h, int w, const float* x, int ldx, const float* wt, float* y, int ctot, int coff,
+                           jm_stream_t stream) {
+    if (int e = deconv_check(m, c, k, r, h, w, ctot, coff)) return e;
+    JM_REQUIRE(x && wt && y && ldx >= c && ldx % 4 == 0, "rows_deconv_forward: bad arguments");
+    if (m == 0) return JM_OK;
+    RGemm p{};
+    p.sh = RShuffle{1, k, r, h, w, ctot, coff};
+    p.M = m; p.N = k * k * r; p.K = c; p.A = x; p.lda = ldx; p.K1 = c; p.B = wt; p.ldb = c; p.out = y; p.ldo = p.N; p.splits = 1;
+    const long long tiles = (long long)divup(m, RBM) * divup(p.N, RBN);
+    hipLaunchKernelGGL((rows_gemm_kernel<RM_FWD>), dim3((unsigned)persistent_grid(tiles)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("rows_deconv_forward");
+}
+
+int jm_rows_deconv_dgrad(int m, int c, int k, int r, int h, int w, const float* dy, int ctot, int coff, const float* wt, float* dx, int lddx,
+                         jm_stream_t stream) {
+    if (int e = deconv_check(m, c, k, r, h, w, ctot, coff)) return e;
+    JM_REQUIRE(dy && wt && dx && lddx >= c, "rows_deconv_dgrad: bad arguments");
+    if (m == 0) return JM_OK;
+    RGemm p{};
+    p.sh = RShuffle{1, k, r, h, w, ctot, coff};
+    p.M = m; p.N = c; p.K = k * k * r; p.A = dy; p.lda = p.K; p.B = wt; p.ldb = c; p.out = dx; p.ldo = lddx; p.splits = 1;
+    const long long tiles = (long long)divup(m, RBM) * divup(c, RBN);
+    hipLaunchKernelGGL((rows_gemm_kernel<RM_DGRAD>), dim3((unsigned)persistent_grid(tiles)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("rows_deconv_dgrad");
+}
+
+int jm_rows_deconv_wgrad(int m, int c, int k, int r, int h, int w, const float* dy, int ctot, int coff, const float* x, int ldx, float* dwt,
+                         void* ws, size_t ws_bytes, jm_stream_t stream) {
+    if (int e = deconv_check(m, c, k, r, h, w, ctot, coff)) return e;
+    JM_REQUIRE(dy && x && dwt && ldx >= c && ldx % 4 == 0, "rows_deconv_wgrad: bad arguments");
+    const int n = k * k * r;
+    const int splits = jm_rows_wgrad_splits(m, n, c);
+    if (splits > 1 && (ws_bytes < jm_rows_wgrad_workspace_bytes(m, n, c) || !ws)) {
+        set_error("rows_deconv_wgrad: workspace of %zu bytes, need %zu", ws_bytes, jm_rows_wgrad_workspace_bytes(m, n, c));
+        return JM_EWORKSPACE;
+    }
+    JM_REQUIRE(m > 0, "rows_deconv_wgrad: no rows");
+    RGemm p{};
+    p.sh = RShuffle{1, k, r, h, w, ctot, coff};
+    p.M = n; p.N = c; p.K = m; p.A = dy; p.lda = n; p.B = x; p.ldb = ldx; p.splits = splits;
+    if (splits > 1) { p.out = (float*)ws; p.ldo = c; } else { p.out = dwt; p.ldo = c; }
+    hipLaunchKernelGGL((rows_gemm_kernel<RM_WGRAD>), dim3((unsigned)(divup(n, RBM) * divup(c, RBN)), (unsigned)splits), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    if (splits > 1) {
+        const int work = n * (c / 4);
+        hipLaunchKernelGGL(rows_wgrad_reduce_kernel, dim3((unsigned)divup(work, 256)), dim3(256), 0, (hipStream_t)stream, n, c, splits, m,
+                           (const int*)nullptr, (const float*)ws, dwt, c, (const float*)nullptr, (float*)nullptr, 0);
+    }
+    return check_launch("rows_deconv_wgrad");
 }
 
 int jm_rows_wgrad_splits(int m, int n, int k) {

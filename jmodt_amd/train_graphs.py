@@ -353,8 +353,10 @@ def forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local, rois_per
     mark("pooled")
     n = float(rpn_cls.shape[1])
     rpn_loss = (rpn_cls.sum() + rpn_reg.sum()) / n
-    rpn_loss.backward()
-    mark("rpn_backward")
+    rcnn_first = bool(int(os.environ.get("JM_JOINT_RCNN_FIRST", "0")))
+    if not rcnn_first:
+        rpn_loss.backward()
+        mark("rpn_backward")
     side = side_stream(dev, 3) if engine.overlap else main
     if side is not main:
         side.wait_event(pooled_ev)            # not main's position NOW: that would put the RCNN behind the backbone's whole backward
@@ -371,6 +373,9 @@ def forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local, rois_per
         rcnn_loss.backward()
         total = rcnn_loss.detach() + rpn_loss.detach()
     mark("rcnn")
+    if rcnn_first:
+        rpn_loss.backward()
+        mark("rpn_backward")
     # every stream that ran a piece of the step is joined before the all-reduce / optimizer on the main stream
     if side is not main:
         gt_tids.record_stream(side)

@@ -256,18 +256,37 @@ def _image_pyramid(fold: BnFold, net, image: torch.Tensor) -> List[torch.Tensor]
     return maps
 
 
+import os as _os
+DECONV_GEMM = bool(int(_os.environ.get("JM_DECONV_GEMM", "0")))
+
+
 def _image_fusion_map(fold: BnFold, net, maps: List[torch.Tensor]) -> torch.Tensor:
     """relu(bn(conv1x1(cat_i deconv_i(img_i)))) (backbone.py:187-193), BatchNorm folded.  The training path keeps the reference's
     un-composed form: four kernel == stride transposed convolutions, their 64-channel concatenation, one 1x1 convolution —
     204 GFLOP per 4 frames forward + backward against 363 for the composed form the inference engine gathers from
     (tools/joint_image_probe.py: 5.1 against 6.1 ms)"""
-    de = torch.cat([F.conv_transpose2d(m, dc.weight, None, stride=dc.stride, padding=dc.padding, output_padding=dc.output_padding)
-                    for dc, m in zip(net.DeConv, maps)], dim=1)
     Wf, bf = fold.conv4d(net.image_fusion_conv)
     # the deconvolutions' biases ride through the (linear) 1x1 convolution: Wf (de + b_d) + bf = Wf de + (Wf b_d + bf) — a 64-vector
     # product instead of a pass over the concatenated map, and no bias inside any library convolution
     biases = [dc.bias if dc.bias is not None else m.new_zeros(dc.out_channels) for dc, m in zip(net.DeConv, maps)]
-    b_eff = bf + Wf.reshape(Wf.shape[0], -1) @ torch.cat(biases)
+    Wf2 = Wf.reshape(Wf.shape[0], -1)
+    b_eff = bf + Wf2 @ torch.cat(biases)
+    ks = [dc.kernel_size[0] for dc in net.DeConv]
+    plain = all(tuple(dc.kernel_size) == tuple(dc.stride) == (k, k) and tuple(dc.padding) == (0, 0) and tuple(dc.output_padding) == (0, 0)
+                and dc.groups == 1 and dc.in_channels % 4 == 0 and dc.out_channels % 4 == 0 for dc, k in zip(net.DeConv, ks))
+    if DECONV_GEMM and plain and maps[0].is_cuda and Wf2.shape[0] % 4 == 0:
+        # kernel == stride transposed convolutions ARE GEMMs with a pixel-shuffled output: one launch per level writes its channel
+        # slice of the channels-last concatenation (csrc/rows_gemm.hip), the 1x1 fusion convolution + ReLU is a rows layer on it.
+        # OPT-IN (JM_DECONV_GEMM=1): exact (tests/test_gpu_rows.py) but measured SLOWER than the library route — 5.7 ms of
+        # rows_gemm_kernel time on the image stream against 3.5 ms of MIOpen for the same 204 GFLOP per 4 frames (tools/joint_timeline.sh;
+        # the 128 x 128 x 32 tiles waste three quarters of their columns on the 32- and 64-wide outputs and the operands are
+        # HBM-bound skinny matrices); the joint step stays at 23.9 ms either way
+        de = R.deconv_pyramid(maps, [dc.weight for dc in net.DeConv], ks)                     # (B, 64, H, W) channels-last
+        B, ctot, H, W = de.shape
+        y = R.rows_mlp(de.permute(0, 2, 3, 1).reshape(B * H * W, ctot), [(Wf2, b_eff)], [1])  # (B H W, q)
+        return y.view(B, H, W, Wf2.shape[0]).permute(0, 3, 1, 2)                              # = channels-last (B, q, H, W)
+    de = torch.cat([F.conv_transpose2d(m, dc.weight, None, stride=dc.stride, padding=dc.padding, output_padding=dc.output_padding)
+                    for dc, m in zip(net.DeConv, maps)], dim=1)
     return _BiasReluInplace.apply(F.conv2d(de, Wf, None), b_eff)
 
 

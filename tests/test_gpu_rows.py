@@ -333,3 +333,28 @@ def test_joint_step_rows_route_updates_every_parameter(tiny):
     assert all(bool(torch.isfinite(p.grad).all()) for p in params)
     moved = sum(int(not torch.equal(a, b)) for a, b in zip(before, params))
     assert moved >= len(params) - 12, (moved, len(params))
+
+
+@pytest.mark.parametrize("B,H,W,chans,rs,ks", [(2, 32, 64, (16, 32, 64, 64), (16, 16, 16, 16), (2, 4, 8, 16)),
+                                              (1, 16, 48, (8, 12), (4, 8), (2, 4)), (3, 8, 8, (20,), (4,), (1,))])
+def test_deconv_pyramid_gemms_vs_conv_transpose2d(B, H, W, chans, rs, ks):
+    """the kernel == stride transposed convolutions as pixel-shuffled GEMMs (rows_gemm.hip: jm_rows_deconv_*): forward, gradient of
+    every map and of every weight against F.conv_transpose2d under autograd in float64"""
+    import torch.nn.functional as F
+    from jmodt_amd.ops import rows as R
+    g = torch.Generator().manual_seed(11)
+    maps = [torch.randn(B, c, H // k, W // k, generator=g).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            for c, k in zip(chans, ks)]
+    ws = [(torch.randn(c, r, k, k, generator=g) * 0.2).to(DEV).requires_grad_(True) for c, r, k in zip(chans, rs, ks)]
+    de = R.deconv_pyramid(maps, ws, ks)
+    assert de.shape == (B, sum(rs), H, W) and de.is_contiguous(memory_format=torch.channels_last)
+    go = torch.randn(de.shape, generator=g).to(DEV)
+    de.backward(go)
+    m64 = [m.detach().double().requires_grad_(True) for m in maps]
+    w64 = [w.detach().double().requires_grad_(True) for w in ws]
+    ref = torch.cat([F.conv_transpose2d(m, w, None, stride=k) for m, w, k in zip(m64, w64, ks)], dim=1)
+    ref.backward(go.double())
+    close(de, ref, what="deconv pyramid forward")
+    for i, (m, w) in enumerate(zip(maps, ws)):
+        close(m.grad, m64[i].grad, tol=2e-4, what=f"d map {i}")
+        close(w.grad, w64[i].grad, tol=2e-4, what=f"d weight {i}")
