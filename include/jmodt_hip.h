@@ -768,6 +768,12 @@ typedef struct {
 int jm_rows_mlp_forward(const jm_rows_mlp_t* d, jm_stream_t stream);
 int jm_rows_mlp_backward(const jm_rows_mlp_t* d, const jm_rows_mlp_grad_t* g, jm_stream_t stream);
 int jm_rows_tanh_grad(int m, const int* m_dev, int n, const float* dy, int ldd, const float* y, int ldy, float* out, int ldo, jm_stream_t stream);
+/* The backward in two phases (round 5: weight gradients off the critical path): `_chain` = the data-gradient chain only, keeping every
+ * layer's pre-activation gradient in dys[l] (m, widths[l]) — a HOST array of nl device pointers, caller-allocated — and writing dx1 /
+ * dx2; `_wgrads` = dw / db of every layer from dys and the saved activations (scratch[] unused by both).  The caller orders phase 2
+ * behind phase 1 on whatever stream it likes.  dys[nl - 1] is not written when the last layer has no activation (dout is read instead). */
+int jm_rows_mlp_backward_chain(const jm_rows_mlp_t* d, const jm_rows_mlp_grad_t* g, float* const* dys, jm_stream_t stream);
+int jm_rows_mlp_backward_wgrads(const jm_rows_mlp_t* d, const jm_rows_mlp_grad_t* g, float* const* dys, jm_stream_t stream);
 typedef struct {
     int nl, groups, max_rows;        /* layers (>= 2), groups, row capacity (= groups * nsample) */
     const int* rows_dev; const int* offsets; const int* row_point; const int* row_group;   /* jm_sa_rows_plan's outputs */
@@ -788,6 +794,10 @@ typedef struct {
 } jm_sa_scale_grad_t;
 int jm_sa_scale_forward(const jm_sa_scale_t* d, jm_stream_t stream);
 int jm_sa_scale_backward(const jm_sa_scale_t* d, const jm_sa_scale_grad_t* g, jm_stream_t stream);
+/* jm_sa_scale_backward in two phases, as above: dys[l] (max_rows, widths[l]); `_chain` also produces du and df (the gradient that goes
+ * upstream), `_wgrads` every weight / bias gradient (it reads du) */
+int jm_sa_scale_backward_chain(const jm_sa_scale_t* d, const jm_sa_scale_grad_t* g, float* const* dys, jm_stream_t stream);
+int jm_sa_scale_backward_wgrads(const jm_sa_scale_t* d, const jm_sa_scale_grad_t* g, float* const* dys, jm_stream_t stream);
 
 /* Eval-mode BatchNorm folded into the preceding convolution, for all n (convolution, BatchNorm) pairs of a network in one launch:
  * wf[l] (rows_l, cols_l) = w[l] * s[soff[l] + row] with s = gamma / sqrt(running_var + eps) (pytorch_utils.py:21-33 / backbone.py

@@ -95,6 +95,92 @@ int jm_rows_mlp_backward(const jm_rows_mlp_t* d, const jm_rows_mlp_grad_t* g, jm
     return JM_OK;
 }
 
+// ---- the backward in TWO phases (round 5: weight gradients off the critical path).  Nothing downstream waits for a weight gradient
+// until the optimizer, but on one stream every layer's wgrad (+ its split-K reduce) sits between two links of the data-gradient chain
+// the NEXT module's backward waits for: 97 wgrad launches of ~60 us per joint-mode step.  Phase 1 (`_chain`) runs the data-gradient chain
+// only and keeps every layer's pre-activation gradient dys[l] (m, widths[l]); phase 2 (`_wgrads`) computes the weight / bias
+// gradients from them and from the saved activations — on whatever stream the caller orders behind phase 1.  Same kernels, same bits.
+static const float* mlp_dy(const jm_rows_mlp_t* d, const jm_rows_mlp_grad_t* g, float* const* dys, int l, int* ld) {
+    if (l == d->nl - 1 && d->acts[l] == 0) { *ld = g->lddout; return g->dout; }      // no activation behind the last layer: dout IS it
+    *ld = d->widths[l];
+    return dys[l];
+}
+
+int jm_rows_mlp_backward_chain(const jm_rows_mlp_t* d, const jm_rows_mlp_grad_t* g, float* const* dys, jm_stream_t stream) {
+    JM_REQUIRE(d && g && dys && d->nl >= 1 && d->nl <= JM_ROWS_MAX_LAYERS && g->dout, "rows_mlp_backward_chain: bad arguments");
+    const int last = d->nl - 1, m = d->m;
+    if (d->acts[last] == 1)
+        JM_TRY(jm_rows_relu_mask(m, d->m_dev, d->widths[last], g->dout, g->lddout, d->y[last], d->widths[last], dys[last], d->widths[last], stream));
+    else if (d->acts[last] == 2)
+        JM_TRY(jm_rows_tanh_grad(m, d->m_dev, d->widths[last], g->dout, g->lddout, d->y[last], d->widths[last], dys[last], d->widths[last], stream));
+    for (int l = last; l >= 1; --l) {
+        const int n = d->widths[l], k = d->widths[l - 1];
+        int lddy;
+        const float* dy = mlp_dy(d, g, dys, l, &lddy);
+        const float* x = d->y[l - 1];
+        JM_TRY(jm_rows_linear_dgrad(m, d->m_dev, n, k, dy, lddy, d->w[l], d->ldw[l], d->acts[l - 1] == 1 ? x : nullptr, k, 0, dys[l - 1], k, stream));
+        if (d->acts[l - 1] == 2) JM_TRY(jm_rows_tanh_grad(m, d->m_dev, k, dys[l - 1], k, x, k, dys[l - 1], k, stream));
+    }
+    int lddy;
+    const float* dy = mlp_dy(d, g, dys, 0, &lddy);
+    const int n = d->widths[0];
+    if (g->dx1) JM_TRY(jm_rows_linear_dgrad(m, d->m_dev, n, d->k1, dy, lddy, d->w[0], d->ldw[0], nullptr, 0, 0, g->dx1, d->k1, stream));
+    if (g->dx2 && d->k2)
+        JM_TRY(jm_rows_linear_dgrad(m, d->m_dev, n, d->k2, dy, lddy, d->w[0] + d->k1, d->ldw[0], nullptr, 0, 0, g->dx2, d->k2, stream));
+    return JM_OK;
+}
+
+int jm_rows_mlp_backward_wgrads(const jm_rows_mlp_t* d, const jm_rows_mlp_grad_t* g, float* const* dys, jm_stream_t stream) {
+    JM_REQUIRE(d && g && dys && d->nl >= 1 && d->nl <= JM_ROWS_MAX_LAYERS && g->dout, "rows_mlp_backward_wgrads: bad arguments");
+    const int m = d->m;
+    for (int l = d->nl - 1; l >= 1; --l) {
+        int lddy;
+        const float* dy = mlp_dy(d, g, dys, l, &lddy);
+        const int n = d->widths[l], k = d->widths[l - 1];
+        JM_TRY(jm_rows_linear_wgrad(m, d->m_dev, n, k, dy, lddy, d->y[l - 1], k, g->dw[l], g->lddw[l], g->db[l], 0, g->ws, g->ws_bytes, stream));
+    }
+    int lddy;
+    const float* dy = mlp_dy(d, g, dys, 0, &lddy);
+    const int n = d->widths[0];
+    JM_TRY(jm_rows_linear_wgrad(m, d->m_dev, n, d->k1, dy, lddy, d->x1, d->ldx1, g->dw[0], g->lddw[0], g->db[0], 0, g->ws, g->ws_bytes, stream));
+    if (d->k2)
+        JM_TRY(jm_rows_linear_wgrad(m, d->m_dev, n, d->k2, dy, lddy, d->x2, d->ldx2, g->dw[0] + d->k1, g->lddw[0], nullptr, 0, g->ws, g->ws_bytes, stream));
+    return JM_OK;
+}
+
+int jm_sa_scale_backward_chain(const jm_sa_scale_t* d, const jm_sa_scale_grad_t* g, float* const* dys, jm_stream_t stream) {
+    JM_REQUIRE(d && g && dys && d->nl >= 2 && d->nl <= JM_ROWS_MAX_LAYERS && g->dout, "sa_scale_backward_chain: bad arguments");
+    const int R = d->max_rows, C = d->widths[d->nl - 1], H1 = d->widths[0];
+    JM_TRY(jm_sa_rows_pool_grad(R, d->rows_dev, C, g->dout, g->lddout, d->out, d->ldo, d->argrow, d->row_group, dys[d->nl - 1], C, stream));
+    for (int l = d->nl - 1; l >= 1; --l) {
+        const int n = d->widths[l], k = d->widths[l - 1];
+        JM_TRY(jm_rows_linear_dgrad(R, d->rows_dev, n, k, dys[l], n, d->w[l], k, d->h[l - 1], k, 0, dys[l - 1], k, stream));
+    }
+    if (d->c > 0) {
+        JM_REQUIRE(g->du, "sa_scale_backward_chain: du");
+        (void)jm_zero_async(g->du, (size_t)d->points * H1 * sizeof(float), (hipStream_t)stream);
+        JM_TRY(jm_sa_rows_scatter_add(R, d->rows_dev, H1, dys[0], H1, d->row_point, g->du, H1, stream));
+        if (g->df) JM_TRY(jm_rows_linear_dgrad(d->points, nullptr, H1, d->c, g->du, H1, d->w1f, d->c, nullptr, 0, g->df_accumulate, g->df, d->c, stream));
+    }
+    return check_launch("sa_scale_backward_chain");
+}
+
+int jm_sa_scale_backward_wgrads(const jm_sa_scale_t* d, const jm_sa_scale_grad_t* g, float* const* dys, jm_stream_t stream) {
+    JM_REQUIRE(d && g && dys && d->nl >= 2 && d->nl <= JM_ROWS_MAX_LAYERS && g->dw1 && g->db1 && g->dw4, "sa_scale_backward_wgrads: bad arguments");
+    const int R = d->max_rows, H1 = d->widths[0];
+    hipStream_t s = (hipStream_t)stream;
+    for (int l = d->nl - 1; l >= 1; --l) {
+        const int n = d->widths[l], k = d->widths[l - 1];
+        JM_TRY(jm_rows_linear_wgrad(R, d->rows_dev, n, k, dys[l], n, d->h[l - 1], k, g->dw[l], k, g->db[l], 0, g->ws, g->ws_bytes, stream));
+    }
+    JM_TRY(jm_rows_linear_wgrad(R, d->rows_dev, H1, 4, dys[0], H1, d->delta, 4, g->dw4, 4, g->db1, 0, g->ws, g->ws_bytes, stream));
+    const int ldw1 = 3 + d->c;
+    hipLaunchKernelGGL(rows_copy_cols_kernel, dim3((unsigned)divup(H1 * 3, 256)), dim3(256), 0, s, H1, 3, (const float*)g->dw4, 4, g->dw1, ldw1, 0);
+    if (d->c > 0)
+        JM_TRY(jm_rows_linear_wgrad(d->points, nullptr, H1, d->c, g->du, H1, d->f, d->ldf, g->dw1 + 3, ldw1, nullptr, 0, g->ws, g->ws_bytes, stream));
+    return check_launch("sa_scale_backward_wgrads");
+}
+
 int jm_sa_scale_forward(const jm_sa_scale_t* d, jm_stream_t stream) {
     JM_REQUIRE(d && d->nl >= 2 && d->nl <= JM_ROWS_MAX_LAYERS && d->groups > 0 && d->xyz && d->w1x && d->b1, "sa_scale_forward: bad arguments");
     const int H1 = d->widths[0], R = d->max_rows;

@@ -224,6 +224,8 @@ def _rows_forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local, ro
     img = _image_stream(engine, xyz.device)
     if img is not None:
         main.wait_stream(img)
+    from .ops import rows as R
+    R.release_deferred(xyz.device)           # the weight-gradient passes (ops/rows.py: _WgradHook) ran on streams of their own
     return total
 
 

@@ -358,3 +358,28 @@ def test_deconv_pyramid_gemms_vs_conv_transpose2d(B, H, W, chans, rs, ks):
     for i, (m, w) in enumerate(zip(maps, ws)):
         close(m.grad, m64[i].grad, tol=2e-4, what=f"d map {i}")
         close(w.grad, w64[i].grad, tol=2e-4, what=f"d weight {i}")
+
+
+def test_weight_gradients_on_their_own_stream_give_the_same_gradients(monkeypatch):
+    """ops/rows.py's opt-in split (the data-gradient chain on the module's stream, the weight gradients behind it on another one,
+    handed over by a _WgradHook node): same numbers as the one-stream backward for a dense stack and a set-abstraction level"""
+    from jmodt_amd.ops import rows as R
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(700, 32, generator=g).to(DEV)
+    x2 = torch.randn(700, 8, generator=g).to(DEV)
+    Ws = [(torch.randn(64, 40, generator=g) * 0.2).to(DEV), (torch.randn(16, 64, generator=g) * 0.2).to(DEV)]
+    bs = [torch.randn(64, generator=g).to(DEV) * 0.1, None]
+    go = torch.randn(700, 16, generator=g).to(DEV)
+
+    def run(split):
+        monkeypatch.setattr(R, "SPLIT_WGRAD", split)
+        xa, xb = x.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+        W = [w.clone().requires_grad_(True) for w in Ws]
+        b0 = bs[0].clone().requires_grad_(True)
+        y = R.rows_mlp(xa, [(W[0], b0), (W[1], None)], [1, 0], x2=xb)
+        y.backward(go)
+        R.release_deferred(DEV)
+        torch.cuda.synchronize()
+        return [y.detach(), xa.grad, xb.grad, W[0].grad, W[1].grad, b0.grad]
+    for a, b in zip(run(False), run(True)):
+        assert torch.equal(a, b)
