@@ -2,6 +2,9 @@
 #pragma once
 #include "jm_common.h"
 
+#ifndef JM_EGRID
+#define JM_EGRID 8192
+#endif
 #define JM_ROWS_CHUNKS 128      /* most row chunks of a two-stage (deterministic) reduction; rows_chunks() picks fewer for short tensors */
 
 namespace jm {

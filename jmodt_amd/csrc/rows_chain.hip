@@ -46,7 +46,7 @@ extern "C" {
 int jm_rows_tanh_grad(int m, const int* m_dev, int n, const float* dy, int ldd, const float* y, int ldy, float* out, int ldo, jm_stream_t stream) {
     JM_REQUIRE(m >= 0 && n > 0 && dy && y && out, "rows_tanh_grad: bad arguments");
     if (m == 0) return JM_OK;
-    hipLaunchKernelGGL(rows_tanh_grad_kernel, dim3((unsigned)grid_for((long long)m * n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, m, m_dev, n, dy,
+    hipLaunchKernelGGL(rows_tanh_grad_kernel, dim3((unsigned)grid_for((long long)m * n, 256, JM_EGRID)), dim3(256), 0, (hipStream_t)stream, m, m_dev, n, dy,
                        ldd, y, ldy, out, ldo);
     return check_launch("rows_tanh_grad");
 }

@@ -30,7 +30,10 @@ namespace jm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int RBM = 128, RBN = 128, RBK = 32, RLDP = RBM + 4;
-constexpr int RNLD = RBK / 8;       // float4 loads per thread and operand per k-tile (128 x RBK floats / 256 threads / 4)
+constexpr int RNLD = RBK / 8;
+#ifndef JM_PGRID
+#define JM_PGRID 2048
+#endif       // float4 loads per thread and operand per k-tile (128 x RBK floats / 256 threads / 4)
 enum { RM_FWD = 0, RM_DGRAD = 1, RM_WGRAD = 2 };
 
 // A matrix stored PIXEL-SHUFFLED (round 5: the image branch's kernel == stride transposed convolutions as GEMMs, backbone.py:187-193):
@@ -415,7 +418,7 @@ static bool small_problem(int m, const int* m_dev, int n) {
     return m_dev == nullptr && (long long)divup(m, RBM) * divup(n, RBN) < 96 && (long long)divup(m, 32) * divup(n, 32) <= 16384;
 }
 
-static int persistent_grid(long long tiles) { return (int)(tiles < 1 ? 1 : (tiles > 2048 ? 2048 : tiles)); }
+static int persistent_grid(long long tiles) { return (int)(tiles < 1 ? 1 : (tiles > JM_PGRID ? JM_PGRID : tiles)); }
 
 }  // namespace jm
 

@@ -320,7 +320,7 @@ int jm_sa_rows_h1(int rows, const int* rows_dev, int h, const float* u, int ldu,
     JM_REQUIRE(rows >= 0 && h > 0 && h % 4 == 0 && (u || b1) && w1x && xyz && row_point && row_group && h1 && ldh % 4 == 0 && (!u || ldu % 4 == 0),
                "sa_rows_h1: bad arguments (h %d, ldu %d, ldh %d)", h, ldu, ldh);
     if (rows == 0) return JM_OK;
-    hipLaunchKernelGGL(sa_rows_h1_kernel, dim3((unsigned)grid_for((long long)rows * (h / 4), 256, 8192)), dim3(256), 0, (hipStream_t)stream, rows,
+    hipLaunchKernelGGL(sa_rows_h1_kernel, dim3((unsigned)grid_for((long long)rows * (h / 4), 256, JM_EGRID)), dim3(256), 0, (hipStream_t)stream, rows,
                        rows_dev, h, u, ldu, b1, w1x, xyz, ctr, row_point, row_group, h1, ldh, delta);
     return check_launch("sa_rows_h1");
 }
@@ -336,7 +336,7 @@ int jm_sa_rows_pool_grad(int rows, const int* rows_dev, int c, const float* dout
                          const int* row_group, float* dh, int ldd, jm_stream_t stream) {
     JM_REQUIRE(rows >= 0 && c > 0 && dout && out && argrow && row_group && dh, "sa_rows_pool_grad: bad arguments");
     if (rows == 0) return JM_OK;
-    hipLaunchKernelGGL(sa_rows_pool_grad_kernel, dim3((unsigned)grid_for((long long)rows * c, 256, 8192)), dim3(256), 0, (hipStream_t)stream, rows,
+    hipLaunchKernelGGL(sa_rows_pool_grad_kernel, dim3((unsigned)grid_for((long long)rows * c, 256, JM_EGRID)), dim3(256), 0, (hipStream_t)stream, rows,
                        rows_dev, c, dout, lddo, out, ldo, argrow, row_group, dh, ldd);
     return check_launch("sa_rows_pool_grad");
 }
@@ -345,7 +345,7 @@ int jm_sa_rows_scatter_add(int rows, const int* rows_dev, int h, const float* dh
                            jm_stream_t stream) {
     JM_REQUIRE(rows >= 0 && h > 0 && dh1 && row_point && du, "sa_rows_scatter_add: bad arguments");
     if (rows == 0) return JM_OK;
-    hipLaunchKernelGGL(sa_rows_scatter_kernel, dim3((unsigned)grid_for((long long)rows * h, 256, 8192)), dim3(256), 0, (hipStream_t)stream, rows,
+    hipLaunchKernelGGL(sa_rows_scatter_kernel, dim3((unsigned)grid_for((long long)rows * h, 256, JM_EGRID)), dim3(256), 0, (hipStream_t)stream, rows,
                        rows_dev, h, dh1, ldd, row_point, du, ldu);
     return check_launch("sa_rows_scatter_add");
 }
@@ -388,7 +388,7 @@ int jm_rows_relu_mask(int m, const int* m_dev, int n, const float* dy, int ldd, 
     JM_REQUIRE(m >= 0 && n > 0 && n % 4 == 0 && ldd % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && dy && y && out,
                "rows_relu_mask: bad arguments (n %d, ldd %d, ldy %d, ldo %d)", n, ldd, ldy, ldo);
     if (m == 0) return JM_OK;
-    hipLaunchKernelGGL(rows_relu_mask_kernel, dim3((unsigned)grid_for((long long)m * (n / 4), 256, 8192)), dim3(256), 0, (hipStream_t)stream, m, m_dev,
+    hipLaunchKernelGGL(rows_relu_mask_kernel, dim3((unsigned)grid_for((long long)m * (n / 4), 256, JM_EGRID)), dim3(256), 0, (hipStream_t)stream, m, m_dev,
                        n, dy, ldd, y, ldy, out, ldo);
     return check_launch("rows_relu_mask");
 }
