@@ -66,7 +66,13 @@ conv1d_stack_kernel(ConvStackParams p) {
         const int r = tid & 31, q0 = tid >> 5;
         if (p.s0) {
             const float* xb = p.x0 + (size_t)bi_ * p.c0 * n + row0 + r;
-            for (int c = q0; c < p.c0p; c += 8) X0[c * SW_LD + r] = c < p.c0 ? xb[(size_t)c * n] : 0.f;
+            for (int cb = q0; cb < p.c0p; cb += 64) {           // eight channel rows in flight per thread (see li_fusion.hip)
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int c = cb + 8 * u; v[u] = c < p.c0 ? xb[(size_t)c * n] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int c = cb + 8 * u; if (c < p.c0p) X0[c * SW_LD + r] = v[u]; }
+            }
         }
         if (p.s1) {
             if (p.xyz1) {

@@ -67,9 +67,25 @@ attention_fusion_kernel(LiFusionParams p) {
         const int r = tid & 31, c0 = tid >> 5;
         const float* Ib = p.I + (size_t)bi_ * ic * n + row0 + r;
         const float* Pb = p.P + (size_t)bi_ * pc * n + row0 + r;
-        for (int c = c0; c < icp; c += 8) XI[c * SW_LD + r] = c < ic ? Ib[(size_t)c * n] : 0.f;
-        if (p_lds)
-            for (int c = c0; c < pcp; c += 8) XP[c * SW_LD + r] = c < pc ? Pb[(size_t)c * n] : 0.f;
+        // eight channel rows in flight per thread: one load per iteration waits a whole global-load latency per channel row (round 5:
+        // measured on conv1d_stack64.hip's staging, where that WAS the kernel's time)
+        auto stage = [&](float* X, const float* Xb, int cw, int cwp) __attribute__((always_inline)) {
+            for (int cb = c0; cb < cwp; cb += 64) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = cb + 8 * u;
+                    v[u] = c < cw ? Xb[(size_t)c * n] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = cb + 8 * u;
+                    if (c < cwp) X[c * SW_LD + r] = v[u];
+                }
+            }
+        };
+        stage(XI, Ib, ic, icp);
+        if (p_lds) stage(XP, Pb, pc, pcp);
     }
     lds_barrier();
     // the P operand: the LDS tile, or — wide levels — the (pc, n) tensor itself: a k-major tile of consecutive points is
