@@ -26,7 +26,7 @@ Rules (the ones torch.cuda.make_graphed_callables lives by, plus address keying)
     dictionary kept around): its AccumulateGrad nodes remember the streams they were created on, the engine orders the capture
     stream against those, and the capture forks into a stream that never joins (observed as a crash in capture_end).
 """
-from typing import Callable, Dict, List, Optional, Sequence, Tuple
+from typing import Callable, Dict, Sequence
 
 import torch
 

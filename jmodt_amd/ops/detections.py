@@ -25,7 +25,6 @@ from .. import _lib as L
 from ..ext import iou3d_cuda
 from .affinity import pairwise_affinity
 from .association import association_cost
-from .iou3d.iou3d_utils import boxes3d_to_bev_torch
 from .proposal import CLS_MEAN_SIZE
 
 _f32 = torch.float32

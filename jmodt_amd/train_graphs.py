@@ -20,18 +20,17 @@ Sections and their streams (F: geometry, I: image, M: main, R: RCNN):
 The host enqueues ~30 graph launches, a dozen event waits, the thin loss, ONE backward, the all-reduce and Adam instead of ~1050
 kernel launches through ~60 autograd Functions.  Requires frozen BatchNorm statistics (train_joint.freeze_bn), like the rows route.
 """
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import train_rows as TR
-from .graphed import GraphedSection, mark_static
+from .graphed import GraphedSection
 from .ops import rows as R
 from .ops.pointnet2 import pointnet2_utils
 from .ops.pointnet2.pyramid import side_stream
-from .ops.roipool3d.roipool3d_utils import roipool3d_canonical_gpu
 
 
 def _split_params(all_pairs, mods: Sequence[nn.Module]):
