@@ -15,6 +15,7 @@ backbone.py:159-196, rpn.py:71-87, rcnn.py:158-202), same outputs, with
   * the image branch's 3x3 convolutions and the deconvolution pyramid on MIOpen's autograd in channels-last memory (not a
     SURVEY.md §8 row), the final fusion map composed per level as detector._image_fusion_map does.
 """
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -361,10 +362,29 @@ def backbone_forward_rows(engine, xyz: torch.Tensor, image: torch.Tensor, pts_xy
     return out
 
 
+# RoI sets are full of exact copies (cyclic roipool padding): centres picked from copies of one point are copies of one another
+# (same coordinates, same neighbour list, hence bit-identical features), so the NEXT level's rows are planned on the first centre of
+# every such class — the training-path form of the inference engine's representative centres (csrc/sa_dedupe.hip)
+CANON_CENTRES = os.environ.get("JM_ROWS_CANON_CENTRES", "1") != "0"
+
+
+def _centre_canon(canon: torch.Tensor, pick: torch.Tensor) -> torch.Tensor:
+    """canon (R, n) int32 canonical point of every point of a set, pick (R, m) the points chosen as centres -> (R, m) int32: the
+    first centre whose point has the same canonical point.  The gradient of a copy's feature row then lands on its representative's
+    row — the same parameters and the same pooled points receive it (max-pool hands the gradient to ONE of the tied copies in the
+    reference as well, pointnet2_modules.py:58-61)"""
+    cp = torch.gather(canon, 1, pick.long())
+    m = cp.shape[1]
+    slot = torch.arange(m, dtype=torch.int32, device=cp.device)
+    same = cp.unsqueeze(2) == cp.unsqueeze(1)                                # (R, m, m): [r, i, j] centre j is a copy of centre i
+    return torch.where(same, slot.view(1, 1, m), slot.new_full((), m)).amin(dim=2)
+
+
 def rcnn_forward_rows(engine, pts_input: torch.Tensor, fold: BnFold, count: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """RCNN.forward (rcnn.py:176-202) on pooled RoI points (R, S, 5 + C): rcnn_cls (R, 1), rcnn_reg (R, 46), rcnn_feat (R, 512).
-    count (R,) int32: distinct points per RoI (rows count .. S - 1 are cyclic copies, roipool3d_kernel.cu:123-160) — the first
-    level's rows are then planned on the canonical points only"""
+    count (R,) int32: distinct points per RoI (rows count .. S - 1 are cyclic copies, roipool3d_kernel.cu:123-160) — every level's
+    rows are then planned on canonical entries only: the first level's on the canonical points, the later ones on the first of
+    the centres that were picked from copies of one point (_centre_canon)"""
     net = engine.rcnn_net
     Rn, S, Cin = pts_input.shape
     k = net.rcnn_input_channel
@@ -387,12 +407,16 @@ def rcnn_forward_rows(engine, pts_input: torch.Tensor, fold: BnFold, count: Opti
         with prof.scope(f"rcnn_sa{li + 1}"):
             n = l_xyz.shape[1]
             if sa.npoint is not None:
-                _, new_xyz = pointnet2_utils.farthest_point_sample_xyz(l_xyz, sa.npoint)
-                feats = _sa_level_rows(fold, sa, l_xyz, feats, new_xyz, canon=canon if li == 0 else None)
+                pick, new_xyz = pointnet2_utils.farthest_point_sample_xyz(l_xyz, sa.npoint)
+                feats = _sa_level_rows(fold, sa, l_xyz, feats, new_xyz, canon=canon)
                 l_xyz = new_xyz
+                if canon is not None and CANON_CENTRES:
+                    canon = _centre_canon(canon, pick)
+                else:
+                    canon = None
             else:       # GroupAll: one group of all n points per RoI, coordinates not re-centred (pointnet2_utils.py:273-290)
                 idx = torch.arange(n, dtype=torch.int32, device=xyz.device).expand(Rn, 1, n).contiguous()
-                plan = R.RowsPlan(idx, n)
+                plan = R.RowsPlan(idx, n, canon)
                 feats = R.sa_scale_rows(feats, l_xyz.reshape(-1, 3), None, plan, [fold.unit(u) for u in sa.mlps[0]])
                 l_xyz = None
     ncls = net.cls_layer[-1].conv.out_channels

@@ -383,3 +383,49 @@ def test_weight_gradients_on_their_own_stream_give_the_same_gradients(monkeypatc
         return [y.detach(), xa.grad, xb.grad, W[0].grad, W[1].grad, b0.grad]
     for a, b in zip(run(False), run(True)):
         assert torch.equal(a, b)
+
+
+def test_rcnn_rows_on_canonical_centres_same_outputs_same_gradients_fewer_rows(tiny, monkeypatch):
+    """RoI sets full of cyclic copies (roipool3d_kernel.cu:123-160): planning levels 2 and 3 on the first of every class of copied
+    centres leaves the forward bit-identical (copies have bit-identical features, max-pool is idempotent) and moves each copy's
+    gradient to its representative — the parameters' gradients agree to rounding (summation order)"""
+    from jmodt_amd import train_rows as TR
+    from jmodt_amd.ops import rows as R
+    eng = tiny[0]
+    S = eng.cfg.rcnn_num_points
+    Rn = 12
+    k = eng.rcnn_net.rcnn_input_channel
+    Cf = eng.rcnn_net.merge_down_layer[0].conv.in_channels - eng.rcnn_net.xyz_up_layer[-1].conv.out_channels
+    g = torch.Generator().manual_seed(11)
+    base = torch.randn(Rn, S, k + Cf, generator=g)
+    base[:, :, :3] *= 0.6
+    count = torch.tensor([1, 3, 7, 20, 33, 64, 100, S, 5, 2, 50, 17], dtype=torch.int32)[:Rn].clamp(max=S)
+    slot = torch.arange(S).view(1, S) % count.view(-1, 1).long()
+    pts = torch.gather(base, 1, slot.unsqueeze(-1).expand(-1, -1, k + Cf)).to(DEV)                 # rows count .. S - 1 are cyclic copies
+    count = count.to(DEV)
+    seen = []
+    plan_init = R.RowsPlan.__init__
+
+    def counting(self, idx, n, canon=None):
+        plan_init(self, idx, n, canon)
+        seen[-1].append(self.rows_dev)
+    monkeypatch.setattr(R.RowsPlan, "__init__", counting)
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(TR, "CANON_CENTRES", on)
+        seen.append([])
+        eng.zero_grad(set_to_none=True)
+        out = TR.rcnn_forward_rows(eng, pts, TR.BnFold(eng), count)
+        w = rnd(*out["rcnn_feat"].shape, seed=5)
+        ((out["rcnn_feat"] * w).sum() + out["rcnn_cls"].sum() + (out["rcnn_reg"] * rnd(*out["rcnn_reg"].shape, seed=6)).sum()).backward()
+        res[on] = ({kk: v.detach().clone() for kk, v in out.items()},
+                   {kk: v.grad.detach().clone() for kk, v in eng.rcnn_net.named_parameters() if v.grad is not None})
+    eng.zero_grad(set_to_none=True)
+    rows = [[int(r) for r in s_] for s_ in seen]
+    print("rows per level, copies kept / canonical centres:", rows)
+    assert rows[0][0] == rows[1][0] and all(a >= b for a, b in zip(rows[0], rows[1])) and sum(rows[1]) < sum(rows[0])
+    for kk in res[False][0]:
+        assert torch.equal(res[False][0][kk], res[True][0][kk]), kk
+    assert res[False][1].keys() == res[True][1].keys() and len(res[True][1]) > 10
+    for kk, want in res[False][1].items():
+        close(res[True][1][kk], want, tol=2e-4, what=kk)
