@@ -295,42 +295,186 @@ rows_gemm_kernel(RGemm p) {
     }
 }
 
-// dW[n, k] (+)= sum over the split partials in split order, and the same for the bias gradient's (splits, N) partials (threads
-// behind the N * K / 4 weight quads); four independent chains per thread so that the partials' loads overlap
-__global__ void rows_wgrad_reduce_kernel(int N, int K, int splits, int m, const int* __restrict__ m_dev, const float* __restrict__ part,
-                                         float* __restrict__ dW, int ldw, const float* __restrict__ bias_part, float* __restrict__ dbias,
-                                         int accumulate) {
-    splits = wgrad_live_splits(dev_count(m, m_dev), splits);          // the splits rows_gemm_kernel<RM_WGRAD> actually wrote
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// dW[n, k] (+)= sum over the split partials, and the same for the bias gradient's (splits, N) partials (items behind the N * K / 4
+// weight quads).  A workgroup = 32 items x 8 split groups: group g sums splits g, g + 8, ... on four independent chains, the groups
+// are added in group order through LDS — a fixed order whatever the launch, so the result is reproducible (no float atomics); the
+// first form (one thread per quad walking ALL splits) took 15 - 30 us on 17 workgroups for a 128 x 128 weight
+__global__ void __launch_bounds__(256)
+rows_wgrad_reduce_kernel(int N, int K, int splits, int m, const int* __restrict__ m_dev, const float* __restrict__ part,
+                         float* __restrict__ dW, int ldw, const float* __restrict__ bias_part, float* __restrict__ dbias, int accumulate) {
+    __shared__ float4 sh[8][32];
+    splits = wgrad_live_splits(dev_count(m, m_dev), splits);          // the splits the weight-gradient kernel actually wrote
+    const int item = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
     const int quads = N * (K / 4);
-    if (i < quads) {
-        const int n = i / (K / 4), k4 = (i % (K / 4)) * 4;
-        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
-        int t = 0;
-        for (; t + 4 <= splits; t += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)t * N + n) * K + k4);
-            const float4 w = *reinterpret_cast<const float4*>(part + ((size_t)(t + 1) * N + n) * K + k4);
-            const float4 x = *reinterpret_cast<const float4*>(part + ((size_t)(t + 2) * N + n) * K + k4);
-            const float4 y = *reinterpret_cast<const float4*>(part + ((size_t)(t + 3) * N + n) * K + k4);
-            s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
-            s1.x += w.x; s1.y += w.y; s1.z += w.z; s1.w += w.w;
-            s2.x += x.x; s2.y += x.y; s2.z += x.z; s2.w += x.w;
-            s3.x += y.x; s3.y += y.y; s3.z += y.z; s3.w += y.w;
+    const bool is_w = item < quads, is_b = !is_w && dbias != nullptr && item - quads < N;
+    const int n = is_w ? item / (K / 4) : item - quads, k4 = is_w ? (item % (K / 4)) * 4 : 0;
+    const float* src = is_w ? part + (size_t)n * K + k4 : bias_part + n;
+    const size_t step = is_w ? (size_t)N * K : (size_t)N;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    auto ld = [&](int t) {
+        if (is_w) return *reinterpret_cast<const float4*>(src + (size_t)t * step);
+        return make_float4(is_b ? src[(size_t)t * step] : 0.f, 0.f, 0.f, 0.f);
+    };
+    auto add = [](float4& a, const float4& v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
+    if (is_w || is_b) {
+        int t = grp;
+        for (; t + 24 < splits; t += 32) {
+            const float4 v = ld(t), w = ld(t + 8), x = ld(t + 16), y = ld(t + 24);
+            add(s0, v); add(s1, w); add(s2, x); add(s3, y);
         }
-        for (; t < splits; ++t) {
-            const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)t * N + n) * K + k4);
-            s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
-        }
-        s0.x += s2.x; s0.y += s2.y; s0.z += s2.z; s0.w += s2.w;
-        s1.x += s3.x; s1.y += s3.y; s1.z += s3.z; s1.w += s3.w;
+        for (; t < splits; t += 8) add(s0, ld(t));
+        add(s0, s2); add(s1, s3); add(s0, s1);
+    }
+    sh[grp][threadIdx.x & 31] = s0;
+    __syncthreads();
+    if (grp != 0 || !(is_w || is_b)) return;
+    float4 s = sh[0][threadIdx.x];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) add(s, sh[g][threadIdx.x]);
+    if (is_w) {
         float* d = dW + (size_t)n * ldw + k4;
-        if (accumulate) { d[0] += s0.x + s1.x; d[1] += s0.y + s1.y; d[2] += s0.z + s1.z; d[3] += s0.w + s1.w; }
-        else { d[0] = s0.x + s1.x; d[1] = s0.y + s1.y; d[2] = s0.z + s1.z; d[3] = s0.w + s1.w; }
-    } else if (dbias != nullptr && i - quads < N) {
-        const int n = i - quads;
-        float s = 0.f;
-        for (int t = 0; t < splits; ++t) s += bias_part[(size_t)t * N + n];
-        dbias[n] = accumulate ? dbias[n] + s : s;
+        if (accumulate) { d[0] += s.x; d[1] += s.y; d[2] += s.z; d[3] += s.w; }
+        else { d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w; }
+    } else {
+        dbias[n] = accumulate ? dbias[n] + s.x : s.x;
+    }
+}
+
+// Weight gradient, DIRECT form (round 5): dW (n, k) = dY (rows, n)^T X (rows, k) with both operands read straight from their rows into
+// the MFMA registers — no LDS tile, no barrier in the contraction.  One MFMA step contracts the row pair (r, r + 1): lane (lr, lk)
+// supplies dY[r + lk][column of lr] and X[r + lk][column of lr], i.e. a half wave reads 32 BA (32 BB) CONSECUTIVE floats of one row
+// (float / float2 loads, fully coalesced); a wave owns BA x BB blocks of 32 x 32 (block (a, b): output row BA lr' + a, column
+// BB lr + b of its 32 BA x 32 BB patch — the interleaving is what makes the loads contiguous).  The workgroup's four waves cover a
+// tile of up to 128 x 128 as WA x WB patches; when the tile needs fewer than four (narrow layers: most of the network), the spare
+// waves take OTHER rows of the split (row groups) and the partial tiles are added in group order through LDS.  U row pairs are in
+// flight per wave.  The tiled kernel above spends 64 MFMAs per wave and 32 rows on a 128 x 128 tile whatever the layer's widths and
+// walks a split at one global-load latency per 32 rows: 17 us at best, 53 us for the usual 1-tile x 128-split launch (measured inside
+// the joint step, tools/joint_timeline.py); this one does the work the widths ask for.
+template <int BA, int BB>
+__global__ void __launch_bounds__(256)
+rows_wgrad_direct_kernel(RGemm p, int WA, int WB) {
+    constexpr int U = 16, NV = BA * BB * 16 + BA;
+    __shared__ float red[3][NV][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lk = lane >> 5;
+    const int Kv = dev_count(p.K, p.m_dev);
+    const int live = wgrad_live_splits(Kv, p.splits);
+    if ((int)blockIdx.y >= live) return;
+    const int chunk = ((Kv + live - 1) / live + 7) & ~7;
+    const int k_begin = min((int)blockIdx.y * chunk, Kv), k_end = min(Kv, k_begin + chunk);
+    const int W = WA * WB, RG = 4 / W;
+    const int wsub = wave % W, g = wave / W, wa = wsub / WB, wb = wsub % WB;
+    const int ntn = (p.N + 127) / 128;
+    const int m0 = ((int)blockIdx.x / ntn) * 128, n0 = ((int)blockIdx.x % ntn) * 128;
+    const int a_base = m0 + wa * 32 * BA, b_base = n0 + wb * 32 * BB;
+    // columns beyond the matrix are read from a clamped (valid) address: they only reach output elements that are never stored
+    const float* Ap = p.A + min(a_base + BA * lr, p.M - BA);
+    const float* Bp = p.B + min(b_base + BB * lr, p.N - BB);
+    const int npairs = (k_end - k_begin + 1) / 2;
+    const int nt = npairs > g ? (npairs - g + RG - 1) / RG : 0;          // this wave's row pairs: g, g + RG, ...
+    const bool do_bias = p.bias_out != nullptr && wb == 0 && n0 == 0;
+    const int last = max(Kv - 1, 0);
+
+    // raw loads; rows beyond the split are zeroed when the slot is CONSUMED (a select at load time makes the load's wait immediate)
+    float av[U][BA], bv[U][BB];
+    auto fetch = [&](int u, int t) __attribute__((always_inline)) {
+        const size_t rc = (size_t)min(k_begin + 2 * (g + RG * t) + lk, last);
+        if (BA == 2) {
+            const float2 v = *reinterpret_cast<const float2*>(Ap + rc * p.lda);
+            av[u][0] = v.x; av[u][BA - 1] = v.y;
+        } else {
+            av[u][0] = Ap[rc * p.lda];
+        }
+        if (BB == 2) {
+            const float2 v = *reinterpret_cast<const float2*>(Bp + rc * p.ldb);
+            bv[u][0] = v.x; bv[u][BB - 1] = v.y;
+        } else {
+            bv[u][0] = Bp[rc * p.ldb];
+        }
+    };
+    f32x16 acc[BA][BB];
+    float bs[BA];
+#pragma unroll
+    for (int a = 0; a < BA; ++a) {
+        bs[a] = 0.f;
+#pragma unroll
+        for (int b = 0; b < BB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) fetch(u, u);
+    for (int t0 = 0; t0 < nt; t0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // branch-free: steps beyond the wave's last pair contract zeros (with a branch around the loads hipcc's s_waitcnt
+            // placement degrades to vmcnt(0..1) and the U steps in flight are lost)
+            float a_[BA], b_[BB];
+            const bool ok = k_begin + 2 * (g + RG * (t0 + u)) + lk < k_end;          // (implies t0 + u < nt)
+#pragma unroll
+            for (int a = 0; a < BA; ++a) a_[a] = ok ? av[u][a] : 0.f;
+#pragma unroll
+            for (int b = 0; b < BB; ++b) b_[b] = ok ? bv[u][b] : 0.f;
+            fetch(u, t0 + u + U);                // refill the slot (beyond the split: a clamped load, never used)
+            __builtin_amdgcn_sched_barrier(0);   // the refill stays HERE, U steps ahead of its use (hipcc sinks it next to the use otherwise)
+#pragma unroll
+            for (int a = 0; a < BA; ++a) {
+                bs[a] += a_[a];
+#pragma unroll
+                for (int b = 0; b < BB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[a], b_[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < BA; ++a) bs[a] += __shfl_xor(bs[a], 32);        // both row parities
+
+    if (RG > 1) {               // add the row groups' partial tiles in group order
+        if (g > 0) {
+            float (*r)[64] = red[(g - 1) * W + wsub];
+#pragma unroll
+            for (int a = 0; a < BA; ++a) {
+#pragma unroll
+                for (int b = 0; b < BB; ++b)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) r[(a * BB + b) * 16 + i][lane] = acc[a][b][i];
+                r[BA * BB * 16 + a][lane] = bs[a];
+            }
+        }
+        __syncthreads();
+        if (g > 0) return;
+        for (int gg = 1; gg < RG; ++gg) {
+            float (*r)[64] = red[(gg - 1) * W + wsub];
+#pragma unroll
+            for (int a = 0; a < BA; ++a) {
+#pragma unroll
+                for (int b = 0; b < BB; ++b)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[a][b][i] += r[(a * BB + b) * 16 + i][lane];
+                bs[a] += r[BA * BB * 16 + a][lane];
+            }
+        }
+    }
+
+    const bool direct = p.splits == 1;
+    float* out = p.out + (direct ? 0 : (size_t)blockIdx.y * p.M * p.ldo);
+    const int col = b_base + BB * lr;
+#pragma unroll
+    for (int a = 0; a < BA; ++a) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = a_base + BA * ((i & 3) + 8 * (i >> 2) + 4 * lk) + a;
+            if (row < p.M && col < p.N) {
+                float* o = out + (size_t)row * p.ldo + col;
+#pragma unroll
+                for (int b = 0; b < BB; ++b) o[b] = (direct && p.accumulate) ? o[b] + acc[a][b][i] : acc[a][b][i];
+            }
+        }
+        const int bc = a_base + BA * lr + a;
+        if (do_bias && lk == 0 && bc < p.M) {
+            float* bo = p.bias_out + (direct ? 0 : (size_t)blockIdx.y * p.M) + bc;
+            *bo = (direct && p.accumulate) ? *bo + bs[a] : bs[a];
+        }
     }
 }
 
@@ -349,47 +493,37 @@ rows_gemm_small_kernel(RGemm p) {
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
     const int row = min(m0 + r, p.M - 1), col = min(n0 + r, p.N - 1);
     const int nk = (p.K + 7) / 8;
+    // raw loads from clamped addresses; a step's values are zeroed beyond the contraction when it is CONSUMED (`live`)
     auto loadA = [&](int s) {
-        const int k = 8 * s + 4 * h;
-        const int kc = min(k, p.K - 4);
-        float4 v;
-        if (MODE == RM_FWD && p.A2 != nullptr && kc >= p.K1) v = *reinterpret_cast<const float4*>(p.A2 + (size_t)row * p.lda2 + (kc - p.K1));
-        else v = *reinterpret_cast<const float4*>(p.A + (size_t)row * p.lda + kc);
-        return k < p.K ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int kc = min(8 * s + 4 * h, p.K - 4);
+        if (MODE == RM_FWD && p.A2 != nullptr && kc >= p.K1) return *reinterpret_cast<const float4*>(p.A2 + (size_t)row * p.lda2 + (kc - p.K1));
+        return *reinterpret_cast<const float4*>(p.A + (size_t)row * p.lda + kc);
     };
     auto loadB = [&](int s) {
-        const int k = 8 * s + 4 * h;
-        const int kc = min(k, p.K - 4);
-        float4 v;
-        if (MODE == RM_FWD) {
-            v = *reinterpret_cast<const float4*>(p.B + (size_t)col * p.ldb + kc);
-        } else {
-            const float* q = p.B + (size_t)kc * p.ldb + col;       // 4 contraction rows of this lane's column
-            v = make_float4(q[0], q[p.ldb], q[2 * (size_t)p.ldb], q[3 * (size_t)p.ldb]);
-        }
-        return k < p.K ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int kc = min(8 * s + 4 * h, p.K - 4);
+        if (MODE == RM_FWD) return *reinterpret_cast<const float4*>(p.B + (size_t)col * p.ldb + kc);
+        const float* q = p.B + (size_t)kc * p.ldb + col;       // 4 contraction rows of this lane's column
+        return make_float4(q[0], q[p.ldb], q[2 * (size_t)p.ldb], q[3 * (size_t)p.ldb]);
     };
+    auto live = [&](int s, const float4& v) { return 8 * s + 4 * h < p.K ? v : make_float4(0.f, 0.f, 0.f, 0.f); };
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float4 ra[SPF], rb[SPF];
 #pragma unroll
-    for (int s = 0; s < SPF; ++s) {
-        const int ss = min(s, nk - 1);
-        ra[s] = loadA(ss); rb[s] = loadB(ss);
-    }
+    for (int s = 0; s < SPF; ++s) { ra[s] = loadA(s); rb[s] = loadB(s); }
     for (int s0 = 0; s0 < nk; s0 += SPF) {
 #pragma unroll
         for (int s = 0; s < SPF; ++s) {
-            if (s0 + s < nk) {           // wave-uniform
-                const float4 a = ra[s], b = rb[s];
-                const int nx = min(s0 + s + SPF, nk - 1);        // refill this slot (clamped: unconditional load)
-                ra[s] = loadA(nx); rb[s] = loadB(nx);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-            }
+            // branch-free: steps beyond the contraction load from a clamped address and contract zeros (a branch around the loads
+            // costs the steps in flight: hipcc then waits with vmcnt(0..1))
+            const float4 a = live(s0 + s, ra[s]), b = rb[s];
+            ra[s] = loadA(s0 + s + SPF); rb[s] = loadB(s0 + s + SPF);
+            __builtin_amdgcn_sched_barrier(0);       // the refill stays SPF steps ahead of its use
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
         }
     }
     const int c = n0 + r;
@@ -520,21 +654,21 @@ int jm_rows_deconv_wgrad(int m, int c, int k, int r, int h, int w, const float* 
                        (hipStream_t)stream, p);
     if (splits > 1) {
         const int work = n * (c / 4);
-        hipLaunchKernelGGL(rows_wgrad_reduce_kernel, dim3((unsigned)divup(work, 256)), dim3(256), 0, (hipStream_t)stream, n, c, splits, m,
+        hipLaunchKernelGGL(rows_wgrad_reduce_kernel, dim3((unsigned)divup(work, 32)), dim3(256), 0, (hipStream_t)stream, n, c, splits, m,
                            (const int*)nullptr, (const float*)ws, dwt, c, (const float*)nullptr, (float*)nullptr, 0);
     }
     return check_launch("rows_deconv_wgrad");
 }
 
 int jm_rows_wgrad_splits(int m, int n, int k) {
-    // enough (tile, split) workgroups to fill 256 CUs twice over with at least 128 contraction rows (8 k-tiles) per split: a
-    // k-tile costs a workgroup one global-load latency (~1.5 us) whatever the tile count, so a long contraction on a handful of
-    // tiles is pure latency; a short contraction runs un-split and writes dW / dbias straight from the accumulators (one launch)
+    // enough (tile, split) workgroups to fill 256 CUs four times over with at least 256 contraction rows per split (a workgroup of the
+    // direct kernel has up to 128 rows in flight); a short contraction runs un-split and writes dW / dbias straight from the
+    // accumulators (one launch).  With the row count in device memory only the splits that hold >= 128 rows exist (wgrad_live_splits)
     const int tiles = divup(n, RBM) * divup(k, RBN);
-    int s = divup(512, tiles);
-    const int cap = imax(1, m / 128);
+    int s = divup(1024, tiles);
+    const int cap = imax(1, m / 256);
     if (s > cap) s = cap;
-    if (s > 128) s = 128;
+    if (s > 256) s = 256;
     return imax(1, s);
 }
 
@@ -585,11 +719,17 @@ int jm_rows_linear_wgrad(int m, const int* m_dev, int n, int k, const float* dy,
     float* bias_part = (float*)ws + (size_t)splits * n * k;
     if (splits > 1) { p.out = (float*)ws; p.ldo = k; p.bias_out = dbias ? bias_part : nullptr; }
     else { p.out = dw; p.ldo = lddw; p.bias_out = dbias; }
-    hipLaunchKernelGGL((rows_gemm_kernel<RM_WGRAD>), dim3((unsigned)(divup(n, RBM) * divup(k, RBN)), (unsigned)splits), dim3(256), 0,
-                       (hipStream_t)stream, p);
+    // the tile's patches: one wave takes 32 or 64 columns of dY (BA) and of X (BB); up to 2 x 2 waves per 128 x 128 tile
+    const int ba = n > 32 ? 2 : 1, bb = k > 32 ? 2 : 1;
+    const int wa = n > 64 ? 2 : 1, wb = k > 64 ? 2 : 1;
+    const dim3 grid((unsigned)(divup(n, RBM) * divup(k, RBN)), (unsigned)splits);
+    if (ba == 1 && bb == 1) hipLaunchKernelGGL((rows_wgrad_direct_kernel<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, p, wa, wb);
+    else if (ba == 1) hipLaunchKernelGGL((rows_wgrad_direct_kernel<1, 2>), grid, dim3(256), 0, (hipStream_t)stream, p, wa, wb);
+    else if (bb == 1) hipLaunchKernelGGL((rows_wgrad_direct_kernel<2, 1>), grid, dim3(256), 0, (hipStream_t)stream, p, wa, wb);
+    else hipLaunchKernelGGL((rows_wgrad_direct_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, p, wa, wb);
     if (splits > 1) {
         const int work = n * (k / 4) + (dbias ? n : 0);
-        hipLaunchKernelGGL(rows_wgrad_reduce_kernel, dim3((unsigned)divup(work, 256)), dim3(256), 0, (hipStream_t)stream, n, k, splits, m, m_dev,
+        hipLaunchKernelGGL(rows_wgrad_reduce_kernel, dim3((unsigned)divup(work, 32)), dim3(256), 0, (hipStream_t)stream, n, k, splits, m, m_dev,
                            (const float*)ws, dw, lddw, (const float*)bias_part, dbias, accumulate);
     }
     return check_launch("rows_linear_wgrad");

@@ -429,3 +429,25 @@ def test_rcnn_rows_on_canonical_centres_same_outputs_same_gradients_fewer_rows(t
     assert res[False][1].keys() == res[True][1].keys() and len(res[True][1]) > 10
     for kk, want in res[False][1].items():
         close(res[True][1][kk], want, tol=2e-4, what=kk)
+
+
+@pytest.mark.parametrize("M,n,k", [(70000, 16, 16), (70000, 32, 16), (65537, 64, 32), (40001, 32, 64), (300000, 64, 64), (9000, 128, 64), (9001, 64, 128),
+                                   (50000, 128, 128), (3000, 512, 256), (2, 16, 4), (511, 36, 132), (100000, 16, 4), (1200, 256, 260)])
+def test_rows_wgrad_direct_form_every_patch_shape(M, n, k):
+    """the weight-gradient kernel's wave patches (32 / 64 columns per operand, 1 / 2 / 4 waves per tile, spare waves on other rows of
+    the split), split and un-split, odd row counts, the row count in device memory, against float64; run to run bit-identical"""
+    from jmodt_amd.ops import rows as R
+    dy, x = rnd(M, n, seed=1), rnd(M, k, seed=2)
+    dw, db = R.linear_wgrad(dy, [x])
+    scale = max(1.0, float(M) ** 0.5 / 30)
+    close(dw, dy.double().t() @ x.double(), tol=2e-4 * scale, what="wgrad")
+    close(db, dy.double().sum(0), tol=2e-4 * scale, what="bias gradient")
+    for mv in (0, 1, M // 3 + 1, M - 1):
+        if mv > M:
+            continue
+        m_dev = torch.tensor([mv], dtype=torch.int32, device=DEV)
+        dw2, db2 = R.linear_wgrad(dy, [x], m_dev=m_dev)
+        close(dw2, dy[:mv].double().t() @ x[:mv].double(), tol=2e-4 * scale, what=f"wgrad, {mv} rows on the device")
+        close(db2, dy[:mv].double().sum(0), tol=2e-4 * scale, what=f"bias gradient, {mv} rows on the device")
+        again = R.linear_wgrad(dy, [x], m_dev=m_dev)
+        assert torch.equal(dw2, again[0]) and torch.equal(db2, again[1])

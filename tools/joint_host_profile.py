@@ -1,29 +1,60 @@
-"""where does the HOST spend the joint-mode step's enqueue time?  cProfile over N steps + the wall-clock of enqueue vs device:
-    gpurun -- 'python tools/joint_host_profile.py 10'"""
-import cProfile, os, pstats, sys, io, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""Where the HOST time of a joint-mode training step goes (rows route): cProfile over a few steps on the GPU box, the main thread and
+the autograd engine's worker thread (threading.setprofile) alike.
+
+    python tools/joint_host_profile.py [steps] > gpurun_out/joint_host_profile.txt
+"""
+import cProfile
+import io
+import os
+import pstats
+import sys
+import threading
+import time
+
 import torch
-import bench
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-st = bench.make_joint_state(4, 1234, torch.device("cuda:0"))
-for _ in range(4):
-    bench.train_step(st, None)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(N):
-    bench.train_step(st, None)
-t1 = time.perf_counter()
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print(f"un-profiled: host enqueue {(t1 - t0) / N * 1e3:.2f} ms per step, step {(t2 - t0) / N * 1e3:.2f} ms")
-pr = cProfile.Profile()
-pr.enable()
-for _ in range(N):
-    bench.train_step(st, None)
-pr.disable()
-torch.cuda.synchronize()
-for key, n in (("tottime", 40), ("cumulative", 45)):
-    s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats(key).print_stats(n)
-    txt = s.getvalue()
-    print(txt[txt.index("ncalls"):] if "ncalls" in txt else txt)
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench        # noqa: E402
+
+
+def main(steps):
+    dev = torch.device("cuda:0")
+    st = bench.make_joint_state(4, 0, dev)
+    for _ in range(4):
+        bench.train_step(st, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        bench.train_step(st, None)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"un-profiled: host {1e3 * (t1 - t0) / steps:.2f} ms / step, step {1e3 * (t2 - t0) / steps:.2f} ms")
+    profs = []
+
+    def hook(frame, event, arg):      # every thread that starts running Python code gets its own profiler
+        p = cProfile.Profile()
+        profs.append((threading.current_thread().name, p))
+        sys.setprofile(None)
+        p.enable()
+    threading.setprofile(hook)
+    main_p = cProfile.Profile()
+    main_p.enable()
+    for _ in range(steps):
+        bench.train_step(st, None)
+    main_p.disable()
+    torch.cuda.synchronize()
+    for name, p in [("main", main_p)] + profs:
+        p.disable()
+        s = io.StringIO()
+        ps = pstats.Stats(p, stream=s)
+        print(f"==== thread {name}: total {ps.total_tt * 1e3 / steps:.2f} ms / step")
+        ps.sort_stats("tottime").print_stats(28)
+        print("\n".join(s.getvalue().splitlines()[6:40]))
+        s = io.StringIO()
+        pstats.Stats(p, stream=s).sort_stats("cumulative").print_stats(30)
+        print("\n".join(s.getvalue().splitlines()[6:42]))
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 5)
