@@ -478,22 +478,31 @@ rows_wgrad_direct_kernel(RGemm p, int WA, int WB) {
     }
 }
 
-// Small-problem variant (FWD / DGRAD with a few hundred to a few thousand rows: the coarse backbone levels, the RoI heads — 150 of
-// the ~250 GEMMs of a joint-mode step): ONE wave per 32 x 32 output tile, operands straight from L2 into the MFMA registers (no
-// LDS, no barrier), SPF steps of 8 contraction elements in flight.  A 128 x 128-tile launch of such a problem is 8 - 32
-// workgroups marching through the contraction at one global-load latency per k-tile (30 - 130 us measured); here it is
-// (M / 32)(N / 32) independent waves.  Lane (r = lane & 31, h = lane >> 5) holds 4 consecutive k of its row per step; MFMA step q
-// pairs k = 8 s + q (h = 0) with k = 8 s + 4 + q (h = 1) on both operands.  Same operand forms and epilogues as rows_gemm_kernel.
-constexpr int SPF = 4;
+// Small-problem variant (FWD / DGRAD with a few hundred to a few thousand rows: the coarse backbone levels, the RoI heads, the
+// set-abstraction levels whose distinct rows are a fraction of their capacity — 150 of the ~250 GEMMs of a joint-mode step): one
+// WORKGROUP per 32 x 32 output tile, operands straight from L2 into the MFMA registers (no operand tile in LDS, no barrier in the
+// contraction), the contraction split over the workgroup's four waves (contiguous quarters, SPF steps of 8 contraction elements in
+// flight each), the four partial tiles added in wave order through LDS.  A 128 x 128-tile launch of such a problem is 8 - 32
+// workgroups marching through the contraction at one global-load latency per k-tile (30 - 130 us measured); the first form of this
+// kernel (one wave per tile, 4 steps in flight) still took 77 - 260 us on 1024 rows x 512 columns x 1024 contraction (tools/
+// joint_timeline.py): a lone wave walks 128 steps at a quarter of a round trip each.  Lane (r = lane & 31, h = lane >> 5) holds 4
+// consecutive k of its row per step; MFMA step q pairs k = 8 s + q (h = 0) with k = 8 s + 4 + q (h = 1) on both operands.  Same
+// operand forms and epilogues as rows_gemm_kernel; with the row count in device memory the workgroups beyond it return at once.
+constexpr int SPF = 8;
 
 template <int MODE>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 rows_gemm_small_kernel(RGemm p) {
-    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    __shared__ float red[3][16][64];
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
-    const int row = min(m0 + r, p.M - 1), col = min(n0 + r, p.N - 1);
+    const int Mv = dev_count(p.M, p.m_dev);
+    if (m0 >= Mv) return;
+    const int row = min(m0 + r, Mv - 1), col = min(n0 + r, p.N - 1);
     const int nk = (p.K + 7) / 8;
-    // raw loads from clamped addresses; a step's values are zeroed beyond the contraction when it is CONSUMED (`live`)
+    const int per = (nk + 3) / 4, s_begin = wave * per, s_end = min(nk, s_begin + per);
+    // raw loads from clamped addresses; a step's values are zeroed beyond the wave's quarter when it is CONSUMED (`live`)
     auto loadA = [&](int s) {
         const int kc = min(8 * s + 4 * h, p.K - 4);
         if (MODE == RM_FWD && p.A2 != nullptr && kc >= p.K1) return *reinterpret_cast<const float4*>(p.A2 + (size_t)row * p.lda2 + (kc - p.K1));
@@ -505,17 +514,17 @@ rows_gemm_small_kernel(RGemm p) {
         const float* q = p.B + (size_t)kc * p.ldb + col;       // 4 contraction rows of this lane's column
         return make_float4(q[0], q[p.ldb], q[2 * (size_t)p.ldb], q[3 * (size_t)p.ldb]);
     };
-    auto live = [&](int s, const float4& v) { return 8 * s + 4 * h < p.K ? v : make_float4(0.f, 0.f, 0.f, 0.f); };
+    auto live = [&](int s, const float4& v) { return (s < s_end && 8 * s + 4 * h < p.K) ? v : make_float4(0.f, 0.f, 0.f, 0.f); };
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float4 ra[SPF], rb[SPF];
 #pragma unroll
-    for (int s = 0; s < SPF; ++s) { ra[s] = loadA(s); rb[s] = loadB(s); }
-    for (int s0 = 0; s0 < nk; s0 += SPF) {
+    for (int s = 0; s < SPF; ++s) { ra[s] = loadA(s_begin + s); rb[s] = loadB(s_begin + s); }
+    for (int s0 = s_begin; s0 < s_end; s0 += SPF) {
 #pragma unroll
         for (int s = 0; s < SPF; ++s) {
-            // branch-free: steps beyond the contraction load from a clamped address and contract zeros (a branch around the loads
+            // branch-free: steps beyond the quarter load from a clamped address and contract zeros (a branch around the loads
             // costs the steps in flight: hipcc then waits with vmcnt(0..1))
             const float4 a = live(s0 + s, ra[s]), b = rb[s];
             ra[s] = loadA(s0 + s + SPF); rb[s] = loadB(s0 + s + SPF);
@@ -526,13 +535,23 @@ rows_gemm_small_kernel(RGemm p) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
         }
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave - 1][i][lane] = acc[i];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += red[w][i][lane];
     const int c = n0 + r;
     const bool cok = c < p.N;
     const float bv = (MODE == RM_FWD && p.bias != nullptr && cok) ? p.bias[c] : 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int orow = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const bool ok = cok && orow < p.M;
+        const bool ok = cok && orow < Mv;
         float v = acc[i];
         if (MODE == RM_FWD) {
             v += bv;
@@ -547,9 +566,13 @@ rows_gemm_small_kernel(RGemm p) {
     }
 }
 
-// which launch a FWD / DGRAD problem of m rows (host count; a device-side count always takes the persistent tiles) gets
+// which launch a FWD / DGRAD problem of m rows gets.  Row count on the host: few 128 x 128 tiles.  Row count in device memory (m =
+// the capacity): the distinct rows of a set-abstraction level are a fraction of it (7 - 30 % on the benchmark clouds), so a capacity of
+// up to 131072 rows takes the small tiles as well — the workgroups beyond the count return at once
 static bool small_problem(int m, const int* m_dev, int n) {
-    return m_dev == nullptr && (long long)divup(m, RBM) * divup(n, RBN) < 96 && (long long)divup(m, 32) * divup(n, 32) <= 16384;
+    const long long wgs = (long long)divup(m, 32) * divup(n, 32);
+    if (m_dev != nullptr) return m <= 131072 && wgs <= 16384;
+    return (long long)divup(m, RBM) * divup(n, RBN) < 96 && wgs <= 16384;
 }
 
 static int persistent_grid(long long tiles) { return (int)(tiles < 1 ? 1 : (tiles > JM_PGRID ? JM_PGRID : tiles)); }
@@ -574,7 +597,7 @@ int jm_rows_linear_forward(int m, const int* m_dev, int k1, int k2, int n, const
     p.B = w; p.ldb = ldw; p.bias = bias; p.act = act; p.rowscale = rowscale; p.out = y; p.ldo = ldy; p.splits = 1;
     const long long tiles = (long long)divup(m, RBM) * divup(n, RBN);
     if (small_problem(m, m_dev, n))
-        hipLaunchKernelGGL((rows_gemm_small_kernel<RM_FWD>), dim3((unsigned)divup(n, 32), (unsigned)divup(m, 32)), dim3(64), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((rows_gemm_small_kernel<RM_FWD>), dim3((unsigned)divup(n, 32), (unsigned)divup(m, 32)), dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL((rows_gemm_kernel<RM_FWD>), dim3((unsigned)persistent_grid(tiles)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("rows_linear_forward");
@@ -592,7 +615,7 @@ int jm_rows_linear_dgrad(int m, const int* m_dev, int n, int k, const float* dy,
     p.accumulate = accumulate; p.out = dx; p.ldo = lddx; p.splits = 1;
     const long long tiles = (long long)divup(m, RBM) * divup(k, RBN);
     if (small_problem(m, m_dev, k))
-        hipLaunchKernelGGL((rows_gemm_small_kernel<RM_DGRAD>), dim3((unsigned)divup(k, 32), (unsigned)divup(m, 32)), dim3(64), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((rows_gemm_small_kernel<RM_DGRAD>), dim3((unsigned)divup(k, 32), (unsigned)divup(m, 32)), dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL((rows_gemm_kernel<RM_DGRAD>), dim3((unsigned)persistent_grid(tiles)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("rows_linear_dgrad");

@@ -38,6 +38,8 @@ def main(steps):
         sys.setprofile(None)
         p.enable()
     threading.setprofile(hook)
+    # the autograd engine's worker threads are not Python threads: run the backward on the calling thread so that it is profiled
+    torch.autograd.grad_mode.set_multithreading_enabled(False)
     main_p = cProfile.Profile()
     main_p.enable()
     for _ in range(steps):
@@ -49,11 +51,11 @@ def main(steps):
         s = io.StringIO()
         ps = pstats.Stats(p, stream=s)
         print(f"==== thread {name}: total {ps.total_tt * 1e3 / steps:.2f} ms / step")
-        ps.sort_stats("tottime").print_stats(28)
-        print("\n".join(s.getvalue().splitlines()[6:40]))
+        ps.sort_stats("tottime").print_stats(45)
+        print("\n".join(s.getvalue().splitlines()[6:56]))
         s = io.StringIO()
-        pstats.Stats(p, stream=s).sort_stats("cumulative").print_stats(30)
-        print("\n".join(s.getvalue().splitlines()[6:42]))
+        pstats.Stats(p, stream=s).sort_stats("cumulative").print_stats(60)
+        print("\n".join(s.getvalue().splitlines()[6:70]))
 
 
 if __name__ == "__main__":
