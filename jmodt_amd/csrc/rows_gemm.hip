@@ -568,10 +568,10 @@ rows_gemm_small_kernel(RGemm p) {
 
 // which launch a FWD / DGRAD problem of m rows gets.  Row count on the host: few 128 x 128 tiles.  Row count in device memory (m =
 // the capacity): the distinct rows of a set-abstraction level are a fraction of it (7 - 30 % on the benchmark clouds), so a capacity of
-// up to 131072 rows takes the small tiles as well — the workgroups beyond the count return at once
+// up to 32768 rows takes the small tiles as well (beyond that the persistent tiles win: 30000 of 131072 rows, 64 -> 128: 20 vs 58 us) — the workgroups beyond the count return at once
 static bool small_problem(int m, const int* m_dev, int n) {
     const long long wgs = (long long)divup(m, 32) * divup(n, 32);
-    if (m_dev != nullptr) return m <= 131072 && wgs <= 16384;
+    if (m_dev != nullptr) return m <= 32768 && wgs <= 16384;
     return (long long)divup(m, RBM) * divup(n, RBN) < 96 && wgs <= 16384;
 }
 
