@@ -254,10 +254,16 @@ def load():
     return _lib
 
 
+SYNC_DEBUG = False       # debugging aid: device synchronisation behind every library call, so that an asynchronous device fault
+                         # aborts inside the call that caused it (python -X faulthandler then names it); never on in product runs
+
+
 def check(rc, what):
     if rc != 0:
         msg = load().jm_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"jmodt_amd.{what} failed (code {rc}): {msg}")
+    if SYNC_DEBUG:
+        torch.cuda.synchronize()
 
 
 # the raw queries: torch.cuda.current_stream() builds a Stream object and re-checks the lazy initialisation, ~8 us x 80 launches

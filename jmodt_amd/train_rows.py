@@ -482,7 +482,12 @@ def rcnn_branch_rows(engine, pts_input, count, fold: BnFold, ready: Optional[tor
 
 
 def joint_forward_rows(engine, xyz, image, pts_xy, rois_per_frame: int = 64, pyr: Optional[FpsPyramid] = None) -> Dict[str, torch.Tensor]:
-    """the detector in TRAIN composition (point_rcnn.py:24-70) on rows; same outputs as train_joint.joint_forward"""
+    """the detector in TRAIN composition (point_rcnn.py:24-70) on rows; same outputs as train_joint.joint_forward.
+    Its backward runs on three streams (main, image, RCNN).  RULE for callers: no OTHER autograd graph over the same parameters may
+    be alive when it does (outputs of an earlier forward that still carry a grad_fn): that graph's AccumulateGrad nodes, made on
+    the main stream, would take this backward's gradients (torch warns "AccumulateGrad node's stream does not match ...") — with
+    such a graph held, tests/test_gpu_rows.py aborted with a device memory fault in this backward, three runs of three, and passes
+    once it is dropped (detach + gc.collect()), as it does with every launch serialised.  joint_step never holds one."""
     fold = BnFold(engine)
     out = rpn_forward_rows(engine, xyz, image, pts_xy, fold, pyr)
     rois, pts_input, count = pooled_rois(engine, xyz, out, rois_per_frame)

@@ -279,12 +279,29 @@ def test_joint_rows_route_matches_the_operator_route(tiny):
     K = eng.cfg.rpn_post_nms_top_n
     tids = torch.randint(0, 6, (2, K), generator=torch.Generator().manual_seed(4)).float().to(DEV)
     eng.zero_grad(set_to_none=True)
+    # (the synchronisation points localise an asynchronous device fault to its phase)
     ref = train_joint.joint_forward(eng, xyz, img, xy, rois_per_frame=K)
+    torch.cuda.synchronize()
     train_joint.thin_loss(eng, ref, tids).backward()
+    torch.cuda.synchronize()
     want = _grads(eng)
     eng.zero_grad(set_to_none=True)
+    # the operator route's autograd graph must be GONE before the rows route runs its backward on side streams: as long as `ref`
+    # holds it, its AccumulateGrad nodes (made on the main stream) stay alive and take the rows route's gradients
+    # (torch warns: "AccumulateGrad node's stream does not match ...") — same rule as for captures, jmodt_amd/graphed.py
+    import gc
+    ref = {k: v.detach() for k, v in ref.items()}
+    gc.collect()
     got = joint_forward_rows(eng, xyz, img, xy, rois_per_frame=K)
-    train_joint.thin_loss(eng, got, tids).backward()
+    torch.cuda.synchronize()
+    import os
+    from jmodt_amd import _lib as L_
+    L_.SYNC_DEBUG = bool(os.environ.get("JM_TEST_SYNC_DEBUG"))
+    try:
+        train_joint.thin_loss(eng, got, tids).backward()
+        torch.cuda.synchronize()
+    finally:
+        L_.SYNC_DEBUG = False
     mine = _grads(eng)
     eng.zero_grad(set_to_none=True)
     for k in ("backbone_features", "rpn_cls", "rpn_reg"):
