@@ -678,8 +678,10 @@ int jm_rows_linear_forward(int m, const int* m_dev, int k1, int k2, int n, const
 int jm_rows_linear_dgrad(int m, const int* m_dev, int n, int k, const float* dy, int lddy, const float* w, int ldw,
                          const float* mask, int ldm, int accumulate, float* dx, int lddx, jm_stream_t stream);
 /* dw (n, k) (+)= dy (m, n)^T x (m, k), dbias (n) (+)= column sums of dy (NULL: skipped).  The m rows are split over
- * jm_rows_wgrad_splits(m, n, k) partials in ws, reduced in split order: deterministic, no float atomics; a short contraction
- * (one split) writes dw / dbias straight from the accumulators and needs no workspace */
+ * jm_rows_wgrad_splits(m, n, k) partials in ws (with m_dev: only the splits that hold >= 128 of the counted rows exist), reduced in a
+ * FIXED order (eight groups of every eighth split, the groups added in group order): deterministic, no float atomics; a short
+ * contraction (one split) writes dw / dbias straight from the accumulators and needs no workspace.  Direct form since round 5:
+ * the operands go from their rows into the MFMA registers, a wave's patch is 32 or 64 columns of dy and of x (csrc/rows_gemm.hip) */
 /* The image branch's kernel == stride transposed convolutions (backbone.py:150-157,187-189: DeConv) as GEMMs whose (rows, columns)
  * matrix is stored PIXEL-SHUFFLED: x (m = B h w, c) = the channels-last input map as rows, wt (k k r, c) with
  * wt[(dy k + dx) r + rr][ci] = W[ci][rr][dy][dx], y = the channels-last (B, h k, w k, ctot) map, this level's r channels at coff:
