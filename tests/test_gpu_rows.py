@@ -294,9 +294,13 @@ def test_joint_rows_route_matches_the_operator_route(tiny):
     gc.collect()
     got = joint_forward_rows(eng, xyz, img, xy, rois_per_frame=K)
     torch.cuda.synchronize()
+    # belt and braces for this parity test: the rows backward with a device synchronisation behind every library call, so that a
+    # device fault — seen here before the rule above was applied — would abort inside the call that caused it (python -X
+    # faulthandler names it).  The asynchronous three-stream backward is what test_joint_step_rows_route_updates_every_parameter,
+    # the data-parallel test and tests/test_gpu_graphs.py run; JM_TEST_ASYNC_BACKWARD=1 runs it here as well
     import os
     from jmodt_amd import _lib as L_
-    L_.SYNC_DEBUG = bool(os.environ.get("JM_TEST_SYNC_DEBUG"))
+    L_.SYNC_DEBUG = not os.environ.get("JM_TEST_ASYNC_BACKWARD")
     try:
         train_joint.thin_loss(eng, got, tids).backward()
         torch.cuda.synchronize()
