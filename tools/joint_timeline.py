@@ -7,9 +7,10 @@ One row per dispatch: start (us after the step's first dispatch), duration, queu
 fused Adam launches (multi_tensor_apply).  The table answers what a stats summary cannot: which dispatches are on the chain the
 step waits for, and how long each shape of a kernel takes inside the composed step."""
 import sqlite3
+import os
 import sys
 
-sys.path.insert(0, __file__.rsplit("/", 2)[0] + "/profiles")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/profiles")
 from summarize import _shape_cols, short        # noqa: E402
 
 

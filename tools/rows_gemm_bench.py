@@ -1,10 +1,11 @@
 """Isolated times of the training path's row GEMMs (forward / data gradient) on shapes of the joint-mode step, HIP-graph replays of
 20 back-to-back calls:   python tools/rows_gemm_bench.py"""
+import os
 import sys
 
 import torch
 
-sys.path.insert(0, __file__.rsplit("/", 2)[0])
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from jmodt_amd.ops import rows as R        # noqa: E402
 
 dev = "cuda:0"

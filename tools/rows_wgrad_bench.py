@@ -1,10 +1,11 @@
 """Isolated time of the training path's weight gradient + its reduction (csrc/rows_gemm.hip: rows_wgrad_direct_kernel, rows_wgrad_reduce_kernel)
 on shapes of the joint-mode step, HIP-graph replays of 20 back-to-back calls:   python tools/rows_wgrad_bench.py"""
+import os
 import sys
 
 import torch
 
-sys.path.insert(0, __file__.rsplit("/", 2)[0])
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from jmodt_amd.ops import rows as R
 dev='cuda:0'
 def bench(M,n,k,mv=None):
