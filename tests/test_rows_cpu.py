@@ -26,3 +26,19 @@ def test_centre_canon_is_the_first_centre_of_every_class_of_copies():
     for r in range(3):
         for i in range(3):
             assert int(got2[r, i]) == next(j for j in range(3) if int(rep[r, j]) == int(rep[r, i]))
+
+
+def test_weight_gradient_split_and_workspace_queries_are_consistent():
+    """host-only queries of the C-ABI (no device work): jm_rows_wgrad_splits / jm_rows_wgrad_workspace_bytes (include/jmodt_hip.h) —
+    1 <= splits <= 256, at least 256 rows per split, at most ~1024 (tile, split) workgroups, workspace = splits (n k + n) floats or 0"""
+    from jmodt_amd import _lib as L
+    lib = L.load()
+    for m in (0, 1, 255, 256, 511, 512, 5000, 65536, 524288, 2097152):
+        for n, k in ((4, 4), (16, 16), (32, 64), (128, 128), (196, 128), (512, 256), (1024, 1536)):
+            s = int(lib.jm_rows_wgrad_splits(m, n, k))
+            tiles = -(-n // 128) * -(-k // 128)
+            assert 1 <= s <= 256
+            assert s == 1 or m // s >= 256, (m, n, k, s)
+            assert s == 1 or (s - 1) * tiles < 1024, (m, n, k, s)
+            want = 0 if s == 1 else s * (n * k + n) * 4
+            assert int(lib.jm_rows_wgrad_workspace_bytes(m, n, k)) == want, (m, n, k, s)
