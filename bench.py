@@ -440,16 +440,39 @@ def dense_step(d):
 
 
 # ---------------------------------------------------------------------------------------------- train
-def make_joint_state(frames, seed, dev, tiny=False):
-    """BASELINE configs[3] in JOINT mode (tools/train.py:96-107 without cfg.TRAIN.FINETUNE): every parameter of the detector and
-    of the affinity heads trains; the step is jmodt_amd/train_joint.joint_step"""
+def joint_route():
+    """the route joint_step takes for this process (JM_JOINT_ROUTE: rows (default) | operators | auto)"""
+    r = os.environ.get("JM_JOINT_ROUTE", "rows")
+    return "rows" if r == "auto" else r
+
+
+def make_rcnn_state(frames, seed, dev, tiny=False, kind="uniform"):
+    """BASELINE configs[3] in the reference's DEFAULT training mode (tools/train.py:86-107 with the shipped config.py:57
+    RPN.FIXED = True, FINETUNE off): the RPN frozen and evaluated without gradient (point_rcnn.py:28-31), the RCNN and the re-id
+    heads train; the step is jmodt_amd/train_joint.rcnn_step"""
     from jmodt_amd import train_joint
-    st = make_detect_state(frames, seed, dev, tiny=tiny)
+    st = make_detect_state(frames, seed, dev, tiny=tiny, kind=kind)
     eng = st["engine"]
-    if os.environ.get("JM_JOINT_ROUTE", "rows") in ("rows", "graphs", "auto"):
+    train_joint.prepare_rcnn(eng)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    rois_per_frame = min(64, eng.cfg.rpn_post_nms_top_n)
+    st["tids"] = torch.randint(0, 13, (frames, rois_per_frame), generator=g).float().to(dev)
+    st["opt"] = torch.optim.Adam(train_joint.rcnn_parameters(eng), lr=2e-4, weight_decay=1e-2, fused=True)
+    st["rois_per_frame"] = rois_per_frame
+    st["rcnn"] = True
+    return st
+
+
+def make_joint_state(frames, seed, dev, tiny=False, kind="uniform"):
+    """BASELINE configs[3] in JOINT mode (tools/train.py:96-107 without cfg.TRAIN.FINETUNE, RPN.FIXED off): every parameter of the
+    detector and of the affinity heads trains; the step is jmodt_amd/train_joint.joint_step"""
+    from jmodt_amd import train_joint
+    st = make_detect_state(frames, seed, dev, tiny=tiny, kind=kind)
+    eng = st["engine"]
+    if joint_route() == "rows":
         if "JM_JOINT_CONV_FIND" not in os.environ and not tiny:
             train_joint.CONV_FIND = True     # MIOpen's find mode for the image convolutions, forward and backward (+2 %; seconds at first use)
-        train_joint.prepare_rows(eng)    # train mode (RPN-head dropout active), BatchNorm on its running statistics: cfg.RPN.FIXED-style
+        train_joint.prepare_rows(eng)    # train mode (RPN-head dropout active), every BatchNorm FROZEN on its running statistics
     else:
         eng.train()                      # the un-fused operator route: BatchNorm on batch statistics
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -463,11 +486,11 @@ def make_joint_state(frames, seed, dev, tiny=False):
     return st
 
 
-def make_train_state(frames, seed, dev, tiny=False):
+def make_train_state(frames, seed, dev, tiny=False, kind="uniform"):
     """BASELINE configs[3] per-GPU share: `frames` frames (= frames/2 (prev, next) pairs) through the FROZEN
     detector (cfg.RPN.FIXED + finetune: tools/train.py:96-107 trains only the link / start-end heads), then the
     pairwise affinity losses on the 64 sampled RoIs per frame (config.py:153) and Adam"""
-    st = make_detect_state(frames, seed, dev, tiny=tiny)
+    st = make_detect_state(frames, seed, dev, tiny=tiny, kind=kind)
     eng = st["engine"]
     g = torch.Generator(device="cpu").manual_seed(seed)
     rois_per_frame = min(64, eng.cfg.rpn_post_nms_top_n)
@@ -483,6 +506,7 @@ def make_train_state(frames, seed, dev, tiny=False):
 
 
 def _grad_collectives(joint=False):
+    """gradient collectives the last step issued (joint / rcnn steps: train_joint; finetune: affinity_train)"""
     if joint:
         from jmodt_amd import train_joint
         return train_joint.LAST_GRAD_COLLECTIVES
@@ -495,10 +519,15 @@ def train_step(st, world):
     local forward/backward of the pairwise affinity losses -> ONE bucketed gradient all-reduce over RCCL -> Adam"""
     from jmodt_amd.ops.affinity_train import finetune_step_static
     eng = st["engine"]
+    if st.get("rcnn"):
+        from jmodt_amd.train_joint import rcnn_step
+        pf = st.get("prefetch", True)
+        return rcnn_step(eng, st["xyz"], st["image"], st["pts_xy"], st["tids"], st["opt"], world=world, rois_per_frame=st["rois_per_frame"],
+                         next_xyz=_upcoming(st) if pf else None, next_image=st["image"] if pf else None)
     if st.get("joint"):
         from jmodt_amd.train_joint import joint_step
         return joint_step(eng, st["xyz"], st["image"], st["pts_xy"], st["tids"], st["opt"], world=world,
-                          rois_per_frame=st["rois_per_frame"], route=os.environ.get("JM_JOINT_ROUTE", "auto"),
+                          rois_per_frame=st["rois_per_frame"], route=joint_route(),
                           next_xyz=st["xyz"] if st.get("prefetch", True) else None)
     with torch.no_grad():
         pf = st.get("prefetch", True)
@@ -539,14 +568,52 @@ WORKLOAD_TEXT = {
            "pts x 133), RPN nms_normal (6300 boxes), proposal selection, fused RCNN SA1, 128x128 affinity, per frame",
     "train": "BASELINE configs[3]: frozen composed detector forward + data-parallel finetune step of the link / "
              "start-end heads (64 RoIs x 512-d per frame, pairwise affinity losses, bucketed fp32 gradient all-reduce, Adam)",
-    "train_joint": "BASELINE configs[3], joint mode: differentiable forward of the WHOLE detector (un-fused operator route: grouping / "
-                   "interpolation / LI-Fusion gather backward on the jm_*_grad kernels, convolutions on MIOpen's autograd), RPN + RCNN head "
-                   "sums + re-id loss, backward, bucketed fp32 all-reduce of all 16.7 M parameters (66.9 MB), Adam",
+    "train_joint": "BASELINE configs[3], joint mode (every parameter trains): differentiable forward AND backward of the whole detector "
+                   "on the hand-written row kernels (csrc/rows_*.hip: set abstraction on the distinct (centre, neighbour) rows, feature "
+                   "propagation, LI-Fusion gather + attention, heads; image 3x3 / stride-2 / transposed convolutions on MIOpen), RPN + RCNN "
+                   "head sums + re-id loss, bucketed fp32 all-reduce of all 16.7 M parameters (66.9 MB), Adam",
+    "train_joint_operators": "BASELINE configs[3], joint mode (every parameter trains), UN-FUSED operator route: torch autograd over the "
+                             "(B, C, npoint, nsample) tensors (grouping / interpolation / LI-Fusion gather backward on the jm_*_grad kernels, "
+                             "convolutions and BatchNorm on MIOpen's autograd), RPN + RCNN head sums + re-id loss, bucketed fp32 all-reduce "
+                             "of all 16.7 M parameters (66.9 MB), Adam",
+    "train_rcnn": "BASELINE configs[3], the reference's default training mode (config.py:57 RPN.FIXED, point_rcnn.py:28-31): frozen fused "
+                  "RPN forward without gradient -> proposals -> roipool3d -> RCNN forward / backward on the row kernels (csrc/rows_*.hip) + "
+                  "re-id heads (csrc/affinity_train.hip), bucketed fp32 all-reduce of the RCNN's + heads' gradients only, Adam",
     "dense_detect": "BASELINE configs[4], composed: the SAME detect+affinity forward as `detect` on 65536-pt frames (co-operative "
                     "FPS, hash-grid ball query / 3-NN at the first level), 256 proposals/frame, 256x256 affinity per frame pair",
     "dense": "supplementary, BASELINE configs[4] shapes: 65536-pt clouds (co-operative FPS -> 4096, dual ball query, "
              "grouping, 3-NN), roipool3d+canonical for 256 RoIs, 256x256 affinity per frame",
 }
+
+
+def workload_key(args):
+    if args.workload == "train" and args.joint:
+        return "train_joint" if joint_route() == "rows" else "train_joint_operators"
+    if args.workload == "train" and getattr(args, "rcnn", False):
+        return "train_rcnn"
+    return args.workload
+
+
+def train_mode_keys(args):
+    """what a training line times, spelled out in `config`: which route, which loss, where the RoIs
+    come from, what the BatchNorms do — so that nobody reads the proxy step as the reference's full training iteration"""
+    if args.workload != "train":
+        return {}
+    proxy = {"loss": "proxy: sums of the head outputs + the re-id loss of rcnn.py:204-287 / train_functions.py:282-329 (the reference's "
+                     "classification / regression losses are the caller's: SURVEY.md section 2 out of scope)",
+             "proposals": "test-mode first-K of the ProposalLayer stand in for ProposalTargetLayer's GT-sampled RoIs (config.py:153: 64 per frame)"}
+    if args.joint:
+        rows = joint_route() == "rows"
+        return {"mode": "joint (RPN.FIXED off: every parameter trains)", "route": joint_route(),
+                "batchnorm": ("frozen: eval-mode running statistics folded into the weights, gamma / beta trainable (the reference's joint "
+                              "mode trains BatchNorm on batch statistics: JM_JOINT_ROUTE=operators is that form)" if rows else
+                              "train mode: batch statistics, running statistics updated (as the reference's joint mode)"), **proxy}
+    if getattr(args, "rcnn", False):
+        return {"mode": "rcnn (config.py:57 RPN.FIXED = True, FINETUNE off: the reference's default)", "route": "frozen fused engine + rows",
+                "batchnorm": "RPN: eval mode, folded (point_rcnn.py:29-30); RCNN: none (config.py RCNN.USE_BN = False)", **proxy}
+    return {"mode": "finetune (tools/train.py:96-107: link / start-end heads only)", "route": "frozen fused engine + affinity_train kernels",
+            "batchnorm": "eval mode, folded", "loss": "the re-id loss of train_functions.py:282-329 (L1 forms)",
+            "proposals": "test-mode first-K of the ProposalLayer (config.py:153: 64 per frame)"}
 
 
 # the image branch's own kernels: not a SURVEY.md §8 row (the reference calls nn.Conv2d there); priced in `image_branch_kernel`
@@ -915,13 +982,17 @@ def main():
                          "engine workloads (work-bound: a second chain in flight changes nothing at 8 frames per step and costs 2-4 %% at "
                          "4, tools/prefetch_depth_probe.py)")
     ap.add_argument("--tiny", action="store_true", help="smoke-sized shapes (tests only; the JSON says so)")
-    ap.add_argument("--workload", default="detect", choices=[w for w in WORKLOAD_TEXT if w != "train_joint"])
+    ap.add_argument("--workload", default="detect", choices=[w for w in WORKLOAD_TEXT if not w.startswith("train_")])
     ap.add_argument("--cloud", default="uniform", choices=["uniform", "kitti", "packed"],
-                    help="detect only: the synthetic cloud the whole line (value, kernel table) is measured on; the default line "
-                         "always carries all three values under `clouds`")
+                    help="detect / train: the synthetic cloud the whole line (value, kernel table) is measured on; the default detect line "
+                         "and the --joint / --rcnn train lines always carry all three values under `clouds`")
     ap.add_argument("--joint", action="store_true",
-                    help="train only: joint mode — forward / backward through the WHOLE detector (un-fused autograd route) and the "
-                         "bucketed all-reduce of all 16.7 M parameters (66.9 MB), instead of the finetune step of the two heads (4.2 MB)")
+                    help="train only: joint mode — forward / backward through the WHOLE detector (row kernels; JM_JOINT_ROUTE=operators: the "
+                         "un-fused autograd route) and the bucketed all-reduce of all 16.7 M parameters (66.9 MB), instead of the finetune "
+                         "step of the two heads (4.2 MB)")
+    ap.add_argument("--rcnn", action="store_true",
+                    help="train only: the reference's default mode (config.py:57 RPN.FIXED) — frozen fused RPN forward, RCNN + re-id heads "
+                         "forward / backward on the row kernels, all-reduce of their gradients only")
     ap.add_argument("--no-listed", action="store_true",
                     help="RPN set-abstraction scales on the dense kernels (every back-filled row executed) instead of the listed form")
     ap.add_argument("--headline-only", action="store_true",
@@ -938,6 +1009,8 @@ def main():
                     help="re-execute under torch.distributed.run even for --gpus 1 (the N > 1 launch path incl. RCCL init / "
                          "barrier / all-reduce on one GPU: what the GPU tier runs)")
     args = ap.parse_args()
+    if (args.joint or args.rcnn) and args.workload != "train" or (args.joint and args.rcnn):
+        raise SystemExit("bench.py: --joint / --rcnn are modes of --workload train (one of them)")
     if args.batch is None:
         args.batch = 4 if args.workload == "train" else 8
 
@@ -1052,7 +1125,8 @@ def main():
         dense_in = make_dense_inputs(args.batch, seed + 4, dev, small=args.tiny)
         step = lambda: dense_step(dense_in)  # noqa: E731
     else:
-        train_st = (make_joint_state if args.joint else make_train_state)(args.batch, seed + 3, dev, tiny=args.tiny)
+        train_st = (make_joint_state if args.joint else make_rcnn_state if args.rcnn else make_train_state)(
+            args.batch, seed + 3, dev, tiny=args.tiny, kind=args.cloud)
         train_st["engine"].overlap = not args.no_overlap
         train_st["engine"].prefetch_depth = args.prefetch_depth
         train_st["prefetch"] = not args.no_prefetch
@@ -1235,6 +1309,29 @@ def main():
         if dist is not None:
             dist.barrier(group=ctl)
 
+    if args.workload == "train" and (args.joint or args.rcnn) and args.steps >= 2 and not args.headline_only and not args.tiny and args.cloud == "uniform":
+        # the same step on the other synthetic clouds (the uniform one leaves ~1 distinct row per RPN group; these have rows): a few
+        # steps each after the timed region, this rank x world
+        n_var = max(2, min(10, args.steps))
+        clouds = {"uniform": {"value": None, "note": "the headline workload"}}
+        for kind in ("kitti", "packed"):
+            keep = {k: train_st[k] for k in ("xyz", "image", "pts_xy")}
+            train_st.update(detect_inputs(args.batch, seed + 3, dev, False, kind))
+            try:
+                step(); step()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                for _ in range(n_var):
+                    step()
+                torch.cuda.synchronize()
+                clouds[kind] = {"value": round(world * args.batch * n_var / (time.perf_counter() - t2), 2), "note": f"{n_var} steps after the timed region"}
+            finally:
+                train_st.update(keep)
+                step(); step()
+                torch.cuda.synchronize()
+        variants["clouds"] = clouds
+        if dist is not None:
+            dist.barrier(group=ctl)
     if args.workload == "detect" and args.headline_only:
         torch.cuda.synchronize()
         variants["clouds"] = {"uniform": {"value": None, "rcnn": rcnn_rows(), "note": "--headline-only: the other clouds were not run"}}
@@ -1347,9 +1444,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": (WORKLOAD_TEXT["train_joint"] if args.workload == "train" and args.joint else WORKLOAD_TEXT[args.workload])
+            "config": {"workload": WORKLOAD_TEXT[workload_key(args)]
                                    + (" [TINY smoke shapes: not a benchmark]" if args.tiny else "")
                                    + (f" [cloud: {args.cloud}]" if args.cloud != "uniform" else ""),
+                       **train_mode_keys(args),
                        "frames_per_gpu_per_step": args.batch,
                        "points": (65536 if args.workload in ("dense", "dense_detect") else 16384) if not args.tiny else "tiny",
                        "parallelism": (f"dp{world} (gradient all-reduce)" if args.workload == "train" else f"replicas x{world}")
@@ -1389,11 +1487,12 @@ def main():
             "grad_allreduce": ({"world": world, "bytes_per_step": next((k.get("algo_bytes_per_step") for k in kernels
                                                                          if k["kernel"].endswith("grad_allreduce(RCCL)")), None),
                                 "ms_per_step": next((k["ms_per_step"] for k in kernels if k["kernel"].endswith("grad_allreduce(RCCL)")), None),
-                                "issued": _grad_collectives(args.joint),
+                                "issued": _grad_collectives(args.joint or args.rcnn),
                                 "mode": "RCCL all_reduce(SUM) on the flat fp32 gradient bucket, issued whenever a process group exists (a "
                                         "one-rank group included)" if dist is not None else "no process group: nothing issued",
                                 "note": ("joint mode: the gradient of every parameter in 64 MiB flat fp32 buckets (66.9 MB = one collective at the "
-                                         "reference widths); " if args.joint else "") +
+                                         "reference widths); " if args.joint else
+                                         "rcnn mode: the gradient of the RCNN's and the re-id heads' parameters in one flat fp32 bucket; " if args.rcnn else "") +
                                         "one flat fp32 all-reduce of the link / start-end heads' gradients per step (RCCL; HIP events on the "
                                         "launching stream around the collective and its wait) + two 3-float / 1-float all-reduces (global "
                                         "loss-mean counts, loss); `issued` = gradient collectives of the last step"}
@@ -1428,7 +1527,7 @@ def main():
             result["dropped_fractions"] = [{"path": p_, "value": v_} for p_, v_ in dropped]
         # stdout carries ONE compact line (<= COMPACT_LIMIT bytes); the full record (kernel table, variants, per-stage parity
         # against the CPU chain) goes to a file next to it
-        full_path = args.full_out or os.path.join("bench_out", args.workload + ("_joint" if args.joint else "") + ("" if args.cloud == "uniform" else "_" + args.cloud)
+        full_path = args.full_out or os.path.join("bench_out", args.workload + ("_joint" if args.joint else "_rcnn" if args.rcnn else "") + ("" if args.cloud == "uniform" else "_" + args.cloud)
                                                   + ("_tiny" if args.tiny else "") + ".json")
         abs_path = full_path if os.path.isabs(full_path) else os.path.join(ROOT, full_path)
         try:

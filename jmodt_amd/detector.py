@@ -38,6 +38,7 @@ from .ops.pointnet2 import pytorch_utils as pt_utils
 from .ops.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModule, PointnetSAModuleMSG
 from .ops.pointnet2.pyramid import FpsPyramid, side_stream
 
+_RCNN_KEYS = ("xyz_up.", "merge_down", "rcnn_")   # keys of `_folded` made from rcnn_net's parameters (see _refresh)
 _FPS_SLOTS = (0, 4, 5, 6)      # side-stream slots of the FPS pyramids in flight (1: image branch, 2: start/end head, 3: detections)
 from .profile import prof
 from .ops.rcnn_lift import PackedRcnnLift
@@ -349,13 +350,23 @@ class DetectAffinityEngine(nn.Module):
         # list is rebuilt only when some module of the process (re-)registered a parameter or buffer since it was made — torch's
         # global registration hooks bump _REGISTRATION_EPOCH on every `register_parameter` / `register_buffer`, which is what an
         # attribute assignment of a Parameter, load_state_dict(assign=True) and parametrizations go through
+        # Two groups, each with its own signature: the RPN (backbone, image branch, RPN heads) and the RCNN.  The reference's default
+        # training mode (config.py:57 RPN.FIXED, point_rcnn.py:28-31) updates the RCNN every step under a FROZEN RPN — the frozen
+        # half's ~100 packed weights must survive those optimizer steps (train_joint.rcnn_step)
         if self._sig_tensors is None or self._sig_epoch != _REGISTRATION_EPOCH[0]:
             skip = {id(t) for head in (self.rcnn_net.link_layer, self.rcnn_net.se_layer) for t in head.parameters()}
-            self._sig_tensors = [t for t in list(self.parameters()) + list(self.buffers()) if id(t) not in skip]
+            rcnn = [t for t in list(self.rcnn_net.parameters()) + list(self.rcnn_net.buffers()) if id(t) not in skip]
+            mine = {id(t) for t in rcnn} | skip
+            self._sig_tensors = ([t for t in list(self.parameters()) + list(self.buffers()) if id(t) not in mine], rcnn)
             self._sig_epoch = _REGISTRATION_EPOCH[0]
-        sig = tuple([(id(t), t.data_ptr(), t._version) for t in self._sig_tensors])
-        if sig != self._folded_sig:
-            self._folded.clear()
+        sig = tuple(tuple([(id(t), t.data_ptr(), t._version) for t in grp]) for grp in self._sig_tensors)
+        old = self._folded_sig
+        if sig != old:
+            if old is None or sig[0] != old[0]:
+                self._folded.clear()
+            else:
+                for k in [k for k in self._folded if k.startswith(_RCNN_KEYS)]:
+                    del self._folded[k]
             self._folded_sig = sig
 
     def _attention_fusion(self, tag: str, mod: AttentionFusion, point_feats: torch.Tensor, img_feats: torch.Tensor):

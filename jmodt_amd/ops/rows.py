@@ -672,6 +672,27 @@ def deconv_pyramid(maps: Sequence[torch.Tensor], weights: Sequence[torch.Tensor]
 
 
 # ---------------------------------------------------------------------------------------------------- BatchNorm folding
+# A convolution library may read PAST the end of a small weight tensor: MIOpen's data-gradient kernel for the 1 x 1 convolution of
+# 16 -> 8 channels (2 x 96 x 320, fp32: the fusion convolution of DetectorConfig.tiny()) loads whole tiles of output channels from its
+# 512-byte weight without a bound — a device memory fault whenever that tensor is the last block of a caching-allocator segment and
+# the next page is unmapped (tools/miopen_oob_probe.py reproduces it with plain torch; DESIGN.md section 6: the "rows backward fault"
+# of round 5 was this, not stream ordering).  Folded weights are temporaries made every step, so they would land anywhere: they are
+# carved from ONE slab with slack behind the last of them — an over-read of a folded copy stays inside mapped, owned memory (and the
+# step makes one allocation instead of one per convolution).
+FOLD_SLAB_SLACK = 64 << 10       # bytes behind the last folded weight (the over-read seen: < 4 x the tensor; the largest folded weight
+                                 # of the reference network is 2.4 MB and sits in front of others)
+
+
+def _slab_like(ws):
+    """[empty tensor laid out like w for w in ws] as views of one float32 slab: 256-byte aligned, FOLD_SLAB_SLACK bytes behind the last"""
+    offs, total = [], 0
+    for w in ws:
+        offs.append(total)
+        total += (w.numel() + 63) // 64 * 64
+    slab = torch.empty((total + FOLD_SLAB_SLACK // 4,), dtype=_f32, device=ws[0].device)
+    return [slab[o:o + w.numel()].as_strided(w.shape, w.stride()) for o, w in zip(offs, ws)]
+
+
 class _FoldAll(Function):
     """wf_l = w_l * s[soff_l + row] for every (convolution, BatchNorm) pair of a network in ONE launch, and its backward in one more
     (csrc/rows_ops.hip: fold_bn_multi).  apply(s (sum C,), soffs, w_0, w_1, ...) -> (wf_0, wf_1, ...), each wf_l laid out like w_l."""
@@ -687,7 +708,7 @@ class _FoldAll(Function):
         for w in ws:
             if not (w.is_contiguous() or (w.dim() == 4 and w.is_contiguous(memory_format=torch.channels_last))):
                 raise RuntimeError("fold: weights must be dense (contiguous or channels-last)")
-        outs = [torch.empty_like(w) for w in ws]
+        outs = _slab_like(ws)
         rows = (ctypes.c_int * n)(*[w.shape[0] for w in ws])
         cols = (ctypes.c_int * n)(*[w.numel() // w.shape[0] for w in ws])
         so = (ctypes.c_int * n)(*soffs)

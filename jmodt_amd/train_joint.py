@@ -229,6 +229,81 @@ def _rows_forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local, ro
     return total
 
 
+def rcnn_parameters(engine):
+    """what tools/train.py:104 ends up updating with the shipped configuration (config.py:57 RPN.FIXED = True, FINETUNE off): the
+    optimizer holds model.parameters(), the RPN runs under no_grad (point_rcnn.py:28-31) — only the RCNN's tensors (set abstraction,
+    heads, link / start-end heads) ever receive a gradient"""
+    return [p for p in engine.rcnn_net.parameters() if p.requires_grad]
+
+
+def prepare_rcnn(engine) -> None:
+    """once, before the optimizer is built: the RPN in eval mode without gradient (point_rcnn.py:29-30 `self.rpn.eval()` under
+    set_grad_enabled(False)), the RCNN in train mode with gradient"""
+    engine.eval()
+    engine.rcnn_net.train()
+    for p in engine.rpn.parameters():
+        p.requires_grad_(False)
+    for p in engine.rcnn_net.parameters():
+        p.requires_grad_(True)
+    bad = [n for n, m in engine.rcnn_net.named_modules() if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d))]
+    if bad:      # config.py:107 RCNN.USE_BN = False; a train-mode BatchNorm (batch statistics) has no rows form
+        raise NotImplementedError(f"rcnn_step: the RCNN carries BatchNorm layers ({bad[:3]} ...); the rows route folds eval-mode statistics only")
+
+
+def rcnn_forward_backward(engine, xyz, image, pts_xy, gt_tids, world=None, local=False, rois_per_frame: int = 64,
+                          next_xyz=None, next_image=None):
+    """forward + loss + backward of the RPN-fixed step; returns (local loss, outputs).  The frozen half is the fused inference
+    engine as it stands (detector.py: rpn_forward, proposals, pts_feature: no autograd graph, the next batch's FPS pyramid and image
+    pyramid started on their side streams under this batch's RCNN); the trainable half is train_rows.rcnn_forward_rows on the
+    CURRENT stream (forward and backward = csrc/rows_*.hip), the re-id loss on csrc/affinity_train.hip."""
+    import torch.distributed as tdist
+    from .ops.affinity_train import AffinityTrainState, affinity_train_loss
+    from .train_rows import BnFold, rcnn_forward_rows
+    cfg = engine.cfg
+    with torch.no_grad():
+        rpn_out = engine.rpn_forward(xyz, image, pts_xy, next_xyz, next_image)
+        rois, _ = engine.proposals(rpn_out)
+        rois = rois[:, :rois_per_frame].contiguous()
+        pf = engine.pts_feature(rpn_out)
+        pooled, _, count = roipool3d_canonical_gpu(xyz, pf, rois, cfg.pool_extra_width, cfg.rcnn_num_points, return_count=True)
+        pts_input = pooled.view(-1, cfg.rcnn_num_points, pooled.shape[-1])
+    fold = BnFold(None, pairs=[])                       # (no BatchNorm in the RCNN: prepare_rcnn checks)
+    out = prof.region("rcnn_forward(span)", lambda: rcnn_forward_rows(engine, pts_input, fold, count.view(-1)))
+    B = gt_tids.shape[0]
+    feats = out["rcnn_feat"].view(B, -1, out["rcnn_feat"].shape[-1])
+    st = AffinityTrainState(feats, gt_tids)
+    counts = None
+    if jdist.collective_path(world, local):             # the re-id means run over the GLOBAL element counts (as in the finetune step)
+        counts = st.counts.clone()
+        tdist.all_reduce(counts, op=tdist.ReduceOp.SUM)
+    reid = affinity_train_loss(st, engine.rcnn_net.link_layer, engine.rcnn_net.se_layer, counts=counts)
+    loss = out["rcnn_cls"].sum() + out["rcnn_reg"].sum() + reid
+    prof.region("rcnn_backward(span)", lambda: loss.backward())
+    out.update(rois=rois, rpn_cls=rpn_out["rpn_cls"], rpn_reg=rpn_out["rpn_reg"])
+    return loss.detach(), out
+
+
+def rcnn_step(engine, xyz, image, pts_xy, gt_tids, optimizer, world: Optional[int] = None, rois_per_frame: int = 64,
+              bucket_bytes: int = 64 << 20, next_xyz=None, next_image=None, local: bool = False) -> torch.Tensor:
+    """one data-parallel step of the reference's DEFAULT training mode — tools/train.py:86-107 with the shipped config.py:57
+    (`RPN.FIXED = True`) and FINETUNE off: the RPN is evaluated without gradient (point_rcnn.py:28-31), the RCNN and the re-id heads
+    train (rcnn.py:158-287).  This rank's frames: frozen fused detector forward -> proposals -> RoI pooling -> RCNN forward / loss /
+    backward on the row kernels -> ONE bucketed all-reduce of the RCNN's gradients (head sums + re-id loss with global counts: shard
+    gradients ADD, dist.py) -> optimizer step.  Returns the local loss (device scalar).  Call prepare_rcnn(engine) once before
+    building the optimizer."""
+    params = rcnn_parameters(engine)
+    if any(p.requires_grad for p in engine.rpn.parameters()) or engine.rpn.training:
+        raise RuntimeError("rcnn_step runs the RPN frozen: call train_joint.prepare_rcnn(engine) first (point_rcnn.py:28-31)")
+    optimizer.zero_grad(set_to_none=True)
+    loss, _ = rcnn_forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local, rois_per_frame, next_xyz, next_image)
+    global LAST_GRAD_COLLECTIVES
+    LAST_GRAD_COLLECTIVES = prof.region("grad_allreduce(RCCL)", lambda: jdist.allreduce_gradients(params, world=world, bucket_bytes=bucket_bytes,
+                                                                                                  average=False, local=local),
+                                        algo_bytes=sum(p.numel() for p in params) * 4)
+    optimizer.step()
+    return loss
+
+
 def _image_stream(engine, device):
     from .ops.pointnet2.pyramid import side_stream
     return side_stream(device, 1) if engine.overlap else None

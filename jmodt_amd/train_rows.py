@@ -259,6 +259,7 @@ def _image_pyramid(fold: BnFold, net, image: torch.Tensor) -> List[torch.Tensor]
 
 import os as _os
 DECONV_GEMM = bool(int(_os.environ.get("JM_DECONV_GEMM", "0")))
+FUSION_CONV_ROWS = bool(int(_os.environ.get("JM_FUSION_CONV_ROWS", "1")))    # (0: MIOpen, for the A/B of DESIGN.md section 6)
 
 
 def _image_fusion_map(fold: BnFold, net, maps: List[torch.Tensor]) -> torch.Tensor:
@@ -288,6 +289,12 @@ def _image_fusion_map(fold: BnFold, net, maps: List[torch.Tensor]) -> torch.Tens
         return y.view(B, H, W, Wf2.shape[0]).permute(0, 3, 1, 2)                              # = channels-last (B, q, H, W)
     de = torch.cat([F.conv_transpose2d(m, dc.weight, None, stride=dc.stride, padding=dc.padding, output_padding=dc.output_padding)
                     for dc, m in zip(net.DeConv, maps)], dim=1)
+    if FUSION_CONV_ROWS and de.is_cuda and de.is_contiguous(memory_format=torch.channels_last) and de.shape[1] % 4 == 0 and Wf2.shape[0] % 4 == 0:
+        # the 1 x 1 fusion convolution + bias + ReLU IS a dense layer on the (B H W, C) rows of the channels-last map: one bounds-checked
+        # GEMM launch per direction (csrc/rows_gemm.hip) instead of a library convolution, a bias / ReLU pass and a channel sum
+        B, ctot, H, W = de.shape
+        y = R.rows_mlp(de.permute(0, 2, 3, 1).reshape(B * H * W, ctot), [(Wf2, b_eff)], [1])  # (B H W, q)
+        return y.view(B, H, W, Wf2.shape[0]).permute(0, 3, 1, 2)                              # = channels-last (B, q, H, W)
     return _BiasReluInplace.apply(F.conv2d(de, Wf, None), b_eff)
 
 
@@ -316,6 +323,9 @@ def backbone_forward_rows(engine, xyz: torch.Tensor, image: torch.Tensor, pts_xy
         with torch.cuda.stream(img_stream):
             blk = net.Img_Block[i]
             w1, t = fold.conv4d(blk.conv1)         # (channels-last when the parameter is: train_joint.prepare_rows converts them once)
+            if img_stream is not main:             # made on the main stream, read here — and by this stream's backward nodes after
+                w1.record_stream(img_stream)       # the fold object is gone: the allocator must not recycle them under those reads
+                t.record_stream(img_stream)        # (w1 = a view of the fold's ONE slab: one block, one mark)
             y = _Conv3x3BiasRelu.apply(image if i == 0 else maps[i - 1], w1, t)
             m = F.conv2d(y, blk.conv2.weight, blk.conv2.bias, stride=blk.conv2.stride, padding=blk.conv2.padding)
             ev = torch.cuda.Event()
@@ -340,6 +350,9 @@ def backbone_forward_rows(engine, xyz: torch.Tensor, image: torch.Tensor, pts_xy
             feats = _attention_rows(fold, net.Fusion_Conv[i], feats, R.feature_gather_rows(maps[i], xy_i))
         l_xyz.append(new_xyz); l_feats.append(feats); l_xy.append(xy_i)
     # the fused image map: issued here (under the feature-propagation modules), consumed by the final attention block
+    if img_stream is not main:
+        for t_ in fold.conv4d(net.image_fusion_conv):
+            t_.record_stream(img_stream)
     with torch.cuda.stream(img_stream):
         fused_img = prof.region("image_deconv+fusion_conv(MIOpen)", lambda: _image_fusion_map(fold, net, maps))
         fused_ev = torch.cuda.Event()
@@ -483,11 +496,9 @@ def rcnn_branch_rows(engine, pts_input, count, fold: BnFold, ready: Optional[tor
 
 def joint_forward_rows(engine, xyz, image, pts_xy, rois_per_frame: int = 64, pyr: Optional[FpsPyramid] = None) -> Dict[str, torch.Tensor]:
     """the detector in TRAIN composition (point_rcnn.py:24-70) on rows; same outputs as train_joint.joint_forward.
-    Its backward runs on three streams (main, image, RCNN).  RULE for callers: no OTHER autograd graph over the same parameters may
-    be alive when it does (outputs of an earlier forward that still carry a grad_fn): that graph's AccumulateGrad nodes, made on
-    the main stream, would take this backward's gradients (torch warns "AccumulateGrad node's stream does not match ...") — with
-    such a graph held, tests/test_gpu_rows.py aborted with a device memory fault in this backward, three runs of three, and passes
-    once it is dropped (detach + gc.collect()), as it does with every launch serialised.  joint_step never holds one."""
+    Its backward runs on three streams (main, image, RCNN), each node on the stream of its forward; gradients cross streams only
+    through the autograd engine's own hand-over.  Safe next to other live autograd graphs over the same parameters (an earlier
+    step's outputs, DDP's stashed AccumulateGrad nodes: tests/test_gpu_rows.py holds two of them across ten asynchronous steps)."""
     fold = BnFold(engine)
     out = rpn_forward_rows(engine, xyz, image, pts_xy, fold, pyr)
     rois, pts_input, count = pooled_rois(engine, xyz, out, rois_per_frame)
