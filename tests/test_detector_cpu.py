@@ -260,7 +260,17 @@ def test_folded_weight_cache_sees_in_place_updates_and_replaced_parameters():
     conv = e.rpn.rpn_cls_layer[0].conv
     conv.weight = torch.nn.Parameter(conv.weight.detach().clone())       # a new object with the same values
     e._refresh()
-    assert "probe" not in e._folded and any(t is conv.weight for t in e._sig_tensors)
+    assert "probe" not in e._folded and any(t is conv.weight for t in e._sig_tensors[0])
+    # the RCNN's tensors are their own group (train_joint.rcnn_step updates them every step under a frozen RPN): a change there drops
+    # the RCNN's folded entries only
+    e._folded["probe"] = 1
+    e._folded["rcnn_probe"] = 1
+    rc = next(p for p in e.rcnn_net.parameters() if not any(p is q for h in (e.rcnn_net.link_layer, e.rcnn_net.se_layer) for q in h.parameters()))
+    assert any(t is rc for t in e._sig_tensors[1])
+    with torch.no_grad():
+        rc.mul_(1.5)
+    e._refresh()
+    assert "probe" in e._folded and "rcnn_probe" not in e._folded
     e._folded["probe"] = 1
     sd = {k: v.clone() for k, v in e.state_dict().items()}
     e.load_state_dict(sd, assign=True)                                   # every parameter replaced
