@@ -943,24 +943,39 @@ def sanitise_fractions(node, path="", dropped=None):
     return dropped
 
 
-def pin_rank(local_rank: int, ranks_on_node: int):
+def pin_rank(local_rank: int, ranks_on_node: int, sysfs: str = "/sys", bus_ids=None):
     """one process per GPU: bind this rank to its own block of host cores and bound its intra-op thread pool (the reference's
     nn.DataParallel runs ONE process, tools/train.py:86-88; eight processes that each enqueue 4 - 20 ms of launches per step on
-    cores they share with the others' 128-thread pools do not).  The block: with `rocm-smi --showtoponuma`-style NUMA information
-    absent in the container, the node's allowed cores are split evenly in rank order — on the 2-socket MI355X hosts ranks 0-3 / 4-7
-    then sit on the socket their GPUs hang off.  JM_BENCH_NO_PIN=1 switches it off.  Returns what was done (goes into the line)."""
+    cores they share with the others' 128-thread pools do not).  The block = whole physical cores of the NUMA node this rank's GPU
+    hangs off (jmodt_amd/hostbind.py: the GPU's PCI address from the HIP runtime, its numa_node and the node's cpulist from sysfs),
+    shared evenly with the other local ranks on that node; where the platform does not tell (numa_node = -1, no sysfs nodes in the
+    container) the allowed cores are split evenly in rank order.  JM_BENCH_NO_PIN=1 switches it off.  Returns what was done (goes
+    into the line)."""
     if os.environ.get("JM_BENCH_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
         return {"pinned": False}
     try:
-        allowed = sorted(os.sched_getaffinity(0))
-        per = max(1, len(allowed) // max(1, ranks_on_node))
-        mine = allowed[local_rank * per:(local_rank + 1) * per] or allowed
+        from jmodt_amd import hostbind
+        got = hostbind.rank_cores(local_rank, ranks_on_node, sorted(os.sched_getaffinity(0)), sysfs, bus_ids)
+        mine = sorted(got["cores"])
         os.sched_setaffinity(0, mine)
-        threads = max(1, min(per, 16))
+        threads = max(1, min(len(mine), 16))
         torch.set_num_threads(threads)
-        return {"pinned": True, "cores": f"{mine[0]}-{mine[-1]}", "n_cores": len(mine), "torch_threads": threads}
+        return {"pinned": True, "cores": hostbind_ranges(mine), "n_cores": len(mine), "torch_threads": threads,
+                "source": got["source"], "numa_node": got["numa_node"]}
     except OSError as e:                   # (a container that forbids it: run unpinned, say so)
         return {"pinned": False, "error": str(e)}
+
+
+def hostbind_ranges(cores):
+    """[0, 1, 2, 3, 64, 65] -> "0-3,64-65" """
+    out, i = [], 0
+    while i < len(cores):
+        j = i
+        while j + 1 < len(cores) and cores[j + 1] == cores[j] + 1:
+            j += 1
+        out.append(str(cores[i]) if i == j else f"{cores[i]}-{cores[j]}")
+        i = j + 1
+    return ",".join(out)
 
 
 def main():

@@ -15,12 +15,12 @@
 
 namespace jm {
 
-constexpr int DET_MAX_M = 1024;
+constexpr int DET_MAX_M = 32768;      // slots per frame: the keys of one frame in dynamic LDS (128 KB of the CU's 160 KB at the maximum)
 
 __global__ void __launch_bounds__(256)
 detections_sort_kernel(int M, const float* __restrict__ boxes, const float* __restrict__ raw, float thresh, long long* __restrict__ order,
                        int* __restrict__ counts, float* __restrict__ bev) {
-    __shared__ float key[DET_MAX_M];
+    extern __shared__ float key[];          // M floats (the launcher sizes it)
     __shared__ int cnt;
     const int b = blockIdx.x;
     const float* rs = raw + (size_t)b * M;
@@ -85,7 +85,15 @@ extern "C" int jm_detections_sort(int frames, int slots, const float* boxes, con
     JM_REQUIRE(frames >= 0 && slots >= 0 && slots <= DET_MAX_M, "detections_sort: at most %d slots per frame (got %d)", DET_MAX_M, slots);
     if (frames == 0) return JM_OK;
     JM_REQUIRE(counts && (slots == 0 || (boxes && raw_scores && order && bev)), "detections_sort: null pointer");
-    hipLaunchKernelGGL(detections_sort_kernel, dim3((unsigned)frames), dim3(256), 0, (hipStream_t)stream, slots, boxes, raw_scores, score_thresh,
+    // (the reference's eval keeps at most config.py:213 RPN_POST_NMS_TOP_N = 100 slots; 1024 slots = 4 KB; above 64 KB of dynamic LDS the
+    // attribute must say so, once)
+    const size_t lds = (size_t)slots * sizeof(float);
+    if (lds > (48u << 10)) {
+        static const bool once = [] { (void)hipFuncSetAttribute((const void*)detections_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                (int)(DET_MAX_M * sizeof(float))); return true; }();
+        (void)once;
+    }
+    hipLaunchKernelGGL(detections_sort_kernel, dim3((unsigned)frames), dim3(256), lds, (hipStream_t)stream, slots, boxes, raw_scores, score_thresh,
                        order, counts, bev);
     return check_launch("detections_sort");
 }

@@ -725,7 +725,11 @@ class DetectAffinityEngine(nn.Module):
 
     @torch.no_grad()
     def rpn_forward(self, xyz, image, pts_xy, next_xyz=None, next_image=None) -> Dict[str, torch.Tensor]:
-        """RPN.forward (rpn.py:71-87): backbone features + objectness / box regression per point"""
+        """RPN.forward (rpn.py:71-87): backbone features + objectness / box regression per point.
+        rpn_cls (B, N, 1) and rpn_reg (B, N, C) are STRIDED views of one channel-major (B, 1 + C, N) buffer whenever the two heads run
+        as one stack (the engine's own consumers read it in place): same values and shapes as the reference's tensors, `.reshape`,
+        indexing and every operator work; a caller that wants `.view(-1, C)` (the reference's loss code does, on the TRAIN route's
+        outputs, which are contiguous) calls `.contiguous()` first."""
         feats = self.backbone(xyz, image, pts_xy, next_xyz, next_image)
         def heads():
             both = self._rpn_heads_stack(feats)

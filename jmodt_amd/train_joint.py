@@ -194,15 +194,15 @@ def _rows_forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local, ro
     pyr = engine._take_prefetched(xyz)
     if next_xyz is not None:
         engine.prefetch(next_xyz, None)
-    fold = BnFold(engine)
+    fold = BnFold(engine.rpn)                   # (the RCNN branch folds its own BatchNorms, on its stream, into its own graph)
     out = rpn_forward_rows(engine, xyz, image, pts_xy, fold, pyr)
     rois, pts_input, count = pooled_rois(engine, xyz, out, rois_per_frame)
     pooled_ev = torch.cuda.Event()
-    pooled_ev.record()                          # (the fold's tensors the RCNN reads were made before this point too)
+    pooled_ev.record()
     n = float(out["rpn_cls"].shape[1])
     rpn_loss = (out["rpn_cls"].sum() + out["rpn_reg"].sum()) / n
     rpn_loss.backward()
-    rc = rcnn_branch_rows(engine, pts_input, count, fold, ready=pooled_ev)
+    rc = rcnn_branch_rows(engine, pts_input, count, ready=pooled_ev)
     side = rc.pop("_stream")
     main = torch.cuda.current_stream(xyz.device)
     B = gt_tids.shape[0]
@@ -267,7 +267,7 @@ def rcnn_forward_backward(engine, xyz, image, pts_xy, gt_tids, world=None, local
         pf = engine.pts_feature(rpn_out)
         pooled, _, count = roipool3d_canonical_gpu(xyz, pf, rois, cfg.pool_extra_width, cfg.rcnn_num_points, return_count=True)
         pts_input = pooled.view(-1, cfg.rcnn_num_points, pooled.shape[-1])
-    fold = BnFold(None, pairs=[])                       # (no BatchNorm in the RCNN: prepare_rcnn checks)
+    fold = BnFold(engine.rcnn_net)                      # (config.py:107 ships none; eval-mode ones would fold here)
     out = prof.region("rcnn_forward(span)", lambda: rcnn_forward_rows(engine, pts_input, fold, count.view(-1)))
     B = gt_tids.shape[0]
     feats = out["rcnn_feat"].view(B, -1, out["rcnn_feat"].shape[-1])

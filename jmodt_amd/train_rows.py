@@ -472,10 +472,13 @@ def pooled_rois(engine, xyz, rpn_out: Dict[str, torch.Tensor], rois_per_frame: i
     return rois, pooled.view(-1, cfg.rcnn_num_points, pooled.shape[-1]), count.view(-1)
 
 
-def rcnn_branch_rows(engine, pts_input, count, fold: BnFold, ready: Optional[torch.cuda.Event] = None) -> Dict[str, torch.Tensor]:
+def rcnn_branch_rows(engine, pts_input, count, fold: Optional[BnFold] = None, ready: Optional[torch.cuda.Event] = None) -> Dict[str, torch.Tensor]:
     """stream R: the RCNN (rcnn.py:158-202).  Its BACKWARD then runs there too (autograd: a node's backward on its forward's
     stream), next to the backbone's backward on the main stream — neither feeds the other: roipool3d has no gradient.  The
-    caller's stream waits for the outputs (main.wait_stream) before it reads them."""
+    caller's stream waits for the outputs (main.wait_stream) before it reads them.
+    fold: None = the branch folds the RCNN's own BatchNorms (config.py:107 ships none) on ITS stream, into a graph of its own —
+    the RPN's and the RCNN's halves of the loss are back-propagated separately (train_joint._rows_forward_backward), and a fold node
+    serves one backward."""
     dev = pts_input.device
     main = torch.cuda.current_stream(dev)
     side = side_stream(dev, 3) if engine.overlap else main
@@ -486,7 +489,7 @@ def rcnn_branch_rows(engine, pts_input, count, fold: BnFold, ready: Optional[tor
     else:
         side.wait_stream(main)
     with torch.cuda.stream(side):
-        out = rcnn_forward_rows(engine, pts_input, fold, count)
+        out = rcnn_forward_rows(engine, pts_input, BnFold(engine.rcnn_net) if fold is None else fold, count)
     if side is not main:
         pts_input.record_stream(side)
         count.record_stream(side)
@@ -499,10 +502,10 @@ def joint_forward_rows(engine, xyz, image, pts_xy, rois_per_frame: int = 64, pyr
     Its backward runs on three streams (main, image, RCNN), each node on the stream of its forward; gradients cross streams only
     through the autograd engine's own hand-over.  Safe next to other live autograd graphs over the same parameters (an earlier
     step's outputs, DDP's stashed AccumulateGrad nodes: tests/test_gpu_rows.py holds two of them across ten asynchronous steps)."""
-    fold = BnFold(engine)
+    fold = BnFold(engine.rpn)
     out = rpn_forward_rows(engine, xyz, image, pts_xy, fold, pyr)
     rois, pts_input, count = pooled_rois(engine, xyz, out, rois_per_frame)
-    rc = rcnn_branch_rows(engine, pts_input, count, fold)
+    rc = rcnn_branch_rows(engine, pts_input, count)
     side = rc.pop("_stream")
     main = torch.cuda.current_stream(xyz.device)
     if side is not main:

@@ -34,11 +34,13 @@ def _select_reference(pred_boxes3d, raw_scores, feats, score_thresh, nms_thresh)
                 feats=out_feats, count=num_keep.to(torch.int32), roi_index=torch.where(live, src, torch.zeros_like(src)))
 
 
-@pytest.mark.parametrize("B,M,C,seed", [(8, 128, 512, 0), (3, 100, 64, 1), (1, 1, 8, 2), (2, 37, 12, 3)])
+@pytest.mark.parametrize("B,M,C,seed", [(8, 128, 512, 0), (3, 100, 64, 1), (1, 1, 8, 2), (2, 37, 12, 3),
+                                        (2, 1500, 16, 4), (1, 20000, 4, 5)])          # (> 1024 / > 16384 slots: keys in dynamic LDS)
 def test_select_detections_two_kernels_equal_the_framework_formulation(B, M, C, seed):
     from jmodt_amd.ops.detections import select_detections
     g = torch.Generator().manual_seed(seed)
-    centre = torch.rand(B, M, 3, generator=g) * torch.tensor([8.0, 1.0, 8.0])          # crowded: the NMS has work to do
+    spread = 8.0 * max(1.0, (M / 128.0) ** 0.5)
+    centre = torch.rand(B, M, 3, generator=g) * torch.tensor([spread, 1.0, spread])    # crowded: the NMS has work to do
     size = torch.tensor([1.5, 1.6, 3.9]) * (0.9 + 0.2 * torch.rand(B, M, 3, generator=g))
     ry = (torch.rand(B, M, 1, generator=g) * 2 - 1) * 3.14159
     boxes = torch.cat([centre, size, ry], dim=2).to(DEV)

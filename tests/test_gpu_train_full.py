@@ -1,0 +1,90 @@
+"""GPU tier (-m gpu): the DEFAULT training route — train_rows.joint_forward_rows, what joint_step(route="auto") and `bench.py --workload
+train --joint` run, three streams, asynchronous — at the BENCHMARKED widths (DetectorConfig.survey(): 16.7 M parameters, hidden widths
+to 512, 16384-point frames on the 384 x 1280 canvas) on the three benchmark clouds.
+
+  * forward: backbone features and RPN heads against oracle/pipeline.Chain in float64 (the restatement of backbone.py:159-196 /
+    pointnet2_modules.py:20-63,135-164 that every composed inference test is checked against, itself pinned to the reference's
+    Python in tests/test_oracle_cpu.py), the RCNN on the route's own pooled points against Chain.rcnn (rcnn.py:176-202);
+  * backward: the gradient of every parameter against the operator route (torch autograd over the grouped (B, C, npoint, nsample)
+    tensors, pinned to the reference's autograd at 5e-4 in test_gpu_train_joint.py), same frames, same RoIs, eval-mode BatchNorm.
+The tiny-configuration tests of test_gpu_rows.py select other kernels (narrow layers, one wave patch shape); these are the shapes
+that are timed."""
+import numpy as np
+import pytest
+import torch
+
+from jmodt_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+K = 64                 # RoIs per frame of the training step (config.py:153)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _close(got, want, tol, what):
+    got = got.detach().double().cpu()
+    want = torch.as_tensor(want).double().cpu()
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got - want).abs().max())
+    assert err <= tol * scale, (what, err, scale)
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from jmodt_amd.detector import DetectorConfig
+    from tests.test_gpu_detector import make_engine
+    eng = make_engine(seed=5, cfg=DetectorConfig.survey()).to(DEV).eval()
+    for p in eng.parameters():
+        p.requires_grad_(True)
+    return eng
+
+
+@pytest.mark.parametrize("kind", ["uniform", "kitti", "packed"])
+def test_rows_route_at_the_benchmarked_widths(engine, kind):
+    from jmodt_amd import train_joint
+    from jmodt_amd.train_rows import joint_forward_rows, pooled_rois
+    from oracle.pipeline import Chain
+    from tests.test_gpu_rows import _grads, _relative_gradient_error
+    eng = engine
+    xyz_h, img_h, xy_h = synth.frames(2, 16384, 4321, kind=kind)
+    xyz, img, xy = T(xyz_h), T(img_h), T(xy_h)
+    tids = torch.randint(0, 6, (2, K), generator=torch.Generator().manual_seed(4)).float().to(DEV)
+    eng.zero_grad(set_to_none=True)
+    # ---- the rows route as joint_step runs it (asynchronous, three streams)
+    got = joint_forward_rows(eng, xyz, img, xy, rois_per_frame=K)
+    train_joint.thin_loss(eng, got, tids).backward()
+    torch.cuda.synchronize()
+    mine = _grads(eng)
+    eng.zero_grad(set_to_none=True)
+    # ---- forward against the float64 chain
+    chain = Chain(eng.state_dict(), eng.cfg, torch.float64)
+    want = chain.rpn(xyz_h, img_h, xy_h)
+    assert float(want["backbone_features"].abs().max()) > 0.5
+    _close(got["backbone_features"], want["backbone_features"], 1e-4, "backbone_features")
+    _close(got["rpn_cls"], want["rpn_cls"], 1e-4, "rpn_cls")
+    _close(got["rpn_reg"], want["rpn_reg"], 1e-4, "rpn_reg")
+    # the pooled points the route's RCNN saw (deterministic: the same proposal / pooling kernels on the same head outputs)
+    N, C = xyz.shape[1], got["backbone_features"].shape[1]
+    rows = got["backbone_features"].detach().transpose(1, 2).reshape(2 * N, C).contiguous()
+    rois, pts_input, count = pooled_rois(eng, xyz, dict(rpn_cls=got["rpn_cls"], rpn_reg=got["rpn_reg"], feature_rows=rows), K)
+    assert torch.equal(rois, got["rois"])
+    assert int((count > 0).sum()) >= K                         # the scene gives the RCNN real RoIs
+    rc = chain.rcnn(pts_input.cpu().numpy())
+    _close(got["rcnn_feat"], rc["rcnn_feat"].reshape(2 * K, -1), 1e-4, "rcnn_feat")
+    _close(got["rcnn_cls"], rc["rcnn_cls"].reshape(2 * K, -1), 1e-4, "rcnn_cls")
+    _close(got["rcnn_reg"], rc["rcnn_reg"].reshape(2 * K, -1), 1e-4, "rcnn_reg")
+    # ---- backward against the operator route on the same RoIs (the RCNN half teacher-forced on the rows route's pooled points:
+    # a proposal that flips between two routes 1e-6 apart would compare two different losses)
+    feats = train_joint.backbone_forward(eng.rpn.backbone_net, xyz, img, xy)
+    ref = train_joint.rcnn_forward_train(eng.rcnn_net, pts_input)
+    ref.update(rpn_cls=eng.rpn.rpn_cls_layer(feats).transpose(1, 2), rpn_reg=eng.rpn.rpn_reg_layer(feats).transpose(1, 2))
+    train_joint.thin_loss(eng, ref, tids).backward()
+    torch.cuda.synchronize()
+    want_g = _grads(eng)
+    eng.zero_grad(set_to_none=True)
+    worst, gmax = _relative_gradient_error(mine, want_g)
+    print(kind, "worst relative gradient error", worst, "largest gradient", gmax)
+    assert worst[1] < 5e-4, worst

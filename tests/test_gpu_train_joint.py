@@ -119,14 +119,32 @@ def test_bench_joint_training_step_under_the_launcher():
     assert "joint" in r["config"]["workload"]
 
 
-def test_joint_forward_matches_the_references_complete_forward():
+def _route_forward(route, eng, xyz, img, xy):
+    """(backbone features (B, C, N), rpn_cls (B, N, 1), rpn_reg (B, N, C), rcnn(pts) -> dict) of one training route on the module
+    containers of `eng`: "operators" = train_joint.backbone_forward / rcnn_forward_train (torch autograd over the grouped tensors),
+    "rows" = train_rows.rpn_forward_rows / rcnn_forward_rows (csrc/rows_*.hip forward and backward, BatchNorm folded) — what
+    joint_step(route="auto") and rcnn_step run"""
+    if route == "operators":
+        from jmodt_amd.train_joint import backbone_forward, rcnn_forward_train
+        feats = backbone_forward(eng.rpn.backbone_net, xyz, img, xy)
+        rpn_cls = eng.rpn.rpn_cls_layer(feats).transpose(1, 2)
+        rpn_reg = eng.rpn.rpn_reg_layer(feats).transpose(1, 2)
+        return feats, rpn_cls, rpn_reg, lambda pts: rcnn_forward_train(eng.rcnn_net, pts)
+    from jmodt_amd.train_rows import BnFold, rcnn_forward_rows, rpn_forward_rows
+    fold = BnFold(eng)
+    out = rpn_forward_rows(eng, xyz, img, xy, fold)
+    # (a fold object serves ONE backward: the RCNN half of the loss is back-propagated on its own, with its own fold)
+    return out["backbone_features"], out["rpn_cls"], out["rpn_reg"], lambda pts: rcnn_forward_rows(eng, pts, BnFold(eng), None)
+
+
+@pytest.mark.parametrize("route", ["operators", "rows"])
+def test_joint_forward_matches_the_references_complete_forward(route):
     """the DIFFERENTIABLE composition (train_joint.joint_forward / rcnn_forward_train) against the reference's own
     `PointRCNN.forward` executed over the oracle's extension entry points (tests/golden/forward_ref.npz, the fixture the inference
     engine is checked against): same weights by name, eval-mode BatchNorm, backbone + RPN heads free running, the RCNN on the
     pooled points the engine forms from the REFERENCE's proposals.  With this the training route of round 4 is pinned to the
     reference's Python as well, not only to the engine"""
     from jmodt_amd.detector import DetectAffinityEngine
-    from jmodt_amd.train_joint import backbone_forward, rcnn_forward_train
     from tests.test_gpu_detector import close as close_np
     from tests.test_oracle_cpu import reference_forward_fixture
     cfg, sd, g = reference_forward_fixture()
@@ -135,10 +153,10 @@ def test_joint_forward_matches_the_references_complete_forward():
     eng.load_state_dict({**{k: v for k, v in own.items() if k not in sd}, **sd}, strict=True)
     eng = eng.to(DEV).eval()
     xyz, img, xy = T(g["xyz"]), T(g["img"]), T(g["pts_xy"])
+    for p in eng.parameters():
+        p.requires_grad_(True)
     with torch.enable_grad():
-        feats = backbone_forward(eng.rpn.backbone_net, xyz, img, xy)
-        rpn_cls = eng.rpn.rpn_cls_layer(feats).transpose(1, 2)
-        rpn_reg = eng.rpn.rpn_reg_layer(feats).transpose(1, 2)
+        feats, rpn_cls, rpn_reg, rcnn = _route_forward(route, eng, xyz, img, xy)
     assert feats.requires_grad
     close_np(feats, g["out.backbone_features"])
     close_np(rpn_cls, g["out.rpn_cls"])
@@ -147,15 +165,17 @@ def test_joint_forward_matches_the_references_complete_forward():
     with torch.no_grad():
         pts = eng.roi_pool(ref_rpn, T(g["out.rois"]))
     with torch.enable_grad():
-        out = rcnn_forward_train(eng.rcnn_net, pts)
+        out = rcnn(pts)
     close_np(out["rcnn_feat"].unsqueeze(-1), g["out.rcnn_feat"])
     close_np(out["rcnn_cls"], g["out.rcnn_cls"])
     close_np(out["rcnn_reg"], g["out.rcnn_reg"])
 
 
-def test_joint_backward_matches_the_references_autograd():
-    """gradients of ALL detector parameters through the differentiable route (jm_*_grad kernels + torch autograd on the module
-    containers) against the reference's own backward — `model.rpn(input)` / `PointRCNN.forward` with autograd on, its
+@pytest.mark.parametrize("route", ["operators", "rows"])
+def test_joint_backward_matches_the_references_autograd(route):
+    """gradients of ALL detector parameters through each training route — "operators": jm_*_grad kernels + torch autograd on the module
+    containers; "rows": the hand-written forward / backward row kernels with folded BatchNorm, the DEFAULT of joint_step and what
+    rcnn_step runs — against the reference's own backward — `model.rpn(input)` / `PointRCNN.forward` with autograd on, its
     pointnet2_utils Functions bound to the CPU oracle (tests/golden/make_golden_backward.py -> backward_ref.npz: per tensor the
     L2 norm, the sum, max |g| and 64 entries).  Same weights / frames as forward_ref.npz, eval-mode BatchNorm, the thin loss of
     train_joint without its re-id term.  240 tensors: backbone SA / FP / image blocks / LI-Fusion / deconvolutions, RPN heads,
@@ -163,7 +183,6 @@ def test_joint_backward_matches_the_references_autograd():
     import json
     import os
     from jmodt_amd.detector import DetectAffinityEngine
-    from jmodt_amd.train_joint import backbone_forward, rcnn_forward_train
     from tests.test_oracle_cpu import reference_forward_fixture
     ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "backward_ref.npz"))
     names = json.loads(str(ref["names"]))
@@ -177,9 +196,10 @@ def test_joint_backward_matches_the_references_autograd():
     xyz, img, xy = T(g["xyz"]), T(g["img"]), T(g["pts_xy"])
     N = xyz.shape[1]
     with torch.enable_grad():
-        feats = backbone_forward(eng.rpn.backbone_net, xyz, img, xy)
-        loss_rpn = (eng.rpn.rpn_cls_layer(feats).sum() + eng.rpn.rpn_reg_layer(feats).sum()) / N
+        _, rpn_cls, rpn_reg, rcnn = _route_forward(route, eng, xyz, img, xy)
+        loss_rpn = (rpn_cls.sum() + rpn_reg.sum()) / N
     loss_rpn.backward()
+    torch.cuda.synchronize()
     assert abs(loss_rpn.item() - float(ref["loss_rpn"])) < 1e-4 * max(1.0, abs(float(ref["loss_rpn"])))
     grads = {k: p.grad.detach().clone() for k, p in eng.named_parameters() if p.grad is not None}
     assert all(k.startswith("rpn.") for k in grads)
@@ -188,9 +208,10 @@ def test_joint_backward_matches_the_references_autograd():
     with torch.no_grad():
         pts = eng.roi_pool(ref_rpn, T(g["out.rois"]))
     with torch.enable_grad():
-        out = rcnn_forward_train(eng.rcnn_net, pts)
+        out = rcnn(pts)
         loss_rcnn = out["rcnn_cls"].sum() + out["rcnn_reg"].sum()
     loss_rcnn.backward()
+    torch.cuda.synchronize()
     assert abs(loss_rcnn.item() - float(ref["loss_rcnn"])) < 1e-4 * abs(float(ref["loss_rcnn"]))
     grads.update({k: p.grad.detach().clone() for k, p in eng.named_parameters() if p.grad is not None})
     assert sorted(grads) == names, (sorted(set(names) - set(grads))[:5], sorted(set(grads) - set(names))[:5])
@@ -209,8 +230,11 @@ def test_joint_backward_matches_the_references_autograd():
     assert worst[0] > 0                                        # (not a comparison of a thing with itself)
 
 
-def test_joint_step_data_parallel_equals_single_process(tmp_path):
-    """the data-parallel joint step (tools/train.py:86-107: nn.DataParallel's scatter / gather / gradient reduction as one process
+@pytest.mark.parametrize("mode", ["joint", "rcnn"])
+def test_joint_step_data_parallel_equals_single_process(tmp_path, mode):
+    """mode "rcnn": the same for the RPN-fixed step (train_joint.rcnn_forward_backward; tools/train.py:104 with config.py:57) — only
+    the RCNN's and the re-id heads' gradients exist and are exchanged.  mode "joint":
+    the data-parallel joint step (tools/train.py:86-107: nn.DataParallel's scatter / gather / gradient reduction as one process
     per GPU): two ranks, each on its pair-aligned half of a 4-frame batch, re-id element counts and the gradients of all parameters
     all-reduced (SUM, several buckets) — against ONE process on the whole batch.  The ranks share cuda:0 and exchange over gloo
     (RCCL cannot put two ranks on one device); eval-mode BatchNorm, so that no statistic depends on the shard"""
@@ -223,17 +247,20 @@ def test_joint_step_data_parallel_equals_single_process(tmp_path):
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = [subprocess.Popen([sys.executable, helper, str(tmp_path / f"r{r}.pt")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+    extra = ["--rcnn"] if mode == "rcnn" else []
+    procs = [subprocess.Popen([sys.executable, helper, str(tmp_path / f"r{r}.pt")] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                               env=dict(base, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
              for r in range(2)]
-    single = subprocess.run([sys.executable, helper, str(tmp_path / "one.pt"), "--single"], capture_output=True, text=True, timeout=900, env=base)
+    single = subprocess.run([sys.executable, helper, str(tmp_path / "one.pt"), "--single"] + extra, capture_output=True, text=True, timeout=900, env=base)
     assert single.returncode == 0, single.stderr[-3000:]
     for p in procs:
         _, err = p.communicate(timeout=900)
         assert p.returncode == 0, err[-3000:]
     one = torch.load(tmp_path / "one.pt")
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
-    assert r0["frames"] == (0, 2) and r1["frames"] == (2, 4) and one["collectives"] == 0 and r0["collectives"] >= 2
+    assert r0["frames"] == (0, 2) and r1["frames"] == (2, 4) and one["collectives"] == 0 and r0["collectives"] >= (1 if mode == "rcnn" else 2)
+    if mode == "rcnn":
+        assert one["grads"] and all(k.startswith("rcnn_net.") for k in one["grads"])
     assert abs(r0["loss"] + r1["loss"] - one["loss"]) < 1e-4 * max(1.0, abs(one["loss"]))     # the shards' losses ADD
     assert sorted(r0["grads"]) == sorted(one["grads"])
     worst = 0.0
@@ -246,3 +273,60 @@ def test_joint_step_data_parallel_equals_single_process(tmp_path):
         worst = max(worst, err / max(scale, 1e-3))
         assert err <= 2e-4 * scale + 1e-7, (k, err, scale)
     print("worst relative gradient difference DP vs single process:", worst)
+
+
+def test_rcnn_step_trains_the_rcnn_under_a_frozen_rpn(tiny):
+    """the reference's default training mode (config.py:57 RPN.FIXED = True, point_rcnn.py:28-31, tools/train.py:104): the fused
+    no-grad engine for the RPN half, the RCNN and the re-id heads on the row kernels.  Every RCNN tensor receives a finite gradient and
+    moves; no RPN tensor has a gradient or changes; the step's RCNN outputs are the fused inference RCNN's on the same pooled points;
+    after the optimizer step the inference engine runs on the UPDATED RCNN weights (its packed copies of them are re-made, the RPN's
+    ~100 packed weights are not: detector._refresh's two signature groups)"""
+    from jmodt_amd import train_joint
+    from jmodt_amd.detector import DetectorConfig
+    from tests.test_gpu_detector import make_engine
+    _, xyz, img, xy = tiny
+    eng = make_engine(seed=3, cfg=DetectorConfig.tiny()).to(DEV)
+    opt = torch.optim.Adam(eng.rcnn_net.parameters(), lr=1e-3, fused=True)
+    K = min(64, eng.cfg.rpn_post_nms_top_n)
+    tids = torch.randint(0, 6, (2, K), generator=torch.Generator().manual_seed(4)).float().to(DEV)
+    with pytest.raises(RuntimeError, match="prepare_rcnn"):
+        train_joint.rcnn_step(eng, xyz, img, xy, tids, opt, rois_per_frame=K)
+    train_joint.prepare_rcnn(eng)
+    for m in eng.modules():                     # (Dropout off: the outputs are compared with the inference RCNN's)
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    rcnn_names = [n for n, _ in eng.named_parameters() if n.startswith("rcnn_net.")]
+    before = {n: p.detach().clone() for n, p in eng.named_parameters()}
+    # forward + backward alone first: outputs against the fused inference RCNN on the same RoIs
+    loss, out = train_joint.rcnn_forward_backward(eng, xyz, img, xy, tids, rois_per_frame=K)
+    with torch.no_grad():
+        rpn_out = eng.rpn_forward(xyz, img, xy)
+        rois, _ = eng.proposals(rpn_out)
+        assert torch.equal(rois[:, :K], out["rois"])
+        ref = eng.rcnn_forward(eng.roi_pool(rpn_out, rois[:, :K].contiguous()))
+    close(out["rcnn_cls"], ref["rcnn_cls"]); close(out["rcnn_reg"], ref["rcnn_reg"]); close(out["rcnn_feat"], ref["rcnn_feat"].squeeze(-1))
+    eng.zero_grad(set_to_none=True)
+    packed_rpn = {k: v for k, v in eng._folded.items() if not k.startswith(("xyz_up.", "merge_down", "rcnn_"))}
+    assert packed_rpn
+    loss = train_joint.rcnn_step(eng, xyz, img, xy, tids, opt, rois_per_frame=K, next_xyz=xyz)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and train_joint.LAST_GRAD_COLLECTIVES == 0
+    named = dict(eng.named_parameters())
+    for n in rcnn_names:
+        assert named[n].grad is not None and bool(torch.isfinite(named[n].grad).all()), n
+    stuck = [n for n in rcnn_names if torch.equal(before[n], named[n].detach())]
+    # (the link head's last bias: the dual softmax is invariant to a constant added to every score — gradient zero up to rounding)
+    assert len(stuck) <= 1, stuck
+    for n, p in named.items():
+        if not n.startswith("rcnn_net."):
+            assert p.grad is None and torch.equal(before[n], p.detach()), n
+    # the engine after the step: RCNN re-packed from the updated weights, the RPN's packed weights untouched (same objects)
+    with torch.no_grad():
+        rpn_out = eng.rpn_forward(xyz, img, xy)
+        pts = eng.roi_pool(rpn_out, out["rois"])
+        fused = eng.rcnn_forward(pts)
+        want = train_joint.rcnn_forward_train(eng.rcnn_net, pts)
+    close(fused["rcnn_cls"], want["rcnn_cls"]); close(fused["rcnn_reg"], want["rcnn_reg"])
+    assert float((fused["rcnn_cls"] - ref["rcnn_cls"]).abs().max()) > 0          # (the step changed the network)
+    for k, v in packed_rpn.items():
+        assert eng._folded.get(k) is v, k
