@@ -270,6 +270,7 @@ def _unit_wb(unit: nn.Module) -> Tuple[torch.Tensor, torch.Tensor]:
     return _fold_conv_bn(unit.conv, bn)
 
 
+from ._registry import tensor_sig
 from ._registry import EPOCH as _REGISTRATION_EPOCH      # bumped whenever ANY nn.Module of the process registers a parameter / buffer
 
 
@@ -338,8 +339,8 @@ class DetectAffinityEngine(nn.Module):
 
     def _refresh(self):
         """drop every folded / packed weight when ANY parameter or buffer of the engine changed since it was made: torch
-        bumps `_version` on every in-place update (load_state_dict, optimizer steps, manual copy_), `.to()` changes the
-        storage.  Same rule as the SA / FP module caches (ops/pointnet2/fused.py:_packed_layers); called at every public
+        bumps `_version` on every in-place update (load_state_dict, manual copy_, the for-loop / foreach optimizers), the FUSED
+        optimizers (which do not) are counted by _registry's optimizer-step hook, `.to()` changes the storage.  Same rule as the SA / FP module caches (ops/pointnet2/fused.py:_packed_layers); called at every public
         entry (a few hundred attribute reads, ~0.1 ms of host time per batch)."""
         # (the link / start-end heads are never folded: ops/affinity.py hands their live tensors to the kernels on every
         # call, and the finetune step updates them every iteration — tools/train.py:96-107)
@@ -359,7 +360,7 @@ class DetectAffinityEngine(nn.Module):
             mine = {id(t) for t in rcnn} | skip
             self._sig_tensors = ([t for t in list(self.parameters()) + list(self.buffers()) if id(t) not in mine], rcnn)
             self._sig_epoch = _REGISTRATION_EPOCH[0]
-        sig = tuple(tuple([(id(t), t.data_ptr(), t._version) for t in grp]) for grp in self._sig_tensors)
+        sig = tuple(tuple([tensor_sig(t) for t in grp]) for grp in self._sig_tensors)
         old = self._folded_sig
         if sig != old:
             if old is None or sig[0] != old[0]:

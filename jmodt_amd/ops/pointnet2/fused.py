@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib as L
-from ..._registry import module_tensors
+from ..._registry import module_tensors, tensor_sig
 from ...profile import prof
 
 _f32, _i32 = torch.float32, torch.int32
@@ -85,7 +85,7 @@ def _packed_layers(mlp: nn.Sequential, device):
     """[(wp, bp, cout, cin)] in the kernel's device layout (jm_sa_mlp_pack), cached per module until a
     parameter or BatchNorm buffer changes (torch bumps `_version` on every in-place update)."""
     tensors = module_tensors(mlp)
-    sig = tuple((id(t), t.data_ptr(), t._version) for t in tensors) + (str(device),)
+    sig = tuple(tensor_sig(t) for t in tensors) + (str(device),)
     hit = _packed_cache.get(mlp)
     if hit is not None and hit[0] == sig:
         return hit[1]
@@ -335,7 +335,7 @@ def pm_plan(mlp: nn.Sequential, device, B: int, N: int, M: int, ns: int):
 def _pre_layers(mlp: nn.Sequential, device):
     """the pre-projected form's operands: (W1 (H1, 3 + C) folded, b1, W1x (H1, 4), [(wp, bp, cout, cin)] of layers 2..L)"""
     tensors = module_tensors(mlp)
-    sig = tuple((id(t), t.data_ptr(), t._version) for t in tensors) + (str(device), "pre")
+    sig = tuple(tensor_sig(t) for t in tensors) + (str(device), "pre")
     hit = _pre_cache.get(mlp)
     if hit is not None and hit[0] == sig:
         return hit[1]
@@ -575,7 +575,7 @@ _folded_cache = weakref.WeakKeyDictionary()   # module -> (signature, [(W, b)])
 def _folded_layers(mlp: nn.Sequential):
     """[(W (out, in), b (out))] with eval-mode BatchNorm folded, cached until a parameter / buffer changes"""
     tensors = module_tensors(mlp)
-    sig = tuple((id(t), t.data_ptr(), t._version) for t in tensors)
+    sig = tuple(tensor_sig(t) for t in tensors)
     hit = _folded_cache.get(mlp)
     if hit is not None and hit[0] == sig:
         return hit[1]

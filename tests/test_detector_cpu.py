@@ -271,6 +271,19 @@ def test_folded_weight_cache_sees_in_place_updates_and_replaced_parameters():
         rc.mul_(1.5)
     e._refresh()
     assert "probe" in e._folded and "rcnn_probe" not in e._folded
+    # a FUSED optimizer step updates in place WITHOUT moving `_version` (torch._fused_adam_): seen through the optimizer-step hook
+    e._folded["rcnn_probe"] = 1
+    opt = torch.optim.Adam([rc], lr=1e-3, fused=True)
+    rc.grad = torch.ones_like(rc)
+    v = rc._version
+    opt.step()
+    e._refresh()
+    assert "probe" in e._folded and "rcnn_probe" not in e._folded, ("fused Adam", v, rc._version)
+    rc.grad = None
+    e._folded["rcnn_probe"] = 1
+    opt.step()                                                          # no gradient: nothing updated, nothing dropped
+    e._refresh()
+    assert "rcnn_probe" in e._folded
     e._folded["probe"] = 1
     sd = {k: v.clone() for k, v in e.state_dict().items()}
     e.load_state_dict(sd, assign=True)                                   # every parameter replaced
