@@ -682,17 +682,6 @@ int jm_rows_linear_dgrad(int m, const int* m_dev, int n, int k, const float* dy,
  * FIXED order (eight groups of every eighth split, the groups added in group order): deterministic, no float atomics; a short
  * contraction (one split) writes dw / dbias straight from the accumulators and needs no workspace.  Direct form since round 5:
  * the operands go from their rows into the MFMA registers, a wave's patch is 32 or 64 columns of dy and of x (csrc/rows_gemm.hip) */
-/* The image branch's kernel == stride transposed convolutions (backbone.py:150-157,187-189: DeConv) as GEMMs whose (rows, columns)
- * matrix is stored PIXEL-SHUFFLED: x (m = B h w, c) = the channels-last input map as rows, wt (k k r, c) with
- * wt[(dy k + dx) r + rr][ci] = W[ci][rr][dy][dx], y = the channels-last (B, h k, w k, ctot) map, this level's r channels at coff:
- * y[b][y k + dy][x k + dx][coff + rr] = sum_ci x[(b, y, x)][ci] wt[...][ci] (no bias).  _dgrad: dx (m, c) from dy in that layout;
- * _wgrad: dwt (k k r, c), workspace jm_rows_wgrad_workspace_bytes(m, k k r, c).  c, r, ctot, coff multiples of 4. */
-int jm_rows_deconv_forward(int m, int c, int k, int r, int h, int w, const float* x, int ldx, const float* wt, float* y, int ctot, int coff,
-                           jm_stream_t stream);
-int jm_rows_deconv_dgrad(int m, int c, int k, int r, int h, int w, const float* dy, int ctot, int coff, const float* wt, float* dx, int lddx,
-                         jm_stream_t stream);
-int jm_rows_deconv_wgrad(int m, int c, int k, int r, int h, int w, const float* dy, int ctot, int coff, const float* x, int ldx, float* dwt,
-                         void* ws, size_t ws_bytes, jm_stream_t stream);
 int jm_rows_wgrad_splits(int m, int n, int k);
 size_t jm_rows_wgrad_workspace_bytes(int m, int n, int k);
 int jm_rows_linear_wgrad(int m, const int* m_dev, int n, int k, const float* dy, int lddy, const float* x, int ldx,
@@ -770,12 +759,6 @@ typedef struct {
 int jm_rows_mlp_forward(const jm_rows_mlp_t* d, jm_stream_t stream);
 int jm_rows_mlp_backward(const jm_rows_mlp_t* d, const jm_rows_mlp_grad_t* g, jm_stream_t stream);
 int jm_rows_tanh_grad(int m, const int* m_dev, int n, const float* dy, int ldd, const float* y, int ldy, float* out, int ldo, jm_stream_t stream);
-/* The backward in two phases (round 5: weight gradients off the critical path): `_chain` = the data-gradient chain only, keeping every
- * layer's pre-activation gradient in dys[l] (m, widths[l]) — a HOST array of nl device pointers, caller-allocated — and writing dx1 /
- * dx2; `_wgrads` = dw / db of every layer from dys and the saved activations (scratch[] unused by both).  The caller orders phase 2
- * behind phase 1 on whatever stream it likes.  dys[nl - 1] is not written when the last layer has no activation (dout is read instead). */
-int jm_rows_mlp_backward_chain(const jm_rows_mlp_t* d, const jm_rows_mlp_grad_t* g, float* const* dys, jm_stream_t stream);
-int jm_rows_mlp_backward_wgrads(const jm_rows_mlp_t* d, const jm_rows_mlp_grad_t* g, float* const* dys, jm_stream_t stream);
 typedef struct {
     int nl, groups, max_rows;        /* layers (>= 2), groups, row capacity (= groups * nsample) */
     const int* rows_dev; const int* offsets; const int* row_point; const int* row_group;   /* jm_sa_rows_plan's outputs */
@@ -796,10 +779,6 @@ typedef struct {
 } jm_sa_scale_grad_t;
 int jm_sa_scale_forward(const jm_sa_scale_t* d, jm_stream_t stream);
 int jm_sa_scale_backward(const jm_sa_scale_t* d, const jm_sa_scale_grad_t* g, jm_stream_t stream);
-/* jm_sa_scale_backward in two phases, as above: dys[l] (max_rows, widths[l]); `_chain` also produces du and df (the gradient that goes
- * upstream), `_wgrads` every weight / bias gradient (it reads du) */
-int jm_sa_scale_backward_chain(const jm_sa_scale_t* d, const jm_sa_scale_grad_t* g, float* const* dys, jm_stream_t stream);
-int jm_sa_scale_backward_wgrads(const jm_sa_scale_t* d, const jm_sa_scale_grad_t* g, float* const* dys, jm_stream_t stream);
 
 /* Eval-mode BatchNorm folded into the preceding convolution, for all n (convolution, BatchNorm) pairs of a network in one launch:
  * wf[l] (rows_l, cols_l) = w[l] * s[soff[l] + row] with s = gamma / sqrt(running_var + eps) (pytorch_utils.py:21-33 / backbone.py

@@ -130,13 +130,6 @@ SIGNATURES = {
     "jm_conv1d_stack64_packed_elems": (_Z, [_I, _I]),
     "jm_conv1d_stack64_pack": (_I, [_I, _I, _P, _I, _P, _P, _P, _P]),
     "jm_conv1d_stack64_forward": (_I, [_I, _I, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
-    "jm_rows_mlp_backward_chain": (_I, [ctypes.POINTER(RowsMlp), ctypes.POINTER(RowsMlpGrad), _P, _P]),
-    "jm_rows_mlp_backward_wgrads": (_I, [ctypes.POINTER(RowsMlp), ctypes.POINTER(RowsMlpGrad), _P, _P]),
-    "jm_sa_scale_backward_chain": (_I, [ctypes.POINTER(SaScale), ctypes.POINTER(SaScaleGrad), _P, _P]),
-    "jm_sa_scale_backward_wgrads": (_I, [ctypes.POINTER(SaScale), ctypes.POINTER(SaScaleGrad), _P, _P]),
-    "jm_rows_deconv_forward": (_I, [_I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _I, _P]),
-    "jm_rows_deconv_dgrad": (_I, [_I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P]),
-    "jm_rows_deconv_wgrad": (_I, [_I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _Z, _P]),
     "jm_points_linear_supported": (_I, [_I, _I, _I, _I, _I]),
     "jm_points_linear": (_I, [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
     "jm_three_nn_weights": (_I, [ctypes.c_longlong, _P, _P, _P]),

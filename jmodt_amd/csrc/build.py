@@ -50,7 +50,7 @@ def _compile(path, obj_dir, flags, force, save_temps):
 def build(force=False, save_temps=False, verbose=True, tools=False):
     obj_dir = os.path.join(HERE, "build_tools") if tools else OBJ_DIR
     lib = TOOLS_LIB if tools else LIB
-    flags = FLAGS + (["-DJM_TOOLS_BUILD", "-I", HERE] + os.environ.get("JM_TOOLS_DEFS", "").split() if tools else [])
+    flags = FLAGS + (["-DJM_TOOLS_BUILD", "-I", HERE, "-I", os.path.join(TOOLS_DIR, "csrc"), "-I", os.path.join(ROOT, "include")] + os.environ.get("JM_TOOLS_DEFS", "").split() if tools else [])
     paths = [os.path.join(HERE, s) for s in SOURCES]
     if tools:
         extra = os.path.join(TOOLS_DIR, "csrc")

@@ -9,6 +9,9 @@
 // workspace) and nothing is allocated or synchronised.  The kernels are exactly the single-layer entries' (jm_rows_linear_*,
 // jm_sa_rows_*): same bits.
 #include "jm_rows.h"
+#ifdef JM_TOOLS_BUILD
+#include "jmodt_hip_tools.h"
+#endif
 
 namespace jm {
 
@@ -95,6 +98,7 @@ int jm_rows_mlp_backward(const jm_rows_mlp_t* d, const jm_rows_mlp_grad_t* g, jm
     return JM_OK;
 }
 
+#ifdef JM_TOOLS_BUILD   // (tools/csrc/jmodt_hip_tools.h: measured slower on side streams than inline, not in the product ABI)
 // ---- the backward in TWO phases (round 5: weight gradients off the critical path).  Nothing downstream waits for a weight gradient
 // until the optimizer, but on one stream every layer's wgrad (+ its split-K reduce) sits between two links of the data-gradient chain
 // the NEXT module's backward waits for: 97 wgrad launches of ~60 us per joint-mode step.  Phase 1 (`_chain`) runs the data-gradient chain
@@ -180,6 +184,8 @@ int jm_sa_scale_backward_wgrads(const jm_sa_scale_t* d, const jm_sa_scale_grad_t
         JM_TRY(jm_rows_linear_wgrad(d->points, nullptr, H1, d->c, g->du, H1, d->f, d->ldf, g->dw1 + 3, ldw1, nullptr, 0, g->ws, g->ws_bytes, stream));
     return check_launch("sa_scale_backward_wgrads");
 }
+
+#endif  // JM_TOOLS_BUILD
 
 int jm_sa_scale_forward(const jm_sa_scale_t* d, jm_stream_t stream) {
     JM_REQUIRE(d && d->nl >= 2 && d->nl <= JM_ROWS_MAX_LAYERS && d->groups > 0 && d->xyz && d->w1x && d->b1, "sa_scale_forward: bad arguments");

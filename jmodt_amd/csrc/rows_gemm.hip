@@ -24,6 +24,9 @@
 // unconditional on a clamped, valid address.  Requirements (checked by the entries): K % 4 == 0 and lda / ldb % 4 == 0 for
 // row operands, N % 4 == 0 for k-major operands.
 #include "jm_rows.h"
+#ifdef JM_TOOLS_BUILD
+#include "jmodt_hip_tools.h"
+#endif
 
 namespace jm {
 
@@ -621,6 +624,7 @@ int jm_rows_linear_dgrad(int m, const int* m_dev, int n, int k, const float* dy,
     return check_launch("rows_linear_dgrad");
 }
 
+#ifdef JM_TOOLS_BUILD   // (tools/csrc/jmodt_hip_tools.h: 5.7 ms against MIOpen's 3.5 ms per 4 frames, not in the product ABI)
 // ---- kernel == stride transposed convolution (backbone.py:150-157 DeConv) as a GEMM with a pixel-shuffled output: x (m = B h w, c) rows of
 // the channels-last input map, wt (k k r, c) with wt[(dy k + dx) r + rr][ci] = W[ci][rr][dy][dx]; y = the channels-last (B, h k, w k, ctot)
 // map, this level in channels coff .. coff + r
@@ -682,6 +686,8 @@ int jm_rows_deconv_wgrad(int m, int c, int k, int r, int h, int w, const float* 
     }
     return check_launch("rows_deconv_wgrad");
 }
+
+#endif  // JM_TOOLS_BUILD
 
 int jm_rows_wgrad_splits(int m, int n, int k) {
     // enough (tile, split) workgroups to fill 256 CUs four times over with at least 256 contraction rows per split (a workgroup of the

@@ -14,11 +14,11 @@ from .. import _lib as L
 from .fusion import _pack
 
 _f32 = torch.float32
-import os as _os
-# the 64-point-tile kernel (csrc/conv1d_stack64.hip): 0 never, 1 where it measured faster than the 32-point kernel (single-layer
-# stacks: the hoisted first set-abstraction layers, 13 against 20 us and 76 against 80 us), 2 wherever its tiles fit the LDS
-# (tools/conv1d_bench.py: RPN heads 189 against 187 us, FP1 181 against 160 us — one workgroup per CU, nothing hides its phases)
-TILE64 = int(_os.environ.get("JM_CONV1D_TILE64", "1"))
+# the 64-point-tile kernel (csrc/conv1d_stack64.hip) serves SINGLE-layer stacks — the hoisted first set-abstraction layers, where it
+# measured faster than the 32-point kernel (13 against 20 us, 76 against 80 us); on multi-layer stacks it measured slower (RPN heads
+# 189 against 187 us, FP1 181 against 160 us: one workgroup per CU, nothing hides its phases) and is not offered there
+TILE64 = 1        # (a module constant, no environment switch.  0: never, 2: wherever the kernel's tiles fit — what
+                  # tests/test_gpu_detector.py sets to check the kernel itself on multi-layer stacks against float64)
 
 
 class PackedConv1dStack:

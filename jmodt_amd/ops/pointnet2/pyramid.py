@@ -25,15 +25,11 @@ from . import pointnet2_utils
 _side = {}
 
 
+SIDE_PRIORITY = {}     # slot -> stream priority (default 0 everywhere; tools/stream_prio_probe.py fills it — no environment switch)
+
+
 def _side_priority(slot: int) -> int:
-    """JM_SIDE_PRIO="slot:priority,..." (experiments: tools/stream_prio_probe.py); default 0 everywhere"""
-    import os
-    for item in os.environ.get("JM_SIDE_PRIO", "").split(","):
-        if ":" in item:
-            k, v = item.split(":")
-            if int(k) == slot:
-                return int(v)
-    return 0
+    return int(SIDE_PRIORITY.get(slot, 0))
 
 
 def side_stream(device, slot: int = 0) -> torch.cuda.Stream:

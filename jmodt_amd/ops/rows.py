@@ -128,101 +128,6 @@ def _wgrad_ws_bytes(lib, M, pairs) -> int:
     return max([int(lib.jm_rows_wgrad_workspace_bytes(M, n, k)) for n, k in pairs] + [0])
 
 
-# ---------------------------------------------------------------------------------------------------- weight gradients off the chain
-import os as _os
-# OPT-IN (JM_ROWS_WGRAD_STREAM=1).  Exact (tests/test_gpu_rows.py passes with it on) and measured SLOWER on one MI355X, joint-mode step of
-# 4 frames: 23.9 ms inline; 28.1 ms with the weight gradients on the idle FPS stream; 40 - 44 ms on wgrad streams of their own (and
-# with `record_stream` on the tensors they touch instead of the deferred release: 43 ms of host enqueue).  The ~1000 small launches of
-# the step do not gain from more concurrency — they lose, as the graph sections do.
-SPLIT_WGRAD = bool(int(_os.environ.get("JM_ROWS_WGRAD_STREAM", "0")))
-WGRAD_ON_FPS_STREAM = bool(int(_os.environ.get("JM_ROWS_WGRAD_ON_FPS", "1")))
-_wgrad_streams = {}
-
-
-def wgrad_stream(device) -> torch.cuda.Stream:
-    """the stream the weight gradients of the modules whose forward ran on the CURRENT stream are computed on (one per parent stream)"""
-    cur = torch.cuda.current_stream(device)
-    if WGRAD_ON_FPS_STREAM:
-        # NOT a stream of its own: with more than four streams busy at once the device's throughput collapses on this stack (joint
-        # step 23.9 -> 40 ms with two extra wgrad streams, at 4, 6, 8 or 12 hardware queues; the same cliff the graph sections hit,
-        # DESIGN.md section 6).  The FPS side stream is idle once the next batch's sampling chain is through (6.5 ms into the
-        # step, before any backward starts): the weight gradients of every module run there
-        from .pointnet2.pyramid import side_stream
-        st = side_stream(cur.device, 0)
-        _wgrad_streams[(cur.device.index, -1)] = st
-        return st
-    key = (cur.device.index, cur.cuda_stream)
-    st = _wgrad_streams.get(key)
-    if st is None:
-        st = _wgrad_streams[key] = torch.cuda.Stream(device=cur.device)
-    return st
-
-
-def wgrad_streams():
-    return list(_wgrad_streams.values())
-
-
-# Tensors a weight-gradient pass reads or writes were allocated on the MODULE's stream; the caching allocator would hand their blocks
-# out again as soon as the last reference dies, while the wgrad stream may still be working on them.  `record_stream` on each of
-# them (~20 per module, 60 modules) cost more host time than the split saves (one allocator event per block: 17 -> 43 ms of enqueue
-# per step, measured), so the pass parks its references here instead and the step drops them once its main stream has waited for
-# the wgrad streams (train_joint: release_deferred).
-_DEFERRED = []
-
-
-def release_deferred(device=None) -> None:
-    """order the current stream behind every wgrad stream, then drop the references the weight-gradient passes parked"""
-    if _DEFERRED:
-        cur = torch.cuda.current_stream(device)
-        for ws in _wgrad_streams.values():
-            cur.wait_stream(ws)
-        _DEFERRED.clear()
-
-
-class _Phase2:
-    """what a module's backward leaves for its weight-gradient pass: a closure (run on the wgrad stream by _WgradHook.backward) and
-    the tensors it reads, kept alive until then"""
-    __slots__ = ("run", "keep")
-
-    def __init__(self):
-        self.run, self.keep = None, None
-
-
-class _WgradHook(Function):
-    """identity on a module's weights whose BACKWARD is the module's weight-gradient pass.  The node is created under the wgrad
-    stream, so the autograd engine runs its backward there — ordered behind the module's own backward (which produced the
-    pre-activation gradients on the main stream) and in front of whatever consumes the weight gradients, by the engine's own
-    stream hand-over.  The gradients that arrive are the module's PLACEHOLDERS (allocated, not yet written): the pass fills them."""
-
-    @staticmethod
-    def forward(ctx, state, *ws):
-        ctx.state = state
-        return tuple(w.view_as(w) for w in ws)
-
-    @staticmethod
-    def backward(ctx, *grads):
-        st = ctx.state
-        if st.run is not None:
-            st.run()
-            st.run, st.keep = None, None
-        return (None, *grads)
-
-
-def _hook_weights(tensors, device):
-    """(state, hooked tensors) — or (None, tensors) when the split does not apply (no gradient wanted, a graph capture in progress:
-    a captured section is one stream)"""
-    live = [t for t in tensors if t is not None]
-    if not (SPLIT_WGRAD and torch.is_grad_enabled() and live and all(t.requires_grad for t in live)) or torch.cuda.is_current_stream_capturing():
-        return None, tensors
-    if len(_DEFERRED) > 4096:                # a caller that never releases (train_joint does, every step)
-        release_deferred(device)
-    state = _Phase2()
-    with torch.cuda.stream(wgrad_stream(device)):
-        hooked = _WgradHook.apply(state, *live)
-    it = iter(hooked)
-    return state, [None if t is None else next(it) for t in tensors]
-
-
 class _RowsMLP(Function):
     """a chain of dense layers on rows: x = [x1 | x2] -> act_0(W_0 x + b_0) -> ... ; acts[l] in {0 none, 1 ReLU, 2 tanh}.
     apply(x1, x2 or None, acts, W_0, b_0, W_1, b_1, ...) with b_l a tensor or None.  ONE C call per direction
@@ -252,9 +157,8 @@ class _RowsMLP(Function):
         return d
 
     @staticmethod
-    def forward(ctx, x1, x2, acts, state, *wb):
+    def forward(ctx, x1, x2, acts, *wb):
         nl = len(acts)
-        ctx.state = state
         assert len(wb) == 2 * nl and nl <= L.ROWS_MAX_LAYERS
         Ws, bs = wb[0::2], wb[1::2]
         M = x1.shape[0]
@@ -297,31 +201,12 @@ class _RowsMLP(Function):
         grads = []
         for l in range(nl):
             grads += [dws[l], dbs[l]]
-        state = ctx.state
-        if state is not None:
-            # phase 1 here (the data-gradient chain), phase 2 = the weight gradients, left for _WgradHook.backward on the wgrad stream
-            widths = [W.shape[0] for W in Ws]
-            dybuf = torch.empty((M * sum(widths),), dtype=_f32, device=dev)
-            dys, off = (ctypes.c_void_p * nl)(), 0
-            for l in range(nl):
-                dys[l] = dybuf.data_ptr() + 4 * off
-                off += M * widths[l]
-            L.check(lib.jm_rows_mlp_backward_chain(ctypes.byref(d), ctypes.byref(g), dys, L.stream_ptr()), "rows_mlp_backward_chain")
-            keep = [dout, dybuf, x1, x2, *Ws, *ys, *dws, *dbs]
-
-            def phase2(d=d, g=g, dys=dys, keep=keep, nbytes=nbytes, dev=dev):
-                ws_ = _ws(nbytes, dev) if nbytes else None
-                g.ws, g.ws_bytes = _vp(ws_), nbytes
-                _DEFERRED.append(keep)               # allocated on the module's stream, read / written here: see release_deferred
-                L.check(lib.jm_rows_mlp_backward_wgrads(ctypes.byref(d), ctypes.byref(g), dys, L.stream_ptr()), "rows_mlp_backward_wgrads")
-            state.run, state.keep = phase2, keep
-            return (dx1, dx2, None, None, *grads)
         scratch = torch.empty((2, M, wmax), dtype=_f32, device=dev)
         g.scratch[0], g.scratch[1] = scratch[0].data_ptr(), scratch[1].data_ptr()
         ws = _ws(nbytes, dev) if nbytes else None
         g.ws, g.ws_bytes = _vp(ws), nbytes
         L.check(lib.jm_rows_mlp_backward(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "rows_mlp_backward")
-        return (dx1, dx2, None, None, *grads)
+        return (dx1, dx2, None, *grads)
 
 
 def rows_mlp(x1: torch.Tensor, layers: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]], acts: Sequence[int],
@@ -330,8 +215,7 @@ def rows_mlp(x1: torch.Tensor, layers: Sequence[Tuple[torch.Tensor, Optional[tor
     flat = []
     for W, b in layers:
         flat += [W, b]
-    state, flat = _hook_weights(flat, x1.device)
-    return _RowsMLP.apply(x1, x2, tuple(int(a) for a in acts), state, *flat)
+    return _RowsMLP.apply(x1, x2, tuple(int(a) for a in acts), *flat)
 
 
 # ---------------------------------------------------------------------------------------------------- set abstraction on rows
@@ -357,7 +241,7 @@ class RowsPlan:
     @classmethod
     def from_tensors(cls, d: torch.Tensor, offsets: torch.Tensor, row_point: torch.Tensor, row_group: torch.Tensor, groups: int,
                      ns: int) -> "RowsPlan":
-        """a plan whose four device tensors were made elsewhere (e.g. by a replayed graph: train_graphs.py)"""
+        """a plan whose four device tensors were made elsewhere (e.g. by a replayed graph: tools/quarantine/train_graphs.py)"""
         p = cls.__new__(cls)
         p.groups, p.max_rows, p.ns = int(groups), int(groups) * int(ns), int(ns)
         p.d, p.offsets, p.row_point, p.row_group = d, offsets, row_point, row_group
@@ -405,9 +289,8 @@ class _SaLevel(Function):
         return (f.shape[0] * widths[0] if f is not None else 0) + plan.max_rows * (4 + sum(widths[:nl]))
 
     @staticmethod
-    def forward(ctx, f, xyz, ctr, plans, nlayers, state, *wb):
+    def forward(ctx, f, xyz, ctr, plans, nlayers, *wb):
         lib = L.load()
-        ctx.state = state
         dev = xyz.device
         K, per = len(plans), 2 * nlayers
         G = plans[0].groups
@@ -484,31 +367,10 @@ class _SaLevel(Function):
                 gk += [dws[l - 1], dbs[l - 1]]
             grads += gk
             c0 += ctx.couts[k]
-            if ctx.state is not None:
-                # phase 1: pool gradient, data-gradient chain, the scatter into du and df (what goes upstream); the weight gradients are
-                # left for _WgradHook.backward on the wgrad stream
-                dybuf = torch.empty((R * sum(widths),), dtype=_f32, device=dev)
-                dys, off = (ctypes.c_void_p * nl)(), 0
-                for l in range(nl):
-                    dys[l] = dybuf.data_ptr() + 4 * off
-                    off += R * widths[l]
-                L.check(lib.jm_sa_scale_backward_chain(ctypes.byref(d), ctypes.byref(g), dys, L.stream_ptr()), "sa_scale_backward_chain")
-                later.append((d, g, dys, nbytes, [dybuf, scratch, slab, argrow, w1x, w1f, *Ws, *gk, dW1]))
-                continue
             ws = _ws(nbytes, dev) if nbytes else None
             g.ws, g.ws_bytes = _vp(ws), nbytes
             L.check(lib.jm_sa_scale_backward(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "sa_scale_backward")
-        if ctx.state is not None:
-            keep_all = [out, xyz, ctr, f, dout]
-
-            def phase2(later=later, keep_all=keep_all, dev=dev):
-                _DEFERRED.append((keep_all, later))
-                for d_, g_, dys_, nbytes_, keep_ in later:
-                    ws_ = _ws(nbytes_, dev) if nbytes_ else None
-                    g_.ws, g_.ws_bytes = _vp(ws_), nbytes_
-                    L.check(lib.jm_sa_scale_backward_wgrads(ctypes.byref(d_), ctypes.byref(g_), dys_, L.stream_ptr()), "sa_scale_backward_wgrads")
-            ctx.state.run, ctx.state.keep = phase2, (later, keep_all)
-        return (df, None, None, None, None, None, *grads)
+        return (df, None, None, None, None, *grads)
 
 
 def sa_level_rows(f: Optional[torch.Tensor], xyz: torch.Tensor, ctr: Optional[torch.Tensor], plans: Sequence[RowsPlan],
@@ -522,8 +384,7 @@ def sa_level_rows(f: Optional[torch.Tensor], xyz: torch.Tensor, ctr: Optional[to
     for sc in scales:
         for W, b in sc:
             flat += [W, b]
-    state, flat = _hook_weights(flat, xyz.device)
-    return _SaLevel.apply(f, xyz, ctr, tuple(plans), nl, state, *flat)
+    return _SaLevel.apply(f, xyz, ctr, tuple(plans), nl, *flat)
 
 
 def sa_scale_rows(f, xyz, ctr, plan: RowsPlan, layers) -> torch.Tensor:
@@ -592,83 +453,6 @@ class _FeatureGatherRows(Function):
 def feature_gather_rows(feature_map: torch.Tensor, xy: torch.Tensor) -> torch.Tensor:
     """feature_map (B, C, H, W) (channels-last memory), xy (B, N, 2) in [-1, 1] -> (B N, C): backbone.py:79-89 on rows"""
     return _FeatureGatherRows.apply(feature_map, xy)
-
-
-# ---------------------------------------------------------------------------------------------------- deconvolution pyramid
-def _cl_ptr(t: torch.Tensor, name: str):
-    """raw pointer of a float32 channels-last (B, C, H, W) GPU tensor"""
-    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == _f32 and t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)):
-        raise RuntimeError(f"{name} must be a float32 channels-last (B, C, H, W) GPU tensor")
-    return ctypes.c_void_p(t.data_ptr())
-
-
-class _DeconvPyramid(Function):
-    """cat_i ConvTranspose2d_i(map_i) (kernel == stride k_i, no bias; backbone.py:187-189) as one GEMM per level writing its channel
-    slice of the channels-last result directly (csrc/rows_gemm.hip, pixel-shuffled output): apply(ks, H, W, map_1.., wt_1..) with
-    map_i (B, C_i, H / k_i, W / k_i) channels-last and wt_i (k_i k_i r_i, C_i) = W_i.permute(2, 3, 1, 0) rows.  No concatenation, no
-    library convolution; the backward reads the gradient of the concatenated map in place (dgrad, wgrad GEMMs per level)."""
-
-    @staticmethod
-    def forward(ctx, ks, H, W, *tens):
-        lib = L.load()
-        nl = len(ks)
-        maps, wts = tens[:nl], tens[nl:]
-        B = maps[0].shape[0]
-        rs = [wt.shape[0] // (k * k) for wt, k in zip(wts, ks)]
-        ctot = sum(rs)
-        de = torch.empty((B, ctot, H, W), dtype=_f32, device=maps[0].device, memory_format=torch.channels_last)
-        coff, keep = 0, []
-        for mp, wt, k, r in zip(maps, wts, ks, rs):
-            if not mp.is_contiguous(memory_format=torch.channels_last):
-                mp = mp.contiguous(memory_format=torch.channels_last)
-            _, C, h, w = mp.shape
-            if h * k != H or w * k != W:
-                raise ValueError(f"deconv pyramid: a {h} x {w} map with kernel = stride {k} does not give {H} x {W}")
-            wt = wt.contiguous()
-            L.check(lib.jm_rows_deconv_forward(B * h * w, C, k, r, h, w, _cl_ptr(mp, "map"), C, L.dev(wt, _f32, "wt"), _ptr(de), ctot, coff,
-                                               L.stream_ptr()), "rows_deconv_forward")
-            keep += [mp, wt]
-            coff += r
-        ctx.ks, ctx.rs, ctx.dims = tuple(ks), tuple(rs), (B, ctot, H, W)
-        ctx.save_for_backward(*keep)
-        return de
-
-    @staticmethod
-    def backward(ctx, dde):
-        lib = L.load()
-        B, ctot, H, W = ctx.dims
-        if not dde.is_contiguous(memory_format=torch.channels_last):
-            dde = dde.contiguous(memory_format=torch.channels_last)
-        saved = ctx.saved_tensors
-        nl = len(ctx.ks)
-        dmaps, dwts, coff = [], [], 0
-        for i, (k, r) in enumerate(zip(ctx.ks, ctx.rs)):
-            mp, wt = saved[2 * i], saved[2 * i + 1]
-            _, C, h, w = mp.shape
-            m = B * h * w
-            dm = dw = None
-            if ctx.needs_input_grad[3 + i]:
-                dm = torch.empty_like(mp)                     # channels-last, like the map
-                L.check(lib.jm_rows_deconv_dgrad(m, C, k, r, h, w, _cl_ptr(dde, "dde"), ctot, coff, L.dev(wt, _f32, "wt"), _ptr(dm), C,
-                                                 L.stream_ptr()), "rows_deconv_dgrad")
-            if ctx.needs_input_grad[3 + nl + i]:
-                dw = torch.empty_like(wt)
-                nbytes = int(lib.jm_rows_wgrad_workspace_bytes(m, k * k * r, C))
-                ws = _ws(nbytes, dde.device) if nbytes else None
-                L.check(lib.jm_rows_deconv_wgrad(m, C, k, r, h, w, _cl_ptr(dde, "dde"), ctot, coff, _cl_ptr(mp, "map"), C, _ptr(dw),
-                                                 _ptr(ws), nbytes, L.stream_ptr()), "rows_deconv_wgrad")
-            dmaps.append(dm)
-            dwts.append(dw)
-            coff += r
-        return (None, None, None, *dmaps, *dwts)
-
-
-def deconv_pyramid(maps: Sequence[torch.Tensor], weights: Sequence[torch.Tensor], ks: Sequence[int]) -> torch.Tensor:
-    """maps[i] (B, C_i, h_i, w_i) channels-last, weights[i] = the ConvTranspose2d weight (C_i, r_i, k_i, k_i) -> the channels-last
-    (B, sum r_i, h_i k_i, w_i k_i) concatenation of the transposed convolutions (biases are the caller's: they commute with what follows)"""
-    H, W = maps[0].shape[2] * ks[0], maps[0].shape[3] * ks[0]
-    wts = [wd.permute(2, 3, 1, 0).reshape(k * k * wd.shape[1], wd.shape[0]) for wd, k in zip(weights, ks)]
-    return _DeconvPyramid.apply(tuple(int(k) for k in ks), int(H), int(W), *maps, *wts)
 
 
 # ---------------------------------------------------------------------------------------------------- BatchNorm folding

@@ -89,8 +89,7 @@ def thin_loss(engine, out: Dict[str, torch.Tensor], gt_tids: torch.Tensor, count
     return (out["rpn_cls"].sum() + out["rpn_reg"].sum()) / n + out["rcnn_cls"].sum() + out["rcnn_reg"].sum() + reid
 
 
-import os as _os
-CONV_FIND = bool(int(_os.environ.get("JM_JOINT_CONV_FIND", "0")))    # see joint_step (bench.py switches it on: seconds of search per shape)
+CONV_FIND = False    # see joint_step (bench.py switches it on: seconds of MIOpen search per convolution shape at first use)
 
 _bn_lists = {}       # id(engine) -> (registration epoch, [BatchNorm modules], [parameters])
 
@@ -135,10 +134,9 @@ def joint_step(engine, xyz, image, pts_xy, gt_tids, optimizer, world: Optional[i
     collective), optimizer step.  Returns the local loss (device scalar, detached).
 
     route: "rows" = forward and backward on the hand-written row kernels (train_rows.py; BatchNorm frozen: eval-mode statistics),
-    "graphs" = the rows route with every single-stream piece captured once as a HIP graph and replayed (train_graphs.py: the same
-    kernels and gradients, ~30 graph launches instead of ~1050 kernel launches through ~60 autograd Functions),
     "operators" = the un-fused operator route above (torch autograd over (B, C, npoint, nsample) tensors; any BatchNorm mode),
-    "auto" = rows whenever the BatchNorms are frozen (the faster of the two on this stack: see below).  next_xyz: the next batch's cloud — its FPS pyramid / neighbour search
+    "auto" = rows whenever the BatchNorms are frozen (the faster of the two: DESIGN.md section 6; the HIP-graph form of the rows route
+    measured slower than eager and lives under tools/quarantine/).  next_xyz: the next batch's cloud — its FPS pyramid / neighbour search
     starts on the side stream under this step (rows route).  world / local: see dist.group_world."""
     import torch.distributed as tdist
     from .ops.affinity_train import AffinityTrainState
@@ -149,17 +147,10 @@ def joint_step(engine, xyz, image, pts_xy, gt_tids, optimizer, world: Optional[i
         torch.backends.cudnn.benchmark = True
     optimizer.zero_grad(set_to_none=True)
     if route == "auto":
-        # rows, not graphs: measured on one MI355X (4 frames, tools/joint_stream_probe.py / bench.py) the graphs route takes the
-        # host from 18 ms to 4 ms per step but its replayed sections do not overlap across streams the way the eager launches do —
-        # 25.7 ms per step at 4 hardware queues (39 - 41 ms at 1, 6 or 8) against 23.6 ms for the rows route at 8
         route = "rows" if frozen_bn(engine) and xyz.is_cuda else "operators"
-    if route == "graphs":
-        if not frozen_bn(engine):
-            raise RuntimeError("joint_step(route='graphs') folds the BatchNorms: call train_joint.freeze_bn(engine) (or engine.eval()) first")
-        from . import train_graphs
-        loss = prof.region("joint_forward+backward(span)", lambda: train_graphs.forward_backward(
-            engine, xyz, image, pts_xy, gt_tids, world, local, rois_per_frame, next_xyz)[0])
-    elif route == "rows":
+    if route not in ("rows", "operators"):
+        raise ValueError(f"joint_step: route {route!r} (rows | operators | auto)")
+    if route == "rows":
         if not frozen_bn(engine):
             raise RuntimeError("joint_step(route='rows') folds the BatchNorms: call train_joint.freeze_bn(engine) (or engine.eval()) first")
         loss = prof.region("joint_forward+backward(span)", lambda: _rows_forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local,
@@ -224,8 +215,6 @@ def _rows_forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local, ro
     img = _image_stream(engine, xyz.device)
     if img is not None:
         main.wait_stream(img)
-    from .ops import rows as R
-    R.release_deferred(xyz.device)           # the weight-gradient passes (ops/rows.py: _WgradHook) ran on streams of their own
     return total
 
 

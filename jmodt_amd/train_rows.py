@@ -71,7 +71,7 @@ class BnFold:
 
     def __init__(self, root, pairs=None):
         """root: the module whose BatchNorms are folded — or `pairs`, an explicit [(convolution, BatchNorm)] list (a section of
-        the network: train_graphs.py)"""
+        the network: tools/quarantine/train_graphs.py)"""
         pairs = bn_pairs(root) if pairs is None else list(pairs)
         self._slots = {}
         if not pairs:
@@ -177,7 +177,7 @@ def _sa_level_rows(fold: BnFold, sa, xyz: torch.Tensor, feats: Optional[torch.Te
 def _channel_sums(g: torch.Tensor) -> torch.Tensor:
     """(B, C, H, W) -> (C) sums over batch and pixels.  On channels-last maps = the column sums of the (B H W, C) row matrix on the
     two-pass kernels of csrc/jm_rows.h: torch's reduction of many inputs to few outputs zeroes a semaphore buffer with a memset,
-    which is not reliably ordered inside a replayed HIP graph on this stack (graphed.py)"""
+    which is not reliably ordered inside a replayed HIP graph on this stack (tools/quarantine/graphed.py)"""
     if (g.is_cuda and torch.cuda.is_current_stream_capturing() and g.dtype == torch.float32 and g.shape[1] % 4 == 0
             and g.is_contiguous(memory_format=torch.channels_last)):
         return R.colsum(g.permute(0, 2, 3, 1).reshape(-1, g.shape[1]))
@@ -219,7 +219,7 @@ class _Conv3x3BiasRelu(torch.autograd.Function):
         if wino_dx:
             dx = conv3x3_wino_bias_relu(dpre, pack_wino_weight(w.flip(2, 3).transpose(0, 1)), None, cin, relu=False)
         # d(b) = the channel sums of d(pre), as a plain reduction: the library's own bias gradient comes out as ZEROS when the
-        # call is replayed from a HIP graph (train_graphs.py; tools/_dbg notes in graphed.py) — and costs a launch either way
+        # call is replayed from a HIP graph (tools/quarantine/train_graphs.py; tools/_dbg notes in tools/quarantine/graphed.py) — and costs a launch either way
         gx, dw, _ = torch.ops.aten.convolution_backward(dpre, x, w, [cout], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                        [need_x and not wino_dx, True, False])
         return (dx if wino_dx else gx), dw, _channel_sums(dpre)
@@ -257,11 +257,6 @@ def _image_pyramid(fold: BnFold, net, image: torch.Tensor) -> List[torch.Tensor]
     return maps
 
 
-import os as _os
-DECONV_GEMM = bool(int(_os.environ.get("JM_DECONV_GEMM", "0")))
-FUSION_CONV_ROWS = bool(int(_os.environ.get("JM_FUSION_CONV_ROWS", "1")))    # (0: MIOpen, for the A/B of DESIGN.md section 6)
-
-
 def _image_fusion_map(fold: BnFold, net, maps: List[torch.Tensor]) -> torch.Tensor:
     """relu(bn(conv1x1(cat_i deconv_i(img_i)))) (backbone.py:187-193), BatchNorm folded.  The training path keeps the reference's
     un-composed form: four kernel == stride transposed convolutions, their 64-channel concatenation, one 1x1 convolution —
@@ -273,23 +268,9 @@ def _image_fusion_map(fold: BnFold, net, maps: List[torch.Tensor]) -> torch.Tens
     biases = [dc.bias if dc.bias is not None else m.new_zeros(dc.out_channels) for dc, m in zip(net.DeConv, maps)]
     Wf2 = Wf.reshape(Wf.shape[0], -1)
     b_eff = bf + Wf2 @ torch.cat(biases)
-    ks = [dc.kernel_size[0] for dc in net.DeConv]
-    plain = all(tuple(dc.kernel_size) == tuple(dc.stride) == (k, k) and tuple(dc.padding) == (0, 0) and tuple(dc.output_padding) == (0, 0)
-                and dc.groups == 1 and dc.in_channels % 4 == 0 and dc.out_channels % 4 == 0 for dc, k in zip(net.DeConv, ks))
-    if DECONV_GEMM and plain and maps[0].is_cuda and Wf2.shape[0] % 4 == 0:
-        # kernel == stride transposed convolutions ARE GEMMs with a pixel-shuffled output: one launch per level writes its channel
-        # slice of the channels-last concatenation (csrc/rows_gemm.hip), the 1x1 fusion convolution + ReLU is a rows layer on it.
-        # OPT-IN (JM_DECONV_GEMM=1): exact (tests/test_gpu_rows.py) but measured SLOWER than the library route — 5.7 ms of
-        # rows_gemm_kernel time on the image stream against 3.5 ms of MIOpen for the same 204 GFLOP per 4 frames (tools/joint_timeline.sh;
-        # the 128 x 128 x 32 tiles waste three quarters of their columns on the 32- and 64-wide outputs and the operands are
-        # HBM-bound skinny matrices); the joint step stays at 23.9 ms either way
-        de = R.deconv_pyramid(maps, [dc.weight for dc in net.DeConv], ks)                     # (B, 64, H, W) channels-last
-        B, ctot, H, W = de.shape
-        y = R.rows_mlp(de.permute(0, 2, 3, 1).reshape(B * H * W, ctot), [(Wf2, b_eff)], [1])  # (B H W, q)
-        return y.view(B, H, W, Wf2.shape[0]).permute(0, 3, 1, 2)                              # = channels-last (B, q, H, W)
     de = torch.cat([F.conv_transpose2d(m, dc.weight, None, stride=dc.stride, padding=dc.padding, output_padding=dc.output_padding)
                     for dc, m in zip(net.DeConv, maps)], dim=1)
-    if FUSION_CONV_ROWS and de.is_cuda and de.is_contiguous(memory_format=torch.channels_last) and de.shape[1] % 4 == 0 and Wf2.shape[0] % 4 == 0:
+    if de.is_cuda and de.is_contiguous(memory_format=torch.channels_last) and de.shape[1] % 4 == 0 and Wf2.shape[0] % 4 == 0:
         # the 1 x 1 fusion convolution + bias + ReLU IS a dense layer on the (B H W, C) rows of the channels-last map: one bounds-checked
         # GEMM launch per direction (csrc/rows_gemm.hip) instead of a library convolution, a bias / ReLU pass and a channel sum
         B, ctot, H, W = de.shape
@@ -378,7 +359,7 @@ def backbone_forward_rows(engine, xyz: torch.Tensor, image: torch.Tensor, pts_xy
 # RoI sets are full of exact copies (cyclic roipool padding): centres picked from copies of one point are copies of one another
 # (same coordinates, same neighbour list, hence bit-identical features), so the NEXT level's rows are planned on the first centre of
 # every such class — the training-path form of the inference engine's representative centres (csrc/sa_dedupe.hip)
-CANON_CENTRES = os.environ.get("JM_ROWS_CANON_CENTRES", "1") != "0"
+CANON_CENTRES = True      # (a module constant, not an environment switch: tests/test_gpu_rows.py compares both settings)
 
 
 def _centre_canon(canon: torch.Tensor, pick: torch.Tensor) -> torch.Tensor:
