@@ -1468,6 +1468,9 @@ def main():
                        "parallelism": (f"dp{world} (gradient all-reduce)" if args.workload == "train" else f"replicas x{world}")
                                       + (" [TEST: ranks share one GPU, not a benchmark]" if shared else ""),
                        "rank_binding": rank_binding,
+                       # what one-process-per-GPU set for THIS rank before HIP / MIOpen initialised (asserted by the launcher tests)
+                       "rank_env": {k: os.environ.get(k) for k in ("GPU_MAX_HW_QUEUES", "MIOPEN_USER_DB_PATH", "MIOPEN_CUSTOM_CACHE_DIR",
+                                                                   "HSA_ENABLE_IPC_MODE_LEGACY") if os.environ.get(k) is not None},
                        "process_groups": (None if dist is None else
                                           ("data plane RCCL (gradient all-reduce), control plane gloo (barriers, max over ranks)"
                                            if args.workload == "train" else

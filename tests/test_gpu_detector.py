@@ -556,7 +556,10 @@ def test_bench_self_launch_under_torch_distributed_run(extra):
     line, r = _one_compact_line(p.stdout)
     assert r["n_gpus"] == 1 and r["value"] > 0 and r["steps"] == 2
     assert "dp1" in r["config"]["parallelism"] or "replicas x1" in r["config"]["parallelism"]
+    full_cfg = json.load(open(os.path.join(ROOT, r["full_record"])))["config"]
+    assert full_cfg["rank_env"]["MIOPEN_USER_DB_PATH"].endswith(os.path.join("rank0", "db"))
     if "train" in extra:
+        assert full_cfg["rank_env"]["GPU_MAX_HW_QUEUES"] == "8"      # (RCCL takes hardware queues: 381 instead of ~500 frames/s at the default 4)
         # the one-rank RCCL group takes the collective path: the gradient bucket went through all_reduce and was timed
         ga = r["grad_allreduce"]
         assert ga["issued"] == 1 and ga["ms_per_step"] > 0 and ga["bytes_per_step"] > 0 and ga["world"] == 1
@@ -584,6 +587,12 @@ def test_bench_two_ranks_through_the_drivers_launch_command():
     assert "gloo" in r["config"]["process_groups"] and "no RCCL" in r["config"]["process_groups"]
     full = json.load(open(os.path.join(ROOT, r["full_record"])))
     assert abs(full["value"] - 2 * full["config"]["frames_per_gpu_per_step"] * 3 / (full["ms_per_step"] * 3e-3)) < 0.02 * full["value"]
+    # one process per GPU: rank 0 bound to its own cores (half of the allowed ones here: both "GPUs" sit on one NUMA node or the
+    # platform does not say), its own MIOpen user database / cache
+    rb, envr = full["config"]["rank_binding"], full["config"]["rank_env"]
+    if hasattr(os, "sched_setaffinity"):
+        assert rb["pinned"] and rb["source"] in ("numa", "even-split") and 1 <= rb["n_cores"] <= max(1, len(os.sched_getaffinity(0)) // 2 + 1)
+    assert envr["MIOPEN_USER_DB_PATH"].endswith(os.path.join("rank0", "db")) and envr["MIOPEN_CUSTOM_CACHE_DIR"].endswith(os.path.join("rank0", "cache"))
 
 
 def test_bench_refuses_more_ranks_than_gpus():
