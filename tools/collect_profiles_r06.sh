@@ -30,6 +30,8 @@ if [ "$WHAT" = all ] || [ "$WHAT" = joint ]; then
     for mode in joint rcnn; do
         timeout 600 python "$REPO/bench.py" --workload train --$mode --steps 2 --warmup 2 --no-cpu-baseline --headline-only > /tmp/warm_$mode.log 2>&1
         run ${mode}_kernel_stats "--stats" "" --workload train --$mode --steps 8 --warmup 3 --no-cpu-baseline --headline-only
+        db=$(find /tmp/prof_${mode}_kernel_stats -name '*.db' | head -1)
+        [ -n "$db" ] && python "$REPO/tools/joint_timeline.py" "$db" "$OUT/${ROUND}_${mode}_timeline.csv" | cut -c1-160
         for c in MfmaUtil FETCH_SIZE WRITE_SIZE; do
             run ${mode}_pmc_$c "--pmc $c" "--pmc" --workload train --$mode --steps 2 --warmup 2 --no-cpu-baseline --headline-only
         done
