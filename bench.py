@@ -522,8 +522,12 @@ def train_step(st, world):
     if st.get("rcnn"):
         from jmodt_amd.train_joint import rcnn_step
         pf = st.get("prefetch", True)
+        # the NEXT step's frozen half (RPN forward, proposals, RoI pooling: nothing of it depends on this step's update) is issued
+        # under this step's RCNN forward / backward / Adam; every timed step still executes one frozen half and one trainable half
+        ahead = pf and st.get("ahead", True)
         return rcnn_step(eng, st["xyz"], st["image"], st["pts_xy"], st["tids"], st["opt"], world=world, rois_per_frame=st["rois_per_frame"],
-                         next_xyz=_upcoming(st) if pf else None, next_image=st["image"] if pf else None)
+                         next_xyz=_upcoming(st) if pf else None, next_image=st["image"] if pf else None,
+                         next_batch=(st["xyz"], st["image"], st["pts_xy"]) if ahead else None)
     if st.get("joint"):
         from jmodt_amd.train_joint import joint_step
         return joint_step(eng, st["xyz"], st["image"], st["pts_xy"], st["tids"], st["opt"], world=world,

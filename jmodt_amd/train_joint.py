@@ -239,15 +239,12 @@ def prepare_rcnn(engine) -> None:
         raise NotImplementedError(f"rcnn_step: the RCNN carries BatchNorm layers ({bad[:3]} ...); the rows route folds eval-mode statistics only")
 
 
-def rcnn_forward_backward(engine, xyz, image, pts_xy, gt_tids, world=None, local=False, rois_per_frame: int = 64,
-                          next_xyz=None, next_image=None):
-    """forward + loss + backward of the RPN-fixed step; returns (local loss, outputs).  The frozen half is the fused inference
-    engine as it stands (detector.py: rpn_forward, proposals, pts_feature: no autograd graph, the next batch's FPS pyramid and image
-    pyramid started on their side streams under this batch's RCNN); the trainable half is train_rows.rcnn_forward_rows on the
-    CURRENT stream (forward and backward = csrc/rows_*.hip), the re-id loss on csrc/affinity_train.hip."""
-    import torch.distributed as tdist
-    from .ops.affinity_train import AffinityTrainState, affinity_train_loss
-    from .train_rows import BnFold, rcnn_forward_rows
+_AHEAD_SLOT = 7          # side-stream slot of the frozen half that runs one batch ahead (pyramid.side_stream: 0-6 are the engine's)
+
+
+def _frozen_half(engine, xyz, image, pts_xy, rois_per_frame, next_xyz, next_image):
+    """what the RPN-fixed step computes WITHOUT gradient (point_rcnn.py:28-47 under cfg.RPN.FIXED): the fused engine's RPN forward,
+    the proposal layer, the per-point [mask, depth, features] rows and the RoI pooling of the first `rois_per_frame` proposals"""
     cfg = engine.cfg
     with torch.no_grad():
         rpn_out = engine.rpn_forward(xyz, image, pts_xy, next_xyz, next_image)
@@ -255,9 +252,60 @@ def rcnn_forward_backward(engine, xyz, image, pts_xy, gt_tids, world=None, local
         rois = rois[:, :rois_per_frame].contiguous()
         pf = engine.pts_feature(rpn_out)
         pooled, _, count = roipool3d_canonical_gpu(xyz, pf, rois, cfg.pool_extra_width, cfg.rcnn_num_points, return_count=True)
-        pts_input = pooled.view(-1, cfg.rcnn_num_points, pooled.shape[-1])
+    return dict(rois=rois, pts_input=pooled.view(-1, cfg.rcnn_num_points, pooled.shape[-1]), count=count.view(-1),
+                rpn_cls=rpn_out["rpn_cls"], rpn_reg=rpn_out["rpn_reg"])
+
+
+def _batch_key(xyz, image, pts_xy, rois_per_frame):
+    return tuple((id(t), t.data_ptr(), t._version) for t in (xyz, image, pts_xy)) + (int(rois_per_frame),)
+
+
+def drop_ahead(engine) -> None:
+    """forget a frozen half computed ahead (after the RPN's weights were changed by hand: rcnn_step itself never changes them)"""
+    engine.__dict__.pop("_rcnn_ahead", None)
+
+
+def rcnn_forward_backward(engine, xyz, image, pts_xy, gt_tids, world=None, local=False, rois_per_frame: int = 64,
+                          next_xyz=None, next_image=None, next_batch=None):
+    """forward + loss + backward of the RPN-fixed step; returns (local loss, outputs).  The frozen half is the fused inference
+    engine as it stands (detector.py: rpn_forward, proposals, pts_feature: no autograd graph, the next batch's FPS pyramid and image
+    pyramid started on their side streams under this batch's RCNN); the trainable half is train_rows.rcnn_forward_rows on the
+    CURRENT stream (forward and backward = csrc/rows_*.hip), the re-id loss on csrc/affinity_train.hip.
+
+    next_batch = (xyz, image, pts_xy) of the NEXT step: its whole frozen half is then issued NOW, on a stream of its own, and runs
+    UNDER this batch's RCNN forward / backward / optimizer — the RPN is frozen, so nothing of it depends on the update this step
+    makes (the reference evaluates it under no_grad for the same reason, point_rcnn.py:28-31).  The next call must pass the same
+    tensor objects (unchanged); anything else is computed in line.  With next_batch, next_xyz / next_image announce the batch AFTER
+    it (its FPS pyramid / image pyramid start under the next batch's frozen half)."""
+    import torch.distributed as tdist
+    from .ops.affinity_train import AffinityTrainState, affinity_train_loss
+    from .ops.pointnet2.pyramid import side_stream
+    from .train_rows import BnFold, rcnn_forward_rows
+    dev = xyz.device
+    main = torch.cuda.current_stream(dev)
+    ahead = engine.__dict__.pop("_rcnn_ahead", None)
+    if ahead is not None and ahead["key"] == _batch_key(xyz, image, pts_xy, rois_per_frame):
+        main.wait_event(ahead["event"])
+        fh = ahead["out"]
+        for t in fh.values():                   # allocated on the other stream, consumed (and later freed) under this one
+            t.record_stream(main)
+    else:
+        fh = _frozen_half(engine, xyz, image, pts_xy, rois_per_frame, None if next_batch is not None else next_xyz,
+                          None if next_batch is not None else next_image)
+    if next_batch is not None and engine.overlap:
+        nx, ni, npxy = next_batch
+        side = side_stream(dev, _AHEAD_SLOT)
+        side.wait_stream(main)                  # the batch is resident; what this stream's last round allocated is consumed
+        with torch.cuda.stream(side):
+            out_next = _frozen_half(engine, nx, ni, npxy, rois_per_frame, next_xyz, next_image)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        for t in (nx, ni, npxy):
+            t.record_stream(side)
+        engine._rcnn_ahead = dict(key=_batch_key(nx, ni, npxy, rois_per_frame), event=ev, out=out_next)
+    rois, pts_input, count = fh["rois"], fh["pts_input"], fh["count"]
     fold = BnFold(engine.rcnn_net)                      # (config.py:107 ships none; eval-mode ones would fold here)
-    out = prof.region("rcnn_forward(span)", lambda: rcnn_forward_rows(engine, pts_input, fold, count.view(-1)))
+    out = prof.region("rcnn_forward(span)", lambda: rcnn_forward_rows(engine, pts_input, fold, count))
     B = gt_tids.shape[0]
     feats = out["rcnn_feat"].view(B, -1, out["rcnn_feat"].shape[-1])
     st = AffinityTrainState(feats, gt_tids)
@@ -268,23 +316,23 @@ def rcnn_forward_backward(engine, xyz, image, pts_xy, gt_tids, world=None, local
     reid = affinity_train_loss(st, engine.rcnn_net.link_layer, engine.rcnn_net.se_layer, counts=counts)
     loss = out["rcnn_cls"].sum() + out["rcnn_reg"].sum() + reid
     prof.region("rcnn_backward(span)", lambda: loss.backward())
-    out.update(rois=rois, rpn_cls=rpn_out["rpn_cls"], rpn_reg=rpn_out["rpn_reg"])
+    out.update(rois=rois, rpn_cls=fh["rpn_cls"], rpn_reg=fh["rpn_reg"])
     return loss.detach(), out
 
 
 def rcnn_step(engine, xyz, image, pts_xy, gt_tids, optimizer, world: Optional[int] = None, rois_per_frame: int = 64,
-              bucket_bytes: int = 64 << 20, next_xyz=None, next_image=None, local: bool = False) -> torch.Tensor:
+              bucket_bytes: int = 64 << 20, next_xyz=None, next_image=None, local: bool = False, next_batch=None) -> torch.Tensor:
     """one data-parallel step of the reference's DEFAULT training mode — tools/train.py:86-107 with the shipped config.py:57
     (`RPN.FIXED = True`) and FINETUNE off: the RPN is evaluated without gradient (point_rcnn.py:28-31), the RCNN and the re-id heads
     train (rcnn.py:158-287).  This rank's frames: frozen fused detector forward -> proposals -> RoI pooling -> RCNN forward / loss /
     backward on the row kernels -> ONE bucketed all-reduce of the RCNN's gradients (head sums + re-id loss with global counts: shard
     gradients ADD, dist.py) -> optimizer step.  Returns the local loss (device scalar).  Call prepare_rcnn(engine) once before
-    building the optimizer."""
+    building the optimizer.  next_batch: see rcnn_forward_backward (the next step's frozen half under this step's RCNN)."""
     params = rcnn_parameters(engine)
     if any(p.requires_grad for p in engine.rpn.parameters()) or engine.rpn.training:
         raise RuntimeError("rcnn_step runs the RPN frozen: call train_joint.prepare_rcnn(engine) first (point_rcnn.py:28-31)")
     optimizer.zero_grad(set_to_none=True)
-    loss, _ = rcnn_forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local, rois_per_frame, next_xyz, next_image)
+    loss, _ = rcnn_forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local, rois_per_frame, next_xyz, next_image, next_batch)
     global LAST_GRAD_COLLECTIVES
     LAST_GRAD_COLLECTIVES = prof.region("grad_allreduce(RCCL)", lambda: jdist.allreduce_gradients(params, world=world, bucket_bytes=bucket_bytes,
                                                                                                   average=False, local=local),

@@ -330,3 +330,45 @@ def test_rcnn_step_trains_the_rcnn_under_a_frozen_rpn(tiny):
     assert float((fused["rcnn_cls"] - ref["rcnn_cls"]).abs().max()) > 0          # (the step changed the network)
     for k, v in packed_rpn.items():
         assert eng._folded.get(k) is v, k
+
+
+def test_rcnn_step_with_the_next_batchs_frozen_half_issued_ahead(tiny):
+    """rcnn_step(next_batch=...): the next step's RPN forward / proposals / RoI pooling run on a stream of their own under this
+    step's RCNN — same losses and the same weights after four steps over alternating batches as the plain step (the frozen half does
+    not depend on the update; the library convolutions of the image branch are reproducible to ~1e-6 only, hence 1e-4 and not
+    equality); a batch other than the announced one is computed in line"""
+    from jmodt_amd import train_joint
+    from jmodt_amd.detector import DetectorConfig
+    from tests.test_gpu_detector import make_engine
+    _, xyz, img, xy = tiny
+    xyz2, img2, xy2 = synth.frames(2, 2048, 78, H=96, W=320, native=(94, 310))
+    xy2 = np.random.default_rng(6).uniform(-0.98, 0.98, size=xy2.shape).astype(np.float32)
+    batches = [(xyz, img, xy), (T(xyz2), T(img2), T(xy2))]
+    K = 16
+    tids = torch.randint(0, 6, (2, K), generator=torch.Generator().manual_seed(4)).float().to(DEV)
+    runs = {}
+    for mode in ("plain", "ahead", "wrong"):
+        eng = make_engine(seed=3, cfg=DetectorConfig.tiny()).to(DEV)
+        train_joint.prepare_rcnn(eng)
+        for m in eng.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.eval()
+        # (plain SGD: Adam's g / sqrt(v) turns a 1e-7 difference of a near-zero gradient into a full-size step)
+        opt = torch.optim.SGD(eng.rcnn_net.parameters(), lr=1e-4)
+        losses = []
+        for i in range(4):
+            cur, nxt = batches[i % 2], batches[(i + 1) % 2]
+            if mode == "wrong":                  # announces the batch it is NOT given next
+                nxt = cur
+            losses.append(train_joint.rcnn_step(eng, *cur, tids, opt, rois_per_frame=K, next_batch=None if mode == "plain" else nxt))
+            assert (getattr(eng, "_rcnn_ahead", None) is not None) == (mode != "plain")
+        torch.cuda.synchronize()
+        runs[mode] = ([float(x) for x in losses], {k: v.detach().clone() for k, v in eng.rcnn_net.named_parameters()})
+    base_l, base_w = runs["plain"]
+    assert len(set(round(x, 3) for x in base_l)) > 1                    # (the batches differ and the weights move)
+    for mode in ("ahead", "wrong"):
+        ls, ws = runs[mode]
+        for a, b in zip(ls, base_l):
+            assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (mode, ls, base_l)
+        for k, w in base_w.items():
+            close(ws[k], w, 1e-4)
