@@ -613,7 +613,9 @@ def train_mode_keys(args):
                               "mode trains BatchNorm on batch statistics: JM_JOINT_ROUTE=operators is that form)" if rows else
                               "train mode: batch statistics, running statistics updated (as the reference's joint mode)"), **proxy}
     if getattr(args, "rcnn", False):
-        return {"mode": "rcnn (config.py:57 RPN.FIXED = True, FINETUNE off: the reference's default)", "route": "frozen fused engine + rows",
+        return {"mode": "rcnn (config.py:57 RPN.FIXED = True, FINETUNE off: the reference's default)",
+                "route": "frozen fused engine + rows" + ("" if getattr(args, "no_ahead", False) else
+                                                         "; the NEXT step's frozen half is issued under this step's RCNN (each timed step runs one of each)"),
                 "batchnorm": "RPN: eval mode, folded (point_rcnn.py:29-30); RCNN: none (config.py RCNN.USE_BN = False)", **proxy}
     return {"mode": "finetune (tools/train.py:96-107: link / start-end heads only)", "route": "frozen fused engine + affinity_train kernels",
             "batchnorm": "eval mode, folded", "loss": "the re-id loss of train_functions.py:282-329 (L1 forms)",
@@ -995,6 +997,8 @@ def main():
                          "the image stream is the critical path and this fills the step's tail, +4 %%), after it, or not announced "
                          "(`no_image_prefetch_value` in the line)")
     ap.add_argument("--no-prefetch", action="store_true", help="do not start the next batch's FPS pyramid early")
+    ap.add_argument("--no-ahead", action="store_true",
+                    help="train --rcnn only: do not issue the next step's frozen half (RPN forward, proposals, RoI pooling) under this step's RCNN")
     ap.add_argument("--prefetch-depth", type=int, default=None,
                     help="FPS pyramids of this many upcoming batches in flight, each serial chain on a side stream of its own (one CU per "
                          "frame).  Default 2 for `sa` (configs[1] IS a sampling chain: 1397 / 2754 / 3920 frames/s at 0 / 1 / 2), 1 for the "
@@ -1149,6 +1153,7 @@ def main():
         train_st["engine"].overlap = not args.no_overlap
         train_st["engine"].prefetch_depth = args.prefetch_depth
         train_st["prefetch"] = not args.no_prefetch
+        train_st["ahead"] = not args.no_ahead
         train_st["engine"].prefetch_image = args.image_prefetch != "off"
         train_st["engine"].prefetch_image_late = args.image_prefetch == "late"
         step = lambda: train_step(train_st, world)  # noqa: E731
