@@ -879,7 +879,7 @@ ROCPROF_NEEDLE = {"rcnn_sa1/sa_mlp_pm_forward": ["sa_mlp_pm_kernel"],
                                                                   "softmax_stats_kernel", "dual_softmax_kernel"]}
 
 
-PROFILE_ROUNDS = ("r05", "r04")      # this round's committed summaries, else the previous round's OF THE SAME WORKLOAD
+PROFILE_ROUNDS = ("r06", "r05", "r04")      # this round's committed summaries, else the previous round's OF THE SAME WORKLOAD
 
 
 def rocprof_average(kernel_row, workload="detect", live_us=None, launches=None):

@@ -14,6 +14,10 @@ for c in kitti packed; do
 done
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --workload train --no-cpu-baseline --full-out $OUT/train_launch.json 2>$OUT/train_launch.err | grep "^{" > $OUT/train_launch.line.json
 python bench.py --workload train --joint --launch --no-cpu-baseline --steps 6 --warmup 2 --full-out $OUT/train_joint_launch.json 2>$OUT/train_joint_launch.err | grep "^{" > $OUT/train_joint_launch.line.json
+# the reference's default training mode (RPN fixed): plain, under the launcher (one-rank RCCL group), without the frozen half issued ahead
+python bench.py --workload train --rcnn --no-cpu-baseline --full-out $OUT/train_rcnn.json 2>$OUT/train_rcnn.err | grep "^{" > $OUT/train_rcnn.line.json
+python bench.py --workload train --rcnn --launch --no-cpu-baseline --full-out $OUT/train_rcnn_launch.json 2>$OUT/train_rcnn_launch.err | grep "^{" > $OUT/train_rcnn_launch.line.json
+python bench.py --workload train --rcnn --no-ahead --no-cpu-baseline --headline-only --full-out $OUT/train_rcnn_no_ahead.json 2>$OUT/train_rcnn_no_ahead.err | grep "^{" > $OUT/train_rcnn_no_ahead.line.json
 for f in $OUT/*.line.json; do python - "$f" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
