@@ -270,7 +270,7 @@ def _unit_wb(unit: nn.Module) -> Tuple[torch.Tensor, torch.Tensor]:
     return _fold_conv_bn(unit.conv, bn)
 
 
-from ._registry import tensor_sig
+from ._registry import OPT_GEN as _OPT_GEN
 from ._registry import EPOCH as _REGISTRATION_EPOCH      # bumped whenever ANY nn.Module of the process registers a parameter / buffer
 
 
@@ -360,7 +360,8 @@ class DetectAffinityEngine(nn.Module):
             mine = {id(t) for t in rcnn} | skip
             self._sig_tensors = ([t for t in list(self.parameters()) + list(self.buffers()) if id(t) not in mine], rcnn)
             self._sig_epoch = _REGISTRATION_EPOCH[0]
-        sig = tuple(tuple([tensor_sig(t) for t in grp]) for grp in self._sig_tensors)
+        gen = _OPT_GEN.get                       # (inlined _registry.tensor_sig: ~500 tensors per call, two calls per step)
+        sig = tuple(tuple([(id(t), t.data_ptr(), t._version, gen(id(t), 0)) for t in grp]) for grp in self._sig_tensors)
         old = self._folded_sig
         if sig != old:
             if old is None or sig[0] != old[0]:

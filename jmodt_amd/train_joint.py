@@ -218,11 +218,25 @@ def _rows_forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local, ro
     return total
 
 
+_rcnn_lists = {}      # id(engine) -> (registration epoch, weakref, RCNN parameters, RPN parameters)
+
+
+def _rcnn_split(engine):
+    """(RCNN parameters, RPN parameters), re-collected only after a module / parameter registration anywhere in the process (two
+    module walks per step are ~0.5 ms of host time on a step whose host side is 5.6 ms)"""
+    from ._registry import EPOCH
+    hit = _rcnn_lists.get(id(engine))
+    if hit is None or hit[0] != EPOCH[0] or hit[1]() is not engine:
+        import weakref
+        hit = _rcnn_lists[id(engine)] = (EPOCH[0], weakref.ref(engine), list(engine.rcnn_net.parameters()), list(engine.rpn.parameters()))
+    return hit[2], hit[3]
+
+
 def rcnn_parameters(engine):
     """what tools/train.py:104 ends up updating with the shipped configuration (config.py:57 RPN.FIXED = True, FINETUNE off): the
     optimizer holds model.parameters(), the RPN runs under no_grad (point_rcnn.py:28-31) — only the RCNN's tensors (set abstraction,
     heads, link / start-end heads) ever receive a gradient"""
-    return [p for p in engine.rcnn_net.parameters() if p.requires_grad]
+    return [p for p in _rcnn_split(engine)[0] if p.requires_grad]
 
 
 def prepare_rcnn(engine) -> None:
@@ -329,7 +343,7 @@ def rcnn_step(engine, xyz, image, pts_xy, gt_tids, optimizer, world: Optional[in
     gradients ADD, dist.py) -> optimizer step.  Returns the local loss (device scalar).  Call prepare_rcnn(engine) once before
     building the optimizer.  next_batch: see rcnn_forward_backward (the next step's frozen half under this step's RCNN)."""
     params = rcnn_parameters(engine)
-    if any(p.requires_grad for p in engine.rpn.parameters()) or engine.rpn.training:
+    if engine.rpn.training or any(p.requires_grad for p in _rcnn_split(engine)[1]):
         raise RuntimeError("rcnn_step runs the RPN frozen: call train_joint.prepare_rcnn(engine) first (point_rcnn.py:28-31)")
     optimizer.zero_grad(set_to_none=True)
     loss, _ = rcnn_forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local, rois_per_frame, next_xyz, next_image, next_batch)
