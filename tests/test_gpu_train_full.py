@@ -23,9 +23,15 @@ Two things measured while writing this test (tools/grad_state_probe.py, tools/fo
     memory.  Between the two ROUTES the same happens deterministically: their forwards differ by rounding (1e-7: different kernels,
     different summation orders), and among the 10^7 pre-activations of a batch some lie that close to zero.  Worst tensor over six
     runs of this test on three clouds: 0.7 - 5.4e-4 for the better operator call (the packed cloud's RCNN input layer at the top:
-    every RoI holds hundreds of real points), up to 4.6e-4 for the other.  The comparison runs the operator route twice: the better
-    call must agree to 1e-3, the other to 5e-3; the routes are pinned at 5e-4 where no mask sits on the fence — against the
-    reference's autograd fixture (test_gpu_train_joint.py: 3.6e-6) and at the tiny widths (test_gpu_rows.py).
+    every RoI holds hundreds of real points), and one run in three or four lands above 5e-4 on some tensor.  tools/rcnn_state_probe.py
+    pinned one such case down: 25 rows-route steps on the uniform cloud in every stream mode (asynchronous, synchronised between
+    forward and backward, single stream, synchronised behind every call) — pooled RoI points 2 - 4e-6 apart from step to step
+    (the proposals' decoded boxes move with the features), 24 gradients equal to 1e-7 and ONE (single-stream mode) off by 1.78e-3 on
+    rcnn_net.SA_modules.0.mlps.0.layer1.conv.weight, the same tensor and amount every time it appears: one pre-activation of a row
+    that stands for dozens of copied RoI points sits within 1e-6 of zero.  Not a stream race.  The comparison therefore makes up to
+    three complete attempts (own rows step, own two operator-route calls): every attempt's forward must match the float64 chain
+    and stay within 5e-3, ONE attempt must agree entry-wise to 5e-4; the entry-wise bar holds unconditionally where no mask sits on the
+    fence — against the reference's autograd fixture (test_gpu_train_joint.py: 3.6e-6) and at the tiny widths (test_gpu_rows.py).
 """
 import numpy as np
 import pytest
@@ -50,6 +56,19 @@ def _close(got, want, tol, what):
     assert err <= tol * scale, (what, err, scale)
 
 
+def _relative_l2_error(mine, want):
+    """worst ||a - b||_2 / ||b||_2 over the tensors (those below 1e-4 of the network's largest gradient norm are measured against that floor)"""
+    nmax = max(float(w.double().norm()) for w in want.values() if w is not None)
+    worst = ("", 0.0)
+    for k, w in want.items():
+        if w is None:
+            continue
+        err = float((mine[k].double() - w.double()).norm()) / max(float(w.double().norm()), 1e-4 * nmax)
+        if err > worst[1]:
+            worst = (k, err)
+    return worst
+
+
 @pytest.fixture(scope="module")
 def engine():
     from jmodt_amd.detector import DetectorConfig
@@ -60,27 +79,19 @@ def engine():
     return eng
 
 
-@pytest.mark.parametrize("kind", ["uniform", "kitti", "packed"])
-def test_rows_route_at_the_benchmarked_widths(engine, kind):
+def _attempt(eng, chain, xyz_h, img_h, xy_h, xyz, img, xy, tids, kind):
+    """one complete comparison: the rows route as joint_step runs it (asynchronous, three streams), its forward against the float64
+    chain, then two calls of the operator route on the SAME RoIs; returns the per-call (worst max-norm error, worst relative L2 error)"""
     from jmodt_amd import train_joint
     from jmodt_amd.train_rows import joint_forward_rows, pooled_rois
-    from oracle.pipeline import Chain
     from tests.test_gpu_rows import _grads, _relative_gradient_error
-    eng = engine
-    xyz_h, img_h, xy_h = synth.frames(2, 16384, 4321, kind=kind, H=96, W=320, native=(94, 310))
-    # (synth.frames projects with the intrinsics of the 1280-wide canvas: on the 320-wide image nearly every point would fall outside)
-    xy_h = np.random.default_rng(5).uniform(-0.98, 0.98, size=xy_h.shape).astype(np.float32)
-    xyz, img, xy = T(xyz_h), T(img_h), T(xy_h)
-    tids = torch.randint(0, 6, (2, K), generator=torch.Generator().manual_seed(4)).float().to(DEV)
     eng.zero_grad(set_to_none=True)
-    # ---- the rows route as joint_step runs it (asynchronous, three streams)
     got = joint_forward_rows(eng, xyz, img, xy, rois_per_frame=K)
     train_joint.thin_loss(eng, got, tids).backward()
     torch.cuda.synchronize()
     mine = _grads(eng)
     eng.zero_grad(set_to_none=True)
     # ---- forward against the float64 chain
-    chain = Chain(eng.state_dict(), eng.cfg, torch.float64)
     want = chain.rpn(xyz_h, img_h, xy_h)
     assert float(want["backbone_features"].abs().max()) > 0.5
     _close(got["backbone_features"], want["backbone_features"], 1e-4, "backbone_features")
@@ -96,6 +107,7 @@ def test_rows_route_at_the_benchmarked_widths(engine, kind):
     _close(got["rcnn_feat"], rc["rcnn_feat"].reshape(2 * K, -1), 1e-4, "rcnn_feat")
     _close(got["rcnn_cls"], rc["rcnn_cls"].reshape(2 * K, -1), 1e-4, "rcnn_cls")
     _close(got["rcnn_reg"], rc["rcnn_reg"].reshape(2 * K, -1), 1e-4, "rcnn_reg")
+    del got
     # ---- backward against the operator route on the same RoIs (the RCNN half teacher-forced on the rows route's pooled points:
     # a proposal that flips between two routes 1e-6 apart would compare two different losses), two calls: see the module docstring
     results = []
@@ -108,8 +120,31 @@ def test_rows_route_at_the_benchmarked_widths(engine, kind):
         want_g = _grads(eng)
         eng.zero_grad(set_to_none=True)
         del feats, ref
-        results.append(_relative_gradient_error(mine, want_g))
-    print(kind, "worst relative gradient error per operator-route call", [r[0] for r in results], "largest gradient", results[0][1])
-    worst = min(r[0][1] for r in results)
-    assert worst < 1e-3, results
-    assert max(r[0][1] for r in results) < 5e-3, results          # (the other state: mask flips, not a different network)
+        results.append((_relative_gradient_error(mine, want_g)[0], _relative_l2_error(mine, want_g)))
+    print(kind, "per operator-route call: worst max-norm error", [r[0] for r in results], "worst relative L2 error", [r[1] for r in results])
+    return results
+
+
+@pytest.mark.parametrize("kind", ["uniform", "kitti", "packed"])
+def test_rows_route_at_the_benchmarked_widths(engine, kind):
+    from oracle.pipeline import Chain
+    eng = engine
+    xyz_h, img_h, xy_h = synth.frames(2, 16384, 4321, kind=kind, H=96, W=320, native=(94, 310))
+    # (synth.frames projects with the intrinsics of the 1280-wide canvas: on the 320-wide image nearly every point would fall outside)
+    xy_h = np.random.default_rng(5).uniform(-0.98, 0.98, size=xy_h.shape).astype(np.float32)
+    xyz, img, xy = T(xyz_h), T(img_h), T(xy_h)
+    tids = torch.randint(0, 6, (2, K), generator=torch.Generator().manual_seed(4)).float().to(DEV)
+    chain = Chain(eng.state_dict(), eng.cfg, torch.float64)
+    attempts = []
+    for _ in range(3):
+        # every attempt is a complete, independent comparison (its own rows forward / backward, its own two operator calls); the
+        # forward of every attempt must match the float64 chain; the gradients of ONE attempt must agree entry-wise to 5e-4 — an
+        # attempt that lands on a fence-sitting pre-activation (module docstring) shows up as a single tensor off by a fixed amount
+        # (uniform cloud: always 1.73e-3 on rcnn_net.SA_modules.0.mlps.0.layer1.conv.weight) and is bounded at 5e-3
+        res = _attempt(eng, chain, xyz_h, img_h, xy_h, xyz, img, xy, tids, kind)
+        attempts.append(res)
+        assert max(r[0][1] for r in res) < 5e-3, attempts
+        if min(r[0][1] for r in res) < 5e-4:
+            break
+    else:
+        raise AssertionError(f"no attempt of three agreed to 5e-4: {attempts}")
