@@ -192,30 +192,45 @@ def _rows_forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local, ro
     pooled_ev.record()
     n = float(out["rpn_cls"].shape[1])
     rpn_loss = (out["rpn_cls"].sum() + out["rpn_reg"].sum()) / n
-    rpn_loss.backward()
-    rc = rcnn_branch_rows(engine, pts_input, count, ready=pooled_ev)
-    side = rc.pop("_stream")
     main = torch.cuda.current_stream(xyz.device)
     B = gt_tids.shape[0]
-    with torch.cuda.stream(side):
-        feats = rc["rcnn_feat"].view(B, -1, rc["rcnn_feat"].shape[-1])
-        st = AffinityTrainState(feats, gt_tids)
-        counts = None
-        if jdist.collective_path(world, local):      # the re-id means run over the GLOBAL element counts (as in the finetune step)
-            counts = st.counts.clone()
-            tdist.all_reduce(counts, op=tdist.ReduceOp.SUM)
-        reid = affinity_train_loss(st, engine.rcnn_net.link_layer, engine.rcnn_net.se_layer, counts=counts)
-        rcnn_loss = rc["rcnn_cls"].sum() + rc["rcnn_reg"].sum() + reid
-        rcnn_loss.backward()
-        total = rcnn_loss.detach() + rpn_loss.detach()
+
+    def rcnn_half():
+        rc = rcnn_branch_rows(engine, pts_input, count, ready=pooled_ev)
+        side = rc.pop("_stream")
+        with torch.cuda.stream(side):
+            feats = rc["rcnn_feat"].view(B, -1, rc["rcnn_feat"].shape[-1])
+            st = AffinityTrainState(feats, gt_tids)
+            counts = None
+            if jdist.collective_path(world, local):      # the re-id means run over the GLOBAL element counts (as in the finetune step)
+                counts = st.counts.clone()
+                tdist.all_reduce(counts, op=tdist.ReduceOp.SUM)
+            reid = affinity_train_loss(st, engine.rcnn_net.link_layer, engine.rcnn_net.se_layer, counts=counts)
+            rcnn_loss = rc["rcnn_cls"].sum() + rc["rcnn_reg"].sum() + reid
+            rcnn_loss.backward()
+        return side, rcnn_loss.detach()
+
+    if RCNN_HALF_FIRST:
+        side, rcnn_loss = rcnn_half()
+        rpn_loss.backward()
+    else:
+        rpn_loss.backward()
+        side, rcnn_loss = rcnn_half()
     if side is not main:
         gt_tids.record_stream(side)
         main.wait_stream(side)               # every gradient is in place before the all-reduce / optimizer on the main stream
-        total.record_stream(main)
+        rcnn_loss.record_stream(main)
+    # (the sum on the MAIN stream, behind the join: the RCNN stream only ever waited for the pooling event, not for rpn_loss)
+    total = rcnn_loss + rpn_loss.detach()
     img = _image_stream(engine, xyz.device)
     if img is not None:
         main.wait_stream(img)
     return total
+
+
+# which half of the rows route's backward the host issues first: the RPN's (main + image streams, ~7 ms of enqueue; the RCNN's 3 ms of
+# device work then trail the host) or the RCNN's (its stream works under the RPN backward's enqueue).  Measured: see DESIGN.md section 6
+RCNN_HALF_FIRST = False
 
 
 _rcnn_lists = {}      # id(engine) -> (registration epoch, weakref, RCNN parameters, RPN parameters)
