@@ -472,10 +472,6 @@ def make_joint_state(frames, seed, dev, tiny=False, kind="uniform"):
     if joint_route() == "rows":
         if "JM_JOINT_CONV_FIND" not in os.environ and not tiny:
             train_joint.CONV_FIND = True     # MIOpen's find mode for the image convolutions, forward and backward (+2 %; seconds at first use)
-        if os.environ.get("JM_JOINT_RCNN_FIRST") is not None:         # (A/B of the issue order of the two backward halves; bench only)
-            train_joint.RCNN_HALF_FIRST = os.environ["JM_JOINT_RCNN_FIRST"] == "1"
-        if os.environ.get("JM_JOINT_BWD_THREAD") is not None:
-            train_joint.BACKWARD_THREAD = os.environ["JM_JOINT_BWD_THREAD"] == "1"
         train_joint.prepare_rows(eng)    # train mode (RPN-head dropout active), every BatchNorm FROZEN on its running statistics
     else:
         eng.train()                      # the un-fused operator route: BatchNorm on batch statistics

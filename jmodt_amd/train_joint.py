@@ -210,33 +210,11 @@ def _rows_forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local, ro
             rcnn_loss.backward()
         return side, rcnn_loss.detach()
 
-    if BACKWARD_THREAD and engine.overlap and not prof.enabled:
-        # the RPN half's backward from a helper thread: its ~7 ms of host work happen in the autograd engine's device thread either
-        # way (the calling thread only waits), so the calling thread can issue the RCNN half's forward meanwhile — ctypes calls and
-        # torch operators release the interpreter lock while they launch
-        import threading
-        failure = []
-
-        def run():
-            try:
-                with torch.cuda.device(xyz.device), torch.cuda.stream(main):
-                    rpn_loss.backward()
-            except BaseException as e:          # noqa: BLE001 — re-raised in the calling thread
-                failure.append(e)
-        th = threading.Thread(target=run, name="jm-rpn-backward")
-        th.start()
-        try:
-            side, rcnn_loss = rcnn_half()
-        finally:
-            th.join()
-        if failure:
-            raise failure[0]
-    elif RCNN_HALF_FIRST:
-        side, rcnn_loss = rcnn_half()
-        rpn_loss.backward()
-    else:
-        rpn_loss.backward()
-        side, rcnn_loss = rcnn_half()
+    # (which half the host issues first does not matter — 192.1 / 192.7 frames/s RPN half first, 192.3 / 192.3 RCNN half first;
+    # issuing the RPN half from a helper thread next to the RCNN half's forward: 191.2 / 190.7 against 191.2 / 190.4 — the step is
+    # the host's 17.3 ms of interpreter-bound enqueue plus a 3.3 ms tail either way)
+    rpn_loss.backward()
+    side, rcnn_loss = rcnn_half()
     if side is not main:
         gt_tids.record_stream(side)
         main.wait_stream(side)               # every gradient is in place before the all-reduce / optimizer on the main stream
@@ -247,12 +225,6 @@ def _rows_forward_backward(engine, xyz, image, pts_xy, gt_tids, world, local, ro
     if img is not None:
         main.wait_stream(img)
     return total
-
-
-# which half of the rows route's backward the host issues first: the RPN's (main + image streams, ~7 ms of enqueue; the RCNN's 3 ms of
-# device work then trail the host) or the RCNN's (its stream works under the RPN backward's enqueue).  Measured: see DESIGN.md section 6
-RCNN_HALF_FIRST = False      # (192.1 / 192.7 against 192.3 / 192.3 frames/s: the order does not matter, the step is the host's 17.3 ms + a 3.3 ms tail)
-BACKWARD_THREAD = False      # the RPN half's backward issued from a helper thread while the calling thread issues the RCNN half
 
 
 _rcnn_lists = {}      # id(engine) -> (registration epoch, weakref, RCNN parameters, RPN parameters)
