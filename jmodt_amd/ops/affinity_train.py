@@ -342,7 +342,11 @@ class _AffinityTrainLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (None, None, None, None, g * ctx.dfeat if ctx.dfeat is not None else None) + tuple(g * t for t in ctx.grads)
+        # every stored gradient times the incoming scalar as ONE multi-tensor launch (13 element-wise launches per step otherwise)
+        ts = list(ctx.grads) + ([ctx.dfeat] if ctx.dfeat is not None else [])
+        scaled = torch._foreach_mul(ts, g) if g.dim() == 0 else [g * t for t in ts]
+        dfeat = scaled.pop() if ctx.dfeat is not None else None
+        return (None, None, None, None, dfeat) + tuple(scaled)
 
 
 def affinity_train_loss(st: AffinityTrainState, link_layer: nn.Module, se_layer: nn.Module, counts: Optional[torch.Tensor] = None,

@@ -88,12 +88,17 @@ class BnFold:
         t = beta - mean * s
         sizes = [m.num_features for m in bns]
         soffs = [sum(sizes[:i]) for i in range(len(sizes))]
+        if any(conv.bias is not None for conv, _ in pairs):
+            # folded biases b * s + t of ALL pairs as one vector expression (a cached zero block stands in where a convolution has no
+            # bias): two launches and one split whose outputs are all used — per pair it was a mul + an add forward, two muls
+            # backward, and SplitWithSizesBackward materialised a zero gradient for every scale slice that no bias consumed (~110
+            # launches per joint-mode step, tools/joint_aten_sources.py)
+            bvec = torch.cat([conv.bias if conv.bias is not None else _zeros_const((bn.num_features,), s.device) for conv, bn in pairs])
+            t = bvec * s + t
         ts = torch.split(t, sizes)
-        ss = torch.split(s, sizes)
         wfs = R.fold_all(s, soffs, [conv.weight for conv, _ in pairs])
-        for (conv, bn), wf, sv, tv in zip(pairs, wfs, ss, ts):
-            b = conv.bias
-            self._slots[id(conv)] = (wf, tv if b is None else b * sv + tv)
+        for (conv, bn), wf, tv in zip(pairs, wfs, ts):
+            self._slots[id(conv)] = (wf, tv)
 
     def unit(self, unit: nn.Module) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """folded (W (out, in), b (out)) of a pytorch_utils Conv1d / Conv2d unit (conv [+ bn.bn]), differentiable"""
@@ -111,6 +116,28 @@ class BnFold:
         return self._slots[id(conv)]
 
 
+_zero_blocks = {}      # (shape, device) -> a constant block of zeros (never written, never requires grad)
+
+
+def _zeros_const(shape, device) -> torch.Tensor:
+    key = (tuple(int(v) for v in shape), str(device))
+    z = _zero_blocks.get(key)
+    if z is None:
+        z = _zero_blocks[key] = torch.zeros(key[0], dtype=torch.float32, device=device)
+    return z
+
+
+def _pad_dim(x: torch.Tensor, dim: int, pad: int) -> torch.Tensor:
+    """x with `pad` zeros appended along `dim` — as a concatenation with a cached zero block: ONE launch forward and NONE backward
+    (cat's backward hands out views), where F.pad is fill + copy forward and a clone backward (35 launches per joint-mode step,
+    tools/joint_aten_sources.py)"""
+    if pad == 0:
+        return x
+    shape = list(x.shape)
+    shape[dim] = pad
+    return torch.cat([x, _zeros_const(shape, x.device)], dim=dim)
+
+
 def _pad_rows(W: torch.Tensor, b: Optional[torch.Tensor], mult: int = 4):
     """zero rows appended so that the layer's output width is a multiple of `mult` (the 1-wide objectness and the 46-wide RCNN
     regression layers: the row kernels work on multiples of four channels)"""
@@ -118,7 +145,7 @@ def _pad_rows(W: torch.Tensor, b: Optional[torch.Tensor], mult: int = 4):
     pad = (-n) % mult
     if pad == 0:
         return W, b
-    return F.pad(W, (0, 0, 0, pad)), (F.pad(b, (0, pad)) if b is not None else None)
+    return _pad_dim(W, 0, pad), (_pad_dim(b, 0, pad) if b is not None else None)
 
 
 def _head_rows(fold: BnFold, head: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
@@ -150,7 +177,7 @@ def _attention_rows(fold: BnFold, mod, point: torch.Tensor, img: torch.Tensor) -
     t = R.rows_mlp(img, [_pad_rows(w12, ia.fc1.bias + ia.fc2.bias)], [2], x2=point)            # (M, pad4(rc)); padded columns tanh(0) = 0
     w3 = ia.fc3.weight
     if t.shape[1] != rc:
-        w3 = F.pad(w3, (0, t.shape[1] - rc))
+        w3 = _pad_dim(w3, 1, t.shape[1] - rc)
     z = R.rows_mlp(t, [_pad_rows(w3, ia.fc3.bias)], [0])                                        # (M, 4): column 0 is the logit
     gate = torch.sigmoid(z[:, :1])
     Wi, bi = fold.conv(ia.conv1[0], ia.conv1[1])
@@ -384,11 +411,11 @@ def rcnn_forward_rows(engine, pts_input: torch.Tensor, fold: BnFold, count: Opti
     k = net.rcnn_input_channel
     rows = pts_input.reshape(Rn * S, Cin)
     xyz = pts_input[:, :, 0:3].contiguous()
-    x5 = F.pad(rows[:, :k], (0, (-k) % 4))                                   # (R S, 8): K = 5 padded to a multiple of 4
+    x5 = _pad_dim(rows[:, :k], 1, (-k) % 4)                                     # (R S, 8): K = 5 padded to a multiple of 4
     rpn_feat = rows[:, k:].contiguous()
     up = [fold.unit(u) for u in net.xyz_up_layer]
     W0, b0 = up[0]
-    up[0] = (F.pad(W0, (0, x5.shape[1] - W0.shape[1])), b0)
+    up[0] = (_pad_dim(W0, 1, x5.shape[1] - W0.shape[1]), b0)
     xyz_feat = R.rows_mlp(x5, up, [1] * len(up))
     Wm, bm = fold.unit(net.merge_down_layer[0])
     feats = R.rows_mlp(xyz_feat, [(Wm, bm)], [1], x2=rpn_feat)              # (R S, C): merge_down on [xyz_feature | rpn_feature]
