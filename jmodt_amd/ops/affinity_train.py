@@ -344,7 +344,7 @@ class _AffinityTrainLoss(torch.autograd.Function):
     def backward(ctx, g):
         # every stored gradient times the incoming scalar as ONE multi-tensor launch (13 element-wise launches per step otherwise)
         ts = list(ctx.grads) + ([ctx.dfeat] if ctx.dfeat is not None else [])
-        scaled = torch._foreach_mul(ts, g) if g.dim() == 0 else [g * t for t in ts]
+        scaled = list(torch._foreach_mul(ts, g)) if g.dim() == 0 else [g * t for t in ts]
         dfeat = scaled.pop() if ctx.dfeat is not None else None
         return (None, None, None, None, dfeat) + tuple(scaled)
 
