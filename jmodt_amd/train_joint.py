@@ -313,6 +313,8 @@ def rcnn_forward_backward(engine, xyz, image, pts_xy, gt_tids, world=None, local
         for t in fh.values():                   # allocated on the other stream, consumed (and later freed) under this one
             t.record_stream(main)
     else:
+        if ahead is not None:                   # another batch than the announced one: its frozen half is of no use, but it may still
+            main.wait_event(ahead["event"])     # be running on its stream — the engine's cached scratch buffers serve one call at a time
         fh = _frozen_half(engine, xyz, image, pts_xy, rois_per_frame, None if next_batch is not None else next_xyz,
                           None if next_batch is not None else next_image)
     if next_batch is not None and engine.overlap:
